@@ -1,0 +1,280 @@
+"""CPU oracle for the S2ANet dense-inference hot path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this package, and only as the checker / CPU baseline.  The product path
+(``s2anet_amd``) never imports it.
+
+Two layers:
+  * ``libs2a_oracle.so``  (oracle/s2a_oracle.cpp): C++ restatement of the native ops
+    (rotated IoU both sort branches, NMS / ml-NMS both rules, polyiou, ARF, rotation
+    invariant pooling, deformable conv forward).
+  * numpy float32 restatements of the reference's Python head glue (this file):
+    grid anchors, rotated delta decode, AlignConv.get_offset, multiclass NMS.
+
+Pinning status: see the header of s2a_oracle.cpp and tests/test_oracle_pinned.py.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libs2a_oracle.so")
+
+SORT_CPU = 0   # std::sort branch (reference host build)
+SORT_GPU = 1   # swap-sort branch (reference __CUDACC__ build)
+RULE_GE = 0    # reference CPU NMS: suppress when iou >= thr
+RULE_GT = 1    # reference GPU NMS: suppress when iou >  thr
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "s2a_oracle.cpp")
+    if force or (not os.path.exists(_LIB_PATH)) or (
+            os.path.exists(src) and os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        f64p = ctypes.POINTER(ctypes.c_double)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        i64, ci = ctypes.c_int64, ctypes.c_int
+        L.orc_iou_single.restype = ctypes.c_float
+        L.orc_iou_single.argtypes = [f32p, f32p, ci]
+        L.orc_box_iou_rotated.restype = None
+        L.orc_box_iou_rotated.argtypes = [f32p, i64, f32p, i64, f32p, ci, ci]
+        L.orc_iou_pairs.restype = None
+        L.orc_iou_pairs.argtypes = [f32p, f32p, i64, ci, f32p, ci]
+        L.orc_nms_rotated.restype = i64
+        L.orc_nms_rotated.argtypes = [f32p, f32p, f32p, i64, ctypes.c_float, ci, ci, ci, i64p]
+        L.orc_nms_margin.restype = ctypes.c_double
+        L.orc_nms_margin.argtypes = [f32p, f32p, i64, ctypes.c_float, ci]
+        L.orc_polyiou.restype = ctypes.c_double
+        L.orc_polyiou.argtypes = [f64p, f64p]
+        L.orc_polyiou_pairs.restype = None
+        L.orc_polyiou_pairs.argtypes = [f64p, f64p, i64, f64p]
+        L.orc_arf_forward.restype = None
+        L.orc_arf_forward.argtypes = [f32p, u8p, i64, i64, ci, ci, ci, ci, f32p]
+        L.orc_rot_inv_pool.restype = None
+        L.orc_rot_inv_pool.argtypes = [f32p, i64, i64, i64, ci, f32p]
+        L.orc_deform_conv_forward.restype = None
+        L.orc_deform_conv_forward.argtypes = [f32p, f32p, f32p, i64, i64, i64, i64, i64,
+                                              ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, f32p]
+        L.orc_round_f16.restype = ctypes.c_float
+        L.orc_round_f16.argtypes = [ctypes.c_float]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=ctypes.c_float):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+# --------------------------------------------------------------------------- native ops
+def box_iou_rotated(boxes1, boxes2, sort_mode=SORT_GPU, cull=False):
+    b1, b2 = _f32(boxes1).reshape(-1, 5), _f32(boxes2).reshape(-1, 5)
+    out = np.empty((b1.shape[0], b2.shape[0]), np.float32)
+    if out.size:
+        lib().orc_box_iou_rotated(_p(b1), b1.shape[0], _p(b2), b2.shape[0], _p(out),
+                                  sort_mode, int(cull))
+    return out
+
+
+def iou_pairs(b1, b2, sort_mode=SORT_GPU):
+    b1, b2 = _f32(b1), _f32(b2)
+    assert b1.shape == b2.shape and b1.shape[1] in (5, 6)
+    out = np.empty(b1.shape[0], np.float32)
+    lib().orc_iou_pairs(_p(b1), _p(b2), b1.shape[0], b1.shape[1], _p(out), sort_mode)
+    return out
+
+
+def nms_rotated(dets, scores, iou_thr, labels=None, rule=RULE_GT, sort_mode=SORT_GPU, cull=False):
+    d, s = _f32(dets).reshape(-1, 5), _f32(scores).reshape(-1)
+    n = d.shape[0]
+    keep = np.empty(n, np.int64)
+    lab = None if labels is None else _f32(labels).reshape(-1)
+    k = lib().orc_nms_rotated(_p(d), _p(s), None if lab is None else _p(lab), n,
+                              float(iou_thr), rule, sort_mode, int(cull),
+                              _p(keep, ctypes.c_int64))
+    return keep[:k].copy()
+
+
+def ml_nms_rotated(dets, scores, labels, iou_thr, **kw):
+    return nms_rotated(dets, scores, iou_thr, labels=labels, **kw)
+
+
+def nms_margin(dets, labels, iou_thr, sort_mode=SORT_GPU):
+    d = _f32(dets).reshape(-1, 5)
+    lab = None if labels is None else _f32(labels).reshape(-1)
+    return lib().orc_nms_margin(_p(d), None if lab is None else _p(lab), d.shape[0],
+                                float(iou_thr), sort_mode)
+
+
+def polyiou(p8, q8):
+    p = np.ascontiguousarray(p8, np.float64).reshape(-1, 8)
+    q = np.ascontiguousarray(q8, np.float64).reshape(-1, 8)
+    out = np.empty(p.shape[0], np.float64)
+    lib().orc_polyiou_pairs(_p(p, ctypes.c_double), _p(q, ctypes.c_double), p.shape[0],
+                            _p(out, ctypes.c_double))
+    return out
+
+
+def arf_forward(weight, indices):
+    w = _f32(weight)
+    idx = np.ascontiguousarray(indices, np.uint8)
+    O, I, nOri, kH, kW = w.shape
+    nRot = idx.shape[3]
+    out = np.empty((O * nRot, I * nOri, kH, kW), np.float32)
+    lib().orc_arf_forward(_p(w), _p(idx, ctypes.c_uint8), O, I, nOri, kH, kW, nRot, _p(out))
+    return out
+
+
+def rot_inv_pool(x, n_ori=8):
+    x = _f32(x)
+    B, C, H, W = x.shape
+    out = np.empty((B, C // n_ori, H, W), np.float32)
+    lib().orc_rot_inv_pool(_p(x), B, C, H * W, n_ori, _p(out))
+    return out
+
+
+def deform_conv_forward(x, offset, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1),
+                        groups=1, deformable_groups=1, f16_cols=False, relu=False):
+    x, offset, weight = _f32(x), _f32(offset), _f32(weight)
+    B, C, H, W = x.shape
+    O, _, kH, kW = weight.shape
+    Ho = (H + 2 * padding[0] - (dilation[0] * (kH - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (kW - 1) + 1)) // stride[1] + 1
+    assert offset.shape == (B, deformable_groups * 2 * kH * kW, Ho, Wo), offset.shape
+    out = np.empty((B, O, Ho, Wo), np.float32)
+    lib().orc_deform_conv_forward(_p(x), _p(offset), _p(weight), B, C, H, W, O, kH, kW,
+                                  stride[0], stride[1], padding[0], padding[1],
+                                  dilation[0], dilation[1], groups, deformable_groups,
+                                  int(f16_cols), int(relu), _p(out))
+    return out
+
+
+# --------------------------------------------------------------------------- ORN index table
+# ORConv2d.get_indices (models/orn/modules/ORConv.py:41-75): 1-based, [nOri,kH,kW,nRot] uint8.
+_ROT3 = {0: (1, 2, 3, 4, 5, 6, 7, 8, 9), 45: (2, 3, 6, 1, 5, 9, 4, 7, 8),
+         90: (3, 6, 9, 2, 5, 8, 1, 4, 7), 135: (6, 9, 8, 3, 5, 7, 2, 1, 4),
+         180: (9, 8, 7, 6, 5, 4, 3, 2, 1), 225: (8, 7, 4, 9, 5, 1, 6, 3, 2),
+         270: (7, 4, 1, 8, 5, 2, 9, 6, 3), 315: (4, 1, 2, 7, 5, 3, 8, 9, 6)}
+
+
+def arf_indices(n_ori, n_rot, k=3):
+    tab = _ROT3 if k == 3 else {a: (1,) for a in range(0, 360, 45)}
+    idx = np.zeros((n_ori * k * k, n_rot), np.uint8)
+    d_ori, d_rot = 360 / n_ori, 360 / n_rot
+    for i in range(n_ori):
+        for j in range(k * k):
+            for r in range(n_rot):
+                ang = d_rot * r
+                layer = (i + int(np.floor(ang / d_ori))) % n_ori
+                idx[i * k * k + j, r] = layer * k * k + tab[int(ang)][j]
+    return idx.reshape(n_ori, k, k, n_rot)
+
+
+# --------------------------------------------------------------------------- head glue (numpy f32)
+def grid_anchors(feat_h, feat_w, stride, scale=4.0):
+    """AnchorGeneratorRotated.gen_grid_anchors, 1 square anchor/position, angle 0
+    (models/anchors.py:36-61, :75-126): centre = idx*stride + 0.5*(stride-1), side = scale*stride.
+    Returns [H*W, 5] float32 (x, y, w, h, a), row-major over (y, x)."""
+    xs = np.arange(feat_w, dtype=np.float32) * np.float32(stride) + np.float32(0.5 * (stride - 1))
+    ys = np.arange(feat_h, dtype=np.float32) * np.float32(stride) + np.float32(0.5 * (stride - 1))
+    out = np.zeros((feat_h, feat_w, 5), np.float32)
+    out[..., 0] = xs[None, :]
+    out[..., 1] = ys[:, None]
+    out[..., 2] = np.float32(scale * stride)
+    out[..., 3] = np.float32(scale * stride)
+    return out.reshape(-1, 5)
+
+
+def norm_angle(a):
+    """utils/general.py:925-929: (a + pi/4) mod pi - pi/4 (python/torch floor-mod)."""
+    a = np.asarray(a, np.float32)
+    lo = np.float32(-np.pi / 4)
+    return (np.mod(a - lo, np.float32(np.pi)) + lo).astype(np.float32)
+
+
+def delta2bbox_rotated(rois, deltas, wh_ratio_clip=16 / 1000):
+    """models/boxes.py:82-162 (is_encode_relative=True).  float32 throughout."""
+    r, d = _f32(rois), _f32(deltas)
+    max_ratio = np.float32(np.abs(np.log(wh_ratio_clip)))
+    dx, dy = d[:, 0], d[:, 1]
+    dw = np.clip(d[:, 2], -max_ratio, max_ratio)
+    dh = np.clip(d[:, 3], -max_ratio, max_ratio)
+    ca, sa = np.cos(r[:, 4]), np.sin(r[:, 4])
+    gx = dx * r[:, 2] * ca - dy * r[:, 3] * sa + r[:, 0]
+    gy = dx * r[:, 2] * sa + dy * r[:, 3] * ca + r[:, 1]
+    gw = r[:, 2] * np.exp(dw)
+    gh = r[:, 3] * np.exp(dh)
+    ga = norm_angle(np.float32(np.pi) * d[:, 4] + r[:, 4])
+    return np.stack([gx, gy, gw, gh, ga], -1).astype(np.float32)
+
+
+def align_offsets(anchors, feat_h, feat_w, stride, k=3):
+    """AlignConv.get_offset (models/alignconv.py:30-87) for ONE image.
+    anchors [H*W,5] px/rad -> [2*k*k, H, W]; channel 2t = dy, 2t+1 = dx, tap t = ky*k+kx."""
+    a = _f32(anchors)
+    pad = (k - 1) // 2
+    idx = np.arange(-pad, pad + 1, dtype=np.float32)
+    yy, xx = np.meshgrid(idx, idx, indexing="ij")
+    xx, yy = xx.reshape(-1), yy.reshape(-1)
+    xc = np.arange(feat_w, dtype=np.float32)
+    yc = np.arange(feat_h, dtype=np.float32)
+    ycg, xcg = np.meshgrid(yc, xc, indexing="ij")
+    x_conv = xcg.reshape(-1)[:, None] + xx
+    y_conv = ycg.reshape(-1)[:, None] + yy
+    s = np.float32(stride)
+    x_ctr, y_ctr, w, h = a[:, 0] / s, a[:, 1] / s, a[:, 2] / s, a[:, 3] / s
+    cos, sin = np.cos(a[:, 4]), np.sin(a[:, 4])
+    dw, dh = w / np.float32(k), h / np.float32(k)
+    x, y = dw[:, None] * xx, dh[:, None] * yy
+    xr = cos[:, None] * x - sin[:, None] * y
+    yr = sin[:, None] * x + cos[:, None] * y
+    off_x = xr + x_ctr[:, None] - x_conv
+    off_y = yr + y_ctr[:, None] - y_conv
+    off = np.stack([off_y, off_x], -1).reshape(a.shape[0], -1)
+    return np.ascontiguousarray(off.T.reshape(-1, feat_h, feat_w), np.float32)
+
+
+def multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, max_per_img=2000,
+                           rule=RULE_GT, sort_mode=SORT_GPU):
+    """utils/bbox_nms_rotated.py:5-64.  Returns ([K,6] x,y,w,h,a,score ; labels float32 [K])."""
+    b, s = _f32(bboxes), _f32(scores)
+    mask = s > np.float32(score_thr)
+    rows, cols = np.nonzero(mask)          # row-major, same order as torch boolean indexing
+    cb, cs, cl = b[rows], s[rows, cols], cols.astype(np.float32)
+    if cb.shape[0] == 0:
+        return np.zeros((0, 6), np.float32), np.zeros((0,), np.float32)
+    keep = ml_nms_rotated(cb, cs, cl, iou_thr, rule=rule, sort_mode=sort_mode)
+    cb, cs, cl = cb[keep], cs[keep], cl[keep]
+    if keep.shape[0] > max_per_img:
+        inds = np.argsort(-cs, kind="stable")[:max_per_img]
+        cb, cs, cl = cb[inds], cs[inds], cl[inds]
+    return np.concatenate([cb, cs[:, None]], 1), cl
+
+
+def rboxes_to_polys(rboxes):
+    """corner points of (x,y,w,h,a) boxes in double, order as get_rotated_vertices
+    (box_iou_rotated_utils.h:56-75) — used to feed polyiou the same rectangles."""
+    r = np.asarray(rboxes, np.float64).reshape(-1, 5)
+    c, s = np.cos(r[:, 4]) * 0.5, np.sin(r[:, 4]) * 0.5
+    x, y, w, h = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+    p0x, p0y = x - s * h - c * w, y + c * h - s * w
+    p1x, p1y = x + s * h - c * w, y - c * h - s * w
+    return np.stack([p0x, p0y, p1x, p1y, 2 * x - p0x, 2 * y - p0y, 2 * x - p1x, 2 * y - p1y], 1)

@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+  * native ops  : the reference's CPU sources built unmodified into oracle/_ref
+                  (oracle/build_ref.py) + its geometry header host-compiled with __CUDACC__
+  * head glue   : the reference's Python modules imported in place (sys.path), with stub
+                  modules for the absent third-party cv2 / torchvision and the oracle/_ref
+                  CPU builds standing in for the *_cuda extension modules
+The fixtures hold DATA only (inputs + expected outputs).  The reference never travels to the
+GPU box; these arrays do.
+"""
+import ctypes
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+from oracle import build_ref, ref  # noqa: E402
+import oracle  # noqa: E402
+
+torch.set_num_threads(1)
+SEED = 1234
+
+
+def rand_boxes(rng, n, span=1024.0, lo=4.0, hi=100.0):
+    b = np.empty((n, 5), np.float32)
+    b[:, 0:2] = rng.uniform(0, span, (n, 2))
+    b[:, 2:4] = rng.uniform(lo, hi, (n, 2))
+    b[:, 4] = rng.uniform(-np.pi / 4, 3 * np.pi / 4, n)
+    return b
+
+
+EDGE_BOXES = np.array([
+    [50, 50, 20, 10, 0.0],            # base
+    [50, 50, 20, 10, 0.0],            # identical
+    [50, 50, 10, 5, 0.0],             # contained
+    [70, 50, 20, 10, 0.0],            # shared edge
+    [50, 60, 20, 10, 0.0],            # shared long edge
+    [50, 50, 20, 10, np.pi / 4],      # 45 deg
+    [50, 50, 10, 10, np.pi / 4],      # square in square rotated (0.707 case scale)
+    [50, 50, 20, 10, np.pi / 2],      # 90 deg
+    [50, 50, 20, 10, -np.pi / 4],     # angle range ends
+    [50, 50, 20, 10, 3 * np.pi / 4],
+    [50, 50, 1e-8, 1e-8, 0.3],        # area < 1e-14
+    [50, 50, 0, 10, 0.0],             # zero width
+    [500, 500, 20, 10, 0.2],          # far away
+    [55, 52, 18, 9, 0.1],             # generic overlap
+    [0.5, 0.5, 1, 1, 0],              # the reference's own 1/7 example
+    [1.0, 1.0, 1, 1, 0],
+    [50, 50, 20, 10, 1e-4],           # nearly parallel
+    [60, 50, 20, 10, 1e-7],
+    [50.000004, 50, 20, 10, 0.0],     # sub-ulp shifts
+    [1e4, 1e4, 300, 200, 0.7],        # large coordinates
+    [1e4 + 10, 1e4 - 5, 250, 220, -0.3],
+], np.float32)
+
+
+def gen_iou(rng):
+    b1 = np.concatenate([EDGE_BOXES, rand_boxes(rng, 256 - len(EDGE_BOXES), span=300)])
+    b2 = np.concatenate([EDGE_BOXES[::-1], rand_boxes(rng, 256 - len(EDGE_BOXES), span=300)])
+    iou_cpu = ref.box_iou_rotated()(torch.from_numpy(b1), torch.from_numpy(b2)).numpy()
+    # GPU (swap-sort) branch of the reference header, all pairs
+    L = ref.geom_gpubranch()
+    f32p = ctypes.POINTER(ctypes.c_float)
+    n, m = b1.shape[0], b2.shape[0]
+    a6 = np.zeros((n * m, 6), np.float32)
+    c6 = np.zeros((n * m, 6), np.float32)
+    a6[:, :5] = np.repeat(b1, m, 0)
+    c6[:, :5] = np.tile(b2, (n, 1))
+    iou_gpu = np.empty(n * m, np.float32)
+    L.ref_gpubranch_iou6_pairs(a6.ctypes.data_as(f32p), c6.ctypes.data_as(f32p), n * m,
+                               iou_gpu.ctypes.data_as(f32p))
+    iou_gpu = iou_gpu.reshape(n, m)
+    # polyiou (double) on the overlapping pairs
+    P1, P2 = oracle.rboxes_to_polys(b1), oracle.rboxes_to_polys(b2)
+    ii, jj = np.nonzero(iou_cpu > 0)
+    sel = np.arange(len(ii))[:4000]
+    fpoly = ref.polyiou()
+    poly = np.array([fpoly(P1[ii[k]], P2[jj[k]]) for k in sel], np.float64)
+    np.savez_compressed(os.path.join(OUT, "iou_256.npz"), boxes1=b1, boxes2=b2,
+                        iou_ref_cpu=iou_cpu, iou_ref_gpubranch=iou_gpu,
+                        poly_i=ii[sel].astype(np.int32), poly_j=jj[sel].astype(np.int32),
+                        poly_iou=poly)
+    print("iou_256: nonzero %.3f  cpu!=gpu-branch: %d" % (
+        (iou_cpu > 0).mean(), (iou_cpu.view(np.uint32) != iou_gpu.view(np.uint32)).sum()))
+
+
+def gen_nms(rng):
+    n = 2048
+    d = rand_boxes(rng, n, span=320)
+    s = (rng.permutation(n).astype(np.float32) + 1) / np.float32(n + 1) * np.float32(0.95) + np.float32(0.05)
+    assert len(np.unique(s)) == n
+    lab = rng.integers(0, 15, n).astype(np.float32)
+    td, ts, tl = torch.from_numpy(d), torch.from_numpy(s), torch.from_numpy(lab)
+    out = dict(dets=d, scores=s, labels=lab)
+    for thr in (0.1, 0.5):
+        k_ml = ref.ml_nms_rotated()(td, ts, tl, thr).numpy()
+        k_sc = ref.nms_rotated()(td, ts, thr).numpy()
+        out[f"ml_keep_ge_{thr}"] = k_ml
+        out[f"sc_keep_ge_{thr}"] = k_sc
+        # GPU rule (>) with GPU sort branch: restated (reference CUDA cannot run here)
+        out[f"ml_keep_gt_{thr}"] = oracle.ml_nms_rotated(d, s, lab, thr, rule=oracle.RULE_GT,
+                                                         sort_mode=oracle.SORT_GPU)
+        out[f"sc_keep_gt_{thr}"] = oracle.nms_rotated(d, s, thr, rule=oracle.RULE_GT,
+                                                      sort_mode=oracle.SORT_GPU)
+        out[f"ml_margin_{thr}"] = np.float64(oracle.nms_margin(d, lab, thr))
+        out[f"sc_margin_{thr}"] = np.float64(oracle.nms_margin(d, None, thr))
+        print("nms thr", thr, "ml keep", len(k_ml), "sc keep", len(k_sc),
+              "margins", out[f"ml_margin_{thr}"], out[f"sc_margin_{thr}"])
+    # the reference's 4-box sanity case
+    d4 = np.array([[10, 10, 8, 4, 0.3], [10, 10, 8, 4, 0.3], [10, 10, 8, 4, 0.3], [100, 100, 8, 4, 0]], np.float32)
+    s4 = np.array([0.9, 0.8, 0.7, 0.6], np.float32)
+    l4 = np.array([0, 0, 1, 0], np.float32)
+    out["d4"], out["s4"], out["l4"] = d4, s4, l4
+    out["ml_keep4"] = ref.ml_nms_rotated()(torch.from_numpy(d4), torch.from_numpy(s4), torch.from_numpy(l4), 0.5).numpy()
+    out["sc_keep4"] = ref.nms_rotated()(torch.from_numpy(d4), torch.from_numpy(s4), 0.5).numpy()
+    np.savez_compressed(os.path.join(OUT, "nms_2k.npz"), **out)
+
+
+def gen_arf(rng):
+    orn = ref.orn()
+    out = {}
+    for tag, shp in (("s1", (4, 2, 1, 3, 3)), ("s8", (4, 2, 8, 3, 3))):
+        w = rng.standard_normal(shp).astype(np.float32)
+        idx = oracle.arf_indices(shp[2], 8, 3)
+        out[f"w_{tag}"] = w
+        out[f"idx_{tag}"] = idx
+        out[f"out_{tag}"] = orn.arf_forward(torch.from_numpy(w), torch.from_numpy(idx)).numpy()
+    np.savez_compressed(os.path.join(OUT, "arf_small.npz"), **out)
+
+
+def import_reference_python():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    cv2 = types.ModuleType("cv2")
+    cv2.setNumThreads = lambda *a, **k: None
+    sys.modules.setdefault("cv2", cv2)
+    sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    from oracle.ref import _load_pyext
+    sys.modules["utils.box_iou_rotated.box_iou_rotated_cuda"] = _load_pyext("ref_box_iou_rotated")
+    sys.modules["utils.ml_nms_rotated.ml_nms_rotated_cuda"] = _load_pyext("ref_ml_nms_rotated")
+    sys.modules["utils.nms_rotated.nms_rotated_cuda"] = _load_pyext("ref_nms_rotated")
+    sys.modules["models.orn.orn_cuda"] = _load_pyext("ref_orn")
+    sys.modules["models.dcn.deform_conv_cuda"] = types.ModuleType("deform_conv_cuda")
+    sys.modules["models.dcn.deform_pool_cuda"] = types.ModuleType("deform_pool_cuda")
+
+
+def gen_glue(rng):
+    import_reference_python()
+    from models.anchors import AnchorGeneratorRotated
+    from models.alignconv import AlignConv
+    from models.boxes import rboxes_decode
+    from models.orn import ORConv2d
+    from utils.bbox_nms_rotated import multiclass_nms_rotated
+    g = torch.Generator().manual_seed(SEED)
+    out = {}
+    # grid anchors, two levels
+    for stride, (h, w) in ((8, (12, 20)), (32, (5, 7))):
+        ag = AnchorGeneratorRotated(stride, [4], [1.0], angles=[0])
+        out[f"anchors_s{stride}"] = ag.gen_grid_anchors((h, w), stride).reshape(-1, 5).numpy()
+    # decode with both clips (head.py:48 uses 1e-6; boxes.py:226 default 16/1000)
+    anc = torch.from_numpy(out["anchors_s8"]).clone()
+    anc[:, 4] = (torch.rand(anc.shape[0], generator=g) - 0.25) * np.pi
+    deltas = torch.randn(anc.shape[0], 5, generator=g) * torch.tensor([0.5, 0.5, 1.5, 1.5, 0.3])
+    deltas[0, 2] = 20.0   # exercise both clamps
+    deltas[1, 3] = -20.0
+    out["dec_anchors"], out["dec_deltas"] = anc.numpy(), deltas.numpy()
+    out["dec_clip_fam"] = rboxes_decode(anc, deltas, wh_ratio_clip=1e-6).numpy()
+    out["dec_clip_odm"] = rboxes_decode(anc, deltas).numpy()
+    # AlignConv.get_offset on refined (rotated) anchors, stride 8, 12x20 map
+    ac = AlignConv(8, 8, kernel_size=3)
+    refined = torch.from_numpy(out["dec_clip_fam"]).clone()
+    refined[:, 2:4] = refined[:, 2:4].clamp(max=400.0)
+    out["off_anchors"] = refined.numpy()
+    out["off_s8"] = ac.get_offset(refined, (12, 20), 8).numpy()
+    # ORConv2d index table
+    oc = ORConv2d(16, 2, kernel_size=3, padding=1, arf_config=(1, 8))
+    out["orconv_indices_1_8"] = oc.indices.numpy()
+    oc8 = ORConv2d(16, 2, kernel_size=3, padding=1, arf_config=(8, 8))
+    out["orconv_indices_8_8"] = oc8.indices.numpy()
+    # multiclass_nms_rotated end to end (reference python + reference CPU ml_nms => ">=" rule)
+    nb = 600
+    bb = torch.from_numpy(rand_boxes(rng, nb, span=220))
+    sc = torch.rand(nb, 15, generator=g) ** 6      # sparse-ish scores
+    det, lab = multiclass_nms_rotated(bb, sc, score_thr=0.05, iou_thr=0.5, max_per_img=300)
+    out["mc_bboxes"], out["mc_scores"] = bb.numpy(), sc.numpy()
+    out["mc_det"], out["mc_labels"] = det.numpy(), lab.numpy()
+    det0, lab0 = multiclass_nms_rotated(bb, sc * 0, score_thr=0.05, iou_thr=0.5, max_per_img=300)
+    out["mc_empty_det_shape"] = np.array(det0.shape)
+    out["mc_empty_lab_shape"] = np.array(lab0.shape)
+    np.savez_compressed(os.path.join(OUT, "head_glue.npz"), **out)
+    print("glue:", {k: v.shape for k, v in out.items()})
+
+
+def gen_dcn(rng):
+    """Deformable conv: the reference has NO runnable implementation here (CUDA only).
+    Expected values come from an independent pure-torch formulation (explicit 4-corner
+    gather written from deform_conv_cuda_kernel.cu:83-114,189-242 semantics) — recorded so
+    the oracle restatement and the HIP kernel are checked against the same numbers."""
+    g = torch.Generator().manual_seed(SEED)
+    B, C, H, W, O = 2, 16, 9, 11, 8
+    x = torch.randn(B, C, H, W, generator=g)
+    wgt = torch.randn(O, C, 3, 3, generator=g) * 0.1
+    off = torch.randn(B, 18, H, W, generator=g) * 2.0
+    off[0, :, 0, 0] = 50.0      # far outside -> zeros
+    off[0, :, 1, 1] = -0.999    # just inside the (-1, ...) border rule
+    out = torch_deform_conv(x, off, wgt)
+    np.savez_compressed(os.path.join(OUT, "dcn_small.npz"), x=x.numpy(), weight=wgt.numpy(),
+                        offset=off.numpy(), out_torch=out.numpy())
+
+
+def torch_deform_conv(x, off, wgt, pad=1):
+    B, C, H, W = x.shape
+    O, _, kH, kW = wgt.shape
+    xd, wd = x.double(), wgt.double()
+    ho = torch.arange(H).view(1, H, 1).float()
+    wo = torch.arange(W).view(1, 1, W).float()
+    cols = []
+    for i in range(kH):
+        for j in range(kW):
+            t = i * kW + j
+            him = (ho - pad + i) + off[:, 2 * t]          # float32, as the kernel
+            wim = (wo - pad + j) + off[:, 2 * t + 1]
+            inside = (him > -1) & (wim > -1) & (him < H) & (wim < W)
+            hl, wl = torch.floor(him), torch.floor(wim)
+            lh, lw = him - hl, wim - wl
+            hh, hw = 1 - lh, 1 - lw
+            hl, wl = hl.long(), wl.long()
+            val = torch.zeros(B, C, H, W, dtype=torch.float32)
+            for (hi, wi, wt) in ((hl, wl, hh * hw), (hl, wl + 1, hh * lw), (hl + 1, wl, lh * hw), (hl + 1, wl + 1, lh * lw)):
+                ok = inside & (hi >= 0) & (wi >= 0) & (hi <= H - 1) & (wi <= W - 1)
+                idx = (hi.clamp(0, H - 1) * W + wi.clamp(0, W - 1)).view(B, 1, H * W).expand(B, C, H * W)
+                v = x.view(B, C, H * W).gather(2, idx).view(B, C, H, W)
+                val = val + torch.where(ok.view(B, 1, H, W), wt.view(B, 1, H, W) * v, torch.zeros(()))
+            cols.append(val)
+    col = torch.stack(cols, 2).double()                    # [B,C,9,H,W]
+    return torch.einsum("ock,bckhw->bohw", wd.view(O, C, kH * kW), col).float()
+
+
+if __name__ == "__main__":
+    assert build_ref.have_reference(), "run in the build container (needs /root/reference)"
+    build_ref.build_all()
+    rng = np.random.default_rng(SEED)
+    gen_iou(rng)
+    gen_nms(rng)
+    gen_arf(rng)
+    gen_dcn(rng)
+    gen_glue(rng)
+    print("done ->", OUT)

@@ -1,0 +1,165 @@
+"""CPU: the oracle (oracle/) against the golden vectors generated from the reference
+(tests/golden/make_golden.py) and, when oracle/_ref is present, against the reference's
+own CPU ops live.  Bit-exact for IoU (both sort branches), NMS keep lists and ARF."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import ref
+from conftest import golden, rand_rboxes, distinct_scores
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_iou_matches_reference_cpu_bitexact():
+    g = golden("iou_256.npz")
+    o = oracle.box_iou_rotated(g["boxes1"], g["boxes2"], sort_mode=oracle.SORT_CPU)
+    assert np.array_equal(bits(o), bits(g["iou_ref_cpu"]))
+
+
+def test_iou_matches_reference_gpubranch_bitexact():
+    g = golden("iou_256.npz")
+    o = oracle.box_iou_rotated(g["boxes1"], g["boxes2"], sort_mode=oracle.SORT_GPU)
+    assert np.array_equal(bits(o), bits(g["iou_ref_gpubranch"]))
+
+
+def test_iou_cull_shortcut_is_exact():
+    g = golden("iou_256.npz")
+    for mode in (oracle.SORT_CPU, oracle.SORT_GPU):
+        a = oracle.box_iou_rotated(g["boxes1"], g["boxes2"], sort_mode=mode, cull=False)
+        b = oracle.box_iou_rotated(g["boxes1"], g["boxes2"], sort_mode=mode, cull=True)
+        assert np.array_equal(bits(a), bits(b))
+
+
+def test_known_answers():
+    # the reference's own commented example: unit squares offset by 0.5 -> 1/7 (polyiou.cpp:130-137)
+    sq1 = np.array([[0.5, 0.5, 1, 1, 0]], np.float32)
+    sq2 = np.array([[1.0, 1.0, 1, 1, 0]], np.float32)
+    assert abs(oracle.box_iou_rotated(sq1, sq2)[0, 0] - 1 / 7) < 1e-6
+    assert abs(oracle.polyiou([0, 0, 1, 0, 1, 1, 0, 1], [0.5, 0.5, 1.5, 0.5, 1.5, 1.5, 0.5, 1.5])[0] - 1 / 7) < 1e-12
+    # square vs itself rotated 45 deg -> 0.7071
+    a = np.array([[0, 0, 2, 2, 0]], np.float32)
+    b = np.array([[0, 0, 2, 2, np.pi / 4]], np.float32)
+    assert abs(oracle.box_iou_rotated(a, b)[0, 0] - 0.707107) < 1e-5
+    # degenerate
+    z = np.array([[0, 0, 1e-8, 1e-8, 0]], np.float32)
+    assert oracle.box_iou_rotated(a, z)[0, 0] == 0.0
+    assert oracle.box_iou_rotated(np.zeros((0, 5), np.float32), a).shape == (0, 1)
+
+
+def test_polyiou_matches_reference_and_rotated_iou():
+    g = golden("iou_256.npz")
+    P1, P2 = oracle.rboxes_to_polys(g["boxes1"]), oracle.rboxes_to_polys(g["boxes2"])
+    p = oracle.polyiou(P1[g["poly_i"]], P2[g["poly_j"]])
+    assert np.array_equal(p, g["poly_iou"])          # f64 bit-exact vs reference polyiou
+    r = g["iou_ref_cpu"][g["poly_i"], g["poly_j"]]
+    big = np.maximum(g["boxes1"][g["poly_i"], 2:4].max(1), g["boxes2"][g["poly_j"], 2:4].max(1)) < 150
+    assert np.abs(p[big] - r[big]).max() < 1e-4      # the two algorithms agree
+
+
+@pytest.mark.parametrize("thr", [0.1, 0.5])
+def test_nms_keep_matches_reference(thr):
+    g = golden("nms_2k.npz")
+    d, s, lab = g["dets"], g["scores"], g["labels"]
+    k = oracle.ml_nms_rotated(d, s, lab, thr, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU)
+    assert np.array_equal(k, g[f"ml_keep_ge_{thr}"])
+    k = oracle.nms_rotated(d, s, thr, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU)
+    assert np.array_equal(k, g[f"sc_keep_ge_{thr}"])
+    # GPU rule + GPU sort branch (restated): recorded keep lists are reproducible, and the
+    # exact-cull fast path of the oracle gives the same list
+    for cull in (False, True):
+        k = oracle.ml_nms_rotated(d, s, lab, thr, rule=oracle.RULE_GT, sort_mode=oracle.SORT_GPU, cull=cull)
+        assert np.array_equal(k, g[f"ml_keep_gt_{thr}"])
+        k = oracle.nms_rotated(d, s, thr, rule=oracle.RULE_GT, sort_mode=oracle.SORT_GPU, cull=cull)
+        assert np.array_equal(k, g[f"sc_keep_gt_{thr}"])
+
+
+def test_nms_four_box_case():
+    g = golden("nms_2k.npz")
+    assert list(g["ml_keep4"]) == [0, 2, 3] and list(g["sc_keep4"]) == [0, 3]
+    assert list(oracle.ml_nms_rotated(g["d4"], g["s4"], g["l4"], 0.5)) == [0, 2, 3]
+    assert list(oracle.nms_rotated(g["d4"], g["s4"], 0.5)) == [0, 3]
+    # rule difference: identical boxes have iou == 1.0; thr=1.0 separates > from >=
+    assert list(oracle.nms_rotated(g["d4"], g["s4"], 1.0, rule=oracle.RULE_GT)) == [0, 1, 2, 3]
+    assert list(oracle.nms_rotated(g["d4"], g["s4"], 1.0, rule=oracle.RULE_GE)) == [0, 3]
+    assert oracle.nms_rotated(np.zeros((0, 5), np.float32), np.zeros(0, np.float32), 0.5).shape == (0,)
+
+
+def test_arf_matches_reference_small_and_definition_large():
+    g = golden("arf_small.npz")
+    for tag in ("s1", "s8"):
+        assert np.array_equal(oracle.arf_forward(g[f"w_{tag}"], g[f"idx_{tag}"]), g[f"out_{tag}"])
+    # production shape: every output element written exactly once (idx[:,k] is a permutation)
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((32, 256, 1, 3, 3)).astype(np.float32)
+    idx = oracle.arf_indices(1, 8, 3)
+    out = oracle.arf_forward(w, idx)
+    assert out.shape == (256, 256, 3, 3)
+    assert np.array_equal(np.sort(out.reshape(32, 8, 256, 9), -1),
+                          np.sort(np.broadcast_to(w.reshape(32, 1, 256, 9), (32, 8, 256, 9)), -1))
+    assert np.array_equal(out.reshape(32, 8, 256, 9)[:, 0], w.reshape(32, 256, 9))  # rotation 0 = identity
+
+
+def test_head_glue_matches_reference_python():
+    g = golden("head_glue.npz")
+    assert np.array_equal(oracle.grid_anchors(12, 20, 8), g["anchors_s8"])
+    assert np.array_equal(oracle.grid_anchors(5, 7, 32), g["anchors_s32"])
+    assert list(g["anchors_s8"][0]) == [3.5, 3.5, 32, 32, 0]
+    for key, clip in (("dec_clip_fam", 1e-6), ("dec_clip_odm", 16 / 1000)):
+        o = oracle.delta2bbox_rotated(g["dec_anchors"], g["dec_deltas"], clip)
+        assert np.allclose(o, g[key], rtol=1e-5, atol=1e-4), key
+    off = oracle.align_offsets(g["off_anchors"], 12, 20, 8)
+    assert off.shape == (18, 12, 20)
+    assert np.allclose(off, g["off_s8"], rtol=1e-5, atol=1e-4)
+    assert np.array_equal(oracle.arf_indices(1, 8), g["orconv_indices_1_8"])
+    assert np.array_equal(oracle.arf_indices(8, 8), g["orconv_indices_8_8"])
+    det, lab = oracle.multiclass_nms_rotated(g["mc_bboxes"], g["mc_scores"], 0.05, 0.5, 300,
+                                             rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU)
+    assert np.array_equal(det, g["mc_det"]) and np.array_equal(lab, g["mc_labels"])
+    assert tuple(g["mc_empty_det_shape"]) == (0, 6)
+
+
+def test_deform_conv_restatement():
+    g = golden("dcn_small.npz")
+    o = oracle.deform_conv_forward(g["x"], g["offset"], g["weight"])
+    assert np.allclose(o, g["out_torch"], rtol=1e-5, atol=1e-5)
+    # zero offsets == plain convolution (identity named in SURVEY 8c)
+    import torch
+    import torch.nn.functional as F
+    x, w = torch.from_numpy(g["x"]), torch.from_numpy(g["weight"])
+    z = oracle.deform_conv_forward(g["x"], np.zeros_like(g["offset"]), g["weight"])
+    assert np.allclose(z, F.conv2d(x, w, padding=1).numpy(), rtol=1e-5, atol=1e-5)
+    # groups / deformable groups / stride / dilation plumbing against grouped conv2d
+    rng = np.random.default_rng(3)
+    x2 = rng.standard_normal((1, 8, 10, 9)).astype(np.float32)
+    w2 = rng.standard_normal((6, 4, 3, 3)).astype(np.float32)
+    off0 = np.zeros((1, 2 * 2 * 9, 4, 4), np.float32)
+    z2 = oracle.deform_conv_forward(x2, off0, w2, stride=(2, 2), padding=(1, 1), dilation=(2, 2),
+                                    groups=2, deformable_groups=2)
+    assert np.allclose(z2, F.conv2d(torch.from_numpy(x2), torch.from_numpy(w2), stride=2, padding=1,
+                                    dilation=2, groups=2).numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_round_f16_helper():
+    import torch
+    v = np.random.default_rng(0).standard_normal(2000).astype(np.float32) * 100
+    v = np.concatenate([v, np.float32([0, 1e-8, 6e-5, 65504, 65519, 70000, -3e-6])])
+    exp = torch.from_numpy(v).half().float().numpy()
+    got = np.array([oracle.lib().orc_round_f16(float(t)) for t in v], np.float32)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.skipif(ref.box_iou_rotated() is None, reason="oracle/_ref not built")
+def test_live_reference_ops_agree_on_fresh_inputs(rng):
+    import torch
+    torch.set_num_threads(1)
+    b1, b2 = rand_rboxes(rng, 150, span=200), rand_rboxes(rng, 170, span=200)
+    r = ref.box_iou_rotated()(torch.from_numpy(b1), torch.from_numpy(b2)).numpy()
+    assert np.array_equal(bits(r), bits(oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_CPU)))
+    n = 800
+    d, s = rand_rboxes(rng, n, span=250), distinct_scores(rng, n)
+    lab = rng.integers(0, 15, n).astype(np.float32)
+    rk = ref.ml_nms_rotated()(torch.from_numpy(d), torch.from_numpy(s), torch.from_numpy(lab), 0.3).numpy()
+    assert np.array_equal(rk, oracle.ml_nms_rotated(d, s, lab, 0.3, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU))
