@@ -1,0 +1,190 @@
+/* ============================================================================
+ * s2anet_hip.h — C ABI of libs2anet_hip.so: the S2ANet dense-inference hot path
+ * as hand-written HIP kernels for MI355X (gfx950, wave64).
+ *
+ * This is the drop-in boundary: every entry point replaces one
+ * function of the reference's six pybind11 extension modules and takes plain
+ * device pointers and sizes — no torch types.  All pointers are DEVICE pointers
+ * unless a parameter is named host_*; every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*) unless documented otherwise.  Tensors are
+ * dense row-major ("contiguous") like the reference requires
+ * (models/utils.py:51-56, deform_conv_cuda.cpp:168-170).
+ *
+ * Return value: 0 on success, negative S2A_E* on error; s2a_last_error() gives
+ * the message (thread-local).  The reference raises c10::Error -> RuntimeError
+ * for the same conditions (deform_conv_cuda.cpp:62-150, nms_rotated_cuda.cu:80-82);
+ * the Python host side maps S2A_E* back to RuntimeError.
+ *
+ * Workspaces: ops that need scratch take (workspace, workspace_bytes); query the
+ * size with the matching *_workspace_bytes().  Nothing in this library calls
+ * hipMalloc/hipFree/hipDeviceSynchronize on the hot path, so every launch
+ * sequence is hipGraph-capturable; the only host synchronisations are the
+ * explicitly documented `host_count` read-backs of the reference-shaped NMS calls.
+ * ==========================================================================*/
+#ifndef S2ANET_HIP_H_
+#define S2ANET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2A_OK 0
+#define S2A_EINVAL (-1)      /* bad shape / argument (reference: TORCH_CHECK / AT_ERROR) */
+#define S2A_EWORKSPACE (-2)  /* workspace too small */
+#define S2A_EHIP (-3)        /* HIP runtime error (launch failure, ...) */
+#define S2A_ENOTIMPL (-4)
+
+#define S2A_DTYPE_F32 0
+#define S2A_DTYPE_F16 1
+
+#define S2A_LAYOUT_NCHW 0 /* reference layout (contiguous NCHW) */
+#define S2A_LAYOUT_NHWC 1 /* channels-last storage of the same logical tensor */
+
+typedef void* s2a_stream_t; /* hipStream_t */
+
+const char* s2a_last_error(void);
+const char* s2a_version(void);
+
+/* ---------------------------------------------------------------------------
+ * Rotated-box IoU.  Replaces  utils.box_iou_rotated.box_iou_rotated_cuda.box_iou_rotated
+ * (utils/box_iou_rotated/src/box_iou_rotated.h:22-42, kernel box_iou_rotated_cuda.cu:14-101).
+ * boxes1[N,5], boxes2[M,5] f32 (x_ctr,y_ctr,w,h,angle_rad) -> ious[N,M] f32.
+ * Arithmetic follows the reference's __CUDACC__ branch of box_iou_rotated_utils.h
+ * operation-for-operation (no FMA contraction).  N==0 or M==0 is a no-op.
+ * ------------------------------------------------------------------------- */
+size_t s2a_box_iou_rotated_workspace_bytes(int64_t n, int64_t m);
+int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* boxes2, int64_t m,
+                        float* ious, void* workspace, size_t workspace_bytes,
+                        s2a_stream_t stream);
+
+/* element-wise variant (pairs i<->i), used by tests and by the merge path */
+int s2a_box_iou_rotated_pairs(const float* boxes1, const float* boxes2, int64_t n, float* ious,
+                              s2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Rotated NMS.  Replaces
+ *   utils.nms_rotated.nms_rotated_cuda.nms_rotated(dets[N,5], scores[N], thr) -> int64[K]
+ *     (utils/nms_rotated/src/nms_rotated.h:21-41, nms_rotated_cuda.cu:14-133)
+ *   utils.ml_nms_rotated.ml_nms_rotated_cuda.ml_nms_rotated(dets, scores, labels, thr)
+ *     (utils/ml_nms_rotated/src/nms_rotated.h:23-44, nms_rotated_cuda.cu:14-137)
+ * Semantics of the reference GPU op: sort by score descending, suppress j by a kept,
+ * higher-scored i when iou(i,j) > thr (strict), IoU == 0 across different labels;
+ * keep[] = indices into the ORIGINAL order, in descending-score order.
+ * Ties in score are broken by ascending original index (the reference leaves them to
+ * torch's unstable sort).
+ *
+ * Everything — sort, suppression mask, greedy scan, compaction — runs on the device;
+ * the reference's device->host copy of the mask (cuda.cu:109) does not exist here.
+ * labels may be NULL (single class).  keep must hold n int64.  *count_dev (device
+ * int64) receives K; if host_count != NULL the call synchronises the stream once and
+ * stores K there (the reference call shape needs K on the host to size its result).
+ * ------------------------------------------------------------------------- */
+size_t s2a_nms_rotated_workspace_bytes(int64_t n, int64_t max_segment_rows);
+int s2a_ml_nms_rotated(const float* dets, const float* scores, const float* labels, int64_t n,
+                       float iou_threshold, int64_t* keep, int64_t* count_dev,
+                       int64_t* host_count, void* workspace, size_t workspace_bytes,
+                       s2a_stream_t stream);
+int s2a_nms_rotated(const float* dets, const float* scores, int64_t n, float iou_threshold,
+                    int64_t* keep, int64_t* count_dev, int64_t* host_count, void* workspace,
+                    size_t workspace_bytes, s2a_stream_t stream);
+
+/* Batched form used by the detector (one call for a whole batch of images):
+ * segment_ids[n] int32 in [0, num_segments) — NMS runs independently inside each
+ * segment (segment = image*num_classes + label); a NEGATIVE segment id marks a padding row
+ * that is ignored (never compared, never kept; lets callers use static-size buffers); group_ids[n] int32 in [0,num_groups)
+ * (group = image) decides the output grouping: keep_flags[n] uint8 (1 = survives) and,
+ * if keep != NULL, per-group lists keep[g*max_per_group + r] (int32 original index, score
+ * descending, -1 padded) with group_counts[g] = min(K_g, max_per_group).
+ * No host synchronisation. */
+int s2a_nms_rotated_segmented(const float* dets, const float* scores, const int32_t* segment_ids,
+                              const int32_t* group_ids, int64_t n, int32_t num_segments,
+                              int32_t num_groups, float iou_threshold, uint8_t* keep_flags,
+                              int32_t* keep, int32_t* group_counts, int32_t max_per_group,
+                              void* workspace, size_t workspace_bytes, s2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * ORN.  Replaces  models.orn.orn_cuda.arf_forward(weight[O,I,nOri,kH,kW], indices u8
+ * [nOri,kH,kW,nRot]) -> [O*nRot, I*nOri, kH, kW]
+ * (models/orn/src/vision.cpp:7-12, cuda/ActiveRotatingFilter_cuda.cu:20-46,79-119).
+ * dtype F32 or F16 (element size only matters: the op is a permuting copy).
+ * ------------------------------------------------------------------------- */
+int s2a_arf_forward(const void* weight, const uint8_t* indices, int64_t n_out, int64_t n_in,
+                    int n_orientation, int kh, int kw, int n_rotation, int dtype, void* output,
+                    s2a_stream_t stream);
+
+/* RotationInvariantPooling.forward (models/orn/functions/rotation_invariant_pooling.py:19-27):
+ * x[B,C,H,W] -> out[B,C/nOri,H,W] = max over each group of nOri consecutive channels. */
+int s2a_rot_inv_pool(const void* x, int64_t batch, int64_t channels, int64_t hw, int n_orientation,
+                     int dtype, int layout, void* out, s2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Deformable convolution v1 forward.  Replaces
+ *   models.dcn.deform_conv_cuda.deform_conv_forward_cuda(input, weight, offset, output,
+ *       columns, ones, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+ *       deformable_group, im2col_step) -> int
+ * (models/dcn/src/deform_conv_cuda.cpp:152-260; sampling kernel
+ *  deform_conv_cuda_kernel.cu:83-114,189-242).  The reference's `columns` / `ones`
+ * scratch tensors and im2col_step have no counterpart: sampling and the channel
+ * contraction are fused (no columns buffer).  Argument order keeps the reference's
+ * W-before-H convention.
+ *   input  [B,C,H,W]                 dtype, `layout` storage
+ *   weight [O, C/group, kH, kW]      dtype, contiguous
+ *   offset [B, dg*2*kH*kW, Ho, Wo]   F32 (or dtype when offset_dtype says so), NCHW;
+ *                                    channel 2t = dy, 2t+1 = dx of tap t (kernel.cu:221-222)
+ *   output [B,O,Ho,Wo]               dtype, `layout` storage, caller-allocated
+ * relu != 0 fuses AlignConv's ReLU (models/alignconv.py:97).
+ * ------------------------------------------------------------------------- */
+typedef struct s2a_dcn_params {
+  int64_t batch, channels, height, width, out_channels;
+  int kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group;
+  int dtype;        /* S2A_DTYPE_* of input/weight/output */
+  int offset_dtype; /* S2A_DTYPE_* of the offset tensor */
+  int layout;       /* S2A_LAYOUT_* of input and output */
+  int relu;
+} s2a_dcn_params;
+
+size_t s2a_deform_conv_workspace_bytes(const s2a_dcn_params* p);
+int s2a_deform_conv_forward(const void* input, const void* weight, const void* offset,
+                            void* output, const s2a_dcn_params* p, void* workspace,
+                            size_t workspace_bytes, s2a_stream_t stream);
+
+/* AlignConv.get_offset (models/alignconv.py:30-87), batched: anchors[B,H*W,5] f32 (pixels,
+ * radians) -> offset[B,2*k*k,H,W] f32 (k = 3). */
+int s2a_align_offsets(const float* anchors, int64_t batch, int64_t height, int64_t width,
+                      float stride, int ksize, float* offset, s2a_stream_t stream);
+
+/* AlignConv.forward (models/alignconv.py:88-98) fully fused: refined anchors ->
+ * sampling offsets (never materialised) -> bilinear sampling -> 3x3 contraction (MFMA)
+ * -> ReLU.  x[B,C,H,W], anchors[B,H,W,5] f32, weight[O,C,3,3], out[B,O,H,W]. */
+typedef struct s2a_align_params {
+  int64_t batch, channels, height, width, out_channels;
+  float stride;
+  int dtype, layout, relu;
+} s2a_align_params;
+size_t s2a_align_conv_workspace_bytes(const s2a_align_params* p);
+int s2a_align_conv_forward(const void* x, const float* anchors, const void* weight, void* out,
+                           const s2a_align_params* p, void* workspace, size_t workspace_bytes,
+                           s2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Head glue, batched and device-side.
+ * s2a_delta2bbox_rotated: models/boxes.py:82-162 (is_encode_relative=True) + norm_angle
+ *   (utils/general.py:925-929).  rois[n,5], deltas[n,5] f32 -> out[n,5].
+ * s2a_fam_refine_anchors: gen_grid_anchors (models/anchors.py:75-126, 1 square anchor of
+ *   side scale*stride per position) + fam_bbox_decode (models/head.py:27-52,
+ *   wh_ratio_clip = 1e-6) straight from the NCHW/NHWC prediction map:
+ *   bbox_pred[B,5,H,W] (dtype/layout) -> refined[B,H,W,5] f32.
+ * ------------------------------------------------------------------------- */
+int s2a_delta2bbox_rotated(const float* rois, const float* deltas, int64_t n, float wh_ratio_clip,
+                           float* out, s2a_stream_t stream);
+int s2a_fam_refine_anchors(const void* bbox_pred, int64_t batch, int64_t height, int64_t width,
+                           float stride, float anchor_scale, int dtype, int layout, float* refined,
+                           s2a_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2ANET_HIP_H_ */

@@ -1,0 +1,57 @@
+// Shared host-side helpers for libs2anet_hip.so (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/s2anet_hip.h"
+
+namespace s2a {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(s2a_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// carve a sub-buffer out of a workspace (256-B aligned); returns nullptr when exhausted
+struct Carver {
+  char* base;
+  size_t size, off;
+  Carver(void* p, size_t n) : base(static_cast<char*>(p)), size(n), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = align_up(count * sizeof(T));
+    if (base == nullptr || off + bytes > size) {
+      off += bytes;  // keep counting so callers can report the need
+      return nullptr;
+    }
+    T* r = reinterpret_cast<T*>(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+}  // namespace s2a
+
+#define S2A_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      s2a::set_error(__VA_ARGS__);        \
+      return S2A_EINVAL;                  \
+    }                                     \
+  } while (0)
+
+#define S2A_HIP(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      s2a::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                    \
+      return S2A_EHIP;                                                             \
+    }                                                                              \
+  } while (0)
+
+#define S2A_LAUNCH_CHECK() S2A_HIP(hipGetLastError())

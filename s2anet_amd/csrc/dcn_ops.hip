@@ -1,0 +1,578 @@
+// Deformable convolution v1 forward / AlignConv for MI355X (gfx950).
+//
+// Replaces:
+//   deform_conv_forward_cuda        models/dcn/src/deform_conv_cuda.cpp:152-260
+//   deformable_im2col_gpu_kernel    models/dcn/src/deform_conv_cuda_kernel.cu:189-242
+//   deformable_im2col_bilinear      models/dcn/src/deform_conv_cuda_kernel.cu:83-114
+//   AlignConv.get_offset / forward  models/alignconv.py:30-98
+//
+// The reference materialises a [C*9, B*H*W] `columns` matrix in HBM (1.2 GB at P3, B=8),
+// zero-fills it, writes it with an uncoalesced NCHW gather and re-reads it in a cuBLAS GEMM.
+// Here the op is ONE kernel per call and `columns` never exists:
+//   * activations are read channels-last (NHWC): a bilinear corner is a contiguous run of
+//     channels, so every gather instruction moves full 128-byte lines
+//   * a workgroup owns 64 output positions x all (<=256) output channels; per (tap, channel
+//     chunk) stage it gathers + blends the column tile straight into LDS and streams the
+//     matching pre-packed weight tile into LDS
+//   * the contraction runs on the matrix cores: v_mfma_f32_32x32x2_f32 (exact f32 FMA chain,
+//     1e-4 parity with the f32 reference) or v_mfma_f32_32x32x16_f16 (f16 in, f32 accumulate)
+//   * LDS tiles are double-buffered (one barrier per stage): next stage's global loads are
+//     in flight under the current stage's MFMAs
+//   * sampling coordinates come either from the reference's [B,18,H,W] offset tensor or —
+//     AlignConv fused — directly from the refined anchors (the 18-channel tensor is never
+//     written), with ReLU fused into the epilogue
+// Sampling semantics (border rule h_im > -1 && < H, corner dropping, weight order) follow
+// deform_conv_cuda_kernel.cu:97-112,:228 exactly.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace s2a {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int kPos = 64;        // output positions per workgroup
+constexpr int kMaxO = 256;      // output channels per workgroup
+constexpr int kRowBytes = 144;  // LDS row: 128 B of K data + 16 B pad (conflict-free b128 reads)
+
+// ------------------------------------------------------------------ layout helpers
+template <typename T>
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const T* __restrict__ src, int64_t B, int C,
+                                                      int64_t HW, T* __restrict__ dst) {
+  // 32x32 tile transpose through LDS: reads coalesced along HW, writes coalesced along C
+  __shared__ T tile[32][33];
+  const int64_t b = blockIdx.z;
+  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    int c = c0 + r;
+    int64_t p = p0 + tx;
+    if (c < C && p < HW) tile[r][tx] = src[(b * C + c) * HW + p];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int64_t p = p0 + r;
+    int c = c0 + tx;
+    if (c < C && p < HW) dst[(b * HW + p) * C + c] = tile[tx][r];
+  }
+}
+
+// weight [O][C][9] -> packed [9][C/KC][O][KC]  (KC = channels per stage)
+template <typename T>
+__global__ void k_pack_weight(const T* __restrict__ w, int O, int C, int KC, T* __restrict__ wp) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)O * C * 9;
+  if (e >= total) return;
+  int k = (int)(e % KC);
+  int64_t r = e / KC;
+  int o = (int)(r % O);
+  r /= O;
+  int cc = (int)(r % (C / KC));
+  int t = (int)(r / (C / KC));
+  wp[e] = w[((int64_t)o * C + cc * KC + k) * 9 + t];
+}
+
+// ------------------------------------------------------------------ sampling table
+struct Tap {
+  int idx[4];   // global pixel index (b*H*W + h*W + w) of the 4 corners, 0 when dropped
+  float w[4];   // bilinear weights hh*hw, hh*lw, lh*hw, lh*lw; 0 when dropped / outside
+};
+
+__device__ __forceinline__ Tap make_tap(float h_im, float w_im, int H, int W, int64_t img_pix0) {
+  Tap t;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    t.idx[k] = (int)img_pix0;
+    t.w[k] = 0.f;
+  }
+  if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {  // kernel.cu:228
+    int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+    int h_high = h_low + 1, w_high = w_low + 1;
+    float lh = h_im - h_low, lw = w_im - w_low;
+    float hh = 1 - lh, hw = 1 - lw;
+    if (h_low >= 0 && w_low >= 0) {
+      t.idx[0] = (int)(img_pix0 + (int64_t)h_low * W + w_low);
+      t.w[0] = hh * hw;
+    }
+    if (h_low >= 0 && w_high <= W - 1) {
+      t.idx[1] = (int)(img_pix0 + (int64_t)h_low * W + w_high);
+      t.w[1] = hh * lw;
+    }
+    if (h_high <= H - 1 && w_low >= 0) {
+      t.idx[2] = (int)(img_pix0 + (int64_t)h_high * W + w_low);
+      t.w[2] = lh * hw;
+    }
+    if (h_high <= H - 1 && w_high <= W - 1) {
+      t.idx[3] = (int)(img_pix0 + (int64_t)h_high * W + w_high);
+      t.w[3] = lh * lw;
+    }
+  }
+  return t;
+}
+
+// sampling point of tap (ky,kx) at output (y,x), 3x3 / stride 1 / pad 1 / dilation 1
+struct AnchorCtx {
+  float x_ctr, y_ctr, dw, dh, cs, sn;
+};
+__device__ __forceinline__ AnchorCtx anchor_ctx(const float* a, float stride) {
+  // models/alignconv.py:58-62
+  AnchorCtx c;
+  c.x_ctr = a[0] / stride;
+  c.y_ctr = a[1] / stride;
+  float w = a[2] / stride, h = a[3] / stride;
+  c.cs = cosf(a[4]);
+  c.sn = sinf(a[4]);
+  c.dw = w / 3.0f;
+  c.dh = h / 3.0f;
+  return c;
+}
+__device__ __forceinline__ void anchor_offset(const AnchorCtx& c, int ky, int kx, float yc, float xc,
+                                              float& off_y, float& off_x) {
+  // models/alignconv.py:63-70 (same operation order as s2a_align_offsets)
+  float xx = (float)(kx - 1), yy = (float)(ky - 1);
+  float x = c.dw * xx, y = c.dh * yy;
+  float xr = c.cs * x - c.sn * y;
+  float yr = c.sn * x + c.cs * y;
+  off_x = (xr + c.x_ctr) - (xc + xx);
+  off_y = (yr + c.y_ctr) - (yc + yy);
+}
+
+// ------------------------------------------------------------------ fused MFMA kernel
+template <typename T>
+struct Traits;
+template <>
+struct Traits<float> {
+  static constexpr int KC = 32;      // channels per stage (128 B per corner)
+  static constexpr int VEC = 4;      // elements per 16-B vector
+};
+template <>
+struct Traits<_Float16> {
+  static constexpr int KC = 64;
+  static constexpr int VEC = 8;
+};
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+  using type = f32x4;
+};
+template <>
+struct Vec16<_Float16> {
+  using type = f16x8;
+};
+
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type blend(const typename Vec16<T>::type (&v)[4],
+                                                         const float (&w)[4]);
+template <>
+__device__ __forceinline__ f32x4 blend<float>(const f32x4 (&v)[4], const float (&w)[4]) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; e++) r[e] = w[0] * v[0][e] + w[1] * v[1][e] + w[2] * v[2][e] + w[3] * v[3][e];
+  return r;
+}
+template <>
+__device__ __forceinline__ f16x8 blend<_Float16>(const f16x8 (&v)[4], const float (&w)[4]) {
+  f16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; e++)
+    r[e] = (_Float16)(w[0] * (float)v[0][e] + w[1] * (float)v[1][e] + w[2] * (float)v[2][e] +
+                      w[3] * (float)v[3][e]);
+  return r;
+}
+
+// SRC: 0 = offset tensor [B,18,H,W] f32, 1 = refined anchors [B,H,W,5] f32
+template <typename T, bool OUT_NHWC, int SRC>
+__global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,       // NHWC
+                                                     const float* __restrict__ src,  // offsets | anchors
+                                                     const T* __restrict__ wp,       // packed weights
+                                                     T* __restrict__ out, int64_t Ntot, int C, int H,
+                                                     int W, int O, float stride, int relu) {
+  constexpr int KC = Traits<T>::KC;
+  constexpr int VEC = Traits<T>::VEC;
+  using V = typename Vec16<T>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [ taps 64*9*32 B | A0 | B0 | A1 | B1 ]
+  Tap* s_tab = reinterpret_cast<Tap*>(smem);
+  constexpr int kTabBytes = kPos * 9 * 32;
+  constexpr int kABytes = kMaxO * kRowBytes, kBBytes = kPos * kRowBytes;
+  char* s_buf = smem + kTabBytes;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t HW = (int64_t)H * W;
+  const int64_t g0 = (int64_t)blockIdx.x * kPos;
+  const int o0 = blockIdx.y * kMaxO;
+  const int Oloc = min(kMaxO, O - o0);
+  const int CC = C / KC;
+  const int nstage = 9 * CC;
+
+  // ---- sampling table for this tile
+  for (int e = tid; e < kPos * 9; e += 256) {
+    int pl = e / 9, t = e % 9;
+    int64_t g = g0 + pl;
+    Tap tp;
+    if (g < Ntot) {
+      int64_t b = g / HW, p = g % HW;
+      int y = (int)(p / W), xq = (int)(p % W);
+      int ky = t / 3, kx = t % 3;
+      float off_y, off_x;
+      if (SRC == 0) {
+        const float* ob = src + (b * 18) * HW + p;
+        off_y = ob[(int64_t)(2 * t) * HW];
+        off_x = ob[(int64_t)(2 * t + 1) * HW];
+      } else {
+        AnchorCtx c = anchor_ctx(src + g * 5, stride);
+        anchor_offset(c, ky, kx, (float)y, (float)xq, off_y, off_x);
+      }
+      float h_im = (float)(y - 1 + ky) + off_y;  // kernel.cu:226-227
+      float w_im = (float)(xq - 1 + kx) + off_x;
+      tp = make_tap(h_im, w_im, H, W, b * HW);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        tp.idx[k] = 0;
+        tp.w[k] = 0.f;
+      }
+    }
+    s_tab[e] = tp;
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  // per-thread staging registers
+  V cv[2][4];
+  float cw[2][4];
+  V av[8];
+
+  auto issue = [&](int s) {
+    const int t = s / CC, cc = s % CC;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      int item = tid + 256 * it;
+      int pl = item >> 3, q = item & 7;
+      const Tap tp = s_tab[pl * 9 + t];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        cw[it][k] = tp.w[k];
+        cv[it][k] = *reinterpret_cast<const V*>(x + (int64_t)tp.idx[k] * C + cc * KC + q * VEC);
+      }
+    }
+    const T* wsrc = wp + ((int64_t)s * O + o0) * KC;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      int idx = tid + 256 * r;
+      int row = idx >> 3, q = idx & 7;
+      if (row < Oloc) av[r] = *reinterpret_cast<const V*>(wsrc + (int64_t)row * KC + q * VEC);
+    }
+  };
+  auto commit = [&](int buf) {
+    char* A = s_buf + buf * (kABytes + kBBytes);
+    char* Bm = A + kABytes;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      int item = tid + 256 * it;
+      int pl = item >> 3, q = item & 7;
+      *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend<T>(cv[it], cw[it]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      int idx = tid + 256 * r;
+      int row = idx >> 3, q = idx & 7;
+      if (row < Oloc) *reinterpret_cast<V*>(A + row * kRowBytes + q * 16) = av[r];
+    }
+  };
+
+  issue(0);
+  commit(0);
+  __syncthreads();
+
+  const bool wave_active = wave * 64 < Oloc;
+  for (int s = 0; s < nstage; s++) {
+    const int buf = s & 1;
+    if (s + 1 < nstage) issue(s + 1);
+    if (wave_active) {
+      const char* A = s_buf + buf * (kABytes + kBBytes);
+      const char* Bm = A + kABytes;
+      const char* wrow = A + (wave * 64 + (lane & 31)) * kRowBytes + (lane >> 5) * 16;
+      const char* prow = Bm + (lane & 31) * kRowBytes + (lane >> 5) * 16;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        V wf[2], pf[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          wf[h] = *reinterpret_cast<const V*>(wrow + h * 32 * kRowBytes + kk * 32);
+          pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
+        }
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+              for (int b = 0; b < 2; b++) {
+                if constexpr (OUT_NHWC)
+                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[a][j], wf[b][j], acc[a][b], 0, 0, 0);
+                else
+                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[a][j], pf[b][j], acc[a][b], 0, 0, 0);
+              }
+        } else {
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              if constexpr (OUT_NHWC)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[a], wf[b], acc[a][b], 0, 0, 0);
+              else
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+            }
+        }
+      }
+    }
+    if (s + 1 < nstage) commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (!wave_active) return;
+  // ---- epilogue: ReLU + store.  acc[a][b][r]: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float v = acc[a][b][r];
+        if (relu) v = fmaxf(v, 0.f);
+        int rowi = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if constexpr (OUT_NHWC) {
+          int64_t g = g0 + 32 * a + rowi;
+          int och = o0 + wave * 64 + 32 * b + (lane & 31);
+          if (g < Ntot) out[g * O + och] = (T)v;
+        } else {
+          int och = o0 + wave * 64 + 32 * a + rowi;
+          int64_t g = g0 + 32 * b + (lane & 31);
+          if (g < Ntot) {
+            int64_t bi = g / HW, p = g % HW;
+            out[(bi * O + och) * HW + p] = (T)v;
+          }
+        }
+      }
+}
+
+constexpr int kMfmaLds = kPos * 9 * 32 + 2 * (kMaxO + kPos) * kRowBytes;  // 110592 B
+
+// ------------------------------------------------------------------ generic fallback
+// Any stride / padding / dilation / groups / deformable groups / channel count, NCHW only.
+// One thread per output element; used when the shape is not the AlignConv fast-path shape.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void k_dcn_generic(const T* __restrict__ x, const TO* __restrict__ offset,
+                                                     const T* __restrict__ w, T* __restrict__ out,
+                                                     s2a_dcn_params p, int Ho, int Wo) {
+  const int64_t total = p.batch * p.out_channels * Ho * Wo;
+  const int Cg = (int)(p.channels / p.group), Og = (int)(p.out_channels / p.group);
+  const int cpdg = (int)(p.channels / p.deformable_group);
+  const int H = (int)p.height, W = (int)p.width;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int wo = (int)(e % Wo);
+    int64_t r = e / Wo;
+    int ho = (int)(r % Ho);
+    r /= Ho;
+    int o = (int)(r % p.out_channels);
+    int64_t b = r / p.out_channels;
+    int g = o / Og;
+    float acc = 0.f;
+    for (int cl = 0; cl < Cg; cl++) {
+      int c = g * Cg + cl;
+      int dg = c / cpdg;
+      const T* plane = x + (b * p.channels + c) * (int64_t)H * W;
+      const TO* offp = offset + (b * p.deformable_group + dg) * 2 * p.kH * p.kW * (int64_t)Ho * Wo;
+      for (int i = 0; i < p.kH; i++)
+        for (int j = 0; j < p.kW; j++) {
+          int t = i * p.kW + j;
+          float oh = (float)offp[((int64_t)(2 * t) * Ho + ho) * Wo + wo];
+          float ow = (float)offp[((int64_t)(2 * t + 1) * Ho + ho) * Wo + wo];
+          float h_im = (float)(ho * p.dH - p.padH + i * p.dilationH) + oh;
+          float w_im = (float)(wo * p.dW - p.padW + j * p.dilationW) + ow;
+          float v = 0.f;
+          if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+            int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            int h_high = h_low + 1, w_high = w_low + 1;
+            float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+            float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+            if (h_low >= 0 && w_low >= 0) v1 = (float)plane[h_low * W + w_low];
+            if (h_low >= 0 && w_high <= W - 1) v2 = (float)plane[h_low * W + w_high];
+            if (h_high <= H - 1 && w_low >= 0) v3 = (float)plane[h_high * W + w_low];
+            if (h_high <= H - 1 && w_high <= W - 1) v4 = (float)plane[h_high * W + w_high];
+            v = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+          }
+          if (sizeof(T) == 2) v = (float)(T)v;  // f16 columns, as the f16 fast path
+          acc += (float)w[(((int64_t)o * Cg + cl) * p.kH + i) * p.kW + j] * v;
+        }
+    }
+    if (p.relu) acc = fmaxf(acc, 0.f);
+    out[e] = (T)acc;
+  }
+}
+
+inline bool fast_path_ok(const s2a_dcn_params& p) {
+  int kc = p.dtype == S2A_DTYPE_F32 ? 32 : 64;
+  return p.kW == 3 && p.kH == 3 && p.dW == 1 && p.dH == 1 && p.padW == 1 && p.padH == 1 &&
+         p.dilationW == 1 && p.dilationH == 1 && p.group == 1 && p.deformable_group == 1 &&
+         p.channels % kc == 0 && p.out_channels % 64 == 0 && p.offset_dtype == S2A_DTYPE_F32 &&
+         p.batch * p.height * p.width < (1ll << 31);
+}
+
+inline size_t esize(int dtype) { return dtype == S2A_DTYPE_F32 ? 4 : 2; }
+
+template <typename T>
+int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* wp, T* out,
+                bool out_nhwc, int64_t B, int C, int H, int W, int O, float stride, int relu,
+                hipStream_t st) {
+  const int64_t Ntot = B * (int64_t)H * W;
+  dim3 grid((unsigned)((Ntot + kPos - 1) / kPos), (unsigned)((O + kMaxO - 1) / kMaxO));
+#define S2A_DCN_LAUNCH(NHWC, SRC)                                                                 \
+  do {                                                                                            \
+    auto kern = k_dcn_mfma<T, NHWC, SRC>;                                                         \
+    S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));           \
+    kern<<<grid, 256, kMfmaLds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu);      \
+  } while (0)
+  if (out_nhwc) {
+    if (from_anchors) S2A_DCN_LAUNCH(true, 1); else S2A_DCN_LAUNCH(true, 0);
+  } else {
+    if (from_anchors) S2A_DCN_LAUNCH(false, 1); else S2A_DCN_LAUNCH(false, 0);
+  }
+#undef S2A_DCN_LAUNCH
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+template <typename T>
+int run_fast(const void* input, const float* src, bool from_anchors, const void* weight, void* output,
+             int64_t B, int C, int H, int W, int O, int layout, float stride, int relu, void* ws,
+             size_t ws_bytes, hipStream_t st) {
+  constexpr int KC = Traits<T>::KC;
+  Carver cv(ws, ws_bytes);
+  T* wp = cv.take<T>((size_t)O * C * 9);
+  T* xn = nullptr;
+  if (layout == S2A_LAYOUT_NCHW) xn = cv.take<T>((size_t)B * C * H * W);
+  if (!wp || (layout == S2A_LAYOUT_NCHW && !xn)) {
+    set_error("deform_conv: workspace too small (%zu < %zu)", ws_bytes, cv.off);
+    return S2A_EWORKSPACE;
+  }
+  const int64_t wtot = (int64_t)O * C * 9;
+  k_pack_weight<T><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const T*)weight, O, C, KC, wp);
+  const T* x_nhwc = (const T*)input;
+  if (layout == S2A_LAYOUT_NCHW) {
+    int64_t HW = (int64_t)H * W;
+    dim3 g((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    k_nchw_to_nhwc<T><<<g, 256, 0, st>>>((const T*)input, B, C, HW, xn);
+    x_nhwc = xn;
+  }
+  return launch_fast<T>(x_nhwc, src, from_anchors, wp, (T*)output, layout == S2A_LAYOUT_NHWC, B, C, H,
+                        W, O, stride, relu, st);
+}
+
+}  // namespace
+}  // namespace s2a
+
+using namespace s2a;
+
+extern "C" size_t s2a_deform_conv_workspace_bytes(const s2a_dcn_params* p) {
+  if (!p) return 0;
+  size_t es = esize(p->dtype);
+  size_t b = align_up((size_t)p->out_channels * p->channels * p->kH * p->kW * es) + 256;
+  if (p->layout == S2A_LAYOUT_NCHW) b += align_up((size_t)p->batch * p->channels * p->height * p->width * es);
+  return b;
+}
+
+extern "C" int s2a_deform_conv_forward(const void* input, const void* weight, const void* offset,
+                                       void* output, const s2a_dcn_params* pp, void* workspace,
+                                       size_t workspace_bytes, s2a_stream_t stream) {
+  S2A_CHECK_ARG(pp != nullptr, "deform_conv: NULL params");
+  const s2a_dcn_params p = *pp;
+  // shape_check (deform_conv_cuda.cpp:62-150)
+  S2A_CHECK_ARG(p.kW > 0 && p.kH > 0, "kernel size should be greater than zero, but got kH: %d kW: %d", p.kH, p.kW);
+  S2A_CHECK_ARG(p.dW > 0 && p.dH > 0, "stride should be greater than zero, but got dH: %d dW: %d", p.dH, p.dW);
+  S2A_CHECK_ARG(p.dilationW > 0 && p.dilationH > 0, "dilation should be greater than 0, but got dilationH: %d dilationW: %d", p.dilationH, p.dilationW);
+  S2A_CHECK_ARG(p.group > 0 && p.deformable_group > 0, "deform_conv: group counts must be positive");
+  S2A_CHECK_ARG(p.channels % p.group == 0 && p.out_channels % p.group == 0, "deform_conv: channels must divide groups");
+  S2A_CHECK_ARG(p.channels % p.deformable_group == 0, "input channels must divide deformable group size");
+  S2A_CHECK_ARG(p.dtype == S2A_DTYPE_F32 || p.dtype == S2A_DTYPE_F16, "deform_conv: dtype");
+  S2A_CHECK_ARG(p.offset_dtype == S2A_DTYPE_F32 || p.offset_dtype == p.dtype, "deform_conv: offset dtype");
+  const int64_t Ho = (p.height + 2 * p.padH - (p.dilationH * (p.kH - 1) + 1)) / p.dH + 1;
+  const int64_t Wo = (p.width + 2 * p.padW - (p.dilationW * (p.kW - 1) + 1)) / p.dW + 1;
+  S2A_CHECK_ARG(Ho >= 1 && Wo >= 1, "Given input size: (%lld x %lld x %lld). Calculated output size: (%lld x %lld x %lld). Output size is too small",
+                (long long)p.channels, (long long)p.height, (long long)p.width, (long long)p.out_channels, (long long)Ho, (long long)Wo);
+  S2A_CHECK_ARG(p.height >= p.kH && p.width >= p.kW, "input image is smaller than kernel");
+  if (p.batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(input && weight && offset && output, "deform_conv: NULL tensor");
+  hipStream_t st = as_stream(stream);
+  if (fast_path_ok(p)) {
+    if (p.dtype == S2A_DTYPE_F32)
+      return run_fast<float>(input, (const float*)offset, false, weight, output, p.batch, (int)p.channels,
+                             (int)p.height, (int)p.width, (int)p.out_channels, p.layout, 1.f, p.relu,
+                             workspace, workspace_bytes, st);
+    return run_fast<_Float16>(input, (const float*)offset, false, weight, output, p.batch, (int)p.channels,
+                              (int)p.height, (int)p.width, (int)p.out_channels, p.layout, 1.f, p.relu,
+                              workspace, workspace_bytes, st);
+  }
+  S2A_CHECK_ARG(p.layout == S2A_LAYOUT_NCHW, "deform_conv: the generic path supports NCHW only");
+  const int64_t total = p.batch * p.out_channels * Ho * Wo;
+  unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 65535);
+  if (p.dtype == S2A_DTYPE_F32)
+    k_dcn_generic<float, float><<<g, 256, 0, st>>>((const float*)input, (const float*)offset, (const float*)weight, (float*)output, p, (int)Ho, (int)Wo);
+  else if (p.offset_dtype == S2A_DTYPE_F32)
+    k_dcn_generic<_Float16, float><<<g, 256, 0, st>>>((const _Float16*)input, (const float*)offset, (const _Float16*)weight, (_Float16*)output, p, (int)Ho, (int)Wo);
+  else
+    k_dcn_generic<_Float16, _Float16><<<g, 256, 0, st>>>((const _Float16*)input, (const _Float16*)offset, (const _Float16*)weight, (_Float16*)output, p, (int)Ho, (int)Wo);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+extern "C" size_t s2a_align_conv_workspace_bytes(const s2a_align_params* p) {
+  if (!p) return 0;
+  size_t es = esize(p->dtype);
+  size_t b = align_up((size_t)p->out_channels * p->channels * 9 * es) + 256;
+  if (p->layout == S2A_LAYOUT_NCHW) b += align_up((size_t)p->batch * p->channels * p->height * p->width * es);
+  return b;
+}
+
+extern "C" int s2a_align_conv_forward(const void* x, const float* anchors, const void* weight, void* out,
+                                      const s2a_align_params* pp, void* workspace,
+                                      size_t workspace_bytes, s2a_stream_t stream) {
+  S2A_CHECK_ARG(pp != nullptr, "align_conv: NULL params");
+  const s2a_align_params p = *pp;
+  S2A_CHECK_ARG(p.dtype == S2A_DTYPE_F32 || p.dtype == S2A_DTYPE_F16, "align_conv: dtype");
+  S2A_CHECK_ARG(p.stride > 0, "align_conv: stride must be positive");
+  const int kc = p.dtype == S2A_DTYPE_F32 ? 32 : 64;
+  S2A_CHECK_ARG(p.channels % kc == 0 && p.out_channels % 64 == 0,
+                "align_conv: channels must be a multiple of %d and out_channels of 64", kc);
+  S2A_CHECK_ARG(p.height >= 3 && p.width >= 3, "input image is smaller than kernel");
+  S2A_CHECK_ARG(p.batch * p.height * p.width < (1ll << 31), "align_conv: too many positions");
+  if (p.batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(x && anchors && weight && out, "align_conv: NULL tensor");
+  hipStream_t st = as_stream(stream);
+  if (p.dtype == S2A_DTYPE_F32)
+    return run_fast<float>(x, anchors, true, weight, out, p.batch, (int)p.channels, (int)p.height,
+                           (int)p.width, (int)p.out_channels, p.layout, p.stride, p.relu, workspace,
+                           workspace_bytes, st);
+  return run_fast<_Float16>(x, anchors, true, weight, out, p.batch, (int)p.channels, (int)p.height,
+                            (int)p.width, (int)p.out_channels, p.layout, p.stride, p.relu, workspace,
+                            workspace_bytes, st);
+}

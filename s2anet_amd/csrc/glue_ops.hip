@@ -1,0 +1,157 @@
+// Head glue of S2ANetHead for gfx950, batched and device-side:
+//   delta2bbox_rotated  models/boxes.py:82-162  (+ norm_angle utils/general.py:925-929)
+//   grid anchors        models/anchors.py:75-126 (one square anchor / position, angle 0)
+//   fam_bbox_decode     models/head.py:27-52 (wh_ratio_clip = 1e-6), no per-image Python loop
+//   AlignConv.get_offset models/alignconv.py:30-87, no per-image Python loop
+// All elementwise, HBM-bound; float32 arithmetic in the reference's operation order.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "common.hpp"
+
+namespace s2a {
+namespace {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+__device__ __forceinline__ float norm_angle(float a) {
+  // (a - (-pi/4)) mod pi + (-pi/4), python floor-mod
+  const float lo = -0.78539816339744830962f;
+  float r = fmodf(a - lo, kPi);
+  if (r != 0.0f && r < 0.0f) r += kPi;
+  return r + lo;
+}
+
+__device__ __forceinline__ void decode_one(const float* roi, const float* d, float max_ratio,
+                                           float* o) {
+  float dw = fminf(fmaxf(d[2], -max_ratio), max_ratio);
+  float dh = fminf(fmaxf(d[3], -max_ratio), max_ratio);
+  float ca = cosf(roi[4]), sa = sinf(roi[4]);
+  o[0] = d[0] * roi[2] * ca - d[1] * roi[3] * sa + roi[0];
+  o[1] = d[0] * roi[2] * sa + d[1] * roi[3] * ca + roi[1];
+  o[2] = roi[2] * expf(dw);
+  o[3] = roi[3] * expf(dh);
+  o[4] = norm_angle(kPi * d[4] + roi[4]);
+}
+
+__global__ void k_delta2bbox(const float* __restrict__ rois, const float* __restrict__ deltas,
+                             int64_t n, float max_ratio, float* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r[5], d[5], o[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    r[k] = rois[5 * i + k];
+    d[k] = deltas[5 * i + k];
+  }
+  decode_one(r, d, max_ratio, o);
+#pragma unroll
+  for (int k = 0; k < 5; k++) out[5 * i + k] = o[k];
+}
+
+template <typename T, bool NHWC>
+__global__ void k_fam_refine(const T* __restrict__ pred, int64_t B, int64_t H, int64_t W,
+                             float stride, float side, float max_ratio,
+                             float* __restrict__ refined) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t HW = H * W;
+  if (e >= B * HW) return;
+  int64_t b = e / HW, p = e % HW;
+  int64_t y = p / W, x = p % W;
+  float d[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++)
+    d[k] = NHWC ? (float)pred[(b * HW + p) * 5 + k] : (float)pred[(b * 5 + k) * HW + p];
+  float half = 0.5f * (stride - 1.0f);
+  float roi[5] = {(float)x * stride + half, (float)y * stride + half, side, side, 0.0f};
+  float o[5];
+  decode_one(roi, d, max_ratio, o);
+#pragma unroll
+  for (int k = 0; k < 5; k++) refined[e * 5 + k] = o[k];
+}
+
+// one thread per (b, position); writes the 18 offset planes (coalesced over positions)
+__global__ void k_align_offsets(const float* __restrict__ anchors, int64_t B, int64_t H, int64_t W,
+                                float stride, int ks, float* __restrict__ offset) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t HW = H * W;
+  if (e >= B * HW) return;
+  int64_t b = e / HW, p = e % HW;
+  float yc = (float)(p / W), xc = (float)(p % W);
+  const float* a = anchors + e * 5;
+  float x_ctr = a[0] / stride, y_ctr = a[1] / stride, w = a[2] / stride, h = a[3] / stride;
+  float cs = cosf(a[4]), sn = sinf(a[4]);
+  float dw = w / (float)ks, dh = h / (float)ks;
+  int pad = (ks - 1) / 2;
+  float* ob = offset + b * (2 * ks * ks) * HW + p;
+  for (int ky = 0; ky < ks; ky++)
+    for (int kx = 0; kx < ks; kx++) {
+      float xx = (float)(kx - pad), yy = (float)(ky - pad);
+      float x = dw * xx, y = dh * yy;
+      float xr = cs * x - sn * y;
+      float yr = sn * x + cs * y;
+      float off_x = (xr + x_ctr) - (xc + xx);
+      float off_y = (yr + y_ctr) - (yc + yy);
+      int t = ky * ks + kx;
+      ob[(int64_t)(2 * t) * HW] = off_y;
+      ob[(int64_t)(2 * t + 1) * HW] = off_x;
+    }
+}
+
+}  // namespace
+}  // namespace s2a
+
+using namespace s2a;
+
+extern "C" int s2a_delta2bbox_rotated(const float* rois, const float* deltas, int64_t n,
+                                      float wh_ratio_clip, float* out, s2a_stream_t stream) {
+  S2A_CHECK_ARG(n >= 0 && wh_ratio_clip > 0, "delta2bbox_rotated: bad argument");
+  if (n == 0) return S2A_OK;
+  S2A_CHECK_ARG(rois && deltas && out, "delta2bbox_rotated: NULL tensor");
+  float max_ratio = (float)std::fabs(std::log((double)wh_ratio_clip));
+  k_delta2bbox<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(rois, deltas, n, max_ratio, out);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+extern "C" int s2a_fam_refine_anchors(const void* bbox_pred, int64_t batch, int64_t height,
+                                      int64_t width, float stride, float anchor_scale, int dtype,
+                                      int layout, float* refined, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && height >= 0 && width >= 0 && stride > 0, "fam_refine_anchors: bad shape");
+  const int64_t total = batch * height * width;
+  if (total == 0) return S2A_OK;
+  S2A_CHECK_ARG(bbox_pred && refined, "fam_refine_anchors: NULL tensor");
+  hipStream_t st = as_stream(stream);
+  const float max_ratio = (float)std::fabs(std::log(1e-6));  // head.py:48
+  const float side = anchor_scale * stride;
+  unsigned g = (unsigned)((total + 255) / 256);
+  if (dtype == S2A_DTYPE_F32) {
+    if (layout == S2A_LAYOUT_NHWC)
+      k_fam_refine<float, true><<<g, 256, 0, st>>>((const float*)bbox_pred, batch, height, width, stride, side, max_ratio, refined);
+    else
+      k_fam_refine<float, false><<<g, 256, 0, st>>>((const float*)bbox_pred, batch, height, width, stride, side, max_ratio, refined);
+  } else if (dtype == S2A_DTYPE_F16) {
+    if (layout == S2A_LAYOUT_NHWC)
+      k_fam_refine<_Float16, true><<<g, 256, 0, st>>>((const _Float16*)bbox_pred, batch, height, width, stride, side, max_ratio, refined);
+    else
+      k_fam_refine<_Float16, false><<<g, 256, 0, st>>>((const _Float16*)bbox_pred, batch, height, width, stride, side, max_ratio, refined);
+  } else {
+    S2A_CHECK_ARG(false, "fam_refine_anchors: dtype");
+  }
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+extern "C" int s2a_align_offsets(const float* anchors, int64_t batch, int64_t height, int64_t width,
+                                 float stride, int ksize, float* offset, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && height >= 0 && width >= 0 && stride > 0 && ksize > 0 && (ksize & 1),
+                "align_offsets: bad argument");
+  const int64_t total = batch * height * width;
+  if (total == 0) return S2A_OK;
+  S2A_CHECK_ARG(anchors && offset, "align_offsets: NULL tensor");
+  k_align_offsets<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(
+      anchors, batch, height, width, stride, ksize, offset);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}

@@ -1,0 +1,144 @@
+"""Deformable convolution host side (models/dcn/deform_conv.py).
+
+    deform_conv_cuda.deform_conv_forward_cuda(input, weight, offset, output, columns, ones,
+        kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group, im2col_step)
+    DeformConvFunction / deform_conv(input, offset, weight, stride, padding, dilation, groups,
+        deformable_groups, im2col_step=64)
+    DeformConv(in, out, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+        deformable_groups=1, bias=False).forward(x, offset)      parameter name: ``weight``
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+
+
+def _is_nhwc(t):
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW,
+                             padH, dilationW, dilationH, group, deformable_group, im2col_step,
+                             relu=False):
+    """Same positional signature as the reference pybind function
+    (models/dcn/src/deform_conv_cuda.cpp:152-157; W-before-H order).  ``output`` is
+    caller-allocated and filled in place; ``columns`` / ``ones`` / ``im2col_step`` are accepted
+    and ignored (the fused kernel has no columns buffer).  Returns 1."""
+    _lib.require_cuda(input, weight, offset, output)
+    if input.dim() not in (3, 4):
+        raise RuntimeError("3D or 4D input tensor expected but got: %d" % input.dim())
+    if weight.dim() != 4:
+        raise RuntimeError("4D weight tensor (nOutputPlane,nInputPlane,kH,kW) expected, but got: %d" % weight.dim())
+    if weight.size(2) != kH or weight.size(3) != kW:
+        raise RuntimeError("kernel size should be consistent with weight")
+    squeeze = input.dim() == 3
+    if squeeze:
+        input, offset, output = input.unsqueeze(0), offset.unsqueeze(0), output.unsqueeze(0)
+    nhwc = _is_nhwc(input) and _is_nhwc(output)
+    x = input if nhwc else input.contiguous()
+    w = weight.contiguous()
+    if w.dtype != x.dtype:
+        w = w.to(x.dtype)
+    off = offset.contiguous()
+    if off.dtype not in (torch.float32, x.dtype):
+        off = off.float()
+    B, C, H, W = x.shape
+    O = w.shape[0]
+    if w.shape[1] * group != C:
+        raise RuntimeError("invalid number of input planes, expected: %d, but got: %d" % (w.shape[1] * group, C))
+    Ho = (H + 2 * padH - (dilationH * (kH - 1) + 1)) // dH + 1
+    Wo = (W + 2 * padW - (dilationW * (kW - 1) + 1)) // dW + 1
+    if off.shape[0] != B:
+        raise RuntimeError("invalid batch size of offset")
+    if off.shape[1] != deformable_group * 2 * kH * kW:
+        raise RuntimeError("invalid number of channels of offset")
+    if off.shape[2] != Ho or off.shape[3] != Wo:
+        raise RuntimeError("invalid spatial size of offset, expected height: %d width: %d, but got "
+                           "height: %d width: %d" % (Ho, Wo, off.shape[2], off.shape[3]))
+    if tuple(output.shape) != (B, O, Ho, Wo):
+        raise RuntimeError("output has the wrong shape")
+    out = output if (nhwc or output.is_contiguous()) else torch.empty_like(output, memory_format=torch.contiguous_format)
+    p = _lib.DcnParams(B, C, H, W, O, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                       deformable_group, _lib.dtype_code(x), _lib.dtype_code(off),
+                       _lib.LAYOUT_NHWC if nhwc else _lib.LAYOUT_NCHW, int(bool(relu)))
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        ws = _lib.workspace(L.s2a_deform_conv_workspace_bytes(p), x.device, "dcn")
+        _lib.check(L.s2a_deform_conv_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(out), p,
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
+    if out is not output:
+        output.copy_(out)
+    return 1
+
+
+class DeformConvFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1,
+                deformable_groups=1, im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
+        stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+        if not input.is_cuda:
+            raise NotImplementedError     # deform_conv.py:58-59
+        cur_im2col_step = min(im2col_step, input.shape[0])
+        assert (input.shape[0] % cur_im2col_step) == 0, "im2col step must divide batchsize"
+        weight = weight.type_as(input)                      # deform_conv.py:45-46
+        kH, kW = weight.shape[2], weight.shape[3]
+        Ho = (input.size(2) + 2 * padding[0] - (dilation[0] * (kH - 1) + 1)) // stride[0] + 1
+        Wo = (input.size(3) + 2 * padding[1] - (dilation[1] * (kW - 1) + 1)) // stride[1] + 1
+        if Ho <= 0 or Wo <= 0:
+            raise ValueError("convolution input is too small (output would be {}x{})".format(Ho, Wo))
+        fmt = torch.channels_last if _is_nhwc(input) else torch.contiguous_format
+        output = torch.empty((input.size(0), weight.size(0), Ho, Wo), dtype=input.dtype,
+                             device=input.device, memory_format=fmt)
+        deform_conv_forward_cuda(input, weight, offset, output, None, None, kW, kH, stride[1],
+                                 stride[0], padding[1], padding[0], dilation[1], dilation[0], groups,
+                                 deformable_groups, cur_im2col_step)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):  # pragma: no cover - training path, SURVEY 8(f) "next"
+        raise NotImplementedError("deform_conv backward is outside the inference hot path (SURVEY.md 8(f))")
+
+
+deform_conv = DeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0, "in_channels {} cannot be divisible by groups {}".format(in_channels, groups)
+        assert out_channels % groups == 0, "out_channels {} cannot be divisible by groups {}".format(out_channels, groups)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1.0 / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        # inputs smaller than the kernel are zero-padded and the result cropped (deform_conv.py:254-271)
+        input_pad = x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1]
+        if input_pad:
+            pad_h = max(self.kernel_size[0] - x.size(2), 0)
+            pad_w = max(self.kernel_size[1] - x.size(3), 0)
+            x = F.pad(x, (0, pad_w, 0, pad_h), "constant", 0).contiguous()
+            offset = F.pad(offset, (0, pad_w, 0, pad_h), "constant", 0).contiguous()
+        out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation,
+                          self.groups, self.deformable_groups)
+        if input_pad:
+            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        return out

@@ -1,0 +1,182 @@
+"""Carrier network for the end-to-end configs: R-50 backbone (C3-C5) + FPN (P3-P7) + S2ANetHead.
+
+The backbone and neck are stock ``torch.nn`` convolutions executed by MIOpen (no
+custom arithmetic there, out of scope for hand-written kernels).  Structure follows
+models/backbone.py:37-175,283-354 and models/neck.py:5-96 (same module/parameter names, so a
+reference ``state_dict`` loads), but the constructor is OFFLINE: no torchvision download
+(backbone.py:241-255); weights are seeded random (kaiming for ResNet backbone.py:134-140,
+xavier-uniform for FPN neck.py:58-62, N(0,0.01) for the head).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .head import S2ANetHead
+
+
+class BottleNeck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        out += residual
+        return self.relu(out)
+
+
+class DetectorBackbone(nn.Module):
+    """ResNet-50 trunk exposing C3, C4, C5 (out_indices=(2,3,4), backbone.py:283-354)"""
+
+    def __init__(self, layers=(3, 4, 6, 3), out_indices=(2, 3, 4)):
+        super().__init__()
+        self.inplanes = 64
+        conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        bn1 = nn.BatchNorm2d(64)
+        layer1 = self._make_layer(64, layers[0])
+        layer2 = self._make_layer(128, layers[1], stride=2)
+        layer3 = self._make_layer(256, layers[2], stride=2)
+        layer4 = self._make_layer(512, layers[3], stride=2)
+        self.backbone = nn.Sequential(
+            nn.Sequential(conv1, bn1, nn.ReLU(inplace=True)),
+            nn.Sequential(nn.MaxPool2d(kernel_size=3, stride=2, padding=1, ceil_mode=False), layer1),
+            layer2, layer3, layer4)
+        self.out_indices = out_indices
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        layers = [BottleNeck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        layers += [BottleNeck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        outs = []
+        for i, m in enumerate(self.backbone):
+            x = m(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class FPN(nn.Module):
+    def __init__(self, in_channels=(512, 1024, 2048), out_channels=256, num_outs=5):
+        super().__init__()
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.lateral_convs = nn.ModuleList(nn.Conv2d(c, out_channels, 1) for c in in_channels)
+        self.fpn_convs = nn.ModuleList(nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels)
+        for i in range(num_outs - self.num_ins):
+            cin = in_channels[-1] if i == 0 else out_channels
+            self.fpn_convs.append(nn.Conv2d(cin, out_channels, 3, stride=2, padding=1))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, inputs):
+        lat = [l(inputs[i]) for i, l in enumerate(self.lateral_convs)]
+        for i in range(self.num_ins - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], scale_factor=2, mode="nearest")
+        outs = [self.fpn_convs[i](lat[i]) for i in range(self.num_ins)]
+        for i in range(self.num_outs - self.num_ins):
+            outs.append(self.fpn_convs[self.num_ins + i](inputs[-1] if i == 0 else outs[-1]))
+        return tuple(outs)
+
+
+class S2ANet(nn.Module):
+    """models/detector.py:9-37.  forward(imgs, post_process) -> dict like the reference."""
+
+    def __init__(self, num_classes=15, **head_kw):
+        super().__init__()
+        self.stride = (8, 16, 32, 64, 128)
+        self.backbone = DetectorBackbone()
+        self.neck = FPN(num_outs=len(self.stride))
+        self.head = S2ANetHead(num_classes=num_classes, featmap_strides=self.stride, **head_kw)
+
+    def forward(self, imgs, post_process=False):
+        return self.head(self.neck(self.backbone(imgs)), post_process=post_process)
+
+    def features_to_pred(self, imgs):
+        feats = self.neck(self.backbone(imgs))
+        per_level = [self.head.forward_single(f, s) for f, s in zip(feats, self.stride)]
+        return tuple(map(list, zip(*per_level)))
+
+    @torch.no_grad()
+    def detect(self, imgs_u8, max_candidates=None):
+        """device-resident uint8 batch [B,3,H,W] -> (dets[B,2000,6], labels[B,2000], counts[B]).
+        /255 normalisation as val.py:246-247; no host synchronisation anywhere."""
+        dt = next(self.parameters()).dtype
+        x = imgs_u8.to(dt).div_(255.0)
+        if imgs_u8.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        return self.head.get_bboxes_batched(self.features_to_pred(x), max_candidates)
+
+
+def fold_batchnorm(model):
+    """inference-time conv+BN folding (BN in eval mode is an affine map): fewer passes over HBM"""
+    def fold(conv, bn):
+        w = conv.weight
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                          conv.dilation, conv.groups, bias=True).to(w.device, w.dtype)
+        fused.weight.data = w * scale.view(-1, 1, 1, 1)
+        b = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+        fused.bias.data = (b - bn.running_mean) * scale + bn.bias
+        return fused
+
+    for mod in model.modules():
+        if isinstance(mod, BottleNeck):
+            mod.conv1, mod.bn1 = fold(mod.conv1, mod.bn1), nn.Identity()
+            mod.conv2, mod.bn2 = fold(mod.conv2, mod.bn2), nn.Identity()
+            mod.conv3, mod.bn3 = fold(mod.conv3, mod.bn3), nn.Identity()
+            if mod.downsample is not None:
+                mod.downsample = nn.Sequential(fold(mod.downsample[0], mod.downsample[1]))
+    stem = model.backbone.backbone[0]
+    model.backbone.backbone[0] = nn.Sequential(fold(stem[0], stem[1]), stem[2])
+    return model
+
+
+def build_synthetic_detector(num_classes=15, seed=1234, dtype=torch.float16, device="cuda",
+                             channels_last=True, fold_bn=True, **head_kw):
+    """random-init S2ANet of the reference architecture (no network access, no checkpoint).
+    The last BN of every bottleneck gets gamma = 0.25 so that activations of the untrained
+    50-layer trunk stay inside fp16 range (a trained network has learned scales instead)."""
+    torch.manual_seed(seed)
+    m = S2ANet(num_classes=num_classes, **head_kw)
+    for mod in m.modules():
+        if isinstance(mod, BottleNeck):
+            mod.bn3.weight.data.fill_(0.25)
+    m.eval()
+    if fold_bn:
+        fold_batchnorm(m)
+    m = m.to(device=device, dtype=dtype)
+    if channels_last:
+        m = m.to(memory_format=torch.channels_last)
+    return m

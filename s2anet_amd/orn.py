@@ -1,0 +1,143 @@
+"""ORN host side: active rotating filters + rotation-invariant pooling.
+
+Mirrors models/orn:
+    orn_cuda.arf_forward(weight, indices)                     models/orn/src/vision.cpp:7-12
+    active_rotating_filter = _ActiveRotatingFilter.apply       functions/active_rotating_filter.py:11-34
+    ORConv2d(in, out, kernel_size, arf_config, ...)            modules/ORConv.py:12-101
+    RotationInvariantPooling(nInputPlane, nOrientation=8)      functions/rotation_invariant_pooling.py:6-27
+State-dict entries of ORConv2d: ``weight [O,I,nOri,k,k]``, ``bias [O*nRot]``, ``indices`` (uint8).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+
+# 3x3 tap permutation of a rotation by k*45 degrees (1-based), ORConv.py:53-62
+_ROT3 = {0: (1, 2, 3, 4, 5, 6, 7, 8, 9), 45: (2, 3, 6, 1, 5, 9, 4, 7, 8),
+         90: (3, 6, 9, 2, 5, 8, 1, 4, 7), 135: (6, 9, 8, 3, 5, 7, 2, 1, 4),
+         180: (9, 8, 7, 6, 5, 4, 3, 2, 1), 225: (8, 7, 4, 9, 5, 1, 6, 3, 2),
+         270: (7, 4, 1, 8, 5, 2, 9, 6, 3), 315: (4, 1, 2, 7, 5, 3, 8, 9, 6)}
+_ROT1 = {a: (1,) for a in range(0, 360, 45)}
+
+
+def arf_forward(weight, indices):
+    """orn_cuda.arf_forward: weight[O,I,nOri,kH,kW], indices uint8[nOri,kH,kW,nRot]
+    -> [O*nRot, I*nOri, kH, kW] (new tensor)."""
+    _lib.require_cuda(weight, indices)
+    if weight.dim() != 5:
+        raise RuntimeError("only supports a batch of ARFs.")   # ARF_forward_cuda:81
+    w = weight.contiguous()
+    idx = indices.contiguous()
+    if idx.dtype != torch.uint8:
+        idx = idx.byte()
+    O, I, nOri, kH, kW = w.shape
+    nRot = idx.shape[3]
+    out = torch.empty((O * nRot, I * nOri, kH, kW), dtype=w.dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().s2a_arf_forward(_lib.ptr(w), _lib.ptr(idx), O, I, nOri, kH, kW, nRot,
+                                              _lib.dtype_code(w), _lib.ptr(out),
+                                              _lib.stream_ptr(w.device)))
+    return out
+
+
+class _ActiveRotatingFilter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, indices):
+        ctx.save_for_backward(indices)
+        ctx.in_shape = input.shape
+        return arf_forward(input, indices)
+
+    @staticmethod
+    def backward(ctx, grad_output):  # pragma: no cover - training path, SURVEY 8(f) "next"
+        raise NotImplementedError("arf_backward is outside the inference hot path (SURVEY.md 8(f))")
+
+
+active_rotating_filter = _ActiveRotatingFilter.apply
+
+
+class ORConv2d(nn.Conv2d):
+    """Conv2d whose weight is the ARF expansion of a [O,I,nOri,k,k] filter bank.
+
+    At inference the expanded filter depends on the parameters only, so it is computed once
+    and cached (the reference recomputes it on every forward of every FPN level,
+    ORConv.py:80-82); the cache is invalidated whenever the weight tensor changes
+    (version counter / dtype / device)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, arf_config=None, stride=1,
+                 padding=0, dilation=1, groups=1, bias=True):
+        self.nOrientation, self.nRotation = _pair(arf_config)
+        for v, name in ((self.nOrientation, "nOrientation"), (self.nRotation, "nRotation")):
+            assert v >= 1 and (v & (v - 1)) == 0, "invalid {} {}".format(name, v)
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        self.register_buffer("indices", self.get_indices())
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, self.nOrientation,
+                                               *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels * self.nRotation))
+        self.reset_parameters()
+        self._arf_cache = None
+
+    def reset_parameters(self):
+        n = self.in_channels * getattr(self, "nOrientation", 1)
+        for k in self.kernel_size:
+            n *= k
+        self.weight.data.normal_(0, math.sqrt(2.0 / n))
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def get_indices(self):
+        kH, kW = self.kernel_size
+        table = _ROT3 if kW == 3 else _ROT1
+        d_ori, d_rot = 360 / self.nOrientation, 360 / self.nRotation
+        idx = torch.zeros(self.nOrientation * kH * kW, self.nRotation, dtype=torch.uint8)
+        for i in range(self.nOrientation):
+            for j in range(kH * kW):
+                for k in range(self.nRotation):
+                    angle = d_rot * k
+                    layer = (i + math.floor(angle / d_ori)) % self.nOrientation
+                    idx[i * kH * kW + j, k] = int(layer * kH * kW + table[int(angle)][j])
+        return idx.view(self.nOrientation, kH, kW, self.nRotation)
+
+    def rotate_arf(self):
+        w = self.weight
+        key = (w._version, w.dtype, w.device, w.data_ptr())
+        if self.training or torch.is_grad_enabled() and w.requires_grad:
+            return active_rotating_filter(w, self.indices)
+        if self._arf_cache is None or self._arf_cache[0] != key:
+            self._arf_cache = (key, arf_forward(w.detach(), self.indices))
+        return self._arf_cache[1]
+
+    def forward(self, input):
+        return F.conv2d(input, self.rotate_arf(), self.bias, self.stride, self.padding,
+                        self.dilation, self.groups)
+
+
+def rot_inv_pool(x, n_orientation=8):
+    _lib.require_cuda(x)
+    N, c, h, w = x.shape
+    if c % n_orientation:
+        raise RuntimeError("channels must be a multiple of nOrientation")
+    nhwc = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+    if not nhwc:
+        x = x.contiguous()
+    out = torch.empty((N, c // n_orientation, h, w), dtype=x.dtype, device=x.device,
+                      memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().s2a_rot_inv_pool(
+            _lib.ptr(x), N, c, h * w, n_orientation, _lib.dtype_code(x),
+            _lib.LAYOUT_NHWC if nhwc else _lib.LAYOUT_NCHW, _lib.ptr(out), _lib.stream_ptr(x.device)))
+    return out
+
+
+class RotationInvariantPooling(nn.Module):
+    def __init__(self, nInputPlane, nOrientation=8):
+        super().__init__()
+        self.nInputPlane = nInputPlane
+        self.nOrientation = nOrientation
+
+    def forward(self, x):
+        return rot_inv_pool(x, self.nOrientation)

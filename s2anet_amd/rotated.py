@@ -1,0 +1,190 @@
+"""Rotated-box IoU and NMS — host side of the reference surface
+
+    utils/box_iou_rotated/__init__.py          box_iou_rotated(boxes1, boxes2)
+    utils/nms_rotated/__init__.py:6-11         nms_rotated(dets[N,6], iou_thr)
+    utils/ml_nms_rotated/__init__.py           ml_nms_rotated(dets, scores, labels, iou_thr)
+    utils/bbox_nms_rotated.py:5-64             multiclass_nms_rotated(...)
+
+plus the pybind-shaped raw entry points used by ``s2anet_amd.compat`` and a batched
+multiclass NMS (one launch sequence for a whole batch of images) used by the detector.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+# ------------------------------------------------------------------ pybind-shaped entry points
+def box_iou_rotated(boxes1, boxes2):
+    """box_iou_rotated(boxes1[N,5], boxes2[M,5]) -> [N,M] float32
+    (utils/box_iou_rotated/src/box_iou_rotated.h:22-42).  The reference reads raw
+    float pointers (contiguous f32 required, models/utils.py:51-56); non-f32 /
+    non-contiguous inputs are converted here instead of being mis-read."""
+    _lib.require_cuda(boxes1, boxes2)
+    if boxes1.device != boxes2.device:
+        raise RuntimeError("boxes1 and boxes2 must be on the same device")
+    b1, b2 = _f32c(boxes1), _f32c(boxes2)
+    n, m = b1.shape[0], b2.shape[0]
+    out = torch.empty((n, m), dtype=torch.float32, device=b1.device)
+    if n == 0 or m == 0:
+        return out
+    if b1.shape[-1] != 5 or b2.shape[-1] != 5:
+        raise RuntimeError("boxes must have 5 columns (x, y, w, h, angle)")
+    L = _lib.lib()
+    with torch.cuda.device(b1.device):
+        nbytes = L.s2a_box_iou_rotated_workspace_bytes(n, m)
+        ws = _lib.workspace(nbytes, b1.device, "iou")
+        _lib.check(L.s2a_box_iou_rotated(_lib.ptr(b1), n, _lib.ptr(b2), m, _lib.ptr(out), _lib.ptr(ws),
+                                         ws.numel(), _lib.stream_ptr(b1.device)))
+    return out
+
+
+def box_iou_rotated_pairs(boxes1, boxes2):
+    _lib.require_cuda(boxes1, boxes2)
+    b1, b2 = _f32c(boxes1), _f32c(boxes2)
+    assert b1.shape == b2.shape and b1.shape[-1] == 5
+    out = torch.empty((b1.shape[0],), dtype=torch.float32, device=b1.device)
+    with torch.cuda.device(b1.device):
+        _lib.check(_lib.lib().s2a_box_iou_rotated_pairs(_lib.ptr(b1), _lib.ptr(b2), b1.shape[0],
+                                                        _lib.ptr(out), _lib.stream_ptr(b1.device)))
+    return out
+
+
+def _nms_raw(dets, scores, labels, iou_threshold):
+    _lib.require_cuda(dets, scores, labels)
+    d = _f32c(dets)
+    s = _f32c(scores)       # f16 scores are only sorted: f16->f32 is order preserving
+    lab = None if labels is None else _f32c(labels)
+    n = d.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=d.device)
+    if d.dim() != 2 or d.shape[1] != 5:
+        raise RuntimeError("dets must be [N,5]")
+    if s.numel() != n or (lab is not None and lab.numel() != n):
+        raise RuntimeError("scores / labels must have N elements")
+    L = _lib.lib()
+    with torch.cuda.device(d.device):
+        keep = torch.empty((n,), dtype=torch.int64, device=d.device)
+        cnt = torch.empty((1,), dtype=torch.int64, device=d.device)
+        ws = _lib.workspace(L.s2a_nms_rotated_workspace_bytes(n, n), d.device, "nms")
+        host_k = ctypes.c_int64(0)
+        st = _lib.stream_ptr(d.device)
+        if lab is None:
+            rc = L.s2a_nms_rotated(_lib.ptr(d), _lib.ptr(s), n, float(iou_threshold), _lib.ptr(keep),
+                                   _lib.ptr(cnt), ctypes.byref(host_k), _lib.ptr(ws), ws.numel(), st)
+        else:
+            rc = L.s2a_ml_nms_rotated(_lib.ptr(d), _lib.ptr(s), _lib.ptr(lab), n, float(iou_threshold),
+                                      _lib.ptr(keep), _lib.ptr(cnt), ctypes.byref(host_k),
+                                      _lib.ptr(ws), ws.numel(), st)
+        _lib.check(rc)
+    return keep[:host_k.value]
+
+
+def nms_rotated_raw(dets, scores, iou_threshold):
+    """nms_rotated_cuda.nms_rotated(dets[N,5], scores[N], thr) -> int64[K]
+    (utils/nms_rotated/src/nms_rotated.h:21-41)"""
+    return _nms_raw(dets, scores, None, iou_threshold)
+
+
+def ml_nms_rotated(dets, scores, labels, iou_threshold):
+    """ml_nms_rotated_cuda.ml_nms_rotated(dets[N,5], scores[N], labels[N], thr) -> int64[K]
+    (utils/ml_nms_rotated/src/nms_rotated.h:23-44): keep indices, descending score."""
+    return _nms_raw(dets, scores, labels, iou_threshold)
+
+
+# ------------------------------------------------------------------ python wrappers of the reference
+def nms_rotated(dets, iou_thr):
+    """utils/nms_rotated/__init__.py:6-11 — dets[N,6] = x,y,w,h,a,score.  Returns ``dets`` alone
+    when empty, ``(dets[keep], keep)`` otherwise (the reference's own quirk)."""
+    if dets.shape[0] == 0:
+        return dets
+    keep_inds = nms_rotated_raw(dets[:, :5], dets[:, 5], iou_thr)
+    return dets[keep_inds, :], keep_inds
+
+
+def multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, max_per_img=2000):
+    """utils/bbox_nms_rotated.py:5-64.  bboxes[n,5], scores[n,C] -> ([K,6], labels[K])."""
+    num_classes = scores.size(1)
+    assert bboxes.shape[1] == 5
+    mask = scores > score_thr
+    idx = mask.nonzero(as_tuple=False)             # row-major == boolean-mask order
+    cand_scores = scores[mask]
+    cand_boxes = bboxes[idx[:, 0]]
+    labels = idx[:, 1].to(cand_boxes)              # float labels, as the reference (:40-42)
+    if cand_boxes.shape[0] > 0:
+        keep = ml_nms_rotated(cand_boxes, cand_scores, labels, iou_thr)
+        cand_boxes, cand_scores, labels = cand_boxes[keep], cand_scores[keep], labels[keep]
+        if keep.size(0) > max_per_img:
+            _, inds = cand_scores.sort(descending=True)
+            inds = inds[:max_per_img]
+            cand_boxes, cand_scores, labels = cand_boxes[inds], cand_scores[inds], labels[inds]
+        return torch.cat([cand_boxes, cand_scores[:, None].to(cand_boxes)], dim=1), labels
+    out = bboxes.new_zeros((0, 6))
+    return out, out.new_zeros((0, 1), dtype=torch.long)   # reference's inconsistent empty shape (:62-63)
+    del num_classes
+
+
+def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, max_per_img=2000,
+                                   max_candidates=None):
+    """Whole-batch multiclass rotated NMS with NO host synchronisation.
+
+    bboxes[B,n,5] f32, scores[B,n,C] -> dets[B,max_per_img,6] (x,y,w,h,a,score; zero padded),
+    labels[B,max_per_img] int32 (-1 padded), counts[B] int32.  Same result per image as
+    ``multiclass_nms_rotated`` (utils/bbox_nms_rotated.py:5-64) — candidates are
+    (box, class) pairs with score > score_thr, suppressed per (image, class), survivors
+    listed by descending score and truncated to max_per_img.
+
+    Static shapes: at most ``max_candidates`` (default n*C, i.e. lossless) candidates per
+    batch are considered; the candidate list is compacted on the device.
+    """
+    _lib.require_cuda(bboxes, scores)
+    B, n, C = scores.shape
+    dev = bboxes.device
+    bb = _f32c(bboxes)
+    sc = _f32c(scores)
+    total = B * n * C
+    cap = total if max_candidates is None else min(int(max_candidates), total)
+    flat = sc.reshape(-1)
+    valid = flat > score_thr
+    if cap == total:
+        cand = torch.arange(total, device=dev, dtype=torch.int64)
+        cand_valid = valid
+    else:
+        # static-size compaction: positions of the first `cap` candidates (stable order)
+        pos = torch.cumsum(valid.to(torch.int32), 0) - 1
+        cand = torch.zeros((cap,), dtype=torch.int64, device=dev)
+        cand_valid = torch.zeros((cap,), dtype=torch.bool, device=dev)
+        sel = valid & (pos < cap)
+        src = torch.arange(total, device=dev, dtype=torch.int64)
+        cand.scatter_(0, pos.clamp(0, cap - 1).to(torch.int64)[sel], src[sel])
+        cand_valid.scatter_(0, pos.clamp(0, cap - 1).to(torch.int64)[sel], sel[sel])
+    img = (cand // (n * C)).to(torch.int32)
+    cls = (cand % C).to(torch.int32)
+    row = cand // C                                     # index into bb.reshape(B*n,5)
+    cboxes = bb.reshape(-1, 5)[row].contiguous()
+    cscores = flat[cand].contiguous()
+    neg = torch.full_like(img, -1)
+    seg = torch.where(cand_valid, img * C + cls, neg).contiguous()   # < 0: padding row, ignored
+    grp = torch.where(cand_valid, img, neg).contiguous()
+    N = cboxes.shape[0]
+    L = _lib.lib()
+    keep = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        # one (image, class) segment holds at most n rows: tight bound for the mask workspace
+        ws = _lib.workspace(L.s2a_nms_rotated_workspace_bytes(N, min(N, n)), dev, "nms_b")
+        _lib.check(L.s2a_nms_rotated_segmented(
+            _lib.ptr(cboxes), _lib.ptr(cscores), _lib.ptr(seg), _lib.ptr(grp), N, B * C, B,
+            float(iou_thr), None, _lib.ptr(keep), _lib.ptr(counts), int(max_per_img),
+            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+    ok = keep >= 0
+    kidx = keep.clamp(min=0).to(torch.int64)
+    dets = torch.cat([cboxes[kidx], cscores[kidx][..., None]], dim=-1)
+    dets = torch.where(ok[..., None], dets, torch.zeros_like(dets))
+    labels = torch.where(ok, cls[kidx], torch.full_like(keep, -1))
+    return dets, labels, counts

@@ -1,0 +1,324 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the same
+seeded inputs and against the committed golden vectors.  Bit-exact for IoU values (GPU sort
+branch) and NMS keep indices; 1e-4 for AlignConv floats (f32)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import golden, rand_rboxes, distinct_scores
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    return t if dtype is None else t.to(dtype)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+# ------------------------------------------------------------------ rotated IoU
+def test_iou_golden_bitexact():
+    import s2anet_amd as S
+    g = golden("iou_256.npz")
+    out = S.box_iou_rotated(cu(g["boxes1"]), cu(g["boxes2"])).cpu().numpy()
+    ref = g["iou_ref_gpubranch"]
+    neq = bits(out) != bits(ref)
+    assert neq.sum() == 0, (neq.sum(), np.abs(out - ref).max())
+    assert np.abs(out - g["iou_ref_cpu"]).max() < 1e-4   # vs the reference CPU op: north-star tolerance
+
+
+def test_iou_random_vs_oracle(rng):
+    import s2anet_amd as S
+    b1, b2 = rand_rboxes(rng, 1111, span=400), rand_rboxes(rng, 777, span=400)
+    out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
+    ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU, cull=True)
+    assert out.shape == (1111, 777)
+    assert (bits(out) != bits(ref)).sum() == 0
+    assert (out > 0).mean() > 0.01
+
+
+def test_iou_pairs_and_edges(rng):
+    import s2anet_amd as S
+    from s2anet_amd.rotated import box_iou_rotated_pairs
+    a, b = rand_rboxes(rng, 5000, span=150), rand_rboxes(rng, 5000, span=150)
+    out = box_iou_rotated_pairs(cu(a), cu(b)).cpu().numpy()
+    ref = oracle.iou_pairs(a, b, sort_mode=oracle.SORT_GPU)
+    assert (bits(out) != bits(ref)).sum() == 0
+    e = torch.zeros((0, 5), device=dev())
+    assert S.box_iou_rotated(e, cu(a[:3])).shape == (0, 3)
+    assert S.box_iou_rotated(cu(a[:3]), e).shape == (3, 0)
+    sq = cu(np.array([[0.5, 0.5, 1, 1, 0]], np.float32))
+    sq2 = cu(np.array([[1.0, 1.0, 1, 1, 0]], np.float32))
+    assert abs(S.box_iou_rotated(sq, sq2).item() - 1 / 7) < 1e-6
+    # f64 / non-contiguous inputs are converted, not mis-read
+    assert abs(S.box_iou_rotated(sq.double(), sq2).item() - 1 / 7) < 1e-6
+
+
+def test_iou_dense_overlap_chunks(rng):
+    """every pair overlapping: the pair list is as long as the matrix"""
+    import s2anet_amd as S
+    b1, b2 = rand_rboxes(rng, 300, span=20, lo=30, hi=60), rand_rboxes(rng, 260, span=20, lo=30, hi=60)
+    out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
+    ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU)
+    assert (out > 0).mean() > 0.95
+    assert (bits(out) != bits(ref)).sum() == 0
+
+
+# ------------------------------------------------------------------ NMS
+@pytest.mark.parametrize("thr", [0.1, 0.5])
+def test_nms_golden_keep_bitexact(thr):
+    import s2anet_amd as S
+    from s2anet_amd.rotated import nms_rotated_raw
+    g = golden("nms_2k.npz")
+    d, s, lab = cu(g["dets"]), cu(g["scores"]), cu(g["labels"])
+    k = S.ml_nms_rotated(d, s, lab, thr).cpu().numpy()
+    assert k.dtype == np.int64 and np.array_equal(k, g[f"ml_keep_gt_{thr}"])
+    k1 = nms_rotated_raw(d, s, thr).cpu().numpy()
+    assert np.array_equal(k1, g[f"sc_keep_gt_{thr}"])
+    # the reference CPU op (>= rule, std::sort branch) keeps the same boxes on this fixture
+    assert np.array_equal(k, g[f"ml_keep_ge_{thr}"])
+    assert np.array_equal(k1, g[f"sc_keep_ge_{thr}"])
+
+
+def test_nms_four_box_case_and_wrapper_quirks():
+    import s2anet_amd as S
+    from s2anet_amd.rotated import nms_rotated_raw
+    g = golden("nms_2k.npz")
+    d, s, lab = cu(g["d4"]), cu(g["s4"]), cu(g["l4"])
+    assert S.ml_nms_rotated(d, s, lab, 0.5).tolist() == [0, 2, 3]
+    assert nms_rotated_raw(d, s, 0.5).tolist() == [0, 3]
+    assert nms_rotated_raw(d, s, 1.0).tolist() == [0, 1, 2, 3]      # strict > (GPU rule)
+    dets6 = torch.cat([d, s[:, None]], 1)
+    kept, inds = S.nms_rotated(dets6, 0.5)
+    assert inds.tolist() == [0, 3] and kept.shape == (2, 6)
+    empty = torch.zeros((0, 6), device=dev())
+    assert S.nms_rotated(empty, 0.5) is empty
+    assert S.ml_nms_rotated(empty[:, :5], empty[:, 5], empty[:, 5], 0.5).shape == (0,)
+    # f16 scores are only sorted
+    assert S.ml_nms_rotated(d, s.half(), lab, 0.5).tolist() == [0, 2, 3]
+
+
+@pytest.mark.parametrize("n,span,nl", [(6000, 500, 15), (3000, 120, 3), (257, 40, 1), (64, 30, 2), (1, 10, 1)])
+def test_nms_random_vs_oracle(rng, n, span, nl):
+    import s2anet_amd as S
+    from s2anet_amd.rotated import nms_rotated_raw
+    d, s = rand_rboxes(rng, n, span=span), distinct_scores(rng, n)
+    lab = rng.integers(0, nl, n).astype(np.float32)
+    k = S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.5).cpu().numpy()
+    ref = oracle.ml_nms_rotated(d, s, lab, 0.5, rule=oracle.RULE_GT, sort_mode=oracle.SORT_GPU, cull=True)
+    assert np.array_equal(k, ref), (len(k), len(ref))
+    k1 = nms_rotated_raw(cu(d), cu(s), 0.3).cpu().numpy()
+    ref1 = oracle.nms_rotated(d, s, 0.3, rule=oracle.RULE_GT, sort_mode=oracle.SORT_GPU, cull=True)
+    assert np.array_equal(k1, ref1)
+
+
+def test_nms_properties_at_scale(rng):
+    """size-independent properties at a size the oracle cannot scan pair by pair quickly:
+    idempotence (NMS of the kept set keeps everything), order, label independence."""
+    import s2anet_amd as S
+    n = 60000
+    d, s = rand_rboxes(rng, n, span=1024), distinct_scores(rng, n)
+    lab = rng.integers(0, 15, n).astype(np.float32)
+    D, Sc, Lb = cu(d), cu(s), cu(lab)
+    k = S.ml_nms_rotated(D, Sc, Lb, 0.5)
+    ks = Sc[k]
+    assert (ks[1:] < ks[:-1]).all()                      # descending score order
+    k2 = S.ml_nms_rotated(D[k], Sc[k], Lb[k], 0.5)
+    assert k2.numel() == k.numel() and (k2 == torch.arange(k.numel(), device=k.device)).all()
+    # per-label decomposition: ml-NMS == union of single-class NMS per label
+    from s2anet_amd.rotated import nms_rotated_raw
+    parts = []
+    for c in range(15):
+        idx = (Lb == c).nonzero()[:, 0]
+        parts.append(idx[nms_rotated_raw(D[idx], Sc[idx], 0.5)])
+    allk = torch.cat(parts)
+    assert torch.equal(torch.sort(allk)[0], torch.sort(k)[0])
+    ref = oracle.ml_nms_rotated(d, s, lab, 0.5, rule=oracle.RULE_GT, sort_mode=oracle.SORT_GPU, cull=True)
+    assert np.array_equal(k.cpu().numpy(), ref)
+
+
+def test_multiclass_nms_matches_reference_python():
+    import s2anet_amd as S
+    g = golden("head_glue.npz")
+    det, lab = S.multiclass_nms_rotated(cu(g["mc_bboxes"]), cu(g["mc_scores"]), 0.05, 0.5, 300)
+    assert np.array_equal(det.cpu().numpy(), g["mc_det"])
+    assert np.array_equal(lab.cpu().numpy(), g["mc_labels"])
+    det0, lab0 = S.multiclass_nms_rotated(cu(g["mc_bboxes"]), cu(g["mc_scores"]) * 0, 0.05, 0.5, 300)
+    assert tuple(det0.shape) == tuple(g["mc_empty_det_shape"]) and tuple(lab0.shape) == tuple(g["mc_empty_lab_shape"])
+
+
+def test_batched_multiclass_nms_equals_per_image(rng):
+    import s2anet_amd as S
+    B, n, C = 3, 700, 15
+    boxes = np.stack([rand_rboxes(rng, n, span=260) for _ in range(B)])
+    scores = (rng.random((B, n, C)) ** 8).astype(np.float32)
+    scores[2] *= 0.01                                    # an image without candidates
+    for cap in (None, 4000):
+        dets, labels, counts = S.batched_multiclass_nms_rotated(cu(boxes), cu(scores), 0.05, 0.5, 200,
+                                                                max_candidates=cap)
+        for b in range(B):
+            rd, rl = oracle.multiclass_nms_rotated(boxes[b], scores[b], 0.05, 0.5, 200)
+            kb = int(counts[b])
+            assert kb == rd.shape[0]
+            assert np.array_equal(dets[b, :kb].cpu().numpy(), rd)
+            assert np.array_equal(labels[b, :kb].cpu().numpy().astype(np.float32), rl)
+            assert (labels[b, kb:] == -1).all()
+
+
+# ------------------------------------------------------------------ ORN
+def test_arf_and_pool(rng):
+    import s2anet_amd as S
+    g = golden("arf_small.npz")
+    for tag in ("s1", "s8"):
+        out = S.arf_forward(cu(g[f"w_{tag}"]), cu(g[f"idx_{tag}"]))
+        assert np.array_equal(out.cpu().numpy(), g[f"out_{tag}"])
+    w = rng.standard_normal((32, 256, 1, 3, 3)).astype(np.float32)
+    idx = oracle.arf_indices(1, 8, 3)
+    out = S.arf_forward(cu(w), cu(idx))
+    assert out.shape == (256, 256, 3, 3)
+    assert np.array_equal(out.cpu().numpy(), oracle.arf_forward(w, idx))
+    outh = S.arf_forward(cu(w).half(), cu(idx))
+    assert torch.equal(outh, out.half())
+    # ORConv2d caches the expansion at inference and follows weight updates
+    oc = S.ORConv2d(256, 32, kernel_size=3, padding=1, arf_config=(1, 8)).to(dev()).eval()
+    with torch.no_grad():
+        a = oc.rotate_arf()
+        assert oc.rotate_arf() is a
+        oc.weight.mul_(2.0)
+        assert torch.equal(oc.rotate_arf(), a * 2)
+        x = torch.randn(2, 256, 9, 11, device=dev())
+        y = oc(x)
+        assert y.shape == (2, 256, 9, 11)
+    x = rng.standard_normal((2, 64, 7, 9)).astype(np.float32)
+    x[0, 3, 2, 2] = np.nan
+    ref = oracle.rot_inv_pool(x, 8)
+    pool = S.RotationInvariantPooling(64, 8)
+    o = pool(cu(x)).cpu().numpy()
+    tref = torch.from_numpy(x).view(2, 8, 8, 7, 9).max(2)[0].numpy()
+    assert np.array_equal(o, tref, equal_nan=True)
+    m = ~np.isnan(tref)
+    assert np.array_equal(o[m], ref[m])
+    xc = cu(x).contiguous(memory_format=torch.channels_last)
+    oc_ = pool(xc)
+    assert oc_.is_contiguous(memory_format=torch.channels_last)
+    assert np.array_equal(oc_.cpu().numpy(), tref, equal_nan=True)
+    assert torch.equal(pool(cu(x).half()).float().nan_to_num(0), torch.from_numpy(x).half().view(2, 8, 8, 7, 9).max(2)[0].float().nan_to_num(0).to(dev()))
+
+
+# ------------------------------------------------------------------ head glue
+def test_glue_kernels():
+    from s2anet_amd import _lib
+    from s2anet_amd.alignconv import align_offsets
+    from s2anet_amd.head import delta2bbox_rotated, fam_refine_anchors
+    g = golden("head_glue.npz")
+    for key, clip in (("dec_clip_fam", 1e-6), ("dec_clip_odm", 16 / 1000)):
+        o = delta2bbox_rotated(cu(g["dec_anchors"]), cu(g["dec_deltas"]), clip).cpu().numpy()
+        assert np.allclose(o, g[key], rtol=1e-5, atol=1e-4), key
+    off = align_offsets(cu(g["off_anchors"])[None], (12, 20), 8)[0].cpu().numpy()
+    assert np.allclose(off, g["off_s8"], rtol=1e-5, atol=1e-4)
+    # fam refine == grid anchors + decode(clip 1e-6) of the NCHW prediction map
+    rng = np.random.default_rng(5)
+    pred = (rng.standard_normal((2, 5, 12, 20)) * 0.3).astype(np.float32)
+    ref = np.stack([oracle.delta2bbox_rotated(g["anchors_s8"], pred[b].transpose(1, 2, 0).reshape(-1, 5), 1e-6)
+                    for b in range(2)]).reshape(2, 12, 20, 5)
+    o = fam_refine_anchors(cu(pred), 8).cpu().numpy()
+    assert np.allclose(o, ref, rtol=1e-5, atol=1e-4)
+    o2 = fam_refine_anchors(cu(pred).contiguous(memory_format=torch.channels_last), 8).cpu().numpy()
+    assert np.array_equal(o, o2)
+
+
+# ------------------------------------------------------------------ deformable conv / AlignConv
+def _dcn_inputs(rng, B, C, H, W, O, sigma=1.5):
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((O, C, 3, 3)) * 0.05).astype(np.float32)
+    off = (rng.standard_normal((B, 18, H, W)) * sigma).astype(np.float32)
+    off[0, :, 0, 0] = 40.0
+    off[0, :, 1, 1] = -0.999
+    return x, w, off
+
+
+def test_dcn_generic_path_golden():
+    import s2anet_amd as S
+    g = golden("dcn_small.npz")                       # C=16: generic kernel
+    conv = S.DeformConv(16, 8, 3, padding=1).to(dev())
+    with torch.no_grad():
+        conv.weight.copy_(cu(g["weight"]))
+        out = conv(cu(g["x"]), cu(g["offset"])).cpu().numpy()
+    assert np.allclose(out, g["out_torch"], rtol=1e-4, atol=1e-4)
+    # stride / dilation / groups / deformable groups vs the oracle
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 8, 10, 9)).astype(np.float32)
+    w = rng.standard_normal((6, 4, 3, 3)).astype(np.float32)
+    off = (rng.standard_normal((2, 36, 4, 4)) * 1.2).astype(np.float32)
+    ref = oracle.deform_conv_forward(x, off, w, (2, 2), (1, 1), (2, 2), 2, 2)
+    out = S.deform_conv(cu(x), cu(off), cu(w), 2, 1, 2, 2, 2).cpu().numpy()
+    assert np.allclose(out, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 13, 17, 64), (2, 256, 16, 16, 256), (1, 32, 8, 8, 128), (3, 64, 5, 7, 320)])
+def test_dcn_mfma_f32_vs_oracle(rng, shape):
+    import s2anet_amd as S
+    B, C, H, W, O = shape
+    x, w, off = _dcn_inputs(rng, B, C, H, W, O)
+    ref = oracle.deform_conv_forward(x, off, w)
+    out = S.deform_conv(cu(x), cu(off), cu(w), 1, 1, 1, 1, 1).cpu().numpy()
+    err = np.abs(out - ref).max()
+    assert err < 1e-4, err                              # north-star tolerance, f32 path
+    # channels-last storage in and out: same numbers
+    xc = cu(x).contiguous(memory_format=torch.channels_last)
+    outc = S.deform_conv(xc, cu(off), cu(w), 1, 1, 1, 1, 1)
+    assert outc.is_contiguous(memory_format=torch.channels_last)
+    assert np.abs(outc.cpu().numpy() - ref).max() < 1e-4
+    # zero offsets == plain convolution
+    z = S.deform_conv(cu(x), cu(off) * 0, cu(w), 1, 1, 1, 1, 1)
+    zr = torch.nn.functional.conv2d(cu(x).double(), cu(w).double(), padding=1).float()
+    assert (z - zr).abs().max().item() < 1e-4
+
+
+def test_dcn_f16_vs_oracle(rng):
+    import s2anet_amd as S
+    B, C, H, W, O = 2, 128, 12, 10, 64
+    x, w, off = _dcn_inputs(rng, B, C, H, W, O)
+    xh, wh = cu(x).half(), cu(w).half()
+    ref = oracle.deform_conv_forward(xh.float().cpu().numpy(), off, wh.float().cpu().numpy(), f16_cols=True)
+    out = S.deform_conv(xh, cu(off), wh, 1, 1, 1, 1, 1)
+    assert out.dtype == torch.float16
+    err = (out.float().cpu().numpy() - ref)
+    assert np.abs(err).max() < 2e-2 and np.abs(err).mean() < 2e-3      # f16 output rounding
+    outc = S.deform_conv(xh.contiguous(memory_format=torch.channels_last), cu(off), wh, 1, 1, 1, 1, 1)
+    assert np.abs(outc.float().cpu().numpy() - ref).max() < 2e-2
+
+
+def test_alignconv_fused_vs_oracle(rng):
+    """anchors -> offsets (oracle numpy restatement of get_offset) -> deform conv oracle -> ReLU"""
+    import s2anet_amd as S
+    B, C, H, W, O, stride = 2, 64, 16, 20, 64, 8
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    anchors = np.stack([oracle.grid_anchors(H, W, stride) for _ in range(B)])
+    anchors[..., 0:2] += rng.normal(0, 4, anchors[..., 0:2].shape)
+    anchors[..., 2:4] = 32 * np.exp(rng.normal(0, 0.5, anchors[..., 2:4].shape))
+    anchors[..., 4] = rng.uniform(-np.pi / 4, 3 * np.pi / 4, anchors[..., 4].shape)
+    anchors = anchors.astype(np.float32)
+    ac = S.AlignConv(C, O, 3).to(dev())
+    ac.init_weights()
+    w = ac.deform_conv.weight.detach().cpu().numpy() * 5
+    with torch.no_grad():
+        ac.deform_conv.weight.mul_(5)
+        out = ac(cu(x), cu(anchors).view(B, H, W, 5), stride).cpu().numpy()
+        off_gpu = torch.stack([ac.get_offset(cu(anchors[b]), (H, W), stride) for b in range(B)])
+        unfused = torch.relu(ac.deform_conv(cu(x), off_gpu)).cpu().numpy()
+    offs = np.stack([oracle.align_offsets(anchors[b], H, W, stride) for b in range(B)])
+    assert np.allclose(off_gpu.cpu().numpy(), offs, rtol=1e-5, atol=1e-4)
+    ref = oracle.deform_conv_forward(x, offs, w, relu=True)
+    assert np.abs(out - ref).max() < 1e-4
+    assert np.abs(unfused - ref).max() < 1e-4
+    assert (out >= 0).all() and (out == 0).mean() > 0.2
