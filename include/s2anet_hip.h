@@ -163,8 +163,14 @@ typedef struct s2a_align_params {
   int64_t batch, channels, height, width, out_channels;
   float stride;
   int dtype, layout, relu;
+  int weight_packed; /* 1: `weight` is the output of s2a_dcn_pack_weight (cached by the caller at
+                        inference, the weights do not change between forwards) */
 } s2a_align_params;
 size_t s2a_align_conv_workspace_bytes(const s2a_align_params* p);
+/* weight[O,C,3,3] -> stage-major layout [9][C/KC][O][KC] (KC = 32 for f32, 64 for f16) that the
+ * fused kernel streams; same element count as the input. */
+int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int64_t channels, int dtype,
+                        void* packed, s2a_stream_t stream);
 int s2a_align_conv_forward(const void* x, const float* anchors, const void* weight, void* out,
                            const s2a_align_params* p, void* workspace, size_t workspace_bytes,
                            s2a_stream_t stream);

@@ -32,7 +32,7 @@ class DcnParams(ctypes.Structure):
 class AlignParams(ctypes.Structure):
     _fields_ = [("batch", c_i64), ("channels", c_i64), ("height", c_i64), ("width", c_i64),
                 ("out_channels", c_i64), ("stride", c_f32), ("dtype", c_int), ("layout", c_int),
-                ("relu", c_int)]
+                ("relu", c_int), ("weight_packed", c_int)]
 
 
 # every symbol include/s2anet_hip.h declares: name -> (restype, argtypes)
@@ -60,6 +60,7 @@ SYMBOLS = {
     "s2a_align_conv_workspace_bytes": (c_sz, [ctypes.POINTER(AlignParams)]),
     "s2a_align_conv_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AlignParams), c_vp,
                                        c_sz, c_vp]),
+    "s2a_dcn_pack_weight": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
     "s2a_delta2bbox_rotated": (c_int, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
     "s2a_fam_refine_anchors": (c_int, [c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_int, c_int,
                                        c_vp, c_vp]),

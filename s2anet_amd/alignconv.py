@@ -28,8 +28,20 @@ def align_offsets(anchors, featmap_size, stride, kernel_size=3):
     return out
 
 
-def align_conv_forward(x, anchors, weight, stride, relu=True):
-    """fused AlignConv: x[B,C,H,W] (NCHW or channels_last), anchors[B,H,W,5] f32, weight[O,C,3,3]"""
+def pack_weight(weight, dtype):
+    """weight[O,C,3,3] -> the stage-major layout the fused kernel streams (s2a_dcn_pack_weight)"""
+    _lib.require_cuda(weight)
+    w = weight.detach().to(dtype).contiguous()
+    out = torch.empty_like(w)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().s2a_dcn_pack_weight(_lib.ptr(w), w.shape[0], w.shape[1], _lib.dtype_code(w),
+                                                  _lib.ptr(out), _lib.stream_ptr(w.device)))
+    return out
+
+
+def align_conv_forward(x, anchors, weight, stride, relu=True, packed=False):
+    """fused AlignConv: x[B,C,H,W] (NCHW or channels_last), anchors[B,H,W,5] f32, weight[O,C,3,3]
+    (or, with packed=True, the output of pack_weight)"""
     _lib.require_cuda(x, anchors, weight)
     if x.dim() != 4:
         raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(x.dim()))
@@ -44,7 +56,7 @@ def align_conv_forward(x, anchors, weight, stride, relu=True):
     out = torch.empty((B, O, H, W), dtype=xx.dtype, device=xx.device,
                       memory_format=torch.channels_last if nhwc else torch.contiguous_format)
     p = _lib.AlignParams(B, C, H, W, O, float(stride), _lib.dtype_code(xx),
-                         _lib.LAYOUT_NHWC if nhwc else _lib.LAYOUT_NCHW, int(bool(relu)))
+                         _lib.LAYOUT_NHWC if nhwc else _lib.LAYOUT_NCHW, int(bool(relu)), int(bool(packed)))
     L = _lib.lib()
     with torch.cuda.device(xx.device):
         ws = _lib.workspace(L.s2a_align_conv_workspace_bytes(p), xx.device, "dcn")
@@ -61,6 +73,15 @@ class AlignConv(nn.Module):
         self.deform_conv = DeformConv(in_channels, out_channels, kernel_size=self.kernel_size,
                                       padding=self.padding, deformable_groups=deformable_groups)
         self.relu = nn.ReLU(inplace=True)
+        self._packed = None
+
+    def packed_weight(self, dtype):
+        """inference-time cache of the packed filter (invalidated when the parameter changes)"""
+        w = self.deform_conv.weight
+        key = (w._version, w.data_ptr(), dtype, w.device)
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, pack_weight(w, dtype))
+        return self._packed[1]
 
     def init_weights(self):
         nn.init.normal_(self.deform_conv.weight, 0, 0.01)   # alignconv.py:25-26
@@ -79,6 +100,8 @@ class AlignConv(nn.Module):
     def forward(self, x, anchors, stride):
         num_imgs, H, W = anchors.shape[:3]
         if self.fused_ok(x):
+            if not (torch.is_grad_enabled() and self.deform_conv.weight.requires_grad):
+                return align_conv_forward(x, anchors, self.packed_weight(x.dtype), stride, relu=True, packed=True)
             return align_conv_forward(x, anchors, self.deform_conv.weight, stride, relu=True)
         offset = align_offsets(anchors.reshape(num_imgs, H * W, 5), (H, W), stride, self.kernel_size[0])
         return self.relu(self.deform_conv(x, offset))

@@ -465,10 +465,12 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
 template <typename T>
 int run_fast(const void* input, const float* src, bool from_anchors, const void* weight, void* output,
              int64_t B, int C, int H, int W, int O, int layout, float stride, int relu, void* ws,
-             size_t ws_bytes, hipStream_t st) {
+             size_t ws_bytes, hipStream_t st, bool weight_packed = false) {
   constexpr int KC = Traits<T>::KC;
+  S2A_CHECK_ARG(((uintptr_t)input % 16) == 0 && ((uintptr_t)output % 16) == 0 && ((uintptr_t)weight % 16) == 0 &&
+                ((uintptr_t)ws % 16) == 0, "deform_conv: tensors must be 16-byte aligned");
   Carver cv(ws, ws_bytes);
-  T* wp = cv.take<T>((size_t)O * C * 9);
+  T* wp = weight_packed ? const_cast<T*>((const T*)weight) : cv.take<T>((size_t)O * C * 9);
   T* xn = nullptr;
   if (layout == S2A_LAYOUT_NCHW) xn = cv.take<T>((size_t)B * C * H * W);
   if (!wp || (layout == S2A_LAYOUT_NCHW && !xn)) {
@@ -476,7 +478,8 @@ int run_fast(const void* input, const float* src, bool from_anchors, const void*
     return S2A_EWORKSPACE;
   }
   const int64_t wtot = (int64_t)O * C * 9;
-  k_pack_weight<T><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const T*)weight, O, C, KC, wp);
+  if (!weight_packed)
+    k_pack_weight<T><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const T*)weight, O, C, KC, wp);
   const T* x_nhwc = (const T*)input;
   if (layout == S2A_LAYOUT_NCHW) {
     int64_t HW = (int64_t)H * W;
@@ -571,8 +574,25 @@ extern "C" int s2a_align_conv_forward(const void* x, const float* anchors, const
   if (p.dtype == S2A_DTYPE_F32)
     return run_fast<float>(x, anchors, true, weight, out, p.batch, (int)p.channels, (int)p.height,
                            (int)p.width, (int)p.out_channels, p.layout, p.stride, p.relu, workspace,
-                           workspace_bytes, st);
+                           workspace_bytes, st, p.weight_packed != 0);
   return run_fast<_Float16>(x, anchors, true, weight, out, p.batch, (int)p.channels, (int)p.height,
                             (int)p.width, (int)p.out_channels, p.layout, p.stride, p.relu, workspace,
-                            workspace_bytes, st);
+                            workspace_bytes, st, p.weight_packed != 0);
+}
+
+extern "C" int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int64_t channels,
+                                   int dtype, void* packed, s2a_stream_t stream) {
+  S2A_CHECK_ARG(dtype == S2A_DTYPE_F32 || dtype == S2A_DTYPE_F16, "dcn_pack_weight: dtype");
+  const int kc = dtype == S2A_DTYPE_F32 ? 32 : 64;
+  S2A_CHECK_ARG(out_channels > 0 && channels > 0 && channels % kc == 0,
+                "dcn_pack_weight: channels must be a multiple of %d", kc);
+  S2A_CHECK_ARG(weight && packed, "dcn_pack_weight: NULL tensor");
+  const int64_t wtot = out_channels * channels * 9;
+  hipStream_t st = as_stream(stream);
+  if (dtype == S2A_DTYPE_F32)
+    k_pack_weight<float><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const float*)weight, (int)out_channels, (int)channels, kc, (float*)packed);
+  else
+    k_pack_weight<_Float16><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, kc, (_Float16*)packed);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
 }

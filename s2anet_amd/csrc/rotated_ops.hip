@@ -453,8 +453,9 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
         unsigned long long r = s_remv[b];
         uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
         for (int t = 0; t < 64; t++) {
-          unsigned long long dt = ((unsigned long long)__builtin_amdgcn_readlane(dhi, t) << 32) |
-                                  (unsigned long long)__builtin_amdgcn_readlane(dlo, t);
+          // readlane returns a signed int: go through uint32_t or bit 31 sign-extends
+          unsigned long long dt = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dhi, t) << 32) |
+                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dlo, t);
           if (!((r >> t) & 1ull)) r |= dt;
         }
         unsigned long long validmask = (ns - b * 64 >= 64) ? ~0ull : ((1ull << (ns - b * 64)) - 1ull);
@@ -749,7 +750,7 @@ using namespace s2a;
 extern "C" size_t s2a_box_iou_rotated_workspace_bytes(int64_t n, int64_t m) {
   if (n <= 0 || m <= 0) return 256;
   unsigned long long pairs = (unsigned long long)n * (unsigned long long)m;
-  unsigned long long cap = std::min<unsigned long long>(pairs, std::max<unsigned long long>(kIouQueueCap, (unsigned long long)m * 256));
+  unsigned long long cap = std::max<unsigned long long>(std::min<unsigned long long>(pairs, kIouQueueCap), (unsigned long long)m * 256);
   return align_up((size_t)(n + m) * sizeof(PreBox)) * 2 + align_up(cap * sizeof(uint2)) + 4096;
 }
 

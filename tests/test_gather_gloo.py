@@ -1,0 +1,68 @@
+"""CPU, world_size 2, gloo: the detection all-gather of the data-parallel path.
+Gathered result must equal the concatenation of the per-rank outputs."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from s2anet_amd.gather import DetectionGather, pack_detections, shard_range, unpack_detections
+
+
+def make_rank_output(rank, B, K):
+    g = torch.Generator().manual_seed(100 + rank)
+    counts = torch.randint(0, K + 1, (B,), generator=g, dtype=torch.int32)
+    dets = torch.rand(B, K, 6, generator=g)
+    labels = torch.randint(0, 15, (B, K), generator=g, dtype=torch.int32)
+    for b in range(B):
+        dets[b, counts[b]:] = 0
+        labels[b, counts[b]:] = -1
+    return dets, labels, counts
+
+
+def worker(rank, world, port, B, K, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gather = DetectionGather(world, B, K, torch.device("cpu"))
+    d, l, c = gather(*make_rank_output(rank, B, K))
+    q.put((rank, d.clone(), l.clone(), c.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_batch():
+    for gb, w in ((64, 8), (10, 4), (3, 8)):
+        spans = [shard_range(gb, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == gb
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_pack_roundtrip():
+    d, l, c = make_rank_output(0, 3, 17)
+    d2, l2, c2 = unpack_detections(pack_detections(d, l, c), 17)
+    assert torch.equal(d, d2) and torch.equal(l, l2) and torch.equal(c, c2)
+
+
+def test_all_gather_equals_concatenation():
+    world, B, K = 2, 3, 50
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, B, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = [make_rank_output(r, B, K) for r in range(world)]
+    ed = torch.cat([e[0] for e in exp])
+    el = torch.cat([e[1] for e in exp])
+    ec = torch.cat([e[2] for e in exp])
+    for _, d, l, c in got:
+        assert torch.equal(d, ed) and torch.equal(l, el) and torch.equal(c, ec)

@@ -162,7 +162,7 @@ def test_batched_multiclass_nms_equals_per_image(rng):
     boxes = np.stack([rand_rboxes(rng, n, span=260) for _ in range(B)])
     scores = (rng.random((B, n, C)) ** 8).astype(np.float32)
     scores[2] *= 0.01                                    # an image without candidates
-    for cap in (None, 4000):
+    for cap in (None, 8000):      # 8000 >= all candidates of the batch: lossless
         dets, labels, counts = S.batched_multiclass_nms_rotated(cu(boxes), cu(scores), 0.05, 0.5, 200,
                                                                 max_candidates=cap)
         for b in range(B):
