@@ -55,22 +55,26 @@ def parse():
     return ap.parse_args()
 
 
-def calibrate_cls_bias(model, imgs, target_per_chip):
-    """Random weights give score 0.01 everywhere (bias init -4.595, head.py:232) and no detection.
-    Shift odm_cls_head.bias so that about `target_per_chip` (box, class) scores of the per-level
-    top-k candidates exceed the 0.05 threshold — the post-processing then does real work."""
+def calibrate_cls_bias(model, imgs, target_per_chip, logit_std=1.5):
+    """Random N(0,0.01) weights give the same score 0.01 everywhere (bias init -4.595, head.py:232)
+    and no detection.  Give the synthetic classifier a realistic spread (scale odm_cls_head.weight so
+    the logits have std `logit_std`) and shift its bias so that about `target_per_chip` (box, class)
+    scores of the per-level top-k candidates exceed the 0.05 threshold — the post-processing then
+    does real work on distinct scores."""
+    head = model.head
     with torch.no_grad():
         x = imgs.to(next(model.parameters()).dtype).div_(255.0)
         p = model.features_to_pred(x)
-        _, scores = model.head.candidates(p)               # [B,n,C] sigmoid
-        logits = torch.logit(scores.float().clamp(1e-6, 1 - 1e-6)).reshape(-1)
-        frac = min(max(target_per_chip / (scores.shape[1] * scores.shape[2]), 1e-5), 0.999)
-        k = max(1, int(round(frac * logits.numel())))
-        q = torch.topk(logits, k)[0][-1].item()
-        shift = math.log(0.05 / 0.95) - q
-        model.head.odm_cls_head.bias.add_(shift)
+        raw = torch.cat([l.float().reshape(-1) for l in p[2]])
+        head.odm_cls_head.weight.mul_(logit_std / max(raw.std().item(), 1e-6))
         p = model.features_to_pred(x)
-        _, scores = model.head.candidates(p)
+        _, logits = head.candidates(p, raw_logits=True)     # [B,n,C] pre-sigmoid, f32
+        frac = min(max(target_per_chip / (logits.shape[1] * logits.shape[2]), 1e-5), 0.999)
+        k = max(1, int(round(frac * logits.numel())))
+        q = torch.topk(logits.reshape(-1), k)[0][-1].item()
+        head.odm_cls_head.bias.add_(math.log(0.05 / 0.95) - q)   # uniform shift: ranking unchanged
+        p = model.features_to_pred(x)
+        _, scores = head.candidates(p)
         got = (scores > 0.05).sum().item() / scores.shape[0]
     return got
 
@@ -135,8 +139,13 @@ def cpu_baseline(seed, candidates):
         if mod.__class__.__name__ == "BottleNeck":
             mod.bn3.weight.data.fill_(0.25)
     img = torch.randint(0, 256, (1, 3, CHIP, CHIP), dtype=torch.uint8)
-    ncores = os.cpu_count() or 1
+    ncores = min(os.cpu_count() or 1, 16)              # the GPU box's CPU share for one GPU
     torch.set_num_threads(ncores)
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(ncores)
+    except OSError:
+        pass
     ref_nms = ref.ml_nms_rotated()
     h = m.head
     t0 = time.time()

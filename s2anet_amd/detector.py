@@ -178,5 +178,10 @@ def build_synthetic_detector(num_classes=15, seed=1234, dtype=torch.float16, dev
         fold_batchnorm(m)
     m = m.to(device=device, dtype=dtype)
     if channels_last:
-        m = m.to(memory_format=torch.channels_last)
+        # 4-D conv filters only (ORConv2d keeps its 5-D filter bank; its cached ARF expansion is
+        # converted in ORConv2d.rotate_arf)
+        for mod in m.modules():
+            if isinstance(mod, nn.Conv2d) and mod.weight.dim() == 4:
+                mod.weight.data = mod.weight.data.contiguous(memory_format=torch.channels_last)
+        m.head.or_conv.channels_last = True
     return m

@@ -133,7 +133,7 @@ class S2ANetHead(nn.Module):
         return results
 
     # ------------------------------------------------------------------ decode + NMS, batched
-    def candidates(self, p):
+    def candidates(self, p, raw_logits=False):
         """per-level sigmoid + top-k (head.py:697-705), levels concatenated (head.py:712-714),
         final decode (head.py:717).  -> bboxes[B,n,5] f32, scores[B,n,C] f32 with n <= 5344"""
         odm_cls, odm_bbox, anchors = p[2], p[3], p[4]
@@ -141,7 +141,8 @@ class S2ANetHead(nn.Module):
         sc_l, bb_l, an_l = [], [], []
         for cls, reg, anc in zip(odm_cls, odm_bbox, anchors):
             B = cls.shape[0]
-            s = cls.detach().permute(0, 2, 3, 1).reshape(B, -1, self.num_classes).sigmoid()
+            s = cls.detach().permute(0, 2, 3, 1).reshape(B, -1, self.num_classes)
+            s = s.float() if raw_logits else s.sigmoid()   # raw_logits: calibration only (same ranking)
             d = reg.detach().permute(0, 2, 3, 1).reshape(B, -1, 5)
             a = anc.reshape(B, -1, 5)
             if k > 0 and s.shape[1] > k:

@@ -108,7 +108,10 @@ class ORConv2d(nn.Conv2d):
         if self.training or torch.is_grad_enabled() and w.requires_grad:
             return active_rotating_filter(w, self.indices)
         if self._arf_cache is None or self._arf_cache[0] != key:
-            self._arf_cache = (key, arf_forward(w.detach(), self.indices))
+            e = arf_forward(w.detach(), self.indices)
+            if getattr(self, "channels_last", False):
+                e = e.contiguous(memory_format=torch.channels_last)
+            self._arf_cache = (key, e)
         return self._arf_cache[1]
 
     def forward(self, input):
