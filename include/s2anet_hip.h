@@ -190,6 +190,13 @@ int s2a_fam_refine_anchors(const void* bbox_pred, int64_t batch, int64_t height,
                            float stride, float anchor_scale, int dtype, int layout, float* refined,
                            s2a_stream_t stream);
 
+/* Convolution epilogue for the conv layers of the head/carrier that MIOpen runs without fusion:
+ * y[positions, channels] (channels-last storage) = act(y + bias[c] (+ residual)), in place.
+ * Replaces the bias add / residual add / ReLU passes that follow every nn.Conv2d of
+ * models/head.py:163-222 and models/backbone.py:37-83 (same arithmetic, one pass over HBM). */
+int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual, int64_t positions,
+                      int64_t channels, int dtype, int relu, s2a_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

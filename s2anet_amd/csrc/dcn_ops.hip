@@ -189,8 +189,39 @@ __device__ __forceinline__ f16x8 blend<_Float16>(const f16x8 (&v)[4], const floa
   return r;
 }
 
+// f16 blend in packed half arithmetic (v_pk_mul/v_pk_fma_f16): the reference's half path
+// evaluates w1*v1 + w2*v2 + w3*v3 + w4*v4 in scalar_t = half as well (kernel.cu:110-112)
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ f16x8 blend_pk(const f16x8 (&v)[4], const float (&w)[4]) {
+  f16x8 r;
+  f16x2 w0 = {(_Float16)w[0], (_Float16)w[0]}, w1 = {(_Float16)w[1], (_Float16)w[1]};
+  f16x2 w2 = {(_Float16)w[2], (_Float16)w[2]}, w3 = {(_Float16)w[3], (_Float16)w[3]};
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    f16x2 a0 = {v[0][2 * e], v[0][2 * e + 1]}, a1 = {v[1][2 * e], v[1][2 * e + 1]};
+    f16x2 a2 = {v[2][2 * e], v[2][2 * e + 1]}, a3 = {v[3][2 * e], v[3][2 * e + 1]};
+    f16x2 acc = w0 * a0;
+    acc = w1 * a1 + acc;
+    acc = w2 * a2 + acc;
+    acc = w3 * a3 + acc;
+    r[2 * e] = acc[0];
+    r[2 * e + 1] = acc[1];
+  }
+  return r;
+}
+
+// XCD-aware tile order: blockIdx round-robins over the 8 XCDs (private L2 each); give every XCD
+// a contiguous run of position tiles so neighbouring tiles (which sample overlapping input rows)
+// share one L2.  Bijective for any tile count (cdna guide T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned n) {
+  const unsigned q = n / 8, r = n % 8, x = bid % 8;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+}
+
 // SRC: 0 = offset tensor [B,18,H,W] f32, 1 = refined anchors [B,H,W,5] f32
-template <typename T, bool OUT_NHWC, int SRC>
+// NPOS: output positions per workgroup (64: more workgroups for small inputs; 128: the weight tile
+// is amortised over twice the positions)
+template <typename T, bool OUT_NHWC, int SRC, int NPOS>
 __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,       // NHWC
                                                      const float* __restrict__ src,  // offsets | anchors
                                                      const T* __restrict__ wp,       // packed weights
@@ -198,24 +229,26 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
                                                      int W, int O, float stride, int relu) {
   constexpr int KC = Traits<T>::KC;
   constexpr int VEC = Traits<T>::VEC;
+  constexpr int NT = NPOS / 32;    // 32-wide position tiles per wave
+  constexpr int ITEMS = NPOS / 32; // (position, 16-byte channel group) items per thread
   using V = typename Vec16<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [ taps 64*9*32 B | A0 | B0 | A1 | B1 ]
+  // [ taps NPOS*9*32 B | A0 | B0 | A1 | B1 ]
   Tap* s_tab = reinterpret_cast<Tap*>(smem);
-  constexpr int kTabBytes = kPos * 9 * 32;
-  constexpr int kABytes = kMaxO * kRowBytes, kBBytes = kPos * kRowBytes;
+  constexpr int kTabBytes = NPOS * 9 * 32;
+  constexpr int kABytes = kMaxO * kRowBytes, kBBytes = NPOS * kRowBytes;
   char* s_buf = smem + kTabBytes;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t HW = (int64_t)H * W;
-  const int64_t g0 = (int64_t)blockIdx.x * kPos;
+  const int64_t g0 = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * NPOS;
   const int o0 = blockIdx.y * kMaxO;
   const int Oloc = min(kMaxO, O - o0);
   const int CC = C / KC;
   const int nstage = 9 * CC;
 
   // ---- sampling table for this tile
-  for (int e = tid; e < kPos * 9; e += 256) {
+  for (int e = tid; e < NPOS * 9; e += 256) {
     int pl = e / 9, t = e % 9;
     int64_t g = g0 + pl;
     Tap tp;
@@ -246,23 +279,23 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
   }
   __syncthreads();
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NT];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < NT; b++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   // per-thread staging registers
-  V cv[2][4];
-  float cw[2][4];
+  V cv[ITEMS][4];
+  float cw[ITEMS][4];
   V av[8];
 
   auto issue = [&](int s) {
     const int t = s / CC, cc = s % CC;
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < ITEMS; it++) {
       int item = tid + 256 * it;
       int pl = item >> 3, q = item & 7;
       const Tap tp = s_tab[pl * 9 + t];
@@ -284,10 +317,13 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
     char* A = s_buf + buf * (kABytes + kBBytes);
     char* Bm = A + kABytes;
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < ITEMS; it++) {
       int item = tid + 256 * it;
       int pl = item >> 3, q = item & 7;
-      *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend<T>(cv[it], cw[it]);
+      if constexpr (sizeof(T) == 2)
+        *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_pk(cv[it], cw[it]);
+      else
+        *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend<T>(cv[it], cw[it]);
     }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -312,21 +348,20 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
       const char* prow = Bm + (lane & 31) * kRowBytes + (lane >> 5) * 16;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
-        V wf[2], pf[2];
+        V wf[2], pf[NT];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          wf[h] = *reinterpret_cast<const V*>(wrow + h * 32 * kRowBytes + kk * 32);
-          pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
-        }
+        for (int h = 0; h < 2; h++) wf[h] = *reinterpret_cast<const V*>(wrow + h * 32 * kRowBytes + kk * 32);
+#pragma unroll
+        for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
           for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
-              for (int b = 0; b < 2; b++) {
+              for (int b = 0; b < NT; b++) {
                 if constexpr (OUT_NHWC)
-                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[a][j], wf[b][j], acc[a][b], 0, 0, 0);
+                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[b][j], wf[a][j], acc[a][b], 0, 0, 0);
                 else
                   acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[a][j], pf[b][j], acc[a][b], 0, 0, 0);
               }
@@ -334,9 +369,9 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
 #pragma unroll
           for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
+            for (int b = 0; b < NT; b++) {
               if constexpr (OUT_NHWC)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[a], wf[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[b], wf[a], acc[a][b], 0, 0, 0);
               else
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[a], pf[b], acc[a][b], 0, 0, 0);
             }
@@ -348,19 +383,21 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
   }
 
   if (!wave_active) return;
-  // ---- epilogue: ReLU + store.  acc[a][b][r]: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+  // ---- epilogue: ReLU + store.  acc[a][b] = (out-channel tile a, position tile b);
+  // MFMA D layout: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < NT; b++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         float v = acc[a][b][r];
         if (relu) v = fmaxf(v, 0.f);
         int rowi = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if constexpr (OUT_NHWC) {
-          int64_t g = g0 + 32 * a + rowi;
-          int och = o0 + wave * 64 + 32 * b + (lane & 31);
+          // operands swapped: rows = positions, columns = out channels (128 B runs along channels)
+          int64_t g = g0 + 32 * b + rowi;
+          int och = o0 + wave * 64 + 32 * a + (lane & 31);
           if (g < Ntot) out[g * O + och] = (T)v;
         } else {
           int och = o0 + wave * 64 + 32 * a + rowi;
@@ -373,7 +410,8 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
       }
 }
 
-constexpr int kMfmaLds = kPos * 9 * 32 + 2 * (kMaxO + kPos) * kRowBytes;  // 110592 B
+template <int NPOS>
+constexpr int mfma_lds_bytes() { return NPOS * 9 * 32 + 2 * (kMaxO + NPOS) * kRowBytes; }  // 110592 / 147456
 
 // ------------------------------------------------------------------ generic fallback
 // Any stride / padding / dilation / groups / deformable groups / channel count, NCHW only.
@@ -444,19 +482,24 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
                 bool out_nhwc, int64_t B, int C, int H, int W, int O, float stride, int relu,
                 hipStream_t st) {
   const int64_t Ntot = B * (int64_t)H * W;
-  dim3 grid((unsigned)((Ntot + kPos - 1) / kPos), (unsigned)((O + kMaxO - 1) / kMaxO));
-#define S2A_DCN_LAUNCH(NHWC, SRC)                                                                 \
+  // 128-position tiles once they still give every CU >= 2 workgroups; else 64
+  const bool big = (Ntot + 127) / 128 >= 512;
+#define S2A_DCN_LAUNCH(NHWC, SRC, NPOS)                                                           \
   do {                                                                                            \
-    auto kern = k_dcn_mfma<T, NHWC, SRC>;                                                         \
+    auto kern = k_dcn_mfma<T, NHWC, SRC, NPOS>;                                                   \
+    constexpr int lds = mfma_lds_bytes<NPOS>();                                                   \
+    dim3 grid((unsigned)((Ntot + NPOS - 1) / NPOS), (unsigned)((O + kMaxO - 1) / kMaxO));         \
     S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));           \
-    kern<<<grid, 256, kMfmaLds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu);      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));                \
+    kern<<<grid, 256, lds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu);           \
   } while (0)
+#define S2A_DCN_PICK(NHWC, SRC) do { if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
   if (out_nhwc) {
-    if (from_anchors) S2A_DCN_LAUNCH(true, 1); else S2A_DCN_LAUNCH(true, 0);
+    if (from_anchors) S2A_DCN_PICK(true, 1); else S2A_DCN_PICK(true, 0);
   } else {
-    if (from_anchors) S2A_DCN_LAUNCH(false, 1); else S2A_DCN_LAUNCH(false, 0);
+    if (from_anchors) S2A_DCN_PICK(false, 1); else S2A_DCN_PICK(false, 0);
   }
+#undef S2A_DCN_PICK
 #undef S2A_DCN_LAUNCH
   S2A_LAUNCH_CHECK();
   return S2A_OK;

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused import FusedConv2d
 from .head import S2ANetHead
 
 
@@ -33,6 +34,11 @@ class BottleNeck(nn.Module):
 
     def forward(self, x):
         residual = x
+        if isinstance(self.conv3, FusedConv2d):           # BN folded, epilogues fused (inference)
+            out = self.conv2(self.conv1(x))
+            if self.downsample is not None:
+                residual = self.downsample(x)
+            return self.conv3(out, residual)              # relu(conv3 + bias + residual) in one pass
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
@@ -153,13 +159,29 @@ def fold_batchnorm(model):
 
     for mod in model.modules():
         if isinstance(mod, BottleNeck):
-            mod.conv1, mod.bn1 = fold(mod.conv1, mod.bn1), nn.Identity()
-            mod.conv2, mod.bn2 = fold(mod.conv2, mod.bn2), nn.Identity()
-            mod.conv3, mod.bn3 = fold(mod.conv3, mod.bn3), nn.Identity()
+            mod.conv1, mod.bn1 = FusedConv2d.from_conv(fold(mod.conv1, mod.bn1), relu=True), nn.Identity()
+            mod.conv2, mod.bn2 = FusedConv2d.from_conv(fold(mod.conv2, mod.bn2), relu=True), nn.Identity()
+            mod.conv3, mod.bn3 = FusedConv2d.from_conv(fold(mod.conv3, mod.bn3), relu=True), nn.Identity()
             if mod.downsample is not None:
-                mod.downsample = nn.Sequential(fold(mod.downsample[0], mod.downsample[1]))
+                mod.downsample = nn.Sequential(FusedConv2d.from_conv(fold(mod.downsample[0], mod.downsample[1])))
     stem = model.backbone.backbone[0]
-    model.backbone.backbone[0] = nn.Sequential(fold(stem[0], stem[1]), stem[2])
+    model.backbone.backbone[0] = nn.Sequential(FusedConv2d.from_conv(fold(stem[0], stem[1]), relu=True), nn.Identity())
+    return model
+
+
+def fuse_epilogues(model):
+    """swap every remaining biased nn.Conv2d (FPN, head towers, prediction heads) for FusedConv2d;
+    conv+ReLU pairs inside nn.Sequential collapse into one module (names/params unchanged)"""
+    from .orn import ORConv2d
+    for parent in list(model.modules()):
+        if isinstance(parent, nn.Sequential) and len(parent) == 2 and type(parent[0]) is nn.Conv2d \
+                and isinstance(parent[1], nn.ReLU) and parent[0].bias is not None:
+            parent[0] = FusedConv2d.from_conv(parent[0], relu=True)
+            parent[1] = nn.Identity()
+    for parent in list(model.modules()):
+        for name, child in list(parent.named_children()):
+            if type(child) is nn.Conv2d and child.bias is not None and not isinstance(child, ORConv2d):
+                setattr(parent, name, FusedConv2d.from_conv(child, relu=False))
     return model
 
 
@@ -176,12 +198,13 @@ def build_synthetic_detector(num_classes=15, seed=1234, dtype=torch.float16, dev
     m.eval()
     if fold_bn:
         fold_batchnorm(m)
+        fuse_epilogues(m)
     m = m.to(device=device, dtype=dtype)
     if channels_last:
         # 4-D conv filters only (ORConv2d keeps its 5-D filter bank; its cached ARF expansion is
         # converted in ORConv2d.rotate_arf)
         for mod in m.modules():
-            if isinstance(mod, nn.Conv2d) and mod.weight.dim() == 4:
+            if isinstance(mod, nn.Conv2d) and mod.weight.dim() == 4 and mod.weight.shape[1] >= 8:
                 mod.weight.data = mod.weight.data.contiguous(memory_format=torch.channels_last)
         m.head.or_conv.channels_last = True
     return m

@@ -1,0 +1,55 @@
+"""Convolution with a fused epilogue: MIOpen runs the convolution itself (the carrier, SURVEY.md
+#13), the bias / residual / ReLU that follow it are ONE in-place HIP pass (s2a_bias_act_nhwc)
+instead of up to three stock elementwise kernels.  Parameter names stay ``weight`` / ``bias`` so
+reference state_dicts load unchanged."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def bias_act_(y, bias, residual=None, relu=False):
+    """in place: y = act(y + bias[c] (+ residual)); y must be channels-last contiguous"""
+    _lib.require_cuda(y, bias, residual)
+    B, C, H, W = y.shape
+    ok = (y.is_contiguous(memory_format=torch.channels_last) and
+          C % (8 if y.dtype == torch.float16 else 4) == 0 and y.dtype in (torch.float16, torch.float32) and
+          (residual is None or (residual.shape == y.shape and residual.dtype == y.dtype and
+                                residual.is_contiguous(memory_format=torch.channels_last))))
+    if not ok:      # odd channel count / NCHW storage: stock ops (still on the GPU)
+        y = y + bias.view(1, -1, 1, 1).to(y.dtype)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    b = bias.to(y.dtype).contiguous()
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.lib().s2a_bias_act_nhwc(_lib.ptr(y), _lib.ptr(b), _lib.ptr(residual), B * H * W, C,
+                                                _lib.dtype_code(y), int(bool(relu)), _lib.stream_ptr(y.device)))
+    return y
+
+
+class FusedConv2d(nn.Conv2d):
+    """nn.Conv2d + (bias, optional residual, optional ReLU) epilogue in one pass"""
+
+    def __init__(self, *args, relu=False, **kw):
+        super().__init__(*args, **kw)
+        self.fuse_relu = relu
+
+    @classmethod
+    def from_conv(cls, conv, relu=False):
+        m = cls(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                conv.dilation, conv.groups, bias=conv.bias is not None, relu=relu)
+        m = m.to(conv.weight.device, conv.weight.dtype)
+        m.weight = conv.weight
+        m.bias = conv.bias
+        return m
+
+    def forward(self, x, residual=None):
+        if (not x.is_cuda) or self.bias is None:
+            y = super().forward(x)
+            if residual is not None:
+                y = y + residual
+            return F.relu(y) if self.fuse_relu else y
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+        return bias_act_(y, self.bias, residual, self.fuse_relu)

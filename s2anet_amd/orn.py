@@ -115,8 +115,12 @@ class ORConv2d(nn.Conv2d):
         return self._arf_cache[1]
 
     def forward(self, input):
-        return F.conv2d(input, self.rotate_arf(), self.bias, self.stride, self.padding,
-                        self.dilation, self.groups)
+        w = self.rotate_arf()
+        if input.is_cuda and self.bias is not None and not torch.is_grad_enabled():
+            from .fused import bias_act_
+            y = F.conv2d(input, w, None, self.stride, self.padding, self.dilation, self.groups)
+            return bias_act_(y, self.bias, None, False)      # one-pass bias epilogue
+        return F.conv2d(input, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 
 def rot_inv_pool(x, n_orientation=8):

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Per-op timings of the hot-path kernels on one MI355X (BASELINE.json configs 1, 2, 5 and the
+small ops).  HIP events on torch's current stream (the stream the C ABI launches on)."""
+import argparse, json, math, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import s2anet_amd as S
+from s2anet_amd.alignconv import align_conv_forward, pack_weight
+
+dev = torch.device("cuda:0")
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+def rboxes(rng, n, span=1024.0):
+    b = np.empty((n, 5), np.float32)
+    b[:, :2] = rng.uniform(0, span, (n, 2)); b[:, 2:4] = rng.uniform(4, 100, (n, 2)); b[:, 4] = rng.uniform(-np.pi/4, 3*np.pi/4, n)
+    return b
+
+def alignconv(batch, dtype, H=128, W=128, C=256, O=256, stride=8):
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(batch, C, H, W, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    anc = torch.zeros(batch, H, W, 5)
+    anc[..., 0] = xs * stride + 0.5*(stride-1) + torch.randn(batch, H, W, generator=g) * 4
+    anc[..., 1] = ys * stride + 0.5*(stride-1) + torch.randn(batch, H, W, generator=g) * 4
+    anc[..., 2:4] = 4 * stride * torch.exp(torch.randn(batch, H, W, 2, generator=g) * 0.5)
+    anc[..., 4] = (torch.rand(batch, H, W, generator=g) - 0.25) * math.pi
+    anc = anc.to(dev)
+    w = (torch.randn(O, C, 3, 3, generator=g) * 0.01).to(dev, dtype)
+    wp = pack_weight(w, dtype)
+    sec = timeit(lambda: align_conv_forward(x, anc, wp, stride, relu=True, packed=True))
+    flops = 2.0 * O * C * 9 * batch * H * W
+    es = 2 if dtype == torch.float16 else 4
+    byts = batch*H*W*(C+O)*es + O*C*9*es + batch*H*W*20
+    peak = 2500.0 if es == 2 else 157.3
+    return dict(op="alignconv_fused", dtype=str(dtype).split(".")[-1], batch=batch, hw=[H, W], us=round(sec*1e6, 1),
+                tflops=round(flops/sec/1e12, 1), mfma_frac=round(flops/sec/1e12/peak, 4),
+                alg_GBs=round(byts/sec/1e9, 1), hbm_frac=round(byts/sec/1e9/8000, 4))
+
+def iou(n, m):
+    rng = np.random.default_rng(1234)
+    b1, b2 = torch.from_numpy(rboxes(rng, n)).to(dev), torch.from_numpy(rboxes(rng, m)).to(dev)
+    out = S.box_iou_rotated(b1, b2)
+    sec = timeit(lambda: S.box_iou_rotated(b1, b2), iters=10)
+    byts = n*m*4 + (n+m)*20
+    return dict(op="box_iou_rotated", n=n, m=m, us=round(sec*1e6, 1), Mpairs_s=round(n*m/sec/1e6, 1),
+                nonzero_frac=round((out > 0).float().mean().item(), 4), alg_GBs=round(byts/sec/1e9, 1), hbm_frac=round(byts/sec/1e9/8000, 4))
+
+def nms(n, nl=15):
+    rng = np.random.default_rng(1234)
+    d = torch.from_numpy(rboxes(rng, n)).to(dev)
+    s = torch.from_numpy(((rng.permutation(n) + 1) / (n + 1) * 0.95 + 0.05).astype(np.float32)).to(dev)
+    lab = torch.from_numpy(rng.integers(0, nl, n).astype(np.float32)).to(dev)
+    k = S.ml_nms_rotated(d, s, lab, 0.5)
+    sec = timeit(lambda: S.ml_nms_rotated(d, s, lab, 0.5), iters=5, warm=1)
+    cnt = np.bincount(lab.cpu().numpy().astype(int))
+    pairs = float((cnt.astype(np.float64) * (cnt - 1) / 2).sum())
+    return dict(op="ml_nms_rotated", n=n, labels=nl, ms=round(sec*1e3, 3), keep=int(k.numel()),
+                same_label_pairs=pairs, Gpairs_s=round(pairs/sec/1e9, 2))
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(); ap.add_argument("--which", default="all"); a = ap.parse_args()
+    res = []
+    if a.which in ("all", "align"):
+        for b, dt in ((8, torch.float16), (1, torch.float16), (8, torch.float32), (1, torch.float32)):
+            res.append(alignconv(b, dt))
+        res.append(alignconv(8, torch.float16, 64, 64, stride=16))
+    if a.which in ("all", "iou"):
+        res.append(iou(10000, 10000)); res.append(iou(21824, 128))
+    if a.which in ("all", "nms"):
+        for n in (5000, 20000, 80160, 200000):
+            res.append(nms(n))
+    for r in res: print(json.dumps(r))

@@ -322,3 +322,22 @@ def test_alignconv_fused_vs_oracle(rng):
     assert np.abs(out - ref).max() < 1e-4
     assert np.abs(unfused - ref).max() < 1e-4
     assert (out >= 0).all() and (out == 0).mean() > 0.2
+
+
+def test_fused_conv_epilogue(rng):
+    from s2anet_amd.fused import FusedConv2d, bias_act_
+    for dt, tol in ((torch.float16, 2e-3), (torch.float32, 1e-6)):
+        y = torch.randn(2, 64, 9, 7, device=dev()).to(dt).contiguous(memory_format=torch.channels_last)
+        r = torch.randn_like(y)
+        b = torch.randn(64, device=dev()).to(dt)
+        ref = torch.relu(y.float() + b.float().view(1, -1, 1, 1) + r.float())
+        out = bias_act_(y.clone(memory_format=torch.channels_last), b, r, True)
+        assert (out.float() - ref).abs().max().item() <= tol * 10
+        ref2 = y.float() + b.float().view(1, -1, 1, 1)
+        out2 = bias_act_(y.clone(memory_format=torch.channels_last), b, None, False)
+        assert (out2.float() - ref2).abs().max().item() <= tol * 10
+    conv = torch.nn.Conv2d(16, 32, 3, padding=1).to(dev())
+    fc = FusedConv2d.from_conv(conv, relu=True)
+    x = torch.randn(2, 16, 8, 8, device=dev()).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert (fc(x) - torch.relu(conv(x))).abs().max().item() < 1e-5
