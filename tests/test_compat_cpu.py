@@ -1,0 +1,63 @@
+"""CPU: the alias modules of s2anet_amd.compat carry the reference's pybind names; where the
+reference tree is present (build container) its own Python imports cleanly against them."""
+import inspect
+import os
+import sys
+import types
+
+import pytest
+
+
+def test_alias_modules_have_reference_names():
+    import s2anet_amd.compat as compat
+    mods = compat.build_modules()
+    assert set(mods) == set(compat.MODULES)
+    d = mods["models.dcn.deform_conv_cuda"]
+    sig = inspect.signature(d.deform_conv_forward_cuda)
+    assert list(sig.parameters)[:17] == ["input", "weight", "offset", "output", "columns", "ones", "kW", "kH",
+                                         "dW", "dH", "padW", "padH", "dilationW", "dilationH", "group",
+                                         "deformable_group", "im2col_step"]
+    for n in ("deform_conv_backward_input_cuda", "deform_conv_backward_parameters_cuda",
+              "modulated_deform_conv_cuda_forward", "modulated_deform_conv_cuda_backward"):
+        with pytest.raises(NotImplementedError):
+            getattr(d, n)()
+    assert callable(mods["models.orn.orn_cuda"].arf_forward)
+    assert callable(mods["utils.box_iou_rotated.box_iou_rotated_cuda"].box_iou_rotated)
+    assert callable(mods["utils.nms_rotated.nms_rotated_cuda"].nms_rotated)
+    assert callable(mods["utils.ml_nms_rotated.ml_nms_rotated_cuda"].ml_nms_rotated)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference tree not present")
+def test_reference_python_imports_against_aliases():
+    import s2anet_amd.compat as compat
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("models", "utils", "cv2", "torchvision")}
+    sys.dont_write_bytecode = True
+    try:
+        for k in list(saved):
+            del sys.modules[k]
+        compat.install(force=True)
+        cv2 = types.ModuleType("cv2")
+        cv2.setNumThreads = lambda *a, **k: None
+        sys.modules.setdefault("cv2", cv2)
+        sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+        sys.path.insert(0, "/root/reference")
+        from models.head import S2ANetHead                       # noqa: F401  (reference code)
+        from models.dcn import DeformConv as RefDeformConv
+        from models.orn import ORConv2d as RefORConv2d
+        from utils.bbox_nms_rotated import multiclass_nms_rotated as ref_mc   # noqa: F401
+        ref_dc = sys.modules["models.dcn.deform_conv"]   # (models.dcn re-exports a function of that name)
+        assert ref_dc.deform_conv_cuda is sys.modules["models.dcn.deform_conv_cuda"]
+        head = S2ANetHead(15)
+        assert sum(p.numel() for p in head.parameters()) == 4919592
+        assert isinstance(head.align_conv.deform_conv, RefDeformConv) and isinstance(head.or_conv, RefORConv2d)
+        # the reference head's parameters load into this repo's head unchanged
+        from s2anet_amd.head import S2ANetHead as OurHead
+        ours = OurHead(15)
+        missing, unexpected = ours.load_state_dict(head.state_dict(), strict=True)
+        assert not missing and not unexpected
+    finally:
+        if "/root/reference" in sys.path:
+            sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k.split(".")[0] in ("models", "utils", "cv2", "torchvision")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
