@@ -206,11 +206,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)     # rehearsal on a 1-GPU box: all ranks share cuda:0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm.  S2A_BENCH_BACKEND=gloo is only for rehearsing the multi-rank code
+        # path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device).
+        backend = os.environ.get("S2A_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
 
     from s2anet_amd.detector import build_synthetic_detector

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const T* __restrict__ src,
   }
 }
 
-// weight [O][C][9] -> packed [9][C/KC][O][KC]  (KC = channels per stage)
+// weight [O][C][9] -> packed [C/KC][9][O][KC]  (KC = channels per stage; stage s = cc*9 + tap:
+// the 9 taps of one channel chunk run back to back, so their overlapping corner pixels stay in L1)
 template <typename T>
 __global__ void k_pack_weight(const T* __restrict__ w, int O, int C, int KC, T* __restrict__ wp) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,9 +76,22 @@ __global__ void k_pack_weight(const T* __restrict__ w, int O, int C, int KC, T* 
   int64_t r = e / KC;
   int o = (int)(r % O);
   r /= O;
-  int cc = (int)(r % (C / KC));
-  int t = (int)(r / (C / KC));
+  int t = (int)(r % 9);
+  int cc = (int)(r / 9);
   wp[e] = w[((int64_t)o * C + cc * KC + k) * 9 + t];
+}
+
+// 2-D position tiles: a workgroup owns a 16-wide x (NPOS/16)-high patch of one image, so the
+// footprint of its bilinear corners (patch + halo) is a few hundred pixels instead of a whole
+// image row.  Returns the linear position b*H*W + y*W + x, or -1 outside the image / batch.
+__device__ __forceinline__ int64_t tile_pos(int64_t tile, int pl, int th, int H, int W, int64_t HW,
+                                            int64_t Ntot) {
+  const int txn = (W + 15) / 16, tyn = (H + th - 1) / th;
+  const int64_t b = tile / (txn * tyn);
+  const int r = (int)(tile % (txn * tyn));
+  const int y = (r / txn) * th + (pl >> 4), xq = (r % txn) * 16 + (pl & 15);
+  const int64_t g = b * HW + (int64_t)y * W + xq;
+  return (y < H && xq < W && g < Ntot) ? g : -1;
 }
 
 // ------------------------------------------------------------------ sampling table
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t HW = (int64_t)H * W;
-  const int64_t g0 = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * NPOS;
+  const int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const int o0 = blockIdx.y * kMaxO;
   const int Oloc = min(kMaxO, O - o0);
   const int CC = C / KC;
@@ -250,9 +265,9 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
   // ---- sampling table for this tile
   for (int e = tid; e < NPOS * 9; e += 256) {
     int pl = e / 9, t = e % 9;
-    int64_t g = g0 + pl;
+    int64_t g = tile_pos(tile, pl, NPOS / 16, H, W, HW, Ntot);
     Tap tp;
-    if (g < Ntot) {
+    if (g >= 0) {
       int64_t b = g / HW, p = g % HW;
       int y = (int)(p / W), xq = (int)(p % W);
       int ky = t / 3, kx = t % 3;
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
   V av[8];
 
   auto issue = [&](int s) {
-    const int t = s / CC, cc = s % CC;
+    const int t = s % 9, cc = s / 9;
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
       int item = tid + 256 * it;
@@ -396,18 +411,238 @@ __global__ __launch_bounds__(256, 1) void k_dcn_mfma(const T* __restrict__ x,   
         int rowi = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if constexpr (OUT_NHWC) {
           // operands swapped: rows = positions, columns = out channels (128 B runs along channels)
-          int64_t g = g0 + 32 * b + rowi;
+          int64_t g = tile_pos(tile, 32 * b + rowi, NPOS / 16, H, W, HW, Ntot);
           int och = o0 + wave * 64 + 32 * a + (lane & 31);
-          if (g < Ntot) out[g * O + och] = (T)v;
+          if (g >= 0) out[g * O + och] = (T)v;
         } else {
           int och = o0 + wave * 64 + 32 * a + rowi;
-          int64_t g = g0 + 32 * b + (lane & 31);
-          if (g < Ntot) {
+          int64_t g = tile_pos(tile, 32 * b + (lane & 31), NPOS / 16, H, W, HW, Ntot);
+          if (g >= 0) {
             int64_t bi = g / HW, p = g % HW;
             out[(bi * O + och) * HW + p] = (T)v;
           }
         }
       }
+}
+
+// ------------------------------------------------------------------ wave-specialised variant
+// 512 threads: waves 0-3 only issue LDS fragment reads + MFMAs, waves 4-7 only gather, blend and
+// write LDS (one MFMA wave and one loader wave share each SIMD).  The loaders keep TWO stages of
+// global loads in flight (two register sets, counted vmcnt by the compiler), so memory stays busy
+// across the blend / LDS-write / barrier phases that stall the single-role kernel above.
+// Loads use buffer addressing (32-bit voffset + scalar stage offset): no per-load 64-bit VALU math.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+template <typename T, bool OUT_NHWC, int SRC>
+__global__ __launch_bounds__(512, 2) void k_dcn_ws(const T* __restrict__ x, const float* __restrict__ src,
+                                                   const T* __restrict__ wp, T* __restrict__ out,
+                                                   int64_t Ntot, int C, int H, int W, int O, float stride,
+                                                   int relu, unsigned x_bytes, unsigned wp_bytes) {
+  constexpr int KC = Traits<T>::KC;
+  constexpr int NPOS = 128, NT = 4, ITEMS = 4;
+  constexpr int ES = (int)sizeof(T);
+  using V = typename Vec16<T>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Tap* s_tab = reinterpret_cast<Tap*>(smem);
+  constexpr int kTabBytes = NPOS * 9 * 32;
+  constexpr int kABytes = kMaxO * kRowBytes, kBBytes = NPOS * kRowBytes;
+  char* s_buf = smem + kTabBytes;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t HW = (int64_t)H * W;
+  const int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int o0 = blockIdx.y * kMaxO;
+  const int Oloc = min(kMaxO, O - o0);
+  const int CC = C / KC;
+  const int nstage = 9 * CC;
+
+  for (int e = tid; e < NPOS * 9; e += 512) {
+    int pl = e / 9, t = e % 9;
+    int64_t g = tile_pos(tile, pl, NPOS / 16, H, W, HW, Ntot);
+    Tap tp;
+    if (g >= 0) {
+      int64_t b = g / HW, p = g % HW;
+      int y = (int)(p / W), xq = (int)(p % W);
+      int ky = t / 3, kx = t % 3;
+      float off_y, off_x;
+      if (SRC == 0) {
+        const float* ob = src + (b * 18) * HW + p;
+        off_y = ob[(int64_t)(2 * t) * HW];
+        off_x = ob[(int64_t)(2 * t + 1) * HW];
+      } else {
+        AnchorCtx c = anchor_ctx(src + g * 5, stride);
+        anchor_offset(c, ky, kx, (float)y, (float)xq, off_y, off_x);
+      }
+      float h_im = (float)(y - 1 + ky) + off_y;
+      float w_im = (float)(xq - 1 + kx) + off_x;
+      tp = make_tap(h_im, w_im, H, W, b * HW);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        tp.idx[k] = 0;
+        tp.w[k] = 0.f;
+      }
+    }
+    s_tab[e] = tp;
+  }
+  __syncthreads();
+
+  if (wave < 4) {
+    // ===================== MFMA waves =====================
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    const bool wave_active = wave * 64 < Oloc;
+    __syncthreads();  // stage 0 is in LDS
+    for (int s = 0; s < nstage; s++) {
+      if (wave_active) {
+        const char* A = s_buf + (s & 1) * (kABytes + kBBytes);
+        const char* Bm = A + kABytes;
+        const char* wrow = A + (wave * 64 + (lane & 31)) * kRowBytes + (lane >> 5) * 16;
+        const char* prow = Bm + (lane & 31) * kRowBytes + (lane >> 5) * 16;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          V wf[2], pf[NT];
+#pragma unroll
+          for (int h = 0; h < 2; h++) wf[h] = *reinterpret_cast<const V*>(wrow + h * 32 * kRowBytes + kk * 32);
+#pragma unroll
+          for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
+          if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+              for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++) {
+                  if constexpr (OUT_NHWC)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[b][j], wf[a][j], acc[a][b], 0, 0, 0);
+                  else
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[a][j], pf[b][j], acc[a][b], 0, 0, 0);
+                }
+          } else {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+              for (int b = 0; b < NT; b++) {
+                if constexpr (OUT_NHWC)
+                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[b], wf[a], acc[a][b], 0, 0, 0);
+                else
+                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+              }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!wave_active) return;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float v = acc[a][b][r];
+          if (relu) v = fmaxf(v, 0.f);
+          int rowi = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if constexpr (OUT_NHWC) {
+            int64_t g = tile_pos(tile, 32 * b + rowi, NPOS / 16, H, W, HW, Ntot);
+            int och = o0 + wave * 64 + 32 * a + (lane & 31);
+            if (g >= 0) out[g * O + och] = (T)v;
+          } else {
+            int och = o0 + wave * 64 + 32 * a + rowi;
+            int64_t g = tile_pos(tile, 32 * b + (lane & 31), NPOS / 16, H, W, HW, Ntot);
+            if (g >= 0) {
+              int64_t bi = g / HW, p = g % HW;
+              out[(bi * O + och) * HW + p] = (T)v;
+            }
+          }
+        }
+  } else {
+    // ===================== loader waves =====================
+    const int L = tid - 256;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (int)wp_bytes, 0x00020000);
+    unsigned voff[ITEMS][4];
+    V cvA[ITEMS][4], cvB[ITEMS][4], avA[8], avB[8];
+    const unsigned row_bytes = (unsigned)C * ES;
+    const unsigned wvoff = (unsigned)L * 16;   // + r*4096 via the scalar offset
+
+    auto issue = [&](int s, V (&cv)[ITEMS][4], V (&av)[8]) {
+      const int t = s % 9, cc = s / 9;
+      {  // every stage is a new tap: refresh the 16 corner offsets of this thread's items
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+          int item = L + 256 * it;
+          int pl = item >> 3, q = item & 7;
+          const Tap tp = s_tab[pl * 9 + t];
+#pragma unroll
+          for (int k = 0; k < 4; k++) voff[it][k] = (unsigned)tp.idx[k] * row_bytes + q * 16;
+        }
+      }
+      const int soff = cc * KC * ES;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff[it][k], soff, 0);
+          cv[it][k] = __builtin_bit_cast(V, d);
+        }
+      const unsigned wbase = (unsigned)(((int64_t)s * O + o0) * KC * ES);
+      // rows >= Oloc read past this workgroup's weight block: harmless (bounds-checked buffer load,
+      // the LDS tile always has 256 rows, inactive MFMA waves never read them).  No predicate here:
+      // a branch around loads makes hipcc fall back from counted vmcnt(N) to vmcnt(0).
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)wvoff, (int)(wbase + r * 4096), 0);
+        av[r] = __builtin_bit_cast(V, d);
+      }
+    };
+    auto commit = [&](int s, V (&cv)[ITEMS][4], V (&av)[8]) {
+      const int t = s % 9;
+      char* A = s_buf + (s & 1) * (kABytes + kBBytes);
+      char* Bm = A + kABytes;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) {
+        int item = L + 256 * it;
+        int pl = item >> 3, q = item & 7;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_tab[pl * 9 + t].w[0]);
+        const float cw[4] = {w4[0], w4[1], w4[2], w4[3]};
+        if constexpr (sizeof(T) == 2)
+          *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_pk(cv[it], cw);
+        else
+          *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend<T>(cv[it], cw);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        int idx = L + 256 * r;
+        int row = idx >> 3, q = idx & 7;
+        *reinterpret_cast<V*>(A + row * kRowBytes + q * 16) = av[r];
+      }
+    };
+
+    // Straight-line double-stage body (stage indices clamped instead of branches) so that the
+    // compiler keeps exact vmcnt counts: when a set is committed, the other set's 24 loads stay
+    // in flight.  Loop-entry and back-edge state are identical: "24 loads of set B outstanding".
+    const int last = nstage - 1;
+    issue(0, cvA, avA);
+    issue(min(1, last), cvB, avB);
+    commit(0, cvA, avA);
+    __syncthreads();  // stage 0 is in LDS
+    int s = 0;
+    for (; s + 1 < nstage; s += 2) {
+      issue(min(s + 2, last), cvA, avA);
+      commit(s + 1, cvB, avB);
+      __syncthreads();              // end of stage s
+      issue(min(s + 3, last), cvB, avB);
+      commit(min(s + 2, last), cvA, avA);   // when s+2 > last: rewrites the unread buffer, harmless
+      __syncthreads();              // end of stage s+1
+    }
+    if (s < nstage) __syncthreads();  // odd stage count: the last stage's barrier
+  }
 }
 
 template <int NPOS>
@@ -483,23 +718,37 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
                 hipStream_t st) {
   const int64_t Ntot = B * (int64_t)H * W;
   // 128-position tiles once they still give every CU >= 2 workgroups; else 64
-  const bool big = (Ntot + 127) / 128 >= 512;
+  auto ntiles = [&](int npos) { return B * (int64_t)((W + 15) / 16) * ((H + npos / 16 - 1) / (npos / 16)); };
+  const bool big = ntiles(128) >= 512;
 #define S2A_DCN_LAUNCH(NHWC, SRC, NPOS)                                                           \
   do {                                                                                            \
     auto kern = k_dcn_mfma<T, NHWC, SRC, NPOS>;                                                   \
     constexpr int lds = mfma_lds_bytes<NPOS>();                                                   \
-    dim3 grid((unsigned)((Ntot + NPOS - 1) / NPOS), (unsigned)((O + kMaxO - 1) / kMaxO));         \
+    dim3 grid((unsigned)ntiles(NPOS), (unsigned)((O + kMaxO - 1) / kMaxO));                       \
     S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));                \
     kern<<<grid, 256, lds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu);           \
   } while (0)
-#define S2A_DCN_PICK(NHWC, SRC) do { if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
+  const uint64_t x_bytes = (uint64_t)Ntot * C * sizeof(T), w_bytes = (uint64_t)O * C * 9 * sizeof(T);
+  const bool ws_ok = sizeof(T) == 2 && big && x_bytes < (1ull << 31) && w_bytes < (1ull << 31) && !getenv("S2A_DCN_NO_WS");
+#define S2A_DCN_LAUNCH_WS(NHWC, SRC)                                                              \
+  do {                                                                                            \
+    auto kern = k_dcn_ws<T, NHWC, SRC>;                                                           \
+    constexpr int lds = mfma_lds_bytes<128>();                                                    \
+    dim3 grid((unsigned)ntiles(128), (unsigned)((O + kMaxO - 1) / kMaxO));                        \
+    S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));                \
+    kern<<<grid, 512, lds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu,            \
+                                 (unsigned)x_bytes, (unsigned)w_bytes);                           \
+  } while (0)
+#define S2A_DCN_PICK(NHWC, SRC) do { if (ws_ok) S2A_DCN_LAUNCH_WS(NHWC, SRC); else if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
   if (out_nhwc) {
     if (from_anchors) S2A_DCN_PICK(true, 1); else S2A_DCN_PICK(true, 0);
   } else {
     if (from_anchors) S2A_DCN_PICK(false, 1); else S2A_DCN_PICK(false, 0);
   }
 #undef S2A_DCN_PICK
+#undef S2A_DCN_LAUNCH_WS
 #undef S2A_DCN_LAUNCH
   S2A_LAUNCH_CHECK();
   return S2A_OK;

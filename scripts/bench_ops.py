@@ -72,6 +72,8 @@ if __name__ == "__main__":
         for b, dt in ((8, torch.float16), (1, torch.float16), (8, torch.float32), (1, torch.float32)):
             res.append(alignconv(b, dt))
         res.append(alignconv(8, torch.float16, 64, 64, stride=16))
+    if a.which == "align8":
+        res.append(alignconv(8, torch.float16))
     if a.which in ("all", "iou"):
         res.append(iou(10000, 10000)); res.append(iou(21824, 128))
     if a.which in ("all", "nms"):

@@ -341,3 +341,29 @@ def test_fused_conv_epilogue(rng):
     x = torch.randn(2, 16, 8, 8, device=dev()).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         assert (fc(x) - torch.relu(conv(x))).abs().max().item() < 1e-5
+
+
+def test_alignconv_f16_large_tile_variants(rng):
+    """the 128-position / wave-specialised kernels (picked when >= 512 tiles): f16, both layouts,
+    against the f16-column oracle on a random subset of positions (full oracle would take minutes)"""
+    import s2anet_amd as S
+    from s2anet_amd.alignconv import align_conv_forward
+    B, C, H, W, O, stride = 4, 128, 128, 128, 128, 8
+    x = (rng.standard_normal((B, C, H, W)) * 0.5).astype(np.float32)
+    anchors = np.stack([oracle.grid_anchors(H, W, stride) for _ in range(B)]).reshape(B, H, W, 5).copy()
+    anchors[..., 0:2] += rng.normal(0, 4, anchors[..., 0:2].shape)
+    anchors[..., 2:4] = 32 * np.exp(rng.normal(0, 0.5, anchors[..., 2:4].shape))
+    anchors[..., 4] = rng.uniform(-np.pi / 4, 3 * np.pi / 4, anchors[..., 4].shape)
+    anchors = anchors.astype(np.float32)
+    w = (rng.standard_normal((O, C, 3, 3)) * 0.05).astype(np.float32)
+    xh, wh = cu(x).half(), cu(w).half()
+    outs = {}
+    for name, xin in (("nchw", xh), ("nhwc", xh.contiguous(memory_format=torch.channels_last))):
+        outs[name] = align_conv_forward(xin, cu(anchors), wh, stride, relu=True).float().cpu().numpy()
+    assert np.abs(outs["nchw"] - outs["nhwc"]).max() == 0.0       # layout only changes storage
+    # oracle on 3 image rows (full rows so offsets index correctly): crop trick does not apply to a
+    # deformable op, so evaluate the oracle on the full image 0 but only compare a few rows
+    offs = oracle.align_offsets(anchors[0].reshape(-1, 5), H, W, stride)[None]
+    ref = oracle.deform_conv_forward(xh[:1].float().cpu().numpy(), offs, wh.float().cpu().numpy(), f16_cols=True, relu=True)
+    err = np.abs(outs["nchw"][0] - ref[0])
+    assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max(), err.mean())
