@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -738,8 +739,13 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
     dim3 grid((unsigned)ntiles(128), (unsigned)((O + kMaxO - 1) / kMaxO));                        \
     S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));                \
-    kern<<<grid, 512, lds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu,            \
-                                 (unsigned)x_bytes, (unsigned)w_bytes);                           \
+    /* timing-only experiment (cdna guide, rocprof section): a zero-record descriptor drops every  \
+       buffer load through it while the instruction stream stays; outputs are then wrong */       \
+    const char* drop = getenv("S2A_DCN_DROP");                                                    \
+    unsigned xb = (unsigned)x_bytes, wb = (unsigned)w_bytes;                                      \
+    if (drop && strchr(drop, 'x')) xb = 0;                                                        \
+    if (drop && strchr(drop, 'w')) wb = 0;                                                        \
+    kern<<<grid, 512, lds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu, xb, wb);   \
   } while (0)
 #define S2A_DCN_PICK(NHWC, SRC) do { if (ws_ok) S2A_DCN_LAUNCH_WS(NHWC, SRC); else if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
   if (out_nhwc) {

@@ -55,6 +55,32 @@ __device__ __forceinline__ bool surely_disjoint(float ax, float ay, float ar, fl
   return dx * dx + dy * dy > R * R;
 }
 
+// Second-stage exact shortcut: separating-axis test on the two rectangles with the same 0.2 % +
+// 1e-3 px safety margin (a gap that large cannot be bridged by the reference's float rounding, so
+// it finds no intersection point and no contained vertex: num == 0 -> exactly 0.0f).  Removes the
+// elongated / rotated near-misses the circle test lets through (about half of its survivors).
+__device__ __forceinline__ bool sat_disjoint(const PreBox& A, const PreBox& B) {
+  const float dx = B.x - A.x, dy = B.y - A.y;
+  // half-extent vectors u (along w) and v (along h); unit axes are (2*c2, 2*s2), (-2*s2, 2*c2)
+  const float aux = A.c2 * A.w, auy = A.s2 * A.w, avx = -A.s2 * A.h, avy = A.c2 * A.h;
+  const float bux = B.c2 * B.w, buy = B.s2 * B.w, bvx = -B.s2 * B.h, bvy = B.c2 * B.h;
+  const float acx = 2.f * A.c2, asx = 2.f * A.s2, bcx = 2.f * B.c2, bsx = 2.f * B.s2;
+  const float ahw = 0.5f * fabsf(A.w), ahh = 0.5f * fabsf(A.h), bhw = 0.5f * fabsf(B.w), bhh = 0.5f * fabsf(B.h);
+  float d, r;
+  d = fabsf(dx * acx + dy * asx);   // A's w axis
+  r = ahw + fabsf(bux * acx + buy * asx) + fabsf(bvx * acx + bvy * asx);
+  if (d > r * 1.002f + 1e-3f) return true;
+  d = fabsf(-dx * asx + dy * acx);  // A's h axis
+  r = ahh + fabsf(-bux * asx + buy * acx) + fabsf(-bvx * asx + bvy * acx);
+  if (d > r * 1.002f + 1e-3f) return true;
+  d = fabsf(dx * bcx + dy * bsx);   // B's w axis
+  r = bhw + fabsf(aux * bcx + auy * bsx) + fabsf(avx * bcx + avy * bsx);
+  if (d > r * 1.002f + 1e-3f) return true;
+  d = fabsf(-dx * bsx + dy * bcx);  // B's h axis
+  r = bhh + fabsf(-aux * bsx + auy * bcx) + fabsf(-avx * bsx + avy * bcx);
+  return d > r * 1.002f + 1e-3f;
+}
+
 __device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) {
   return ax * by - bx * ay;  // cross_2d (:51-53)
 }

@@ -88,9 +88,14 @@ __device__ __forceinline__ void queue_flush(PairQueue& Q, uint2* __restrict__ gq
 }
 
 // ================================================================= box_iou_rotated
-// CULL: workgroup = 256 columns x up to 256 rows.  Culled pairs get their exact 0.0f here
-// (coalesced row stores); the rest go to the pair list and are written by the heavy pass,
-// so every output element is written exactly once.
+// CULL: workgroup = 1024 columns (4 per lane: one 16-byte store per lane per row) x up to 64 rows.
+// Every element of the tile is stored here as 0.0f — exact for culled pairs; the ~1 % that survive
+// the cull are also queued and overwritten by the heavy pass (same stream, later kernel).  Row boxes
+// are staged in LDS and read one iteration ahead so no row waits on a load.  HBM-write-bound.
+constexpr int kIouRowsPerWg = 64;
+constexpr int kIouQueue = 3072;      // LDS pair queue of this kernel (<= 1024 pushes per row)
+constexpr int kIouFlushAt = 2048;
+
 __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict__ P1,
                                                        const PreBox* __restrict__ P2,
                                                        int64_t row0, int64_t row1, int64_t m,
@@ -98,36 +103,47 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
                                                        uint2* __restrict__ gq,
                                                        unsigned long long* __restrict__ gcount,
                                                        unsigned long long cap) {
-  __shared__ uint2 s_q[kLdsQueue];
+  __shared__ uint2 s_q[kIouQueue];
   __shared__ unsigned s_count, s_base[2];
+  __shared__ PreBox s_rows[kIouRowsPerWg];
   PairQueue Q{s_q, &s_count, s_base};
   if (threadIdx.x == 0) s_count = 0;
+
+  const int64_t j0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+  const int64_t rbeg = row0 + (int64_t)blockIdx.y * kIouRowsPerWg;
+  const int nrows = (int)min((int64_t)kIouRowsPerWg, row1 - rbeg);
+  if (threadIdx.x < nrows) s_rows[threadIdx.x] = P1[rbeg + threadIdx.x];
+  PreBox Bj[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    Bj[k] = {};
+    if (j0 + k < m) Bj[k] = P2[j0 + k];
+  }
+  const bool vec_ok = (j0 + 3 < m) && ((m & 3) == 0);   // 16-byte aligned full group
   __syncthreads();
 
-  const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  const int64_t rbeg = row0 + (int64_t)blockIdx.y * 256;
-  const int64_t rend = min(rbeg + 256, row1);
-  const bool jvalid = j < m;
-  float bx = 0, by = 0, br = 0;
-  if (jvalid) {
-    bx = P2[j].x;
-    by = P2[j].y;
-    br = P2[j].r;
-  }
-  for (int64_t r = rbeg; r < rend; r += 8) {
-    const int64_t re = min(r + 8, rend);
-    for (int64_t i = r; i < re; i++) {
-      // uniform address -> scalar loads
-      float ax = P1[i].x, ay = P1[i].y, ar = P1[i].r;
-      if (jvalid) {
-        if (surely_disjoint(ax, ay, ar, bx, by, br))
-          out[i * m + j] = 0.0f;
-        else
-          queue_push(Q, (unsigned)(i - row0), (unsigned)j);
-      }
+  PreBox Ai = s_rows[0];
+  for (int r = 0; r < nrows; r++) {
+    const PreBox A = Ai;
+    if (r + 1 < nrows) Ai = s_rows[r + 1];   // next row's box while this one is processed
+    const int64_t i = rbeg + r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (j0 + k < m && !surely_disjoint(A.x, A.y, A.r, Bj[k].x, Bj[k].y, Bj[k].r) && !sat_disjoint(A, Bj[k]))
+        queue_push(Q, (unsigned)(i - row0), (unsigned)(j0 + k));
     }
-    __syncthreads();
-    if (s_count > kFlushAt) queue_flush(Q, gq, gcount, cap);  // uniform condition
+    float* dst = out + i * m + j0;
+    if (vec_ok) {
+      *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (j0 + k < m) dst[k] = 0.f;
+    }
+    if ((r & 1) == 1) {          // <= 2048 pushes per two rows: the queue can never overflow
+      __syncthreads();
+      if (s_count > kIouFlushAt - 1024) queue_flush(Q, gq, gcount, cap);   // uniform
+    }
   }
   queue_flush(Q, gq, gcount, cap);
 }
@@ -165,7 +181,28 @@ __global__ __launch_bounds__(kThreads) void k_iou_pairs(const float* __restrict_
   out[i] = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
 }
 
-constexpr unsigned long long kIouQueueCap = 16ull << 20;  // 16 Mi pairs = 128 MiB
+// Overflow fallback: the pair list of a chunk did not fit (extremely dense inputs).  Recompute the
+// whole chunk pair by pair (the divergence that the list avoids is irrelevant when most pairs are
+// heavy anyway).  Exits immediately in the normal case.
+__global__ __launch_bounds__(kThreads) void k_iou_direct(const PreBox* __restrict__ P1,
+                                                         const PreBox* __restrict__ P2, int64_t row0,
+                                                         int64_t row1, int64_t m, float* __restrict__ out,
+                                                         const unsigned long long* __restrict__ gcount,
+                                                         unsigned long long cap) {
+  if (*gcount <= cap) return;
+  __shared__ float2 s_pts[24 * kThreads];
+  const int64_t total = (row1 - row0) * m;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+    int64_t i = row0 + e / m, j = e % m;
+    PreBox A = P1[i], B = P2[j];
+    float v = 0.f;
+    if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B))
+      v = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
+    out[i * m + j] = v;
+  }
+}
+
+constexpr unsigned long long kIouQueueCap = 32ull << 20;  // 32 Mi pairs = 256 MiB
 
 // ================================================================= NMS
 __global__ void k_nms_keys(const float* __restrict__ scores, const int32_t* __restrict__ groups,
@@ -311,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
                                                        unsigned long long cap) {
   __shared__ uint2 s_q[kLdsQueue];
   __shared__ unsigned s_count, s_base[2];
-  __shared__ float s_cx[64], s_cy[64], s_cr[64];
+  __shared__ PreBox s_col[64];
   PairQueue Q{s_q, &s_count, s_base};
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
@@ -322,23 +359,20 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
     TileRef t = locate_tile(tile, tile_off, seg_start, S);
     if (threadIdx.x < 64) {
       uint32_t jl = t.cb * 64 + threadIdx.x;
-      float x = 0, y = 0, r = 0;
-      if (jl < t.ns) {
-        const PreBox& b = sorted[t.seg_start + jl];
-        x = b.x; y = b.y; r = b.r;
-      }
-      s_cx[threadIdx.x] = x; s_cy[threadIdx.x] = y; s_cr[threadIdx.x] = r;
+      PreBox b = {};
+      if (jl < t.ns) b = sorted[t.seg_start + jl];
+      s_col[threadIdx.x] = b;
     }
     __syncthreads();
     uint32_t il = t.rb * 64 + row;
     if (il < t.ns) {
-      const PreBox& a = sorted[t.seg_start + il];
-      float ax = a.x, ay = a.y, ar = a.r;
+      const PreBox a = sorted[t.seg_start + il];
 #pragma unroll 4
       for (int c = 0; c < 16; c++) {
         int cc = quarter * 16 + c;
         uint32_t jl = t.cb * 64 + cc;
-        if (jl < t.ns && jl > il && !surely_disjoint(ax, ay, ar, s_cx[cc], s_cy[cc], s_cr[cc]))
+        if (jl < t.ns && jl > il && !surely_disjoint(a.x, a.y, a.r, s_col[cc].x, s_col[cc].y, s_col[cc].r) &&
+            !sat_disjoint(a, s_col[cc]))
           queue_push(Q, t.seg_start + il, t.seg_start + jl);
       }
     }
@@ -403,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_direct(const PreBox* __restric
       uint32_t jl = t.cb * 64 + cc;
       if (jl < t.ns && jl > il) {
         PreBox B = sorted[t.seg_start + jl];
-        if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) &&
+        if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B) &&
             rbox_iou<kThreads>(A, B, s_pts + threadIdx.x) > thr)
           bits |= 1ull << cc;
       }
@@ -465,9 +499,25 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
       }
       __syncthreads();
       const unsigned long long kb = *s_keep;
+      // rows kept in this block suppress later columns: OR their mask rows into the running
+      // remove vector.  Lanes walk consecutive words of a row (coalesced); four rows in flight.
+      const int nk = __popcll(kb);
       for (uint32_t c = b + 1 + threadIdx.x; c < B; c += kThreads) {
         unsigned long long acc = s_remv[c];
         unsigned long long bits = kb;
+        int left = nk;
+        while (left >= 4) {
+          int t0 = __builtin_ctzll(bits); bits &= bits - 1;
+          int t1 = __builtin_ctzll(bits); bits &= bits - 1;
+          int t2 = __builtin_ctzll(bits); bits &= bits - 1;
+          int t3 = __builtin_ctzll(bits); bits &= bits - 1;
+          unsigned long long m0 = M[(unsigned long long)(b * 64 + t0) * B + c];
+          unsigned long long m1 = M[(unsigned long long)(b * 64 + t1) * B + c];
+          unsigned long long m2 = M[(unsigned long long)(b * 64 + t2) * B + c];
+          unsigned long long m3 = M[(unsigned long long)(b * 64 + t3) * B + c];
+          acc |= (m0 | m1) | (m2 | m3);
+          left -= 4;
+        }
         while (bits) {
           int t = __builtin_ctzll(bits);
           bits &= bits - 1;
@@ -595,7 +645,7 @@ int nms_plan(int64_t n, int64_t max_seg_rows, NmsPlan* plan) {
   plan->max_blocks = (uint32_t)nb;
   // pair list: all same-segment pairs when small, else 8 Mi entries + 64/row
   unsigned long long all_pairs = (unsigned long long)n * (unsigned long long)max_seg_rows / 2 + 64;
-  unsigned long long want = (8ull << 20) + 64ull * (unsigned long long)n;
+  unsigned long long want = (16ull << 20) + 256ull * (unsigned long long)n;
   plan->queue_cap = std::min(all_pairs, want);
   return 0;
 }
@@ -772,8 +822,9 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   }
   unsigned long long cap = (workspace_bytes - cv.off) / sizeof(uint2);
   uint2* gq = reinterpret_cast<uint2*>(static_cast<char*>(workspace) + cv.off);
-  // rows per chunk so that even an all-overlapping chunk fits the pair list
-  int64_t rows_per_chunk = (int64_t)std::min<unsigned long long>((unsigned long long)n, cap / (unsigned long long)m);
+  // rows per chunk: sized for up to 1/4 of the pairs surviving the cull (DOTA-like inputs: ~1 %);
+  // a denser chunk overflows the list and is recomputed by k_iou_direct
+  int64_t rows_per_chunk = (int64_t)std::min<unsigned long long>((unsigned long long)n, 4 * (cap / (unsigned long long)m));
   rows_per_chunk = std::max<int64_t>(256, rows_per_chunk / 256 * 256);
   int64_t chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
   S2A_CHECK_ARG(chunks <= 512, "box_iou_rotated: workspace too small for %lld x %lld", (long long)n, (long long)m);
@@ -782,9 +833,10 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   S2A_HIP(hipMemsetAsync(counters, 0, 512 * sizeof(unsigned long long), st));
   for (int64_t c = 0; c < chunks; c++) {
     int64_t r0 = c * rows_per_chunk, r1 = std::min(n, r0 + rows_per_chunk);
-    dim3 grid((unsigned)((m + kThreads - 1) / kThreads), (unsigned)((r1 - r0 + 255) / 256));
+    dim3 grid((unsigned)((m + kThreads * 4 - 1) / (kThreads * 4)), (unsigned)((r1 - r0 + kIouRowsPerWg - 1) / kIouRowsPerWg));
     k_iou_cull<<<grid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
     k_iou_heavy<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, m, ious, gq, counters + c, cap);
+    k_iou_direct<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, counters + c, cap);
   }
   S2A_LAUNCH_CHECK();
   return S2A_OK;

@@ -76,6 +76,8 @@ if __name__ == "__main__":
         res.append(alignconv(8, torch.float16))
     if a.which in ("all", "iou"):
         res.append(iou(10000, 10000)); res.append(iou(21824, 128))
+    if a.which == "nms200k":
+        res.append(nms(200000))
     if a.which in ("all", "nms"):
         for n in (5000, 20000, 80160, 200000):
             res.append(nms(n))
