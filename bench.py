@@ -97,12 +97,12 @@ def measure_alignconv(model, batch, dtype, iters=30):
     anc = anc.to(dev)
     wp = model.head.align_conv.packed_weight(dtype)
     for _ in range(3):
-        align_conv_forward(x, anc, wp, 8, relu=True, packed=True)
+        align_conv_forward(x, anc, wp, 8, relu=True, packed=True, out_channels=256)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        align_conv_forward(x, anc, wp, 8, relu=True, packed=True)
+        align_conv_forward(x, anc, wp, 8, relu=True, packed=True, out_channels=256)
     e1.record()
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) / 1e3 / iters

@@ -167,8 +167,10 @@ typedef struct s2a_align_params {
                         inference, the weights do not change between forwards) */
 } s2a_align_params;
 size_t s2a_align_conv_workspace_bytes(const s2a_align_params* p);
-/* weight[O,C,3,3] -> stage-major layout [9][C/KC][O][KC] (KC = 32 for f32, 64 for f16) that the
- * fused kernel streams; same element count as the input. */
+/* weight[O,C,3,3] -> the layouts the fused kernels stream: stage-major [C/KC][9][O][KC]
+ * (KC = 32 for f32, 64 for f16) and, for f16, a second copy in MFMA-fragment order right behind it.
+ * `packed` must hold s2a_dcn_packed_elems(O, C, dtype) elements. */
+int64_t s2a_dcn_packed_elems(int64_t out_channels, int64_t channels, int dtype);
 int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int64_t channels, int dtype,
                         void* packed, s2a_stream_t stream);
 int s2a_align_conv_forward(const void* x, const float* anchors, const void* weight, void* out,

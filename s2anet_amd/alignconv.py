@@ -32,14 +32,15 @@ def pack_weight(weight, dtype):
     """weight[O,C,3,3] -> the stage-major layout the fused kernel streams (s2a_dcn_pack_weight)"""
     _lib.require_cuda(weight)
     w = weight.detach().to(dtype).contiguous()
-    out = torch.empty_like(w)
+    L = _lib.lib()
+    out = torch.empty((L.s2a_dcn_packed_elems(w.shape[0], w.shape[1], _lib.dtype_code(w)),), dtype=w.dtype, device=w.device)
     with torch.cuda.device(w.device):
         _lib.check(_lib.lib().s2a_dcn_pack_weight(_lib.ptr(w), w.shape[0], w.shape[1], _lib.dtype_code(w),
                                                   _lib.ptr(out), _lib.stream_ptr(w.device)))
     return out
 
 
-def align_conv_forward(x, anchors, weight, stride, relu=True, packed=False):
+def align_conv_forward(x, anchors, weight, stride, relu=True, packed=False, out_channels=None):
     """fused AlignConv: x[B,C,H,W] (NCHW or channels_last), anchors[B,H,W,5] f32, weight[O,C,3,3]
     (or, with packed=True, the output of pack_weight)"""
     _lib.require_cuda(x, anchors, weight)
@@ -51,7 +52,7 @@ def align_conv_forward(x, anchors, weight, stride, relu=True, packed=False):
     w = weight.contiguous()
     if w.dtype != xx.dtype:
         w = w.to(xx.dtype)
-    O = w.shape[0]
+    O = out_channels if packed else w.shape[0]
     a = anchors.reshape(B, H, W, 5).float().contiguous()
     out = torch.empty((B, O, H, W), dtype=xx.dtype, device=xx.device,
                       memory_format=torch.channels_last if nhwc else torch.contiguous_format)
@@ -101,7 +102,8 @@ class AlignConv(nn.Module):
         num_imgs, H, W = anchors.shape[:3]
         if self.fused_ok(x):
             if not (torch.is_grad_enabled() and self.deform_conv.weight.requires_grad):
-                return align_conv_forward(x, anchors, self.packed_weight(x.dtype), stride, relu=True, packed=True)
+                return align_conv_forward(x, anchors, self.packed_weight(x.dtype), stride, relu=True, packed=True,
+                                          out_channels=self.deform_conv.out_channels)
             return align_conv_forward(x, anchors, self.deform_conv.weight, stride, relu=True)
         offset = align_offsets(anchors.reshape(num_imgs, H * W, 5), (H, W), stride, self.kernel_size[0])
         return self.relu(self.deform_conv(x, offset))

@@ -35,6 +35,10 @@
 namespace s2a {
 namespace {
 
+// S2A_ABL: compile-time ablation switches for timing experiments only (never set in a shipped build)
+#ifndef S2A_ABL
+#define S2A_ABL 0
+#endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -646,6 +650,336 @@ __global__ __launch_bounds__(512, 2) void k_dcn_ws(const T* __restrict__ x, cons
   }
 }
 
+// ------------------------------------------------------------------ patch-staged variant (f16)
+// The vector-memory path of a CU sustains only ~30 B/clk for 16-B-per-lane gathers (measured: the
+// loader side of k_dcn_ws takes 3.3 k cycles per stage even with every load dropped by a
+// zero-record descriptor), and the 9 taps of one position re-read almost the same pixels.  So:
+//   * the input patch around the 8x16 position tile (16x24 pixels x 64 channels = 48 KB) is
+//     loaded ONCE per channel chunk into LDS; the 9 taps gather their corners from LDS
+//     (ds_read_b128, ~10x the bandwidth of the global gather); corners outside the patch fall
+//     back to global loads (rare for anchor-sized offsets)
+//   * the weight tile never touches LDS: it is pre-packed in MFMA-fragment order and every MFMA
+//     wave loads its own 8 KB per stage straight into registers (1 KB contiguous per instruction),
+//     one stage ahead — which frees 72 KB of LDS for the double-buffered patch
+// L1 traffic per stage drops from 96 KB to ~38 KB.
+struct alignas(16) PTap {
+  short y, x;        // top-left bilinear corner (h_low, w_low), image coordinates
+  unsigned flags;    // bit 0: all four corners lie inside the LDS patch
+  _Float16 w[4];     // hh*hw, hh*lw, lh*hw, lh*lw; 0 where the corner is dropped
+};
+constexpr int kPH = 16, kPW = 24, kHalo = 4;
+constexpr int kPatchBytes = kPH * kPW * 128;
+constexpr int kPatchLds = 128 * 9 * 16 + 2 * 128 * kRowBytes + 2 * kPatchBytes;  // 153600 B
+
+// weight [O][C][9] f16 -> [stage = cc*9+t][och group of 64][mt 2][kk 4][lane 64][8 halfs]:
+// lane l, element j of fragment (mt,kk) = W[g*64 + mt*32 + (l&31)][cc*64 + kk*16 + 8*(l>>5) + j][t]
+__global__ void k_pack_weight_frag(const _Float16* __restrict__ w, int O, int C, _Float16* __restrict__ wp) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)O * C * 9;
+  if (e >= total) return;
+  const int G = O / 64;
+  int j = (int)(e & 7);
+  int lane = (int)((e >> 3) & 63);
+  int kk = (int)((e >> 9) & 3);
+  int mt = (int)((e >> 11) & 1);
+  int64_t r = e >> 12;
+  int g = (int)(r % G);
+  int st = (int)(r / G);
+  int t = st % 9, cc = st / 9;
+  int och = g * 64 + mt * 32 + (lane & 31);
+  int k = cc * 64 + kk * 16 + 8 * (lane >> 5) + j;
+  wp[e] = w[((int64_t)och * C + k) * 9 + t];
+}
+
+constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs + 16 B pad
+
+template <bool OUT_NHWC, int SRC>
+__global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict__ x,
+                                                      const float* __restrict__ src,
+                                                      const _Float16* __restrict__ wfrag,
+                                                      _Float16* __restrict__ out, int64_t Ntot, int C,
+                                                      int H, int W, int O, float stride, int relu,
+                                                      unsigned x_bytes) {
+  using T = _Float16;
+  using V = f16x8;
+  constexpr int NPOS = 128, NT = 4, ITEMS = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  PTap* s_tab = reinterpret_cast<PTap*>(smem);
+  char* s_B = smem + 128 * 9 * 16;
+  char* s_patch = s_B + 2 * 128 * kRowBytes;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t HW = (int64_t)H * W;
+  const int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int txn = (W + 15) / 16, tyn = (H + 7) / 8;
+  const int64_t bimg = tile / (txn * tyn);
+  const int trem = (int)(tile % (txn * tyn));
+  const int ty0 = (trem / txn) * 8, tx0 = (trem % txn) * 16;
+  const int oy = ty0 - kHalo, ox = tx0 - kHalo;
+  const int o0 = blockIdx.y * kMaxO;
+  const int Oloc = min(kMaxO, O - o0);
+  const int CC = C / 64;
+  const int nstage = 9 * CC;
+  const int G = O / 64;
+  const unsigned row_bytes = (unsigned)C * 2;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
+
+  // ---- loader waves: put the first patch in flight before anything else (its latency hides
+  // under the table build).  patch element v = L + 256*i: pixel v>>3, 16-byte channel group v&7;
+  // out-of-image pixels get an out-of-range offset -> the bounds-checked load returns zeros.
+  const int L = tid - 256;
+  unsigned pvoff[12];
+  V pv[12];
+  if (wave >= 4) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      int v = L + 256 * i, p = v >> 3, q = v & 7;
+      int yy = oy + p / kPW, xx = ox + p % kPW;
+      bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      pvoff[i] = in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
+      u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)pvoff[i], 0, 0);
+      pv[i] = __builtin_bit_cast(V, d);
+    }
+  }
+
+  // ---- per-position anchor context (cos/sin once per position, not once per tap)
+  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);   // B tiles are not in use yet
+  if (SRC == 1 && tid < NPOS) {
+    int y = ty0 + (tid >> 4), xq = tx0 + (tid & 15);
+    AnchorCtx c = {0, 0, 0, 0, 1, 0};
+    if (y < H && xq < W) c = anchor_ctx(src + (bimg * HW + (int64_t)y * W + xq) * 5, stride);
+    s_ctx[tid] = c;
+  }
+  if (SRC == 1) __syncthreads();
+
+  // ---- sampling table
+  for (int e = tid; e < NPOS * 9; e += 512) {
+    int pl = e / 9, t = e % 9;
+    int y = ty0 + (pl >> 4), xq = tx0 + (pl & 15);
+    PTap tp;
+    tp.y = (short)oy;
+    tp.x = (short)ox;
+    tp.flags = 1u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
+    if (y < H && xq < W) {
+      const int64_t p = (int64_t)y * W + xq;
+      int ky = t / 3, kx = t % 3;
+      float off_y, off_x;
+      if (SRC == 0) {
+        const float* ob = src + (bimg * 18) * HW + p;
+        off_y = ob[(int64_t)(2 * t) * HW];
+        off_x = ob[(int64_t)(2 * t + 1) * HW];
+      } else {
+        anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
+      }
+      float h_im = (float)(y - 1 + ky) + off_y;
+      float w_im = (float)(xq - 1 + kx) + off_x;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+        int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+        bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+        tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
+        tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
+        tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
+        tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
+        tp.y = (short)h_low;
+        tp.x = (short)w_low;
+        bool in = h_low >= oy && h_low + 1 <= oy + kPH - 1 && w_low >= ox && w_low + 1 <= ox + kPW - 1;
+        tp.flags = in ? 1u : 0u;
+      }
+    }
+    s_tab[e] = tp;
+  }
+  if (wave >= 4) {  // first patch -> LDS
+#pragma unroll
+    for (int i = 0; i < 12; i++) *reinterpret_cast<V*>(s_patch + (L + 256 * i) * 16) = pv[i];
+  }
+  __syncthreads();  // #1 table + patch 0 ready (s_ctx is dead from here on)
+
+  f32x16 acc[2][NT];
+  const bool wave_active = wave < 4 && wave * 64 < Oloc;
+  if (wave < 4) {
+    // ===================== MFMA waves =====================
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    const int g = min(o0 / 64 + wave, G - 1);
+    const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
+    V wA[2][4], wB[2][4];
+    auto load_w = [&](int s, V (&wv)[2][4]) {
+      const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
+    };
+    auto compute = [&](int s, const V (&wv)[2][4]) {
+      if (!wave_active || (S2A_ABL & 4)) return;
+      const char* prow = s_B + (s & 1) * (128 * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        V pf[NT];
+#pragma unroll
+        for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
+        // weights are the A operand: D rows = out channels (4 consecutive per register quad),
+        // D columns = positions (lane & 31)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < NT; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], pf[b], acc[a][b], 0, 0, 0);
+      }
+    };
+    const int last = nstage - 1;
+    load_w(0, wA);
+    __syncthreads();  // #2 stage 0 columns in LDS
+    int s = 0;
+    for (; s + 1 < nstage; s += 2) {
+      load_w(s + 1, wB);
+      compute(s, wA);
+      __syncthreads();
+      load_w(min(s + 2, last), wA);
+      compute(s + 1, wB);
+      __syncthreads();
+    }
+    if (s < nstage) {
+      compute(s, wA);
+      __syncthreads();
+    }
+  } else {
+    // ===================== loader waves =====================
+    auto patch_issue = [&](int cc) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)pvoff[i], cc * 128, 0);
+        pv[i] = __builtin_bit_cast(V, d);
+      }
+    };
+    auto patch_write = [&](int cc) {
+      char* P = s_patch + (cc & 1) * kPatchBytes;
+#pragma unroll
+      for (int i = 0; i < 12; i++) *reinterpret_cast<V*>(P + (L + 256 * i) * 16) = pv[i];
+    };
+    auto produce = [&](int s) {  // columns of stage s -> B[s&1]
+      if (S2A_ABL & 2) return;
+      const int t = s % 9, cc = s / 9;
+      const char* P = s_patch + (cc & 1) * kPatchBytes;
+      char* Bm = s_B + (s & 1) * (128 * kRowBytes);
+      // batched so that the LDS latencies overlap: 4 table reads, then 16 patch reads, then 4 blends
+      PTap tp[ITEMS];
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) tp[it] = s_tab[((L + 256 * it) >> 3) * 9 + t];
+      V c[ITEMS][4];
+      bool any_out = false;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) {
+        const int q = (L + 256 * it) & 7;
+        // out-of-patch items read a clamped (wrong) location here and are redone below
+        int py = min(max((int)tp[it].y - oy, 0), kPH - 2), px = min(max((int)tp[it].x - ox, 0), kPW - 2);
+        const char* b0 = P + (py * kPW + px) * 128 + q * 16;
+        c[it][0] = *reinterpret_cast<const V*>(b0);
+        c[it][1] = *reinterpret_cast<const V*>(b0 + 128);
+        c[it][2] = *reinterpret_cast<const V*>(b0 + kPW * 128);
+        c[it][3] = *reinterpret_cast<const V*>(b0 + kPW * 128 + 128);
+        any_out |= !(tp[it].flags & 1u);
+      }
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) {
+        const int item = L + 256 * it, pl = item >> 3, q = item & 7;
+        const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
+        *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_pk(c[it], cw);
+      }
+      if (any_out) {  // rare: a corner left the patch -> global gather for that (position, tap)
+        for (int it = 0; it < ITEMS; it++) {
+          if (tp[it].flags & 1u) continue;
+          const int item = L + 256 * it, pl = item >> 3, q = item & 7;
+          V g4[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            int yy = min(max((int)tp[it].y + (k >> 1), 0), H - 1), xx = min(max((int)tp[it].x + (k & 1), 0), W - 1);
+            unsigned vo = (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16);
+            u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, cc * 128, 0);
+            g4[k] = __builtin_bit_cast(V, d);
+          }
+          const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
+          *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_pk(g4, cw);
+        }
+      }
+    };
+
+    if (CC > 1) patch_issue(1);
+    produce(0);
+    __syncthreads();  // #2 stage 0 columns in LDS
+    for (int s = 0; s < nstage; s++) {
+      const int sn = s + 1;          // stage produced while stage s is consumed
+      if (sn < nstage) {
+        const int t = sn % 9, cc = sn / 9;
+        if (t == 4 && cc + 1 < CC) patch_write(cc + 1);   // loads issued >= 3 stages ago
+        produce(sn);
+        if (t == 8 && cc + 2 < CC) patch_issue(cc + 2);   // next-next chunk: lands during the next chunk
+      }
+      __syncthreads();
+    }
+  }
+
+  // ===================== epilogue =====================
+  if ((S2A_ABL & 1) && relu != 12345) return;
+  if constexpr (OUT_NHWC) {
+    // Stage the 128 x 256 tile through LDS (the patch buffers are free now) and store whole
+    // 512-byte position rows, 16 B per lane, instead of 2-byte scattered stores.
+    char* s_out = s_patch;
+    if (wave_active) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+#pragma unroll
+          for (int rq = 0; rq < 4; rq++) {
+            using h4 = __attribute__((ext_vector_type(4))) _Float16;
+            h4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              float v = acc[a][b][rq * 4 + e];
+              if (relu) v = fmaxf(v, 0.f);
+              v4[e] = (_Float16)v;
+            }
+            int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);   // rows (r&3)+8*(r>>2)+4*(lane>>5)
+            int pos = 32 * b + (lane & 31);
+            *reinterpret_cast<h4*>(s_out + pos * kOutRow + och * 2) = v4;
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      int idx = tid + 512 * i, pos = idx >> 5, col = idx & 31;
+      int64_t gp = tile_pos(tile, pos, 8, H, W, HW, Ntot);
+      if (gp >= 0 && col * 8 < Oloc)
+        *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
+    }
+  } else {
+    if (!wave_active) return;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float v = acc[a][b][r];
+          if (relu) v = fmaxf(v, 0.f);
+          int och = o0 + wave * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          int64_t gp = tile_pos(tile, 32 * b + (lane & 31), 8, H, W, HW, Ntot);
+          if (gp >= 0) {
+            int64_t bi = gp / HW, p = gp % HW;
+            out[(bi * O + och) * HW + p] = (T)v;
+          }
+        }
+  }
+}
+
 template <int NPOS>
 constexpr int mfma_lds_bytes() { return NPOS * 9 * 32 + 2 * (kMaxO + NPOS) * kRowBytes; }  // 110592 / 147456
 
@@ -714,8 +1048,8 @@ inline bool fast_path_ok(const s2a_dcn_params& p) {
 inline size_t esize(int dtype) { return dtype == S2A_DTYPE_F32 ? 4 : 2; }
 
 template <typename T>
-int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* wp, T* out,
-                bool out_nhwc, int64_t B, int C, int H, int W, int O, float stride, int relu,
+int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* wp, const T* wfrag,
+                T* out, bool out_nhwc, int64_t B, int C, int H, int W, int O, float stride, int relu,
                 hipStream_t st) {
   const int64_t Ntot = B * (int64_t)H * W;
   // 128-position tiles once they still give every CU >= 2 workgroups; else 64
@@ -747,7 +1081,24 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
     if (drop && strchr(drop, 'w')) wb = 0;                                                        \
     kern<<<grid, 512, lds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu, xb, wb);   \
   } while (0)
-#define S2A_DCN_PICK(NHWC, SRC) do { if (ws_ok) S2A_DCN_LAUNCH_WS(NHWC, SRC); else if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
+  const char* variant = getenv("S2A_DCN_VARIANT");   // A/B switch for measurements: "ws" | "mfma"
+  bool patch_ok = false;
+  if constexpr (sizeof(T) == 2)
+    patch_ok = ntiles(128) >= 128 && x_bytes < (1ull << 31) && !getenv("S2A_DCN_NO_WS") && wfrag != nullptr && C % 64 == 0 && H < 32000 && W < 32000 &&
+               !(variant && (!strcmp(variant, "ws") || !strcmp(variant, "mfma")));
+  const bool ws_use = ws_ok && !(variant && !strcmp(variant, "mfma"));
+#define S2A_DCN_LAUNCH_PATCH(NHWC, SRC)                                                           \
+  do {                                                                                            \
+    if constexpr (sizeof(T) == 2) {                                                               \
+      auto kern = k_dcn_patch<NHWC, SRC>;                                                         \
+      dim3 grid((unsigned)ntiles(128), (unsigned)((O + kMaxO - 1) / kMaxO));                      \
+      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));        \
+      kern<<<grid, 512, kPatchLds, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, relu, \
+                                         (unsigned)x_bytes);                                      \
+    }                                                                                             \
+  } while (0)
+#define S2A_DCN_PICK(NHWC, SRC) do { if (patch_ok) S2A_DCN_LAUNCH_PATCH(NHWC, SRC); else if (ws_use) S2A_DCN_LAUNCH_WS(NHWC, SRC); else if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
   if (out_nhwc) {
     if (from_anchors) S2A_DCN_PICK(true, 1); else S2A_DCN_PICK(true, 0);
   } else {
@@ -755,6 +1106,7 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
   }
 #undef S2A_DCN_PICK
 #undef S2A_DCN_LAUNCH_WS
+#undef S2A_DCN_LAUNCH_PATCH
 #undef S2A_DCN_LAUNCH
   S2A_LAUNCH_CHECK();
   return S2A_OK;
@@ -768,7 +1120,9 @@ int run_fast(const void* input, const float* src, bool from_anchors, const void*
   S2A_CHECK_ARG(((uintptr_t)input % 16) == 0 && ((uintptr_t)output % 16) == 0 && ((uintptr_t)weight % 16) == 0 &&
                 ((uintptr_t)ws % 16) == 0, "deform_conv: tensors must be 16-byte aligned");
   Carver cv(ws, ws_bytes);
-  T* wp = weight_packed ? const_cast<T*>((const T*)weight) : cv.take<T>((size_t)O * C * 9);
+  const size_t wel = (size_t)O * C * 9;
+  const bool has_frag = sizeof(T) == 2;             // f16 packs both layouts back to back
+  T* wp = weight_packed ? const_cast<T*>((const T*)weight) : cv.take<T>(wel * (has_frag ? 2 : 1));
   T* xn = nullptr;
   if (layout == S2A_LAYOUT_NCHW) xn = cv.take<T>((size_t)B * C * H * W);
   if (!wp || (layout == S2A_LAYOUT_NCHW && !xn)) {
@@ -776,8 +1130,12 @@ int run_fast(const void* input, const float* src, bool from_anchors, const void*
     return S2A_EWORKSPACE;
   }
   const int64_t wtot = (int64_t)O * C * 9;
-  if (!weight_packed)
+  if (!weight_packed) {
     k_pack_weight<T><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const T*)weight, O, C, KC, wp);
+    if constexpr (sizeof(T) == 2)
+      k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, O, C, wp + wel);
+  }
+  const T* wfrag = has_frag ? wp + wel : nullptr;
   const T* x_nhwc = (const T*)input;
   if (layout == S2A_LAYOUT_NCHW) {
     int64_t HW = (int64_t)H * W;
@@ -785,8 +1143,8 @@ int run_fast(const void* input, const float* src, bool from_anchors, const void*
     k_nchw_to_nhwc<T><<<g, 256, 0, st>>>((const T*)input, B, C, HW, xn);
     x_nhwc = xn;
   }
-  return launch_fast<T>(x_nhwc, src, from_anchors, wp, (T*)output, layout == S2A_LAYOUT_NHWC, B, C, H,
-                        W, O, stride, relu, st);
+  return launch_fast<T>(x_nhwc, src, from_anchors, wp, wfrag, (T*)output, layout == S2A_LAYOUT_NHWC, B, C,
+                        H, W, O, stride, relu, st);
 }
 
 }  // namespace
@@ -797,7 +1155,7 @@ using namespace s2a;
 extern "C" size_t s2a_deform_conv_workspace_bytes(const s2a_dcn_params* p) {
   if (!p) return 0;
   size_t es = esize(p->dtype);
-  size_t b = align_up((size_t)p->out_channels * p->channels * p->kH * p->kW * es) + 256;
+  size_t b = align_up((size_t)p->out_channels * p->channels * p->kH * p->kW * es * 2) + 256;
   if (p->layout == S2A_LAYOUT_NCHW) b += align_up((size_t)p->batch * p->channels * p->height * p->width * es);
   return b;
 }
@@ -849,7 +1207,7 @@ extern "C" int s2a_deform_conv_forward(const void* input, const void* weight, co
 extern "C" size_t s2a_align_conv_workspace_bytes(const s2a_align_params* p) {
   if (!p) return 0;
   size_t es = esize(p->dtype);
-  size_t b = align_up((size_t)p->out_channels * p->channels * 9 * es) + 256;
+  size_t b = align_up((size_t)p->out_channels * p->channels * 9 * es * 2) + 256;
   if (p->layout == S2A_LAYOUT_NCHW) b += align_up((size_t)p->batch * p->channels * p->height * p->width * es);
   return b;
 }
@@ -887,10 +1245,19 @@ extern "C" int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int
   S2A_CHECK_ARG(weight && packed, "dcn_pack_weight: NULL tensor");
   const int64_t wtot = out_channels * channels * 9;
   hipStream_t st = as_stream(stream);
-  if (dtype == S2A_DTYPE_F32)
+  if (dtype == S2A_DTYPE_F32) {
     k_pack_weight<float><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const float*)weight, (int)out_channels, (int)channels, kc, (float*)packed);
-  else
+  } else {
+    S2A_CHECK_ARG(out_channels % 64 == 0, "dcn_pack_weight: out_channels must be a multiple of 64");
     k_pack_weight<_Float16><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, kc, (_Float16*)packed);
+    k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + wtot);
+  }
   S2A_LAUNCH_CHECK();
   return S2A_OK;
+}
+
+extern "C" int64_t s2a_dcn_packed_elems(int64_t out_channels, int64_t channels, int dtype) {
+  // f16 holds two layouts back to back (stage-major for the LDS-staged kernels, MFMA-fragment
+  // order for the patch-staged kernel)
+  return out_channels * channels * 9 * (dtype == S2A_DTYPE_F16 ? 2 : 1);
 }

@@ -23,24 +23,24 @@ def rboxes(rng, n, span=1024.0):
     b[:, :2] = rng.uniform(0, span, (n, 2)); b[:, 2:4] = rng.uniform(4, 100, (n, 2)); b[:, 4] = rng.uniform(-np.pi/4, 3*np.pi/4, n)
     return b
 
-def alignconv(batch, dtype, H=128, W=128, C=256, O=256, stride=8):
+def alignconv(batch, dtype, H=128, W=128, C=256, O=256, stride=8, sigma=0.5, jitter=4.0):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(batch, C, H, W, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last)
     ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
     anc = torch.zeros(batch, H, W, 5)
-    anc[..., 0] = xs * stride + 0.5*(stride-1) + torch.randn(batch, H, W, generator=g) * 4
-    anc[..., 1] = ys * stride + 0.5*(stride-1) + torch.randn(batch, H, W, generator=g) * 4
-    anc[..., 2:4] = 4 * stride * torch.exp(torch.randn(batch, H, W, 2, generator=g) * 0.5)
+    anc[..., 0] = xs * stride + 0.5*(stride-1) + torch.randn(batch, H, W, generator=g) * jitter
+    anc[..., 1] = ys * stride + 0.5*(stride-1) + torch.randn(batch, H, W, generator=g) * jitter
+    anc[..., 2:4] = 4 * stride * torch.exp(torch.randn(batch, H, W, 2, generator=g) * sigma)
     anc[..., 4] = (torch.rand(batch, H, W, generator=g) - 0.25) * math.pi
     anc = anc.to(dev)
     w = (torch.randn(O, C, 3, 3, generator=g) * 0.01).to(dev, dtype)
     wp = pack_weight(w, dtype)
-    sec = timeit(lambda: align_conv_forward(x, anc, wp, stride, relu=True, packed=True))
+    sec = timeit(lambda: align_conv_forward(x, anc, wp, stride, relu=True, packed=True, out_channels=O))
     flops = 2.0 * O * C * 9 * batch * H * W
     es = 2 if dtype == torch.float16 else 4
     byts = batch*H*W*(C+O)*es + O*C*9*es + batch*H*W*20
     peak = 2500.0 if es == 2 else 157.3
-    return dict(op="alignconv_fused", dtype=str(dtype).split(".")[-1], batch=batch, hw=[H, W], us=round(sec*1e6, 1),
+    return dict(op="alignconv_fused", sigma=sigma, dtype=str(dtype).split(".")[-1], batch=batch, hw=[H, W], us=round(sec*1e6, 1),
                 tflops=round(flops/sec/1e12, 1), mfma_frac=round(flops/sec/1e12/peak, 4),
                 alg_GBs=round(byts/sec/1e9, 1), hbm_frac=round(byts/sec/1e9/8000, 4))
 
@@ -74,6 +74,9 @@ if __name__ == "__main__":
         res.append(alignconv(8, torch.float16, 64, 64, stride=16))
     if a.which == "align8":
         res.append(alignconv(8, torch.float16))
+    if a.which == "align8s":
+        for sg in (0.0, 0.25, 0.5, 0.75):
+            res.append(alignconv(8, torch.float16, sigma=sg))
     if a.which in ("all", "iou"):
         res.append(iou(10000, 10000)); res.append(iou(21824, 128))
     if a.which == "nms200k":
