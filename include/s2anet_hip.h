@@ -105,6 +105,19 @@ int s2a_nms_rotated_segmented(const float* dets, const float* scores, const int3
                               int32_t* keep, int32_t* group_counts, int32_t max_per_group,
                               void* workspace, size_t workspace_bytes, s2a_stream_t stream);
 
+/* Candidate selection of multiclass_nms_rotated (utils/bbox_nms_rotated.py:29-42) for a whole
+ * batch: every (box, class) pair with score > score_thr, in row-major (image, box, class) order,
+ * compacted into `cap` slots (first `cap` in that order if there are more; *count_dev holds the
+ * untruncated count).  boxes[batch*n,5], scores[batch*n*num_classes] f32.  Unused slots become
+ * padding rows: out_seg = out_grp = out_cls = -1, score -1 (ignored by
+ * s2a_nms_rotated_segmented).  out_seg = image*num_classes + class, out_grp = image. */
+size_t s2a_multiclass_candidates_workspace_bytes(int64_t total_scores);
+int s2a_multiclass_candidates(const float* boxes, const float* scores, int64_t batch, int64_t n,
+                              int64_t num_classes, float score_thr, int64_t cap, float* out_boxes,
+                              float* out_scores, int32_t* out_seg, int32_t* out_grp, int32_t* out_cls,
+                              int64_t* count_dev, void* workspace, size_t workspace_bytes,
+                              s2a_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * ORN.  Replaces  models.orn.orn_cuda.arf_forward(weight[O,I,nOri,kH,kW], indices u8
  * [nOri,kH,kW,nRot]) -> [O*nRot, I*nOri, kH, kW]

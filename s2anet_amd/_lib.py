@@ -50,6 +50,9 @@ SYMBOLS = {
     "s2a_nms_rotated_segmented": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int32,
                                           ctypes.c_int32, c_f32, c_vp, c_vp, c_vp, ctypes.c_int32,
                                           c_vp, c_sz, c_vp]),
+    "s2a_multiclass_candidates_workspace_bytes": (c_sz, [c_i64]),
+    "s2a_multiclass_candidates": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i64, c_vp, c_vp, c_vp,
+                                          c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "s2a_arf_forward": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp,
                                 c_vp]),
     "s2a_rot_inv_pool": (c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp]),

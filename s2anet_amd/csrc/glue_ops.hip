@@ -103,17 +103,18 @@ __global__ void k_align_offsets(const float* __restrict__ anchors, int64_t B, in
 // y = act(y + bias[c] (+ residual)) in place, channels-last (the channel is the fastest
 // dimension): one pass instead of the three (bias add, residual add, ReLU) the stock
 // elementwise kernels make after every convolution.  8 halfs / 4 floats per lane (16 B).
-template <typename T, int VEC>
+template <typename T, int VEC, bool HOIST>
 __global__ __launch_bounds__(256) void k_bias_act(T* __restrict__ y, const T* __restrict__ bias,
                                                   const T* __restrict__ res, int64_t nvec, int cvec,
                                                   int relu) {
   using V = T __attribute__((ext_vector_type(VEC)));
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    V v = reinterpret_cast<V*>(y)[i];
-    V b = reinterpret_cast<const V*>(bias)[i % cvec];
-    V r;
-    if (res) r = reinterpret_cast<const V*>(res)[i];
+  const int64_t T0 = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // HOIST: the launch makes the total thread count a multiple of cvec (cvec is a power of two
+  // <= 256 for every layer of the network), so a thread always meets the same channel group
+  V b0;
+  if (HOIST) b0 = reinterpret_cast<const V*>(bias)[i0 % cvec];
+  auto apply = [&](V v, V b, V r) {
 #pragma unroll
     for (int e = 0; e < VEC; e++) {
       float f = (float)v[e] + (float)b[e];
@@ -121,7 +122,26 @@ __global__ __launch_bounds__(256) void k_bias_act(T* __restrict__ y, const T* __
       if (relu) f = fmaxf(f, 0.f);
       v[e] = (T)f;
     }
-    reinterpret_cast<V*>(y)[i] = v;
+    return v;
+  };
+  int64_t i = i0;
+  // four independent 16-byte streams per lane in flight
+  for (; i + 3 * T0 < nvec; i += 4 * T0) {
+    V v[4], r[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[k] = reinterpret_cast<V*>(y)[i + k * T0];
+      if (res) r[k] = reinterpret_cast<const V*>(res)[i + k * T0];
+      b[k] = HOIST ? b0 : reinterpret_cast<const V*>(bias)[(i + k * T0) % cvec];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) reinterpret_cast<V*>(y)[i + k * T0] = apply(v[k], b[k], r[k]);
+  }
+  for (; i < nvec; i += T0) {
+    V v = reinterpret_cast<V*>(y)[i], r;
+    if (res) r = reinterpret_cast<const V*>(res)[i];
+    V b = HOIST ? b0 : reinterpret_cast<const V*>(bias)[i % cvec];
+    reinterpret_cast<V*>(y)[i] = apply(v, b, r);
   }
 }
 
@@ -141,12 +161,18 @@ extern "C" int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual
   S2A_CHECK_ARG(((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0 && ((uintptr_t)residual % 16) == 0,
                 "bias_act: tensors must be 16-byte aligned");
   const int64_t nvec = positions * channels / vec;
-  unsigned g = (unsigned)std::min<int64_t>((nvec + 255) / 256, 256 * 16);
+  const int cvec = (int)(channels / vec);
+  unsigned g = (unsigned)std::min<int64_t>((nvec + 1023) / 1024, 256 * 8);
+  if (g == 0) g = 1;
+  const bool hoist = cvec <= 256 && (256 % cvec) == 0;   // then gridDim*256 is a multiple of cvec
   hipStream_t st = as_stream(stream);
-  if (dtype == S2A_DTYPE_F16)
-    k_bias_act<_Float16, 8><<<g, 256, 0, st>>>((_Float16*)y, (const _Float16*)bias, (const _Float16*)residual, nvec, (int)(channels / 8), relu);
-  else
-    k_bias_act<float, 4><<<g, 256, 0, st>>>((float*)y, (const float*)bias, (const float*)residual, nvec, (int)(channels / 4), relu);
+#define S2A_BA(T, V, H) k_bias_act<T, V, H><<<g, 256, 0, st>>>((T*)y, (const T*)bias, (const T*)residual, nvec, cvec, relu)
+  if (dtype == S2A_DTYPE_F16) {
+    if (hoist) S2A_BA(_Float16, 8, true); else S2A_BA(_Float16, 8, false);
+  } else {
+    if (hoist) S2A_BA(float, 4, true); else S2A_BA(float, 4, false);
+  }
+#undef S2A_BA
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -852,6 +852,96 @@ extern "C" int s2a_box_iou_rotated_pairs(const float* boxes1, const float* boxes
   return S2A_OK;
 }
 
+// ---------------------------------------------------------------- multiclass candidates
+// utils/bbox_nms_rotated.py:29-42 for a whole batch, static shapes, no host round trip:
+// (box, class) pairs with score > thr, in row-major (image, box, class) order, compacted into
+// `cap` slots; unused slots are padding rows (segment id -1, ignored by the segmented NMS).
+namespace s2a {
+namespace {
+struct ScoreAbove {
+  const float* s;
+  float thr;
+  __device__ uint8_t operator()(int i) const { return s[i] > thr ? 1 : 0; }
+};
+
+__global__ void k_gather_candidates(const float* __restrict__ boxes5, const float* __restrict__ scores,
+                                    const int32_t* __restrict__ sel, const unsigned long long* __restrict__ count,
+                                    int64_t cap, int n, int C, float* __restrict__ obox,
+                                    float* __restrict__ oscore, int32_t* __restrict__ oseg,
+                                    int32_t* __restrict__ ogrp, int32_t* __restrict__ ocls) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  const bool valid = (unsigned long long)i < *count;
+  int32_t flat = valid ? sel[i] : 0;
+  int32_t cls = flat % C;
+  int32_t row = flat / C;          // image * n + box
+  int32_t img = row / n;
+#pragma unroll
+  for (int k = 0; k < 5; k++) obox[i * 5 + k] = valid ? boxes5[(int64_t)row * 5 + k] : 0.f;
+  oscore[i] = valid ? scores[flat] : -1.f;
+  oseg[i] = valid ? img * C + cls : -1;
+  ogrp[i] = valid ? img : -1;
+  ocls[i] = valid ? cls : -1;
+}
+}  // namespace
+}  // namespace s2a
+
+extern "C" size_t s2a_multiclass_candidates_workspace_bytes(int64_t total) {
+  size_t tb = 0;
+  hipStream_t s0 = nullptr;
+  int32_t* i32 = nullptr;
+  unsigned long long* cnt = nullptr;
+  uint8_t* f = nullptr;
+  if (rocprim::select(nullptr, tb, i32, f, i32, cnt, (size_t)std::max<int64_t>(total, 1), s0) != hipSuccess) {
+    (void)hipGetLastError();
+    tb = (size_t)total * 8 + (1u << 20);
+  }
+  return align_up(tb) + align_up((size_t)total * 4) + align_up((size_t)total) + 1024;
+}
+
+extern "C" int s2a_multiclass_candidates(const float* boxes, const float* scores, int64_t batch,
+                                         int64_t n, int64_t num_classes, float score_thr, int64_t cap,
+                                         float* out_boxes, float* out_scores, int32_t* out_seg,
+                                         int32_t* out_grp, int32_t* out_cls, int64_t* count_dev,
+                                         void* workspace, size_t workspace_bytes, s2a_stream_t stream) {
+  const int64_t total = batch * n * num_classes;
+  S2A_CHECK_ARG(batch >= 0 && n >= 0 && num_classes > 0 && cap > 0, "multiclass_candidates: bad shape");
+  S2A_CHECK_ARG(total < (1ll << 31), "multiclass_candidates: too many scores");
+  S2A_CHECK_ARG(out_boxes && out_scores && out_seg && out_grp && out_cls && count_dev, "multiclass_candidates: NULL output");
+  hipStream_t st = as_stream(stream);
+  if (total == 0) {
+    S2A_HIP(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
+    S2A_HIP(hipMemsetAsync(out_seg, 0xff, (size_t)cap * 4, st));
+    S2A_HIP(hipMemsetAsync(out_grp, 0xff, (size_t)cap * 4, st));
+    return S2A_OK;
+  }
+  S2A_CHECK_ARG(boxes && scores, "multiclass_candidates: NULL input");
+  Carver cv(workspace, workspace_bytes);
+  int32_t* sel = cv.take<int32_t>((size_t)total);
+  size_t tb = 0;
+  {
+    hipStream_t s0 = nullptr;
+    int32_t* i32 = nullptr;
+    unsigned long long* cnt = nullptr;
+    uint8_t* f = nullptr;
+    S2A_HIP(rocprim::select(nullptr, tb, i32, f, i32, cnt, (size_t)total, s0));
+  }
+  char* temp = cv.take<char>(tb);
+  if (!sel || !temp) {
+    set_error("multiclass_candidates: workspace too small (%zu bytes)", workspace_bytes);
+    return S2A_EWORKSPACE;
+  }
+  rocprim::counting_iterator<int32_t> ids(0);
+  auto flags = rocprim::make_transform_iterator(ids, ScoreAbove{scores, score_thr});
+  S2A_HIP(rocprim::select(temp, tb, ids, flags, sel, reinterpret_cast<unsigned long long*>(count_dev),
+                          (size_t)total, st));
+  k_gather_candidates<<<(unsigned)((cap + 255) / 256), 256, 0, st>>>(
+      boxes, scores, sel, reinterpret_cast<const unsigned long long*>(count_dev), cap, (int)n,
+      (int)num_classes, out_boxes, out_scores, out_seg, out_grp, out_cls);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
 extern "C" size_t s2a_nms_rotated_workspace_bytes(int64_t n, int64_t max_segment_rows) {
   return nms_workspace_bytes(n, max_segment_rows);
 }

@@ -145,43 +145,31 @@ def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, 
     _lib.require_cuda(bboxes, scores)
     B, n, C = scores.shape
     dev = bboxes.device
-    bb = _f32c(bboxes)
-    sc = _f32c(scores)
+    bb = _f32c(bboxes).reshape(-1, 5)
+    sc = _f32c(scores).reshape(-1)
     total = B * n * C
     cap = total if max_candidates is None else min(int(max_candidates), total)
-    flat = sc.reshape(-1)
-    valid = flat > score_thr
-    if cap == total:
-        cand = torch.arange(total, device=dev, dtype=torch.int64)
-        cand_valid = valid
-    else:
-        # static-size compaction: positions of the first `cap` candidates (stable order)
-        pos = torch.cumsum(valid.to(torch.int32), 0) - 1
-        cand = torch.zeros((cap,), dtype=torch.int64, device=dev)
-        cand_valid = torch.zeros((cap,), dtype=torch.bool, device=dev)
-        sel = valid & (pos < cap)
-        src = torch.arange(total, device=dev, dtype=torch.int64)
-        cand.scatter_(0, pos.clamp(0, cap - 1).to(torch.int64)[sel], src[sel])
-        cand_valid.scatter_(0, pos.clamp(0, cap - 1).to(torch.int64)[sel], sel[sel])
-    img = (cand // (n * C)).to(torch.int32)
-    cls = (cand % C).to(torch.int32)
-    row = cand // C                                     # index into bb.reshape(B*n,5)
-    cboxes = bb.reshape(-1, 5)[row].contiguous()
-    cscores = flat[cand].contiguous()
-    neg = torch.full_like(img, -1)
-    seg = torch.where(cand_valid, img * C + cls, neg).contiguous()   # < 0: padding row, ignored
-    grp = torch.where(cand_valid, img, neg).contiguous()
-    N = cboxes.shape[0]
     L = _lib.lib()
+    cboxes = torch.empty((cap, 5), dtype=torch.float32, device=dev)
+    cscores = torch.empty((cap,), dtype=torch.float32, device=dev)
+    seg = torch.empty((cap,), dtype=torch.int32, device=dev)
+    grp = torch.empty((cap,), dtype=torch.int32, device=dev)
+    cls = torch.empty((cap,), dtype=torch.int32, device=dev)
+    ncand = torch.empty((1,), dtype=torch.int64, device=dev)
     keep = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
+        st = _lib.stream_ptr(dev)
+        ws = _lib.workspace(L.s2a_multiclass_candidates_workspace_bytes(total), dev, "cand")
+        _lib.check(L.s2a_multiclass_candidates(_lib.ptr(bb), _lib.ptr(sc), B, n, C, float(score_thr), cap,
+                                               _lib.ptr(cboxes), _lib.ptr(cscores), _lib.ptr(seg), _lib.ptr(grp),
+                                               _lib.ptr(cls), _lib.ptr(ncand), _lib.ptr(ws), ws.numel(), st))
         # one (image, class) segment holds at most n rows: tight bound for the mask workspace
-        ws = _lib.workspace(L.s2a_nms_rotated_workspace_bytes(N, min(N, n)), dev, "nms_b")
+        ws2 = _lib.workspace(L.s2a_nms_rotated_workspace_bytes(cap, min(cap, n)), dev, "nms_b")
         _lib.check(L.s2a_nms_rotated_segmented(
-            _lib.ptr(cboxes), _lib.ptr(cscores), _lib.ptr(seg), _lib.ptr(grp), N, B * C, B,
+            _lib.ptr(cboxes), _lib.ptr(cscores), _lib.ptr(seg), _lib.ptr(grp), cap, B * C, B,
             float(iou_thr), None, _lib.ptr(keep), _lib.ptr(counts), int(max_per_img),
-            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+            _lib.ptr(ws2), ws2.numel(), st))
     ok = keep >= 0
     kidx = keep.clamp(min=0).to(torch.int64)
     dets = torch.cat([cboxes[kidx], cscores[kidx][..., None]], dim=-1)
