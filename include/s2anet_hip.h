@@ -212,6 +212,10 @@ int s2a_fam_refine_anchors(const void* bbox_pred, int64_t batch, int64_t height,
 int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual, int64_t positions,
                       int64_t channels, int dtype, int relu, s2a_stream_t stream);
 
+/* Diagnostic builds only (-DS2A_STAMP=1): per-workgroup s_memtime phase stamps of the AlignConv
+ * kernel; returns S2A_ENOTIMPL in a normal build. */
+int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

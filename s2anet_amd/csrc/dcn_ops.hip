@@ -39,6 +39,30 @@ namespace {
 #ifndef S2A_ABL
 #define S2A_ABL 0
 #endif
+#ifndef S2A_STAMP
+#define S2A_STAMP 0
+#endif
+#if S2A_STAMP
+// diagnostic build only: per-workgroup phase stamps (s_memtime) into a buffer nothing else reads
+__device__ unsigned long long g_stamps[4096 * 16];
+#define S2A_STAMP_AT(slot)                                                                   \
+  do {                                                                                       \
+    if (lane == 0 && (wave == 0 || wave == 4))                                               \
+      g_stamps[((blockIdx.x & 4095) * 16) + (wave ? 8 : 0) + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define S2A_TIC() (t_tic = __builtin_amdgcn_s_memtime())
+#define S2A_TOC(accv) (accv += __builtin_amdgcn_s_memtime() - t_tic)
+#define S2A_STAMP_VAL(slot, val)                                                             \
+  do {                                                                                       \
+    if (lane == 0 && (wave == 0 || wave == 4))                                               \
+      g_stamps[((blockIdx.x & 4095) * 16) + (wave ? 8 : 0) + (slot)] = (val);                \
+  } while (0)
+#else
+#define S2A_STAMP_AT(slot) do {} while (0)
+#define S2A_TIC() do {} while (0)
+#define S2A_TOC(accv) do {} while (0)
+#define S2A_STAMP_VAL(slot, val) do {} while (0)
+#endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -724,6 +748,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   const unsigned row_bytes = (unsigned)C * 2;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
 
+  S2A_STAMP_AT(0);
   // ---- loader waves: put the first patch in flight before anything else (its latency hides
   // under the table build).  patch element v = L + 256*i: pixel v>>3, 16-byte channel group v&7;
   // out-of-image pixels get an out-of-range offset -> the bounds-checked load returns zeros.
@@ -741,6 +766,20 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       pv[i] = __builtin_bit_cast(V, d);
     }
   }
+
+  // ---- MFMA waves: first weight fragments in flight now as well (one memory latency for the
+  // whole prologue instead of three in a row)
+  const int g = min(o0 / 64 + (wave & 3), G - 1);
+  const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
+  V wA[2][4], wB[2][4];
+  auto load_w = [&](int s, V (&wv)[2][4]) {
+    const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
+  };
+  if (wave < 4) load_w(0, wA);
 
   // ---- per-position anchor context (cos/sin once per position, not once per tap)
   AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);   // B tiles are not in use yet
@@ -795,7 +834,9 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
     for (int i = 0; i < 12; i++) *reinterpret_cast<V*>(s_patch + (L + 256 * i) * 16) = pv[i];
   }
+  S2A_STAMP_AT(1);
   __syncthreads();  // #1 table + patch 0 ready (s_ctx is dead from here on)
+  S2A_STAMP_AT(2);
 
   f32x16 acc[2][NT];
   const bool wave_active = wave < 4 && wave * 64 < Oloc;
@@ -807,16 +848,6 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       for (int b = 0; b < NT; b++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-    const int g = min(o0 / 64 + wave, G - 1);
-    const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
-    V wA[2][4], wB[2][4];
-    auto load_w = [&](int s, V (&wv)[2][4]) {
-      const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
-    };
     auto compute = [&](int s, const V (&wv)[2][4]) {
       if (!wave_active || (S2A_ABL & 4)) return;
       const char* prow = s_B + (s & 1) * (128 * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
@@ -835,21 +866,30 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       }
     };
     const int last = nstage - 1;
-    load_w(0, wA);
     __syncthreads();  // #2 stage 0 columns in LDS
+    S2A_STAMP_AT(3);
     int s = 0;
+    unsigned long long t_tic = 0, t_work = 0, t_wait = 0;
+    (void)t_tic; (void)t_work; (void)t_wait;
     for (; s + 1 < nstage; s += 2) {
+      S2A_TIC();
       load_w(s + 1, wB);
       compute(s, wA);
+      S2A_TOC(t_work); S2A_TIC();
       __syncthreads();
+      S2A_TOC(t_wait); S2A_TIC();
       load_w(min(s + 2, last), wA);
       compute(s + 1, wB);
+      S2A_TOC(t_work); S2A_TIC();
       __syncthreads();
+      S2A_TOC(t_wait);
     }
     if (s < nstage) {
       compute(s, wA);
       __syncthreads();
     }
+    S2A_STAMP_VAL(6, t_work);
+    S2A_STAMP_VAL(7, t_wait);
   } else {
     // ===================== loader waves =====================
     auto patch_issue = [&](int cc) {
@@ -913,19 +953,29 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 
     if (CC > 1) patch_issue(1);
     produce(0);
+    S2A_STAMP_AT(6);
     __syncthreads();  // #2 stage 0 columns in LDS
+    S2A_STAMP_AT(3);
+    unsigned long long t_tic = 0, t_work = 0, t_wait = 0;
+    (void)t_tic; (void)t_work; (void)t_wait;
     for (int s = 0; s < nstage; s++) {
       const int sn = s + 1;          // stage produced while stage s is consumed
+      S2A_TIC();
       if (sn < nstage) {
         const int t = sn % 9, cc = sn / 9;
         if (t == 4 && cc + 1 < CC) patch_write(cc + 1);   // loads issued >= 3 stages ago
         produce(sn);
         if (t == 8 && cc + 2 < CC) patch_issue(cc + 2);   // next-next chunk: lands during the next chunk
       }
+      S2A_TOC(t_work); S2A_TIC();
       __syncthreads();
+      S2A_TOC(t_wait);
     }
+    S2A_STAMP_VAL(7, t_work);
+    S2A_STAMP_VAL(5, t_wait);   // (loader slot 5 = 13 overall; its end stamp is not used)
   }
 
+  S2A_STAMP_AT(4);
   // ===================== epilogue =====================
   if ((S2A_ABL & 1) && relu != 12345) return;
   if constexpr (OUT_NHWC) {
@@ -960,6 +1010,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       if (gp >= 0 && col * 8 < Oloc)
         *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
     }
+    S2A_STAMP_AT(5);
   } else {
     if (!wave_active) return;
 #pragma unroll
@@ -1260,4 +1311,15 @@ extern "C" int64_t s2a_dcn_packed_elems(int64_t out_channels, int64_t channels, 
   // f16 holds two layouts back to back (stage-major for the LDS-staged kernels, MFMA-fragment
   // order for the patch-staged kernel)
   return out_channels * channels * 9 * (dtype == S2A_DTYPE_F16 ? 2 : 1);
+}
+
+extern "C" int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count) {
+#if S2A_STAMP
+  S2A_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(s2a::g_stamps), (size_t)count * 8));
+  return S2A_OK;
+#else
+  (void)host_dst; (void)count;
+  s2a::set_error("s2a_debug_read_stamps: not a diagnostic build");
+  return S2A_ENOTIMPL;
+#endif
 }

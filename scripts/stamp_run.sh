@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+rm -f s2anet_amd/csrc/dcn_ops.o; make -C s2anet_amd/csrc -s EXTRA=-DS2A_STAMP=1 2>&1 | grep error
+timeout -k 10 200 python scripts/stamps.py 2>&1 | tail -5
+rm -f s2anet_amd/csrc/dcn_ops.o; make -C s2anet_amd/csrc -s

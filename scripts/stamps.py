@@ -1,0 +1,17 @@
+import sys, ctypes, numpy as np, torch
+sys.path.insert(0, '.')
+from s2anet_amd import _lib
+import scripts.bench_ops as bo
+r = bo.alignconv(8, torch.float16)
+print(r)
+torch.cuda.synchronize()
+buf = np.zeros(4096 * 16, np.uint64)
+_lib.check(_lib.lib().s2a_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size))
+st = buf.reshape(4096, 16).astype(np.int64)
+st = st[st[:, 0] > 0][:1024]
+c = st[:, :8]; l = st[:, 8:]
+def d(a, i, j): return np.median(a[:, j] - a[:, i])
+print("consumer: start->pre#1 %d | #1 wait %d | #1->#2 %d | main loop %d | epilogue %d | total %d" % (d(c,0,1), d(c,1,2), d(c,2,3), d(c,3,4), d(c,4,5), d(c,0,5)))
+print("loader:   start->pre#1 %d | #1 wait %d | produce0 %d | #2 wait %d | main loop %d" % (d(l,0,1), d(l,1,2), d(l,2,6), d(l,6,3), d(l,3,4)))
+print("consumer loop: work %d wait %d   loader loop: work %d wait %d" % (np.median(c[:,6]), np.median(c[:,7]), np.median(l[:,7]), np.median(l[:,5])))
+print("WG duration cycles (memtime ticks @100MHz?):", np.median(c[:,5]-c[:,0]), " first-start to last-end:", (st[:, [5, 13]].max() - st[:, [0, 8]].min()))
