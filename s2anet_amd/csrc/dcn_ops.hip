@@ -1031,6 +1031,177 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   }
 }
 
+// ------------------------------------------------------------------ regular 3x3 convolution (f16)
+// The conv towers of S2ANetHead (models/head.py:163-222: fam_reg_ls, fam_cls_ls, odm_reg_ls,
+// odm_cls_ls, or_conv — nine 256->256 3x3 convolutions per FPN level) are the patch-staged
+// AlignConv with integer sampling points: no blend, no column tile — the MFMA waves read their B
+// fragments straight out of the LDS patch (XOR-swizzled: conflict-free), the weights come in
+// fragment order from L2, and a barrier is only needed once per 64-channel chunk (every 288
+// MFMAs per wave).  256 threads = 4 waves (64 out channels x 128 positions each); 67.6 KB of LDS
+// -> two workgroups per CU, so one tile's prologue/epilogue overlaps the other's MFMA loop.
+// Bias and ReLU are fused into the LDS-staged epilogue.
+constexpr int kCPH = 10, kCPW = 18;                       // 8x16 positions + 1 halo
+constexpr int kConvPatchBytes = 26 * 1024;               // 10*18 pixels * 144 B, rounded up to whole 1 KB DMA pieces
+constexpr int kConvLds = 128 * kOutRow;                   // 67584 >= 2 * 23040
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f16(const _Float16* __restrict__ x,
+                                                        const _Float16* __restrict__ wfrag,
+                                                        const _Float16* __restrict__ bias,
+                                                        _Float16* __restrict__ out, int64_t Ntot, int C,
+                                                        int H, int W, int O, int relu, unsigned x_bytes) {
+  using T = _Float16;
+  using V = f16x8;
+  constexpr int NT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t HW = (int64_t)H * W;
+  const int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int txn = (W + 15) / 16, tyn = (H + 7) / 8;
+  const int64_t bimg = tile / (txn * tyn);
+  const int trem = (int)(tile % (txn * tyn));
+  const int ty0 = (trem / txn) * 8, tx0 = (trem % txn) * 16;
+  const int o0 = blockIdx.y * kMaxO;
+  const int Oloc = min(kMaxO, O - o0);
+  const int CC = C / 64, G = O / 64;
+  const unsigned row_bytes = (unsigned)C * 2;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
+
+  // The patch goes global -> LDS by LDS-DMA (buffer_load ... lds: no staging registers).  One wave
+  // instruction writes 64 x 16 B linearly; pixels are kept 144 B apart (128 B of channels + one
+  // 16-byte pad chunk, the same conflict-free row stride as the column tiles), so linear slot
+  // v = pixel*9 + chunk and the lanes that land on a pad chunk (chunk 8) or outside the image
+  // read an out-of-range offset (-> zeros).  26 instructions per patch, wave w issues w, w+4, ...
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned pvoff[7];
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    int v = (wave_u + 4 * j) * 64 + lane, p = v / 9, q = v % 9;
+    int yy = ty0 - 1 + p / kCPW, xx = tx0 - 1 + p % kCPW;
+    bool in = q < 8 && p < kCPH * kCPW && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    pvoff[j] = in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
+  }
+  auto patch_issue = [&](int cc) {
+    char* P = smem + (cc & 1) * kConvPatchBytes;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const int i = wave_u + 4 * j;
+      if (i < 26)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(P + i * 1024), 16,
+                                                 (int)pvoff[j], cc * 128, 0, 0);
+    }
+  };
+
+  const bool wave_active = wave * 64 < Oloc;
+  const int g = min(o0 / 64 + wave, G - 1);
+  const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
+  V wA[2][4], wB[2][4];
+  auto load_w = [&](int s, V (&wv)[2][4]) {
+    const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
+  };
+  // per N-tile b: byte offset of this lane's position (tap (0,0)) and k-half inside the patch;
+  // everything else of a fragment address is a compile-time immediate (tap, kk)
+  int fbase[NT];
+#pragma unroll
+  for (int b = 0; b < NT; b++) {
+    int pl = 32 * b + (lane & 31);
+    fbase[b] = ((pl >> 4) * kCPW + (pl & 15)) * kRowBytes + (lane >> 5) * 16;
+  }
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  auto compute = [&](const char* P, int t, const V (&wv)[2][4]) {
+    if (!wave_active) return;
+    const int toff = ((t / 3) * kCPW + (t % 3)) * kRowBytes;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      V pf[NT];
+#pragma unroll
+      for (int b = 0; b < NT; b++) pf[b] = *reinterpret_cast<const V*>(P + fbase[b] + toff + kk * 32);
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], pf[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  patch_issue(0);
+  load_w(0, wA);
+  __syncthreads();   // (the compiler drains the DMA with vmcnt(0) before the barrier)
+  const int nstage = 9 * CC, last = nstage - 1;
+  for (int cc = 0; cc < CC; cc++) {
+    const int s0 = cc * 9;
+    const char* Pc = smem + (cc & 1) * kConvPatchBytes;
+    // 9 taps, weight fragments double-buffered in registers (static indexing: unrolled by hand)
+#define S2A_TAP(T_, WCUR, WNEXT)                                                     \
+    load_w(min(s0 + (T_) + 1, last), WNEXT);                                            \
+    compute(Pc, (T_), WCUR);                                                            \
+    __builtin_amdgcn_sched_barrier(0); /* keep the next taps' loads from being hoisted (registers) */
+    S2A_TAP(0, wA, wB)
+    S2A_TAP(1, wB, wA)
+    S2A_TAP(2, wA, wB)
+    S2A_TAP(3, wB, wA)
+    S2A_TAP(4, wA, wB)
+    S2A_TAP(5, wB, wA)
+    // next chunk's patch: issued here so that tap 6 still runs on weights loaded before the DMA
+    // (vmcnt is in-order) and taps 6-8 cover its latency
+    if (cc + 1 < CC) patch_issue(cc + 1);
+    S2A_TAP(6, wA, wB)
+    S2A_TAP(7, wB, wA)
+    S2A_TAP(8, wA, wB)
+#undef S2A_TAP
+    __syncthreads();
+    // after an odd number of taps the roles of wA/wB are swapped: copy back (8 v_movs per chunk)
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) wA[a][kk] = wB[a][kk];
+  }
+
+  // ---- epilogue: bias + ReLU, tile staged through LDS, whole 512-byte rows stored 16 B per lane
+  char* s_out = smem;
+  if (wave_active) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        using h4 = __attribute__((ext_vector_type(4))) _Float16;
+        const int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
+        h4 bq = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (bias) bq = *reinterpret_cast<const h4*>(bias + o0 + och);
+#pragma unroll
+        for (int b = 0; b < NT; b++) {
+          h4 v4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float v = acc[a][b][rq * 4 + e] + (float)bq[e];
+            if (relu) v = fmaxf(v, 0.f);
+            v4[e] = (_Float16)v;
+          }
+          int pos = 32 * b + (lane & 31);
+          *reinterpret_cast<h4*>(s_out + pos * kOutRow + och * 2) = v4;
+        }
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int idx = tid + 256 * i, pos = idx >> 5, col = idx & 31;
+    int64_t gp = tile_pos(tile, pos, 8, H, W, HW, Ntot);
+    if (gp >= 0 && col * 8 < Oloc)
+      *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
+  }
+}
+
 template <int NPOS>
 constexpr int mfma_lds_bytes() { return NPOS * 9 * 32 + 2 * (kMaxO + NPOS) * kRowBytes; }  // 110592 / 147456
 
@@ -1322,4 +1493,29 @@ extern "C" int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count
   s2a::set_error("s2a_debug_read_stamps: not a diagnostic build");
   return S2A_ENOTIMPL;
 #endif
+}
+
+extern "C" int s2a_conv3x3_nhwc_f16(const void* x, const void* weight_packed, const void* bias, void* out,
+                                    int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                    int64_t out_channels, int relu, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0 && height > 0 && width > 0, "conv3x3: bad shape");
+  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 64 == 0, "conv3x3: channels and out_channels must be multiples of 64");
+  const int64_t Ntot = batch * height * width;
+  const uint64_t x_bytes = (uint64_t)Ntot * channels * 2;
+  S2A_CHECK_ARG(x_bytes < (1ull << 31) && height < 32000 && width < 32000, "conv3x3: input too large for 32-bit offsets");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(x && weight_packed && out, "conv3x3: NULL tensor");
+  S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_packed % 16) == 0 &&
+                ((uintptr_t)bias % 8) == 0, "conv3x3: tensors must be 16-byte aligned");
+  // weight_packed = output of s2a_dcn_pack_weight(f16): the fragment-order copy is the second half
+  const _Float16* wfrag = (const _Float16*)weight_packed + out_channels * channels * 9;
+  hipStream_t st = as_stream(stream);
+  const int64_t tiles = batch * ((width + 15) / 16) * ((height + 7) / 8);
+  dim3 grid((unsigned)tiles, (unsigned)((out_channels + kMaxO - 1) / kMaxO));
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_f16), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds));
+  k_conv3x3_f16<<<grid, 256, kConvLds, st>>>((const _Float16*)x, wfrag, (const _Float16*)bias, (_Float16*)out, Ntot,
+                                             (int)channels, (int)height, (int)width, (int)out_channels, relu,
+                                             (unsigned)x_bytes);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
 }

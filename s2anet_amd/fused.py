@@ -29,6 +29,44 @@ def bias_act_(y, bias, residual=None, relu=False):
     return y
 
 
+def conv3x3_ok(x, in_channels, out_channels, kernel_size, stride, padding, dilation, groups):
+    """shapes the patch-staged MFMA convolution (s2a_conv3x3_nhwc_f16) handles"""
+    import os
+    return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and
+            x.is_contiguous(memory_format=torch.channels_last) and tuple(kernel_size) == (3, 3) and
+            tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1 and
+            in_channels % 64 == 0 and out_channels % 64 == 0 and x.numel() * 2 < (1 << 31) and
+            not os.environ.get("S2A_NO_OWN_CONV"))
+
+
+def conv3x3_f16(x, packed_weight, bias, out_channels, relu):
+    """x[B,C,H,W] f16 channels-last, packed_weight = alignconv.pack_weight(weight[O,C,3,3], f16)
+    -> relu?(conv3x3(x) + bias) as channels-last f16, one kernel"""
+    B, C, H, W = x.shape
+    out = torch.empty((B, out_channels, H, W), dtype=torch.float16, device=x.device,
+                      memory_format=torch.channels_last)
+    b = None if bias is None else bias.to(torch.float16).contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().s2a_conv3x3_nhwc_f16(_lib.ptr(x), _lib.ptr(packed_weight), _lib.ptr(b), _lib.ptr(out),
+                                                   B, C, H, W, out_channels, int(bool(relu)),
+                                                   _lib.stream_ptr(x.device)))
+    return out
+
+
+class PackedWeightCache:
+    """inference-time cache of a pack_weight() result, invalidated when the tensor changes"""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, w):
+        from .alignconv import pack_weight
+        key = (w._version, w.data_ptr(), w.device)
+        if self.key != key:
+            self.key, self.val = key, pack_weight(w, torch.float16)
+        return self.val
+
+
 class FusedConv2d(nn.Conv2d):
     """nn.Conv2d + (bias, optional residual, optional ReLU) epilogue in one pass"""
 
@@ -46,6 +84,12 @@ class FusedConv2d(nn.Conv2d):
         return m
 
     def forward(self, x, residual=None):
+        if residual is None and not torch.is_grad_enabled() and conv3x3_ok(
+                x, self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+                self.dilation, self.groups):
+            if not hasattr(self, "_packed"):
+                self._packed = PackedWeightCache()
+            return conv3x3_f16(x, self._packed.get(self.weight), self.bias, self.out_channels, self.fuse_relu)
         if (not x.is_cuda) or self.bias is None:
             y = super().forward(x)
             if residual is not None:

@@ -44,6 +44,21 @@ def alignconv(batch, dtype, H=128, W=128, C=256, O=256, stride=8, sigma=0.5, jit
                 tflops=round(flops/sec/1e12, 1), mfma_frac=round(flops/sec/1e12/peak, 4),
                 alg_GBs=round(byts/sec/1e9, 1), hbm_frac=round(byts/sec/1e9/8000, 4))
 
+def conv3(batch, hw, C=256, O=256):
+    from s2anet_amd.fused import conv3x3_f16
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(batch, C, hw, hw, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(O, C, 3, 3, generator=g) * 0.02).to(dev).half()
+    b = torch.randn(O, generator=g).to(dev).half()
+    wp = pack_weight(w, torch.float16)
+    wcl = w.contiguous(memory_format=torch.channels_last)
+    torch.backends.cudnn.benchmark = True
+    t_own = timeit(lambda: conv3x3_f16(x, wp, b, O, True))
+    t_mi = timeit(lambda: torch.nn.functional.conv2d(x, wcl, None, padding=1))
+    flops = 2.0 * O * C * 9 * batch * hw * hw
+    return dict(op="conv3x3_f16", batch=batch, hw=hw, own_us=round(t_own*1e6, 1), own_tflops=round(flops/t_own/1e12, 1),
+                mfma_frac=round(flops/t_own/1e12/2500, 4), miopen_us=round(t_mi*1e6, 1), miopen_tflops=round(flops/t_mi/1e12, 1))
+
 def iou(n, m):
     rng = np.random.default_rng(1234)
     b1, b2 = torch.from_numpy(rboxes(rng, n)).to(dev), torch.from_numpy(rboxes(rng, m)).to(dev)
@@ -72,6 +87,9 @@ if __name__ == "__main__":
         for b, dt in ((8, torch.float16), (1, torch.float16), (8, torch.float32), (1, torch.float32)):
             res.append(alignconv(b, dt))
         res.append(alignconv(8, torch.float16, 64, 64, stride=16))
+    if a.which in ("all", "conv"):
+        for hw in (128, 64, 32):
+            res.append(conv3(8, hw))
     if a.which == "align8":
         res.append(alignconv(8, torch.float16))
     if a.which == "align8s":

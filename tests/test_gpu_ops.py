@@ -367,3 +367,29 @@ def test_alignconv_f16_large_tile_variants(rng):
     ref = oracle.deform_conv_forward(xh[:1].float().cpu().numpy(), offs, wh.float().cpu().numpy(), f16_cols=True, relu=True)
     err = np.abs(outs["nchw"][0] - ref[0])
     assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max(), err.mean())
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 128, 128, 256), (1, 64, 20, 37, 128), (3, 128, 8, 8, 64), (1, 256, 5, 3, 320)])
+def test_own_conv3x3_f16_vs_torch(shape):
+    """the patch-staged MFMA 3x3 convolution of the head towers against torch (f32 math on the same
+    f16 inputs); bias + ReLU fused"""
+    from s2anet_amd.alignconv import pack_weight
+    from s2anet_amd.fused import conv3x3_f16, FusedConv2d
+    B, C, H, W, O = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(O, C, 3, 3, generator=g) * 0.03).to(dev()).half()
+    b = torch.randn(O, generator=g).to(dev()).half()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b.float(), padding=1)
+    for relu in (False, True):
+        out = conv3x3_f16(x, pack_weight(w, torch.float16), b, O, relu)
+        r = torch.relu(ref) if relu else ref
+        assert out.is_contiguous(memory_format=torch.channels_last) and out.shape == r.shape
+        err = (out.float() - r).abs()
+        assert err.max().item() < 2e-2 and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
+    out_nb = conv3x3_f16(x, pack_weight(w, torch.float16), None, O, False)
+    assert (out_nb.float() - torch.nn.functional.conv2d(x.float(), w.float(), None, padding=1)).abs().max().item() < 2e-2
+    conv = torch.nn.Conv2d(C, O, 3, padding=1).to(dev()).half()
+    fc = FusedConv2d.from_conv(conv, relu=True)
+    with torch.no_grad():
+        assert (fc(x).float() - torch.relu(conv(x)).float()).abs().max().item() < 3e-2
