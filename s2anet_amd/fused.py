@@ -35,7 +35,10 @@ def conv3x3_ok(x, in_channels, out_channels, kernel_size, stride, padding, dilat
     return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and
             x.is_contiguous(memory_format=torch.channels_last) and tuple(kernel_size) == (3, 3) and
             tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1 and
-            in_channels % 64 == 0 and out_channels % 64 == 0 and x.numel() * 2 < (1 << 31) and
+            in_channels % 64 == 0 and out_channels % 256 == 0 and x.numel() * 2 < (1 << 31) and
+            # measured on MI355X (scripts/bench_ops.py --which convbb): the kernel wins once all four MFMA
+            # waves have an out-channel group and the grid has >= 64 position tiles; MIOpen keeps the rest
+            x.shape[0] * ((x.shape[2] + 7) // 8) * ((x.shape[3] + 15) // 16) >= 64 and
             not os.environ.get("S2A_NO_OWN_CONV"))
 
 

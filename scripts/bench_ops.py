@@ -80,9 +80,54 @@ def nms(n, nl=15):
     return dict(op="ml_nms_rotated", n=n, labels=nl, ms=round(sec*1e3, 3), keep=int(k.numel()),
                 same_label_pairs=pairs, Gpairs_s=round(pairs/sec/1e9, 2))
 
+def cpu_baselines():
+    """the reference's own CPU ops (oracle/_ref, built from /root/reference unmodified) timed on this
+    box's host cores, single thread as the reference loops are serial; bounded samples"""
+    import oracle
+    from oracle import ref
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(1234)
+    out = []
+    f = ref.box_iou_rotated()
+    kind = "reference" if f is not None else "port"
+    b1, b2 = rboxes(rng, 1500), rboxes(rng, 1500)
+    t = time.time()
+    if f is not None: f(torch.from_numpy(b1), torch.from_numpy(b2))
+    else: oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_CPU)
+    dt = time.time() - t
+    out.append(dict(op="cpu box_iou_rotated", kind=kind, n=1500, m=1500, s=round(dt, 3), Mpairs_s=round(2.25 / dt, 3), cores=1))
+    fp = ref.polyiou()
+    P, Q = oracle.rboxes_to_polys(rboxes(rng, 20000, span=300)), oracle.rboxes_to_polys(rboxes(rng, 20000, span=300))
+    t = time.time()
+    if fp is not None:
+        for i in range(20000): fp(P[i], Q[i])
+        pk = "reference"
+    else:
+        oracle.polyiou(P, Q); pk = "port"
+    dt = time.time() - t
+    out.append(dict(op="cpu polyiou", kind=pk, pairs=20000, s=round(dt, 3), Kpairs_s=round(20 / dt, 1), cores=1))
+    fn = ref.ml_nms_rotated()
+    for n in (2000, 5000):
+        d = rboxes(rng, n); sc = ((rng.permutation(n) + 1) / (n + 1)).astype(np.float32); lab = rng.integers(0, 15, n).astype(np.float32)
+        t = time.time()
+        if fn is not None: k = fn(torch.from_numpy(d), torch.from_numpy(sc), torch.from_numpy(lab), 0.5)
+        else: k = oracle.ml_nms_rotated(d, sc, lab, 0.5, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU)
+        dt = time.time() - t
+        out.append(dict(op="cpu ml_nms_rotated", kind="reference" if fn is not None else "port", n=n, s=round(dt, 3), keep=int(len(k)), cores=1))
+    x = rng.standard_normal((1, 256, 32, 32)).astype(np.float32); w = (rng.standard_normal((256, 256, 3, 3)) * 0.01).astype(np.float32)
+    off = (rng.standard_normal((1, 18, 32, 32))).astype(np.float32)
+    ncores = min(os.cpu_count() or 1, 16)
+    t = time.time(); oracle.deform_conv_forward(x, off, w); dt = time.time() - t
+    out.append(dict(op="cpu deform_conv forward (oracle port, OpenMP; the reference has no CPU path)", kind="port",
+                    shape=[1, 256, 32, 32], s=round(dt, 3), GFLOPs=round(2 * 256 * 2304 * 1024 / dt / 1e9, 2), cores=ncores))
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(); ap.add_argument("--which", default="all"); a = ap.parse_args()
     res = []
+    if a.which in ("all", "cpu"):
+        res += cpu_baselines()
     if a.which in ("all", "align"):
         for b, dt in ((8, torch.float16), (1, torch.float16), (8, torch.float32), (1, torch.float32)):
             res.append(alignconv(b, dt))
@@ -90,6 +135,9 @@ if __name__ == "__main__":
     if a.which in ("all", "conv"):
         for hw in (128, 64, 32):
             res.append(conv3(8, hw))
+    if a.which == "convbb":
+        for (c, o, hw) in ((64, 64, 256), (128, 128, 128), (256, 256, 64), (512, 512, 32), (256, 256, 16), (256, 256, 8)):
+            r = conv3(8, hw, c, o); r["C"], r["O"] = c, o; res.append(r)
     if a.which == "align8":
         res.append(alignconv(8, torch.float16))
     if a.which == "align8s":
