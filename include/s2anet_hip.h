@@ -212,13 +212,17 @@ int s2a_fam_refine_anchors(const void* bbox_pred, int64_t batch, int64_t height,
 int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual, int64_t positions,
                       int64_t channels, int dtype, int relu, s2a_stream_t stream);
 
-/* Regular 3x3 / stride 1 / pad 1 convolution, f16 channels-last, bias + ReLU fused — the conv towers
- * of S2ANetHead (models/head.py:163-222; nn.Conv2d + nn.ReLU pairs) on the same patch-staged MFMA
- * structure as AlignConv.  x[B,H,W,C], out[B,H,W,O]; weight_packed = s2a_dcn_pack_weight(f16) of the
- * [O,C,3,3] filter; bias[O] f16 or NULL.  C and O must be multiples of 64. */
-int s2a_conv3x3_nhwc_f16(const void* x, const void* weight_packed, const void* bias, void* out,
-                         int64_t batch, int64_t channels, int64_t height, int64_t width,
-                         int64_t out_channels, int relu, s2a_stream_t stream);
+/* Regular convolutions, f16 channels-last, with bias / residual / ReLU fused — the conv towers of
+ * S2ANetHead (models/head.py:163-222, nn.Conv2d + nn.ReLU pairs) and the 1x1 layers of the carrier,
+ * on the same patch-staged MFMA structure as AlignConv.  ksize 3: stride 1, pad 1.  ksize 1: pad 0,
+ * stride 1 or 2.  x[B,H,W,C] -> out[B,Ho,Wo,O] = relu?(conv(x) + bias (+ residual[B,Ho,Wo,O])).
+ * weight_frag = s2a_conv_pack_weight_f16 of the [O,C,k,k] filter (O*C*k*k halfs, MFMA-fragment order);
+ * bias[O] f16 or NULL; residual or NULL.  C and O must be multiples of 64. */
+int s2a_conv_pack_weight_f16(const void* weight, int64_t out_channels, int64_t channels, int ksize,
+                             void* packed, s2a_stream_t stream);
+int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
+                      void* out, int64_t batch, int64_t channels, int64_t height, int64_t width,
+                      int64_t out_channels, int ksize, int stride, int relu, s2a_stream_t stream);
 
 /* Diagnostic builds only (-DS2A_STAMP=1): per-workgroup s_memtime phase stamps of the AlignConv
  * kernel; returns S2A_ENOTIMPL in a normal build. */

@@ -66,7 +66,9 @@ SYMBOLS = {
     "s2a_dcn_packed_elems": (c_i64, [c_i64, c_i64, c_int]),
     "s2a_dcn_pack_weight": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
     "s2a_bias_act_nhwc": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
-    "s2a_conv3x3_nhwc_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]),
+    "s2a_conv_pack_weight_f16": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
+    "s2a_conv_nhwc_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int,
+                                  c_int, c_vp]),
     "s2a_debug_read_stamps": (c_int, [c_vp, c_i64]),
     "s2a_delta2bbox_rotated": (c_int, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
     "s2a_fam_refine_anchors": (c_int, [c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_int, c_int,

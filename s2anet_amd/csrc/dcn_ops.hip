@@ -697,9 +697,10 @@ constexpr int kPatchLds = 128 * 9 * 16 + 2 * 128 * kRowBytes + 2 * kPatchBytes; 
 
 // weight [O][C][9] f16 -> [stage = cc*9+t][och group of 64][mt 2][kk 4][lane 64][8 halfs]:
 // lane l, element j of fragment (mt,kk) = W[g*64 + mt*32 + (l&31)][cc*64 + kk*16 + 8*(l>>5) + j][t]
-__global__ void k_pack_weight_frag(const _Float16* __restrict__ w, int O, int C, _Float16* __restrict__ wp) {
+__global__ void k_pack_weight_frag(const _Float16* __restrict__ w, int O, int C, _Float16* __restrict__ wp,
+                                   int taps = 9) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t total = (int64_t)O * C * 9;
+  int64_t total = (int64_t)O * C * taps;
   if (e >= total) return;
   const int G = O / 64;
   int j = (int)(e & 7);
@@ -709,10 +710,10 @@ __global__ void k_pack_weight_frag(const _Float16* __restrict__ w, int O, int C,
   int64_t r = e >> 12;
   int g = (int)(r % G);
   int st = (int)(r / G);
-  int t = st % 9, cc = st / 9;
+  int t = st % taps, cc = st / taps;
   int och = g * 64 + mt * 32 + (lane & 31);
   int k = cc * 64 + kk * 16 + 8 * (lane >> 5) + j;
-  wp[e] = w[((int64_t)och * C + k) * 9 + t];
+  wp[e] = w[((int64_t)och * C + k) * taps + t];
 }
 
 constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs + 16 B pad
@@ -1031,68 +1032,97 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   }
 }
 
-// ------------------------------------------------------------------ regular 3x3 convolution (f16)
+// ------------------------------------------------------------------ regular convolutions (f16)
 // The conv towers of S2ANetHead (models/head.py:163-222: fam_reg_ls, fam_cls_ls, odm_reg_ls,
 // odm_cls_ls, or_conv — nine 256->256 3x3 convolutions per FPN level) are the patch-staged
 // AlignConv with integer sampling points: no blend, no column tile — the MFMA waves read their B
-// fragments straight out of the LDS patch (XOR-swizzled: conflict-free), the weights come in
-// fragment order from L2, and a barrier is only needed once per 64-channel chunk (every 288
-// MFMAs per wave).  256 threads = 4 waves (64 out channels x 128 positions each); 67.6 KB of LDS
-// -> two workgroups per CU, so one tile's prologue/epilogue overlaps the other's MFMA loop.
-// Bias and ReLU are fused into the LDS-staged epilogue.
+// fragments straight out of the LDS patch, the weights come in fragment order from L2, and a
+// barrier is only needed once per 64-channel chunk.  256 threads = 4 waves; <= 67.6 KB of LDS ->
+// two workgroups per CU, so one tile's prologue/epilogue overlaps the other's MFMA loop.  Bias,
+// residual and ReLU are fused into the LDS-staged epilogue (one pass over the output instead of
+// conv + bias/add/ReLU kernels).  TAPS = 9: 3x3/stride 1/pad 1 on an 8x16 position tile with a
+// one-pixel halo.  TAPS = 1: 1x1 (stride 1 or 2) on 128 consecutive output positions — a plain
+// GEMM with the same pipeline (the bottleneck 1x1 layers and FPN laterals of the carrier).
+// OG = 64-channel output groups per workgroup (4, 2 or 1): with fewer than four groups the waves
+// split the 128 positions instead, so narrow layers still use all four MFMA waves.
 constexpr int kCPH = 10, kCPW = 18;                       // 8x16 positions + 1 halo
-constexpr int kConvPatchBytes = 26 * 1024;               // 10*18 pixels * 144 B, rounded up to whole 1 KB DMA pieces
-constexpr int kConvLds = 128 * kOutRow;                   // 67584 >= 2 * 23040
 
-__global__ __launch_bounds__(256, 2) void k_conv3x3_f16(const _Float16* __restrict__ x,
-                                                        const _Float16* __restrict__ wfrag,
-                                                        const _Float16* __restrict__ bias,
-                                                        _Float16* __restrict__ out, int64_t Ntot, int C,
-                                                        int H, int W, int O, int relu, unsigned x_bytes) {
+template <int TAPS, int OG>
+struct ConvCfg {
+  static constexpr int kPix = TAPS == 9 ? kCPH * kCPW : 128;          // patch pixels
+  static constexpr int kDma = (kPix * 9 + 63) / 64;                   // 1 KB LDS-DMA pieces per patch
+  static constexpr int kPatchBytes = kDma * 1024;
+  static constexpr int kOutRowB = OG * 128 + 16;                      // staged output row (bytes)
+  static constexpr int kLds = (2 * kPatchBytes > 128 * kOutRowB) ? 2 * kPatchBytes : 128 * kOutRowB;
+  static constexpr int kJ = (kDma + 3) / 4;                           // DMA pieces per wave
+};
+
+template <int TAPS, int OG>
+__global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict__ x,
+                                                     const _Float16* __restrict__ wfrag,
+                                                     const _Float16* __restrict__ bias,
+                                                     const _Float16* __restrict__ residual,
+                                                     _Float16* __restrict__ out, int64_t Ntot, int C,
+                                                     int H, int W, int Ho, int Wo, int cstride, int O,
+                                                     int relu, unsigned x_bytes) {
   using T = _Float16;
   using V = f16x8;
-  constexpr int NT = 4;
+  using Cfg = ConvCfg<TAPS, OG>;
+  constexpr int NT = OG;              // 32-position tiles per wave
+  constexpr int WPG = 4 / OG;         // waves per out-channel group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t HW = (int64_t)H * W;
+  const int64_t HWo = (int64_t)Ho * Wo, HWi = (int64_t)H * W;
   const int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int txn = (W + 15) / 16, tyn = (H + 7) / 8;
-  const int64_t bimg = tile / (txn * tyn);
-  const int trem = (int)(tile % (txn * tyn));
+  // TAPS 9: 2-D tile of one image; TAPS 1: 128 consecutive output positions of the whole batch
+  const int txn = (Wo + 15) / 16, tyn = (Ho + 7) / 8;
+  const int64_t bimg = TAPS == 9 ? tile / (txn * tyn) : 0;
+  const int trem = TAPS == 9 ? (int)(tile % (txn * tyn)) : 0;
   const int ty0 = (trem / txn) * 8, tx0 = (trem % txn) * 16;
-  const int o0 = blockIdx.y * kMaxO;
-  const int Oloc = min(kMaxO, O - o0);
+  const int64_t g0 = tile * 128;
+  const int o0 = blockIdx.y * (64 * OG);
+  const int Oloc = min(64 * OG, O - o0);
   const int CC = C / 64, G = O / 64;
   const unsigned row_bytes = (unsigned)C * 2;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
 
-  // The patch goes global -> LDS by LDS-DMA (buffer_load ... lds: no staging registers).  One wave
-  // instruction writes 64 x 16 B linearly; pixels are kept 144 B apart (128 B of channels + one
-  // 16-byte pad chunk, the same conflict-free row stride as the column tiles), so linear slot
-  // v = pixel*9 + chunk and the lanes that land on a pad chunk (chunk 8) or outside the image
-  // read an out-of-range offset (-> zeros).  26 instructions per patch, wave w issues w, w+4, ...
+  // Patch: global -> LDS by LDS-DMA (buffer_load ... lds).  One wave instruction writes 64 x 16 B
+  // linearly; pixels sit 144 B apart (128 B of channels + a 16-byte pad chunk: conflict-free
+  // ds_read_b128 fragments), linear slot v = pixel*9 + chunk; pad chunks and pixels outside the
+  // image read an out-of-range offset (-> zeros).
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  unsigned pvoff[7];
+  unsigned pvoff[Cfg::kJ];
 #pragma unroll
-  for (int j = 0; j < 7; j++) {
+  for (int j = 0; j < Cfg::kJ; j++) {
     int v = (wave_u + 4 * j) * 64 + lane, p = v / 9, q = v % 9;
-    int yy = ty0 - 1 + p / kCPW, xx = tx0 - 1 + p % kCPW;
-    bool in = q < 8 && p < kCPH * kCPW && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    pvoff[j] = in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
+    bool in = q < 8 && p < Cfg::kPix;
+    int64_t pix = 0;
+    if (TAPS == 9) {
+      int yy = ty0 - 1 + p / kCPW, xx = tx0 - 1 + p % kCPW;
+      in = in && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      pix = bimg * HWi + (int64_t)yy * W + xx;
+    } else {
+      int64_t g = g0 + p;
+      in = in && g < Ntot;
+      int64_t bb = g / HWo, r = g % HWo;
+      pix = bb * HWi + (r / Wo) * cstride * (int64_t)W + (r % Wo) * cstride;
+    }
+    pvoff[j] = in ? (unsigned)(pix * row_bytes + q * 16) : 0x80000000u;
   }
   auto patch_issue = [&](int cc) {
-    char* P = smem + (cc & 1) * kConvPatchBytes;
+    char* P = smem + (cc & 1) * Cfg::kPatchBytes;
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
+    for (int j = 0; j < Cfg::kJ; j++) {
       const int i = wave_u + 4 * j;
-      if (i < 26)
+      if (i < Cfg::kDma)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(P + i * 1024), 16,
                                                  (int)pvoff[j], cc * 128, 0, 0);
     }
   };
 
-  const bool wave_active = wave * 64 < Oloc;
-  const int g = min(o0 / 64 + wave, G - 1);
+  const int grp = wave / WPG, sub = wave % WPG;       // out-channel group, position sub-range
+  const bool wave_active = grp * 64 < Oloc;
+  const int g = min(o0 / 64 + grp, G - 1);
   const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
   V wA[2][4], wB[2][4];
   auto load_w = [&](int s, V (&wv)[2][4]) {
@@ -1103,12 +1133,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16(const _Float16* __restri
       for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
   };
   // per N-tile b: byte offset of this lane's position (tap (0,0)) and k-half inside the patch;
-  // everything else of a fragment address is a compile-time immediate (tap, kk)
+  // the rest of a fragment address is a compile-time immediate (tap, kk)
   int fbase[NT];
 #pragma unroll
   for (int b = 0; b < NT; b++) {
-    int pl = 32 * b + (lane & 31);
-    fbase[b] = ((pl >> 4) * kCPW + (pl & 15)) * kRowBytes + (lane >> 5) * 16;
+    int pl = 32 * (sub * NT + b) + (lane & 31);
+    int pix = TAPS == 9 ? (pl >> 4) * kCPW + (pl & 15) : pl;
+    fbase[b] = pix * kRowBytes + (lane >> 5) * 16;
   }
   f32x16 acc[2][NT];
 #pragma unroll
@@ -1137,37 +1168,53 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16(const _Float16* __restri
   patch_issue(0);
   load_w(0, wA);
   __syncthreads();   // (the compiler drains the DMA with vmcnt(0) before the barrier)
-  const int nstage = 9 * CC, last = nstage - 1;
-  for (int cc = 0; cc < CC; cc++) {
-    const int s0 = cc * 9;
-    const char* Pc = smem + (cc & 1) * kConvPatchBytes;
-    // 9 taps, weight fragments double-buffered in registers (static indexing: unrolled by hand)
+  const int nstage = TAPS * CC, last = nstage - 1;
+  if constexpr (TAPS == 9) {
+    for (int cc = 0; cc < CC; cc++) {
+      const int s0 = cc * 9;
+      const char* Pc = smem + (cc & 1) * Cfg::kPatchBytes;
+      // 9 taps, weight fragments double-buffered in registers (static indexing: unrolled by hand)
 #define S2A_TAP(T_, WCUR, WNEXT)                                                     \
-    load_w(min(s0 + (T_) + 1, last), WNEXT);                                            \
-    compute(Pc, (T_), WCUR);                                                            \
-    __builtin_amdgcn_sched_barrier(0); /* keep the next taps' loads from being hoisted (registers) */
-    S2A_TAP(0, wA, wB)
-    S2A_TAP(1, wB, wA)
-    S2A_TAP(2, wA, wB)
-    S2A_TAP(3, wB, wA)
-    S2A_TAP(4, wA, wB)
-    S2A_TAP(5, wB, wA)
-    // next chunk's patch: issued here so that tap 6 still runs on weights loaded before the DMA
-    // (vmcnt is in-order) and taps 6-8 cover its latency
-    if (cc + 1 < CC) patch_issue(cc + 1);
-    S2A_TAP(6, wA, wB)
-    S2A_TAP(7, wB, wA)
-    S2A_TAP(8, wA, wB)
+      load_w(min(s0 + (T_) + 1, last), WNEXT);                                          \
+      compute(Pc, (T_), WCUR);                                                          \
+      __builtin_amdgcn_sched_barrier(0); /* keep the next taps' loads from being hoisted (registers) */
+      S2A_TAP(0, wA, wB)
+      S2A_TAP(1, wB, wA)
+      S2A_TAP(2, wA, wB)
+      S2A_TAP(3, wB, wA)
+      S2A_TAP(4, wA, wB)
+      S2A_TAP(5, wB, wA)
+      // next chunk's patch: issued here so that tap 6 still runs on weights loaded before the DMA
+      // (vmcnt is in-order) and taps 6-8 cover its latency
+      if (cc + 1 < CC) patch_issue(cc + 1);
+      S2A_TAP(6, wA, wB)
+      S2A_TAP(7, wB, wA)
+      S2A_TAP(8, wA, wB)
 #undef S2A_TAP
+      __syncthreads();
+      // after an odd number of taps the roles of wA/wB are swapped: copy back (8 v_movs per chunk)
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) wA[a][kk] = wB[a][kk];
+    }
+  } else {
+    // one stage per 64-channel chunk: next chunk's tile and weights in flight under this one's MFMAs
+#define S2A_STAGE(C_, WCUR, WNEXT)                                                   \
+    if ((C_) + 1 < CC) patch_issue((C_) + 1);                                           \
+    load_w(min((C_) + 1, last), WNEXT);                                                 \
+    compute(smem + ((C_) & 1) * Cfg::kPatchBytes, 0, WCUR);                             \
     __syncthreads();
-    // after an odd number of taps the roles of wA/wB are swapped: copy back (8 v_movs per chunk)
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) wA[a][kk] = wB[a][kk];
+    int cc = 0;
+    for (; cc + 1 < CC; cc += 2) {
+      S2A_STAGE(cc, wA, wB)
+      S2A_STAGE(cc + 1, wB, wA)
+    }
+    if (cc < CC) { S2A_STAGE(cc, wA, wB) }
+#undef S2A_STAGE
   }
 
-  // ---- epilogue: bias + ReLU, tile staged through LDS, whole 512-byte rows stored 16 B per lane
+  // ---- epilogue: bias (+ residual) + ReLU; tile staged through LDS, rows stored 16 B per lane
   char* s_out = smem;
   if (wave_active) {
 #pragma unroll
@@ -1175,7 +1222,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16(const _Float16* __restri
 #pragma unroll
       for (int rq = 0; rq < 4; rq++) {
         using h4 = __attribute__((ext_vector_type(4))) _Float16;
-        const int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
+        const int och = grp * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
         h4 bq = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
         if (bias) bq = *reinterpret_cast<const h4*>(bias + o0 + och);
 #pragma unroll
@@ -1184,21 +1231,33 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16(const _Float16* __restri
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             float v = acc[a][b][rq * 4 + e] + (float)bq[e];
-            if (relu) v = fmaxf(v, 0.f);
+            if (relu && !residual) v = fmaxf(v, 0.f);
             v4[e] = (_Float16)v;
           }
-          int pos = 32 * b + (lane & 31);
-          *reinterpret_cast<h4*>(s_out + pos * kOutRow + och * 2) = v4;
+          int pos = 32 * (sub * NT + b) + (lane & 31);
+          *reinterpret_cast<h4*>(s_out + pos * Cfg::kOutRowB + och * 2) = v4;
         }
       }
   }
   __syncthreads();
+  constexpr int VPR = 8 * OG;                     // 16-byte vectors per output row
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    int idx = tid + 256 * i, pos = idx >> 5, col = idx & 31;
-    int64_t gp = tile_pos(tile, pos, 8, H, W, HW, Ntot);
-    if (gp >= 0 && col * 8 < Oloc)
-      *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
+  for (int i = 0; i < (128 * VPR) / 256; i++) {
+    int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
+    int64_t gp = TAPS == 9 ? tile_pos(tile, pos, 8, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
+    if (gp >= 0 && col * 8 < Oloc) {
+      V v = *reinterpret_cast<const V*>(s_out + pos * Cfg::kOutRowB + col * 16);
+      if (residual) {
+        V r = *reinterpret_cast<const V*>(residual + gp * O + o0 + col * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float f = (float)v[e] + (float)r[e];
+          if (relu) f = fmaxf(f, 0.f);
+          v[e] = (_Float16)f;
+        }
+      }
+      *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = v;
+    }
   }
 }
 
@@ -1495,27 +1554,60 @@ extern "C" int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count
 #endif
 }
 
-extern "C" int s2a_conv3x3_nhwc_f16(const void* x, const void* weight_packed, const void* bias, void* out,
-                                    int64_t batch, int64_t channels, int64_t height, int64_t width,
-                                    int64_t out_channels, int relu, s2a_stream_t stream) {
-  S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0 && height > 0 && width > 0, "conv3x3: bad shape");
-  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 64 == 0, "conv3x3: channels and out_channels must be multiples of 64");
-  const int64_t Ntot = batch * height * width;
-  const uint64_t x_bytes = (uint64_t)Ntot * channels * 2;
-  S2A_CHECK_ARG(x_bytes < (1ull << 31) && height < 32000 && width < 32000, "conv3x3: input too large for 32-bit offsets");
+namespace s2a {
+namespace {
+template <int TAPS, int OG>
+int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
+                _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
+                hipStream_t st) {
+  using Cfg = ConvCfg<TAPS, OG>;
+  const int64_t Ntot = B * (int64_t)Ho * Wo;
+  const int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + 7) / 8) : (Ntot + 127) / 128;
+  dim3 grid((unsigned)tiles, (unsigned)((O + 64 * OG - 1) / (64 * OG)));
+  auto kern = k_conv_f16<TAPS, OG>;
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
+  kern<<<grid, 256, Cfg::kLds, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
+                                     (unsigned)((uint64_t)B * H * W * C * 2));
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+}  // namespace
+}  // namespace s2a
+
+extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
+                                 void* out, int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                 int64_t out_channels, int ksize, int stride, int relu, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0 && height > 0 && width > 0, "conv: bad shape");
+  S2A_CHECK_ARG(ksize == 3 || ksize == 1, "conv: kernel size must be 1 or 3");
+  S2A_CHECK_ARG(stride == 1 || (ksize == 1 && stride == 2), "conv: stride must be 1 (or 2 for 1x1)");
+  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 64 == 0, "conv: channels and out_channels must be multiples of 64");
+  const uint64_t x_bytes = (uint64_t)batch * height * width * channels * 2;
+  S2A_CHECK_ARG(x_bytes < (1ull << 31) && height < 32000 && width < 32000, "conv: input too large for 32-bit offsets");
   if (batch == 0) return S2A_OK;
-  S2A_CHECK_ARG(x && weight_packed && out, "conv3x3: NULL tensor");
-  S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_packed % 16) == 0 &&
-                ((uintptr_t)bias % 8) == 0, "conv3x3: tensors must be 16-byte aligned");
-  // weight_packed = output of s2a_dcn_pack_weight(f16): the fragment-order copy is the second half
-  const _Float16* wfrag = (const _Float16*)weight_packed + out_channels * channels * 9;
+  S2A_CHECK_ARG(x && weight_frag && out, "conv: NULL tensor");
+  S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_frag % 16) == 0 &&
+                ((uintptr_t)bias % 8) == 0 && ((uintptr_t)residual % 16) == 0, "conv: tensors must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  const int64_t tiles = batch * ((width + 15) / 16) * ((height + 7) / 8);
-  dim3 grid((unsigned)tiles, (unsigned)((out_channels + kMaxO - 1) / kMaxO));
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_f16), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds));
-  k_conv3x3_f16<<<grid, 256, kConvLds, st>>>((const _Float16*)x, wfrag, (const _Float16*)bias, (_Float16*)out, Ntot,
-                                             (int)channels, (int)height, (int)width, (int)out_channels, relu,
-                                             (unsigned)x_bytes);
+  const int Ho = (int)((height - 1) / stride + 1), Wo = (int)((width - 1) / stride + 1);   // k=1,p=0 / k=3,p=1,s=1
+  const int og = out_channels % 256 == 0 ? 4 : (out_channels % 128 == 0 ? 2 : 1);
+  const _Float16 *X = (const _Float16*)x, *Wf = (const _Float16*)weight_frag, *Bi = (const _Float16*)bias,
+                 *R = (const _Float16*)residual;
+  _Float16* Y = (_Float16*)out;
+#define S2A_CONV(TAPS, OG_) launch_conv<TAPS, OG_>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, stride, (int)out_channels, relu, st)
+  if (ksize == 3) return og == 4 ? S2A_CONV(9, 4) : (og == 2 ? S2A_CONV(9, 2) : S2A_CONV(9, 1));
+  return og == 4 ? S2A_CONV(1, 4) : (og == 2 ? S2A_CONV(1, 2) : S2A_CONV(1, 1));
+#undef S2A_CONV
+}
+
+extern "C" int s2a_conv_pack_weight_f16(const void* weight, int64_t out_channels, int64_t channels, int ksize,
+                                        void* packed, s2a_stream_t stream) {
+  S2A_CHECK_ARG(ksize == 3 || ksize == 1, "conv_pack_weight: kernel size must be 1 or 3");
+  S2A_CHECK_ARG(out_channels % 64 == 0 && channels % 64 == 0, "conv_pack_weight: channel counts must be multiples of 64");
+  S2A_CHECK_ARG(weight && packed, "conv_pack_weight: NULL tensor");
+  const int taps = ksize * ksize;
+  const int64_t wtot = out_channels * channels * taps;
+  k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, as_stream(stream)>>>(
+      (const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed, taps);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -29,44 +29,65 @@ def bias_act_(y, bias, residual=None, relu=False):
     return y
 
 
-def conv3x3_ok(x, in_channels, out_channels, kernel_size, stride, padding, dilation, groups):
-    """shapes the patch-staged MFMA convolution (s2a_conv3x3_nhwc_f16) handles"""
+def own_conv_ok(x, in_channels, out_channels, kernel_size, stride, padding, dilation, groups):
+    """shapes the patch-staged MFMA convolution (s2a_conv_nhwc_f16) handles AND wins on (measured on
+    MI355X, scripts/bench_ops.py --which convbb): 3x3/s1/p1 or 1x1/p0 (stride 1 or 2), f16
+    channels-last, channel counts multiples of 64, enough position tiles to fill the chip"""
     import os
-    return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and
-            x.is_contiguous(memory_format=torch.channels_last) and tuple(kernel_size) == (3, 3) and
-            tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1 and
-            in_channels % 64 == 0 and out_channels % 256 == 0 and x.numel() * 2 < (1 << 31) and
-            # measured on MI355X (scripts/bench_ops.py --which convbb): the kernel wins once all four MFMA
-            # waves have an out-channel group and the grid has >= 64 position tiles; MIOpen keeps the rest
-            x.shape[0] * ((x.shape[2] + 7) // 8) * ((x.shape[3] + 15) // 16) >= 64 and
-            not os.environ.get("S2A_NO_OWN_CONV"))
+    if not (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and
+            x.is_contiguous(memory_format=torch.channels_last) and tuple(dilation) == (1, 1) and groups == 1 and
+            in_channels % 64 == 0 and out_channels % 64 == 0 and x.numel() * 2 < (1 << 31)):
+        return False
+    if os.environ.get("S2A_NO_OWN_CONV"):
+        return False
+    k, st, pd = tuple(kernel_size), tuple(stride), tuple(padding)
+    B, _, H, W = x.shape
+    if k == (3, 3) and st == (1, 1) and pd == (1, 1):
+        return B * ((H + 7) // 8) * ((W + 15) // 16) >= 64
+    if k == (1, 1) and pd == (0, 0) and st in ((1, 1), (2, 2)) and not os.environ.get("S2A_NO_OWN_CONV1"):
+        Ho, Wo = (H - 1) // st[0] + 1, (W - 1) // st[1] + 1
+        return B * Ho * Wo >= 64 * 128
+    return False
 
 
-def conv3x3_f16(x, packed_weight, bias, out_channels, relu):
-    """x[B,C,H,W] f16 channels-last, packed_weight = alignconv.pack_weight(weight[O,C,3,3], f16)
-    -> relu?(conv3x3(x) + bias) as channels-last f16, one kernel"""
+def conv_pack_weight(weight):
+    """[O,C,k,k] -> MFMA-fragment order (s2a_conv_pack_weight_f16)"""
+    w = weight.detach().to(torch.float16).contiguous()
+    out = torch.empty_like(w)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().s2a_conv_pack_weight_f16(_lib.ptr(w), w.shape[0], w.shape[1], w.shape[2],
+                                                       _lib.ptr(out), _lib.stream_ptr(w.device)))
+    return out
+
+
+def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, residual=None):
+    """relu?(conv(x) + bias (+ residual)) in ONE kernel; x f16 channels-last, packed_weight from
+    conv_pack_weight; ksize 3 (stride 1, pad 1) or 1 (pad 0, stride 1|2)"""
     B, C, H, W = x.shape
-    out = torch.empty((B, out_channels, H, W), dtype=torch.float16, device=x.device,
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((B, out_channels, Ho, Wo), dtype=torch.float16, device=x.device,
                       memory_format=torch.channels_last)
     b = None if bias is None else bias.to(torch.float16).contiguous()
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == torch.float16 and \
+            residual.is_contiguous(memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().s2a_conv3x3_nhwc_f16(_lib.ptr(x), _lib.ptr(packed_weight), _lib.ptr(b), _lib.ptr(out),
-                                                   B, C, H, W, out_channels, int(bool(relu)),
-                                                   _lib.stream_ptr(x.device)))
+        _lib.check(_lib.lib().s2a_conv_nhwc_f16(_lib.ptr(x), _lib.ptr(packed_weight), _lib.ptr(b), _lib.ptr(residual),
+                                                _lib.ptr(out), B, C, H, W, out_channels, int(ksize), int(stride),
+                                                int(bool(relu)), _lib.stream_ptr(x.device)))
     return out
 
 
 class PackedWeightCache:
-    """inference-time cache of a pack_weight() result, invalidated when the tensor changes"""
+    """inference-time cache of a conv_pack_weight() result, invalidated when the tensor changes"""
 
     def __init__(self):
         self.key, self.val = None, None
 
     def get(self, w):
-        from .alignconv import pack_weight
         key = (w._version, w.data_ptr(), w.device)
         if self.key != key:
-            self.key, self.val = key, pack_weight(w, torch.float16)
+            self.key, self.val = key, conv_pack_weight(w)
         return self.val
 
 
@@ -87,12 +108,14 @@ class FusedConv2d(nn.Conv2d):
         return m
 
     def forward(self, x, residual=None):
-        if residual is None and not torch.is_grad_enabled() and conv3x3_ok(
+        if not torch.is_grad_enabled() and own_conv_ok(
                 x, self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
-                self.dilation, self.groups):
+                self.dilation, self.groups) and (residual is None or (
+                    residual.dtype == torch.float16 and residual.is_contiguous(memory_format=torch.channels_last))):
             if not hasattr(self, "_packed"):
                 self._packed = PackedWeightCache()
-            return conv3x3_f16(x, self._packed.get(self.weight), self.bias, self.out_channels, self.fuse_relu)
+            return conv_f16(x, self._packed.get(self.weight), self.bias, self.out_channels, self.kernel_size[0],
+                            self.stride[0], self.fuse_relu, residual)
         if (not x.is_cuda) or self.bias is None:
             y = super().forward(x)
             if residual is not None:

@@ -117,12 +117,12 @@ class ORConv2d(nn.Conv2d):
     def forward(self, input):
         w = self.rotate_arf()
         if input.is_cuda and not torch.is_grad_enabled():
-            from .fused import conv3x3_ok, conv3x3_f16, PackedWeightCache
-            if conv3x3_ok(input, w.shape[1], w.shape[0], w.shape[2:], self.stride, self.padding, self.dilation,
-                          self.groups):
+            from .fused import own_conv_ok, conv_f16, PackedWeightCache
+            if own_conv_ok(input, w.shape[1], w.shape[0], w.shape[2:], self.stride, self.padding, self.dilation,
+                           self.groups):
                 if not hasattr(self, "_packed"):
                     self._packed = PackedWeightCache()
-                return conv3x3_f16(input, self._packed.get(w), self.bias, w.shape[0], False)
+                return conv_f16(input, self._packed.get(w), self.bias, w.shape[0], w.shape[2], 1, False)
         if input.is_cuda and self.bias is not None and not torch.is_grad_enabled():
             from .fused import bias_act_
             y = F.conv2d(input, w, None, self.stride, self.padding, self.dilation, self.groups)

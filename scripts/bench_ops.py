@@ -44,20 +44,24 @@ def alignconv(batch, dtype, H=128, W=128, C=256, O=256, stride=8, sigma=0.5, jit
                 tflops=round(flops/sec/1e12, 1), mfma_frac=round(flops/sec/1e12/peak, 4),
                 alg_GBs=round(byts/sec/1e9, 1), hbm_frac=round(byts/sec/1e9/8000, 4))
 
-def conv3(batch, hw, C=256, O=256):
-    from s2anet_amd.fused import conv3x3_f16
+def conv3(batch, hw, C=256, O=256, k=3, st=1):
+    from s2anet_amd.fused import conv_f16, conv_pack_weight, bias_act_
     g = torch.Generator().manual_seed(1)
     x = torch.randn(batch, C, hw, hw, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(O, C, 3, 3, generator=g) * 0.02).to(dev).half()
+    w = (torch.randn(O, C, k, k, generator=g) * 0.02).to(dev).half()
     b = torch.randn(O, generator=g).to(dev).half()
-    wp = pack_weight(w, torch.float16)
+    wp = conv_pack_weight(w)
     wcl = w.contiguous(memory_format=torch.channels_last)
     torch.backends.cudnn.benchmark = True
-    t_own = timeit(lambda: conv3x3_f16(x, wp, b, O, True))
-    t_mi = timeit(lambda: torch.nn.functional.conv2d(x, wcl, None, padding=1))
-    flops = 2.0 * O * C * 9 * batch * hw * hw
-    return dict(op="conv3x3_f16", batch=batch, hw=hw, own_us=round(t_own*1e6, 1), own_tflops=round(flops/t_own/1e12, 1),
-                mfma_frac=round(flops/t_own/1e12/2500, 4), miopen_us=round(t_mi*1e6, 1), miopen_tflops=round(flops/t_mi/1e12, 1))
+    pad = k // 2
+    t_own = timeit(lambda: conv_f16(x, wp, b, O, k, st, True))
+    t_mi = timeit(lambda: bias_act_(torch.nn.functional.conv2d(x, wcl, None, stride=st, padding=pad), b, None, True))
+    ho = (hw - 1) // st + 1
+    flops = 2.0 * O * C * k * k * batch * ho * ho
+    byts = batch * (hw * hw * C + ho * ho * O) * 2
+    return dict(op="conv%dx%d_f16+bias+relu" % (k, k), batch=batch, hw=hw, C=C, O=O, stride=st, own_us=round(t_own*1e6, 1),
+                own_tflops=round(flops/t_own/1e12, 1), own_GBs=round(byts/t_own/1e9, 1),
+                miopen_plus_epilogue_us=round(t_mi*1e6, 1))
 
 def iou(n, m):
     rng = np.random.default_rng(1234)
@@ -137,7 +141,11 @@ if __name__ == "__main__":
             res.append(conv3(8, hw))
     if a.which == "convbb":
         for (c, o, hw) in ((64, 64, 256), (128, 128, 128), (256, 256, 64), (512, 512, 32), (256, 256, 16), (256, 256, 8)):
-            r = conv3(8, hw, c, o); r["C"], r["O"] = c, o; res.append(r)
+            res.append(conv3(8, hw, c, o))
+        for (c, o, hw, st) in ((64, 64, 256, 1), (64, 256, 256, 1), (256, 64, 256, 1), (256, 128, 256, 1), (128, 512, 128, 1),
+                               (512, 128, 128, 1), (256, 512, 256, 2), (512, 256, 128, 1), (256, 1024, 64, 1), (1024, 256, 64, 1),
+                               (1024, 512, 64, 1), (512, 2048, 32, 1), (2048, 512, 32, 1), (1024, 2048, 64, 2), (2048, 256, 32, 1)):
+            res.append(conv3(8, hw, c, o, 1, st))
     if a.which == "align8":
         res.append(alignconv(8, torch.float16))
     if a.which == "align8s":

@@ -372,24 +372,48 @@ def test_alignconv_f16_large_tile_variants(rng):
 @pytest.mark.parametrize("shape", [(2, 256, 128, 128, 256), (1, 64, 20, 37, 128), (3, 128, 8, 8, 64), (1, 256, 5, 3, 320)])
 def test_own_conv3x3_f16_vs_torch(shape):
     """the patch-staged MFMA 3x3 convolution of the head towers against torch (f32 math on the same
-    f16 inputs); bias + ReLU fused"""
-    from s2anet_amd.alignconv import pack_weight
-    from s2anet_amd.fused import conv3x3_f16, FusedConv2d
+    f16 inputs); bias + ReLU fused; out-channel groupings 4 / 2 / 1 and a ragged last group"""
+    from s2anet_amd.fused import conv_f16, conv_pack_weight, FusedConv2d
     B, C, H, W, O = shape
     g = torch.Generator().manual_seed(7)
     x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(O, C, 3, 3, generator=g) * 0.03).to(dev()).half()
     b = torch.randn(O, generator=g).to(dev()).half()
     ref = torch.nn.functional.conv2d(x.float(), w.float(), b.float(), padding=1)
+    wp = conv_pack_weight(w)
     for relu in (False, True):
-        out = conv3x3_f16(x, pack_weight(w, torch.float16), b, O, relu)
+        out = conv_f16(x, wp, b, O, 3, 1, relu)
         r = torch.relu(ref) if relu else ref
         assert out.is_contiguous(memory_format=torch.channels_last) and out.shape == r.shape
         err = (out.float() - r).abs()
         assert err.max().item() < 2e-2 and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
-    out_nb = conv3x3_f16(x, pack_weight(w, torch.float16), None, O, False)
+    out_nb = conv_f16(x, wp, None, O, 3, 1, False)
     assert (out_nb.float() - torch.nn.functional.conv2d(x.float(), w.float(), None, padding=1)).abs().max().item() < 2e-2
     conv = torch.nn.Conv2d(C, O, 3, padding=1).to(dev()).half()
     fc = FusedConv2d.from_conv(conv, relu=True)
     with torch.no_grad():
         assert (fc(x).float() - torch.relu(conv(x)).float()).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 256, 1), (2, 256, 33, 47, 64, 1), (1, 512, 32, 32, 128, 1),
+                                   (2, 256, 64, 64, 512, 2), (1, 1024, 17, 9, 2048, 2), (4, 128, 40, 40, 320, 1)])
+def test_own_conv1x1_f16_vs_torch(shape):
+    """1x1 convolutions (bottleneck / lateral layers) on the same pipeline: stride 1 and 2, residual add"""
+    from s2anet_amd.fused import conv_f16, conv_pack_weight
+    B, C, H, W, O, st = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(O, C, 1, 1, generator=g) * 0.05).to(dev()).half()
+    b = torch.randn(O, generator=g).to(dev()).half()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), b.float(), stride=st)
+    res = torch.randn(ref.shape, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+    wp = conv_pack_weight(w)
+    out = conv_f16(x, wp, b, O, 1, st, True)
+    assert out.shape == ref.shape
+    err = (out.float() - torch.relu(ref)).abs()
+    assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (err.max().item(), err.mean().item())
+    out2 = conv_f16(x, wp, b, O, 1, st, True, res)
+    err2 = (out2.float() - torch.relu(ref + res.float())).abs()
+    assert err2.max().item() < 3e-2 and err2.mean().item() < 3e-3
+    out3 = conv_f16(x, wp, None, O, 1, st, False, res)
+    assert (out3.float() - (torch.nn.functional.conv2d(x.float(), w.float(), None, stride=st) + res.float())).abs().max().item() < 3e-2
