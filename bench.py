@@ -112,16 +112,50 @@ def measure_alignconv(model, batch, dtype, iters=30):
     alg_bytes = npos * C * es * 2 + 256 * 2304 * es + npos * 5 * 4   # in + out + weight + anchors
     peak = PEAK_F16_TFLOPS if dtype == torch.float16 else PEAK_F32_TFLOPS
     ach = flops / sec / 1e12
+    # HBM traffic per launch from rocprofv3 PMC passes of this kernel at this shape (FETCH_SIZE x2 as
+    # the gfx950 correction prescribes + WRITE_SIZE; profiles/r01_alignconv_p3_pmc.txt) — a recorded
+    # measurement, not collected live; only valid for the f16 batch-8 shape it was taken on
+    traffic = 177.9e6 if (es == 2 and batch == 8) else None
     return {
-        "kernel": "k_dcn_mfma (fused AlignConv, P3 128x128, batch %d, %s)" % (batch, "f16" if es == 2 else "f32"),
+        "kernel": "%s (fused AlignConv: anchors -> sampling -> 3x3 contraction -> ReLU; P3 128x128, batch %d, %s)"
+                  % ("k_dcn_patch" if es == 2 else "k_dcn_mfma", batch, "f16" if es == 2 else "f32"),
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(ach / peak, 4), "traffic": None,
+        "frac": round(ach / peak, 4), "traffic": traffic,
         "avg_launch_us": round(sec * 1e6, 1),
         "flops_per_launch": flops,
         "hbm_algorithmic_bytes_per_launch": alg_bytes,
         "hbm_achieved_GBs": round(alg_bytes / sec / 1e9, 1),
         "hbm_frac_of_8TBs": round(alg_bytes / sec / 1e9 / PEAK_HBM_GBS, 4),
     }
+
+
+def measure_conv_tower(batch, iters=30):
+    """the kernel that takes the most time per step once the head towers run on it: the patch-staged
+    3x3 convolution (256 -> 256, P3, bias + ReLU fused).  Same event timing as measure_alignconv."""
+    from s2anet_amd.fused import conv_f16, conv_pack_weight
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    H = W = CHIP // 8
+    x = torch.randn(batch, 256, H, W, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev, torch.float16)
+    b = torch.randn(256, generator=g).to(dev, torch.float16)
+    wp = conv_pack_weight(w)
+    for _ in range(3):
+        conv_f16(x, wp, b, 256, 3, 1, True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        conv_f16(x, wp, b, 256, 3, 1, True)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    flops = 2.0 * 256 * 2304 * batch * H * W
+    ach = flops / sec / 1e12
+    return {"kernel": "k_conv_f16<9,4> (head conv tower 3x3 256->256 + bias + ReLU, P3 128x128, batch %d, f16)" % batch,
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(sec * 1e6, 1),
+            "flops_per_launch": flops}
 
 
 def cpu_baseline(seed, candidates):
@@ -290,6 +324,8 @@ def main():
     }
     if rank == 0:
         result["roofline"] = measure_alignconv(model, B, dtype)
+        if dtype == torch.float16:
+            result["roofline_conv_tower"] = measure_conv_tower(B)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(1234, args.candidates)

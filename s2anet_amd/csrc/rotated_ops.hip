@@ -38,6 +38,7 @@ constexpr int kThreads = 256;
 constexpr int kLdsQueue = 6144;      // entries per workgroup queue
 constexpr int kFlushAt = 2048;       // flush when more than this is pending
 constexpr int kPersistentGrid = 1024;
+constexpr unsigned kScanCacheWords = 6144;  // 48 KB of suppression mask cached in LDS per segment
 
 __device__ __forceinline__ uint32_t float_sortable(float f) {
   uint32_t u = __float_as_uint(f);
@@ -459,8 +460,9 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
                                                        const unsigned long long* __restrict__ words_total,
                                                        unsigned long long words_bound,
                                                        uint32_t* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_remv[];  // max_blocks + 1
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_remv[];  // max_blocks + 2 | mask cache
   unsigned long long* s_keep = s_remv + max_blocks;
+  unsigned long long* s_mask = s_remv + max_blocks + 10;  // kScanCacheWords words (after keep[1] + rows[8] + pad)
   const uint32_t S = *num_seg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (*words_total > words_bound) {  // mask would not fit: keep nothing, report (status bit 0)
@@ -476,54 +478,68 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
       continue;
     }
     const unsigned long long* M = mask + mask_off[s];
+    // small segment (the usual per-(image, class) case): pull its whole mask into LDS with one
+    // coalesced sweep, so the serial block loop below never waits on HBM/L2 latency again
+    const unsigned long long nwords = (unsigned long long)ns * B;
+    const bool cached = nwords <= kScanCacheWords;
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < B; c += kThreads) s_remv[c] = 0ull;
+    if (cached) {
+      for (uint32_t i = threadIdx.x; i < nwords; i += kThreads) s_mask[i] = M[i];
+      M = s_mask;   // (generic pointer: LDS from here on)
+    }
     __syncthreads();
+    unsigned char* s_rows = reinterpret_cast<unsigned char*>(s_keep + 1);   // kept rows of the block (64 B)
     for (uint32_t b = 0; b < B; b++) {
       if (wave == 0) {
         uint32_t rowl = b * 64 + lane;
         bool valid = rowl < ns;
         unsigned long long d = valid ? M[(unsigned long long)rowl * B + b] : 0ull;
-        unsigned long long r = s_remv[b];
+        const unsigned long long r0 = s_remv[b];
+        // the running remove word lives in SGPRs (it is wave-uniform): the 64-step greedy resolve is
+        // then a chain of scalar bit tests, one v_readlane pair per step
+        uint32_t rlo = __builtin_amdgcn_readfirstlane((uint32_t)r0);
+        uint32_t rhi = __builtin_amdgcn_readfirstlane((uint32_t)(r0 >> 32));
         uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
-        for (int t = 0; t < 64; t++) {
+#pragma unroll
+        for (int t = 0; t < 32; t++) {
           // readlane returns a signed int: go through uint32_t or bit 31 sign-extends
-          unsigned long long dt = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dhi, t) << 32) |
-                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dlo, t);
-          if (!((r >> t) & 1ull)) r |= dt;
+          uint32_t tl = (uint32_t)__builtin_amdgcn_readlane(dlo, t), th = (uint32_t)__builtin_amdgcn_readlane(dhi, t);
+          if (!((rlo >> t) & 1u)) { rlo |= tl; rhi |= th; }
         }
+#pragma unroll
+        for (int t = 32; t < 64; t++) {
+          uint32_t th = (uint32_t)__builtin_amdgcn_readlane(dhi, t);   // bits <= t are never set in row t
+          if (!((rhi >> (t - 32)) & 1u)) rhi |= th;
+        }
+        const unsigned long long r = ((unsigned long long)rhi << 32) | rlo;
         unsigned long long validmask = (ns - b * 64 >= 64) ? ~0ull : ((1ull << (ns - b * 64)) - 1ull);
         unsigned long long kb = ~r & validmask;
         if (valid) keep_orig[perm_seg[st + rowl]] = (uint8_t)((kb >> lane) & 1ull);
+        if ((kb >> lane) & 1ull) s_rows[__popcll(kb & ((1ull << lane) - 1ull))] = (unsigned char)lane;
         if (lane == 0) *s_keep = kb;
       }
       __syncthreads();
-      const unsigned long long kb = *s_keep;
-      // rows kept in this block suppress later columns: OR their mask rows into the running
-      // remove vector.  Lanes walk consecutive words of a row (coalesced); four rows in flight.
-      const int nk = __popcll(kb);
-      for (uint32_t c = b + 1 + threadIdx.x; c < B; c += kThreads) {
-        unsigned long long acc = s_remv[c];
-        unsigned long long bits = kb;
-        int left = nk;
-        while (left >= 4) {
-          int t0 = __builtin_ctzll(bits); bits &= bits - 1;
-          int t1 = __builtin_ctzll(bits); bits &= bits - 1;
-          int t2 = __builtin_ctzll(bits); bits &= bits - 1;
-          int t3 = __builtin_ctzll(bits); bits &= bits - 1;
-          unsigned long long m0 = M[(unsigned long long)(b * 64 + t0) * B + c];
-          unsigned long long m1 = M[(unsigned long long)(b * 64 + t1) * B + c];
-          unsigned long long m2 = M[(unsigned long long)(b * 64 + t2) * B + c];
-          unsigned long long m3 = M[(unsigned long long)(b * 64 + t3) * B + c];
-          acc |= (m0 | m1) | (m2 | m3);
-          left -= 4;
+      // rows kept in this block suppress later columns: OR their mask rows into the running remove
+      // vector.  The four waves split the kept rows (every 4th each, four loads in flight per lane);
+      // lanes walk consecutive words of a row (coalesced); partial ORs meet in LDS (ds_or_b64).
+      const int nk = __popcll(*s_keep);
+      for (uint32_t c0 = b + 1; c0 < B; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const bool cv = c < B;
+        unsigned long long acc = 0ull;
+        int k = wave;
+        for (; k + 12 < nk; k += 16) {
+          const unsigned long long t0 = s_rows[k], t1 = s_rows[k + 4], t2 = s_rows[k + 8], t3 = s_rows[k + 12];
+          if (cv) {
+            unsigned long long m0 = M[(b * 64ull + t0) * B + c], m1 = M[(b * 64ull + t1) * B + c];
+            unsigned long long m2 = M[(b * 64ull + t2) * B + c], m3 = M[(b * 64ull + t3) * B + c];
+            acc |= (m0 | m1) | (m2 | m3);
+          }
         }
-        while (bits) {
-          int t = __builtin_ctzll(bits);
-          bits &= bits - 1;
-          acc |= M[(unsigned long long)(b * 64 + t) * B + c];
-        }
-        s_remv[c] = acc;
+        for (; k < nk; k += 4)
+          if (cv) acc |= M[(b * 64ull + s_rows[k]) * B + c];
+        if (cv && acc) atomicOr(&s_remv[c], acc);
       }
       __syncthreads();
     }
@@ -737,7 +753,8 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   k_nms_direct<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.tile_off,
                                                      B.row_base, thr, B.gcount, pl.queue_cap, B.mask,
                                                      B.mask_off + n, pl.mask_words);
-  size_t lds = ((size_t)pl.max_blocks + 2) * sizeof(unsigned long long);
+  size_t lds = ((size_t)pl.max_blocks + 10 + kScanCacheWords) * sizeof(unsigned long long);
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   k_nms_scan<<<512, kThreads, lds, st>>>(B.mask, B.seg_start, B.num_seg, B.mask_off, B.nblk, B.perm_seg,
                                          B.keep_orig, pl.max_blocks, B.mask_off + n, pl.mask_words,
                                          reinterpret_cast<uint32_t*>(B.gcount + 1));
@@ -777,7 +794,7 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
     set_error("nms_rotated: workspace too small (%zu < %zu)", ws_bytes, cv.off);
     return S2A_EWORKSPACE;
   }
-  S2A_CHECK_ARG(((size_t)pl.max_blocks + 2) * 8 <= 64 * 1024,
+  S2A_CHECK_ARG(((size_t)pl.max_blocks + 10 + kScanCacheWords) * 8 <= 112 * 1024,
                 "nms_rotated: more than 524k rows in one segment is not supported");
   int rc = nms_core(dets, scores, labels, nullptr, nullptr, n, 0, 1, thr, pl, B, st);
   if (rc != S2A_OK) return rc;
@@ -1008,7 +1025,7 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
   unsigned long long nb = pl.mask_words / (unsigned long long)n;
   S2A_CHECK_ARG(nb >= 1, "nms_rotated_segmented: workspace too small for the suppression mask");
   pl.max_blocks = (uint32_t)std::min<unsigned long long>(nb, ((unsigned long long)n + 63) / 64);
-  S2A_CHECK_ARG(((size_t)pl.max_blocks + 2) * 8 <= 64 * 1024, "nms_rotated_segmented: segment too large");
+  S2A_CHECK_ARG(((size_t)pl.max_blocks + 10 + kScanCacheWords) * 8 <= 112 * 1024, "nms_rotated_segmented: segment too large");
   int rc = nms_core(dets, scores, nullptr, segment_ids, group_ids, n, (uint32_t)num_segments,
                     (uint32_t)num_groups, iou_threshold, pl, B, st);
   if (rc != S2A_OK) return rc;
