@@ -64,6 +64,12 @@ int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* boxes2, int
 int s2a_box_iou_rotated_pairs(const float* boxes1, const float* boxes2, int64_t n, float* ious,
                               s2a_stream_t stream);
 
+/* polyiou.iou_poly (DOTA_devkit/polyiou/csrc/polyiou.cpp:108-128; SWIG module `polyiou`), element-wise
+ * over n pairs of quadrilaterals: polys[n,8] f64 (x1,y1,...,x4,y4) -> ious[n] f64.  Double precision,
+ * same operation order as the reference (bit-identical to it on the tested inputs). */
+int s2a_polyiou_pairs(const double* polys1, const double* polys2, int64_t n, double* ious,
+                      s2a_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Rotated NMS.  Replaces
  *   utils.nms_rotated.nms_rotated_cuda.nms_rotated(dets[N,5], scores[N], thr) -> int64[K]
@@ -127,6 +133,13 @@ int s2a_multiclass_candidates(const float* boxes, const float* scores, int64_t b
 int s2a_arf_forward(const void* weight, const uint8_t* indices, int64_t n_out, int64_t n_in,
                     int n_orientation, int kh, int kw, int n_rotation, int dtype, void* output,
                     s2a_stream_t stream);
+
+/* orn_cuda.arf_backward(indices, gradOutput[O*nRot, I*nOri, kH, kW]) -> gradInput[O,I,nOri,kH,kW]
+ * (models/orn/src/vision.cpp:9, cuda/ActiveRotatingFilter_cuda.cu:49-76,122-162): sum over the nRot
+ * rotated copies, ascending k.  float32 (the reference dispatches float/double only). */
+int s2a_arf_backward(const uint8_t* indices, const void* grad_output, int64_t n_out, int64_t n_in,
+                     int n_orientation, int kh, int kw, int n_rotation, int dtype, void* grad_input,
+                     s2a_stream_t stream);
 
 /* RotationInvariantPooling.forward (models/orn/functions/rotation_invariant_pooling.py:19-27):
  * x[B,C,H,W] -> out[B,C/nOri,H,W] = max over each group of nOri consecutive channels. */

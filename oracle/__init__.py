@@ -65,6 +65,8 @@ def lib():
         L.orc_polyiou_pairs.argtypes = [f64p, f64p, i64, f64p]
         L.orc_arf_forward.restype = None
         L.orc_arf_forward.argtypes = [f32p, u8p, i64, i64, ci, ci, ci, ci, f32p]
+        L.orc_arf_backward.restype = None
+        L.orc_arf_backward.argtypes = [f32p, u8p, i64, i64, ci, ci, ci, ci, f32p]
         L.orc_rot_inv_pool.restype = None
         L.orc_rot_inv_pool.argtypes = [f32p, i64, i64, i64, ci, f32p]
         L.orc_deform_conv_forward.restype = None
@@ -140,6 +142,17 @@ def arf_forward(weight, indices):
     nRot = idx.shape[3]
     out = np.empty((O * nRot, I * nOri, kH, kW), np.float32)
     lib().orc_arf_forward(_p(w), _p(idx, ctypes.c_uint8), O, I, nOri, kH, kW, nRot, _p(out))
+    return out
+
+
+def arf_backward(indices, grad_output):
+    """grad_output [O*nRot, I*nOri, kH, kW] -> grad_input [O, I, nOri, kH, kW]"""
+    idx = np.ascontiguousarray(indices, np.uint8)
+    g = _f32(grad_output)
+    nOri, kH, kW, nRot = idx.shape
+    O, I = g.shape[0] // nRot, g.shape[1] // nOri
+    out = np.empty((O, I, nOri, kH, kW), np.float32)
+    lib().orc_arf_backward(_p(g), _p(idx, ctypes.c_uint8), O, I, nOri, kH, kW, nRot, _p(out))
     return out
 
 

@@ -407,6 +407,24 @@ void orc_arf_forward(const float* w, const uint8_t* idx, int64_t nOut, int64_t n
       }
 }
 
+// ARF_backward (models/orn/src/cuda/ActiveRotatingFilter_cuda.cu:49-76; CPU :41-79):
+//   gradInput[i, j, l] = sum_{k=0..nRot-1} gradOutput[(i*nRot + k), j*nEntry + idx[l,k]-1]
+// accumulated in ascending k from 0, as the reference does (float order matters for bit parity).
+void orc_arf_backward(const float* gout, const uint8_t* idx, int64_t nOut, int64_t nIn, int nOri, int kH,
+                      int kW, int nRot, float* gin) {
+  const int64_t nEntry = (int64_t)nOri * kH * kW;
+  for (int64_t i = 0; i < nOut; i++)
+    for (int64_t j = 0; j < nIn; j++)
+      for (int64_t l = 0; l < nEntry; l++) {
+        float v = 0;
+        for (int k = 0; k < nRot; k++) {
+          int64_t t = (int64_t)idx[l * nRot + k] - 1;
+          v = v + gout[((i * nRot + k) * nIn + j) * nEntry + t];
+        }
+        gin[(i * nIn + j) * nEntry + l] = v;
+      }
+}
+
 // RotationInvariantPooling (models/orn/functions/rotation_invariant_pooling.py:19-27)
 // x[B, C, HW] -> out[B, C/nOri, HW], max over groups of nOri consecutive channels
 void orc_rot_inv_pool(const float* x, int64_t B, int64_t C, int64_t HW, int nOri, float* out) {

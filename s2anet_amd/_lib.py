@@ -42,6 +42,7 @@ SYMBOLS = {
     "s2a_box_iou_rotated_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "s2a_box_iou_rotated": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "s2a_box_iou_rotated_pairs": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "s2a_polyiou_pairs": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "s2a_nms_rotated_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "s2a_ml_nms_rotated": (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp,
                                    ctypes.POINTER(c_i64), c_vp, c_sz, c_vp]),
@@ -55,6 +56,7 @@ SYMBOLS = {
                                           c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "s2a_arf_forward": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp,
                                 c_vp]),
+    "s2a_arf_backward": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "s2a_rot_inv_pool": (c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "s2a_deform_conv_workspace_bytes": (c_sz, [ctypes.POINTER(DcnParams)]),
     "s2a_deform_conv_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(DcnParams), c_vp,

@@ -40,7 +40,8 @@ def build_modules():
     m[p.__name__] = p
     o = types.ModuleType("models.orn.orn_cuda")
     o.arf_forward = orn.arf_forward                                       # vision.cpp:7-12
-    for n in ("arf_backward", "rie_forward", "rie_backward"):
+    o.arf_backward = orn.arf_backward                                     # vision.cpp:9
+    for n in ("rie_forward", "rie_backward"):
         setattr(o, n, _not_impl(n))
     m[o.__name__] = o
     b = types.ModuleType("utils.box_iou_rotated.box_iou_rotated_cuda")

@@ -38,6 +38,31 @@ __global__ __launch_bounds__(256) void k_arf_forward(const T* __restrict__ w,
   }
 }
 
+// ARF backward (ActiveRotatingFilter_cuda.cu:49-76): gather-sum of the nRot rotated copies, one
+// thread per filter-bank element, k ascending like the reference (plain adds: bit-identical)
+template <typename T>
+__global__ __launch_bounds__(256) void k_arf_backward(const T* __restrict__ gout,
+                                                      const uint8_t* __restrict__ idx, int64_t n_out,
+                                                      int64_t n_in, int n_entry, int n_rot,
+                                                      T* __restrict__ gin) {
+  __shared__ uint8_t s_idx[8 * 256];
+  for (int e = threadIdx.x; e < n_entry * n_rot; e += blockDim.x) s_idx[e] = idx[e];
+  __syncthreads();
+  const int64_t total = n_out * n_in * n_entry;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int l = (int)(e % n_entry);
+    int64_t r = e / n_entry;
+    int64_t j = r % n_in, i = r / n_in;
+    T v = 0;
+    for (int k = 0; k < n_rot; k++) {
+      int t = (int)s_idx[l * n_rot + k] - 1;
+      v = v + gout[((i * n_rot + k) * n_in + j) * n_entry + t];
+    }
+    gin[e] = v;
+  }
+}
+
 __device__ __forceinline__ float nanmax(float m, float a) {
   // torch.max propagates NaN
   return (a > m || a != a) ? a : m;
@@ -121,6 +146,23 @@ extern "C" int s2a_arf_forward(const void* weight, const uint8_t* indices, int64
   else
     k_arf_forward<uint16_t><<<g, 256, 0, st>>>((const uint16_t*)weight, indices, n_out, n_in,
                                                n_entry, n_rotation, (uint16_t*)output);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+extern "C" int s2a_arf_backward(const uint8_t* indices, const void* grad_output, int64_t n_out, int64_t n_in,
+                                int n_orientation, int kh, int kw, int n_rotation, int dtype,
+                                void* grad_input, s2a_stream_t stream) {
+  S2A_CHECK_ARG(n_out >= 0 && n_in >= 0 && n_orientation > 0 && kh > 0 && kw > 0 && n_rotation > 0,
+                "arf_backward: bad shape");
+  const int n_entry = n_orientation * kh * kw;
+  S2A_CHECK_ARG(n_entry <= 255 && n_rotation <= 8, "arf_backward: index table too large");
+  S2A_CHECK_ARG(dtype == S2A_DTYPE_F32, "arf_backward: float32 only (the reference dispatches float/double, cuda.cu:149)");
+  const int64_t total = n_out * n_in * n_entry;
+  if (total == 0) return S2A_OK;
+  S2A_CHECK_ARG(indices && grad_output && grad_input, "arf_backward: NULL tensor");
+  k_arf_backward<float><<<grid_cap(total), 256, 0, as_stream(stream)>>>((const float*)grad_output, indices, n_out, n_in,
+                                                                       n_entry, n_rotation, (float*)grad_input);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

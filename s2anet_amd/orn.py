@@ -44,16 +44,38 @@ def arf_forward(weight, indices):
     return out
 
 
+def arf_backward(indices, grad_output):
+    """orn_cuda.arf_backward: indices uint8[nOri,kH,kW,nRot], gradOutput[O*nRot, I*nOri, kH, kW]
+    -> gradInput[O, I, nOri, kH, kW] (new tensor; float32)"""
+    _lib.require_cuda(indices, grad_output)
+    idx = indices.contiguous()
+    if idx.dtype != torch.uint8:
+        idx = idx.byte()
+    g = grad_output.contiguous()
+    if g.dtype != torch.float32:
+        raise RuntimeError("arf_backward: float32 gradients only")
+    nOri, kH, kW, nRot = idx.shape
+    O, I = g.shape[0] // nRot, g.shape[1] // nOri
+    out = torch.empty((O, I, nOri, kH, kW), dtype=g.dtype, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().s2a_arf_backward(_lib.ptr(idx), _lib.ptr(g), O, I, nOri, kH, kW, nRot,
+                                               _lib.dtype_code(g), _lib.ptr(out), _lib.stream_ptr(g.device)))
+    return out
+
+
 class _ActiveRotatingFilter(torch.autograd.Function):
+    """models/orn/functions/active_rotating_filter.py:11-34"""
+
     @staticmethod
     def forward(ctx, input, indices):
+        indices = indices.byte()
         ctx.save_for_backward(indices)
-        ctx.in_shape = input.shape
         return arf_forward(input, indices)
 
     @staticmethod
-    def backward(ctx, grad_output):  # pragma: no cover - training path, SURVEY 8(f) "next"
-        raise NotImplementedError("arf_backward is outside the inference hot path (SURVEY.md 8(f))")
+    def backward(ctx, grad_output):
+        indices, = ctx.saved_tensors
+        return arf_backward(indices, grad_output), None
 
 
 active_rotating_filter = _ActiveRotatingFilter.apply

@@ -55,6 +55,20 @@ def box_iou_rotated_pairs(boxes1, boxes2):
     return out
 
 
+def polyiou_pairs(polys1, polys2):
+    """polyiou.iou_poly element-wise: polys[n,8] (x1,y1..x4,y4) -> float64[n]
+    (DOTA_devkit/polyiou/csrc/polyiou.cpp:108-128)"""
+    _lib.require_cuda(polys1, polys2)
+    p = polys1.to(torch.float64).contiguous().reshape(-1, 8)
+    q = polys2.to(torch.float64).contiguous().reshape(-1, 8)
+    assert p.shape == q.shape
+    out = torch.empty((p.shape[0],), dtype=torch.float64, device=p.device)
+    with torch.cuda.device(p.device):
+        _lib.check(_lib.lib().s2a_polyiou_pairs(_lib.ptr(p), _lib.ptr(q), p.shape[0], _lib.ptr(out),
+                                                _lib.stream_ptr(p.device)))
+    return out
+
+
 def _nms_raw(dets, scores, labels, iou_threshold):
     _lib.require_cuda(dets, scores, labels)
     d = _f32c(dets)

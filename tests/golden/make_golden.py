@@ -137,6 +137,21 @@ def gen_arf(rng):
     np.savez_compressed(os.path.join(OUT, "arf_small.npz"), **out)
 
 
+def gen_arf_backward():
+    """separate file + own rng so the other fixtures stay byte-identical"""
+    rng = np.random.default_rng(4321)
+    orn = ref.orn()
+    out = {}
+    for tag, shp in (("s1", (4, 2, 1, 3, 3)), ("s8", (4, 2, 8, 3, 3))):
+        O, I, nOri, kH, kW = shp
+        idx = oracle.arf_indices(nOri, 8, 3)
+        g = rng.standard_normal((O * 8, I * nOri, kH, kW)).astype(np.float32)
+        out[f"idx_{tag}"] = idx
+        out[f"gout_{tag}"] = g
+        out[f"gin_{tag}"] = orn.arf_backward(torch.from_numpy(idx), torch.from_numpy(g)).numpy()
+    np.savez_compressed(os.path.join(OUT, "arf_backward_small.npz"), **out)
+
+
 def import_reference_python():
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
@@ -254,4 +269,5 @@ if __name__ == "__main__":
     gen_arf(rng)
     gen_dcn(rng)
     gen_glue(rng)
+    gen_arf_backward()
     print("done ->", OUT)

@@ -21,7 +21,7 @@ def test_alias_modules_have_reference_names():
               "modulated_deform_conv_cuda_forward", "modulated_deform_conv_cuda_backward"):
         with pytest.raises(NotImplementedError):
             getattr(d, n)()
-    assert callable(mods["models.orn.orn_cuda"].arf_forward)
+    assert callable(mods["models.orn.orn_cuda"].arf_forward) and callable(mods["models.orn.orn_cuda"].arf_backward)
     assert callable(mods["utils.box_iou_rotated.box_iou_rotated_cuda"].box_iou_rotated)
     assert callable(mods["utils.nms_rotated.nms_rotated_cuda"].nms_rotated)
     assert callable(mods["utils.ml_nms_rotated.ml_nms_rotated_cuda"].ml_nms_rotated)

@@ -417,3 +417,39 @@ def test_own_conv1x1_f16_vs_torch(shape):
     assert err2.max().item() < 3e-2 and err2.mean().item() < 3e-3
     out3 = conv_f16(x, wp, None, O, 1, st, False, res)
     assert (out3.float() - (torch.nn.functional.conv2d(x.float(), w.float(), None, stride=st) + res.float())).abs().max().item() < 3e-2
+
+
+def test_arf_backward_and_autograd(rng):
+    import s2anet_amd as S
+    g = golden("arf_backward_small.npz")
+    for tag in ("s1", "s8"):
+        out = S.arf_backward(cu(g[f"idx_{tag}"]), cu(g[f"gout_{tag}"]))
+        assert np.array_equal(out.cpu().numpy(), g[f"gin_{tag}"])          # bit-exact vs the reference CPU op
+    idx = oracle.arf_indices(1, 8, 3)
+    gy = rng.standard_normal((256, 256, 3, 3)).astype(np.float32)
+    assert np.array_equal(S.arf_backward(cu(idx), cu(gy)).cpu().numpy(), oracle.arf_backward(idx, gy))
+    # autograd through ORConv2d (training-mode filter expansion): gradient reaches the ARF bank
+    oc = S.ORConv2d(16, 2, kernel_size=3, padding=1, arf_config=(1, 8)).to(dev()).train()
+    x = torch.randn(2, 16, 6, 6, device=dev())
+    y = oc(x)
+    y.square().sum().backward()
+    assert oc.weight.grad is not None and oc.weight.grad.shape == oc.weight.shape
+    w_exp = S.arf_forward(oc.weight.detach(), oc.indices).requires_grad_(True)
+    y2 = torch.nn.functional.conv2d(x, w_exp, oc.bias, padding=1)
+    y2.square().sum().backward()
+    assert torch.allclose(oc.weight.grad, S.arf_backward(oc.indices, w_exp.grad), rtol=1e-5, atol=1e-5)
+
+
+def test_polyiou_pairs_bitexact(rng):
+    from s2anet_amd.rotated import polyiou_pairs
+    g = golden("iou_256.npz")
+    P1, P2 = oracle.rboxes_to_polys(g["boxes1"]), oracle.rboxes_to_polys(g["boxes2"])
+    out = polyiou_pairs(cu(P1[g["poly_i"]]), cu(P2[g["poly_j"]])).cpu().numpy()
+    assert np.array_equal(out, g["poly_iou"])                   # f64, bit for bit vs the reference SWIG module
+    a, b = oracle.rboxes_to_polys(rand_rboxes(rng, 20000, span=300)), oracle.rboxes_to_polys(rand_rboxes(rng, 20000, span=300))
+    b[:10] = a[:10]                                             # identical polygons
+    a[10:20, :] = a[10:20, [6, 7, 4, 5, 2, 3, 0, 1]]            # clockwise input -> reversed internally
+    out = polyiou_pairs(cu(a), cu(b)).cpu().numpy()
+    ref = oracle.polyiou(a, b)
+    assert np.array_equal(out, ref, equal_nan=True)
+    assert abs(polyiou_pairs(cu(np.array([[0, 0, 1, 0, 1, 1, 0, 1.0]])), cu(np.array([[.5, .5, 1.5, .5, 1.5, 1.5, .5, 1.5]]))).item() - 1 / 7) < 1e-12

@@ -102,6 +102,20 @@ def test_arf_matches_reference_small_and_definition_large():
     assert np.array_equal(out.reshape(32, 8, 256, 9)[:, 0], w.reshape(32, 256, 9))  # rotation 0 = identity
 
 
+def test_arf_backward_matches_reference():
+    g = golden("arf_backward_small.npz")
+    for tag in ("s1", "s8"):
+        assert np.array_equal(oracle.arf_backward(g[f"idx_{tag}"], g[f"gout_{tag}"]), g[f"gin_{tag}"])
+    # adjoint identity at production shape: <arf(w), g> == <w, arf_backward(g)>
+    rng = np.random.default_rng(2)
+    idx = oracle.arf_indices(1, 8, 3)
+    w = rng.standard_normal((32, 256, 1, 3, 3)).astype(np.float32)
+    gy = rng.standard_normal((256, 256, 3, 3)).astype(np.float32)
+    lhs = float((oracle.arf_forward(w, idx).astype(np.float64) * gy).sum())
+    rhs = float((w.astype(np.float64) * oracle.arf_backward(idx, gy)).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
 def test_head_glue_matches_reference_python():
     g = golden("head_glue.npz")
     assert np.array_equal(oracle.grid_anchors(12, 20, 8), g["anchors_s8"])
