@@ -70,6 +70,14 @@ int s2a_box_iou_rotated_pairs(const float* boxes1, const float* boxes2, int64_t 
 int s2a_polyiou_pairs(const double* polys1, const double* polys2, int64_t n, double* ious,
                       s2a_stream_t stream);
 
+/* Chip-merge polygon NMS: py_cpu_nms_poly_fast(dets[n,9] f64 = 8 polygon coordinates + score, thresh)
+ * (DOTA_devkit/ResultMerge_multi_process.py:62-123) entirely on the device.  keep[] (n int64) receives
+ * the surviving original indices in descending-score order, *count_dev their number; host_count as in
+ * s2a_nms_rotated.  Score ties: ascending index. */
+size_t s2a_nms_poly_workspace_bytes(int64_t n);
+int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64_t* keep, int64_t* count_dev,
+                 int64_t* host_count, void* workspace, size_t workspace_bytes, s2a_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Rotated NMS.  Replaces
  *   utils.nms_rotated.nms_rotated_cuda.nms_rotated(dets[N,5], scores[N], thr) -> int64[K]

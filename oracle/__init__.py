@@ -63,6 +63,8 @@ def lib():
         L.orc_polyiou.argtypes = [f64p, f64p]
         L.orc_polyiou_pairs.restype = None
         L.orc_polyiou_pairs.argtypes = [f64p, f64p, i64, f64p]
+        L.orc_nms_poly.restype = i64
+        L.orc_nms_poly.argtypes = [f64p, i64, ctypes.c_double, i64p]
         L.orc_arf_forward.restype = None
         L.orc_arf_forward.argtypes = [f32p, u8p, i64, i64, ci, ci, ci, ci, f32p]
         L.orc_arf_backward.restype = None
@@ -133,6 +135,14 @@ def polyiou(p8, q8):
     lib().orc_polyiou_pairs(_p(p, ctypes.c_double), _p(q, ctypes.c_double), p.shape[0],
                             _p(out, ctypes.c_double))
     return out
+
+
+def nms_poly(dets9, thresh=0.5):
+    """py_cpu_nms_poly_fast restated: dets[n,9] float64 -> kept original indices, score descending"""
+    d = np.ascontiguousarray(dets9, np.float64).reshape(-1, 9)
+    keep = np.empty(d.shape[0], np.int64)
+    k = lib().orc_nms_poly(_p(d, ctypes.c_double), d.shape[0], float(thresh), _p(keep, ctypes.c_int64))
+    return keep[:k].copy()
 
 
 def arf_forward(weight, indices):

@@ -388,6 +388,45 @@ void orc_polyiou_pairs(const double* p8, const double* q8, int64_t n, double* ou
   for (int64_t i = 0; i < n; i++) out[i] = quad_iou(p8 + 8 * i, q8 + 8 * i);
 }
 
+// ----- polygon NMS of the chip-merge step -------------------------------------
+// py_cpu_nms_poly_fast (DOTA_devkit/ResultMerge_multi_process.py:62-123).  dets[n,9] = x1,y1..x4,y4,score
+// (float64).  Order: score descending; ties by ascending index (the reference's
+// `scores.argsort()[::-1]` leaves ties to numpy's unstable sort).  A remaining j survives a kept i
+// iff hbb_ovr <= thresh, where hbb_ovr is replaced by polyiou(i, j) when the axis-aligned boxes
+// overlap (hbb_ovr > 0) (:87-115).  keep[] = original indices in descending-score order.
+int64_t orc_nms_poly(const double* dets, int64_t n, double thresh, int64_t* keep) {
+  std::vector<int64_t> order(n);
+  for (int64_t i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return dets[9 * a + 8] > dets[9 * b + 8]; });
+  std::vector<double> x1(n), y1(n), x2(n), y2(n), area(n);
+  for (int64_t i = 0; i < n; i++) {
+    const double* d = dets + 9 * i;
+    x1[i] = std::min(std::min(d[0], d[2]), std::min(d[4], d[6]));
+    y1[i] = std::min(std::min(d[1], d[3]), std::min(d[5], d[7]));
+    x2[i] = std::max(std::max(d[0], d[2]), std::max(d[4], d[6]));
+    y2[i] = std::max(std::max(d[1], d[3]), std::max(d[5], d[7]));
+    area[i] = (x2[i] - x1[i] + 1) * (y2[i] - y1[i] + 1);
+  }
+  std::vector<uint8_t> dead(n, 0);
+  int64_t k = 0;
+  for (int64_t oi = 0; oi < n; oi++) {
+    int64_t i = order[oi];
+    if (dead[i]) continue;
+    keep[k++] = i;
+    for (int64_t oj = oi + 1; oj < n; oj++) {
+      int64_t j = order[oj];
+      if (dead[j]) continue;
+      double w = std::max(0.0, std::min(x2[i], x2[j]) - std::max(x1[i], x1[j]));
+      double h = std::max(0.0, std::min(y2[i], y2[j]) - std::max(y1[i], y1[j]));
+      double inter = w * h;
+      double ovr = inter / (area[i] + area[j] - inter);
+      if (ovr > 0) ovr = quad_iou(dets + 9 * i, dets + 9 * j);
+      if (!(ovr <= thresh)) dead[j] = 1;
+    }
+  }
+  return k;
+}
+
 // ----- ORN: active rotating filter ------------------------------------------
 // ARF_forward (models/orn/src/cuda/ActiveRotatingFilter_cuda.cu:20-46, the
 // int-indexed GPU kernel; the CPU file's uint16 weightIndex wraps at 65536 and

@@ -34,6 +34,12 @@ struct Carver {
   }
 };
 
+// greedy NMS scan over a suppression bitmask (rotated_ops.hip), shared with the polygon NMS
+int launch_nms_scan(const unsigned long long* mask, const uint32_t* seg_start, const uint32_t* num_seg,
+                    const unsigned long long* mask_off, const uint32_t* nblk, const int32_t* perm_seg,
+                    uint8_t* keep_orig, uint32_t max_blocks, const unsigned long long* words_total,
+                    unsigned long long words_bound, uint32_t* status, hipStream_t st);
+
 }  // namespace s2a
 
 #define S2A_CHECK_ARG(cond, ...)          \

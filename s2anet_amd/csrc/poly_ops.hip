@@ -11,6 +11,11 @@
 // of box_iou_rotated.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 #include "common.hpp"
 
 namespace s2a {
@@ -145,8 +150,159 @@ __global__ __launch_bounds__(kPolyThreads) void k_polyiou_pairs(const double* __
   out[i] = poly_iou(p8 + 8 * i, q8 + 8 * i, s_p + threadIdx.x, s_t + threadIdx.x);
 }
 
+// ---------------------------------------------------------------- polygon NMS (chip merge)
+// py_cpu_nms_poly_fast (DOTA_devkit/ResultMerge_multi_process.py:62-123): dets[n,9] = 8 polygon
+// coordinates + score; greedy over descending score; a lower-scored j is dropped by a kept i unless
+// NOT (iou <= thresh), where iou = polyiou when the axis-aligned boxes overlap (hbb_ovr > 0) and 0
+// otherwise (:87-115).  Same device pipeline as the rotated NMS: radix sort, 64x64 upper-triangle
+// tiles -> bitmask in HBM, on-device greedy scan, compaction — no host round trip of the mask.
+struct PolyBox {
+  double c[8];
+  double x1, y1, x2, y2;   // hbb (:64-67); area = (x2-x1+1)*(y2-y1+1) (:69)
+};
+
+__device__ __forceinline__ unsigned long long dbl_sortable(double d) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__global__ void k_poly_keys(const double* __restrict__ dets9, int64_t n, unsigned long long* __restrict__ key,
+                            int32_t* __restrict__ idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  key[i] = ~dbl_sortable(dets9[9 * i + 8]);   // ascending radix sort == descending score
+  idx[i] = (int32_t)i;
+}
+
+__global__ void k_poly_prep(const double* __restrict__ dets9, const int32_t* __restrict__ order, int64_t n,
+                            PolyBox* __restrict__ sorted, uint32_t* __restrict__ seg_start,
+                            uint32_t* __restrict__ num_seg, unsigned long long* __restrict__ mask_off,
+                            uint32_t* __restrict__ nblk) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) {
+    const unsigned long long nb = (unsigned long long)(n + 63) / 64;
+    seg_start[0] = 0;
+    seg_start[1] = (uint32_t)n;
+    *num_seg = 1;
+    mask_off[0] = 0;
+    mask_off[1] = (unsigned long long)n * nb;
+    nblk[0] = (uint32_t)nb;
+  }
+  if (p >= n) return;
+  const double* d = dets9 + 9 * (int64_t)order[p];
+  PolyBox b;
+#pragma unroll
+  for (int k = 0; k < 8; k++) b.c[k] = d[k];
+  b.x1 = fmin(fmin(d[0], d[2]), fmin(d[4], d[6]));
+  b.y1 = fmin(fmin(d[1], d[3]), fmin(d[5], d[7]));
+  b.x2 = fmax(fmax(d[0], d[2]), fmax(d[4], d[6]));
+  b.y2 = fmax(fmax(d[1], d[3]), fmax(d[5], d[7]));
+  sorted[p] = b;
+}
+
+#define P(i) p[(i) * 64]
+#define T(i) tmp[(i) * 64]
+// 64 threads = the 64 rows of a tile; each walks the 64 columns of the tile
+__global__ __launch_bounds__(64) void k_poly_mask(const PolyBox* __restrict__ sorted, int64_t n, double thresh,
+                                                  unsigned long long* __restrict__ mask) {
+  const uint32_t rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  __shared__ D2 s_p[kPMax * 64];
+  __shared__ D2 s_t[kTmpMax * 64];
+  __shared__ PolyBox s_col[64];
+  const uint32_t nb = (uint32_t)((n + 63) / 64);
+  const int64_t j0 = (int64_t)cb * 64;
+  if (j0 + threadIdx.x < n) s_col[threadIdx.x] = sorted[j0 + threadIdx.x];
+  __syncthreads();
+  const int64_t i = (int64_t)rb * 64 + threadIdx.x;
+  if (i >= n) return;
+  const PolyBox A = sorted[i];
+  const double areaA = (A.x2 - A.x1 + 1) * (A.y2 - A.y1 + 1);
+  unsigned long long bits = 0;
+  // the per-thread LDS polygons are strided by 64 here (block of 64 threads)
+  D2* p = s_p + threadIdx.x;
+  D2* tmp = s_t + threadIdx.x;
+  for (int c = 0; c < 64; c++) {
+    const int64_t j = j0 + c;
+    if (j >= n || j <= i) continue;
+    const PolyBox& B = s_col[c];
+    double w = fmax(0.0, fmin(A.x2, B.x2) - fmax(A.x1, B.x1));
+    double h = fmax(0.0, fmin(A.y2, B.y2) - fmax(A.y1, B.y1));
+    double inter = w * h;
+    double ovr = inter / (areaA + (B.x2 - B.x1 + 1) * (B.y2 - B.y1 + 1) - inter);
+    if (ovr > 0) {
+      // poly_iou with the 64-thread LDS stride
+      D2 a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        a[k] = {A.c[2 * k], A.c[2 * k + 1]};
+        b[k] = {B.c[2 * k], B.c[2 * k + 1]};
+      }
+      if (quad_area(a) < 0) { D2 t = a[0]; a[0] = a[3]; a[3] = t; t = a[1]; a[1] = a[2]; a[2] = t; }
+      if (quad_area(b) < 0) { D2 t = b[0]; b[0] = b[3]; b[3] = t; t = b[1]; b[1] = b[2]; b[2] = t; }
+      double isum = 0;
+#pragma unroll
+      for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          // fan_overlap with stride-64 LDS polygons
+          D2 pa = a[ii], pb = a[(ii + 1) & 3], pc = b[jj], pd = b[(jj + 1) & 3];
+          D2 o{0, 0};
+          int s1 = sgn(tri_cross(o, pa, pb)), s2 = sgn(tri_cross(o, pc, pd));
+          if (s1 == 0 || s2 == 0) continue;
+          if (s1 == -1) { D2 t = pa; pa = pb; pb = t; }
+          if (s2 == -1) { D2 t = pc; pc = pd; pd = t; }
+          P(0) = o; P(1) = pa; P(2) = pb;
+          int np_ = 3;
+          // three half-plane cuts (polygon_cut), stride 64
+          D2 ca[3] = {o, pc, pd}, cbv[3] = {pc, pd, o};
+          for (int cut = 0; cut < 3; cut++) {
+            const D2 la = ca[cut], lb = cbv[cut];
+            int m = 0;
+            P(np_) = P(0);
+            for (int q = 0; q < np_; q++) {
+              D2 pi = P(q), pn = P(q + 1);
+              int si = sgn(tri_cross(la, lb, pi));
+              if (si > 0) { T(m) = pi; m++; }
+              if (si != sgn(tri_cross(la, lb, pn))) {
+                double c1 = tri_cross(la, lb, pi), c2 = tri_cross(la, lb, pn);
+                D2 hit = T(m);
+                if (!(sgn(c1) == 0 && sgn(c2) == 0) && sgn(c2 - c1) != 0) {
+                  hit.x = (pi.x * c2 - pn.x * c1) / (c2 - c1);
+                  hit.y = (pi.y * c2 - pn.y * c1) / (c2 - c1);
+                }
+                T(m) = hit; m++;
+              }
+            }
+            np_ = 0;
+            for (int q = 0; q < m; q++) {
+              D2 tq = T(q);
+              if (!q || !same_pt(tq, T(q - 1))) { P(np_) = tq; np_++; }
+            }
+            while (np_ > 1 && same_pt(P(np_ - 1), P(0))) np_--;
+          }
+          P(np_) = P(0);
+          double r = 0;
+          for (int q = 0; q < np_; q++) { D2 u = P(q), v = P(q + 1); r += u.x * v.y - u.y * v.x; }
+          r = fabs(r / 2.0);
+          if (s1 * s2 == -1) r = -r;
+          isum += r;
+        }
+      double uni = fabs(quad_area(a)) + fabs(quad_area(b)) - isum;
+      ovr = isum / uni;
+    }
+    if (!(ovr <= thresh)) bits |= 1ull << c;   // :115 keeps j only when hbb_ovr <= thresh
+  }
+  mask[(unsigned long long)i * nb + cb] = bits;
+}
 #undef P
 #undef T
+
+__global__ void k_poly_flags(const uint8_t* __restrict__ keep_orig, const int32_t* __restrict__ order, int64_t n,
+                             uint8_t* __restrict__ flags) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) flags[p] = keep_orig[order[p]];
+}
 
 }  // namespace
 }  // namespace s2a
@@ -160,5 +316,75 @@ extern "C" int s2a_polyiou_pairs(const double* polys1, const double* polys2, int
   S2A_CHECK_ARG(polys1 && polys2 && ious, "polyiou_pairs: NULL tensor");
   k_polyiou_pairs<<<(unsigned)((n + kPolyThreads - 1) / kPolyThreads), kPolyThreads, 0, as_stream(stream)>>>(polys1, polys2, n, ious);
   S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+
+extern "C" size_t s2a_nms_poly_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  size_t sz = (size_t)n, nb = (sz + 63) / 64;
+  return align_up(sz * 8) * 2 + align_up(sz * 4) * 2 + align_up(sz * sizeof(PolyBox)) + align_up(sz * nb * 8) +
+         align_up(sz) * 2 + align_up(sz * 40 + (8u << 20)) + 8192;
+}
+
+extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64_t* keep, int64_t* count_dev,
+                            int64_t* host_count, void* workspace, size_t workspace_bytes, s2a_stream_t stream) {
+  S2A_CHECK_ARG(n >= 0 && n < (1ll << 31), "nms_poly: n out of range");
+  S2A_CHECK_ARG(count_dev != nullptr, "nms_poly: count_dev must not be NULL");
+  hipStream_t st = as_stream(stream);
+  if (n == 0) {
+    S2A_HIP(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
+    if (host_count) *host_count = 0;
+    return S2A_OK;
+  }
+  S2A_CHECK_ARG(dets9 && keep, "nms_poly: NULL tensor");
+  const size_t sz = (size_t)n, nb = (sz + 63) / 64;
+  S2A_CHECK_ARG(nb <= 65535, "nms_poly: more than 4.19 M boxes is not supported");
+  Carver cv(workspace, workspace_bytes);
+  auto* key_a = cv.take<unsigned long long>(sz);
+  auto* key_b = cv.take<unsigned long long>(sz);
+  auto* idx_a = cv.take<int32_t>(sz);
+  auto* order = cv.take<int32_t>(sz);
+  auto* sorted = cv.take<PolyBox>(sz);
+  auto* mask = cv.take<unsigned long long>(sz * nb);
+  auto* keep_orig = cv.take<uint8_t>(sz);
+  auto* flags = cv.take<uint8_t>(sz);
+  auto* small = cv.take<unsigned long long>(64);   // seg_start[2] | num_seg | nblk | mask_off[2] | status
+  size_t rpb = sz * 40 + (8u << 20);
+  void* rp = cv.take<char>(rpb);
+  if (!rp || !small || cv.off > workspace_bytes) {
+    set_error("nms_poly: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+    return S2A_EWORKSPACE;
+  }
+  uint32_t* seg_start = reinterpret_cast<uint32_t*>(small);
+  uint32_t* num_seg = seg_start + 4;
+  uint32_t* nblk = seg_start + 6;
+  uint32_t* status = seg_start + 8;
+  unsigned long long* mask_off = small + 8;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  S2A_HIP(hipMemsetAsync(small, 0, 64 * 8, st));
+  S2A_HIP(hipMemsetAsync(keep_orig, 0, sz, st));
+  k_poly_keys<<<g, 256, 0, st>>>(dets9, n, key_a, idx_a);
+  size_t need = 0;
+  S2A_HIP(rocprim::radix_sort_pairs(nullptr, need, key_a, key_b, idx_a, order, sz, 0, 64, st));
+  S2A_CHECK_ARG(need <= rpb, "nms_poly: sort scratch too small");
+  S2A_HIP(rocprim::radix_sort_pairs(rp, need, key_a, key_b, idx_a, order, sz, 0, 64, st));
+  k_poly_prep<<<g, 256, 0, st>>>(dets9, order, n, sorted, seg_start, num_seg, mask_off, nblk);
+  dim3 grid((unsigned)nb, (unsigned)nb);
+  k_poly_mask<<<grid, 64, 0, st>>>(sorted, n, thresh, mask);
+  S2A_LAUNCH_CHECK();
+  int rc = launch_nms_scan(mask, seg_start, num_seg, mask_off, nblk, order, keep_orig, (uint32_t)nb, mask_off + 1,
+                           (unsigned long long)sz * nb, status, st);
+  if (rc != S2A_OK) return rc;
+  k_poly_flags<<<g, 256, 0, st>>>(keep_orig, order, n, flags);
+  need = 0;
+  S2A_HIP(rocprim::select(nullptr, need, order, flags, keep, count_dev, sz, st));
+  S2A_CHECK_ARG(need <= rpb, "nms_poly: select scratch too small");
+  S2A_HIP(rocprim::select(rp, need, order, flags, keep, count_dev, sz, st));
+  S2A_LAUNCH_CHECK();
+  if (host_count) {
+    S2A_HIP(hipMemcpyAsync(host_count, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    S2A_HIP(hipStreamSynchronize(st));
+  }
   return S2A_OK;
 }

@@ -812,6 +812,22 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
 }  // namespace
 }  // namespace s2a
 
+namespace s2a {
+// the greedy scan is metric-agnostic: poly_ops.hip (chip-merge NMS on polygon IoU) reuses it
+int launch_nms_scan(const unsigned long long* mask, const uint32_t* seg_start, const uint32_t* num_seg,
+                    const unsigned long long* mask_off, const uint32_t* nblk, const int32_t* perm_seg,
+                    uint8_t* keep_orig, uint32_t max_blocks, const unsigned long long* words_total,
+                    unsigned long long words_bound, uint32_t* status, hipStream_t st) {
+  S2A_CHECK_ARG(((size_t)max_blocks + 10 + kScanCacheWords) * 8 <= 112 * 1024, "nms scan: segment too large");
+  size_t lds = ((size_t)max_blocks + 10 + kScanCacheWords) * sizeof(unsigned long long);
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_nms_scan<<<512, kThreads, lds, st>>>(mask, seg_start, num_seg, mask_off, nblk, perm_seg, keep_orig, max_blocks,
+                                         words_total, words_bound, status);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+}  // namespace s2a
+
 using namespace s2a;
 
 extern "C" size_t s2a_box_iou_rotated_workspace_bytes(int64_t n, int64_t m) {

@@ -69,6 +69,25 @@ def polyiou_pairs(polys1, polys2):
     return out
 
 
+def nms_poly(dets, thresh=0.5):
+    """py_cpu_nms_poly_fast (DOTA_devkit/ResultMerge_multi_process.py:62-123) on the GPU:
+    dets[n,9] = x1,y1,...,x4,y4,score -> kept indices (int64), descending score"""
+    _lib.require_cuda(dets)
+    d = dets.to(torch.float64).contiguous().reshape(-1, 9)
+    n = d.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=d.device)
+    L = _lib.lib()
+    keep = torch.empty((n,), dtype=torch.int64, device=d.device)
+    cnt = torch.empty((1,), dtype=torch.int64, device=d.device)
+    host_k = ctypes.c_int64(0)
+    with torch.cuda.device(d.device):
+        ws = _lib.workspace(L.s2a_nms_poly_workspace_bytes(n), d.device, "nms_poly")
+        _lib.check(L.s2a_nms_poly(_lib.ptr(d), n, float(thresh), _lib.ptr(keep), _lib.ptr(cnt), ctypes.byref(host_k),
+                                  _lib.ptr(ws), ws.numel(), _lib.stream_ptr(d.device)))
+    return keep[:host_k.value]
+
+
 def _nms_raw(dets, scores, labels, iou_threshold):
     _lib.require_cuda(dets, scores, labels)
     d = _f32c(dets)

@@ -152,6 +152,32 @@ def gen_arf_backward():
     np.savez_compressed(os.path.join(OUT, "arf_backward_small.npz"), **out)
 
 
+def gen_merge_nms():
+    """chip-merge polygon NMS from the reference's own script (DOTA_devkit/ResultMerge_multi_process.py),
+    imported in place with the SWIG polyiou module built into oracle/_ref and a stub for shapely"""
+    rng = np.random.default_rng(999)
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref", "polyiou"))
+    sh = types.ModuleType("shapely")
+    sh.geometry = types.ModuleType("shapely.geometry")
+    sys.modules.setdefault("shapely", sh)
+    sys.modules.setdefault("shapely.geometry", sh.geometry)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from DOTA_devkit.ResultMerge_multi_process import py_cpu_nms_poly_fast
+    n = 900
+    polys = oracle.rboxes_to_polys(rand_boxes(rng, n, span=420))
+    scores = (rng.permutation(n) + 1.0) / (n + 1.0)
+    dets = np.concatenate([polys, scores[:, None]], 1).astype(np.float64)
+    out = {"dets": dets}
+    for thr in (0.1, 0.5):
+        out[f"keep_{thr}"] = np.asarray(py_cpu_nms_poly_fast(dets, thr), np.int64)
+        print("merge nms thr", thr, "keep", len(out[f"keep_{thr}"]))
+    np.savez_compressed(os.path.join(OUT, "merge_nms_poly.npz"), **out)
+
+
 def import_reference_python():
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
@@ -270,4 +296,5 @@ if __name__ == "__main__":
     gen_dcn(rng)
     gen_glue(rng)
     gen_arf_backward()
+    gen_merge_nms()
     print("done ->", OUT)

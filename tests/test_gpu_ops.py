@@ -453,3 +453,16 @@ def test_polyiou_pairs_bitexact(rng):
     ref = oracle.polyiou(a, b)
     assert np.array_equal(out, ref, equal_nan=True)
     assert abs(polyiou_pairs(cu(np.array([[0, 0, 1, 0, 1, 1, 0, 1.0]])), cu(np.array([[.5, .5, 1.5, .5, 1.5, 1.5, .5, 1.5]]))).item() - 1 / 7) < 1e-12
+
+
+def test_merge_nms_poly(rng):
+    from s2anet_amd.rotated import nms_poly
+    g = golden("merge_nms_poly.npz")
+    for thr in (0.1, 0.5):
+        k = nms_poly(cu(g["dets"]), thr).cpu().numpy()
+        assert np.array_equal(k, g[f"keep_{thr}"])                      # the reference script's own keep list
+    n = 5000
+    polys = oracle.rboxes_to_polys(rand_rboxes(rng, n, span=700))
+    dets = np.concatenate([polys, ((rng.permutation(n) + 1.0) / (n + 1.0))[:, None]], 1)
+    assert np.array_equal(nms_poly(cu(dets), 0.3).cpu().numpy(), oracle.nms_poly(dets, 0.3))
+    assert nms_poly(torch.zeros((0, 9), device=dev()), 0.5).shape == (0,)

@@ -116,6 +116,12 @@ def test_arf_backward_matches_reference():
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
 
 
+def test_merge_nms_poly_matches_reference_script():
+    g = golden("merge_nms_poly.npz")
+    for thr in (0.1, 0.5):
+        assert np.array_equal(oracle.nms_poly(g["dets"], thr), g[f"keep_{thr}"])
+
+
 def test_head_glue_matches_reference_python():
     g = golden("head_glue.npz")
     assert np.array_equal(oracle.grid_anchors(12, 20, 8), g["anchors_s8"])
