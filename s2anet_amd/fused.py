@@ -36,23 +36,28 @@ def own_conv_ok(x, in_channels, out_channels, kernel_size, stride, padding, dila
     import os
     if not (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and
             x.is_contiguous(memory_format=torch.channels_last) and tuple(dilation) == (1, 1) and groups == 1 and
-            in_channels % 64 == 0 and out_channels % 64 == 0 and x.numel() * 2 < (1 << 31)):
+            in_channels % 64 == 0 and (out_channels % 64 == 0 or out_channels < 64) and
+            x.numel() * 2 < (1 << 31)):
         return False
     if os.environ.get("S2A_NO_OWN_CONV"):
         return False
     k, st, pd = tuple(kernel_size), tuple(stride), tuple(padding)
     B, _, H, W = x.shape
+    narrow = out_channels < 64     # prediction heads (5 / 15 maps): the library's kernels for these cost 13-56 us flat
     if k == (3, 3) and st == (1, 1) and pd == (1, 1):
-        return B * ((H + 7) // 8) * ((W + 15) // 16) >= 64
+        return narrow or B * ((H + 7) // 8) * ((W + 15) // 16) >= 64
     if k == (1, 1) and pd == (0, 0) and st in ((1, 1), (2, 2)) and not os.environ.get("S2A_NO_OWN_CONV1"):
         Ho, Wo = (H - 1) // st[0] + 1, (W - 1) // st[1] + 1
-        return B * Ho * Wo >= 64 * 128
+        return narrow or B * Ho * Wo >= 64 * 128
     return False
 
 
 def conv_pack_weight(weight):
-    """[O,C,k,k] -> MFMA-fragment order (s2a_conv_pack_weight_f16)"""
+    """[O,C,k,k] -> MFMA-fragment order (s2a_conv_pack_weight_f16); fewer than 64 filters are
+    zero-padded to 64 (the kernel's narrowest output group)"""
     w = weight.detach().to(torch.float16).contiguous()
+    if w.shape[0] < 64:
+        w = torch.cat([w, w.new_zeros((64 - w.shape[0],) + tuple(w.shape[1:]))], 0).contiguous()
     out = torch.empty_like(w)
     with torch.cuda.device(w.device):
         _lib.check(_lib.lib().s2a_conv_pack_weight_f16(_lib.ptr(w), w.shape[0], w.shape[1], w.shape[2],
@@ -65,9 +70,15 @@ def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, 
     conv_pack_weight; ksize 3 (stride 1, pad 1) or 1 (pad 0, stride 1|2)"""
     B, C, H, W = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    O_real = out_channels
+    if out_channels < 64:           # narrow head: 64 physical channels, the caller gets the [:, :O] view
+        assert residual is None
+        out_channels = 64
     out = torch.empty((B, out_channels, Ho, Wo), dtype=torch.float16, device=x.device,
                       memory_format=torch.channels_last)
     b = None if bias is None else bias.to(torch.float16).contiguous()
+    if b is not None and b.numel() < out_channels:
+        b = torch.cat([b, b.new_zeros(out_channels - b.numel())])
     if residual is not None:
         assert residual.shape == out.shape and residual.dtype == torch.float16 and \
             residual.is_contiguous(memory_format=torch.channels_last)
@@ -75,7 +86,7 @@ def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, 
         _lib.check(_lib.lib().s2a_conv_nhwc_f16(_lib.ptr(x), _lib.ptr(packed_weight), _lib.ptr(b), _lib.ptr(residual),
                                                 _lib.ptr(out), B, C, H, W, out_channels, int(ksize), int(stride),
                                                 int(bool(relu)), _lib.stream_ptr(x.device)))
-    return out
+    return out if O_real == out_channels else out[:, :O_real]
 
 
 class PackedWeightCache:
@@ -83,12 +94,25 @@ class PackedWeightCache:
 
     def __init__(self):
         self.key, self.val = None, None
+        self.bkey, self.bval = None, None
 
     def get(self, w):
         key = (w._version, w.data_ptr(), w.device)
         if self.key != key:
             self.key, self.val = key, conv_pack_weight(w)
         return self.val
+
+    def get_bias(self, b, width):
+        """f16 bias zero-padded to the physical channel count"""
+        if b is None:
+            return None
+        key = (b._version, b.data_ptr(), b.device, width)
+        if self.bkey != key:
+            v = b.detach().to(torch.float16)
+            if v.numel() < width:
+                v = torch.cat([v, v.new_zeros(width - v.numel())])
+            self.bkey, self.bval = key, v.contiguous()
+        return self.bval
 
 
 class FusedConv2d(nn.Conv2d):
@@ -114,8 +138,8 @@ class FusedConv2d(nn.Conv2d):
                     residual.dtype == torch.float16 and residual.is_contiguous(memory_format=torch.channels_last))):
             if not hasattr(self, "_packed"):
                 self._packed = PackedWeightCache()
-            return conv_f16(x, self._packed.get(self.weight), self.bias, self.out_channels, self.kernel_size[0],
-                            self.stride[0], self.fuse_relu, residual)
+            return conv_f16(x, self._packed.get(self.weight), self._packed.get_bias(self.bias, max(64, self.out_channels)),
+                            self.out_channels, self.kernel_size[0], self.stride[0], self.fuse_relu, residual)
         if (not x.is_cuda) or self.bias is None:
             y = super().forward(x)
             if residual is not None:

@@ -1,0 +1,17 @@
+#!/bin/bash
+# kernel-trace + stats of the default bench command; steady-state per-kernel table via trace_steps.py
+# usage (on the GPU box): bash scripts/prof_bench.sh <tag> [bench args]
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=$1; shift
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1 || { echo "rocprof run failed"; tail -5 $OUT/bench.log; exit 1; }
+T=$(ls $OUT/*kernel_trace.csv $OUT/*/*kernel_trace.csv 2>/dev/null | head -1)
+S=$(ls $OUT/*kernel_stats.csv $OUT/*/*kernel_stats.csv 2>/dev/null | head -1)
+python $R/scripts/trace_steps.py $T 5 60 > $OUT/steady.txt
+cp $S $OUT/kernel_stats.csv
+grep '^{' $OUT/bench.log > $OUT/line.json
+rm -f $T   # the raw trace is large; the summaries are what gets kept
+head -45 $OUT/steady.txt

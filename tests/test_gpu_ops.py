@@ -419,6 +419,25 @@ def test_own_conv1x1_f16_vs_torch(shape):
     assert (out3.float() - (torch.nn.functional.conv2d(x.float(), w.float(), None, stride=st) + res.float())).abs().max().item() < 3e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 16, 16, 15, 3), (8, 256, 8, 8, 5, 3), (2, 256, 40, 24, 5, 1), (1, 256, 128, 128, 15, 1)])
+def test_narrow_prediction_heads(shape):
+    """5 / 15-map prediction heads (head.py:205-222) on the own conv kernel with zero-padded filters;
+    the result is the [:, :O] view of a 64-channel buffer"""
+    from s2anet_amd.fused import FusedConv2d
+    B, C, H, W, O, k = shape
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(C, O, k, padding=k // 2).to(dev()).half()
+    conv.weight.data.normal_(0, 0.02)
+    conv.bias.data.normal_(0, 1.0)
+    x = torch.randn(B, C, H, W, device=dev()).half().contiguous(memory_format=torch.channels_last)
+    fc = FusedConv2d.from_conv(conv)
+    with torch.no_grad():
+        y = fc(x)
+        ref = torch.nn.functional.conv2d(x.float(), conv.weight.float(), conv.bias.float(), padding=k // 2)
+    assert y.shape == ref.shape and hasattr(fc, "_packed")           # own kernel ran (no library fallback)
+    assert (y.float() - ref).abs().max().item() < 2e-2
+
+
 def test_arf_backward_and_autograd(rng):
     import s2anet_amd as S
     g = golden("arf_backward_small.npz")
