@@ -238,12 +238,41 @@ int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual, int64_t p
  * on the same patch-staged MFMA structure as AlignConv.  ksize 3: stride 1, pad 1.  ksize 1: pad 0,
  * stride 1 or 2.  x[B,H,W,C] -> out[B,Ho,Wo,O] = relu?(conv(x) + bias (+ residual[B,Ho,Wo,O])).
  * weight_frag = s2a_conv_pack_weight_f16 of the [O,C,k,k] filter (O*C*k*k halfs, MFMA-fragment order);
- * bias[O] f16 or NULL; residual or NULL.  C and O must be multiples of 64. */
+ * bias[O] f16 or NULL; residual or NULL.  O must be a multiple of 64 (narrower heads: zero-pad the
+ * filter), C a multiple of 64 or exactly 32 (then the filter given to s2a_conv_pack_weight_f16 is
+ * zero-padded to 64 input channels). */
 int s2a_conv_pack_weight_f16(const void* weight, int64_t out_channels, int64_t channels, int ksize,
                              void* packed, s2a_stream_t stream);
 int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
                       void* out, int64_t batch, int64_t channels, int64_t height, int64_t width,
                       int64_t out_channels, int ksize, int stride, int relu, s2a_stream_t stream);
+
+/* Pyramid-packed head launches.  The conv towers, AlignConv and prediction heads of S2ANetHead share
+ * their filters over the FPN levels (models/head.py:261-265 maps forward_single over the levels), so
+ * one launch can serve all of them: the levels sit back to back in ONE channels-last buffer
+ * [sum_l B*H_l*W_l, C], level l = [B,H_l,W_l,C] at pixel offset sum_{k<l} B*H_k*W_k (anchors
+ * [.,5] f32 and outputs packed the same way).  A workgroup finds its level from its tile index.
+ *   s2a_pyramid_pixels            -> total pixel rows of the packed buffer (or -1: bad table)
+ *   s2a_conv3x3_pyramid_f16       = s2a_conv_nhwc_f16(ksize 3) on every level
+ *   s2a_align_conv_pyramid_f16    = s2a_align_conv_forward (f16, NHWC, weight from s2a_dcn_pack_weight)
+ *                                   on every level, stride[l] = the level's anchor stride
+ *   s2a_fam_refine_anchors_pyramid = s2a_fam_refine_anchors on every level; pred rows have
+ *                                   row_stride f16 columns of which the first 5 are the deltas */
+typedef struct s2a_pyramid {
+  int32_t n_levels;     /* 1..8 */
+  int32_t height[8];
+  int32_t width[8];
+  float stride[8];      /* FPN stride of the level (AlignConv / anchor generation) */
+} s2a_pyramid;
+int64_t s2a_pyramid_pixels(const s2a_pyramid* pyr, int64_t batch);
+int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
+                            void* out, int64_t batch, int64_t channels, int64_t out_channels, int relu,
+                            const s2a_pyramid* pyr, s2a_stream_t stream);
+int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, const void* weight_packed, void* out,
+                               int64_t batch, int64_t channels, int64_t out_channels, int relu,
+                               const s2a_pyramid* pyr, s2a_stream_t stream);
+int s2a_fam_refine_anchors_pyramid(const void* pred, int64_t row_stride, int64_t batch, const s2a_pyramid* pyr,
+                                   float anchor_scale, float* refined, s2a_stream_t stream);
 
 /* Diagnostic builds only (-DS2A_STAMP=1): per-workgroup s_memtime phase stamps of the AlignConv
  * kernel; returns S2A_ENOTIMPL in a normal build. */

@@ -35,6 +35,12 @@ class AlignParams(ctypes.Structure):
                 ("relu", c_int), ("weight_packed", c_int)]
 
 
+class Pyramid(ctypes.Structure):
+    """s2a_pyramid: FPN level table of a pyramid-packed buffer"""
+    _fields_ = [("n_levels", ctypes.c_int32), ("height", ctypes.c_int32 * 8), ("width", ctypes.c_int32 * 8),
+                ("stride", c_f32 * 8)]
+
+
 # every symbol include/s2anet_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "s2a_last_error": (ctypes.c_char_p, []),
@@ -74,6 +80,12 @@ SYMBOLS = {
     "s2a_conv_nhwc_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int,
                                   c_int, c_vp]),
     "s2a_debug_read_stamps": (c_int, [c_vp, c_i64]),
+    "s2a_pyramid_pixels": (c_i64, [ctypes.POINTER(Pyramid), c_i64]),
+    "s2a_conv3x3_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
+                                        ctypes.POINTER(Pyramid), c_vp]),
+    "s2a_align_conv_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
+                                           ctypes.POINTER(Pyramid), c_vp]),
+    "s2a_fam_refine_anchors_pyramid": (c_int, [c_vp, c_i64, c_i64, ctypes.POINTER(Pyramid), c_f32, c_vp, c_vp]),
     "s2a_delta2bbox_rotated": (c_int, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
     "s2a_fam_refine_anchors": (c_int, [c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_int, c_int,
                                        c_vp, c_vp]),

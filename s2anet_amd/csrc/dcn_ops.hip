@@ -262,6 +262,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
 }
 
+// Pyramid-packed launches: the FPN levels of one head layer share their filters, so all of them go
+// through ONE launch.  The levels sit back to back in one NHWC buffer (level l = [B,H_l,W_l,C] at
+// pixel offset pix0[l]); a workgroup finds its level from the tile index and rebinds its pointers
+// and geometry -- from there on it is an ordinary single-level tile.  n <= 1: plain tensor.
+constexpr int kMaxLevels = 8;
+struct LevelTab {
+  int n, batch;
+  int H[kMaxLevels], W[kMaxLevels], tile0[kMaxLevels], pix0[kMaxLevels];
+  float stride[kMaxLevels];
+};
+
 // SRC: 0 = offset tensor [B,18,H,W] f32, 1 = refined anchors [B,H,W,5] f32
 // NPOS: output positions per workgroup (64: more workgroups for small inputs; 128: the weight tile
 // is amortised over twice the positions)
@@ -719,12 +730,12 @@ __global__ void k_pack_weight_frag(const _Float16* __restrict__ w, int O, int C,
 constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs + 16 B pad
 
 template <bool OUT_NHWC, int SRC>
-__global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict__ x,
-                                                      const float* __restrict__ src,
+__global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict__ x_,
+                                                      const float* __restrict__ src_,
                                                       const _Float16* __restrict__ wfrag,
-                                                      _Float16* __restrict__ out, int64_t Ntot, int C,
-                                                      int H, int W, int O, float stride, int relu,
-                                                      unsigned x_bytes) {
+                                                      _Float16* __restrict__ out_, int64_t Ntot_, int C,
+                                                      int H_, int W_, int O, float stride_, int relu,
+                                                      unsigned x_bytes_, LevelTab lt) {
   using T = _Float16;
   using V = f16x8;
   constexpr int NPOS = 128, NT = 4, ITEMS = 4;
@@ -734,8 +745,29 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   char* s_patch = s_B + 2 * 128 * kRowBytes;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const T* x = x_;
+  const float* src = src_;
+  T* out = out_;
+  int64_t Ntot = Ntot_;
+  int H = H_, W = W_;
+  float stride = stride_;
+  unsigned x_bytes = x_bytes_;
+  if (SRC == 1 && lt.n > 1) {         // pyramid-packed levels (anchors [sum B*H*W, 5] packed alike)
+    int t0 = 0, p0 = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; i++)
+      if (i < lt.n && tile >= lt.tile0[i]) {
+        t0 = lt.tile0[i]; p0 = lt.pix0[i]; H = lt.H[i]; W = lt.W[i]; stride = lt.stride[i];
+      }
+    tile -= t0;
+    Ntot = (int64_t)lt.batch * H * W;
+    x += (int64_t)p0 * C;
+    out += (int64_t)p0 * O;
+    src += (int64_t)p0 * 5;
+    x_bytes = (unsigned)(Ntot * C * 2);
+  }
   const int64_t HW = (int64_t)H * W;
-  const int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const int txn = (W + 15) / 16, tyn = (H + 7) / 8;
   const int64_t bimg = tile / (txn * tyn);
   const int trem = (int)(tile % (txn * tyn));
@@ -1058,13 +1090,13 @@ struct ConvCfg {
 };
 
 template <int TAPS, int OG>
-__global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict__ x,
+__global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict__ x_,
                                                      const _Float16* __restrict__ wfrag,
                                                      const _Float16* __restrict__ bias,
-                                                     const _Float16* __restrict__ residual,
-                                                     _Float16* __restrict__ out, int64_t Ntot, int C,
-                                                     int H, int W, int Ho, int Wo, int cstride, int O,
-                                                     int relu, unsigned x_bytes) {
+                                                     const _Float16* __restrict__ residual_,
+                                                     _Float16* __restrict__ out_, int64_t Ntot_, int C,
+                                                     int H_, int W_, int Ho_, int Wo_, int cstride, int O,
+                                                     int relu, unsigned x_bytes_, LevelTab lt) {
   using T = _Float16;
   using V = f16x8;
   using Cfg = ConvCfg<TAPS, OG>;
@@ -1072,8 +1104,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
   constexpr int WPG = 4 / OG;         // waves per out-channel group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const T* x = x_;
+  const T* residual = residual_;
+  T* out = out_;
+  int64_t Ntot = Ntot_;
+  int H = H_, W = W_, Ho = Ho_, Wo = Wo_;
+  unsigned x_bytes = x_bytes_;
+  if (TAPS == 9 && lt.n > 1) {        // pyramid-packed levels: rebind this workgroup to its level
+    int t0 = 0, p0 = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; i++)
+      if (i < lt.n && tile >= lt.tile0[i]) {
+        t0 = lt.tile0[i]; p0 = lt.pix0[i]; H = lt.H[i]; W = lt.W[i];
+      }
+    tile -= t0;
+    Ho = H; Wo = W;
+    Ntot = (int64_t)lt.batch * H * W;
+    x += (int64_t)p0 * C;
+    out += (int64_t)p0 * O;
+    if (residual) residual += (int64_t)p0 * O;
+    x_bytes = (unsigned)(Ntot * C * 2);
+  }
   const int64_t HWo = (int64_t)Ho * Wo, HWi = (int64_t)H * W;
-  const int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
   // TAPS 9: 2-D tile of one image; TAPS 1: 128 consecutive output positions of the whole batch
   const int txn = (Wo + 15) / 16, tyn = (Ho + 7) / 8;
   const int64_t bimg = TAPS == 9 ? tile / (txn * tyn) : 0;
@@ -1082,7 +1135,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
   const int64_t g0 = tile * 128;
   const int o0 = blockIdx.y * (64 * OG);
   const int Oloc = min(64 * OG, O - o0);
-  const int CC = C / 64, G = O / 64;
+  const int CC = (C + 63) / 64, G = O / 64;
+  const int qlim = C >= 64 ? 8 : C / 8;   // C = 32: half-filled chunk, the filter is zero-padded to 64 inputs
   const unsigned row_bytes = (unsigned)C * 2;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
 
@@ -1095,7 +1149,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
 #pragma unroll
   for (int j = 0; j < Cfg::kJ; j++) {
     int v = (wave_u + 4 * j) * 64 + lane, p = v / 9, q = v % 9;
-    bool in = q < 8 && p < Cfg::kPix;
+    bool in = q < qlim && p < Cfg::kPix;
     int64_t pix = 0;
     if (TAPS == 9) {
       int yy = ty0 - 1 + p / kCPW, xx = tx0 - 1 + p % kCPW;
@@ -1376,7 +1430,7 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
       S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));        \
       kern<<<grid, 512, kPatchLds, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, relu, \
-                                         (unsigned)x_bytes);                                      \
+                                         (unsigned)x_bytes, LevelTab{});                          \
     }                                                                                             \
   } while (0)
 #define S2A_DCN_PICK(NHWC, SRC) do { if (patch_ok) S2A_DCN_LAUNCH_PATCH(NHWC, SRC); else if (ws_use) S2A_DCN_LAUNCH_WS(NHWC, SRC); else if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
@@ -1559,15 +1613,17 @@ namespace {
 template <int TAPS, int OG>
 int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
                 _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
-                hipStream_t st) {
+                hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0) {
   using Cfg = ConvCfg<TAPS, OG>;
   const int64_t Ntot = B * (int64_t)Ho * Wo;
-  const int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + 7) / 8) : (Ntot + 127) / 128;
+  int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + 7) / 8) : (Ntot + 127) / 128;
+  LevelTab lt = {};
+  if (levels) { lt = *levels; tiles = level_tiles; }
   dim3 grid((unsigned)tiles, (unsigned)((O + 64 * OG - 1) / (64 * OG)));
   auto kern = k_conv_f16<TAPS, OG>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
   kern<<<grid, 256, Cfg::kLds, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
-                                     (unsigned)((uint64_t)B * H * W * C * 2));
+                                     (unsigned)((uint64_t)B * H * W * C * 2), lt);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -1580,9 +1636,11 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
   S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0 && height > 0 && width > 0, "conv: bad shape");
   S2A_CHECK_ARG(ksize == 3 || ksize == 1, "conv: kernel size must be 1 or 3");
   S2A_CHECK_ARG(stride == 1 || (ksize == 1 && stride == 2), "conv: stride must be 1 (or 2 for 1x1)");
-  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 64 == 0, "conv: channels and out_channels must be multiples of 64");
+  S2A_CHECK_ARG((channels % 64 == 0 || channels == 32) && out_channels % 64 == 0,
+                "conv: channels must be 32 or a multiple of 64, out_channels a multiple of 64");
   const uint64_t x_bytes = (uint64_t)batch * height * width * channels * 2;
-  S2A_CHECK_ARG(x_bytes < (1ull << 31) && height < 32000 && width < 32000, "conv: input too large for 32-bit offsets");
+  S2A_CHECK_ARG(x_bytes < (1ull << 31) && (ksize == 1 || (height < 32000 && width < 32000)),
+                "conv: input too large for 32-bit offsets");
   if (batch == 0) return S2A_OK;
   S2A_CHECK_ARG(x && weight_frag && out, "conv: NULL tensor");
   S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_frag % 16) == 0 &&
@@ -1608,6 +1666,91 @@ extern "C" int s2a_conv_pack_weight_f16(const void* weight, int64_t out_channels
   const int64_t wtot = out_channels * channels * taps;
   k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, as_stream(stream)>>>(
       (const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed, taps);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+// ------------------------------------------------------------------ pyramid-packed launches
+namespace s2a {
+namespace {
+// tiles (8 x 16 positions) per level, pixel offsets; returns the total tile count or -1
+int64_t build_levels(const s2a_pyramid* pyr, int64_t batch, LevelTab* lt, int64_t* total_pix) {
+  if (!pyr || pyr->n_levels < 1 || pyr->n_levels > kMaxLevels) return -1;
+  *lt = LevelTab{};
+  lt->n = pyr->n_levels;
+  lt->batch = (int)batch;
+  int64_t tiles = 0, pix = 0;
+  for (int i = 0; i < pyr->n_levels; i++) {
+    const int64_t H = pyr->height[i], W = pyr->width[i];
+    if (H < 1 || W < 1 || H >= 32000 || W >= 32000) return -1;
+    lt->H[i] = (int)H; lt->W[i] = (int)W; lt->stride[i] = pyr->stride[i];
+    lt->tile0[i] = (int)tiles; lt->pix0[i] = (int)pix;
+    tiles += batch * ((W + 15) / 16) * ((H + 7) / 8);
+    pix += batch * H * W;
+    if (tiles >= (1ll << 31) || pix >= (1ll << 31)) return -1;
+  }
+  *total_pix = pix;
+  return tiles;
+}
+}  // namespace
+}  // namespace s2a
+
+extern "C" int64_t s2a_pyramid_pixels(const s2a_pyramid* pyr, int64_t batch) {
+  LevelTab lt; int64_t pix = 0;
+  return build_levels(pyr, batch, &lt, &pix) < 0 ? -1 : pix;
+}
+
+extern "C" int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
+                                       void* out, int64_t batch, int64_t channels, int64_t out_channels,
+                                       int relu, const s2a_pyramid* pyr, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0, "conv_pyramid: bad shape");
+  S2A_CHECK_ARG((channels % 64 == 0 || channels == 32) && out_channels % 64 == 0,
+                "conv_pyramid: channels must be 32 or a multiple of 64, out_channels a multiple of 64");
+  LevelTab lt; int64_t pix = 0;
+  const int64_t tiles = build_levels(pyr, batch, &lt, &pix);
+  S2A_CHECK_ARG(tiles >= 0, "conv_pyramid: bad level table (1..8 levels, positive sizes)");
+  S2A_CHECK_ARG((uint64_t)pix * channels * 2 < (1ull << 31), "conv_pyramid: input too large for 32-bit offsets");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(x && weight_frag && out, "conv_pyramid: NULL tensor");
+  S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_frag % 16) == 0 &&
+                ((uintptr_t)bias % 8) == 0 && ((uintptr_t)residual % 16) == 0, "conv_pyramid: tensors must be 16-byte aligned");
+  if (lt.n == 1) lt.n = 2, lt.tile0[1] = 0x7fffffff;   // keep the rebind path (n > 1) for a one-level table
+  hipStream_t st = as_stream(stream);
+  const int og = out_channels % 256 == 0 ? 4 : (out_channels % 128 == 0 ? 2 : 1);
+  const _Float16 *X = (const _Float16*)x, *Wf = (const _Float16*)weight_frag, *Bi = (const _Float16*)bias,
+                 *R = (const _Float16*)residual;
+  _Float16* Y = (_Float16*)out;
+#define S2A_CONVP(OG_) launch_conv<9, OG_>(X, Wf, Bi, R, Y, batch, (int)channels, lt.H[0], lt.W[0], lt.H[0], lt.W[0], 1, (int)out_channels, relu, st, &lt, tiles)
+  return og == 4 ? S2A_CONVP(4) : (og == 2 ? S2A_CONVP(2) : S2A_CONVP(1));
+#undef S2A_CONVP
+}
+
+extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, const void* weight_packed, void* out,
+                                          int64_t batch, int64_t channels, int64_t out_channels, int relu,
+                                          const s2a_pyramid* pyr, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0, "align_conv_pyramid: bad shape");
+  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 64 == 0, "align_conv_pyramid: channels and out_channels must be multiples of 64");
+  LevelTab lt; int64_t pix = 0;
+  const int64_t tiles = build_levels(pyr, batch, &lt, &pix);
+  S2A_CHECK_ARG(tiles >= 0, "align_conv_pyramid: bad level table (1..8 levels, positive sizes)");
+  for (int i = 0; i < lt.n; i++) {
+    S2A_CHECK_ARG(lt.stride[i] > 0, "align_conv: stride must be positive");
+    S2A_CHECK_ARG(lt.H[i] >= 3 && lt.W[i] >= 3, "input image is smaller than kernel");
+  }
+  S2A_CHECK_ARG((uint64_t)pix * channels * 2 < (1ull << 31), "align_conv_pyramid: input too large for 32-bit offsets");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(x && anchors && weight_packed && out, "align_conv_pyramid: NULL tensor");
+  S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_packed % 16) == 0,
+                "align_conv_pyramid: tensors must be 16-byte aligned");
+  if (lt.n == 1) lt.n = 2, lt.tile0[1] = 0x7fffffff;
+  hipStream_t st = as_stream(stream);
+  // s2a_dcn_pack_weight (f16) = stage-major layout followed by the MFMA-fragment layout
+  const _Float16* wfrag = (const _Float16*)weight_packed + (size_t)out_channels * channels * 9;
+  auto kern = k_dcn_patch<true, 1>;
+  dim3 grid((unsigned)tiles, (unsigned)((out_channels + kMaxO - 1) / kMaxO));
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
+  kern<<<grid, 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels, lt.H[0], lt.W[0],
+                                     (int)out_channels, lt.stride[0], relu, 0u, lt);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

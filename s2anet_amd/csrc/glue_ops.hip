@@ -72,6 +72,38 @@ __global__ void k_fam_refine(const T* __restrict__ pred, int64_t B, int64_t H, i
   for (int k = 0; k < 5; k++) refined[e * 5 + k] = o[k];
 }
 
+// pyramid-packed variant: pred rows [sum_l B*H_l*W_l][row_stride] f16 (first 5 columns = deltas), all
+// FPN levels in one launch; a thread finds its level from the packed pixel index
+struct RefineLevels {
+  int n, batch;
+  int H[8], W[8], pix0[8];
+  float stride[8];
+};
+__global__ void k_fam_refine_pyramid(const _Float16* __restrict__ pred, int row_stride, RefineLevels lv,
+                                     int64_t total, float anchor_scale, float max_ratio,
+                                     float* __restrict__ refined) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int H = lv.H[0], W = lv.W[0], p0 = 0;
+  float stride = lv.stride[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++)
+    if (i < lv.n && e >= lv.pix0[i]) {
+      H = lv.H[i]; W = lv.W[i]; p0 = lv.pix0[i]; stride = lv.stride[i];
+    }
+  const int64_t p = (e - p0) % ((int64_t)H * W);
+  const int64_t y = p / W, x = p % W;
+  float d[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) d[k] = (float)pred[e * row_stride + k];
+  const float half = 0.5f * (stride - 1.0f), side = anchor_scale * stride;
+  float roi[5] = {(float)x * stride + half, (float)y * stride + half, side, side, 0.0f};
+  float o[5];
+  decode_one(roi, d, max_ratio, o);
+#pragma unroll
+  for (int k = 0; k < 5; k++) refined[e * 5 + k] = o[k];
+}
+
 // one thread per (b, position); writes the 18 offset planes (coalesced over positions)
 __global__ void k_align_offsets(const float* __restrict__ anchors, int64_t B, int64_t H, int64_t W,
                                 float stride, int ks, float* __restrict__ offset) {
@@ -212,6 +244,30 @@ extern "C" int s2a_fam_refine_anchors(const void* bbox_pred, int64_t batch, int6
   } else {
     S2A_CHECK_ARG(false, "fam_refine_anchors: dtype");
   }
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+extern "C" int s2a_fam_refine_anchors_pyramid(const void* pred, int64_t row_stride, int64_t batch,
+                                              const s2a_pyramid* pyr, float anchor_scale, float* refined,
+                                              s2a_stream_t stream) {
+  S2A_CHECK_ARG(pyr && pyr->n_levels >= 1 && pyr->n_levels <= 8 && batch >= 0 && row_stride >= 5,
+                "fam_refine_anchors_pyramid: bad argument");
+  RefineLevels lv = {};
+  lv.n = pyr->n_levels;
+  lv.batch = (int)batch;
+  int64_t pix = 0;
+  for (int i = 0; i < lv.n; i++) {
+    S2A_CHECK_ARG(pyr->height[i] > 0 && pyr->width[i] > 0 && pyr->stride[i] > 0, "fam_refine_anchors_pyramid: bad level");
+    lv.H[i] = pyr->height[i]; lv.W[i] = pyr->width[i]; lv.stride[i] = pyr->stride[i]; lv.pix0[i] = (int)pix;
+    pix += batch * pyr->height[i] * pyr->width[i];
+    S2A_CHECK_ARG(pix < (1ll << 31), "fam_refine_anchors_pyramid: too many positions");
+  }
+  if (pix == 0) return S2A_OK;
+  S2A_CHECK_ARG(pred && refined, "fam_refine_anchors_pyramid: NULL tensor");
+  const float max_ratio = (float)std::fabs(std::log(1e-6));  // head.py:48
+  k_fam_refine_pyramid<<<(unsigned)((pix + 255) / 256), 256, 0, as_stream(stream)>>>(
+      (const _Float16*)pred, (int)row_stride, lv, pix, anchor_scale, max_ratio, refined);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -8,6 +8,7 @@ reference ``state_dict`` loads), but the constructor is OFFLINE: no torchvision 
 xavier-uniform for FPN neck.py:58-62, N(0,0.01) for the head).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -106,6 +107,26 @@ class FPN(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
                 nn.init.constant_(m.bias, 0)
 
+    def forward_packed(self, inputs, layout):
+        """same as forward(), but the five outputs land back to back in ONE pyramid-packed buffer
+        [sum B*H*W, 256] (s2anet_amd/pyramid.py) so that the head can run each layer once for all levels"""
+        from .fused import conv_f16
+        lat = [l(inputs[i]) for i, l in enumerate(self.lateral_convs)]
+        for i in range(self.num_ins - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], scale_factor=2, mode="nearest")
+        buf = layout.new(self.fpn_convs[0].out_channels, inputs[0].device)
+        for i in range(self.num_outs):
+            conv = self.fpn_convs[i]
+            src = lat[i] if i < self.num_ins else (inputs[-1] if i == self.num_ins else prev)
+            dst = layout.level(buf, i)                          # [B,C,H,W] channels-last view of the slice
+            if i < self.num_ins and hasattr(conv, "packed_args"):
+                w, b, o = conv.packed_args()
+                prev = conv_f16(src, w, b, o, 3, 1, False, out=dst)
+            else:
+                prev = conv(src)
+                dst.copy_(prev)
+        return buf
+
     def forward(self, inputs):
         lat = [l(inputs[i]) for i, l in enumerate(self.lateral_convs)]
         for i in range(self.num_ins - 1, 0, -1):
@@ -130,7 +151,19 @@ class S2ANet(nn.Module):
         return self.head(self.neck(self.backbone(imgs)), post_process=post_process)
 
     def features_to_pred(self, imgs):
-        feats = self.neck(self.backbone(imgs))
+        c = self.backbone(imgs)
+        sizes = [tuple(c[0].shape[2:])]
+        while len(sizes) < len(self.stride):                    # stride-2 3x3/pad-1 convs: ceil(n/2)
+            sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+        if self.head.pyramid_ok(c[0]) and hasattr(self.neck.fpn_convs[0], "packed_args") and \
+                min(sizes[-1]) >= 3 and not os.environ.get("S2A_NO_PYRAMID"):
+            from .pyramid import PyramidLayout
+            B = imgs.shape[0]
+            key = (B, tuple(sizes))
+            if getattr(self, "_layout_key", None) != key:
+                self._layout_key, self._layout = key, PyramidLayout(B, sizes, self.stride)
+            return self.head.forward_pyramid(self._layout, self.neck.forward_packed(c, self._layout))
+        feats = self.neck(c)
         per_level = [self.head.forward_single(f, s) for f, s in zip(feats, self.stride)]
         return tuple(map(list, zip(*per_level)))
 

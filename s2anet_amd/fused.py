@@ -36,7 +36,7 @@ def own_conv_ok(x, in_channels, out_channels, kernel_size, stride, padding, dila
     import os
     if not (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and
             x.is_contiguous(memory_format=torch.channels_last) and tuple(dilation) == (1, 1) and groups == 1 and
-            in_channels % 64 == 0 and (out_channels % 64 == 0 or out_channels < 64) and
+            (in_channels % 64 == 0 or in_channels == 32) and (out_channels % 64 == 0 or out_channels < 64) and
             x.numel() * 2 < (1 << 31)):
         return False
     if os.environ.get("S2A_NO_OWN_CONV"):
@@ -58,6 +58,8 @@ def conv_pack_weight(weight):
     w = weight.detach().to(torch.float16).contiguous()
     if w.shape[0] < 64:
         w = torch.cat([w, w.new_zeros((64 - w.shape[0],) + tuple(w.shape[1:]))], 0).contiguous()
+    if w.shape[1] == 32:            # 32 input maps (odm_cls_ls after the orientation pooling): zero-pad to one 64-chunk
+        w = torch.cat([w, torch.zeros_like(w)], 1).contiguous()
     out = torch.empty_like(w)
     with torch.cuda.device(w.device):
         _lib.check(_lib.lib().s2a_conv_pack_weight_f16(_lib.ptr(w), w.shape[0], w.shape[1], w.shape[2],
@@ -65,7 +67,7 @@ def conv_pack_weight(weight):
     return out
 
 
-def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, residual=None):
+def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, residual=None, out=None):
     """relu?(conv(x) + bias (+ residual)) in ONE kernel; x f16 channels-last, packed_weight from
     conv_pack_weight; ksize 3 (stride 1, pad 1) or 1 (pad 0, stride 1|2)"""
     B, C, H, W = x.shape
@@ -74,8 +76,12 @@ def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, 
     if out_channels < 64:           # narrow head: 64 physical channels, the caller gets the [:, :O] view
         assert residual is None
         out_channels = 64
-    out = torch.empty((B, out_channels, Ho, Wo), dtype=torch.float16, device=x.device,
-                      memory_format=torch.channels_last)
+    if out is None:
+        out = torch.empty((B, out_channels, Ho, Wo), dtype=torch.float16, device=x.device,
+                          memory_format=torch.channels_last)
+    else:       # caller's buffer (e.g. a level slice of a pyramid-packed tensor): dense NHWC storage required
+        assert out.shape == (B, out_channels, Ho, Wo) and out.dtype == torch.float16 and \
+            out.permute(0, 2, 3, 1).is_contiguous()
     b = None if bias is None else bias.to(torch.float16).contiguous()
     if b is not None and b.numel() < out_channels:
         b = torch.cat([b, b.new_zeros(out_channels - b.numel())])
@@ -130,6 +136,13 @@ class FusedConv2d(nn.Conv2d):
         m.weight = conv.weight
         m.bias = conv.bias
         return m
+
+    def packed_args(self):
+        """(fragment-order filter, f16 bias, physical out channels) for the pyramid-packed launches"""
+        if not hasattr(self, "_packed"):
+            self._packed = PackedWeightCache()
+        width = max(64, self.out_channels)
+        return self._packed.get(self.weight), self._packed.get_bias(self.bias, width), width
 
     def forward(self, x, residual=None):
         if not torch.is_grad_enabled() and own_conv_ok(

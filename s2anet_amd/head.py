@@ -122,6 +122,50 @@ class S2ANetHead(nn.Module):
         odm_bbox_pred = self.odm_reg_head(self.odm_reg_ls(or_feat))
         return fam_cls_pred, fam_bbox_pred, odm_cls_pred, odm_bbox_pred, refine_anchor
 
+    # ------------------------------------------------------------------ all levels per launch
+    def pyramid_ok(self, x):
+        from .fused import FusedConv2d
+        return (x.is_cuda and x.dtype == torch.float16 and not torch.is_grad_enabled() and self.with_orconv and
+                isinstance(self.fam_reg_head, FusedConv2d) and self.in_channels % 64 == 0 and
+                self.feat_channels % 64 == 0 and self.align_conv.kernel_size == (3, 3))
+
+    def forward_pyramid(self, layout, x):
+        """forward_single for ALL FPN levels at once on a pyramid-packed feature buffer x[P,256]
+        (s2anet_amd/pyramid.py).  Returns per-level lists of views with the forward_single shapes."""
+        from . import pyramid as P
+
+        def tower(seq, t):
+            for blk in seq:
+                w, b, o = blk[0].packed_args()
+                t = P.conv3x3(layout, t, w, b, o, relu=True)
+            return t
+
+        w, b, o = self.fam_reg_head.packed_args()
+        fam_bbox = P.conv1x1(tower(self.fam_reg_ls, x), w, b, o, relu=False)               # [P,64], 5 used
+        fam_cls = None
+        if self.compute_fam_cls:
+            w, b, o = self.fam_cls_head.packed_args()
+            fam_cls = P.conv1x1(tower(self.fam_cls_ls, x), w, b, o, relu=False)
+        anchors = P.fam_refine_anchors(layout, fam_bbox, self.anchor_scale)                 # [P,5] f32
+        al = P.align_conv(layout, x, anchors, self.align_conv.packed_weight(torch.float16), self.feat_channels)
+        wa = self.or_conv.rotate_arf()
+        if not hasattr(self.or_conv, "_packed"):
+            from .fused import PackedWeightCache
+            self.or_conv._packed = PackedWeightCache()
+        or_feat = P.conv3x3(layout, al, self.or_conv._packed.get(wa),
+                            self.or_conv._packed.get_bias(self.or_conv.bias, wa.shape[0]), wa.shape[0], relu=False)
+        pooled = P.rot_inv_pool(or_feat, self.or_pool.nOrientation)                         # [P,32]
+        w, b, o = self.odm_cls_head.packed_args()
+        odm_cls = P.conv3x3(layout, tower(self.odm_cls_ls, pooled), w, b, o, relu=False)    # [P,64], C used
+        w, b, o = self.odm_reg_head.packed_args()
+        odm_bbox = P.conv3x3(layout, tower(self.odm_reg_ls, or_feat), w, b, o, relu=False)  # [P,64], 5 used
+        n = len(layout.sizes)
+        return ([layout.level(fam_cls, l, self.num_classes) for l in range(n)] if fam_cls is not None else [None] * n,
+                [layout.level(fam_bbox, l, 5) for l in range(n)],
+                [layout.level(odm_cls, l, self.num_classes) for l in range(n)],
+                [layout.level(odm_bbox, l, 5) for l in range(n)],
+                [layout.rows(anchors, l).view(layout.batch, *layout.sizes[l], 5) for l in range(n)])
+
     def forward(self, feats, post_process=False):
         per_level = [self.forward_single(f, s) for f, s in zip(feats, self.featmap_strides)]
         p = tuple(map(list, zip(*per_level)))

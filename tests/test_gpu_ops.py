@@ -485,3 +485,82 @@ def test_merge_nms_poly(rng):
     dets = np.concatenate([polys, ((rng.permutation(n) + 1.0) / (n + 1.0))[:, None]], 1)
     assert np.array_equal(nms_poly(cu(dets), 0.3).cpu().numpy(), oracle.nms_poly(dets, 0.3))
     assert nms_poly(torch.zeros((0, 9), device=dev()), 0.5).shape == (0,)
+
+
+def _pyr_setup(B=2, sizes=((40, 56), (20, 28), (10, 14), (5, 7), (3, 4)), C=256):
+    from s2anet_amd.pyramid import PyramidLayout
+    layout = PyramidLayout(B, sizes, (8, 16, 32, 64, 128))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(layout.pixels, C, generator=g).to(dev()).half()
+    return layout, x, g
+
+
+def test_pyramid_conv3x3_matches_per_level():
+    """one pyramid-packed launch == the per-level launches of the same kernel (bit-identical), and == torch"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.fused import conv_f16, conv_pack_weight
+    layout, x, g = _pyr_setup()
+    for (C, O) in ((256, 256), (256, 64), (32, 256)):
+        xx = x[:, :C].contiguous()
+        w = (torch.randn(O, C, 3, 3, generator=g) * 0.03).to(dev()).half()
+        b = torch.randn(O, generator=g).to(dev()).half()
+        wp = conv_pack_weight(w)
+        out = P.conv3x3(layout, xx, wp, b, O, relu=True)
+        for l in range(len(layout.sizes)):
+            xl = layout.level(xx, l)
+            ref = torch.relu(torch.nn.functional.conv2d(xl.float(), w.float(), b.float(), padding=1))
+            got = layout.level(out, l)
+            assert (got.float() - ref).abs().max().item() < 3e-2
+            if layout.sizes[l][0] >= 8 and C % 64 == 0:
+                assert torch.equal(got, conv_f16(xl.contiguous(memory_format=torch.channels_last), wp, b, O, 3, 1, True))
+
+
+def test_pyramid_alignconv_and_refine(rng):
+    """pyramid-packed fam_refine + AlignConv against the per-level entry points and the oracle"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.alignconv import align_conv_forward, pack_weight
+    from s2anet_amd.head import fam_refine_anchors
+    layout, x, g = _pyr_setup()
+    pred = (torch.randn(layout.pixels, 64, generator=g) * 0.3).to(dev()).half()
+    anchors = P.fam_refine_anchors(layout, pred, 4.0)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev()).half()
+    out = P.align_conv(layout, x, anchors, pack_weight(w, torch.float16), 256)
+    for l, st in enumerate(layout.strides):
+        a_ref = fam_refine_anchors(layout.level(pred, l, 5), st, 4.0)
+        a_got = layout.rows(anchors, l).view(a_ref.shape)
+        assert torch.equal(a_got, a_ref)
+        xl = layout.level(x, l).contiguous(memory_format=torch.channels_last)
+        ref = align_conv_forward(xl, a_ref, w, st, relu=True)
+        got = layout.level(out, l)
+        assert (got.float() - ref.float()).abs().max().item() < 3e-2
+    # smallest level against the CPU oracle (f32 math on the same f16 inputs)
+    l = 4
+    H, W = layout.sizes[l]
+    a = layout.rows(anchors, l).view(layout.batch, H * W, 5).cpu().numpy()
+    xl = layout.level(x, l).float().cpu().numpy()
+    for bi in range(layout.batch):
+        off = oracle.align_offsets(a[bi], H, W, layout.strides[l])
+        ref = oracle.deform_conv_forward(np.ascontiguousarray(xl[bi:bi + 1]), off[None], w.float().cpu().numpy(), relu=True)
+        got = layout.level(out, l)[bi:bi + 1].float().cpu().numpy()
+        assert np.abs(got - ref).max() < 3e-2
+
+
+def test_detector_pyramid_path_matches_per_level(monkeypatch):
+    """the whole head on the pyramid-packed path == the per-level path (library kernels on the small levels)"""
+    from s2anet_amd.detector import build_synthetic_detector
+    m = build_synthetic_detector(device=dev())
+    g = torch.Generator().manual_seed(1)
+    imgs = (torch.rand(2, 3, 384, 512, generator=g)).to(dev()).half().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        got = m.features_to_pred(imgs)
+        monkeypatch.setenv("S2A_NO_PYRAMID", "1")
+        ref = m.features_to_pred(imgs)
+    assert hasattr(m, "_layout")                                   # the packed path ran
+    for gl, rl in zip(got, ref):
+        for a, b in zip(gl, rl):
+            if a is None:
+                assert b is None
+                continue
+            assert a.shape == b.shape
+            d = (a.float() - b.float()).abs().max().item()
+            assert d < 5e-2 * max(1.0, b.float().abs().max().item()), d
