@@ -1163,6 +1163,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
     }
     pvoff[j] = in ? (unsigned)(pix * row_bytes + q * 16) : 0x80000000u;
   }
+  // bias of this workgroup's out channels -> LDS (behind the tile buffers): the epilogue reads it
+  // with ds_read instead of eight dependent global loads
+  T* s_bias = reinterpret_cast<T*>(smem + Cfg::kLds);
+  T bias_v = (T)0.f;
+  if (bias && tid < Oloc) bias_v = bias[o0 + tid];   // in flight with the first patch / weights
   auto patch_issue = [&](int cc) {
     char* P = smem + (cc & 1) * Cfg::kPatchBytes;
 #pragma unroll
@@ -1221,6 +1226,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
 
   patch_issue(0);
   load_w(0, wA);
+  if (tid < 64 * OG) s_bias[tid] = bias_v;
   __syncthreads();   // (the compiler drains the DMA with vmcnt(0) before the barrier)
   const int nstage = TAPS * CC, last = nstage - 1;
   if constexpr (TAPS == 9) {
@@ -1277,8 +1283,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
       for (int rq = 0; rq < 4; rq++) {
         using h4 = __attribute__((ext_vector_type(4))) _Float16;
         const int och = grp * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
-        h4 bq = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-        if (bias) bq = *reinterpret_cast<const h4*>(bias + o0 + och);
+        const h4 bq = *reinterpret_cast<const h4*>(s_bias + och);
 #pragma unroll
         for (int b = 0; b < NT; b++) {
           h4 v4;
@@ -1295,22 +1300,40 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
   }
   __syncthreads();
   constexpr int VPR = 8 * OG;                     // 16-byte vectors per output row
+  constexpr int NI = (128 * VPR) / 256;
+  if (residual) {
+    // all residual vectors of the tile in flight at once (bounds-checked buffer loads: no branch
+    // around a load, so the compiler does not wait for each one before issuing the next)
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(residual), 0, (int)((uint64_t)Ntot * O * 2), 0x00020000);
+    unsigned off[NI];
+    V r[NI];
 #pragma unroll
-  for (int i = 0; i < (128 * VPR) / 256; i++) {
-    int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
-    int64_t gp = TAPS == 9 ? tile_pos(tile, pos, 8, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
-    if (gp >= 0 && col * 8 < Oloc) {
+    for (int i = 0; i < NI; i++) {
+      int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
+      int64_t gp = TAPS == 9 ? tile_pos(tile, pos, 8, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
+      off[i] = (gp >= 0 && col * 8 < Oloc) ? (unsigned)((gp * O + o0 + col * 8) * 2) : 0x80000000u;
+      r[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)off[i], 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
       V v = *reinterpret_cast<const V*>(s_out + pos * Cfg::kOutRowB + col * 16);
-      if (residual) {
-        V r = *reinterpret_cast<const V*>(residual + gp * O + o0 + col * 8);
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          float f = (float)v[e] + (float)r[e];
-          if (relu) f = fmaxf(f, 0.f);
-          v[e] = (_Float16)f;
-        }
+      for (int e = 0; e < 8; e++) {
+        float f = (float)v[e] + (float)r[i][e];
+        if (relu) f = fmaxf(f, 0.f);
+        v[e] = (_Float16)f;
       }
-      *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = v;
+      if (off[i] != 0x80000000u) *reinterpret_cast<V*>(reinterpret_cast<char*>(out) + off[i]) = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
+      int64_t gp = TAPS == 9 ? tile_pos(tile, pos, 8, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
+      if (gp >= 0 && col * 8 < Oloc)
+        *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * Cfg::kOutRowB + col * 16);
     }
   }
 }
@@ -1621,8 +1644,8 @@ int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, 
   if (levels) { lt = *levels; tiles = level_tiles; }
   dim3 grid((unsigned)tiles, (unsigned)((O + 64 * OG - 1) / (64 * OG)));
   auto kern = k_conv_f16<TAPS, OG>;
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
-  kern<<<grid, 256, Cfg::kLds, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + 512));
+  kern<<<grid, 256, Cfg::kLds + 512, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
                                      (unsigned)((uint64_t)B * H * W * C * 2), lt);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
@@ -1641,6 +1664,8 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
   const uint64_t x_bytes = (uint64_t)batch * height * width * channels * 2;
   S2A_CHECK_ARG(x_bytes < (1ull << 31) && (ksize == 1 || (height < 32000 && width < 32000)),
                 "conv: input too large for 32-bit offsets");
+  S2A_CHECK_ARG(!residual || (uint64_t)batch * ((height - 1) / stride + 1) * ((width - 1) / stride + 1) * out_channels * 2 < (1ull << 31),
+                "conv: output too large for the fused residual (32-bit offsets)");
   if (batch == 0) return S2A_OK;
   S2A_CHECK_ARG(x && weight_frag && out, "conv: NULL tensor");
   S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_frag % 16) == 0 &&
