@@ -274,6 +274,17 @@ int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, const void* 
 int s2a_fam_refine_anchors_pyramid(const void* pred, int64_t row_stride, int64_t batch, const s2a_pyramid* pyr,
                                    float anchor_scale, float* refined, s2a_stream_t stream);
 
+/* Fused ResNet stem of the end-to-end config: uint8 image / divisor
+ * (val.py:246-247) -> conv 7x7 / stride 2 / pad 3, 3 -> 64 maps + bias (BatchNorm folded) -> ReLU ->
+ * max-pool 3x3 / stride 2 / pad 1 (models/backbone.py:112-117, :172-175) in one kernel.
+ * image_u8[B,H,W,3] (channels-last uint8, W % 4 == 0) -> out[B,Hp,Wp,64] f16 with
+ * Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).  weight_packed = s2a_stem_pack_weight_f16 of the
+ * [64,3,7,7] f16 filter (s2a_stem_packed_elems() halfs); bias[64] f16 or NULL. */
+int64_t s2a_stem_packed_elems(void);
+int s2a_stem_pack_weight_f16(const void* weight, void* packed, s2a_stream_t stream);
+int s2a_stem_u8_f16(const void* image_u8, const void* weight_packed, const void* bias, void* out,
+                    int64_t batch, int64_t height, int64_t width, float divisor, s2a_stream_t stream);
+
 /* Diagnostic builds only (-DS2A_STAMP=1): per-workgroup s_memtime phase stamps of the AlignConv
  * kernel; returns S2A_ENOTIMPL in a normal build. */
 int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count);

@@ -92,6 +92,34 @@ class DetectorBackbone(nn.Module):
                 outs.append(x)
         return tuple(outs)
 
+    def stem_fusable(self, imgs_u8):
+        """uint8 channels-last batch + BN-folded stem: /255, conv1, ReLU and the max-pool run as one kernel"""
+        conv, pool = self.backbone[0][0], self.backbone[1][0]
+        return (isinstance(conv, FusedConv2d) and conv.fuse_relu and conv.weight.dtype == torch.float16 and
+                tuple(conv.weight.shape) == (64, 3, 7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and
+                isinstance(pool, nn.MaxPool2d) and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1 and
+                not pool.ceil_mode and imgs_u8.is_cuda and imgs_u8.dtype == torch.uint8 and imgs_u8.shape[1] == 3 and
+                imgs_u8.shape[3] % 4 == 0 and min(imgs_u8.shape[2:]) >= 7 and
+                imgs_u8.permute(0, 2, 3, 1).is_contiguous() and not torch.is_grad_enabled() and
+                not os.environ.get("S2A_NO_FUSED_STEM"))
+
+    def forward_u8(self, imgs_u8, divisor=255.0):
+        """forward() on the raw uint8 batch with the fused stem (s2a_stem_u8_f16)"""
+        from .fused import PackedWeightCache, stem_pack_weight, stem_u8
+        conv = self.backbone[0][0]
+        w = conv.weight
+        key = (w._version, w.data_ptr(), w.device)
+        if getattr(self, "_stem_key", None) != key:
+            self._stem_key, self._stem_w = key, stem_pack_weight(w)
+            self._stem_b = None if conv.bias is None else conv.bias.detach().to(torch.float16).contiguous()
+        x = self.backbone[1][1](stem_u8(imgs_u8, self._stem_w, self._stem_b, divisor))
+        outs = [x] if 1 in self.out_indices else []
+        for i in range(2, len(self.backbone)):
+            x = self.backbone[i](x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
 
 class FPN(nn.Module):
     def __init__(self, in_channels=(512, 1024, 2048), out_channels=256, num_outs=5):
@@ -150,8 +178,8 @@ class S2ANet(nn.Module):
     def forward(self, imgs, post_process=False):
         return self.head(self.neck(self.backbone(imgs)), post_process=post_process)
 
-    def features_to_pred(self, imgs):
-        c = self.backbone(imgs)
+    def features_to_pred(self, imgs, backbone_out=None):
+        c = self.backbone(imgs) if backbone_out is None else backbone_out
         sizes = [tuple(c[0].shape[2:])]
         while len(sizes) < len(self.stride):                    # stride-2 3x3/pad-1 convs: ceil(n/2)
             sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
@@ -171,6 +199,9 @@ class S2ANet(nn.Module):
     def detect(self, imgs_u8, max_candidates=None):
         """device-resident uint8 batch [B,3,H,W] -> (dets[B,2000,6], labels[B,2000], counts[B]).
         /255 normalisation as val.py:246-247; no host synchronisation anywhere."""
+        if self.backbone.stem_fusable(imgs_u8):
+            return self.head.get_bboxes_batched(
+                self.features_to_pred(imgs_u8, self.backbone.forward_u8(imgs_u8, 255.0)), max_candidates)
         dt = next(self.parameters()).dtype
         x = imgs_u8.to(dt).div_(255.0)
         if imgs_u8.is_contiguous(memory_format=torch.channels_last):

@@ -160,3 +160,30 @@ class FusedConv2d(nn.Conv2d):
             return F.relu(y) if self.fuse_relu else y
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
         return bias_act_(y, self.bias, residual, self.fuse_relu)
+
+
+def stem_pack_weight(weight):
+    """[64,3,7,7] -> the fragment order of the fused stem kernel (s2a_stem_pack_weight_f16)"""
+    w = weight.detach().to(torch.float16).contiguous()
+    assert tuple(w.shape) == (64, 3, 7, 7)
+    L = _lib.lib()
+    out = torch.empty((L.s2a_stem_packed_elems(),), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(L.s2a_stem_pack_weight_f16(_lib.ptr(w), _lib.ptr(out), _lib.stream_ptr(w.device)))
+    return out
+
+
+def stem_u8(imgs_u8, packed_weight, bias, divisor=255.0):
+    """uint8 image [B,3,H,W] (channels-last storage) -> relu(conv7x7/2(img / divisor) + bias) -> maxpool 3x3/2:
+    [B,64,H/4,W/4] f16 channels-last, one kernel (s2a_stem_u8_f16)"""
+    _lib.require_cuda(imgs_u8)
+    B, C, H, W = imgs_u8.shape
+    assert C == 3 and imgs_u8.dtype == torch.uint8 and imgs_u8.permute(0, 2, 3, 1).is_contiguous()
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    out = torch.empty((B, 64, Hp, Wp), dtype=torch.float16, device=imgs_u8.device, memory_format=torch.channels_last)
+    b = None if bias is None else bias.to(torch.float16).contiguous()
+    with torch.cuda.device(imgs_u8.device):
+        _lib.check(_lib.lib().s2a_stem_u8_f16(_lib.ptr(imgs_u8), _lib.ptr(packed_weight), _lib.ptr(b), _lib.ptr(out),
+                                              B, H, W, float(divisor), _lib.stream_ptr(imgs_u8.device)))
+    return out

@@ -564,3 +564,38 @@ def test_detector_pyramid_path_matches_per_level(monkeypatch):
             assert a.shape == b.shape
             d = (a.float() - b.float()).abs().max().item()
             assert d < 5e-2 * max(1.0, b.float().abs().max().item()), d
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 200, 132), (3, 39, 44), (1, 256, 256)])
+def test_fused_stem_vs_torch(shape):
+    """uint8 / 255 -> conv7x7/2 + bias -> ReLU -> maxpool3x3/2 in one kernel against the stock ops"""
+    from s2anet_amd.fused import stem_pack_weight, stem_u8
+    B, H, W = shape
+    g = torch.Generator().manual_seed(2)
+    img = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g).to(dev()).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(dev()).half()
+    b = torch.randn(64, generator=g).to(dev()).half()
+    x = img.half().div_(255.0)                                      # the stock normalisation (f16 division)
+    ref = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), b.float(), stride=2, padding=3)),
+                                         3, 2, 1)
+    out = stem_u8(img, stem_pack_weight(w), b)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    err = (out.float() - ref).abs()
+    assert err.max().item() < 2e-2 and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
+    out0 = stem_u8(img, stem_pack_weight(w), None)
+    ref0 = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), None, stride=2, padding=3)), 3, 2, 1)
+    assert (out0.float() - ref0).abs().max().item() < 2e-2
+
+
+def test_detect_fused_stem_matches_stock(monkeypatch):
+    from s2anet_amd.detector import build_synthetic_detector
+    m = build_synthetic_detector(device=dev())
+    g = torch.Generator().manual_seed(4)
+    img = torch.randint(0, 256, (2, 3, 384, 384), dtype=torch.uint8, generator=g).to(dev()).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert m.backbone.stem_fusable(img)
+        a = m.backbone.forward_u8(img)
+        b = m.backbone(img.half().div_(255.0).contiguous(memory_format=torch.channels_last))
+    for u, v in zip(a, b):
+        assert u.shape == v.shape
+        assert (u.float() - v.float()).abs().max().item() < 3e-2 * max(1.0, v.float().abs().max().item())
