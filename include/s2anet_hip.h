@@ -247,6 +247,12 @@ int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const void* bias, 
                       void* out, int64_t batch, int64_t channels, int64_t height, int64_t width,
                       int64_t out_channels, int ksize, int stride, int relu, s2a_stream_t stream);
 
+/* FPN top-down step in one launch (models/neck.py:67-79): out[B,H,W,O] = conv1x1(x[B,H,W,C]) + bias +
+ * nearest-2x-upsample(coarse[B,H/2,W/2,O]); f16 channels-last, H and W even, C and O multiples of 64. */
+int s2a_conv1x1_add_up2_f16(const void* x, const void* weight_frag, const void* bias, const void* coarse,
+                            void* out, int64_t batch, int64_t channels, int64_t height, int64_t width,
+                            int64_t out_channels, s2a_stream_t stream);
+
 /* Pyramid-packed head launches.  The conv towers, AlignConv and prediction heads of S2ANetHead share
  * their filters over the FPN levels (models/head.py:261-265 maps forward_single over the levels), so
  * one launch can serve all of them: the levels sit back to back in ONE channels-last buffer

@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
                                                      const _Float16* __restrict__ residual_,
                                                      _Float16* __restrict__ out_, int64_t Ntot_, int C,
                                                      int H_, int W_, int Ho_, int Wo_, int cstride, int O,
-                                                     int relu, unsigned x_bytes_, LevelTab lt) {
+                                                     int relu, unsigned x_bytes_, LevelTab lt, int res_up) {
   using T = _Float16;
   using V = f16x8;
   using Cfg = ConvCfg<TAPS, OG>;
@@ -1304,16 +1304,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
   if (residual) {
     // all residual vectors of the tile in flight at once (bounds-checked buffer loads: no branch
     // around a load, so the compiler does not wait for each one before issuing the next)
+    // res_up: the residual is a half-resolution map [B,Ho/2,Wo/2,O] added through a nearest 2x
+    // up-sampling (the FPN top-down pathway, models/neck.py:73-79) -- only its row index differs
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(residual), 0, (int)((uint64_t)Ntot * O * 2), 0x00020000);
+        const_cast<T*>(residual), 0, (int)((uint64_t)(res_up ? Ntot / 4 : Ntot) * O * 2), 0x00020000);
     unsigned off[NI];
     V r[NI];
+    const int Wr = Wo >> 1;
+    const int64_t HWr = (int64_t)(Ho >> 1) * Wr;
 #pragma unroll
     for (int i = 0; i < NI; i++) {
       int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
       int64_t gp = TAPS == 9 ? tile_pos(tile, pos, 8, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
-      off[i] = (gp >= 0 && col * 8 < Oloc) ? (unsigned)((gp * O + o0 + col * 8) * 2) : 0x80000000u;
-      r[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)off[i], 0, 0));
+      const bool ok = gp >= 0 && col * 8 < Oloc;
+      off[i] = ok ? (unsigned)((gp * O + o0 + col * 8) * 2) : 0x80000000u;
+      unsigned roff = off[i];
+      if (res_up && ok) {
+        const int64_t bb = gp / HWo, rem = gp % HWo;
+        const int yy = (int)(rem / Wo), xx = (int)(rem % Wo);
+        roff = (unsigned)(((bb * HWr + (int64_t)(yy >> 1) * Wr + (xx >> 1)) * O + o0 + col * 8) * 2);
+      }
+      r[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)roff, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < NI; i++) {
@@ -1636,7 +1647,7 @@ namespace {
 template <int TAPS, int OG>
 int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
                 _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
-                hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0) {
+                hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0, int res_up = 0) {
   using Cfg = ConvCfg<TAPS, OG>;
   const int64_t Ntot = B * (int64_t)Ho * Wo;
   int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + 7) / 8) : (Ntot + 127) / 128;
@@ -1646,7 +1657,7 @@ int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, 
   auto kern = k_conv_f16<TAPS, OG>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + 512));
   kern<<<grid, 256, Cfg::kLds + 512, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
-                                     (unsigned)((uint64_t)B * H * W * C * 2), lt);
+                                     (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -1680,6 +1691,29 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
   if (ksize == 3) return og == 4 ? S2A_CONV(9, 4) : (og == 2 ? S2A_CONV(9, 2) : S2A_CONV(9, 1));
   return og == 4 ? S2A_CONV(1, 4) : (og == 2 ? S2A_CONV(1, 2) : S2A_CONV(1, 1));
 #undef S2A_CONV
+}
+
+extern "C" int s2a_conv1x1_add_up2_f16(const void* x, const void* weight_frag, const void* bias, const void* coarse,
+                                       void* out, int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                       int64_t out_channels, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0 && height > 0 && width > 0, "conv_add_up2: bad shape");
+  S2A_CHECK_ARG(height % 2 == 0 && width % 2 == 0, "conv_add_up2: the map must be exactly twice the coarse map");
+  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 64 == 0, "conv_add_up2: channel counts must be multiples of 64");
+  const uint64_t x_bytes = (uint64_t)batch * height * width * channels * 2;
+  S2A_CHECK_ARG(x_bytes < (1ull << 31) && (uint64_t)batch * height * width * out_channels * 2 < (1ull << 31),
+                "conv_add_up2: tensor too large for 32-bit offsets");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(x && weight_frag && coarse && out, "conv_add_up2: NULL tensor");
+  S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_frag % 16) == 0 &&
+                ((uintptr_t)bias % 2) == 0 && ((uintptr_t)coarse % 16) == 0, "conv_add_up2: tensors must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const int og = out_channels % 256 == 0 ? 4 : (out_channels % 128 == 0 ? 2 : 1);
+  const _Float16 *X = (const _Float16*)x, *Wf = (const _Float16*)weight_frag, *Bi = (const _Float16*)bias,
+                 *R = (const _Float16*)coarse;
+  _Float16* Y = (_Float16*)out;
+#define S2A_CONVU(OG_) launch_conv<1, OG_>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, (int)height, (int)width, 1, (int)out_channels, 0, st, nullptr, 0, 1)
+  return og == 4 ? S2A_CONVU(4) : (og == 2 ? S2A_CONVU(2) : S2A_CONVU(1));
+#undef S2A_CONVU
 }
 
 extern "C" int s2a_conv_pack_weight_f16(const void* weight, int64_t out_channels, int64_t channels, int ksize,

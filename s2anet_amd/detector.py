@@ -138,10 +138,18 @@ class FPN(nn.Module):
     def forward_packed(self, inputs, layout):
         """same as forward(), but the five outputs land back to back in ONE pyramid-packed buffer
         [sum B*H*W, 256] (s2anet_amd/pyramid.py) so that the head can run each layer once for all levels"""
-        from .fused import conv_f16
-        lat = [l(inputs[i]) for i, l in enumerate(self.lateral_convs)]
-        for i in range(self.num_ins - 1, 0, -1):
-            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], scale_factor=2, mode="nearest")
+        from .fused import conv_f16, conv1x1_add_up2, own_conv_ok
+        lat = [None] * self.num_ins
+        lat[-1] = self.lateral_convs[-1](inputs[-1])
+        for i in range(self.num_ins - 1, 0, -1):           # top-down: lateral conv + up-sampled coarser level, one launch
+            l, x = self.lateral_convs[i - 1], inputs[i - 1]
+            if (hasattr(l, "packed_args") and x.shape[2] == 2 * lat[i].shape[2] and x.shape[3] == 2 * lat[i].shape[3] and
+                    lat[i].is_contiguous(memory_format=torch.channels_last) and l.out_channels % 64 == 0 and
+                    own_conv_ok(x, l.in_channels, l.out_channels, l.kernel_size, l.stride, l.padding, l.dilation, l.groups)):
+                w, b, o = l.packed_args()
+                lat[i - 1] = conv1x1_add_up2(x, w, b, lat[i], o)
+            else:
+                lat[i - 1] = l(x) + F.interpolate(lat[i], scale_factor=2, mode="nearest")
         buf = layout.new(self.fpn_convs[0].out_channels, inputs[0].device)
         for i in range(self.num_outs):
             conv = self.fpn_convs[i]

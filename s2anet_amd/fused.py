@@ -95,6 +95,19 @@ def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, 
     return out if O_real == out_channels else out[:, :O_real]
 
 
+def conv1x1_add_up2(x, packed_weight, bias, coarse, out_channels):
+    """FPN top-down step (models/neck.py:67-79) in one launch:
+    conv1x1(x) + bias + nearest-2x-upsample(coarse); x[B,C,H,W], coarse[B,O,H/2,W/2] f16 channels-last"""
+    B, C, H, W = x.shape
+    assert coarse.shape == (B, out_channels, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0
+    assert coarse.dtype == torch.float16 and coarse.is_contiguous(memory_format=torch.channels_last)
+    out = torch.empty((B, out_channels, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().s2a_conv1x1_add_up2_f16(_lib.ptr(x), _lib.ptr(packed_weight), _lib.ptr(bias), _lib.ptr(coarse),
+                                                      _lib.ptr(out), B, C, H, W, out_channels, _lib.stream_ptr(x.device)))
+    return out
+
+
 class PackedWeightCache:
     """inference-time cache of a conv_pack_weight() result, invalidated when the tensor changes"""
 

@@ -599,3 +599,18 @@ def test_detect_fused_stem_matches_stock(monkeypatch):
     for u, v in zip(a, b):
         assert u.shape == v.shape
         assert (u.float() - v.float()).abs().max().item() < 3e-2 * max(1.0, v.float().abs().max().item())
+
+
+def test_fpn_topdown_step_fused():
+    """conv1x1 + bias + nearest-2x-upsample(coarse) in one launch == the separate ops (same f16 roundings)"""
+    from s2anet_amd.fused import conv_f16, conv_pack_weight, conv1x1_add_up2
+    g = torch.Generator().manual_seed(9)
+    for (B, C, H, W, O) in ((2, 512, 32, 48, 256), (1, 1024, 64, 64, 256), (3, 128, 8, 20, 64)):
+        x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(O, C, 1, 1, generator=g) * 0.04).to(dev()).half()
+        b = torch.randn(O, generator=g).to(dev()).half()
+        coarse = torch.randn(B, O, H // 2, W // 2, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        wp = conv_pack_weight(w)
+        got = conv1x1_add_up2(x, wp, b, coarse, O)
+        ref = conv_f16(x, wp, b, O, 1, 1, False) + torch.nn.functional.interpolate(coarse, scale_factor=2, mode="nearest")
+        assert torch.equal(got, ref)
