@@ -37,6 +37,9 @@ NUM_CLASSES = 15
 PEAK_F16_TFLOPS = 2500.0   # dense MFMA f16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+# HBM bytes of ONE pyramid-packed AlignConv launch (f16, batch 8), from rocprofv3 PMC passes over this
+# command (scripts/pmc_bench.sh -> profiles/r01_alignconv_pyramid_pmc.txt): 2 x FETCH_SIZE + WRITE_SIZE
+ALIGN_PYRAMID_TRAFFIC = 256.2e6
 
 
 def parse():
@@ -79,46 +82,74 @@ def calibrate_cls_bias(model, imgs, target_per_chip, logit_std=1.5):
     return got
 
 
-def measure_alignconv(model, batch, dtype, iters=30):
-    """dominant hand-written kernel: fused AlignConv at P3 (128x128) for the whole batch.
-    HIP events on the launching stream (torch's current stream) around `iters` launches."""
-    from s2anet_amd.alignconv import align_conv_forward
-    dev = next(model.parameters()).device
-    C = 256
-    H = W = CHIP // 8
-    g = torch.Generator(device="cpu").manual_seed(1234)
-    x = torch.randn(batch, C, H, W, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last)
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-    anc = torch.zeros(batch, H, W, 5)
-    anc[..., 0] = xs * 8 + 3.5 + torch.randn(batch, H, W, generator=g) * 4     # SURVEY 8(d) config 2
-    anc[..., 1] = ys * 8 + 3.5 + torch.randn(batch, H, W, generator=g) * 4
-    anc[..., 2:4] = 32 * torch.exp(torch.randn(batch, H, W, 2, generator=g) * 0.5)
-    anc[..., 4] = (torch.rand(batch, H, W, generator=g) - 0.25) * math.pi
-    anc = anc.to(dev)
-    wp = model.head.align_conv.packed_weight(dtype)
+def _time_launches(fn, iters):
+    """HIP events on the launching stream (torch's current stream) around `iters` launches"""
     for _ in range(3):
-        align_conv_forward(x, anc, wp, 8, relu=True, packed=True, out_channels=256)
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        align_conv_forward(x, anc, wp, 8, relu=True, packed=True, out_channels=256)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    npos = batch * H * W
-    flops = 2.0 * 256 * 2304 * npos                     # SURVEY 8(d): 19.33 GFLOP per P3 image
+    return e0.elapsed_time(e1) / 1e3 / iters
+
+
+def capture_head_operands(model, imgs):
+    """one step with S2ANetHead.capture armed: the pyramid-packed FPN features, the refined anchors and
+    the level table that the step's AlignConv / conv-tower launches really see (None: per-level path)"""
+    model.head.capture = {}
+    model.detect(imgs)
+    torch.cuda.synchronize()
+    cap, model.head.capture = model.head.capture, None
+    return cap if cap else None
+
+
+def measure_alignconv(model, batch, dtype, cap, iters=30):
+    """dominant hand-written kernel of the path: the fused AlignConv launch exactly as the step issues it
+    -- ONE pyramid-packed launch over the five FPN levels of the whole batch (21 824 positions per chip),
+    on the step's own activations and refined anchors (the duration depends on the data: clocks).
+    Per-unit figures: SURVEY 8(d) config 2 -- 2*256*2304 flop per position (19.33 GFLOP per P3 image)."""
+    dev = next(model.parameters()).device
+    C = O = 256
     es = 2 if dtype == torch.float16 else 4
-    alg_bytes = npos * C * es * 2 + 256 * 2304 * es + npos * 5 * 4   # in + out + weight + anchors
+    if cap is not None:
+        from s2anet_amd import pyramid as P
+        layout, x, anc = cap["layout"], cap["x"], cap["anchors"]
+        wp = model.head.align_conv.packed_weight(dtype)
+        sec = _time_launches(lambda: P.align_conv(layout, x, anc, wp, O), iters)
+        npos = layout.pixels
+        shape = "five FPN levels pyramid-packed, %d positions" % npos
+        kname = "k_dcn_patch"
+    else:           # f32 / per-level path: P3 only, synthetic operands of SURVEY 8(d) config 2
+        from s2anet_amd.alignconv import align_conv_forward
+        H = W = CHIP // 8
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        x = torch.randn(batch, C, H, W, generator=g).to(dev, dtype).contiguous(memory_format=torch.channels_last)
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        anc = torch.zeros(batch, H, W, 5)
+        anc[..., 0] = xs * 8 + 3.5 + torch.randn(batch, H, W, generator=g) * 4
+        anc[..., 1] = ys * 8 + 3.5 + torch.randn(batch, H, W, generator=g) * 4
+        anc[..., 2:4] = 32 * torch.exp(torch.randn(batch, H, W, 2, generator=g) * 0.5)
+        anc[..., 4] = (torch.rand(batch, H, W, generator=g) - 0.25) * math.pi
+        anc = anc.to(dev)
+        wp = model.head.align_conv.packed_weight(dtype)
+        sec = _time_launches(lambda: align_conv_forward(x, anc, wp, 8, relu=True, packed=True, out_channels=O), iters)
+        npos = batch * H * W
+        shape = "P3 128x128"
+        kname = "k_dcn_patch" if es == 2 else "k_dcn_mfma"
+    flops = 2.0 * O * C * 9 * npos
+    alg_bytes = npos * C * es + npos * O * es + O * C * 9 * es + npos * 5 * 4   # in + out + weight + anchors
     peak = PEAK_F16_TFLOPS if dtype == torch.float16 else PEAK_F32_TFLOPS
     ach = flops / sec / 1e12
-    # HBM traffic per launch from rocprofv3 PMC passes of this kernel at this shape (FETCH_SIZE x2 as
-    # the gfx950 correction prescribes + WRITE_SIZE; profiles/r01_alignconv_p3_pmc.txt) — a recorded
-    # measurement, not collected live; only valid for the f16 batch-8 shape it was taken on
-    traffic = 177.9e6 if (es == 2 and batch == 8) else None
+    # HBM traffic per launch: rocprofv3 PMC passes over this very command (FETCH_SIZE x2 as the gfx950
+    # correction prescribes + WRITE_SIZE, averaged over the k_dcn_patch launches; profiles/r01_alignconv_pyramid_pmc.txt)
+    # -- a recorded measurement, not collected live; valid for the default f16 batch-8 pyramid launch only
+    traffic = ALIGN_PYRAMID_TRAFFIC if (cap is not None and es == 2 and batch == 8 and npos == 8 * 21824) else None
     return {
-        "kernel": "%s (fused AlignConv: anchors -> sampling -> 3x3 contraction -> ReLU; P3 128x128, batch %d, %s)"
-                  % ("k_dcn_patch" if es == 2 else "k_dcn_mfma", batch, "f16" if es == 2 else "f32"),
+        "kernel": "%s (fused AlignConv: anchors -> sampling -> 3x3 contraction -> ReLU; %s, batch %d, %s)"
+                  % (kname, shape, batch, "f16" if es == 2 else "f32"),
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(ach / peak, 4), "traffic": traffic,
         "avg_launch_us": round(sec * 1e6, 1),
@@ -129,30 +160,17 @@ def measure_alignconv(model, batch, dtype, iters=30):
     }
 
 
-def measure_conv_tower(batch, iters=30):
-    """the kernel that takes the most time per step once the head towers run on it: the patch-staged
-    3x3 convolution (256 -> 256, P3, bias + ReLU fused).  Same event timing as measure_alignconv."""
-    from s2anet_amd.fused import conv_f16, conv_pack_weight
-    dev = torch.device("cuda", torch.cuda.current_device())
-    g = torch.Generator(device="cpu").manual_seed(1234)
-    H = W = CHIP // 8
-    x = torch.randn(batch, 256, H, W, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev, torch.float16)
-    b = torch.randn(256, generator=g).to(dev, torch.float16)
-    wp = conv_pack_weight(w)
-    for _ in range(3):
-        conv_f16(x, wp, b, 256, 3, 1, True)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        conv_f16(x, wp, b, 256, 3, 1, True)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    flops = 2.0 * 256 * 2304 * batch * H * W
+def measure_conv_tower(model, cap, iters=30):
+    """the kernel with the largest share of the step: the patch-staged 3x3 convolution of the head towers
+    (256 -> 256 + bias + ReLU), as the step issues it -- one pyramid-packed launch on the step's FPN features"""
+    from s2anet_amd import pyramid as P
+    layout, x = cap["layout"], cap["x"]
+    w, b, o = model.head.fam_reg_ls[0][0].packed_args()
+    sec = _time_launches(lambda: P.conv3x3(layout, x, w, b, o, relu=True), iters)
+    flops = 2.0 * 256 * 2304 * layout.pixels
     ach = flops / sec / 1e12
-    return {"kernel": "k_conv_f16<9,4> (head conv tower 3x3 256->256 + bias + ReLU, P3 128x128, batch %d, f16)" % batch,
+    return {"kernel": "k_conv_f16<9,4> (head conv tower 3x3 256->256 + bias + ReLU; five FPN levels pyramid-packed, "
+                      "%d positions, f16)" % layout.pixels,
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(sec * 1e6, 1),
             "flops_per_launch": flops}
@@ -323,9 +341,10 @@ def main():
         },
     }
     if rank == 0:
-        result["roofline"] = measure_alignconv(model, B, dtype)
-        if dtype == torch.float16:
-            result["roofline_conv_tower"] = measure_conv_tower(B)
+        cap = capture_head_operands(model, imgs)
+        result["roofline"] = measure_alignconv(model, B, dtype, cap)
+        if cap is not None:
+            result["roofline_conv_tower"] = measure_conv_tower(model, cap)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(1234, args.candidates)

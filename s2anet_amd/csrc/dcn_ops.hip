@@ -1775,7 +1775,8 @@ extern "C" int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, c
                 ((uintptr_t)bias % 8) == 0 && ((uintptr_t)residual % 16) == 0, "conv_pyramid: tensors must be 16-byte aligned");
   if (lt.n == 1) lt.n = 2, lt.tile0[1] = 0x7fffffff;   // keep the rebind path (n > 1) for a one-level table
   hipStream_t st = as_stream(stream);
-  const int og = out_channels % 256 == 0 ? 4 : (out_channels % 128 == 0 ? 2 : 1);
+  int og = out_channels % 256 == 0 ? 4 : (out_channels % 128 == 0 ? 2 : 1);
+  if (const char* f = getenv("S2A_CONV_OG")) og = std::min(og, std::max(1, atoi(f)));   // A/B switch for measurements
   const _Float16 *X = (const _Float16*)x, *Wf = (const _Float16*)weight_frag, *Bi = (const _Float16*)bias,
                  *R = (const _Float16*)residual;
   _Float16* Y = (_Float16*)out;

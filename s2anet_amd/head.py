@@ -147,6 +147,8 @@ class S2ANetHead(nn.Module):
             w, b, o = self.fam_cls_head.packed_args()
             fam_cls = P.conv1x1(tower(self.fam_cls_ls, x), w, b, o, relu=False)
         anchors = P.fam_refine_anchors(layout, fam_bbox, self.anchor_scale)                 # [P,5] f32
+        if getattr(self, "capture", None) is not None:      # bench.py: the operands of this step's launches
+            self.capture.update(layout=layout, x=x, anchors=anchors)
         al = P.align_conv(layout, x, anchors, self.align_conv.packed_weight(torch.float16), self.feat_channels)
         wa = self.or_conv.rotate_arf()
         if not hasattr(self.or_conv, "_packed"):
