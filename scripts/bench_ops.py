@@ -84,6 +84,29 @@ def nms(n, nl=15):
     return dict(op="ml_nms_rotated", n=n, labels=nl, ms=round(sec*1e3, 3), keep=int(k.numel()),
                 same_label_pairs=pairs, Gpairs_s=round(pairs/sec/1e9, 2))
 
+def poly_ops(n_nms=20000, n_pairs=2000000):
+    """chip-merge polygon NMS (py_cpu_nms_poly_fast) and pairwise polyiou on the GPU, with the oracle's CPU
+    restatement (pinned bit-exact to the reference script / SWIG module) timed beside them on small samples"""
+    import oracle
+    rng = np.random.default_rng(77)
+    res = []
+    polys = oracle.rboxes_to_polys(rboxes(rng, n_nms, span=2048.0))
+    dets = np.concatenate([polys, ((rng.permutation(n_nms) + 1.0) / (n_nms + 1.0))[:, None]], 1)
+    d = torch.from_numpy(dets).to(dev)
+    from s2anet_amd.rotated import nms_poly, polyiou_pairs
+    keep = nms_poly(d, 0.3)
+    sec = timeit(lambda: nms_poly(d, 0.3), iters=10)
+    ns = 4000
+    t0 = time.perf_counter(); kc = oracle.nms_poly(dets[:ns], 0.3); tc = time.perf_counter() - t0
+    res.append(dict(op="nms_poly (chip merge)", n=n_nms, ms=round(sec * 1e3, 3), keep=int(keep.numel()),
+                    cpu_port_s_at_n4000=round(tc, 3), cpu_keep_at_n4000=int(len(kc))))
+    a = torch.from_numpy(oracle.rboxes_to_polys(rboxes(rng, n_pairs, span=300.0))).to(dev)
+    b = torch.from_numpy(oracle.rboxes_to_polys(rboxes(rng, n_pairs, span=300.0))).to(dev)
+    sec = timeit(lambda: polyiou_pairs(a, b), iters=10)
+    res.append(dict(op="polyiou pairs (f64)", pairs=n_pairs, ms=round(sec * 1e3, 3), Mpairs_s=round(n_pairs / sec / 1e6, 1)))
+    return res
+
+
 def cpu_baselines():
     """the reference's own CPU ops (oracle/_ref, built from /root/reference unmodified) timed on this
     box's host cores, single thread as the reference loops are serial; bounded samples"""
@@ -153,6 +176,8 @@ if __name__ == "__main__":
             res.append(alignconv(8, torch.float16, sigma=sg))
     if a.which in ("all", "iou"):
         res.append(iou(10000, 10000)); res.append(iou(21824, 128))
+    if a.which in ("all", "poly"):
+        res += poly_ops()
     if a.which == "nms200k":
         res.append(nms(200000))
     if a.which in ("all", "nms"):
