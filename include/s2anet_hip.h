@@ -247,6 +247,21 @@ int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const void* bias, 
                       void* out, int64_t batch, int64_t channels, int64_t height, int64_t width,
                       int64_t out_channels, int ksize, int stride, int relu, s2a_stream_t stream);
 
+/* Training side of the deformable convolution: the three device functions the reference's
+ * backward is composed of (models/dcn/src/deform_conv_cuda_kernel.cu): deformable_im2col (:244-276),
+ * deformable_col2im (:332-370), deformable_col2im_coord (:431-464).  p->batch = the number of images of
+ * the chunk (the reference's im2col_step / parallel_imgs); layouts as the reference: im [S,C,H,W],
+ * offset [S, dg*2*kH*kW, Ho, Wo] (same dtype as im), columns [C*kH*kW, S*Ho*Wo]; NCHW only.
+ * s2a_deformable_col2im ACCUMULATES into grad_im_f32 [S,C,H,W] (always f32; caller zeroes it, as
+ * deform_conv.py:88-90 does); s2a_deformable_col2im_coord overwrites grad_offset.  The GEMMs around
+ * them (deform_conv_cuda.cpp:323-324, :455-459 addmm_) are library GEMMs on the host side. */
+int s2a_deformable_im2col(const void* im, const void* offset, void* columns, const s2a_dcn_params* p,
+                          s2a_stream_t stream);
+int s2a_deformable_col2im(const void* columns, const void* offset, float* grad_im_f32,
+                          const s2a_dcn_params* p, s2a_stream_t stream);
+int s2a_deformable_col2im_coord(const void* columns, const void* im, const void* offset, void* grad_offset,
+                                const s2a_dcn_params* p, s2a_stream_t stream);
+
 /* FPN top-down step in one launch (models/neck.py:67-79): out[B,H,W,O] = conv1x1(x[B,H,W,C]) + bias +
  * nearest-2x-upsample(coarse[B,H/2,W/2,O]); f16 channels-last, H and W even, C and O multiples of 64. */
 int s2a_conv1x1_add_up2_f16(const void* x, const void* weight_frag, const void* bias, const void* coarse,

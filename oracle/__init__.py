@@ -71,6 +71,9 @@ def lib():
         L.orc_arf_backward.argtypes = [f32p, u8p, i64, i64, ci, ci, ci, ci, f32p]
         L.orc_rot_inv_pool.restype = None
         L.orc_rot_inv_pool.argtypes = [f32p, i64, i64, i64, ci, f32p]
+        L.orc_deform_conv_backward.restype = None
+        L.orc_deform_conv_backward.argtypes = [f32p, f32p, f32p, f32p, i64, i64, i64, i64, i64] + [ctypes.c_int] * 9 + \
+            [f32p, f32p, f32p]
         L.orc_deform_conv_forward.restype = None
         L.orc_deform_conv_forward.argtypes = [f32p, f32p, f32p, i64, i64, i64, i64, i64,
                                               ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, f32p]
@@ -247,6 +250,20 @@ def delta2bbox_rotated(rois, deltas, wh_ratio_clip=16 / 1000):
     gh = r[:, 3] * np.exp(dh)
     ga = norm_angle(np.float32(np.pi) * d[:, 4] + r[:, 4])
     return np.stack([gx, gy, gw, gh, ga], -1).astype(np.float32)
+
+
+def deform_conv_backward(x, offset, weight, grad_out, stride=(1, 1), padding=(1, 1), dilation=(1, 1),
+                         deformable_groups=1):
+    """deform_conv_backward_input_cuda + _parameters_cuda restated (groups = 1):
+    -> (grad_input, grad_offset, grad_weight), float32"""
+    x, offset, weight, grad_out = _f32(x), _f32(offset), _f32(weight), _f32(grad_out)
+    B, C, H, W = x.shape
+    O, _, kH, kW = weight.shape
+    gx, goff, gw = np.zeros_like(x), np.zeros_like(offset), np.zeros_like(weight)
+    lib().orc_deform_conv_backward(_p(x), _p(offset), _p(weight), _p(grad_out), B, C, H, W, O, kH, kW,
+                                   stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                   deformable_groups, _p(gx), _p(goff), _p(gw))
+    return gx, goff, gw
 
 
 def align_offsets(anchors, feat_h, feat_w, stride, k=3):

@@ -427,6 +427,97 @@ int64_t orc_nms_poly(const double* dets, int64_t n, double thresh, int64_t* keep
   return k;
 }
 
+// ----- deformable convolution, backward (training side) ----------------------------
+// Restates deform_conv_backward_input_cuda / _parameters_cuda (models/dcn/src/deform_conv_cuda.cpp:262-489)
+// with the device functions of deform_conv_cuda_kernel.cu: columns = W^T x gradOutput; gradOffset by
+// get_coordinate_weight (:144-187, :372-429); gradInput by get_gradient_weight (:116-142, :278-330);
+// gradWeight = gradOutput x im2col^T.  NCHW, groups = 1, deformable_groups = dg.  Coordinates and
+// bilinear terms in float as the kernels; the two reductions accumulate in double.
+static inline float orc_grad_weight(float ah, float aw, int h, int w, int H, int W) {
+  if (ah <= -1 || ah >= H || aw <= -1 || aw >= W) return 0.f;
+  int hl = (int)std::floor(ah), wl = (int)std::floor(aw), hh = hl + 1, wh = wl + 1;
+  float weight = 0.f;
+  if (h == hl && w == wl) weight = (h + 1 - ah) * (w + 1 - aw);
+  if (h == hl && w == wh) weight = (h + 1 - ah) * (aw + 1 - w);
+  if (h == hh && w == wl) weight = (ah + 1 - h) * (w + 1 - aw);
+  if (h == hh && w == wh) weight = (ah + 1 - h) * (aw + 1 - w);
+  return weight;
+}
+static inline float orc_coord_weight(float ah, float aw, int H, int W, const float* im, int dir) {
+  if (ah <= -1 || ah >= H || aw <= -1 || aw >= W) return 0.f;
+  int hl = (int)std::floor(ah), wl = (int)std::floor(aw), hh = hl + 1, wh = wl + 1;
+  float weight = 0.f;
+  if (dir == 0) {
+    if (hl >= 0 && wl >= 0) weight += -1 * (wl + 1 - aw) * im[hl * W + wl];
+    if (hl >= 0 && wh <= W - 1) weight += -1 * (aw - wl) * im[hl * W + wh];
+    if (hh <= H - 1 && wl >= 0) weight += (wl + 1 - aw) * im[hh * W + wl];
+    if (hh <= H - 1 && wh <= W - 1) weight += (aw - wl) * im[hh * W + wh];
+  } else {
+    if (hl >= 0 && wl >= 0) weight += -1 * (hl + 1 - ah) * im[hl * W + wl];
+    if (hl >= 0 && wh <= W - 1) weight += (hl + 1 - ah) * im[hl * W + wh];
+    if (hh <= H - 1 && wl >= 0) weight += -1 * (ah - hl) * im[hh * W + wl];
+    if (hh <= H - 1 && wh <= W - 1) weight += (ah - hl) * im[hh * W + wh];
+  }
+  return weight;
+}
+static inline float orc_bilinear(const float* im, int H, int W, float h, float w) {
+  int hl = (int)std::floor(h), wl = (int)std::floor(w), hh_ = hl + 1, wh = wl + 1;
+  float lh = h - hl, lw = w - wl, hh = 1 - lh, hw = 1 - lw;
+  float v1 = (hl >= 0 && wl >= 0) ? im[hl * W + wl] : 0.f;
+  float v2 = (hl >= 0 && wh <= W - 1) ? im[hl * W + wh] : 0.f;
+  float v3 = (hh_ <= H - 1 && wl >= 0) ? im[hh_ * W + wl] : 0.f;
+  float v4 = (hh_ <= H - 1 && wh <= W - 1) ? im[hh_ * W + wh] : 0.f;
+  return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+}
+void orc_deform_conv_backward(const float* x, const float* offset, const float* weight, const float* gout,
+                              int64_t B, int64_t C, int64_t H, int64_t W, int64_t O, int kh, int kw, int sh,
+                              int sw, int ph, int pw, int dh, int dw, int dg, float* gx, float* goff,
+                              float* gw) {
+  const int64_t Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1, Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  const int64_t K = kh * kw, HoWo = Ho * Wo, cpg = C / dg;
+  std::vector<double> gxd((size_t)(B * C * H * W), 0.0), gwd((size_t)(O * C * K), 0.0);
+  for (int64_t b = 0; b < B; b++)
+    for (int64_t ho = 0; ho < Ho; ho++)
+      for (int64_t wo = 0; wo < Wo; wo++) {
+        const int64_t p = ho * Wo + wo;
+        for (int64_t c = 0; c < C; c++) {
+          const int64_t dgi = c / cpg;
+          const float* im = x + (b * C + c) * H * W;
+          for (int i = 0; i < kh; i++)
+            for (int j = 0; j < kw; j++) {
+              const int t = i * kw + j;
+              const float* offp = offset + ((b * dg + dgi) * 2 * K) * HoWo + p;
+              const float oh = offp[(2 * t) * HoWo], ow = offp[(2 * t + 1) * HoWo];
+              const float h_im = (float)(ho * sh - ph + i * dh) + oh, w_im = (float)(wo * sw - pw + j * dw) + ow;
+              // column value of the backward-input GEMM (float, as addmm_ stores it)
+              double cd = 0.0;
+              for (int64_t o = 0; o < O; o++) cd += (double)weight[(o * C + c) * K + t] * (double)gout[(b * O + o) * HoWo + p];
+              const float col = (float)cd;
+              // gradOffset (col2im_coord)
+              float ih = h_im, iw = w_im;
+              if (ih <= -1 || iw <= -1 || ih >= H || iw >= W) ih = iw = -2;
+              goff[((b * dg + dgi) * 2 * K + 2 * t) * HoWo + p] += orc_coord_weight(ih, iw, (int)H, (int)W, im, 0) * col;
+              goff[((b * dg + dgi) * 2 * K + 2 * t + 1) * HoWo + p] += orc_coord_weight(ih, iw, (int)H, (int)W, im, 1) * col;
+              // gradInput (col2im)
+              const int ch = (int)h_im, cw = (int)w_im;
+              for (int dy = -2; dy <= 2; dy++)
+                for (int dx = -2; dx <= 2; dx++) {
+                  const int y = ch + dy, xx = cw + dx;
+                  if (y >= 0 && y < H && xx >= 0 && xx < W && std::fabs(h_im - y) < 1 && std::fabs(w_im - xx) < 1)
+                    gxd[(size_t)(((b * C + c) * H + y) * W + xx)] += (double)(orc_grad_weight(h_im, w_im, y, xx, (int)H, (int)W) * col);
+                }
+              // gradWeight (im2col x gradOutput)
+              float val = 0.f;
+              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) val = orc_bilinear(im, (int)H, (int)W, h_im, w_im);
+              if (val != 0.f)
+                for (int64_t o = 0; o < O; o++) gwd[(size_t)((o * C + c) * K + t)] += (double)val * (double)gout[(b * O + o) * HoWo + p];
+            }
+        }
+      }
+  for (size_t i = 0; i < gxd.size(); i++) gx[i] = (float)gxd[i];
+  for (size_t i = 0; i < gwd.size(); i++) gw[i] = (float)gwd[i];
+}
+
 // ----- ORN: active rotating filter ------------------------------------------
 // ARF_forward (models/orn/src/cuda/ActiveRotatingFilter_cuda.cu:20-46, the
 // int-indexed GPU kernel; the CPU file's uint16 weightIndex wraps at 65536 and

@@ -6,8 +6,8 @@ PyTorch-ROCm without building any of its CUDA sources.
     import s2anet_amd.compat as compat; compat.install()
     sys.path.insert(0, "/path/to/S2ANet"); from models.head import S2ANetHead   # reference code
 
-Functions that are outside the inference hot path (backward, modulated DCN, PS-RoI pooling, RIE)
-exist so that imports succeed and raise NotImplementedError when called (SURVEY §8(f) "next").
+Functions the model never calls (modulated DCN, PS-RoI pooling, RIE) exist so that imports succeed and
+raise NotImplementedError when called.
 """
 import sys
 import types
@@ -30,9 +30,10 @@ def build_modules():
     m = {}
     d = types.ModuleType("models.dcn.deform_conv_cuda")
     d.deform_conv_forward_cuda = dcn.deform_conv_forward_cuda            # deform_conv_cuda.cpp:689-690
-    for n in ("deform_conv_backward_input_cuda", "deform_conv_backward_parameters_cuda",
-              "modulated_deform_conv_cuda_forward", "modulated_deform_conv_cuda_backward"):
-        setattr(d, n, _not_impl(n))                                       # :691-701
+    d.deform_conv_backward_input_cuda = dcn.deform_conv_backward_input_cuda            # :691-693
+    d.deform_conv_backward_parameters_cuda = dcn.deform_conv_backward_parameters_cuda  # :694-696
+    for n in ("modulated_deform_conv_cuda_forward", "modulated_deform_conv_cuda_backward"):
+        setattr(d, n, _not_impl(n))                                       # :697-701
     m[d.__name__] = d
     p = types.ModuleType("models.dcn.deform_pool_cuda")
     for n in ("deform_psroi_pooling_cuda_forward", "deform_psroi_pooling_cuda_backward"):

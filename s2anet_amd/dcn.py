@@ -75,6 +75,96 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
     return 1
 
 
+def _bwd_common(input, offset, gradOutput, weight_like, kW, kH, dW, dH, padW, padH, dilationW, dilationH,
+                group, deformable_group, im2col_step):
+    """shape_check + views shared by the two backward entry points (deform_conv_cuda.cpp:62-150)"""
+    _lib.require_cuda(input, offset, gradOutput, weight_like)
+    if input.dim() not in (3, 4):
+        raise RuntimeError("3D or 4D input tensor expected but got: %d" % input.dim())
+    if weight_like.dim() != 4 or weight_like.size(2) != kH or weight_like.size(3) != kW:
+        raise RuntimeError("kernel size should be consistent with weight")
+    x = (input if input.dim() == 4 else input.unsqueeze(0)).contiguous()
+    off = (offset if offset.dim() == 4 else offset.unsqueeze(0)).to(x.dtype).contiguous()
+    go = (gradOutput if gradOutput.dim() == 4 else gradOutput.unsqueeze(0)).to(x.dtype).contiguous()
+    B, C, H, W = x.shape
+    if weight_like.shape[1] * group != C:
+        raise RuntimeError("invalid number of input planes, expected: %d, but got: %d" % (weight_like.shape[1] * group, C))
+    Ho = (H + 2 * padH - (dilationH * (kH - 1) + 1)) // dH + 1
+    Wo = (W + 2 * padW - (dilationW * (kW - 1) + 1)) // dW + 1
+    if off.shape[0] != B:
+        raise RuntimeError("invalid batch size of offset")
+    if off.shape[1] != deformable_group * 2 * kH * kW:
+        raise RuntimeError("invalid number of channels of offset")
+    if tuple(off.shape[2:]) != (Ho, Wo):
+        raise RuntimeError("invalid spatial size of offset, expected height: %d width: %d, but got "
+                           "height: %d width: %d" % (Ho, Wo, off.shape[2], off.shape[3]))
+    O = weight_like.shape[0]
+    if tuple(go.shape) != (B, O, Ho, Wo):
+        raise RuntimeError("invalid size of gradOutput")
+    assert B % im2col_step == 0, "im2col step must divide batchsize"
+
+    def params(step):
+        return _lib.DcnParams(step, C, H, W, O, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                              deformable_group, _lib.dtype_code(x), _lib.dtype_code(x), _lib.LAYOUT_NCHW, 0)
+    return x, off, go, (B, C, H, W, O, Ho, Wo), params
+
+
+def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH,
+                                    dW, dH, padW, padH, dilationW, dilationH, group, deformable_group,
+                                    im2col_step):
+    """models/dcn/src/deform_conv_cuda.cpp:262-374, same positional signature.  gradInput (caller-zeroed,
+    deform_conv.py:88) and gradOffset are filled in place.  Per chunk of im2col_step images:
+    columns = weight^T x gradOutput (library GEMM, the reference's addmm_ :323), then
+    s2a_deformable_col2im_coord -> gradOffset and s2a_deformable_col2im -> gradInput.  Returns 1."""
+    x, off, go, (B, C, H, W, O, Ho, Wo), params = _bwd_common(
+        input, offset, gradOutput, weight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+        deformable_group, im2col_step)
+    w = weight.to(x.dtype).contiguous()
+    L = _lib.lib()
+    step, npos = im2col_step, im2col_step * Ho * Wo
+    p = params(step)
+    gin32 = torch.zeros((B, C, H, W), dtype=torch.float32, device=x.device)
+    goff = torch.empty_like(off)
+    wg = w.view(group, O // group, -1)                                  # [g, O/g, C/g*kh*kw]
+    with torch.cuda.device(x.device):
+        st = _lib.stream_ptr(x.device)
+        for e in range(B // step):
+            sl = slice(e * step, (e + 1) * step)
+            g_e = go[sl].transpose(0, 1).reshape(group, O // group, npos)   # [g, O/g, step*Ho*Wo]
+            cols = torch.bmm(wg.transpose(1, 2), g_e).reshape(C * kH * kW, npos).contiguous()
+            _lib.check(L.s2a_deformable_col2im_coord(_lib.ptr(cols), _lib.ptr(x[sl]), _lib.ptr(off[sl]),
+                                                     _lib.ptr(goff[sl]), p, st))
+            _lib.check(L.s2a_deformable_col2im(_lib.ptr(cols), _lib.ptr(off[sl]), _lib.ptr(gin32[sl]), p, st))
+    gradInput.view(B, C, H, W).add_(gin32.to(gradInput.dtype))          # accumulate, as the reference's atomics do
+    gradOffset.view_as(goff).copy_(goff)
+    return 1
+
+
+def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH,
+                                         padW, padH, dilationW, dilationH, group, deformable_group, scale,
+                                         im2col_step):
+    """models/dcn/src/deform_conv_cuda.cpp:376-489, same positional signature.  Per chunk:
+    columns = s2a_deformable_im2col(input, offset), gradWeight += scale * gradOutput x columns^T (library
+    GEMM, the reference's addmm_ :455-459).  gradWeight is accumulated in place.  Returns 1."""
+    x, off, go, (B, C, H, W, O, Ho, Wo), params = _bwd_common(
+        input, offset, gradOutput, gradWeight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+        deformable_group, im2col_step)
+    L = _lib.lib()
+    step, npos = im2col_step, im2col_step * Ho * Wo
+    p = params(step)
+    cols = torch.empty((C * kH * kW, npos), dtype=x.dtype, device=x.device)
+    acc = torch.zeros((group, O // group, (C // group) * kH * kW), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = _lib.stream_ptr(x.device)
+        for e in range(B // step):
+            sl = slice(e * step, (e + 1) * step)
+            _lib.check(L.s2a_deformable_im2col(_lib.ptr(x[sl]), _lib.ptr(off[sl]), _lib.ptr(cols), p, st))
+            g_e = go[sl].transpose(0, 1).reshape(group, O // group, npos)
+            acc += torch.bmm(g_e, cols.view(group, -1, npos).transpose(1, 2)).float()
+    gradWeight.add_((float(scale) * acc).view_as(gradWeight).to(gradWeight.dtype))
+    return 1
+
+
 class DeformConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1,
@@ -98,11 +188,33 @@ class DeformConvFunction(torch.autograd.Function):
         deform_conv_forward_cuda(input, weight, offset, output, None, None, kW, kH, stride[1],
                                  stride[0], padding[1], padding[0], dilation[1], dilation[0], groups,
                                  deformable_groups, cur_im2col_step)
+        ctx.save_for_backward(input, offset, weight)
+        ctx.conf = (stride, padding, dilation, groups, deformable_groups, im2col_step)
         return output
 
     @staticmethod
-    def backward(ctx, grad_output):  # pragma: no cover - training path, SURVEY 8(f) "next"
-        raise NotImplementedError("deform_conv backward is outside the inference hot path (SURVEY.md 8(f))")
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        """models/dcn/deform_conv.py:73-118"""
+        input, offset, weight = ctx.saved_tensors
+        stride, padding, dilation, groups, deformable_groups, im2col_step = ctx.conf
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        cur = min(im2col_step, input.shape[0])
+        assert (input.shape[0] % cur) == 0, "im2col step must divide batchsize"
+        grad_input = grad_offset = grad_weight = None
+        kH, kW = weight.shape[2], weight.shape[3]
+        args = (kW, kH, stride[1], stride[0], padding[1], padding[0], dilation[1], dilation[0], groups,
+                deformable_groups)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_input = torch.zeros_like(input, memory_format=torch.contiguous_format)
+            grad_offset = torch.zeros_like(offset, memory_format=torch.contiguous_format)
+            deform_conv_backward_input_cuda(input, offset, grad_output, grad_input, grad_offset, weight, None,
+                                            *args, cur)
+        if ctx.needs_input_grad[2]:
+            grad_weight = torch.zeros_like(weight)
+            deform_conv_backward_parameters_cuda(input, offset, grad_output, grad_weight, None, None, *args, 1, cur)
+        return grad_input, grad_offset, grad_weight, None, None, None, None, None, None
 
 
 deform_conv = DeformConvFunction.apply

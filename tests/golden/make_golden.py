@@ -258,6 +258,27 @@ def gen_dcn(rng):
                         offset=off.numpy(), out_torch=out.numpy())
 
 
+def gen_dcn_backward():
+    """gradients of the deformable convolution: autograd through the independent torch formulation
+    (torch_deform_conv; floor() has zero gradient, so d/d(offset) is the derivative of the bilinear
+    interpolation the reference's get_coordinate_weight computes) -- no runnable reference exists"""
+    g = torch.Generator().manual_seed(4242)
+    B, C, H, W, O = 2, 12, 8, 10, 6
+    x = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    wgt = (torch.randn(O, C, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    off = torch.randn(B, 18, H, W, generator=g) * 1.5
+    off[0, :, 0, 0] = 40.0       # far outside: zero gradients
+    off[1, :, 2, 3] = -0.75      # inside the (-1, ...) border band: some corners dropped
+    off = off.requires_grad_(True)
+    gout = torch.randn(B, O, H, W, generator=g)
+    out = torch_deform_conv(x, off, wgt)
+    out.backward(gout)
+    np.savez_compressed(os.path.join(OUT, "dcn_backward_small.npz"), x=x.detach().numpy(), weight=wgt.detach().numpy(),
+                        offset=off.detach().numpy(), grad_out=gout.numpy(), grad_input=x.grad.numpy(),
+                        grad_offset=off.grad.numpy(), grad_weight=wgt.grad.numpy())
+    print("dcn backward golden:", float(x.grad.abs().max()), float(off.grad.abs().max()), float(wgt.grad.abs().max()))
+
+
 def torch_deform_conv(x, off, wgt, pad=1):
     B, C, H, W = x.shape
     O, _, kH, kW = wgt.shape
@@ -297,4 +318,5 @@ if __name__ == "__main__":
     gen_glue(rng)
     gen_arf_backward()
     gen_merge_nms()
+    gen_dcn_backward()
     print("done ->", OUT)

@@ -17,8 +17,14 @@ def test_alias_modules_have_reference_names():
     assert list(sig.parameters)[:17] == ["input", "weight", "offset", "output", "columns", "ones", "kW", "kH",
                                          "dW", "dH", "padW", "padH", "dilationW", "dilationH", "group",
                                          "deformable_group", "im2col_step"]
-    for n in ("deform_conv_backward_input_cuda", "deform_conv_backward_parameters_cuda",
-              "modulated_deform_conv_cuda_forward", "modulated_deform_conv_cuda_backward"):
+    # backward entry points carry the pybind signatures (deform_conv_cuda.cpp:262-268, :376-381)
+    assert list(inspect.signature(d.deform_conv_backward_input_cuda).parameters) == [
+        "input", "offset", "gradOutput", "gradInput", "gradOffset", "weight", "columns", "kW", "kH", "dW", "dH",
+        "padW", "padH", "dilationW", "dilationH", "group", "deformable_group", "im2col_step"]
+    assert list(inspect.signature(d.deform_conv_backward_parameters_cuda).parameters) == [
+        "input", "offset", "gradOutput", "gradWeight", "columns", "ones", "kW", "kH", "dW", "dH", "padW", "padH",
+        "dilationW", "dilationH", "group", "deformable_group", "scale", "im2col_step"]
+    for n in ("modulated_deform_conv_cuda_forward", "modulated_deform_conv_cuda_backward"):
         with pytest.raises(NotImplementedError):
             getattr(d, n)()
     assert callable(mods["models.orn.orn_cuda"].arf_forward) and callable(mods["models.orn.orn_cuda"].arf_backward)

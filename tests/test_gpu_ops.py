@@ -614,3 +614,38 @@ def test_fpn_topdown_step_fused():
         got = conv1x1_add_up2(x, wp, b, coarse, O)
         ref = conv_f16(x, wp, b, O, 1, 1, False) + torch.nn.functional.interpolate(coarse, scale_factor=2, mode="nearest")
         assert torch.equal(got, ref)
+
+
+def test_dcn_backward_vs_oracle_and_golden(rng):
+    """deform_conv backward (three HIP kernels + library GEMMs, autograd wiring) against the golden autograd
+    values, the oracle on a second shape (stride/dilation/deformable groups), and the pybind-shaped entry points"""
+    import s2anet_amd as S
+    from s2anet_amd.dcn import deform_conv, deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda
+    g = golden("dcn_backward_small.npz")
+    x, off, w = (cu(g[k]).requires_grad_(True) for k in ("x", "offset", "weight"))
+    out = deform_conv(x, off, w, 1, 1, 1, 1, 1)
+    out.backward(cu(g["grad_out"]))
+    for got, ref in ((x.grad, g["grad_input"]), (off.grad, g["grad_offset"]), (w.grad, g["grad_weight"])):
+        assert np.abs(got.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    # general geometry: stride 2, dilation 2, two deformable groups, im2col_step < batch
+    B, C, H, W, O, dg = 4, 8, 11, 13, 6, 2
+    st, pd, dl = (2, 1), (2, 1), (2, 1)
+    Ho = (H + 2 * pd[0] - (dl[0] * 2 + 1)) // st[0] + 1
+    Wo = (W + 2 * pd[1] - (dl[1] * 2 + 1)) // st[1] + 1
+    xn = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    wn = (rng.standard_normal((O, C, 3, 3)) * 0.2).astype(np.float32)
+    on = (rng.standard_normal((B, dg * 18, Ho, Wo)) * 1.5).astype(np.float32)
+    gn = rng.standard_normal((B, O, Ho, Wo)).astype(np.float32)
+    gx, goff, gw = oracle.deform_conv_backward(xn, on, wn, gn, st, pd, dl, dg)
+    gi, go_ = torch.zeros(B, C, H, W, device=dev()), torch.zeros(B, dg * 18, Ho, Wo, device=dev())
+    args = (3, 3, st[1], st[0], pd[1], pd[0], dl[1], dl[0], 1, dg)
+    assert deform_conv_backward_input_cuda(cu(xn), cu(on), cu(gn), gi, go_, cu(wn), None, *args, 2) == 1
+    gwt = torch.zeros(O, C, 3, 3, device=dev())
+    assert deform_conv_backward_parameters_cuda(cu(xn), cu(on), cu(gn), gwt, None, None, *args, 1.0, 2) == 1
+    for got, ref in ((gi, gx), (go_, goff), (gwt, gw)):
+        assert np.abs(got.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    # f16 storage (columns and GEMMs in half as the reference's half path): loose tolerance
+    xh, oh, wh = (cu(g[k]).half().requires_grad_(True) for k in ("x", "offset", "weight"))
+    deform_conv(xh, oh, wh, 1, 1, 1, 1, 1).backward(cu(g["grad_out"]).half())
+    for got, ref in ((xh.grad, g["grad_input"]), (oh.grad, g["grad_offset"]), (wh.grad, g["grad_weight"])):
+        assert np.abs(got.float().cpu().numpy() - ref).max() < 3e-2 * max(1.0, np.abs(ref).max())

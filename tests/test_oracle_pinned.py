@@ -116,6 +116,14 @@ def test_arf_backward_matches_reference():
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
 
 
+def test_dcn_backward_oracle_matches_autograd_of_independent_formulation():
+    """parity unpinned against the reference itself (CUDA only); pinned to autograd of the torch formulation"""
+    g = golden("dcn_backward_small.npz")
+    gx, goff, gw = oracle.deform_conv_backward(g["x"], g["offset"], g["weight"], g["grad_out"])
+    for got, ref in ((gx, g["grad_input"]), (goff, g["grad_offset"]), (gw, g["grad_weight"])):
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
 def test_merge_nms_poly_matches_reference_script():
     g = golden("merge_nms_poly.npz")
     for thr in (0.1, 0.5):
