@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -105,6 +106,69 @@ __global__ void k_def_col2im(int64_t n, const T* __restrict__ col, const T* __re
           atomicAdd(grad_im + (((int64_t)s * g.C + c) * g.H + y) * g.W + x, wgt * top);
         }
       }
+  }
+}
+
+// The same scatter for the AlignConv geometry (3x3, stride 1, dilation 1): one workgroup = an 8 x 32 tile of
+// output positions x 8 channels.  Its contributions land in a (8+2+2*6) x (32+2+2*6) window around the tile:
+// they are summed in an LDS copy of that window (ds_add_f32) and the window is flushed once (one global
+// atomic per touched cell instead of one per tap and corner: ~9x fewer, row-contiguous); samples that leave
+// the window go straight to memory.  The four bilinear corners are addressed directly -- the reference's
+// 5 x 5 search (:321-337) visits exactly the cells with |dy| < 1, |dx| < 1, i.e. these four.
+constexpr int kC2TH = 8, kC2TW = 32, kC2Halo = 6, kC2Ch = 8;
+constexpr int kC2PH = kC2TH + 2 + 2 * kC2Halo, kC2PW = kC2TW + 2 + 2 * kC2Halo;   // 22 x 46
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_def_col2im_tiled(const T* __restrict__ col, const T* __restrict__ offset,
+                                                          BwdGeom g, float* __restrict__ grad_im) {
+  __shared__ float s_patch[kC2Ch][kC2PH * kC2PW];
+  const int tid = threadIdx.x;
+  const int txn = (g.Wo + kC2TW - 1) / kC2TW, tyn = (g.Ho + kC2TH - 1) / kC2TH;
+  int t = blockIdx.x;
+  const int tx = t % txn;
+  t /= txn;
+  const int ty = t % tyn, s = t / tyn;
+  const int c0 = blockIdx.y * kC2Ch;
+  const int h_out = ty * kC2TH + tid / kC2TW, w_out = tx * kC2TW + tid % kC2TW;
+  const int oy = ty * kC2TH - g.pad_h - kC2Halo, ox = tx * kC2TW - g.pad_w - kC2Halo;   // window origin (input coords)
+  for (int i = tid; i < kC2Ch * kC2PH * kC2PW; i += 256) (&s_patch[0][0])[i] = 0.f;
+  __syncthreads();
+  const int64_t HoWo = (int64_t)g.Ho * g.Wo;
+  const bool live = h_out < g.Ho && w_out < g.Wo;
+  if (live) {
+    const int dgi = c0 / (g.C / g.dg);          // the 8 channels share a deformable group (C/dg % 8 == 0, host check)
+    const T* offp = offset + ((int64_t)s * g.dg + dgi) * 18 * HoWo + (int64_t)h_out * g.Wo + w_out;
+    for (int tap = 0; tap < 9; tap++) {
+      const float ch = h_out - g.pad_h + tap / 3 + (float)offp[(int64_t)(2 * tap) * HoWo];
+      const float cw = w_out - g.pad_w + tap % 3 + (float)offp[(int64_t)(2 * tap + 1) * HoWo];
+      if (ch <= -1 || ch >= g.H || cw <= -1 || cw >= g.W) continue;      // get_gradient_weight: empty
+      const int hl = (int)floorf(ch), wl = (int)floorf(cw);
+      const float lh = ch - hl, lw = cw - wl;
+      const float wgt[4] = {(1 - lh) * (1 - lw), (1 - lh) * lw, lh * (1 - lw), lh * lw};
+      for (int cc = 0; cc < kC2Ch; cc++) {
+        const int c = c0 + cc;
+        if (c >= g.C) break;
+        const float top = (float)col[(((int64_t)c * 9 + tap) * g.S + s) * HoWo + (int64_t)h_out * g.Wo + w_out];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int y = hl + (k >> 1), x = wl + (k & 1);
+          if (y < 0 || y >= g.H || x < 0 || x >= g.W || wgt[k] == 0.f) continue;
+          const int py = y - oy, px = x - ox;
+          if (py >= 0 && py < kC2PH && px >= 0 && px < kC2PW)
+            atomicAdd(&s_patch[cc][py * kC2PW + px], wgt[k] * top);
+          else
+            atomicAdd(grad_im + (((int64_t)s * g.C + c) * g.H + y) * g.W + x, wgt[k] * top);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < kC2Ch * kC2PH * kC2PW; i += 256) {
+    const int cc = i / (kC2PH * kC2PW), r = i % (kC2PH * kC2PW);
+    const float v = s_patch[cc][r];
+    const int y = oy + r / kC2PW, x = ox + r % kC2PW, c = c0 + cc;
+    if (v != 0.f && c < g.C && y >= 0 && y < g.H && x >= 0 && x < g.W)
+      atomicAdd(grad_im + (((int64_t)s * g.C + c) * g.H + y) * g.W + x, v);
   }
 }
 
@@ -214,7 +278,16 @@ extern "C" int s2a_deformable_col2im(const void* columns, const void* offset, fl
   if (n == 0) return S2A_OK;
   S2A_CHECK_ARG(columns && offset && grad_im_f32, "deformable_col2im: NULL tensor");
   hipStream_t st = as_stream(stream);
-  if (p->dtype == S2A_DTYPE_F32)
+  const bool tiled = g.kh == 3 && g.kw == 3 && g.stride_h == 1 && g.stride_w == 1 && g.dil_h == 1 && g.dil_w == 1 &&
+                     (g.C / g.dg) % kC2Ch == 0 && !getenv("S2A_COL2IM_SIMPLE");
+  if (tiled) {
+    dim3 grid((unsigned)((int64_t)g.S * ((g.Ho + kC2TH - 1) / kC2TH) * ((g.Wo + kC2TW - 1) / kC2TW)),
+              (unsigned)((g.C + kC2Ch - 1) / kC2Ch));
+    if (p->dtype == S2A_DTYPE_F32)
+      k_def_col2im_tiled<float><<<grid, 256, 0, st>>>((const float*)columns, (const float*)offset, g, grad_im_f32);
+    else
+      k_def_col2im_tiled<_Float16><<<grid, 256, 0, st>>>((const _Float16*)columns, (const _Float16*)offset, g, grad_im_f32);
+  } else if (p->dtype == S2A_DTYPE_F32)
     k_def_col2im<float><<<grid_for(n), 256, 0, st>>>(n, (const float*)columns, (const float*)offset, g, grad_im_f32);
   else
     k_def_col2im<_Float16><<<grid_for(n), 256, 0, st>>>(n, (const _Float16*)columns, (const _Float16*)offset, g, grad_im_f32);

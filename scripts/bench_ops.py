@@ -107,6 +107,25 @@ def poly_ops(n_nms=20000, n_pairs=2000000):
     return res
 
 
+def dcn_backward(batch=8, H=128, W=128, C=256, O=256, dtype=torch.float32):
+    """deform_conv backward (input + offset + weight gradients) at the P3 AlignConv shape"""
+    from s2anet_amd.dcn import deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(batch, C, H, W, generator=g).to(dev, dtype)
+    off = (torch.randn(batch, 18, H, W, generator=g) * 2).to(dev, dtype)
+    w = (torch.randn(O, C, 3, 3, generator=g) * 0.01).to(dev, dtype)
+    go = torch.randn(batch, O, H, W, generator=g).to(dev, dtype)
+    gi, goff, gw = torch.zeros_like(x), torch.zeros_like(off), torch.zeros_like(w)
+    args = (3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+    step = min(64, batch)
+    t_in = timeit(lambda: deform_conv_backward_input_cuda(x, off, go, gi, goff, w, None, *args, step), iters=5, warm=2)
+    t_w = timeit(lambda: deform_conv_backward_parameters_cuda(x, off, go, gw, None, None, *args, 1.0, step), iters=5, warm=2)
+    flops = 2.0 * O * C * 9 * batch * H * W
+    return dict(op="deform_conv backward", dtype=str(dtype).split(".")[-1], batch=batch, hw=[H, W],
+                input_offset_ms=round(t_in * 1e3, 3), weight_ms=round(t_w * 1e3, 3),
+                gemm_tflops_each=round(flops / 1e12, 3), note="columns materialised per chunk as the reference does")
+
+
 def cpu_baselines():
     """the reference's own CPU ops (oracle/_ref, built from /root/reference unmodified) timed on this
     box's host cores, single thread as the reference loops are serial; bounded samples"""
@@ -176,6 +195,8 @@ if __name__ == "__main__":
             res.append(alignconv(8, torch.float16, sigma=sg))
     if a.which in ("all", "iou"):
         res.append(iou(10000, 10000)); res.append(iou(21824, 128))
+    if a.which in ("all", "bwd"):
+        res.append(dcn_backward(8, dtype=torch.float32)); res.append(dcn_backward(8, dtype=torch.float16))
     if a.which in ("all", "poly"):
         res += poly_ops()
     if a.which == "nms200k":

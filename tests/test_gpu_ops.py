@@ -644,6 +644,18 @@ def test_dcn_backward_vs_oracle_and_golden(rng):
     assert deform_conv_backward_parameters_cuda(cu(xn), cu(on), cu(gn), gwt, None, None, *args, 1.0, 2) == 1
     for got, ref in ((gi, gx), (go_, goff), (gwt, gw)):
         assert np.abs(got.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    # AlignConv geometry with channel counts the LDS-accumulating col2im takes (3x3, stride 1, C % 8 == 0),
+    # offsets large enough that some samples leave the tile's window (global-atomic path)
+    B, C, H, W, O = 2, 16, 19, 45, 8
+    xn = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    wn = (rng.standard_normal((O, C, 3, 3)) * 0.2).astype(np.float32)
+    on = (rng.standard_normal((B, 18, H, W)) * 4.0).astype(np.float32)
+    gn = rng.standard_normal((B, O, H, W)).astype(np.float32)
+    gx, goff, gw = oracle.deform_conv_backward(xn, on, wn, gn)
+    gi, go_ = torch.zeros(B, C, H, W, device=dev()), torch.zeros(B, 18, H, W, device=dev())
+    assert deform_conv_backward_input_cuda(cu(xn), cu(on), cu(gn), gi, go_, cu(wn), None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 2) == 1
+    for got, ref in ((gi, gx), (go_, goff)):
+        assert np.abs(got.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
     # f16 storage (columns and GEMMs in half as the reference's half path): loose tolerance
     xh, oh, wh = (cu(g[k]).half().requires_grad_(True) for k in ("x", "offset", "weight"))
     deform_conv(xh, oh, wh, 1, 1, 1, 1, 1).backward(cu(g["grad_out"]).half())
