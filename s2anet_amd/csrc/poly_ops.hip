@@ -200,13 +200,78 @@ __global__ void k_poly_prep(const double* __restrict__ dets9, const int32_t* __r
   sorted[p] = b;
 }
 
-#define P(i) p[(i) * 64]
-#define T(i) tmp[(i) * 64]
-// 64 threads = the 64 rows of a tile; each walks the 64 columns of the tile
-__global__ __launch_bounds__(64) void k_poly_mask(const PolyBox* __restrict__ sorted, int64_t n, double thresh,
-                                                  unsigned long long* __restrict__ mask) {
+// Fast path (thresh >= 0): only pairs whose axis-aligned boxes overlap can suppress (hbb_ovr == 0 <= thresh
+// otherwise, :87-115), and on DOTA-like data they are a tiny fraction of n^2/2.  k_poly_cull walks the upper
+// triangle with the HBB test alone (inter > 0  <=>  hbb_ovr > 0: the union term is >= 1) and compacts the hits
+// into a dense pair list (wave ballot + one atomic per hit group); k_poly_heavy then runs polyiou with every
+// lane busy and ORs the suppression bits into the (zeroed) mask.  A full pair list falls back to k_poly_mask.
+__global__ __launch_bounds__(64) void k_poly_cull(const PolyBox* __restrict__ sorted, int64_t n,
+                                                  uint2* __restrict__ pairs, unsigned long long* __restrict__ count,
+                                                  unsigned long long cap) {
   const uint32_t rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;
+  __shared__ double s_hbb[64][4];
+  const int64_t j0 = (int64_t)cb * 64;
+  if (j0 + threadIdx.x < n) {
+    const PolyBox& b = sorted[j0 + threadIdx.x];
+    s_hbb[threadIdx.x][0] = b.x1; s_hbb[threadIdx.x][1] = b.y1; s_hbb[threadIdx.x][2] = b.x2; s_hbb[threadIdx.x][3] = b.y2;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)rb * 64 + threadIdx.x;
+  double ax1 = 0, ay1 = 0, ax2 = -1, ay2 = -1;
+  if (i < n) { const PolyBox& a = sorted[i]; ax1 = a.x1; ay1 = a.y1; ax2 = a.x2; ay2 = a.y2; }
+  const unsigned lane = threadIdx.x;
+  for (int c = 0; c < 64; c++) {
+    const int64_t j = j0 + c;
+    bool hit = false;
+    if (i < n && j < n && j > i) {
+      const double w = fmax(0.0, fmin(ax2, s_hbb[c][2]) - fmax(ax1, s_hbb[c][0]));
+      const double h = fmax(0.0, fmin(ay2, s_hbb[c][3]) - fmax(ay1, s_hbb[c][1]));
+      hit = w * h > 0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m == 0) continue;
+    unsigned long long base = 0;
+    if (lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(count, (unsigned long long)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (hit) {
+      const unsigned long long slot = base + __popcll(m & ((1ull << lane) - 1));
+      if (slot < cap) pairs[slot] = make_uint2((unsigned)i, (unsigned)j);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kPolyThreads) void k_poly_heavy(const PolyBox* __restrict__ sorted,
+                                                             const uint2* __restrict__ pairs,
+                                                             const unsigned long long* __restrict__ count,
+                                                             unsigned long long cap, double thresh, uint32_t nb,
+                                                             unsigned long long* __restrict__ mask) {
+  __shared__ D2 s_p[kPMax * kPolyThreads];
+  __shared__ D2 s_t[kTmpMax * kPolyThreads];
+  const unsigned long long total = *count < cap ? *count : cap;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * kPolyThreads + threadIdx.x; e < total;
+       e += (unsigned long long)gridDim.x * kPolyThreads) {
+    const uint2 pr = pairs[e];
+    const double ovr = poly_iou(sorted[pr.x].c, sorted[pr.y].c, s_p + threadIdx.x, s_t + threadIdx.x);
+    if (!(ovr <= thresh))   // :115 keeps j only when the overlap is <= thresh
+      atomicOr(mask + (unsigned long long)pr.x * nb + (pr.y >> 6), 1ull << (pr.y & 63));
+  }
+}
+
+#undef P
+#undef T
+#define P(i) p[(i) * 64]
+#define T(i) tmp[(i) * 64]
+// 64 threads = the 64 rows of a tile; each walks the 64 columns of the tile (direct form: every pair
+// evaluated in place; used for thresh < 0 and when the pair list overflows: overflow_of != NULL makes the
+// launch a no-op unless *overflow_of > cap)
+__global__ __launch_bounds__(64) void k_poly_mask(const PolyBox* __restrict__ sorted, int64_t n, double thresh,
+                                                  unsigned long long* __restrict__ mask,
+                                                  const unsigned long long* __restrict__ overflow_of,
+                                                  unsigned long long cap) {
+  const uint32_t rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  if (overflow_of && *overflow_of <= cap) return;
   __shared__ D2 s_p[kPMax * 64];
   __shared__ D2 s_t[kTmpMax * 64];
   __shared__ PolyBox s_col[64];
@@ -320,11 +385,16 @@ extern "C" int s2a_polyiou_pairs(const double* polys1, const double* polys2, int
 }
 
 
+static size_t poly_pair_cap(int64_t n) {
+  const size_t all = (size_t)n * (size_t)(n > 0 ? n - 1 : 0) / 2;
+  return std::min(all, std::max<size_t>((size_t)n * 32, (size_t)1 << 20)) + 1;
+}
+
 extern "C" size_t s2a_nms_poly_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   size_t sz = (size_t)n, nb = (sz + 63) / 64;
   return align_up(sz * 8) * 2 + align_up(sz * 4) * 2 + align_up(sz * sizeof(PolyBox)) + align_up(sz * nb * 8) +
-         align_up(sz) * 2 + align_up(sz * 40 + (8u << 20)) + 8192;
+         align_up(sz) * 2 + align_up(sz * 40 + (8u << 20)) + align_up(poly_pair_cap(n) * 8) + 8192;
 }
 
 extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64_t* keep, int64_t* count_dev,
@@ -352,7 +422,9 @@ extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64
   auto* small = cv.take<unsigned long long>(64);   // seg_start[2] | num_seg | nblk | mask_off[2] | status
   size_t rpb = sz * 40 + (8u << 20);
   void* rp = cv.take<char>(rpb);
-  if (!rp || !small || cv.off > workspace_bytes) {
+  const size_t cap = poly_pair_cap(n);
+  auto* pairs = cv.take<uint2>(cap);
+  if (!rp || !small || !pairs || cv.off > workspace_bytes) {
     set_error("nms_poly: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
     return S2A_EWORKSPACE;
   }
@@ -371,7 +443,16 @@ extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64
   S2A_HIP(rocprim::radix_sort_pairs(rp, need, key_a, key_b, idx_a, order, sz, 0, 64, st));
   k_poly_prep<<<g, 256, 0, st>>>(dets9, order, n, sorted, seg_start, num_seg, mask_off, nblk);
   dim3 grid((unsigned)nb, (unsigned)nb);
-  k_poly_mask<<<grid, 64, 0, st>>>(sorted, n, thresh, mask);
+  if (thresh >= 0) {
+    unsigned long long* pair_count = small + 16;
+    S2A_HIP(hipMemsetAsync(mask, 0, sz * nb * 8, st));
+    k_poly_cull<<<grid, 64, 0, st>>>(sorted, n, pairs, pair_count, (unsigned long long)cap);
+    const unsigned hb = (unsigned)std::min<size_t>((cap + kPolyThreads - 1) / kPolyThreads, 256 * 16);
+    k_poly_heavy<<<hb, kPolyThreads, 0, st>>>(sorted, pairs, pair_count, (unsigned long long)cap, thresh, (uint32_t)nb, mask);
+    k_poly_mask<<<grid, 64, 0, st>>>(sorted, n, thresh, mask, pair_count, (unsigned long long)cap);   // overflow only
+  } else {
+    k_poly_mask<<<grid, 64, 0, st>>>(sorted, n, thresh, mask, nullptr, 0);
+  }
   S2A_LAUNCH_CHECK();
   int rc = launch_nms_scan(mask, seg_start, num_seg, mask_off, nblk, order, keep_orig, (uint32_t)nb, mask_off + 1,
                            (unsigned long long)sz * nb, status, st);

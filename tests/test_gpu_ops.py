@@ -485,6 +485,13 @@ def test_merge_nms_poly(rng):
     dets = np.concatenate([polys, ((rng.permutation(n) + 1.0) / (n + 1.0))[:, None]], 1)
     assert np.array_equal(nms_poly(cu(dets), 0.3).cpu().numpy(), oracle.nms_poly(dets, 0.3))
     assert nms_poly(torch.zeros((0, 9), device=dev()), 0.5).shape == (0,)
+    # dense scene: more HBB-overlapping pairs than the pair list holds -> the direct kernel takes over
+    n = 3000
+    polys = oracle.rboxes_to_polys(rand_rboxes(rng, n, span=60))
+    dets = np.concatenate([polys, ((rng.permutation(n) + 1.0) / (n + 1.0))[:, None]], 1)
+    assert np.array_equal(nms_poly(cu(dets), 0.7).cpu().numpy(), oracle.nms_poly(dets, 0.7))
+    # negative threshold: every lower-scored box is dropped (hbb_ovr = 0 is not <= thresh), :115
+    assert np.array_equal(nms_poly(cu(dets[:500]), -0.1).cpu().numpy(), oracle.nms_poly(dets[:500], -0.1))
 
 
 def _pyr_setup(B=2, sizes=((40, 56), (20, 28), (10, 14), (5, 7), (3, 4)), C=256):
