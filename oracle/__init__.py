@@ -140,6 +140,39 @@ def polyiou(p8, q8):
     return out
 
 
+def assign_labels(anchors, gt_boxes, imgs_size=(1024, 1024), pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou_thr=0,
+                  gt_max_assign_all=True, filter_invalid_anchors=True, filter_invalid_ious=True, sort_mode=None):
+    """models/utils.py:33-147 restated on top of the oracle's box_iou_rotated (sort_mode: SORT_CPU to compare
+    with the reference's CPU op, SORT_GPU (default) for what its CUDA op computes)"""
+    a = np.ascontiguousarray(anchors, np.float32).reshape(-1, 5)
+    g = np.ascontiguousarray(gt_boxes, np.float32).reshape(-1, 5)
+    M, N = a.shape[0], g.shape[0]
+    out = np.full(M, -2, np.int64)
+    flags = np.ones(M, bool)
+    if filter_invalid_anchors:                                                      # :63-69
+        flags = (a[:, 0] >= 0) & (a[:, 1] >= 0) & (a[:, 0] <= imgs_size[1]) & (a[:, 1] <= imgs_size[0]) & \
+                (a[:, 2] < imgs_size[1]) & (a[:, 3] < imgs_size[0])
+    if N == 0:                                                                      # :72-80
+        out[flags] = -1
+        return out
+    ious = box_iou_rotated(a, g, sort_mode=SORT_GPU if sort_mode is None else sort_mode).copy()
+    if filter_invalid_ious:                                                         # :86-93
+        ious[~((ious >= 0) & (ious <= 1))] = -0.5
+    ious[~flags] = -0.5                                                             # :97-98
+    max_ious, argmax = ious.max(1), ious.argmax(1)                                  # :107 (first index)
+    out[(max_ious >= 0) & (max_ious < neg_iou_thr)] = -1
+    pos = max_ious >= pos_iou_thr
+    out[pos] = argmax[pos]
+    gt_max, gt_arg = ious.max(0), ious.argmax(0)                                    # :121
+    for i in range(N):                                                              # :123-143
+        if gt_max[i] > min_pos_iou_thr:
+            if gt_max_assign_all:
+                out[ious[:, i] == gt_max[i]] = i
+            else:
+                out[gt_arg[i]] = i
+    return out
+
+
 def nms_poly(dets9, thresh=0.5):
     """py_cpu_nms_poly_fast restated: dets[n,9] float64 -> kept original indices, score descending"""
     d = np.ascontiguousarray(dets9, np.float64).reshape(-1, 9)

@@ -875,6 +875,174 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   return S2A_OK;
 }
 
+// ================================================================= label assignment (training side)
+// assign_labels (models/utils.py:33-147): the real consumer of box_iou_rotated in the reference -- the
+// [M anchors x N gts] IoU matrix, its row and column maxima and the three assignment rules -- without the
+// matrix: pass 1 keeps the row max / first arg-max per anchor in registers and the column maxima in an
+// LDS copy (one global atomicMax per block and gt), pass 2 recomputes the (mostly culled) pairs to find,
+// per anchor, the last gt whose column maximum it attains (the reference's ascending loop lets later gts
+// overwrite earlier ones, :131-145).  Values are bit-identical to s2a_box_iou_rotated (same PreBox, cull, rbox_iou).
+namespace s2a {
+namespace {
+__device__ __forceinline__ float assign_value(const PreBox& A, const PreBox& B, bool valid, int filt_iou,
+                                              float2* pts) {
+  if (!valid) return -0.5f;                                   // ious[~flags] = -0.5 (:97-98)
+  float v = 0.f;
+  if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B)) v = rbox_iou<kThreads>(A, B, pts);
+  if (filt_iou && !(v >= 0.f && v <= 1.f)) v = -0.5f;         // :86-93
+  return v + 0.f;                                             // -0.0 -> +0.0 (orders as the float compare does)
+}
+__device__ __forceinline__ int iou_key(float v) { return v < 0.f ? 0 : __float_as_int(v) + 1; }
+__device__ __forceinline__ float key_iou(int k) { return k == 0 ? -0.5f : __int_as_float(k - 1); }
+
+__device__ __forceinline__ bool anchor_valid(const float* __restrict__ a, float img_h, float img_w) {
+  return a[0] >= 0 && a[1] >= 0 && a[0] <= img_w && a[1] <= img_h && a[2] < img_w && a[3] < img_h;   // :63-69
+}
+
+// pass 1: row maxima + rules 1 and 2(1); column maxima into gt_key (zeroed by the host)
+__global__ __launch_bounds__(kThreads) void k_assign_rows(const float* __restrict__ anchors,
+                                                          const PreBox* __restrict__ PA, const PreBox* __restrict__ PG,
+                                                          int64_t M, int64_t N, float img_h, float img_w, float pos_thr,
+                                                          float neg_thr, int filt_anchor, int filt_iou,
+                                                          int* __restrict__ gt_key, int64_t* __restrict__ assign) {
+  __shared__ float2 s_pts[24 * kThreads];
+  __shared__ PreBox s_g[kThreads];
+  __shared__ int s_key[kThreads];
+  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const bool live = m < M;
+  PreBox A = {};
+  bool valid = false;
+  if (live) {
+    A = PA[m];
+    valid = !filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w);
+  }
+  float best = -2.f;
+  int64_t arg = 0;
+  for (int64_t n0 = 0; n0 < N; n0 += kThreads) {
+    const int cnt = (int)min((int64_t)kThreads, N - n0);
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) s_g[threadIdx.x] = PG[n0 + threadIdx.x];
+    s_key[threadIdx.x] = 0;
+    __syncthreads();
+    if (live)
+      for (int j = 0; j < cnt; j++) {
+        const float v = assign_value(A, s_g[j], valid, filt_iou, s_pts + threadIdx.x);
+        if (v > best) { best = v; arg = n0 + j; }            // first index of the maximum
+        const int k = iou_key(v);
+        if (k > s_key[j]) atomicMax(&s_key[j], k);
+      }
+    __syncthreads();
+    if ((int)threadIdx.x < cnt && s_key[threadIdx.x] > 0) atomicMax(gt_key + n0 + threadIdx.x, s_key[threadIdx.x]);
+  }
+  if (!live) return;
+  int64_t a = -2;
+  if (best >= 0.f && best < neg_thr) a = -1;                  // :108
+  if (best >= pos_thr) a = arg;                               // :114-115
+  assign[m] = a;
+}
+
+// optional (gt_max_assign_all = False): first anchor index attaining each column maximum
+__global__ __launch_bounds__(kThreads) void k_assign_colarg(const float* __restrict__ anchors,
+                                                            const PreBox* __restrict__ PA, const PreBox* __restrict__ PG,
+                                                            int64_t M, int64_t N, float img_h, float img_w, int filt_anchor,
+                                                            int filt_iou, const int* __restrict__ gt_key,
+                                                            int* __restrict__ gt_arg) {
+  __shared__ float2 s_pts[24 * kThreads];
+  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (m >= M) return;
+  const PreBox A = PA[m];
+  const bool valid = !filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w);
+  for (int64_t j = 0; j < N; j++) {
+    const float v = assign_value(A, PG[j], valid, filt_iou, s_pts + threadIdx.x);
+    if (iou_key(v) == gt_key[j]) atomicMin(gt_arg + j, (int)m);
+  }
+}
+
+// pass 2: rule 2(2), :119-145
+__global__ __launch_bounds__(kThreads) void k_assign_cols(const float* __restrict__ anchors,
+                                                          const PreBox* __restrict__ PA, const PreBox* __restrict__ PG,
+                                                          int64_t M, int64_t N, float img_h, float img_w, float min_pos_thr,
+                                                          int filt_anchor, int filt_iou, const int* __restrict__ gt_key,
+                                                          const int* __restrict__ gt_arg, int64_t* __restrict__ assign) {
+  __shared__ float2 s_pts[24 * kThreads];
+  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (m >= M) return;
+  const PreBox A = PA[m];
+  const bool valid = !filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w);
+  int64_t best = -1;
+  for (int64_t j = 0; j < N; j++) {
+    const int k = gt_key[j];
+    if (!(key_iou(k) > min_pos_thr)) continue;
+    if (gt_arg) {
+      if (gt_arg[j] == (int)m) best = j;
+    } else {
+      // cheap reject first: an anchor can only attain a positive column maximum if the pair survives the cull
+      const PreBox B = PG[j];
+      if (k > 1 && (!valid || surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r))) continue;
+      if (iou_key(assign_value(A, B, valid, filt_iou, s_pts + threadIdx.x)) == k) best = j;
+    }
+  }
+  if (best >= 0) assign[m] = best;
+}
+// no gt boxes (:72-80): valid anchors are negatives, the others stay ignored
+__global__ void k_assign_empty(const float* __restrict__ anchors, int64_t M, float img_h, float img_w, int filt_anchor,
+                               int64_t* __restrict__ assign) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  assign[m] = (!filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w)) ? -1 : -2;
+}
+}  // namespace
+}  // namespace s2a
+
+extern "C" size_t s2a_assign_labels_workspace_bytes(int64_t num_anchors, int64_t num_gts) {
+  return align_up((size_t)std::max<int64_t>(num_anchors, 1) * sizeof(PreBox)) +
+         align_up((size_t)std::max<int64_t>(num_gts, 1) * sizeof(PreBox)) +
+         2 * align_up((size_t)std::max<int64_t>(num_gts, 1) * 4) + 1024;
+}
+
+extern "C" int s2a_assign_labels(const float* anchors, int64_t num_anchors, const float* gt_boxes, int64_t num_gts,
+                                 float img_h, float img_w, float pos_iou_thr, float neg_iou_thr, float min_pos_iou_thr,
+                                 int gt_max_assign_all, int filter_invalid_anchors, int filter_invalid_ious,
+                                 int64_t* assign_gt_ids, void* workspace, size_t workspace_bytes, s2a_stream_t stream) {
+  S2A_CHECK_ARG(num_anchors >= 0 && num_gts >= 0 && num_anchors < (1ll << 31) && num_gts < (1ll << 31),
+                "assign_labels: sizes out of range");
+  if (num_anchors == 0) return S2A_OK;
+  S2A_CHECK_ARG(anchors && assign_gt_ids && (gt_boxes || num_gts == 0), "assign_labels: NULL tensor");
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace, workspace_bytes);
+  PreBox* PA = cv.take<PreBox>((size_t)num_anchors);
+  PreBox* PG = cv.take<PreBox>((size_t)std::max<int64_t>(num_gts, 1));
+  int* gt_key = cv.take<int>((size_t)std::max<int64_t>(num_gts, 1));
+  int* gt_arg = cv.take<int>((size_t)std::max<int64_t>(num_gts, 1));
+  if (!PA || !PG || !gt_key || !gt_arg) {
+    set_error("assign_labels: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+    return S2A_EWORKSPACE;
+  }
+  const unsigned g = (unsigned)((num_anchors + kThreads - 1) / kThreads);
+  k_prep_boxes<<<(unsigned)((num_anchors + 255) / 256), 256, 0, st>>>(anchors, num_anchors, PA);
+  if (num_gts > 0) {
+    k_prep_boxes<<<(unsigned)((num_gts + 255) / 256), 256, 0, st>>>(gt_boxes, num_gts, PG);
+    S2A_HIP(hipMemsetAsync(gt_key, 0, (size_t)num_gts * 4, st));
+    S2A_HIP(hipMemsetAsync(gt_arg, 0x7f, (size_t)num_gts * 4, st));
+  }
+  // num_gts == 0 (:72-80): every valid anchor is a negative
+  if (num_gts == 0) {
+    k_assign_empty<<<g, kThreads, 0, st>>>(anchors, num_anchors, img_h, img_w, filter_invalid_anchors, assign_gt_ids);
+    S2A_LAUNCH_CHECK();
+    return S2A_OK;
+  }
+  k_assign_rows<<<g, kThreads, 0, st>>>(anchors, PA, PG, num_anchors, num_gts, img_h, img_w, pos_iou_thr, neg_iou_thr,
+                                        filter_invalid_anchors, filter_invalid_ious, gt_key, assign_gt_ids);
+  if (!gt_max_assign_all)
+    k_assign_colarg<<<g, kThreads, 0, st>>>(anchors, PA, PG, num_anchors, num_gts, img_h, img_w, filter_invalid_anchors,
+                                            filter_invalid_ious, gt_key, gt_arg);
+  k_assign_cols<<<g, kThreads, 0, st>>>(anchors, PA, PG, num_anchors, num_gts, img_h, img_w, min_pos_iou_thr,
+                                        filter_invalid_anchors, filter_invalid_ious, gt_key,
+                                        gt_max_assign_all ? nullptr : gt_arg, assign_gt_ids);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
 extern "C" int s2a_box_iou_rotated_pairs(const float* boxes1, const float* boxes2, int64_t n,
                                          float* ious, s2a_stream_t stream) {
   S2A_CHECK_ARG(n >= 0, "box_iou_rotated_pairs: negative size");

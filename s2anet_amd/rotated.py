@@ -69,6 +69,28 @@ def polyiou_pairs(polys1, polys2):
     return out
 
 
+def assign_labels(anchors, gt_boxes, imgs_size=(1024, 1024), pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou_thr=0,
+                  gt_max_assign_all=True, filter_invalid_anchors=True, filter_invalid_ious=True):
+    """models/utils.py:33-147 in one fused pass sequence (no [M,N] IoU matrix):
+    anchors[M,5], gt_boxes[N,5] (px / rad) -> assign_gt_ids[M] int64: -2 ignore, -1 negative, >= 0 gt index"""
+    _lib.require_cuda(anchors, gt_boxes)
+    a = anchors.float().contiguous()
+    g = gt_boxes.float().contiguous().reshape(-1, 5)
+    M, N = a.shape[0], g.shape[0]
+    out = torch.full((M,), -2, dtype=torch.int64, device=a.device)
+    if M == 0:
+        return out
+    L = _lib.lib()
+    with torch.cuda.device(a.device):
+        ws = _lib.workspace(L.s2a_assign_labels_workspace_bytes(M, N), a.device, "assign")
+        _lib.check(L.s2a_assign_labels(_lib.ptr(a), M, _lib.ptr(g) if N else None, N, float(imgs_size[0]), float(imgs_size[1]),
+                                       float(pos_iou_thr), float(neg_iou_thr), float(min_pos_iou_thr),
+                                       int(bool(gt_max_assign_all)), int(bool(filter_invalid_anchors)),
+                                       int(bool(filter_invalid_ious)), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(a.device)))
+    return out
+
+
 def nms_poly(dets, thresh=0.5):
     """py_cpu_nms_poly_fast (DOTA_devkit/ResultMerge_multi_process.py:62-123) on the GPU:
     dets[n,9] = x1,y1,...,x4,y4,score -> kept indices (int64), descending score"""

@@ -258,6 +258,28 @@ def gen_dcn(rng):
                         offset=off.numpy(), out_torch=out.numpy())
 
 
+def gen_assign_labels():
+    """label assignment from the reference's own models/utils.py:assign_labels run on its CPU box_iou_rotated"""
+    import_reference_python()
+    from models.utils import assign_labels
+    rng = np.random.default_rng(2468)
+    anchors = rand_boxes(rng, 3000, span=1000)
+    anchors[:40, 0] = rng.uniform(-30, 0, 40)            # invalid anchors (outside the image)
+    anchors[40:60, 2] = 1100.0
+    gts = rand_boxes(rng, 37, span=1000)
+    gts[:8] = anchors[100:108]                           # exact matches (IoU 1) ...
+    gts[8:12] = anchors[200:204] + np.array([3, -2, 1, 0.5, 0.02], np.float32)
+    anchors[300] = anchors[301]                          # ... and two anchors tying for a gt's maximum
+    gts[12] = anchors[300] + np.array([6, 6, 0, 0, 0], np.float32)
+    out = {"anchors": anchors, "gts": gts}
+    for tag, kw in (("default", {}), ("first", dict(gt_max_assign_all=False)), ("thr", dict(pos_iou_thr=0.3, neg_iou_thr=0.2, min_pos_iou_thr=0.1)),
+                    ("nofilter", dict(filter_invalid_anchors=False))):
+        out["assign_" + tag] = assign_labels(torch.from_numpy(anchors), torch.from_numpy(gts), **kw).numpy()
+        print("assign", tag, np.bincount(np.clip(out["assign_" + tag] + 2, 0, 3)))
+    out["assign_empty"] = assign_labels(torch.from_numpy(anchors), torch.zeros((0, 5))).numpy()
+    np.savez_compressed(os.path.join(OUT, "assign_labels.npz"), **out)
+
+
 def gen_dcn_backward():
     """gradients of the deformable convolution: autograd through the independent torch formulation
     (torch_deform_conv; floor() has zero gradient, so d/d(offset) is the derivative of the bilinear
@@ -319,4 +341,5 @@ if __name__ == "__main__":
     gen_arf_backward()
     gen_merge_nms()
     gen_dcn_backward()
+    gen_assign_labels()
     print("done ->", OUT)

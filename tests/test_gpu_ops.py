@@ -668,3 +668,24 @@ def test_dcn_backward_vs_oracle_and_golden(rng):
     deform_conv(xh, oh, wh, 1, 1, 1, 1, 1).backward(cu(g["grad_out"]).half())
     for got, ref in ((xh.grad, g["grad_input"]), (oh.grad, g["grad_offset"]), (wh.grad, g["grad_weight"])):
         assert np.abs(got.float().cpu().numpy() - ref).max() < 3e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_assign_labels_fused(rng):
+    """fused label assignment == the reference's assign_labels (golden from its own Python on its CPU IoU op;
+    the two sort branches of the IoU agree on these inputs) and == the oracle on fresh inputs"""
+    from s2anet_amd.rotated import assign_labels
+    from test_oracle_pinned import ASSIGN_CASES
+    g = golden("assign_labels.npz")
+    for tag, kw in ASSIGN_CASES:
+        got = assign_labels(cu(g["anchors"]), cu(g["gts"]), **kw).cpu().numpy()
+        assert np.array_equal(got, oracle.assign_labels(g["anchors"], g["gts"], **kw)), tag
+        assert np.array_equal(got, g["assign_" + tag]), tag
+    assert np.array_equal(assign_labels(cu(g["anchors"]), torch.zeros((0, 5), device=dev())).cpu().numpy(), g["assign_empty"])
+    # the real shape: all 21 824 grid anchors of a 1024^2 chip against 300 ground-truth boxes
+    a = np.concatenate([oracle.grid_anchors(1024 // s, 1024 // s, s).reshape(-1, 5) for s in (8, 16, 32, 64, 128)]).astype(np.float32)
+    a[:, 4] = rng.uniform(-0.7, 2.3, a.shape[0])
+    gt = rand_rboxes(rng, 300, span=1024)
+    gt[:50] = a[rng.choice(a.shape[0], 50, replace=False)] * np.array([1, 1, 1.1, 0.9, 1], np.float32)
+    got = assign_labels(cu(a), cu(gt)).cpu().numpy()
+    assert np.array_equal(got, oracle.assign_labels(a, gt))
+    assert (got >= 0).sum() >= 50

@@ -124,6 +124,18 @@ def test_dcn_backward_oracle_matches_autograd_of_independent_formulation():
         assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
 
+ASSIGN_CASES = (("default", {}), ("first", dict(gt_max_assign_all=False)),
+                ("thr", dict(pos_iou_thr=0.3, neg_iou_thr=0.2, min_pos_iou_thr=0.1)), ("nofilter", dict(filter_invalid_anchors=False)))
+
+
+def test_assign_labels_matches_reference_python():
+    g = golden("assign_labels.npz")
+    for tag, kw in ASSIGN_CASES:
+        got = oracle.assign_labels(g["anchors"], g["gts"], sort_mode=oracle.SORT_CPU, **kw)
+        assert np.array_equal(got, g["assign_" + tag]), tag
+    assert np.array_equal(oracle.assign_labels(g["anchors"], np.zeros((0, 5), np.float32)), g["assign_empty"])
+
+
 def test_merge_nms_poly_matches_reference_script():
     g = golden("merge_nms_poly.npz")
     for thr in (0.1, 0.5):
