@@ -73,8 +73,9 @@ int s2a_polyiou_pairs(const double* polys1, const double* polys2, int64_t n, dou
 /* Label assignment of the training side, fused: assign_labels(anchors[M,5], gt_boxes[N,5], imgs_size, pos_iou_thr,
  * neg_iou_thr, min_pos_iou_thr, gt_max_assign_all, filter_invalid_anchors, filter_invalid_ious)
  * (models/utils.py:33-147) -> assign_gt_ids[M] int64 (-2 ignore, -1 negative, >= 0 the gt index).  The
- * [M,N] IoU matrix of bbox_iou_rotated (utils/metrics.py:85-107) is never materialised; IoU values are those
- * of s2a_box_iou_rotated bit for bit.  Row arg-max ties: first index. */
+ * [M,N] IoU matrix of bbox_iou_rotated (utils/metrics.py:85-107) lives in the workspace only (same pipeline and
+ * values as s2a_box_iou_rotated); three streaming passes over it replace the reference's tensor ops and its
+ * Python loop over the gts.  Row arg-max ties: first index. */
 size_t s2a_assign_labels_workspace_bytes(int64_t num_anchors, int64_t num_gts);
 int s2a_assign_labels(const float* anchors, int64_t num_anchors, const float* gt_boxes, int64_t num_gts,
                       float img_h, float img_w, float pos_iou_thr, float neg_iou_thr, float min_pos_iou_thr,

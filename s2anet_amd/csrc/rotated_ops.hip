@@ -876,22 +876,15 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
 }
 
 // ================================================================= label assignment (training side)
-// assign_labels (models/utils.py:33-147): the real consumer of box_iou_rotated in the reference -- the
-// [M anchors x N gts] IoU matrix, its row and column maxima and the three assignment rules -- without the
-// matrix: pass 1 keeps the row max / first arg-max per anchor in registers and the column maxima in an
-// LDS copy (one global atomicMax per block and gt), pass 2 recomputes the (mostly culled) pairs to find,
-// per anchor, the last gt whose column maximum it attains (the reference's ascending loop lets later gts
-// overwrite earlier ones, :131-145).  Values are bit-identical to s2a_box_iou_rotated (same PreBox, cull, rbox_iou).
+// assign_labels (models/utils.py:33-147): the real consumer of box_iou_rotated in the reference.  The [M,N]
+// matrix comes from the cull -> pair list -> dense pass pipeline above (a per-anchor loop over the gts was 10x
+// slower: divergence); three streaming passes over it replace the reference's dozen tensor ops and its
+// Python loop over the gts: (1) one wave per anchor row: validity / range filters in place, row max and
+// first arg-max, rules 1 and 2(1); (2) column maxima (tiled, atomicMax on order-preserving keys);
+// (3) one wave per row: the LAST gt whose column maximum the anchor attains (the reference's ascending loop
+// lets later gts overwrite earlier ones, :131-145).
 namespace s2a {
 namespace {
-__device__ __forceinline__ float assign_value(const PreBox& A, const PreBox& B, bool valid, int filt_iou,
-                                              float2* pts) {
-  if (!valid) return -0.5f;                                   // ious[~flags] = -0.5 (:97-98)
-  float v = 0.f;
-  if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B)) v = rbox_iou<kThreads>(A, B, pts);
-  if (filt_iou && !(v >= 0.f && v <= 1.f)) v = -0.5f;         // :86-93
-  return v + 0.f;                                             // -0.0 -> +0.0 (orders as the float compare does)
-}
 __device__ __forceinline__ int iou_key(float v) { return v < 0.f ? 0 : __float_as_int(v) + 1; }
 __device__ __forceinline__ float key_iou(int k) { return k == 0 ? -0.5f : __int_as_float(k - 1); }
 
@@ -899,91 +892,79 @@ __device__ __forceinline__ bool anchor_valid(const float* __restrict__ a, float 
   return a[0] >= 0 && a[1] >= 0 && a[0] <= img_w && a[1] <= img_h && a[2] < img_w && a[3] < img_h;   // :63-69
 }
 
-// pass 1: row maxima + rules 1 and 2(1); column maxima into gt_key (zeroed by the host)
-__global__ __launch_bounds__(kThreads) void k_assign_rows(const float* __restrict__ anchors,
-                                                          const PreBox* __restrict__ PA, const PreBox* __restrict__ PG,
-                                                          int64_t M, int64_t N, float img_h, float img_w, float pos_thr,
-                                                          float neg_thr, int filt_anchor, int filt_iou,
-                                                          int* __restrict__ gt_key, int64_t* __restrict__ assign) {
-  __shared__ float2 s_pts[24 * kThreads];
-  __shared__ PreBox s_g[kThreads];
-  __shared__ int s_key[kThreads];
-  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  const bool live = m < M;
-  PreBox A = {};
-  bool valid = false;
-  if (live) {
-    A = PA[m];
-    valid = !filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w);
-  }
+__global__ __launch_bounds__(256) void k_assign_rows(const float* __restrict__ anchors, float* __restrict__ ious,
+                                                     int64_t M, int64_t N, float img_h, float img_w, float pos_thr,
+                                                     float neg_thr, int filt_anchor, int filt_iou,
+                                                     int64_t* __restrict__ assign) {
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const bool valid = !filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w);
+  float* row = ious + m * N;
   float best = -2.f;
   int64_t arg = 0;
-  for (int64_t n0 = 0; n0 < N; n0 += kThreads) {
-    const int cnt = (int)min((int64_t)kThreads, N - n0);
-    __syncthreads();
-    if ((int)threadIdx.x < cnt) s_g[threadIdx.x] = PG[n0 + threadIdx.x];
-    s_key[threadIdx.x] = 0;
-    __syncthreads();
-    if (live)
-      for (int j = 0; j < cnt; j++) {
-        const float v = assign_value(A, s_g[j], valid, filt_iou, s_pts + threadIdx.x);
-        if (v > best) { best = v; arg = n0 + j; }            // first index of the maximum
-        const int k = iou_key(v);
-        if (k > s_key[j]) atomicMax(&s_key[j], k);
-      }
-    __syncthreads();
-    if ((int)threadIdx.x < cnt && s_key[threadIdx.x] > 0) atomicMax(gt_key + n0 + threadIdx.x, s_key[threadIdx.x]);
+  for (int64_t j = lane; j < N; j += 64) {
+    float v = row[j];
+    if (filt_iou && !(v >= 0.f && v <= 1.f)) v = -0.5f;        // :86-93
+    if (!valid) v = -0.5f;                                     // :97-98
+    v += 0.f;                                                  // -0.0 -> +0.0
+    row[j] = v;
+    if (v > best) { best = v; arg = j; }
   }
-  if (!live) return;
-  int64_t a = -2;
-  if (best >= 0.f && best < neg_thr) a = -1;                  // :108
-  if (best >= pos_thr) a = arg;                               // :114-115
-  assign[m] = a;
-}
-
-// optional (gt_max_assign_all = False): first anchor index attaining each column maximum
-__global__ __launch_bounds__(kThreads) void k_assign_colarg(const float* __restrict__ anchors,
-                                                            const PreBox* __restrict__ PA, const PreBox* __restrict__ PG,
-                                                            int64_t M, int64_t N, float img_h, float img_w, int filt_anchor,
-                                                            int filt_iou, const int* __restrict__ gt_key,
-                                                            int* __restrict__ gt_arg) {
-  __shared__ float2 s_pts[24 * kThreads];
-  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (m >= M) return;
-  const PreBox A = PA[m];
-  const bool valid = !filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w);
-  for (int64_t j = 0; j < N; j++) {
-    const float v = assign_value(A, PG[j], valid, filt_iou, s_pts + threadIdx.x);
-    if (iou_key(v) == gt_key[j]) atomicMin(gt_arg + j, (int)m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int64_t oa = __shfl_xor(arg, o);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }   // first index of the maximum
+  }
+  if (lane == 0) {
+    int64_t a = -2;
+    if (best >= 0.f && best < neg_thr) a = -1;                 // :108
+    if (best >= pos_thr) a = arg;                              // :114-115
+    assign[m] = a;
   }
 }
 
-// pass 2: rule 2(2), :119-145
-__global__ __launch_bounds__(kThreads) void k_assign_cols(const float* __restrict__ anchors,
-                                                          const PreBox* __restrict__ PA, const PreBox* __restrict__ PG,
-                                                          int64_t M, int64_t N, float img_h, float img_w, float min_pos_thr,
-                                                          int filt_anchor, int filt_iou, const int* __restrict__ gt_key,
-                                                          const int* __restrict__ gt_arg, int64_t* __restrict__ assign) {
-  __shared__ float2 s_pts[24 * kThreads];
-  const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+// grid (ceil(N/64), ceil(M/256)): thread = one column over 256 rows; rows are read 64 columns wide (coalesced)
+__global__ __launch_bounds__(64) void k_assign_colmax(const float* __restrict__ ious, int64_t M, int64_t N,
+                                                      int* __restrict__ gt_key) {
+  const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (j >= N) return;
+  const int64_t m0 = (int64_t)blockIdx.y * 256, m1 = min(M, m0 + 256);
+  int k = 0;
+  for (int64_t m = m0; m < m1; m++) k = max(k, iou_key(ious[m * N + j]));
+  if (k > 0) atomicMax(gt_key + j, k);
+}
+
+__global__ __launch_bounds__(64) void k_assign_colarg(const float* __restrict__ ious, int64_t M, int64_t N,
+                                                      const int* __restrict__ gt_key, int* __restrict__ gt_arg) {
+  const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (j >= N) return;
+  const int64_t m0 = (int64_t)blockIdx.y * 256, m1 = min(M, m0 + 256);
+  const int k = gt_key[j];
+  for (int64_t m = m0; m < m1; m++)
+    if (iou_key(ious[m * N + j]) == k) { atomicMin(gt_arg + j, (int)m); break; }   // first row of this chunk
+}
+
+__global__ __launch_bounds__(256) void k_assign_cols(const float* __restrict__ ious, int64_t M, int64_t N,
+                                                     float min_pos_thr, const int* __restrict__ gt_key,
+                                                     const int* __restrict__ gt_arg, int64_t* __restrict__ assign) {
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (m >= M) return;
-  const PreBox A = PA[m];
-  const bool valid = !filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w);
+  const float* row = ious + m * N;
   int64_t best = -1;
-  for (int64_t j = 0; j < N; j++) {
+  for (int64_t j = lane; j < N; j += 64) {
     const int k = gt_key[j];
-    if (!(key_iou(k) > min_pos_thr)) continue;
-    if (gt_arg) {
-      if (gt_arg[j] == (int)m) best = j;
-    } else {
-      // cheap reject first: an anchor can only attain a positive column maximum if the pair survives the cull
-      const PreBox B = PG[j];
-      if (k > 1 && (!valid || surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r))) continue;
-      if (iou_key(assign_value(A, B, valid, filt_iou, s_pts + threadIdx.x)) == k) best = j;
-    }
+    if (!(key_iou(k) > min_pos_thr)) continue;                 // :126
+    const bool hit = gt_arg ? gt_arg[j] == (int)m : iou_key(row[j]) == k;
+    if (hit) best = j;
   }
-  if (best >= 0) assign[m] = best;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+  if (lane == 0 && best >= 0) assign[m] = best;
 }
+
 // no gt boxes (:72-80): valid anchors are negatives, the others stay ignored
 __global__ void k_assign_empty(const float* __restrict__ anchors, int64_t M, float img_h, float img_w, int filt_anchor,
                                int64_t* __restrict__ assign) {
@@ -995,9 +976,8 @@ __global__ void k_assign_empty(const float* __restrict__ anchors, int64_t M, flo
 }  // namespace s2a
 
 extern "C" size_t s2a_assign_labels_workspace_bytes(int64_t num_anchors, int64_t num_gts) {
-  return align_up((size_t)std::max<int64_t>(num_anchors, 1) * sizeof(PreBox)) +
-         align_up((size_t)std::max<int64_t>(num_gts, 1) * sizeof(PreBox)) +
-         2 * align_up((size_t)std::max<int64_t>(num_gts, 1) * 4) + 1024;
+  const int64_t M = std::max<int64_t>(num_anchors, 1), N = std::max<int64_t>(num_gts, 1);
+  return align_up((size_t)M * N * 4) + 2 * align_up((size_t)N * 4) + s2a_box_iou_rotated_workspace_bytes(M, N) + 1024;
 }
 
 extern "C" int s2a_assign_labels(const float* anchors, int64_t num_anchors, const float* gt_boxes, int64_t num_gts,
@@ -1009,36 +989,35 @@ extern "C" int s2a_assign_labels(const float* anchors, int64_t num_anchors, cons
   if (num_anchors == 0) return S2A_OK;
   S2A_CHECK_ARG(anchors && assign_gt_ids && (gt_boxes || num_gts == 0), "assign_labels: NULL tensor");
   hipStream_t st = as_stream(stream);
-  Carver cv(workspace, workspace_bytes);
-  PreBox* PA = cv.take<PreBox>((size_t)num_anchors);
-  PreBox* PG = cv.take<PreBox>((size_t)std::max<int64_t>(num_gts, 1));
-  int* gt_key = cv.take<int>((size_t)std::max<int64_t>(num_gts, 1));
-  int* gt_arg = cv.take<int>((size_t)std::max<int64_t>(num_gts, 1));
-  if (!PA || !PG || !gt_key || !gt_arg) {
-    set_error("assign_labels: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
-    return S2A_EWORKSPACE;
-  }
-  const unsigned g = (unsigned)((num_anchors + kThreads - 1) / kThreads);
-  k_prep_boxes<<<(unsigned)((num_anchors + 255) / 256), 256, 0, st>>>(anchors, num_anchors, PA);
-  if (num_gts > 0) {
-    k_prep_boxes<<<(unsigned)((num_gts + 255) / 256), 256, 0, st>>>(gt_boxes, num_gts, PG);
-    S2A_HIP(hipMemsetAsync(gt_key, 0, (size_t)num_gts * 4, st));
-    S2A_HIP(hipMemsetAsync(gt_arg, 0x7f, (size_t)num_gts * 4, st));
-  }
-  // num_gts == 0 (:72-80): every valid anchor is a negative
-  if (num_gts == 0) {
-    k_assign_empty<<<g, kThreads, 0, st>>>(anchors, num_anchors, img_h, img_w, filter_invalid_anchors, assign_gt_ids);
+  const int64_t M = num_anchors, N = num_gts;
+  if (N == 0) {
+    k_assign_empty<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(anchors, M, img_h, img_w, filter_invalid_anchors, assign_gt_ids);
     S2A_LAUNCH_CHECK();
     return S2A_OK;
   }
-  k_assign_rows<<<g, kThreads, 0, st>>>(anchors, PA, PG, num_anchors, num_gts, img_h, img_w, pos_iou_thr, neg_iou_thr,
-                                        filter_invalid_anchors, filter_invalid_ious, gt_key, assign_gt_ids);
-  if (!gt_max_assign_all)
-    k_assign_colarg<<<g, kThreads, 0, st>>>(anchors, PA, PG, num_anchors, num_gts, img_h, img_w, filter_invalid_anchors,
-                                            filter_invalid_ious, gt_key, gt_arg);
-  k_assign_cols<<<g, kThreads, 0, st>>>(anchors, PA, PG, num_anchors, num_gts, img_h, img_w, min_pos_iou_thr,
-                                        filter_invalid_anchors, filter_invalid_ious, gt_key,
-                                        gt_max_assign_all ? nullptr : gt_arg, assign_gt_ids);
+  Carver cv(workspace, workspace_bytes);
+  float* ious = cv.take<float>((size_t)M * N);
+  int* gt_key = cv.take<int>((size_t)N);
+  int* gt_arg = cv.take<int>((size_t)N);
+  const size_t iou_ws = s2a_box_iou_rotated_workspace_bytes(M, N);
+  char* iw = cv.take<char>(iou_ws);
+  if (!ious || !gt_key || !gt_arg || !iw) {
+    set_error("assign_labels: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+    return S2A_EWORKSPACE;
+  }
+  int rc = s2a_box_iou_rotated(anchors, M, gt_boxes, N, ious, iw, iou_ws, stream);
+  if (rc != S2A_OK) return rc;
+  S2A_HIP(hipMemsetAsync(gt_key, 0, (size_t)N * 4, st));
+  const unsigned gr = (unsigned)((M + 3) / 4);
+  k_assign_rows<<<gr, 256, 0, st>>>(anchors, ious, M, N, img_h, img_w, pos_iou_thr, neg_iou_thr, filter_invalid_anchors,
+                                    filter_invalid_ious, assign_gt_ids);
+  dim3 gc((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256));
+  k_assign_colmax<<<gc, 64, 0, st>>>(ious, M, N, gt_key);
+  if (!gt_max_assign_all) {
+    S2A_HIP(hipMemsetAsync(gt_arg, 0x7f, (size_t)N * 4, st));
+    k_assign_colarg<<<gc, 64, 0, st>>>(ious, M, N, gt_key, gt_arg);
+  }
+  k_assign_cols<<<gr, 256, 0, st>>>(ious, M, N, min_pos_iou_thr, gt_key, gt_max_assign_all ? nullptr : gt_arg, assign_gt_ids);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -71,7 +71,7 @@ def polyiou_pairs(polys1, polys2):
 
 def assign_labels(anchors, gt_boxes, imgs_size=(1024, 1024), pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou_thr=0,
                   gt_max_assign_all=True, filter_invalid_anchors=True, filter_invalid_ious=True):
-    """models/utils.py:33-147 in one fused pass sequence (no [M,N] IoU matrix):
+    """models/utils.py:33-147 in one call (IoU matrix in the workspace, three streaming passes over it):
     anchors[M,5], gt_boxes[N,5] (px / rad) -> assign_gt_ids[M] int64: -2 ignore, -1 negative, >= 0 gt index"""
     _lib.require_cuda(anchors, gt_boxes)
     a = anchors.float().contiguous()

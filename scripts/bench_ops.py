@@ -126,6 +126,26 @@ def dcn_backward(batch=8, H=128, W=128, C=256, O=256, dtype=torch.float32):
                 gemm_tflops_each=round(flops / 1e12, 3), note="columns materialised per chunk as the reference does")
 
 
+def assign(n_gt=300):
+    """fused assign_labels on the 21 824 grid anchors of one chip vs box_iou_rotated + the stock max/compare ops"""
+    import oracle
+    from s2anet_amd.rotated import assign_labels
+    rng = np.random.default_rng(5)
+    a = np.concatenate([oracle.grid_anchors(1024 // s, 1024 // s, s).reshape(-1, 5) for s in (8, 16, 32, 64, 128)]).astype(np.float32)
+    a[:, 4] = rng.uniform(-0.7, 2.3, a.shape[0])
+    gt = rboxes(rng, n_gt)
+    A, G = torch.from_numpy(a).to(dev), torch.from_numpy(gt).to(dev)
+    t_f = timeit(lambda: assign_labels(A, G))
+    def unfused():
+        iou = S.box_iou_rotated(A, G)
+        mx, am = iou.max(1)
+        gm, ga = iou.max(0)
+        return (iou == gm[None]).any(1), mx, am
+    t_u = timeit(unfused)
+    return dict(op="assign_labels", anchors=int(a.shape[0]), gts=n_gt, fused_us=round(t_f * 1e6, 1),
+                iou_matrix_plus_maxes_us=round(t_u * 1e6, 1))
+
+
 def cpu_baselines():
     """the reference's own CPU ops (oracle/_ref, built from /root/reference unmodified) timed on this
     box's host cores, single thread as the reference loops are serial; bounded samples"""
@@ -195,6 +215,8 @@ if __name__ == "__main__":
             res.append(alignconv(8, torch.float16, sigma=sg))
     if a.which in ("all", "iou"):
         res.append(iou(10000, 10000)); res.append(iou(21824, 128))
+    if a.which in ("all", "assign"):
+        res.append(assign(300)); res.append(assign(32))
     if a.which in ("all", "bwd"):
         res.append(dcn_backward(8, dtype=torch.float32)); res.append(dcn_backward(8, dtype=torch.float16))
     if a.which in ("all", "poly"):
