@@ -70,6 +70,14 @@ int s2a_box_iou_rotated_pairs(const float* boxes1, const float* boxes2, int64_t 
 int s2a_polyiou_pairs(const double* polys1, const double* polys2, int64_t n, double* ious,
                       s2a_stream_t stream);
 
+/* The search inside voc_eval (DOTA_devkit/dota_evaluation_task1.py:204-263): for every detection polygon
+ * dets8[d] (8 doubles) of image det_image[d], the ground-truth polygon gts8[g], g in
+ * [gt_offsets[img], gt_offsets[img+1]), with the largest iou_poly(GT, det) among those whose axis-aligned boxes
+ * overlap it (:222-246) -> ovmax[d] (-inf when none) and argmax[d] (index into gts8, -1 when none; first maximum). */
+int s2a_polyiou_match(const double* dets8, const int32_t* det_image, int64_t num_dets, const double* gts8,
+                      const int64_t* gt_offsets, int64_t num_images, double* ovmax, int64_t* argmax,
+                      s2a_stream_t stream);
+
 /* Label assignment of the training side, fused: assign_labels(anchors[M,5], gt_boxes[N,5], imgs_size, pos_iou_thr,
  * neg_iou_thr, min_pos_iou_thr, gt_max_assign_all, filter_invalid_anchors, filter_invalid_ious)
  * (models/utils.py:33-147) -> assign_gt_ids[M] int64 (-2 ignore, -1 negative, >= 0 the gt index).  The

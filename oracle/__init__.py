@@ -140,6 +140,63 @@ def polyiou(p8, q8):
     return out
 
 
+def voc_eval_arrays(det_polys, det_scores, det_image, gt_polys, gt_image, gt_difficult, num_images, ovthresh=0.5,
+                    is_filter_difficult=True, use_07_metric=False):
+    """voc_eval (DOTA_devkit/dota_evaluation_task1.py:92-318) for one class on arrays, restated with the oracle's
+    polyiou: -> rec, prec, ap, sorted_scores, (ovmax, argmax) per detection in confidence order"""
+    det_polys = np.asarray(det_polys, np.float64).reshape(-1, 8)
+    det_scores = np.asarray(det_scores, np.float64)
+    det_image = np.asarray(det_image, np.int64)
+    gt_polys = np.asarray(gt_polys, np.float64).reshape(-1, 8)
+    gt_image = np.asarray(gt_image, np.int64)
+    gt_difficult = np.asarray(gt_difficult).astype(bool)
+    num_gts = int((~gt_difficult).sum()) if is_filter_difficult else int(gt_difficult.shape[0])
+    order = np.argsort(-det_scores)
+    taken = np.zeros(gt_polys.shape[0], bool)
+    n = det_polys.shape[0]
+    tp, fp, ovs, args = np.zeros(n), np.zeros(n), np.full(n, -np.inf), np.full(n, -1, np.int64)
+    for k, d in enumerate(order):
+        bb = det_polys[d]
+        idx = np.where(gt_image == det_image[d])[0]
+        ovmax, jmax = -np.inf, -1
+        if idx.size:
+            g = gt_polys[idx]
+            gx1, gy1, gx2, gy2 = g[:, 0::2].min(1), g[:, 1::2].min(1), g[:, 0::2].max(1), g[:, 1::2].max(1)
+            px1, py1, px2, py2 = bb[0::2].min(), bb[1::2].min(), bb[0::2].max(), bb[1::2].max()
+            iw = np.maximum(np.minimum(gx2, px2) - np.maximum(gx1, px1) + 1.0, 0.0)
+            ih = np.maximum(np.minimum(gy2, py2) - np.maximum(gy1, py1) + 1.0, 0.0)
+            inters = iw * ih
+            uni = (px2 - px1 + 1.0) * (py2 - py1 + 1.0) + (gx2 - gx1 + 1.0) * (gy2 - gy1 + 1.0) - inters
+            keep = np.where(inters / uni > 0)[0]
+            if keep.size:
+                ov = polyiou(g[keep], np.repeat(bb[None], keep.size, 0))
+                ovmax, jmax = ov.max(), idx[keep[int(np.argmax(ov))]]
+        ovs[k], args[k] = ovmax, jmax
+        if ovmax > ovthresh:
+            if is_filter_difficult and gt_difficult[jmax]:
+                continue
+            if not taken[jmax]:
+                tp[k], taken[jmax] = 1.0, True
+            else:
+                fp[k] = 1.0
+        else:
+            fp[k] = 1.0
+    fp, tp = np.cumsum(fp), np.cumsum(tp)
+    rec = tp / float(num_gts)
+    prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    if use_07_metric:
+        ap = 0.0
+        for t in np.arange(0.0, 1.1, 0.1):
+            ap += (0 if np.sum(rec >= t) == 0 else np.max(prec[rec >= t])) / 11.0
+    else:
+        mrec, mpre = np.concatenate(([0.0], rec, [1.0])), np.concatenate(([0.0], prec, [0.0]))
+        for i in range(mpre.size - 1, 0, -1):
+            mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
+        i = np.where(mrec[1:] != mrec[:-1])[0]
+        ap = np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+    return rec, prec, ap, det_scores[order], (ovs, args)
+
+
 def assign_labels(anchors, gt_boxes, imgs_size=(1024, 1024), pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou_thr=0,
                   gt_max_assign_all=True, filter_invalid_anchors=True, filter_invalid_ious=True, sort_mode=None):
     """models/utils.py:33-147 restated on top of the oracle's box_iou_rotated (sort_mode: SORT_CPU to compare

@@ -49,6 +49,7 @@ SYMBOLS = {
     "s2a_box_iou_rotated": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "s2a_box_iou_rotated_pairs": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "s2a_polyiou_pairs": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "s2a_polyiou_match": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "s2a_assign_labels_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "s2a_assign_labels": (c_int, [c_vp, c_i64, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int,
                                   c_vp, c_vp, c_sz, c_vp]),

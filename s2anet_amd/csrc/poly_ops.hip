@@ -258,6 +258,40 @@ __global__ __launch_bounds__(kPolyThreads) void k_poly_heavy(const PolyBox* __re
   }
 }
 
+// voc_eval's inner search (DOTA_devkit/dota_evaluation_task1.py:204-263): for one detection, the ground-truth
+// polygon of its image with the largest polyiou among those whose axis-aligned boxes overlap it (the "+ 1"
+// pixel convention of :235-236); ovmax = -inf / index -1 when none does.  One thread per detection.
+__global__ __launch_bounds__(kPolyThreads) void k_poly_match(const double* __restrict__ dets8,
+                                                             const int32_t* __restrict__ det_img, int64_t D,
+                                                             const double* __restrict__ gts8,
+                                                             const int64_t* __restrict__ gt_off,
+                                                             double* __restrict__ ovmax, int64_t* __restrict__ argmax) {
+  __shared__ D2 s_p[kPMax * kPolyThreads];
+  __shared__ D2 s_t[kTmpMax * kPolyThreads];
+  const int64_t d = (int64_t)blockIdx.x * kPolyThreads + threadIdx.x;
+  if (d >= D) return;
+  const double* bb = dets8 + 8 * d;
+  const double px1 = fmin(fmin(bb[0], bb[2]), fmin(bb[4], bb[6])), py1 = fmin(fmin(bb[1], bb[3]), fmin(bb[5], bb[7]));
+  const double px2 = fmax(fmax(bb[0], bb[2]), fmax(bb[4], bb[6])), py2 = fmax(fmax(bb[1], bb[3]), fmax(bb[5], bb[7]));
+  double best = -INFINITY;
+  int64_t arg = -1;
+  const int32_t img = det_img[d];
+  for (int64_t g = gt_off[img]; g < gt_off[img + 1]; g++) {
+    const double* gt = gts8 + 8 * g;
+    const double gx1 = fmin(fmin(gt[0], gt[2]), fmin(gt[4], gt[6])), gy1 = fmin(fmin(gt[1], gt[3]), fmin(gt[5], gt[7]));
+    const double gx2 = fmax(fmax(gt[0], gt[2]), fmax(gt[4], gt[6])), gy2 = fmax(fmax(gt[1], gt[3]), fmax(gt[5], gt[7]));
+    const double iw = fmax(fmin(gx2, px2) - fmax(gx1, px1) + 1.0, 0.0);
+    const double ih = fmax(fmin(gy2, py2) - fmax(gy1, py1) + 1.0, 0.0);
+    const double inters = iw * ih;
+    const double uni = (px2 - px1 + 1.0) * (py2 - py1 + 1.0) + (gx2 - gx1 + 1.0) * (gy2 - gy1 + 1.0) - inters;
+    if (!(inters / uni > 0)) continue;                                       // :244
+    const double ov = poly_iou(gt, bb, s_p + threadIdx.x, s_t + threadIdx.x);   // iou_poly(GT, bb), :250
+    if (arg < 0 || ov > best) { best = ov; arg = g; }                        // np.max / first np.argmax
+  }
+  ovmax[d] = best;
+  argmax[d] = arg;
+}
+
 #undef P
 #undef T
 #define P(i) p[(i) * 64]
@@ -384,6 +418,18 @@ extern "C" int s2a_polyiou_pairs(const double* polys1, const double* polys2, int
   return S2A_OK;
 }
 
+
+extern "C" int s2a_polyiou_match(const double* dets8, const int32_t* det_image, int64_t num_dets, const double* gts8,
+                                 const int64_t* gt_offsets, int64_t num_images, double* ovmax, int64_t* argmax,
+                                 s2a_stream_t stream) {
+  S2A_CHECK_ARG(num_dets >= 0 && num_images >= 0, "polyiou_match: negative size");
+  if (num_dets == 0) return S2A_OK;
+  S2A_CHECK_ARG(dets8 && det_image && gt_offsets && ovmax && argmax && num_images > 0, "polyiou_match: NULL tensor");
+  k_poly_match<<<(unsigned)((num_dets + kPolyThreads - 1) / kPolyThreads), kPolyThreads, 0, as_stream(stream)>>>(
+      dets8, det_image, num_dets, gts8, gt_offsets, ovmax, argmax);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
 
 static size_t poly_pair_cap(int64_t n) {
   const size_t all = (size_t)n * (size_t)(n > 0 ? n - 1 : 0) / 2;

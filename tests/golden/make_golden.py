@@ -258,6 +258,58 @@ def gen_dcn(rng):
                         offset=off.numpy(), out_torch=out.numpy())
 
 
+def gen_voc_eval():
+    """DOTA Task-1 evaluation of one class by the reference's own voc_eval (dota_evaluation_task1.py), run on
+    synthetic detection / annotation files written to a scratch directory; the arrays and its rec / prec / ap are
+    the fixture.  (numpy >= 1.24 dropped the np.bool alias the script uses: restored for the call.)"""
+    import tempfile, shutil
+    rng = np.random.default_rng(1357)
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, os.path.join(REF, "DOTA_devkit"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref", "polyiou"))
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    import dota_evaluation_task1 as ev
+    n_img, cls = 12, "plane"
+    gt_polys, gt_img, gt_diff, det_polys, det_img, det_sc = [], [], [], [], [], []
+    for im in range(n_img):
+        ng = int(rng.integers(0, 9))
+        g = oracle.rboxes_to_polys(rand_boxes(rng, ng, span=600)) if ng else np.zeros((0, 8))
+        for q in g:
+            gt_polys.append(np.round(q, 1)); gt_img.append(im); gt_diff.append(int(rng.random() < 0.2))
+        for q in g:                                   # detections near the ground truth, some duplicated ...
+            for _ in range(int(rng.integers(0, 3))):
+                det_polys.append(np.round(q + rng.normal(0, 2.5, 8), 1)); det_img.append(im); det_sc.append(rng.random())
+        for q in oracle.rboxes_to_polys(rand_boxes(rng, int(rng.integers(0, 6)), span=600)):   # ... and false alarms
+            det_polys.append(np.round(q, 1)); det_img.append(im); det_sc.append(rng.random() * 0.8)
+    det_sc = np.round(np.array(det_sc) + np.arange(len(det_sc)) * 1e-6, 6)     # distinct confidences
+    tmp = tempfile.mkdtemp(prefix="s2a_voc_")
+    try:
+        names = ["P%04d" % i for i in range(n_img)]
+        open(os.path.join(tmp, "set.txt"), "w").write("\n".join(names) + "\n")
+        for im, nm in enumerate(names):
+            with open(os.path.join(tmp, nm + ".txt"), "w") as f:
+                for q, gi, d in zip(gt_polys, gt_img, gt_diff):
+                    if gi == im:
+                        f.write(" ".join("%.1f" % v for v in q) + " %s %d\n" % (cls, d))
+                f.write("1 2 3 4 5 6 7 8 ship 0\n")                              # another class: ignored
+        with open(os.path.join(tmp, "Task1_%s.txt" % cls), "w") as f:
+            for q, di, sc in zip(det_polys, det_img, det_sc):
+                f.write("%s %.6f " % (names[di], sc) + " ".join("%.1f" % v for v in q) + "\n")
+        out = {"det_polys": np.array(det_polys), "det_scores": det_sc, "det_image": np.array(det_img),
+               "gt_polys": np.array(gt_polys), "gt_image": np.array(gt_img), "gt_difficult": np.array(gt_diff),
+               "num_images": np.array(n_img)}
+        for tag, kw in (("default", {}), ("voc07", dict(use_07_metric=True)), ("hard", dict(is_filter_difficult=False)),
+                        ("thr07", dict(ovthresh=0.7))):
+            rec, prec, ap, sc = ev.voc_eval(os.path.join(tmp, "Task1_{:s}.txt"), os.path.join(tmp, "{:s}.txt"),
+                                            os.path.join(tmp, "set.txt"), cls, **kw)
+            out["rec_" + tag], out["prec_" + tag], out["ap_" + tag] = rec, prec, np.array(ap)
+            print("voc_eval", tag, "ap", float(ap), "dets", len(det_sc), "gts", len(gt_diff))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(OUT, "voc_eval.npz"), **out)
+
+
 def gen_assign_labels():
     """label assignment from the reference's own models/utils.py:assign_labels run on its CPU box_iou_rotated"""
     import_reference_python()
@@ -342,4 +394,5 @@ if __name__ == "__main__":
     gen_merge_nms()
     gen_dcn_backward()
     gen_assign_labels()
+    gen_voc_eval()
     print("done ->", OUT)

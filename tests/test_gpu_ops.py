@@ -689,3 +689,26 @@ def test_assign_labels_fused(rng):
     got = assign_labels(cu(a), cu(gt)).cpu().numpy()
     assert np.array_equal(got, oracle.assign_labels(a, gt))
     assert (got >= 0).sum() >= 50
+
+
+def test_voc_eval_on_gpu(rng):
+    """Task-1 evaluation with the overlap search on the GPU == the reference script's voc_eval (golden) and the oracle"""
+    from s2anet_amd.evaluate import voc_eval_arrays, polyiou_match
+    from test_oracle_pinned import VOC_CASES
+    g = golden("voc_eval.npz")
+    a = (g["det_polys"], g["det_scores"], g["det_image"], g["gt_polys"], g["gt_image"], g["gt_difficult"], int(g["num_images"]))
+    for tag, kw in VOC_CASES:
+        rec, prec, ap, _ = voc_eval_arrays(*a, device=dev(), **kw)
+        assert np.array_equal(rec, g["rec_" + tag]) and np.array_equal(prec, g["prec_" + tag]), tag
+        assert ap == float(g["ap_" + tag]), tag
+    # per-detection overlaps bit-exact against the oracle on a larger random case
+    n_img, D, G = 40, 3000, 600
+    gt = oracle.rboxes_to_polys(rand_rboxes(rng, G, span=500)); gi = np.sort(rng.integers(0, n_img, G))
+    dp = oracle.rboxes_to_polys(rand_rboxes(rng, D, span=500)); di = rng.integers(0, n_img, D)
+    sc = (rng.permutation(D) + 1.0) / (D + 1.0)
+    _, _, _, _, (ovs, args) = oracle.voc_eval_arrays(dp, sc, di, gt, gi, np.zeros(G), n_img)
+    order = np.argsort(-sc)
+    off = np.zeros(n_img + 1, np.int64); np.add.at(off, gi + 1, 1); off = np.cumsum(off)
+    ov, am = polyiou_match(cu(dp[order]), torch.from_numpy(di[order].astype(np.int32)).to(dev()), cu(gt),
+                           torch.from_numpy(off).to(dev()))
+    assert np.array_equal(ov.cpu().numpy(), ovs) and np.array_equal(am.cpu().numpy(), args)

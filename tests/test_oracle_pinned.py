@@ -124,6 +124,19 @@ def test_dcn_backward_oracle_matches_autograd_of_independent_formulation():
         assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
 
+VOC_CASES = (("default", {}), ("voc07", dict(use_07_metric=True)), ("hard", dict(is_filter_difficult=False)),
+             ("thr07", dict(ovthresh=0.7)))
+
+
+def test_voc_eval_matches_reference_script():
+    g = golden("voc_eval.npz")
+    a = (g["det_polys"], g["det_scores"], g["det_image"], g["gt_polys"], g["gt_image"], g["gt_difficult"], int(g["num_images"]))
+    for tag, kw in VOC_CASES:
+        rec, prec, ap, _, _ = oracle.voc_eval_arrays(*a, **kw)
+        assert np.array_equal(rec, g["rec_" + tag]) and np.array_equal(prec, g["prec_" + tag]), tag
+        assert ap == float(g["ap_" + tag]), tag
+
+
 ASSIGN_CASES = (("default", {}), ("first", dict(gt_max_assign_all=False)),
                 ("thr", dict(pos_iou_thr=0.3, neg_iou_thr=0.2, min_pos_iou_thr=0.1)), ("nofilter", dict(filter_invalid_anchors=False)))
 
