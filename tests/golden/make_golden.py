@@ -310,6 +310,48 @@ def gen_voc_eval():
     np.savez_compressed(os.path.join(OUT, "voc_eval.npz"), **out)
 
 
+def gen_merge_file():
+    """chip-merge of one class file by the reference's own mergesingle (ResultMerge_multi_process.py:180-243),
+    run on a synthetic result file in a scratch directory; input and output LINES are the fixture"""
+    import tempfile, shutil, warnings
+    rng = np.random.default_rng(8642)
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref", "polyiou"))
+    sh = types.ModuleType("shapely")
+    sh.geometry = types.ModuleType("shapely.geometry")
+    sys.modules.setdefault("shapely", sh)
+    sys.modules.setdefault("shapely.geometry", sh.geometry)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from DOTA_devkit.ResultMerge_multi_process import mergesingle, py_cpu_nms_poly_fast
+    lines = []
+    conf = iter(rng.permutation(np.arange(500, 10000))[:2000] / 10000.0)      # distinct confidences (ties: see DESIGN 2)
+    for img, rate in (("P0003", "1"), ("P0170", "0.5"), ("P0009", "1")):
+        r = float(rate)
+        objs = oracle.rboxes_to_polys(rand_boxes(rng, 120, span=1800))        # objects in original-image pixels
+        for cx, cy in ((0, 0), (824, 0), (0, 824), (824, 824)):               # 1024-px chips, 200 px overlap
+            for q in objs:
+                c = q.reshape(4, 2).mean(0) * r
+                if cx <= c[0] < cx + 1024 and cy <= c[1] < cy + 1024:         # every chip that sees the object reports it
+                    chip = q.reshape(4, 2) * r - np.array([cx, cy]) + rng.normal(0, 1.5, (4, 2))
+                    lines.append("%s__%s__%d___%d %.4f " % (img, rate, cx, cy, next(conf)) +
+                                 " ".join("%.4f" % v for v in chip.reshape(-1)))
+    order = rng.permutation(len(lines))
+    lines = [lines[i] for i in order]
+    tmp = tempfile.mkdtemp(prefix="s2a_merge_")
+    try:
+        src = os.path.join(tmp, "Task1_ship.txt")
+        open(src, "w").write("\n".join(lines) + "\n")
+        os.mkdir(os.path.join(tmp, "out"))
+        mergesingle(os.path.join(tmp, "out"), py_cpu_nms_poly_fast, src)
+        merged = open(os.path.join(tmp, "out", "Task1_ship.txt")).read().splitlines()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print("merge file:", len(lines), "->", len(merged))
+    np.savez_compressed(os.path.join(OUT, "merge_file.npz"), lines=np.array(lines), merged=np.array(merged))
+
+
 def gen_assign_labels():
     """label assignment from the reference's own models/utils.py:assign_labels run on its CPU box_iou_rotated"""
     import_reference_python()
@@ -395,4 +437,5 @@ if __name__ == "__main__":
     gen_dcn_backward()
     gen_assign_labels()
     gen_voc_eval()
+    gen_merge_file()
     print("done ->", OUT)

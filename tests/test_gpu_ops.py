@@ -712,3 +712,18 @@ def test_voc_eval_on_gpu(rng):
     ov, am = polyiou_match(cu(dp[order]), torch.from_numpy(di[order].astype(np.int32)).to(dev()), cu(gt),
                            torch.from_numpy(off).to(dev()))
     assert np.array_equal(ov.cpu().numpy(), ovs) and np.array_equal(am.cpu().numpy(), args)
+
+
+def test_chip_merge_file_matches_reference_script(tmp_path):
+    """mergesingle (chip-name parsing, poly2origpoly, per-image polygon NMS, output formatting) with the NMS on the
+    GPU produces the reference script's output file line for line"""
+    from s2anet_amd.merge import merge_lines, mergesingle, parse_chip_name
+    g = golden("merge_file.npz")
+    assert parse_chip_name("P0003__0.5__824___1648") == ("P0003", 824, 1648, "0.5")
+    lines = [str(x) for x in g["lines"]]
+    assert merge_lines(lines, 0.5, dev()) == [str(x) for x in g["merged"]]
+    src = tmp_path / "Task1_ship.txt"
+    src.write_text("\n".join(lines) + "\n")
+    (tmp_path / "out").mkdir()
+    mergesingle(str(tmp_path / "out"), str(src), 0.5, dev())
+    assert (tmp_path / "out" / "Task1_ship.txt").read_text().splitlines() == [str(x) for x in g["merged"]]
