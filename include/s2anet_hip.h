@@ -240,6 +240,9 @@ int s2a_align_conv_forward(const void* x, const float* anchors, const void* weig
  *   wh_ratio_clip = 1e-6) straight from the NCHW/NHWC prediction map:
  *   bbox_pred[B,5,H,W] (dtype/layout) -> refined[B,H,W,5] f32.
  * ------------------------------------------------------------------------- */
+/* Output side (val.py:40-52): rotated_box_to_poly_single (utils/general.py:886-921) + cv2.boxPoints for a
+ * whole batch: boxes rows (x,y,w,h,angle[,score...]) with row_stride floats -> polys[n,8] f32. */
+int s2a_rbox_to_poly(const float* boxes, int64_t n, int64_t row_stride, float* polys, s2a_stream_t stream);
 int s2a_delta2bbox_rotated(const float* rois, const float* deltas, int64_t n, float wh_ratio_clip,
                            float* out, s2a_stream_t stream);
 int s2a_fam_refine_anchors(const void* bbox_pred, int64_t batch, int64_t height, int64_t width,

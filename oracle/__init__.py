@@ -14,6 +14,7 @@ Two layers:
 Pinning status: see the header of s2a_oracle.cpp and tests/test_oracle_pinned.py.
 """
 import ctypes
+import math
 import os
 import subprocess
 
@@ -137,6 +138,27 @@ def polyiou(p8, q8):
     out = np.empty(p.shape[0], np.float64)
     lib().orc_polyiou_pairs(_p(p, ctypes.c_double), _p(q, ctypes.c_double), p.shape[0],
                             _p(out, ctypes.c_double))
+    return out
+
+
+def rbox_to_poly(boxes):
+    """rotated_box_to_poly_single (utils/general.py:886-921) with cv2.boxPoints restated from OpenCV 4.x
+    RotatedRect::points (OpenCV is absent here: parity unpinned for this helper) -> [N,8] float32"""
+    out = np.empty((len(boxes), 8), np.float32)
+    for i, r in enumerate(np.asarray(boxes, np.float32)):
+        x, y, w, h = (np.float32(v) for v in r[:4])
+        angle = float(r[4])
+        if angle < 0:
+            angle += math.pi
+        angle = (angle / math.pi) * 180
+        e1, e2 = (w, h)
+        if angle > 90:
+            angle, e1, e2 = angle - 90, h, w
+        rad = float(np.float32(angle)) * math.pi / 180.0
+        b, a = np.float32(math.cos(rad)) * np.float32(0.5), np.float32(math.sin(rad)) * np.float32(0.5)
+        p0x, p0y = x - a * e2 - b * e1, y + b * e2 - a * e1
+        p1x, p1y = x + a * e2 - b * e1, y - b * e2 - a * e1
+        out[i] = [p0x, p0y, p1x, p1y, 2 * x - p0x, 2 * y - p0y, 2 * x - p1x, 2 * y - p1y]
     return out
 
 

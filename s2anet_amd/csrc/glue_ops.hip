@@ -272,6 +272,50 @@ extern "C" int s2a_fam_refine_anchors_pyramid(const void* pred, int64_t row_stri
   return S2A_OK;
 }
 
+// rotated_box_to_poly_single (utils/general.py:886-921) for a whole batch: angle in [-pi/4, 3pi/4) -> the
+// OpenCV convention (degrees in [0, 90], edges swapped above 90), then cv2.boxPoints.  boxPoints is OpenCV's
+// RotatedRect::points (third-party, not in the reference tree; OpenCV 4.x modules/core/src/types.cpp), restated:
+// b = (float)cos(a)*0.5f, a = (float)sin(a)*0.5f in double-evaluated trig, corners in float.
+namespace s2a {
+namespace {
+__global__ void k_rbox_to_poly(const float* __restrict__ boxes, int64_t n, int64_t row_stride,
+                               float* __restrict__ polys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = boxes + i * row_stride;
+  const float x = r[0], y = r[1], w = r[2], h = r[3];
+  double angle = (double)r[4];
+  if (angle < 0) angle += 3.141592653589793;
+  angle = (angle / 3.141592653589793) * 180.0;
+  float e1 = w, e2 = h;
+  if (angle > 90) { angle -= 90; e1 = h; e2 = w; }
+  const float af = (float)angle;                      // RotatedRect stores the angle as float
+  const double rad = (double)af * 3.141592653589793 / 180.0;
+  const float b = (float)cos(rad) * 0.5f, a = (float)sin(rad) * 0.5f;
+  float p[8];
+  p[0] = x - a * e2 - b * e1;
+  p[1] = y + b * e2 - a * e1;
+  p[2] = x + a * e2 - b * e1;
+  p[3] = y - b * e2 - a * e1;
+  p[4] = 2 * x - p[0];
+  p[5] = 2 * y - p[1];
+  p[6] = 2 * x - p[2];
+  p[7] = 2 * y - p[3];
+#pragma unroll
+  for (int k = 0; k < 8; k++) polys[i * 8 + k] = p[k];
+}
+}  // namespace
+}  // namespace s2a
+
+extern "C" int s2a_rbox_to_poly(const float* boxes, int64_t n, int64_t row_stride, float* polys, s2a_stream_t stream) {
+  S2A_CHECK_ARG(n >= 0 && row_stride >= 5, "rbox_to_poly: bad argument");
+  if (n == 0) return S2A_OK;
+  S2A_CHECK_ARG(boxes && polys, "rbox_to_poly: NULL tensor");
+  k_rbox_to_poly<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(boxes, n, row_stride, polys);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
 extern "C" int s2a_align_offsets(const float* anchors, int64_t batch, int64_t height, int64_t width,
                                  float stride, int ksize, float* offset, s2a_stream_t stream) {
   S2A_CHECK_ARG(batch >= 0 && height >= 0 && width >= 0 && stride > 0 && ksize > 0 && (ksize & 1),

@@ -727,3 +727,24 @@ def test_chip_merge_file_matches_reference_script(tmp_path):
     (tmp_path / "out").mkdir()
     mergesingle(str(tmp_path / "out"), str(src), 0.5, dev())
     assert (tmp_path / "out" / "Task1_ship.txt").read_text().splitlines() == [str(x) for x in g["merged"]]
+
+
+def test_output_formats(rng):
+    """rbox -> polygon (boxPoints restated; OpenCV absent: checked against the oracle restatement and the geometry),
+    scale_coords_rotated, Task-1 lines"""
+    from s2anet_amd.formats import rbox_to_poly, scale_coords_rotated, task1_lines
+    b = rand_rboxes(rng, 500, span=900)
+    b[0] = [100, 50, 40, 20, 0.0]
+    b[1] = [100, 50, 40, 20, np.pi / 2 - 1e-3]
+    b[2] = [100, 50, 40, 20, -0.5]
+    got = rbox_to_poly(cu(b)).cpu().numpy()
+    ref = oracle.rbox_to_poly(b)
+    assert np.abs(got - ref).max() < 1e-3
+    # the polygon is the rectangle: same centre, edge lengths {w, h}, polyiou with the 4-corner form == 1
+    assert np.abs(got.reshape(-1, 4, 2).mean(1) - b[:, :2]).max() < 1e-2
+    assert np.abs(oracle.polyiou(got.astype(np.float64), oracle.rboxes_to_polys(b)) - 1).max() < 1e-4
+    d = torch.tensor([[110.0, 60, 40, 20, 0.3, 0.9], [510.0, 300, 80, 10, 1.2, 0.5]], device=dev())
+    s = scale_coords_rotated((1024, 1024), d.clone(), (2048, 1000))
+    assert torch.allclose(s[:, :4].cpu(), torch.tensor([[(110 - 262) / 0.5, 120, 80, 40], [(510 - 262) / 0.5, 600, 160, 20]]))
+    lines = task1_lines("P0001.png", d, torch.tensor([1, 0], device=dev()), ["plane", "ship"])
+    assert set(lines) == {"plane", "ship"} and lines["ship"][0].startswith("P0001 0.9000 ") and lines["ship"][0].count(" ") == 9
