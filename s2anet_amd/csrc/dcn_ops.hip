@@ -1077,20 +1077,25 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 // GEMM with the same pipeline (the bottleneck 1x1 layers and FPN laterals of the carrier).
 // OG = 64-channel output groups per workgroup (4, 2 or 1): with fewer than four groups the waves
 // split the 128 positions instead, so narrow layers still use all four MFMA waves.
-constexpr int kCPH = 10, kCPW = 18;                       // 8x16 positions + 1 halo
+constexpr int kCPW = 18;                                  // 16 positions + 1 halo each side
 
-template <int TAPS, int OG>
+// PH = 128-position blocks per workgroup (1: 8 x 16 tile, 256 threads, two workgroups per CU -- the default;
+// 2: 16 x 16 tile, 512 threads, one workgroup per CU: an experiment, see s2a_conv3x3_pyramid_f16)
+template <int TAPS, int OG, int PH = 1>
 struct ConvCfg {
-  static constexpr int kPix = TAPS == 9 ? kCPH * kCPW : 128;          // patch pixels
+  static constexpr int kTH = 8 * PH;                                   // tile rows (TAPS 9)
+  static constexpr int kPos = 128 * PH;                                // output positions per workgroup
+  static constexpr int kWaves = 4 * PH;
+  static constexpr int kPix = TAPS == 9 ? (kTH + 2) * kCPW : kPos;     // patch pixels
   static constexpr int kDma = (kPix * 9 + 63) / 64;                   // 1 KB LDS-DMA pieces per patch
   static constexpr int kPatchBytes = kDma * 1024;
   static constexpr int kOutRowB = OG * 128 + 16;                      // staged output row (bytes)
-  static constexpr int kLds = (2 * kPatchBytes > 128 * kOutRowB) ? 2 * kPatchBytes : 128 * kOutRowB;
-  static constexpr int kJ = (kDma + 3) / 4;                           // DMA pieces per wave
+  static constexpr int kLds = (2 * kPatchBytes > kPos * kOutRowB) ? 2 * kPatchBytes : kPos * kOutRowB;
+  static constexpr int kJ = (kDma + kWaves - 1) / kWaves;             // DMA pieces per wave
 };
 
-template <int TAPS, int OG>
-__global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict__ x_,
+template <int TAPS, int OG, int PH = 1>
+__global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _Float16* __restrict__ x_,
                                                      const _Float16* __restrict__ wfrag,
                                                      const _Float16* __restrict__ bias,
                                                      const _Float16* __restrict__ residual_,
@@ -1099,11 +1104,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
                                                      int relu, unsigned x_bytes_, LevelTab lt, int res_up) {
   using T = _Float16;
   using V = f16x8;
-  using Cfg = ConvCfg<TAPS, OG>;
+  using Cfg = ConvCfg<TAPS, OG, PH>;
   constexpr int NT = OG;              // 32-position tiles per wave
-  constexpr int WPG = 4 / OG;         // waves per out-channel group
+  constexpr int WPG = 4 / OG;         // waves per out-channel group (inside a 128-position block)
+  constexpr int kThreads_ = 256 * PH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave4 = wave & 3, blk = wave >> 2;     // wave inside its 128-position block, block index
   int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const T* x = x_;
   const T* residual = residual_;
@@ -1128,11 +1135,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
   }
   const int64_t HWo = (int64_t)Ho * Wo, HWi = (int64_t)H * W;
   // TAPS 9: 2-D tile of one image; TAPS 1: 128 consecutive output positions of the whole batch
-  const int txn = (Wo + 15) / 16, tyn = (Ho + 7) / 8;
+  const int txn = (Wo + 15) / 16, tyn = (Ho + Cfg::kTH - 1) / Cfg::kTH;
   const int64_t bimg = TAPS == 9 ? tile / (txn * tyn) : 0;
   const int trem = TAPS == 9 ? (int)(tile % (txn * tyn)) : 0;
-  const int ty0 = (trem / txn) * 8, tx0 = (trem % txn) * 16;
-  const int64_t g0 = tile * 128;
+  const int ty0 = (trem / txn) * Cfg::kTH, tx0 = (trem % txn) * 16;
+  const int64_t g0 = tile * Cfg::kPos;
   const int o0 = blockIdx.y * (64 * OG);
   const int Oloc = min(64 * OG, O - o0);
   const int CC = (C + 63) / 64, G = O / 64;
@@ -1148,7 +1155,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
   unsigned pvoff[Cfg::kJ];
 #pragma unroll
   for (int j = 0; j < Cfg::kJ; j++) {
-    int v = (wave_u + 4 * j) * 64 + lane, p = v / 9, q = v % 9;
+    int v = (wave_u + Cfg::kWaves * j) * 64 + lane, p = v / 9, q = v % 9;
     bool in = q < qlim && p < Cfg::kPix;
     int64_t pix = 0;
     if (TAPS == 9) {
@@ -1172,14 +1179,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
     char* P = smem + (cc & 1) * Cfg::kPatchBytes;
 #pragma unroll
     for (int j = 0; j < Cfg::kJ; j++) {
-      const int i = wave_u + 4 * j;
+      const int i = wave_u + Cfg::kWaves * j;
       if (i < Cfg::kDma)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(P + i * 1024), 16,
                                                  (int)pvoff[j], cc * 128, 0, 0);
     }
   };
 
-  const int grp = wave / WPG, sub = wave % WPG;       // out-channel group, position sub-range
+  const int grp = wave4 / WPG, sub = wave4 % WPG;     // out-channel group, position sub-range (inside the block)
   const bool wave_active = grp * 64 < Oloc;
   const int g = min(o0 / 64 + grp, G - 1);
   const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
@@ -1196,7 +1203,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
   int fbase[NT];
 #pragma unroll
   for (int b = 0; b < NT; b++) {
-    int pl = 32 * (sub * NT + b) + (lane & 31);
+    int pl = 128 * blk + 32 * (sub * NT + b) + (lane & 31);
     int pix = TAPS == 9 ? (pl >> 4) * kCPW + (pl & 15) : pl;
     fbase[b] = pix * kRowBytes + (lane >> 5) * 16;
   }
@@ -1293,14 +1300,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
             if (relu && !residual) v = fmaxf(v, 0.f);
             v4[e] = (_Float16)v;
           }
-          int pos = 32 * (sub * NT + b) + (lane & 31);
+          int pos = 128 * blk + 32 * (sub * NT + b) + (lane & 31);
           *reinterpret_cast<h4*>(s_out + pos * Cfg::kOutRowB + och * 2) = v4;
         }
       }
   }
   __syncthreads();
   constexpr int VPR = 8 * OG;                     // 16-byte vectors per output row
-  constexpr int NI = (128 * VPR) / 256;
+  constexpr int NI = (Cfg::kPos * VPR) / kThreads_;
   if (residual) {
     // all residual vectors of the tile in flight at once (bounds-checked buffer loads: no branch
     // around a load, so the compiler does not wait for each one before issuing the next)
@@ -1314,8 +1321,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
     const int64_t HWr = (int64_t)(Ho >> 1) * Wr;
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-      int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
-      int64_t gp = TAPS == 9 ? tile_pos(tile, pos, 8, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
+      int idx = tid + kThreads_ * i, pos = idx / VPR, col = idx % VPR;
+      int64_t gp = TAPS == 9 ? tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
       const bool ok = gp >= 0 && col * 8 < Oloc;
       off[i] = ok ? (unsigned)((gp * O + o0 + col * 8) * 2) : 0x80000000u;
       unsigned roff = off[i];
@@ -1328,7 +1335,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-      int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
+      int idx = tid + kThreads_ * i, pos = idx / VPR, col = idx % VPR;
       V v = *reinterpret_cast<const V*>(s_out + pos * Cfg::kOutRowB + col * 16);
 #pragma unroll
       for (int e = 0; e < 8; e++) {
@@ -1341,8 +1348,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_f16(const _Float16* __restrict_
   } else {
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-      int idx = tid + 256 * i, pos = idx / VPR, col = idx % VPR;
-      int64_t gp = TAPS == 9 ? tile_pos(tile, pos, 8, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
+      int idx = tid + kThreads_ * i, pos = idx / VPR, col = idx % VPR;
+      int64_t gp = TAPS == 9 ? tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
       if (gp >= 0 && col * 8 < Oloc)
         *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * Cfg::kOutRowB + col * 16);
     }
@@ -1644,19 +1651,19 @@ extern "C" int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count
 
 namespace s2a {
 namespace {
-template <int TAPS, int OG>
+template <int TAPS, int OG, int PH = 1>
 int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
                 _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
                 hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0, int res_up = 0) {
-  using Cfg = ConvCfg<TAPS, OG>;
+  using Cfg = ConvCfg<TAPS, OG, PH>;
   const int64_t Ntot = B * (int64_t)Ho * Wo;
-  int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + 7) / 8) : (Ntot + 127) / 128;
+  int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + Cfg::kTH - 1) / Cfg::kTH) : (Ntot + Cfg::kPos - 1) / Cfg::kPos;
   LevelTab lt = {};
   if (levels) { lt = *levels; tiles = level_tiles; }
   dim3 grid((unsigned)tiles, (unsigned)((O + 64 * OG - 1) / (64 * OG)));
-  auto kern = k_conv_f16<TAPS, OG>;
+  auto kern = k_conv_f16<TAPS, OG, PH>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + 512));
-  kern<<<grid, 256, Cfg::kLds + 512, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
+  kern<<<grid, 256 * PH, Cfg::kLds + 512, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
                                      (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
@@ -1732,8 +1739,8 @@ extern "C" int s2a_conv_pack_weight_f16(const void* weight, int64_t out_channels
 // ------------------------------------------------------------------ pyramid-packed launches
 namespace s2a {
 namespace {
-// tiles (8 x 16 positions) per level, pixel offsets; returns the total tile count or -1
-int64_t build_levels(const s2a_pyramid* pyr, int64_t batch, LevelTab* lt, int64_t* total_pix) {
+// tiles (tile_rows x 16 positions) per level, pixel offsets; returns the total tile count or -1
+int64_t build_levels(const s2a_pyramid* pyr, int64_t batch, LevelTab* lt, int64_t* total_pix, int tile_rows = 8) {
   if (!pyr || pyr->n_levels < 1 || pyr->n_levels > kMaxLevels) return -1;
   *lt = LevelTab{};
   lt->n = pyr->n_levels;
@@ -1744,7 +1751,7 @@ int64_t build_levels(const s2a_pyramid* pyr, int64_t batch, LevelTab* lt, int64_
     if (H < 1 || W < 1 || H >= 32000 || W >= 32000) return -1;
     lt->H[i] = (int)H; lt->W[i] = (int)W; lt->stride[i] = pyr->stride[i];
     lt->tile0[i] = (int)tiles; lt->pix0[i] = (int)pix;
-    tiles += batch * ((W + 15) / 16) * ((H + 7) / 8);
+    tiles += batch * ((W + 15) / 16) * ((H + tile_rows - 1) / tile_rows);
     pix += batch * H * W;
     if (tiles >= (1ll << 31) || pix >= (1ll << 31)) return -1;
   }
@@ -1766,7 +1773,11 @@ extern "C" int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, c
   S2A_CHECK_ARG((channels % 64 == 0 || channels == 32) && out_channels % 64 == 0,
                 "conv_pyramid: channels must be 32 or a multiple of 64, out_channels a multiple of 64");
   LevelTab lt; int64_t pix = 0;
-  const int64_t tiles = build_levels(pyr, batch, &lt, &pix);
+  // S2A_CONV_PH=2: 16 x 16 tiles on 512-thread workgroups (measured 4 % slower than two 8 x 16 workgroups per
+  // CU on MI355X: the filter fetches of the two position halves are not merged in the L1; kept as an A/B switch)
+  int ph = 1;
+  if (const char* f = getenv("S2A_CONV_PH")) ph = atoi(f) == 2 && out_channels % 256 == 0 && channels % 64 == 0 ? 2 : 1;
+  const int64_t tiles = build_levels(pyr, batch, &lt, &pix, 8 * ph);
   S2A_CHECK_ARG(tiles >= 0, "conv_pyramid: bad level table (1..8 levels, positive sizes)");
   S2A_CHECK_ARG((uint64_t)pix * channels * 2 < (1ull << 31), "conv_pyramid: input too large for 32-bit offsets");
   if (batch == 0) return S2A_OK;
@@ -1781,6 +1792,9 @@ extern "C" int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, c
                  *R = (const _Float16*)residual;
   _Float16* Y = (_Float16*)out;
 #define S2A_CONVP(OG_) launch_conv<9, OG_>(X, Wf, Bi, R, Y, batch, (int)channels, lt.H[0], lt.W[0], lt.H[0], lt.W[0], 1, (int)out_channels, relu, st, &lt, tiles)
+  if (ph == 2 && og == 4)
+    return launch_conv<9, 4, 2>(X, Wf, Bi, R, Y, batch, (int)channels, lt.H[0], lt.W[0], lt.H[0], lt.W[0], 1,
+                                (int)out_channels, relu, st, &lt, tiles);
   return og == 4 ? S2A_CONVP(4) : (og == 2 ? S2A_CONVP(2) : S2A_CONVP(1));
 #undef S2A_CONVP
 }
