@@ -1079,8 +1079,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 // split the 128 positions instead, so narrow layers still use all four MFMA waves.
 constexpr int kCPW = 18;                                  // 16 positions + 1 halo each side
 
-// PH = 128-position blocks per workgroup (1: 8 x 16 tile, 256 threads, two workgroups per CU -- the default;
-// 2: 16 x 16 tile, 512 threads, one workgroup per CU: an experiment, see s2a_conv3x3_pyramid_f16)
+// PH = 128-position blocks per workgroup (1: 8 x 16 tile, 256 threads, two workgroups per CU; 2: 16 x 16 tile,
+// 512 threads, one workgroup per CU, filter through LDS -- the pyramid-packed 256 -> 256 towers)
 template <int TAPS, int OG, int PH = 1>
 struct ConvCfg {
   static constexpr int kTH = 8 * PH;                                   // tile rows (TAPS 9)
@@ -1090,7 +1090,11 @@ struct ConvCfg {
   static constexpr int kDma = (kPix * 9 + 63) / 64;                   // 1 KB LDS-DMA pieces per patch
   static constexpr int kPatchBytes = kDma * 1024;
   static constexpr int kOutRowB = OG * 128 + 16;                      // staged output row (bytes)
-  static constexpr int kLds = (2 * kPatchBytes > kPos * kOutRowB) ? 2 * kPatchBytes : kPos * kOutRowB;
+  // PH = 2 (TAPS 9, OG 4): the filter of a tap (32 KB) is staged through LDS once per workgroup, two buffers
+  static constexpr bool kWLds = PH == 2 && TAPS == 9 && OG == 4;
+  static constexpr int kWBuf = 32768;
+  static constexpr int kLoop = 2 * kPatchBytes + (kWLds ? 2 * kWBuf : 0);
+  static constexpr int kLds = (kLoop > kPos * kOutRowB) ? kLoop : kPos * kOutRowB;
   static constexpr int kJ = (kDma + kWaves - 1) / kWaves;             // DMA pieces per wave
 };
 
@@ -1231,11 +1235,60 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     }
   };
 
+  const int nstage = TAPS * CC, last = nstage - 1;
+  if constexpr (Cfg::kWLds) {
+    // 16 x 16 tile, filter through LDS: every tap's 32 KB (this workgroup's 256 out channels, fragment order =
+    // contiguous) is DMA-ed once into one of two LDS buffers while the previous tap computes; all eight waves
+    // read their A fragments from there (ds_read_b128, lane-linear).  Halves the filter bytes a CU pulls per
+    // flop compared with two 8 x 16 workgroups; costs a barrier per tap.
+    char* wb = smem + 2 * Cfg::kPatchBytes;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(wfrag), 0, (int)((uint64_t)O * (uint64_t)(CC * 64) * 9 * 2), 0x00020000);
+    const int wbase = (o0 / 64) * 8192;
+    auto w_issue = [&](int s) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int piece = wave_u * 4 + j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wb + (s & 1) * Cfg::kWBuf + piece * 1024),
+                                                 16, piece * 1024 + lane * 16, s * G * 8192 + wbase, 0, 0);
+      }
+    };
+    auto compute_wl = [&](const char* P, int t, const char* Wb) {
+      const int toff = ((t / 3) * kCPW + (t % 3)) * kRowBytes;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        V pf[NT], wv[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) wv[a] = *reinterpret_cast<const V*>(Wb + (((grp * 2 + a) * 4 + kk) * 64 + lane) * 16);
+#pragma unroll
+        for (int b = 0; b < NT; b++) pf[b] = *reinterpret_cast<const V*>(P + fbase[b] + toff + kk * 32);
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < NT; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a], pf[b], acc[a][b], 0, 0, 0);
+      }
+    };
+    patch_issue(0);
+    w_issue(0);
+    if (tid < 64 * OG) s_bias[tid] = bias_v;
+    __syncthreads();
+    for (int cc = 0; cc < CC; cc++) {
+      const char* Pc = smem + (cc & 1) * Cfg::kPatchBytes;
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int s = cc * 9 + t;
+        if (s + 1 < nstage) w_issue(s + 1);
+        if (t == 0 && cc + 1 < CC) patch_issue(cc + 1);
+        compute_wl(Pc, t, wb + (s & 1) * Cfg::kWBuf);
+        __syncthreads();     // drains this tap's DMAs (vmcnt(0)) and frees the buffers they will overwrite next
+      }
+    }
+  } else {
   patch_issue(0);
   load_w(0, wA);
   if (tid < 64 * OG) s_bias[tid] = bias_v;
   __syncthreads();   // (the compiler drains the DMA with vmcnt(0) before the barrier)
-  const int nstage = TAPS * CC, last = nstage - 1;
   if constexpr (TAPS == 9) {
     for (int cc = 0; cc < CC; cc++) {
       const int s0 = cc * 9;
@@ -1280,6 +1333,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     if (cc < CC) { S2A_STAGE(cc, wA, wB) }
 #undef S2A_STAGE
   }
+  }   // !kWLds
 
   // ---- epilogue: bias (+ residual) + ReLU; tile staged through LDS, rows stored 16 B per lane
   char* s_out = smem;
@@ -1773,9 +1827,9 @@ extern "C" int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, c
   S2A_CHECK_ARG((channels % 64 == 0 || channels == 32) && out_channels % 64 == 0,
                 "conv_pyramid: channels must be 32 or a multiple of 64, out_channels a multiple of 64");
   LevelTab lt; int64_t pix = 0;
-  // S2A_CONV_PH=2: 16 x 16 tiles on 512-thread workgroups (measured 4 % slower than two 8 x 16 workgroups per
-  // CU on MI355X: the filter fetches of the two position halves are not merged in the L1; kept as an A/B switch)
-  int ph = 1;
+  // Full-width towers: 16 x 16 tiles on 512-thread workgroups with the filter staged once per workgroup through
+  // LDS (ConvCfg::kWLds) -- 4-7 % faster than two 8 x 16 workgroups per CU, bit-identical.  S2A_CONV_PH=1|2: A/B switch
+  int ph = (out_channels % 256 == 0 && channels % 64 == 0) ? 2 : 1;
   if (const char* f = getenv("S2A_CONV_PH")) ph = atoi(f) == 2 && out_channels % 256 == 0 && channels % 64 == 0 ? 2 : 1;
   const int64_t tiles = build_levels(pyr, batch, &lt, &pix, 8 * ph);
   S2A_CHECK_ARG(tiles >= 0, "conv_pyramid: bad level table (1..8 levels, positive sizes)");
