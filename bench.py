@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-fam-cls", action="store_true",
                     help="skip the FAM classification branch (unused at inference; the reference evaluates it)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="batches in flight: step i runs on HIP stream i %% S (independent batches; S > 1 lets the "
+                         "latency-bound NMS tail of one batch overlap the convolutions of the next)")
     return ap.parse_args()
 
 
@@ -82,7 +85,7 @@ def calibrate_cls_bias(model, imgs, target_per_chip, logit_std=1.5):
     return got
 
 
-def _time_launches(fn, iters):
+def _time_launches(fn, iters=100):
     """HIP events on the launching stream (torch's current stream) around `iters` launches"""
     for _ in range(3):
         fn()
@@ -106,7 +109,7 @@ def capture_head_operands(model, imgs):
     return cap if cap else None
 
 
-def measure_alignconv(model, batch, dtype, cap, iters=30):
+def measure_alignconv(model, batch, dtype, cap, iters=100):
     """dominant hand-written kernel of the path: the fused AlignConv launch exactly as the step issues it
     -- ONE pyramid-packed launch over the five FPN levels of the whole batch (21 824 positions per chip),
     on the step's own activations and refined anchors (the duration depends on the data: clocks).
@@ -150,6 +153,8 @@ def measure_alignconv(model, batch, dtype, cap, iters=30):
     return {
         "kernel": "%s (fused AlignConv: anchors -> sampling -> 3x3 contraction -> ReLU; %s, batch %d, %s)"
                   % (kname, shape, batch, "f16" if es == 2 else "f32"),
+        "timing": "%d back-to-back launches of the step's own launch on one stream, alone on the GPU (HIP events); inside "
+                  "the timed region the kernels of the batches in flight overlap and each takes longer" % iters,
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(ach / peak, 4), "traffic": traffic,
         "avg_launch_us": round(sec * 1e6, 1),
@@ -160,7 +165,7 @@ def measure_alignconv(model, batch, dtype, cap, iters=30):
     }
 
 
-def measure_conv_tower(model, cap, iters=30):
+def measure_conv_tower(model, cap, iters=100):
     """the kernel with the largest share of the step: the patch-staged 3x3 convolution of the head towers
     (256 -> 256 + bias + ReLU), as the step issues it -- one pyramid-packed launch on the step's FPN features"""
     from s2anet_amd import pyramid as P
@@ -169,8 +174,9 @@ def measure_conv_tower(model, cap, iters=30):
     sec = _time_launches(lambda: P.conv3x3(layout, x, w, b, o, relu=True), iters)
     flops = 2.0 * 256 * 2304 * layout.pixels
     ach = flops / sec / 1e12
-    return {"kernel": "k_conv_f16<9,4> (head conv tower 3x3 256->256 + bias + ReLU; five FPN levels pyramid-packed, "
+    return {"kernel": "k_conv_f16<9,4,2> (head conv tower 3x3 256->256 + bias + ReLU; five FPN levels pyramid-packed, "
                       "%d positions, f16)" % layout.pixels,
+            "timing": "%d back-to-back launches of the step's own launch, alone on the GPU" % iters,
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(sec * 1e6, 1),
             "flops_per_launch": flops}
@@ -254,6 +260,8 @@ def cpu_baseline(seed, candidates):
 
 def main():
     args = parse()
+    if args.graph:
+        args.streams = 1                 # graph replay is the single-stream experiment
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -285,18 +293,35 @@ def main():
     imgs = imgs.contiguous(memory_format=torch.channels_last)
     got = calibrate_cls_bias(model, imgs, args.candidates)
     max_cand = int(min(B * 5344 * NUM_CLASSES, max(4 * args.candidates * B, 65536)))
-    gather = DetectionGather(world, B, model.head.max_per_img, dev) if world > 1 else None
+    # one gather object (output buffer) per batch in flight
+    gathers = [DetectionGather(world, B, model.head.max_per_img, dev) for _ in range(max(args.streams, 1))] if world > 1 else None
+    slot = [0]
 
     def step():
         dets, labels, counts = model.detect(imgs, max_candidates=max_cand)
-        if gather is not None:
-            return gather(dets, labels, counts)
+        if gathers is not None:
+            return gathers[slot[0] % len(gathers)](dets, labels, counts)
         return dets, labels, counts
 
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
     runner = step
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    if streams:
+        assert not args.graph, "--streams and --graph are separate experiments"
+        for st in streams:                                   # per-stream workspaces and allocator pools warm
+            with torch.cuda.stream(st):
+                for _ in range(2):
+                    out = step()
+        torch.cuda.synchronize()
+        turn = [0]
+
+        def runner():
+            slot[0] = turn[0] % len(streams)
+            with torch.cuda.stream(streams[slot[0]]):
+                step()
+            turn[0] += 1
     if args.graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -332,11 +357,13 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[2]: full R-50-FPN S2ANet inference, batch %d of 1024x1024 synthetic "
-                        "uint8 chips per GPU%s" % (B, "" if world == 1 else ", detections all-gathered over RCCL"),
+                        "uint8 chips per GPU%s%s" % (B, "" if world == 1 else ", detections all-gathered over RCCL",
+                                                     "" if args.streams == 1 else "; %d independent batches in flight on %d HIP streams"
+                                                     % (args.streams, args.streams)),
             "chips_per_gpu_per_step": B, "global_batch": world * B, "num_classes": NUM_CLASSES,
             "weights": "seeded random init of the reference architecture; odm_cls bias calibrated",
             "nms_candidates_per_chip": round(got, 1), "detections_per_chip": round(counts.float().mean().item(), 1),
-            "fam_cls_branch": not args.no_fam_cls, "hip_graph": bool(args.graph),
+            "fam_cls_branch": not args.no_fam_cls, "hip_graph": bool(args.graph), "batches_in_flight": args.streams,
             "parallelism": "dp%d (one process per GPU)" % world,
         },
     }
