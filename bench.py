@@ -310,7 +310,8 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     if streams:
         assert not args.graph, "--streams and --graph are separate experiments"
-        for st in streams:                                   # per-stream workspaces and allocator pools warm
+        for k, st in enumerate(streams):                     # per-stream workspaces and allocator pools warm
+            slot[0] = k
             with torch.cuda.stream(st):
                 for _ in range(2):
                     out = step()
