@@ -748,3 +748,66 @@ def test_output_formats(rng):
     assert torch.allclose(s[:, :4].cpu(), torch.tensor([[(110 - 262) / 0.5, 120, 80, 40], [(510 - 262) / 0.5, 600, 160, 20]]))
     lines = task1_lines("P0001.png", d, torch.tensor([1, 0], device=dev()), ["plane", "ship"])
     assert set(lines) == {"plane", "ship"} and lines["ship"][0].startswith("P0001 0.9000 ") and lines["ship"][0].count(" ") == 9
+
+
+# ---------------------------------------------------------------- BASELINE.json full sizes: size-independent properties
+def test_full_size_iou_10k_x_10k(rng):
+    """config 1: 10 000 x 10 000 rotated IoU -- range, sparsity, self-overlap, and 30 000 sampled entries bit-exact
+    against the oracle (the oracle cannot do 10^8 pairs in test time)"""
+    import s2anet_amd as S
+    b1, b2 = rand_rboxes(rng, 10000, span=1024), rand_rboxes(rng, 10000, span=1024)
+    iou = S.box_iou_rotated(cu(b1), cu(b2))
+    assert iou.shape == (10000, 10000)
+    assert iou.min().item() >= 0.0 and iou.max().item() <= 1.0 + 1e-5
+    frac = (iou > 0).float().mean().item()
+    assert 0.003 < frac < 0.03                                       # ~1.1 % of DOTA-like pairs overlap
+    ii, jj = rng.integers(0, 10000, 30000), rng.integers(0, 10000, 30000)
+    nz = (iou > 0).nonzero()[:15000].cpu().numpy()                   # plus 15 000 overlapping ones
+    ii, jj = np.concatenate([ii, nz[:, 0]]), np.concatenate([jj, nz[:, 1]])
+    ref = oracle.iou_pairs(b1[ii], b2[jj], sort_mode=oracle.SORT_GPU)
+    got = iou[torch.from_numpy(ii).to(dev()), torch.from_numpy(jj).to(dev())].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    from s2anet_amd.rotated import box_iou_rotated_pairs
+    self_iou = box_iou_rotated_pairs(cu(b1[:4000]), cu(b1[:4000])).cpu().numpy()
+    assert np.abs(self_iou - 1).max() < 1e-4
+
+
+def test_full_size_ml_nms_200k(rng):
+    """config 5: 200 000 rows x 15 labels -- descending order, idempotence, per-label decomposition"""
+    import s2anet_amd as S
+    from s2anet_amd.rotated import nms_rotated_raw
+    n = 200000
+    d, s = rand_rboxes(rng, n, span=1024), distinct_scores(rng, n)
+    lab = rng.integers(0, 15, n).astype(np.float32)
+    D, Sc, Lb = cu(d), cu(s), cu(lab)
+    k = S.ml_nms_rotated(D, Sc, Lb, 0.5)
+    assert 100000 < k.numel() < n
+    ks = Sc[k]
+    assert (ks[1:] < ks[:-1]).all()
+    k2 = S.ml_nms_rotated(D[k], Sc[k], Lb[k], 0.5)
+    assert k2.numel() == k.numel() and (k2 == torch.arange(k.numel(), device=k.device)).all()
+    kept = torch.zeros(n, dtype=torch.bool, device=dev())
+    kept[k] = True
+    for c in (0, 7, 14):
+        idx = (Lb == c).nonzero()[:, 0]
+        kc = idx[nms_rotated_raw(D[idx], Sc[idx], 0.5)]
+        assert torch.equal(torch.sort(kc)[0], idx[kept[idx]])
+
+
+def test_full_size_alignconv_zero_offset_identity():
+    """config 2 at batch 8: anchors that sit on the sampling grid (centre = index * stride, side 3 * stride, angle 0)
+    give zero offsets, so AlignConv == 3x3 convolution + ReLU (SURVEY 8(c) ii) at the full P3 size, f16"""
+    from s2anet_amd.alignconv import align_conv_forward
+    from s2anet_amd.fused import conv_f16, conv_pack_weight
+    B, C, H, W, O, st = 8, 256, 128, 128, 256, 8
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(O, C, 3, 3, generator=g) * 0.02).to(dev()).half()
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    anc = torch.zeros(B, H, W, 5)
+    anc[..., 0], anc[..., 1], anc[..., 2], anc[..., 3] = xs * st, ys * st, 3.0 * st, 3.0 * st
+    out = align_conv_forward(x, anc.to(dev()), w, st, relu=True)
+    ref = conv_f16(x, conv_pack_weight(w), None, O, 3, 1, True)
+    assert out.shape == ref.shape
+    d = (out.float() - ref.float()).abs()
+    assert d.max().item() < 2e-2 and (d > 0).float().mean().item() < 0.05
