@@ -308,6 +308,24 @@ __global__ void k_zero_words(unsigned long long* __restrict__ mask,
     mask[i] = 0ull;
 }
 
+// Word-occupancy bitmap of the suppression mask: bit w of a row's occupancy says "mask word w of this row is
+// non-zero".  The mask of a big segment is sparse (a box overlaps few others), and the greedy scan only has to
+// OR the non-zero words of the rows it keeps -- instead of sweeping every word of every kept row from HBM.
+// Row p (sorted position) owns occupancy words [ (row_base[p] >> 6) + p, ... + ceil(B/64) ): consecutive rows
+// are floor(B/64)+1 apart, so the ranges never overlap.
+__host__ __device__ inline unsigned long long occ_words_for(unsigned long long mask_words, unsigned long long n) {
+  return mask_words / 64 + n + 64;
+}
+__global__ void k_zero_occ(unsigned long long* __restrict__ occ, const unsigned long long* __restrict__ total_ptr,
+                           unsigned long long bound, unsigned long long n) {
+  unsigned long long total = *total_ptr;
+  if (total > bound) total = bound;
+  const unsigned long long cnt = total / 64 + n + 64;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt;
+       i += (unsigned long long)gridDim.x * blockDim.x)
+    occ[i] = 0ull;
+}
+
 struct TileRef {
   uint32_t seg_start, ns, rb, cb;
 };
@@ -339,7 +357,11 @@ __device__ __forceinline__ TileRef locate_tile(unsigned long long tile,
   return t;
 }
 
-// CULL over upper-triangle tiles (persistent grid).  thread = (row = tid&63, 16 columns).
+// CULL over upper-triangle tiles (persistent grid).  thread = (row = tid&63, 16 columns).  Every workgroup
+// walks a CONTIGUOUS run of tile ids: inside a segment consecutive ids share their row block (the 64 row boxes
+// stay in registers) and only step the column block, whose 64 boxes are fetched one tile ahead into the other
+// half of a double-buffered LDS array -- one barrier per tile and no exposed load latency (the per-tile
+// locate + two barriers + cold loads of the first version made the 200 k-row case latency-bound: 3.8 ms).
 __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict__ sorted,
                                                        const uint32_t* __restrict__ seg_start,
                                                        const uint32_t* __restrict__ num_seg,
@@ -349,36 +371,72 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
                                                        unsigned long long cap) {
   __shared__ uint2 s_q[kLdsQueue];
   __shared__ unsigned s_count, s_base[2];
-  __shared__ PreBox s_col[64];
+  __shared__ PreBox s_col[2][64];
   PairQueue Q{s_q, &s_count, s_base};
   if (threadIdx.x == 0) s_count = 0;
-  __syncthreads();
   const uint32_t S = *num_seg;
   const unsigned long long T = tile_off[S];
+  const unsigned long long chunk = (T + gridDim.x - 1) / gridDim.x;
+  unsigned long long tile = (unsigned long long)blockIdx.x * chunk;
+  const unsigned long long tend = min(T, tile + chunk);
   const int row = threadIdx.x & 63, quarter = threadIdx.x >> 6;
-  for (unsigned long long tile = blockIdx.x; tile < T; tile += gridDim.x) {
-    TileRef t = locate_tile(tile, tile_off, seg_start, S);
-    if (threadIdx.x < 64) {
-      uint32_t jl = t.cb * 64 + threadIdx.x;
-      PreBox b = {};
-      if (jl < t.ns) b = sorted[t.seg_start + jl];
-      s_col[threadIdx.x] = b;
+  auto col_box = [&](const TileRef& t) {
+    PreBox b = {};
+    uint32_t jl = t.cb * 64 + threadIdx.x;
+    if (jl < t.ns) b = sorted[t.seg_start + jl];
+    return b;
+  };
+  // next tile id -> its (segment, row block, column block): a step of the column block while the row of the
+  // triangle lasts, a fresh locate otherwise (new row block or new segment)
+  auto advance = [&](const TileRef& t, unsigned long long next_tile) {
+    const uint32_t Bt = (t.ns + 63) / 64;
+    if (t.cb + 1 < Bt) { TileRef n = t; n.cb = t.cb + 1; return n; }
+    return locate_tile(next_tile, tile_off, seg_start, S);
+  };
+  if (tile >= tend) { __syncthreads(); queue_flush(Q, gq, gcount, cap); return; }
+  TileRef t = locate_tile(tile, tile_off, seg_start, S);
+  if (threadIdx.x < 64) s_col[0][threadIdx.x] = col_box(t);
+  __syncthreads();
+  int cur = 0;
+  uint32_t a_seg = 0xffffffffu, a_rb = 0xffffffffu;
+  PreBox a = {};
+  for (; tile < tend; tile++) {
+    const bool has_next = tile + 1 < tend;
+    TileRef tn = t;
+    PreBox nb = {};
+    if (has_next) {
+      tn = advance(t, tile + 1);
+      if (threadIdx.x < 64) nb = col_box(tn);          // in flight under this tile's tests
     }
-    __syncthreads();
-    uint32_t il = t.rb * 64 + row;
+    const uint32_t il = t.rb * 64 + row;
+    if (a_seg != t.seg_start || a_rb != t.rb) {         // (uniform) new row block
+      a_seg = t.seg_start; a_rb = t.rb;
+      if (il < t.ns) a = sorted[t.seg_start + il];
+    }
     if (il < t.ns) {
-      const PreBox a = sorted[t.seg_start + il];
-#pragma unroll 4
+      // two passes: the cheap circle test for all 16 columns first (a bit per survivor), then the separating-
+      // axis test only on the survivors -- about 3 % of the pairs, so the second loop runs max-popcount (2-4)
+      // times per wave instead of once per column (a wave with ANY surviving lane used to pay for the SAT)
+      unsigned m16 = 0;
+#pragma unroll
       for (int c = 0; c < 16; c++) {
-        int cc = quarter * 16 + c;
-        uint32_t jl = t.cb * 64 + cc;
-        if (jl < t.ns && jl > il && !surely_disjoint(a.x, a.y, a.r, s_col[cc].x, s_col[cc].y, s_col[cc].r) &&
-            !sat_disjoint(a, s_col[cc]))
-          queue_push(Q, t.seg_start + il, t.seg_start + jl);
+        const int cc = quarter * 16 + c;
+        const uint32_t jl = t.cb * 64 + cc;
+        if (jl < t.ns && jl > il && !surely_disjoint(a.x, a.y, a.r, s_col[cur][cc].x, s_col[cur][cc].y, s_col[cur][cc].r))
+          m16 |= 1u << c;
+      }
+      while (m16) {
+        const int c = __builtin_ctz(m16);
+        m16 &= m16 - 1;
+        const int cc = quarter * 16 + c;
+        if (!sat_disjoint(a, s_col[cur][cc])) queue_push(Q, t.seg_start + il, t.seg_start + t.cb * 64 + cc);
       }
     }
+    if (has_next && threadIdx.x < 64) s_col[cur ^ 1][threadIdx.x] = nb;
     __syncthreads();
     if (s_count > kFlushAt) queue_flush(Q, gq, gcount, cap);
+    cur ^= 1;
+    t = tn;
   }
   queue_flush(Q, gq, gcount, cap);
 }
@@ -391,7 +449,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict
                                                         unsigned long long cap,
                                                         unsigned long long* __restrict__ mask,
                                                         const unsigned long long* __restrict__ words_total,
-                                                        unsigned long long words_bound) {
+                                                        unsigned long long words_bound,
+                                                        unsigned long long* __restrict__ occ) {
   __shared__ float2 s_pts[24 * kThreads];
   if (*words_total > words_bound) return;  // caller's per-segment promise broken: see k_nms_scan
   unsigned long long total = *gcount;
@@ -404,7 +463,9 @@ __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict
     float v = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
     if (v > thr) {  // reference GPU rule: strict (ml_nms cuda.cu:63-64)
       uint32_t jl = local_idx[ij.y];
-      atomicOr(&mask[row_base[ij.x] + (jl >> 6)], 1ull << (jl & 63));
+      const unsigned long long rb = row_base[ij.x];
+      atomicOr(&mask[rb + (jl >> 6)], 1ull << (jl & 63));
+      if (occ) atomicOr(&occ[(rb >> 6) + ij.x + (jl >> 12)], 1ull << ((jl >> 6) & 63));
     }
   }
 }
@@ -421,7 +482,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_direct(const PreBox* __restric
                                                          unsigned long long cap,
                                                          unsigned long long* __restrict__ mask,
                                                          const unsigned long long* __restrict__ words_total,
-                                                         unsigned long long words_bound) {
+                                                         unsigned long long words_bound,
+                                                         unsigned long long* __restrict__ occ) {
   if (*gcount <= cap || *words_total > words_bound) return;
   __shared__ float2 s_pts[24 * kThreads];
   const uint32_t S = *num_seg;
@@ -443,7 +505,11 @@ __global__ __launch_bounds__(kThreads) void k_nms_direct(const PreBox* __restric
           bits |= 1ull << cc;
       }
     }
-    if (bits) atomicOr(&mask[row_base[t.seg_start + il] + t.cb], bits);
+    if (bits) {
+      const unsigned long long rb = row_base[t.seg_start + il];
+      atomicOr(&mask[rb + t.cb], bits);
+      if (occ) atomicOr(&occ[(rb >> 6) + t.seg_start + il + (t.cb >> 6)], 1ull << (t.cb & 63));
+    }
   }
 }
 
@@ -459,7 +525,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
                                                        uint32_t max_blocks,
                                                        const unsigned long long* __restrict__ words_total,
                                                        unsigned long long words_bound,
-                                                       uint32_t* __restrict__ status) {
+                                                       uint32_t* __restrict__ status,
+                                                       const unsigned long long* __restrict__ occ) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_remv[];  // max_blocks + 2 | mask cache
   unsigned long long* s_keep = s_remv + max_blocks;
   unsigned long long* s_mask = s_remv + max_blocks + 10;  // kScanCacheWords words (after keep[1] + rows[8] + pad)
@@ -524,6 +591,25 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
       // vector.  The four waves split the kept rows (every 4th each, four loads in flight per lane);
       // lanes walk consecutive words of a row (coalesced); partial ORs meet in LDS (ds_or_b64).
       const int nk = __popcll(*s_keep);
+      if (!cached && occ) {
+        // big segment: visit only the non-zero words of the kept rows (occupancy bitmap), columns > b
+        const uint32_t OW = (B + 63) >> 6;
+        const unsigned long long seg_off = mask_off[s];
+        for (uint32_t item = threadIdx.x; item < (uint32_t)nk * OW; item += kThreads) {
+          const uint32_t k = item / OW, q = item % OW;
+          const uint32_t rowl = b * 64 + s_rows[k];
+          unsigned long long o = occ[((seg_off + (unsigned long long)rowl * B) >> 6) + st + rowl + q];
+          if (q < (b >> 6)) o = 0ull;
+          else if (q == (b >> 6)) o &= ~((2ull << (b & 63)) - 1ull);
+          while (o) {
+            const uint32_t c = q * 64 + (uint32_t)__builtin_ctzll(o);
+            o &= o - 1ull;
+            atomicOr(&s_remv[c], M[(unsigned long long)rowl * B + c]);
+          }
+        }
+        __syncthreads();
+        continue;
+      }
       for (uint32_t c0 = b + 1; c0 < B; c0 += 64) {
         const uint32_t c = c0 + lane;
         const bool cv = c < B;
@@ -626,7 +712,7 @@ struct NmsBuffers {
   unsigned long long *key1a, *key1b;
   int32_t *idxa, *perm_glob, *perm_seg;
   uint32_t *key2a, *key2s, *head, *segidx1, *seg_start, *num_seg, *local_idx, *nblk;
-  unsigned long long *words, *tiles, *mask_off, *tile_off, *row_base, *gcount, *mask;
+  unsigned long long *words, *tiles, *mask_off, *tile_off, *row_base, *gcount, *mask, *occ;
   PreBox* sorted;
   uint2* gq;
   uint8_t *keep_orig, *flag_glob;
@@ -692,7 +778,8 @@ void nms_carve(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
   B->flag_glob = cv.take<uint8_t>(sz);
   B->rp_temp = cv.take<char>(pl.rocprim_bytes);
   B->gq = cv.take<uint2>(pl.queue_cap);
-  B->mask = cv.take<unsigned long long>(pl.mask_words);
+  B->mask = cv.take<unsigned long long>(pl.mask_words + occ_words_for(pl.mask_words, (unsigned long long)n));
+  B->occ = B->mask ? B->mask + pl.mask_words : nullptr;
 }
 
 inline unsigned grid_for(int64_t n, int threads = 256) { return (unsigned)((n + threads - 1) / threads); }
@@ -745,19 +832,20 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   // the kernels.  k_zero_words needs the total: mask_off is an exclusive scan over n+1 entries
   // whose tail is constant (= total), so entry n holds it.
   k_zero_words<<<kPersistentGrid, 256, 0, st>>>(B.mask, B.mask_off + n, pl.mask_words);
+  k_zero_occ<<<kPersistentGrid, 256, 0, st>>>(B.occ, B.mask_off + n, pl.mask_words, (unsigned long long)n);
   k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.tile_off, B.gq,
                                                    B.gcount, pl.queue_cap);
   k_nms_heavy<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, B.local_idx, B.row_base, thr, B.gq,
                                                     B.gcount, pl.queue_cap, B.mask, B.mask_off + n,
-                                                    pl.mask_words);
+                                                    pl.mask_words, B.occ);
   k_nms_direct<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.tile_off,
                                                      B.row_base, thr, B.gcount, pl.queue_cap, B.mask,
-                                                     B.mask_off + n, pl.mask_words);
+                                                     B.mask_off + n, pl.mask_words, B.occ);
   size_t lds = ((size_t)pl.max_blocks + 10 + kScanCacheWords) * sizeof(unsigned long long);
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   k_nms_scan<<<512, kThreads, lds, st>>>(B.mask, B.seg_start, B.num_seg, B.mask_off, B.nblk, B.perm_seg,
                                          B.keep_orig, pl.max_blocks, B.mask_off + n, pl.mask_words,
-                                         reinterpret_cast<uint32_t*>(B.gcount + 1));
+                                         reinterpret_cast<uint32_t*>(B.gcount + 1), B.occ);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -822,7 +910,7 @@ int launch_nms_scan(const unsigned long long* mask, const uint32_t* seg_start, c
   size_t lds = ((size_t)max_blocks + 10 + kScanCacheWords) * sizeof(unsigned long long);
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   k_nms_scan<<<512, kThreads, lds, st>>>(mask, seg_start, num_seg, mask_off, nblk, perm_seg, keep_orig, max_blocks,
-                                         words_total, words_bound, status);
+                                         words_total, words_bound, status, nullptr);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -1176,14 +1264,20 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
     return S2A_EWORKSPACE;
   }
   size_t rest = workspace_bytes - cv.off;
-  size_t want_q = (size_t)pl.queue_cap * sizeof(uint2), want_m = (size_t)pl.mask_words * 8;
+  size_t want_q = (size_t)pl.queue_cap * sizeof(uint2),
+         want_m = (size_t)(pl.mask_words + occ_words_for(pl.mask_words, (unsigned long long)n)) * 8;
   size_t qbytes = std::min(want_q, rest / 4);
   qbytes = qbytes / 256 * 256;
   size_t mbytes = std::min(want_m, (rest - qbytes) / 256 * 256);
   pl.queue_cap = qbytes / sizeof(uint2);
-  pl.mask_words = mbytes / 8;
+  {
+    // mbytes hold the mask AND its word-occupancy bitmap (mask_words / 64 + n + 64 words)
+    const unsigned long long W = mbytes / 8, fixed_occ = (unsigned long long)n + 64;
+    pl.mask_words = W > fixed_occ ? (W - fixed_occ) * 64 / 65 : 0;
+  }
   B.gq = reinterpret_cast<uint2*>(static_cast<char*>(workspace) + cv.off);
   B.mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + cv.off + qbytes);
+  B.occ = B.mask + pl.mask_words;
   // the mask bound must cover n * ceil(max_seg/64): recover the implied max segment size
   unsigned long long nb = pl.mask_words / (unsigned long long)n;
   S2A_CHECK_ARG(nb >= 1, "nms_rotated_segmented: workspace too small for the suppression mask");
