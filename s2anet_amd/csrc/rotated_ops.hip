@@ -94,8 +94,10 @@ __device__ __forceinline__ void queue_flush(PairQueue& Q, uint2* __restrict__ gq
 // the cull are also queued and overwritten by the heavy pass (same stream, later kernel).  Row boxes
 // are staged in LDS and read one iteration ahead so no row waits on a load.  HBM-write-bound.
 constexpr int kIouRowsPerWg = 64;
-constexpr int kIouQueue = 3072;      // LDS pair queue of this kernel (<= 1024 pushes per row)
+constexpr int kIouQueue = 3072;      // LDS pair queue of this kernel (survivors of BOTH tests)
 constexpr int kIouFlushAt = 2048;
+constexpr int kIouQ1 = 6144;         // first-stage queue: circle-test survivors, (row << 10 | column) per entry
+constexpr int kIouQ1FlushAt = 4096;  // <= 2048 pushes per two rows on top of this
 
 __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict__ P1,
                                                        const PreBox* __restrict__ P2,
@@ -105,33 +107,56 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
                                                        unsigned long long* __restrict__ gcount,
                                                        unsigned long long cap) {
   __shared__ uint2 s_q[kIouQueue];
-  __shared__ unsigned s_count, s_base[2];
+  __shared__ unsigned s_count, s_base[2], s_cnt1;
   __shared__ PreBox s_rows[kIouRowsPerWg];
+  __shared__ PreBox s_cols[kThreads * 4];
+  __shared__ unsigned short s_q1[kIouQ1];
   PairQueue Q{s_q, &s_count, s_base};
-  if (threadIdx.x == 0) s_count = 0;
+  if (threadIdx.x == 0) { s_count = 0; s_cnt1 = 0; }
 
-  const int64_t j0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+  const int64_t jw = (int64_t)blockIdx.x * kThreads * 4;          // first column of the workgroup
+  const int64_t j0 = jw + threadIdx.x * 4;
   const int64_t rbeg = row0 + (int64_t)blockIdx.y * kIouRowsPerWg;
   const int nrows = (int)min((int64_t)kIouRowsPerWg, row1 - rbeg);
   if (threadIdx.x < nrows) s_rows[threadIdx.x] = P1[rbeg + threadIdx.x];
-  PreBox Bj[4];
+  float bx[4], by[4], br[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    Bj[k] = {};
-    if (j0 + k < m) Bj[k] = P2[j0 + k];
+    PreBox b = {};
+    if (j0 + k < m) b = P2[j0 + k];
+    s_cols[threadIdx.x * 4 + k] = b;
+    bx[k] = b.x; by[k] = b.y; br[k] = b.r;
   }
   const bool vec_ok = (j0 + 3 < m) && ((m & 3) == 0);   // 16-byte aligned full group
   __syncthreads();
 
+  // Second stage, dense: every lane takes one circle-test survivor from the LDS queue and runs the
+  // separating-axis test on it (a wave with ANY surviving lane used to run the SAT for all its lanes: 86 % of
+  // the iterations at a 3 % survival rate -- that, not the 4 B/pair of output, set the kernel's time).
+  auto drain_q1 = [&]() {
+    const unsigned cnt1 = s_cnt1;                          // uniform (read after a barrier)
+    for (unsigned e = threadIdx.x; e < cnt1; e += kThreads) {
+      const unsigned v = s_q1[e], r = v >> 10, jl = v & 1023u;
+      if (!sat_disjoint(s_rows[r], s_cols[jl]))
+        queue_push(Q, (unsigned)(rbeg + r - row0), (unsigned)(jw + jl));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt1 = 0;
+    if (s_count > kIouFlushAt - 1024) queue_flush(Q, gq, gcount, cap);   // uniform
+    __syncthreads();
+  };
+
   PreBox Ai = s_rows[0];
   for (int r = 0; r < nrows; r++) {
-    const PreBox A = Ai;
+    const float ax = Ai.x, ay = Ai.y, ar = Ai.r;
     if (r + 1 < nrows) Ai = s_rows[r + 1];   // next row's box while this one is processed
     const int64_t i = rbeg + r;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      if (j0 + k < m && !surely_disjoint(A.x, A.y, A.r, Bj[k].x, Bj[k].y, Bj[k].r) && !sat_disjoint(A, Bj[k]))
-        queue_push(Q, (unsigned)(i - row0), (unsigned)(j0 + k));
+      if (j0 + k < m && !surely_disjoint(ax, ay, ar, bx[k], by[k], br[k])) {
+        const unsigned p = atomicAdd(&s_cnt1, 1u);
+        s_q1[p] = (unsigned short)((r << 10) | (threadIdx.x * 4 + k));
+      }
     }
     float* dst = out + i * m + j0;
     if (vec_ok) {
@@ -141,11 +166,13 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
       for (int k = 0; k < 4; k++)
         if (j0 + k < m) dst[k] = 0.f;
     }
-    if ((r & 1) == 1) {          // <= 2048 pushes per two rows: the queue can never overflow
+    if ((r & 1) == 1) {          // <= 2048 pushes per two rows: neither queue can overflow
       __syncthreads();
-      if (s_count > kIouFlushAt - 1024) queue_flush(Q, gq, gcount, cap);   // uniform
+      if (s_cnt1 > kIouQ1FlushAt) drain_q1();              // uniform
     }
   }
+  __syncthreads();
+  drain_q1();
   queue_flush(Q, gq, gcount, cap);
 }
 
