@@ -78,7 +78,7 @@ def nms(n, nl=15):
     s = torch.from_numpy(((rng.permutation(n) + 1) / (n + 1) * 0.95 + 0.05).astype(np.float32)).to(dev)
     lab = torch.from_numpy(rng.integers(0, nl, n).astype(np.float32)).to(dev)
     k = S.ml_nms_rotated(d, s, lab, 0.5)
-    sec = timeit(lambda: S.ml_nms_rotated(d, s, lab, 0.5), iters=5, warm=1)
+    sec = timeit(lambda: S.ml_nms_rotated(d, s, lab, 0.5), iters=20 if n <= 20000 else 5, warm=3)
     cnt = np.bincount(lab.cpu().numpy().astype(int))
     pairs = float((cnt.astype(np.float64) * (cnt - 1) / 2).sum())
     return dict(op="ml_nms_rotated", n=n, labels=nl, ms=round(sec*1e3, 3), keep=int(k.numel()),
