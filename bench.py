@@ -260,8 +260,6 @@ def cpu_baseline(seed, candidates):
 
 def main():
     args = parse()
-    if args.graph:
-        args.streams = 1                 # graph replay is the single-stream experiment
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -309,7 +307,6 @@ def main():
     runner = step
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     if streams:
-        assert not args.graph, "--streams and --graph are separate experiments"
         for k, st in enumerate(streams):                     # per-stream workspaces and allocator pools warm
             slot[0] = k
             with torch.cuda.stream(st):
@@ -323,12 +320,33 @@ def main():
             with torch.cuda.stream(streams[slot[0]]):
                 step()
             turn[0] += 1
-    if args.graph:
+    if args.graph and not streams:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = step()
         runner = graph.replay
         runner()
+        torch.cuda.synchronize()
+    elif args.graph:
+        # one captured graph per stream (own workspaces / gather slot), replayed round-robin: the host issues one
+        # launch per batch instead of ~175
+        graphs = []
+        for k, st in enumerate(streams):
+            slot[0] = k
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, stream=st):
+                out = step()
+            graphs.append(g_)
+        torch.cuda.synchronize()
+        gturn = [0]
+
+        def runner():
+            k = gturn[0] % len(streams)
+            with torch.cuda.stream(streams[k]):
+                graphs[k].replay()
+            gturn[0] += 1
+        for _ in range(len(streams)):
+            runner()
         torch.cuda.synchronize()
 
     if world > 1:

@@ -811,3 +811,34 @@ def test_full_size_alignconv_zero_offset_identity():
     assert out.shape == ref.shape
     d = (out.float() - ref.float()).abs()
     assert d.max().item() < 2e-2 and (d > 0).float().mean().item() < 0.05
+
+
+def test_head_on_concurrent_streams_matches_serial():
+    """bench.py keeps three independent batches in flight on three HIP streams: every per-call scratch buffer must
+    be private to its stream.  The whole head + post-processing (own kernels only; the library convolutions of the
+    trunk are not run-to-run deterministic) on three different feature pyramids issued back to back on three
+    streams == the same inputs run one at a time, bit for bit."""
+    from s2anet_amd.detector import build_synthetic_detector
+    from s2anet_amd.pyramid import PyramidLayout
+    m = build_synthetic_detector(device=dev())
+    m.head.odm_cls_head.bias.data.fill_(-2.0)
+    m.head.odm_cls_head.weight.data.mul_(20.0)                 # spread the scores: thousands of candidates, few ties
+    layout = PyramidLayout(2, [(40, 48), (20, 24), (10, 12), (5, 6), (3, 3)], (8, 16, 32, 64, 128))   # no level > 2000 positions
+    g = torch.Generator().manual_seed(77)
+    feats = [torch.randn(layout.pixels, 256, generator=g).to(dev()).half() for _ in range(3)]
+
+    def run(x):
+        return m.head.get_bboxes_batched(m.head.forward_pyramid(layout, x))
+    with torch.no_grad():
+        ref = [tuple(t.clone() for t in run(x)) for x in feats]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev()) for _ in range(3)]
+        for rep in range(3):                                       # warm per-stream pools, then the checked round
+            outs = []
+            for x, st in zip(feats, streams):
+                with torch.cuda.stream(st):
+                    outs.append(run(x))
+            torch.cuda.synchronize()
+    assert int(ref[0][2].sum()) > 100
+    for (d, l, c), (rd, rl, rc) in zip(outs, ref):
+        assert torch.equal(c, rc) and torch.equal(l, rl) and torch.equal(d, rd)
