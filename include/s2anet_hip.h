@@ -258,8 +258,8 @@ int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual, int64_t p
 
 /* Regular convolutions, f16 channels-last, with bias / residual / ReLU fused — the conv towers of
  * S2ANetHead (models/head.py:163-222, nn.Conv2d + nn.ReLU pairs) and the 1x1 layers of the carrier,
- * on the same patch-staged MFMA structure as AlignConv.  ksize 3: stride 1, pad 1.  ksize 1: pad 0,
- * stride 1 or 2.  x[B,H,W,C] -> out[B,Ho,Wo,O] = relu?(conv(x) + bias (+ residual[B,Ho,Wo,O])).
+ * on the same patch-staged MFMA structure as AlignConv.  ksize 3: pad 1, stride 1 or 2 (stride 2: O % 128 == 0).
+ * ksize 1: pad 0, stride 1 or 2.  x[B,H,W,C] -> out[B,Ho,Wo,O] = relu?(conv(x) + bias (+ residual[B,Ho,Wo,O])).
  * weight_frag = s2a_conv_pack_weight_f16 of the [O,C,k,k] filter (O*C*k*k halfs, MFMA-fragment order);
  * bias[O] f16 or NULL; residual or NULL.  O must be a multiple of 64 (narrower heads: zero-pad the
  * filter), C a multiple of 64 or exactly 32 (then the filter given to s2a_conv_pack_weight_f16 is

@@ -1077,16 +1077,20 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 // GEMM with the same pipeline (the bottleneck 1x1 layers and FPN laterals of the carrier).
 // OG = 64-channel output groups per workgroup (4, 2 or 1): with fewer than four groups the waves
 // split the 128 positions instead, so narrow layers still use all four MFMA waves.
-constexpr int kCPW = 18;                                  // 16 positions + 1 halo each side
+constexpr int kCPW = 18;                                  // stride 1: 16 positions + 1 halo each side
 
 // PH = 128-position blocks per workgroup (1: 8 x 16 tile, 256 threads, two workgroups per CU; 2: 16 x 16 tile,
 // 512 threads, one workgroup per CU, filter through LDS -- the pyramid-packed 256 -> 256 towers)
-template <int TAPS, int OG, int PH = 1>
+// SD = spatial stride of the 3x3 form (1, or 2: the down-sampling conv2 of a stage's first bottleneck; output tile
+// 4 x 16 positions from a 9 x 33-pixel patch, two 32-position tiles per wave)
+template <int TAPS, int OG, int PH = 1, int SD = 1>
 struct ConvCfg {
-  static constexpr int kTH = 8 * PH;                                   // tile rows (TAPS 9)
-  static constexpr int kPos = 128 * PH;                                // output positions per workgroup
+  static constexpr int kTH = SD == 2 ? 4 : 8 * PH;                     // tile rows (TAPS 9)
+  static constexpr int kPos = SD == 2 ? 64 : 128 * PH;                 // output positions per workgroup
   static constexpr int kWaves = 4 * PH;
-  static constexpr int kPix = TAPS == 9 ? (kTH + 2) * kCPW : kPos;     // patch pixels
+  static constexpr int kPW = SD == 2 ? 33 : kCPW;                      // patch width in pixels
+  static constexpr int kNT = (kPos / 32) * OG / 4 / PH;                // 32-position tiles per wave
+  static constexpr int kPix = TAPS == 9 ? ((kTH - 1) * SD + 3) * kPW : kPos;   // patch pixels
   static constexpr int kDma = (kPix * 9 + 63) / 64;                   // 1 KB LDS-DMA pieces per patch
   static constexpr int kPatchBytes = kDma * 1024;
   static constexpr int kOutRowB = OG * 128 + 16;                      // staged output row (bytes)
@@ -1098,7 +1102,7 @@ struct ConvCfg {
   static constexpr int kJ = (kDma + kWaves - 1) / kWaves;             // DMA pieces per wave
 };
 
-template <int TAPS, int OG, int PH = 1>
+template <int TAPS, int OG, int PH = 1, int SD = 1>
 __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _Float16* __restrict__ x_,
                                                      const _Float16* __restrict__ wfrag,
                                                      const _Float16* __restrict__ bias,
@@ -1108,8 +1112,9 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
                                                      int relu, unsigned x_bytes_, LevelTab lt, int res_up) {
   using T = _Float16;
   using V = f16x8;
-  using Cfg = ConvCfg<TAPS, OG, PH>;
-  constexpr int NT = OG;              // 32-position tiles per wave
+  using Cfg = ConvCfg<TAPS, OG, PH, SD>;
+  constexpr int NT = Cfg::kNT;        // 32-position tiles per wave
+  static_assert(NT >= 1, "unsupported tile / group combination");
   constexpr int WPG = 4 / OG;         // waves per out-channel group (inside a 128-position block)
   constexpr int kThreads_ = 256 * PH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1163,7 +1168,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     bool in = q < qlim && p < Cfg::kPix;
     int64_t pix = 0;
     if (TAPS == 9) {
-      int yy = ty0 - 1 + p / kCPW, xx = tx0 - 1 + p % kCPW;
+      int yy = ty0 * SD - 1 + p / Cfg::kPW, xx = tx0 * SD - 1 + p % Cfg::kPW;
       in = in && yy >= 0 && yy < H && xx >= 0 && xx < W;
       pix = bimg * HWi + (int64_t)yy * W + xx;
     } else {
@@ -1208,7 +1213,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
 #pragma unroll
   for (int b = 0; b < NT; b++) {
     int pl = 128 * blk + 32 * (sub * NT + b) + (lane & 31);
-    int pix = TAPS == 9 ? (pl >> 4) * kCPW + (pl & 15) : pl;
+    int pix = TAPS == 9 ? SD * ((pl >> 4) * Cfg::kPW + (pl & 15)) : pl;
     fbase[b] = pix * kRowBytes + (lane >> 5) * 16;
   }
   f32x16 acc[2][NT];
@@ -1221,7 +1226,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
 
   auto compute = [&](const char* P, int t, const V (&wv)[2][4]) {
     if (!wave_active) return;
-    const int toff = ((t / 3) * kCPW + (t % 3)) * kRowBytes;
+    const int toff = ((t / 3) * Cfg::kPW + (t % 3)) * kRowBytes;
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       V pf[NT];
@@ -1254,7 +1259,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       }
     };
     auto compute_wl = [&](const char* P, int t, const char* Wb) {
-      const int toff = ((t / 3) * kCPW + (t % 3)) * kRowBytes;
+      const int toff = ((t / 3) * Cfg::kPW + (t % 3)) * kRowBytes;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         V pf[NT], wv[2];
@@ -1705,17 +1710,17 @@ extern "C" int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count
 
 namespace s2a {
 namespace {
-template <int TAPS, int OG, int PH = 1>
+template <int TAPS, int OG, int PH = 1, int SD = 1>
 int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
                 _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
                 hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0, int res_up = 0) {
-  using Cfg = ConvCfg<TAPS, OG, PH>;
+  using Cfg = ConvCfg<TAPS, OG, PH, SD>;
   const int64_t Ntot = B * (int64_t)Ho * Wo;
   int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + Cfg::kTH - 1) / Cfg::kTH) : (Ntot + Cfg::kPos - 1) / Cfg::kPos;
   LevelTab lt = {};
   if (levels) { lt = *levels; tiles = level_tiles; }
   dim3 grid((unsigned)tiles, (unsigned)((O + 64 * OG - 1) / (64 * OG)));
-  auto kern = k_conv_f16<TAPS, OG, PH>;
+  auto kern = k_conv_f16<TAPS, OG, PH, SD>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + 512));
   kern<<<grid, 256 * PH, Cfg::kLds + 512, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
                                      (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up);
@@ -1730,7 +1735,8 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
                                  int64_t out_channels, int ksize, int stride, int relu, s2a_stream_t stream) {
   S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0 && height > 0 && width > 0, "conv: bad shape");
   S2A_CHECK_ARG(ksize == 3 || ksize == 1, "conv: kernel size must be 1 or 3");
-  S2A_CHECK_ARG(stride == 1 || (ksize == 1 && stride == 2), "conv: stride must be 1 (or 2 for 1x1)");
+  S2A_CHECK_ARG(stride == 1 || stride == 2, "conv: stride must be 1 or 2");
+  S2A_CHECK_ARG(!(ksize == 3 && stride == 2) || out_channels % 128 == 0, "conv: 3x3 stride 2 needs out_channels % 128 == 0");
   S2A_CHECK_ARG((channels % 64 == 0 || channels == 32) && out_channels % 64 == 0,
                 "conv: channels must be 32 or a multiple of 64, out_channels a multiple of 64");
   const uint64_t x_bytes = (uint64_t)batch * height * width * channels * 2;
@@ -1743,12 +1749,19 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
   S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_frag % 16) == 0 &&
                 ((uintptr_t)bias % 8) == 0 && ((uintptr_t)residual % 16) == 0, "conv: tensors must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  const int Ho = (int)((height - 1) / stride + 1), Wo = (int)((width - 1) / stride + 1);   // k=1,p=0 / k=3,p=1,s=1
+  const int Ho = (int)((height - 1) / stride + 1), Wo = (int)((width - 1) / stride + 1);   // k=1,p=0 / k=3,p=1 (s = 1, 2)
   const int og = out_channels % 256 == 0 ? 4 : (out_channels % 128 == 0 ? 2 : 1);
   const _Float16 *X = (const _Float16*)x, *Wf = (const _Float16*)weight_frag, *Bi = (const _Float16*)bias,
                  *R = (const _Float16*)residual;
   _Float16* Y = (_Float16*)out;
 #define S2A_CONV(TAPS, OG_) launch_conv<TAPS, OG_>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, stride, (int)out_channels, relu, st)
+  if (ksize == 3 && stride == 2) {
+    if (og == 4)
+      return launch_conv<9, 4, 1, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 2,
+                                     (int)out_channels, relu, st);
+    return launch_conv<9, 2, 1, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 2,
+                                   (int)out_channels, relu, st);
+  }
   if (ksize == 3) return og == 4 ? S2A_CONV(9, 4) : (og == 2 ? S2A_CONV(9, 2) : S2A_CONV(9, 1));
   return og == 4 ? S2A_CONV(1, 4) : (og == 2 ? S2A_CONV(1, 2) : S2A_CONV(1, 1));
 #undef S2A_CONV

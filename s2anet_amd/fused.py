@@ -46,6 +46,9 @@ def own_conv_ok(x, in_channels, out_channels, kernel_size, stride, padding, dila
     narrow = out_channels < 64     # prediction heads (5 / 15 maps): the library's kernels for these cost 13-56 us flat
     if k == (3, 3) and st == (1, 1) and pd == (1, 1):
         return narrow or B * ((H + 7) // 8) * ((W + 15) // 16) >= 64
+    if k == (3, 3) and st == (2, 2) and pd == (1, 1) and not os.environ.get("S2A_NO_OWN_CONV_S2"):
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1            # the down-sampling conv2 of a stage's first bottleneck
+        return out_channels % 128 == 0 and in_channels % 64 == 0 and B * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= 128
     if k == (1, 1) and pd == (0, 0) and st in ((1, 1), (2, 2)) and not os.environ.get("S2A_NO_OWN_CONV1"):
         Ho, Wo = (H - 1) // st[0] + 1, (W - 1) // st[1] + 1
         return narrow or B * Ho * Wo >= 64 * 128
@@ -69,7 +72,7 @@ def conv_pack_weight(weight):
 
 def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, residual=None, out=None):
     """relu?(conv(x) + bias (+ residual)) in ONE kernel; x f16 channels-last, packed_weight from
-    conv_pack_weight; ksize 3 (stride 1, pad 1) or 1 (pad 0, stride 1|2)"""
+    conv_pack_weight; ksize 3 (pad 1, stride 1|2) or 1 (pad 0, stride 1|2)"""
     B, C, H, W = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     O_real = out_channels

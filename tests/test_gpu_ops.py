@@ -419,6 +419,22 @@ def test_own_conv1x1_f16_vs_torch(shape):
     assert (out3.float() - (torch.nn.functional.conv2d(x.float(), w.float(), None, stride=st) + res.float())).abs().max().item() < 3e-2
 
 
+def test_own_conv3x3_stride2_vs_torch():
+    """the down-sampling 3x3 / stride 2 / pad 1 convolutions of the trunk on the own kernel (4 x 16 output tiles
+    from 9 x 33-pixel patches), odd and even sizes, both out-channel groupings"""
+    from s2anet_amd.fused import conv_f16, conv_pack_weight
+    g = torch.Generator().manual_seed(13)
+    for (B, C, H, W, O) in ((2, 128, 64, 96, 128), (1, 256, 37, 51, 256), (3, 64, 10, 18, 384), (2, 512, 16, 16, 512)):
+        x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(O, C, 3, 3, generator=g) * 0.03).to(dev()).half()
+        b = torch.randn(O, generator=g).to(dev()).half()
+        ref = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1))
+        out = conv_f16(x, conv_pack_weight(w), b, O, 3, 2, True)
+        assert out.shape == ref.shape
+        err = (out.float() - ref).abs()
+        assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, ((B, C, H, W, O), err.max().item())
+
+
 @pytest.mark.parametrize("shape", [(2, 256, 16, 16, 15, 3), (8, 256, 8, 8, 5, 3), (2, 256, 40, 24, 5, 1), (1, 256, 128, 128, 15, 1)])
 def test_narrow_prediction_heads(shape):
     """5 / 15-map prediction heads (head.py:205-222) on the own conv kernel with zero-padded filters;
