@@ -312,6 +312,11 @@ int64_t s2a_pyramid_pixels(const s2a_pyramid* pyr, int64_t batch);
 int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
                             void* out, int64_t batch, int64_t channels, int64_t out_channels, int relu,
                             const s2a_pyramid* pyr, s2a_stream_t stream);
+/* ORConv2d + RotationInvariantPooling in one launch (models/head.py:337-341): out[P,O] = conv3x3(x) + bias (no
+ * activation) and pooled[P,O/8] = max over every run of 8 orientation channels of out, both pyramid-packed. */
+int s2a_orconv_pool_pyramid_f16(const void* x, const void* weight_frag, const void* bias, void* out, void* pooled,
+                                int64_t batch, int64_t channels, int64_t out_channels, const s2a_pyramid* pyr,
+                                s2a_stream_t stream);
 int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, const void* weight_packed, void* out,
                                int64_t batch, int64_t channels, int64_t out_channels, int relu,
                                const s2a_pyramid* pyr, s2a_stream_t stream);

@@ -1109,7 +1109,8 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
                                                      const _Float16* __restrict__ residual_,
                                                      _Float16* __restrict__ out_, int64_t Ntot_, int C,
                                                      int H_, int W_, int Ho_, int Wo_, int cstride, int O,
-                                                     int relu, unsigned x_bytes_, LevelTab lt, int res_up) {
+                                                     int relu, unsigned x_bytes_, LevelTab lt, int res_up,
+                                                     _Float16* __restrict__ pool_out_) {
   using T = _Float16;
   using V = f16x8;
   using Cfg = ConvCfg<TAPS, OG, PH, SD>;
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     x += (int64_t)p0 * C;
     out += (int64_t)p0 * O;
     if (residual) residual += (int64_t)p0 * O;
+    if (pool_out_) pool_out_ += (int64_t)p0 * (O / 8);
     x_bytes = (unsigned)(Ntot * C * 2);
   }
   const int64_t HWo = (int64_t)Ho * Wo, HWi = (int64_t)H * W;
@@ -1411,6 +1413,28 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       int64_t gp = TAPS == 9 ? tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
       if (gp >= 0 && col * 8 < Oloc)
         *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * Cfg::kOutRowB + col * 16);
+    }
+  }
+  // optional second output: rotation-invariant pooling of the tile just produced (max over each run of 8
+  // orientation channels, models/orn/functions/rotation_invariant_pooling.py:19-27) straight from the staged
+  // tile -- ORConv2d's output feeds both the regression tower (full tile, stored above) and, pooled, the
+  // classification tower.  One item = one position x 8 pooled channels (128 B read, 16 B stored).
+  if (pool_out_) {
+    constexpr int GP = 8 * OG;                      // pooled channels of this workgroup's 64*OG outputs
+    for (int item = tid; item < Cfg::kPos * (GP / 8); item += kThreads_) {
+      const int pos = item / (GP / 8), q = item % (GP / 8);
+      const int64_t gp = TAPS == 9 ? tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
+      if (gp < 0 || q * 64 >= Oloc) continue;
+      V res;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const V v = *reinterpret_cast<const V*>(s_out + pos * Cfg::kOutRowB + (q * 8 + e) * 16);
+        _Float16 mx = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) mx = v[k] > mx ? v[k] : mx;
+        res[e] = mx;
+      }
+      *reinterpret_cast<V*>(pool_out_ + gp * (O / 8) + o0 / 8 + q * 8) = res;
     }
   }
 }
@@ -1713,7 +1737,8 @@ namespace {
 template <int TAPS, int OG, int PH = 1, int SD = 1>
 int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
                 _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
-                hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0, int res_up = 0) {
+                hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0, int res_up = 0,
+                _Float16* pool_out = nullptr) {
   using Cfg = ConvCfg<TAPS, OG, PH, SD>;
   const int64_t Ntot = B * (int64_t)Ho * Wo;
   int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + Cfg::kTH - 1) / Cfg::kTH) : (Ntot + Cfg::kPos - 1) / Cfg::kPos;
@@ -1723,7 +1748,7 @@ int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, 
   auto kern = k_conv_f16<TAPS, OG, PH, SD>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + 512));
   kern<<<grid, 256 * PH, Cfg::kLds + 512, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
-                                     (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up);
+                                     (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up, pool_out);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -1833,9 +1858,27 @@ extern "C" int64_t s2a_pyramid_pixels(const s2a_pyramid* pyr, int64_t batch) {
   return build_levels(pyr, batch, &lt, &pix) < 0 ? -1 : pix;
 }
 
+static int conv3x3_pyramid_impl(const void* x, const void* weight_frag, const void* bias, const void* residual,
+                                void* out, void* pool_out, int64_t batch, int64_t channels, int64_t out_channels,
+                                int relu, const s2a_pyramid* pyr, s2a_stream_t stream);
+
 extern "C" int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
                                        void* out, int64_t batch, int64_t channels, int64_t out_channels,
                                        int relu, const s2a_pyramid* pyr, s2a_stream_t stream) {
+  return conv3x3_pyramid_impl(x, weight_frag, bias, residual, out, nullptr, batch, channels, out_channels, relu, pyr, stream);
+}
+
+extern "C" int s2a_orconv_pool_pyramid_f16(const void* x, const void* weight_frag, const void* bias, void* out,
+                                           void* pooled, int64_t batch, int64_t channels, int64_t out_channels,
+                                           const s2a_pyramid* pyr, s2a_stream_t stream) {
+  S2A_CHECK_ARG(pooled != nullptr && ((uintptr_t)pooled % 16) == 0 && out_channels % 64 == 0,
+                "orconv_pool_pyramid: pooled must be a 16-byte aligned buffer, out_channels a multiple of 64");
+  return conv3x3_pyramid_impl(x, weight_frag, bias, nullptr, out, pooled, batch, channels, out_channels, 0, pyr, stream);
+}
+
+static int conv3x3_pyramid_impl(const void* x, const void* weight_frag, const void* bias, const void* residual,
+                                void* out, void* pool_out, int64_t batch, int64_t channels, int64_t out_channels,
+                                int relu, const s2a_pyramid* pyr, s2a_stream_t stream) {
   S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0, "conv_pyramid: bad shape");
   S2A_CHECK_ARG((channels % 64 == 0 || channels == 32) && out_channels % 64 == 0,
                 "conv_pyramid: channels must be 32 or a multiple of 64, out_channels a multiple of 64");
@@ -1858,10 +1901,11 @@ extern "C" int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, c
   const _Float16 *X = (const _Float16*)x, *Wf = (const _Float16*)weight_frag, *Bi = (const _Float16*)bias,
                  *R = (const _Float16*)residual;
   _Float16* Y = (_Float16*)out;
-#define S2A_CONVP(OG_) launch_conv<9, OG_>(X, Wf, Bi, R, Y, batch, (int)channels, lt.H[0], lt.W[0], lt.H[0], lt.W[0], 1, (int)out_channels, relu, st, &lt, tiles)
+  _Float16* Pq = (_Float16*)pool_out;
+#define S2A_CONVP(OG_) launch_conv<9, OG_>(X, Wf, Bi, R, Y, batch, (int)channels, lt.H[0], lt.W[0], lt.H[0], lt.W[0], 1, (int)out_channels, relu, st, &lt, tiles, 0, Pq)
   if (ph == 2 && og == 4)
     return launch_conv<9, 4, 2>(X, Wf, Bi, R, Y, batch, (int)channels, lt.H[0], lt.W[0], lt.H[0], lt.W[0], 1,
-                                (int)out_channels, relu, st, &lt, tiles);
+                                (int)out_channels, relu, st, &lt, tiles, 0, Pq);
   return og == 4 ? S2A_CONVP(4) : (og == 2 ? S2A_CONVP(2) : S2A_CONVP(1));
 #undef S2A_CONVP
 }

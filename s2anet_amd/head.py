@@ -154,9 +154,13 @@ class S2ANetHead(nn.Module):
         if not hasattr(self.or_conv, "_packed"):
             from .fused import PackedWeightCache
             self.or_conv._packed = PackedWeightCache()
-        or_feat = P.conv3x3(layout, al, self.or_conv._packed.get(wa),
-                            self.or_conv._packed.get_bias(self.or_conv.bias, wa.shape[0]), wa.shape[0], relu=False)
-        pooled = P.rot_inv_pool(or_feat, self.or_pool.nOrientation)                         # [P,32]
+        if self.or_pool.nOrientation == 8 and wa.shape[0] % 64 == 0:                        # conv + orientation max, one launch
+            or_feat, pooled = P.orconv_pool(layout, al, self.or_conv._packed.get(wa),
+                                            self.or_conv._packed.get_bias(self.or_conv.bias, wa.shape[0]), wa.shape[0])
+        else:
+            or_feat = P.conv3x3(layout, al, self.or_conv._packed.get(wa),
+                                self.or_conv._packed.get_bias(self.or_conv.bias, wa.shape[0]), wa.shape[0], relu=False)
+            pooled = P.rot_inv_pool(or_feat, self.or_pool.nOrientation)                     # [P,32]
         w, b, o = self.odm_cls_head.packed_args()
         odm_cls = P.conv3x3(layout, tower(self.odm_cls_ls, pooled), w, b, o, relu=False)    # [P,64], C used
         w, b, o = self.odm_reg_head.packed_args()

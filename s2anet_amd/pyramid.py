@@ -61,6 +61,19 @@ def conv3x3(layout, x, packed_w, bias, out_channels, relu, residual=None, out=No
     return out
 
 
+def orconv_pool(layout, x, packed_w, bias, out_channels, n_orientation=8):
+    """ORConv2d (cached ARF filter) + orientation max-pool in one launch: -> (out[P,O], pooled[P,O/8])"""
+    assert n_orientation == 8
+    L = _lib.lib()
+    out = layout.new(out_channels, x.device)
+    pooled = layout.new(out_channels // 8, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.s2a_orconv_pool_pyramid_f16(_lib.ptr(x), _lib.ptr(packed_w), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(pooled),
+                                                 layout.batch, x.shape[1], out_channels, ctypes.byref(layout.c),
+                                                 _lib.stream_ptr(x.device)))
+    return out, pooled
+
+
 def conv1x1(x, packed_w, bias, out_channels, relu, residual=None):
     """1x1 on packed rows (no geometry): x[P,C] -> out[P,O]"""
     L = _lib.lib()

@@ -538,6 +538,20 @@ def test_pyramid_conv3x3_matches_per_level():
                 assert torch.equal(got, conv_f16(xl.contiguous(memory_format=torch.channels_last), wp, b, O, 3, 1, True))
 
 
+def test_pyramid_orconv_with_fused_pooling():
+    """ORConv + orientation max-pool in one launch == conv launch followed by the pooling kernel, bit for bit"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.fused import conv_pack_weight
+    layout, x, g = _pyr_setup()
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev()).half()
+    b = torch.randn(256, generator=g).to(dev()).half()
+    wp = conv_pack_weight(w)
+    ref = P.conv3x3(layout, x, wp, b, 256, relu=False)
+    out, pooled = P.orconv_pool(layout, x, wp, b, 256)
+    assert torch.equal(out, ref) and torch.equal(pooled, P.rot_inv_pool(ref, 8))
+    assert torch.equal(pooled, ref.view(-1, 32, 8).max(dim=2)[0])
+
+
 def test_pyramid_alignconv_and_refine(rng):
     """pyramid-packed fam_refine + AlignConv against the per-level entry points and the oracle"""
     from s2anet_amd import pyramid as P
