@@ -312,6 +312,15 @@ int64_t s2a_pyramid_pixels(const s2a_pyramid* pyr, int64_t batch);
 int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
                             void* out, int64_t batch, int64_t channels, int64_t out_channels, int relu,
                             const s2a_pyramid* pyr, s2a_stream_t stream);
+/* A conv tower's last 3x3 layer + the 1x1 prediction head that reads it (fam_reg_ls / fam_cls_ls -> fam_reg_head /
+ * fam_cls_head, models/head.py:163-213, :296-306) in one launch: head_out[P,64] (columns 0..31 written; the head's
+ * <= 32 maps first) = head(relu?(conv3x3(x) + bias)) + head_bias, computed from the staged f16 tile as the separate
+ * layers would.  out may be NULL when nothing else reads the tower (then it is never written).  O must be 256;
+ * head_weight_frag = s2a_conv_pack_weight_f16 of the zero-padded [64,256,1,1] filter, head_bias >= 32 f16. */
+int s2a_conv3x3_head_pyramid_f16(const void* x, const void* weight_frag, const void* bias, void* out,
+                                 const void* head_weight_frag, const void* head_bias, void* head_out,
+                                 int64_t batch, int64_t channels, int64_t out_channels, int relu,
+                                 const s2a_pyramid* pyr, s2a_stream_t stream);
 /* ORConv2d + RotationInvariantPooling in one launch (models/head.py:337-341): out[P,O] = conv3x3(x) + bias (no
  * activation) and pooled[P,O/8] = max over every run of 8 orientation channels of out, both pyramid-packed. */
 int s2a_orconv_pool_pyramid_f16(const void* x, const void* weight_frag, const void* bias, void* out, void* pooled,

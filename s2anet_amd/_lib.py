@@ -91,6 +91,8 @@ SYMBOLS = {
     "s2a_pyramid_pixels": (c_i64, [ctypes.POINTER(Pyramid), c_i64]),
     "s2a_conv3x3_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
                                         ctypes.POINTER(Pyramid), c_vp]),
+    "s2a_conv3x3_head_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
+                                             ctypes.POINTER(Pyramid), c_vp]),
     "s2a_orconv_pool_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, ctypes.POINTER(Pyramid), c_vp]),
     "s2a_align_conv_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
                                            ctypes.POINTER(Pyramid), c_vp]),

@@ -1081,6 +1081,15 @@ constexpr int kCPW = 18;                                  // stride 1: 16 positi
 
 // PH = 128-position blocks per workgroup (1: 8 x 16 tile, 256 threads, two workgroups per CU; 2: 16 x 16 tile,
 // 512 threads, one workgroup per CU, filter through LDS -- the pyramid-packed 256 -> 256 towers)
+// optional second results computed from the staged output tile in the epilogue
+struct ConvExtra {
+  _Float16* pool_out;          // [P, O/8]: max over runs of 8 channels (rotation-invariant pooling) or null
+  const _Float16* head_w;      // 1x1 prediction head on the tile: fragment-order filter (<= 32 maps, zero-padded) or null
+  const _Float16* head_b;      // its bias (>= 32 entries)
+  _Float16* head_out;          // [P, 64] (columns 0..31 written)
+  int store_main;              // 0: the tower's own output is not needed (only the head reads it)
+};
+
 // SD = spatial stride of the 3x3 form (1, or 2: the down-sampling conv2 of a stage's first bottleneck; output tile
 // 4 x 16 positions from a 9 x 33-pixel patch, two 32-position tiles per wave)
 template <int TAPS, int OG, int PH = 1, int SD = 1>
@@ -1110,7 +1119,8 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
                                                      _Float16* __restrict__ out_, int64_t Ntot_, int C,
                                                      int H_, int W_, int Ho_, int Wo_, int cstride, int O,
                                                      int relu, unsigned x_bytes_, LevelTab lt, int res_up,
-                                                     _Float16* __restrict__ pool_out_) {
+                                                     ConvExtra ex) {
+  _Float16* pool_out_ = ex.pool_out;
   using T = _Float16;
   using V = f16x8;
   using Cfg = ConvCfg<TAPS, OG, PH, SD>;
@@ -1142,6 +1152,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     out += (int64_t)p0 * O;
     if (residual) residual += (int64_t)p0 * O;
     if (pool_out_) pool_out_ += (int64_t)p0 * (O / 8);
+    if (ex.head_out) ex.head_out += (int64_t)p0 * 64;
     x_bytes = (unsigned)(Ntot * C * 2);
   }
   const int64_t HWo = (int64_t)Ho * Wo, HWi = (int64_t)H * W;
@@ -1411,8 +1422,42 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     for (int i = 0; i < NI; i++) {
       int idx = tid + kThreads_ * i, pos = idx / VPR, col = idx % VPR;
       int64_t gp = TAPS == 9 ? tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot) : (g0 + pos < Ntot ? g0 + pos : -1);
-      if (gp >= 0 && col * 8 < Oloc)
+      if (gp >= 0 && col * 8 < Oloc && ex.store_main)
         *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * Cfg::kOutRowB + col * 16);
+    }
+  }
+  // optional: a 1x1 prediction head (<= 32 maps: fam_reg_head / fam_cls_head, models/head.py:205-213) applied to
+  // the staged tile -- every wave takes 32 positions, B fragments straight from the staged rows (528-byte stride:
+  // conflict-free), A fragments = the head's filter (16 KB, L2-resident), 16 MFMAs.  Needs the whole channel range
+  // in this workgroup (OG = 4, O = 256).
+  if constexpr (OG == 4) {
+    if (ex.head_w) {
+      f32x16 hacc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) hacc[r] = 0.f;
+      const int hpos = 32 * wave + (lane & 31);
+      const V* hw = reinterpret_cast<const V*>(ex.head_w) + lane;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const V a = hw[(c4 * 8 + kk) * 64];                 // stage c4, m-tile 0 (maps 0..31), k-step kk
+          const V b = *reinterpret_cast<const V*>(s_out + hpos * Cfg::kOutRowB + (c4 * 64 + kk * 16 + (lane >> 5) * 8) * 2);
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, hacc, 0, 0, 0);
+        }
+      const int64_t gp = TAPS == 9 ? tile_pos(tile, hpos, Cfg::kTH, Ho, Wo, HWo, Ntot) : (g0 + hpos < Ntot ? g0 + hpos : -1);
+      if (gp >= 0) {
+        using h4 = __attribute__((ext_vector_type(4))) _Float16;
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+          const int och = 8 * rq + 4 * (lane >> 5);
+          const h4 hb = *reinterpret_cast<const h4*>(ex.head_b + och);
+          h4 v4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v4[e] = (_Float16)(hacc[rq * 4 + e] + (float)hb[e]);
+          *reinterpret_cast<h4*>(ex.head_out + gp * 64 + och) = v4;
+        }
+      }
     }
   }
   // optional second output: rotation-invariant pooling of the tile just produced (max over each run of 8
@@ -1738,7 +1783,7 @@ template <int TAPS, int OG, int PH = 1, int SD = 1>
 int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
                 _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
                 hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0, int res_up = 0,
-                _Float16* pool_out = nullptr) {
+                ConvExtra ex = ConvExtra{nullptr, nullptr, nullptr, nullptr, 1}) {
   using Cfg = ConvCfg<TAPS, OG, PH, SD>;
   const int64_t Ntot = B * (int64_t)Ho * Wo;
   int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + Cfg::kTH - 1) / Cfg::kTH) : (Ntot + Cfg::kPos - 1) / Cfg::kPos;
@@ -1748,7 +1793,7 @@ int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, 
   auto kern = k_conv_f16<TAPS, OG, PH, SD>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + 512));
   kern<<<grid, 256 * PH, Cfg::kLds + 512, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
-                                     (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up, pool_out);
+                                     (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up, ex);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -1859,13 +1904,27 @@ extern "C" int64_t s2a_pyramid_pixels(const s2a_pyramid* pyr, int64_t batch) {
 }
 
 static int conv3x3_pyramid_impl(const void* x, const void* weight_frag, const void* bias, const void* residual,
-                                void* out, void* pool_out, int64_t batch, int64_t channels, int64_t out_channels,
+                                void* out, ConvExtra ex, int64_t batch, int64_t channels, int64_t out_channels,
                                 int relu, const s2a_pyramid* pyr, s2a_stream_t stream);
 
 extern "C" int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
                                        void* out, int64_t batch, int64_t channels, int64_t out_channels,
                                        int relu, const s2a_pyramid* pyr, s2a_stream_t stream) {
-  return conv3x3_pyramid_impl(x, weight_frag, bias, residual, out, nullptr, batch, channels, out_channels, relu, pyr, stream);
+  return conv3x3_pyramid_impl(x, weight_frag, bias, residual, out, ConvExtra{nullptr, nullptr, nullptr, nullptr, 1}, batch,
+                              channels, out_channels, relu, pyr, stream);
+}
+
+extern "C" int s2a_conv3x3_head_pyramid_f16(const void* x, const void* weight_frag, const void* bias, void* out,
+                                            const void* head_weight_frag, const void* head_bias, void* head_out,
+                                            int64_t batch, int64_t channels, int64_t out_channels, int relu,
+                                            const s2a_pyramid* pyr, s2a_stream_t stream) {
+  S2A_CHECK_ARG(out_channels == 256, "conv3x3_head_pyramid: the fused 1x1 head needs a 256-channel tower");
+  S2A_CHECK_ARG(head_weight_frag && head_bias && head_out, "conv3x3_head_pyramid: NULL head tensor");
+  S2A_CHECK_ARG(((uintptr_t)head_weight_frag % 16) == 0 && ((uintptr_t)head_bias % 8) == 0 && ((uintptr_t)head_out % 16) == 0,
+                "conv3x3_head_pyramid: misaligned head tensor");
+  ConvExtra ex{nullptr, (const _Float16*)head_weight_frag, (const _Float16*)head_bias, (_Float16*)head_out, out != nullptr};
+  return conv3x3_pyramid_impl(x, weight_frag, bias, nullptr, out ? out : head_out, ex, batch, channels, out_channels, relu,
+                              pyr, stream);
 }
 
 extern "C" int s2a_orconv_pool_pyramid_f16(const void* x, const void* weight_frag, const void* bias, void* out,
@@ -1873,11 +1932,12 @@ extern "C" int s2a_orconv_pool_pyramid_f16(const void* x, const void* weight_fra
                                            const s2a_pyramid* pyr, s2a_stream_t stream) {
   S2A_CHECK_ARG(pooled != nullptr && ((uintptr_t)pooled % 16) == 0 && out_channels % 64 == 0,
                 "orconv_pool_pyramid: pooled must be a 16-byte aligned buffer, out_channels a multiple of 64");
-  return conv3x3_pyramid_impl(x, weight_frag, bias, nullptr, out, pooled, batch, channels, out_channels, 0, pyr, stream);
+  return conv3x3_pyramid_impl(x, weight_frag, bias, nullptr, out, ConvExtra{(_Float16*)pooled, nullptr, nullptr, nullptr, 1},
+                              batch, channels, out_channels, 0, pyr, stream);
 }
 
 static int conv3x3_pyramid_impl(const void* x, const void* weight_frag, const void* bias, const void* residual,
-                                void* out, void* pool_out, int64_t batch, int64_t channels, int64_t out_channels,
+                                void* out, ConvExtra ex, int64_t batch, int64_t channels, int64_t out_channels,
                                 int relu, const s2a_pyramid* pyr, s2a_stream_t stream) {
   S2A_CHECK_ARG(batch >= 0 && channels > 0 && out_channels > 0, "conv_pyramid: bad shape");
   S2A_CHECK_ARG((channels % 64 == 0 || channels == 32) && out_channels % 64 == 0,
@@ -1901,7 +1961,7 @@ static int conv3x3_pyramid_impl(const void* x, const void* weight_frag, const vo
   const _Float16 *X = (const _Float16*)x, *Wf = (const _Float16*)weight_frag, *Bi = (const _Float16*)bias,
                  *R = (const _Float16*)residual;
   _Float16* Y = (_Float16*)out;
-  _Float16* Pq = (_Float16*)pool_out;
+  const ConvExtra Pq = ex;
 #define S2A_CONVP(OG_) launch_conv<9, OG_>(X, Wf, Bi, R, Y, batch, (int)channels, lt.H[0], lt.W[0], lt.H[0], lt.W[0], 1, (int)out_channels, relu, st, &lt, tiles, 0, Pq)
   if (ph == 2 && og == 4)
     return launch_conv<9, 4, 2>(X, Wf, Bi, R, Y, batch, (int)channels, lt.H[0], lt.W[0], lt.H[0], lt.W[0], 1,

@@ -12,6 +12,7 @@ What changed against the reference glue (same results, no per-image / per-level 
     rotated NMS launch sequence for all images, no host synchronisation
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -140,12 +141,22 @@ class S2ANetHead(nn.Module):
                 t = P.conv3x3(layout, t, w, b, o, relu=True)
             return t
 
-        w, b, o = self.fam_reg_head.packed_args()
-        fam_bbox = P.conv1x1(tower(self.fam_reg_ls, x), w, b, o, relu=False)               # [P,64], 5 used
+        def tower_with_head(seq, head, t):
+            """the tower's last 3x3 layer and the 1x1 head that is its only reader: one launch"""
+            fusable = (head.kernel_size == (1, 1) and head.out_channels <= 32 and seq[-1][0].out_channels == 256 and
+                       seq[-1][0].in_channels % 64 == 0 and not os.environ.get("S2A_NO_FUSED_HEAD"))
+            if not fusable:
+                w, b, o = head.packed_args()
+                return P.conv1x1(tower(seq, t), w, b, o, relu=False)
+            t = tower(seq[:-1], t)
+            w, b, o = seq[-1][0].packed_args()
+            hw, hb, _ = head.packed_args()
+            return P.conv3x3_head(layout, t, w, b, o, hw, hb, relu=True)
+
+        fam_bbox = tower_with_head(self.fam_reg_ls, self.fam_reg_head, x)                   # [P,64], 5 used
         fam_cls = None
         if self.compute_fam_cls:
-            w, b, o = self.fam_cls_head.packed_args()
-            fam_cls = P.conv1x1(tower(self.fam_cls_ls, x), w, b, o, relu=False)
+            fam_cls = tower_with_head(self.fam_cls_ls, self.fam_cls_head, x)
         anchors = P.fam_refine_anchors(layout, fam_bbox, self.anchor_scale)                 # [P,5] f32
         if getattr(self, "capture", None) is not None:      # bench.py: the operands of this step's launches
             self.capture.update(layout=layout, x=x, anchors=anchors)

@@ -61,6 +61,19 @@ def conv3x3(layout, x, packed_w, bias, out_channels, relu, residual=None, out=No
     return out
 
 
+def conv3x3_head(layout, x, packed_w, bias, out_channels, head_w, head_b, relu=True, keep_tower=False):
+    """last 3x3 tower layer + its 1x1 prediction head in one launch -> head_out[P,64] (first <= 32 columns valid)
+    (and the tower output [P,O] when keep_tower)"""
+    L = _lib.lib()
+    head_out = layout.new(64, x.device)
+    tower = layout.new(out_channels, x.device) if keep_tower else None
+    with torch.cuda.device(x.device):
+        _lib.check(L.s2a_conv3x3_head_pyramid_f16(_lib.ptr(x), _lib.ptr(packed_w), _lib.ptr(bias), _lib.ptr(tower), _lib.ptr(head_w),
+                                                  _lib.ptr(head_b), _lib.ptr(head_out), layout.batch, x.shape[1], out_channels,
+                                                  int(bool(relu)), ctypes.byref(layout.c), _lib.stream_ptr(x.device)))
+    return (head_out, tower) if keep_tower else head_out
+
+
 def orconv_pool(layout, x, packed_w, bias, out_channels, n_orientation=8):
     """ORConv2d (cached ARF filter) + orientation max-pool in one launch: -> (out[P,O], pooled[P,O/8])"""
     assert n_orientation == 8

@@ -552,6 +552,26 @@ def test_pyramid_orconv_with_fused_pooling():
     assert torch.equal(pooled, ref.view(-1, 32, 8).max(dim=2)[0])
 
 
+def test_pyramid_tower_with_fused_head():
+    """last tower conv + 1x1 prediction head in one launch == the two launches (same f16 staging), both head widths"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.fused import conv_pack_weight
+    layout, x, g = _pyr_setup()
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(dev()).half()
+    b = torch.randn(256, generator=g).to(dev()).half()
+    wp = conv_pack_weight(w)
+    tower = P.conv3x3(layout, x, wp, b, 256, relu=True)
+    for nh in (5, 15):
+        hw = (torch.randn(nh, 256, 1, 1, generator=g) * 0.05).to(dev()).half()
+        hb = torch.cat([torch.randn(nh, generator=g), torch.zeros(64 - nh)]).to(dev()).half()
+        hwp = conv_pack_weight(hw)
+        ref = P.conv1x1(tower, hwp, hb, 64, relu=False)
+        got = P.conv3x3_head(layout, x, wp, b, 256, hwp, hb, relu=True)
+        assert (got[:, :nh].float() - ref[:, :nh].float()).abs().max().item() < 2e-3      # same operands, f32 sums in another order
+        got2, tw = P.conv3x3_head(layout, x, wp, b, 256, hwp, hb, relu=True, keep_tower=True)
+        assert torch.equal(tw, tower) and torch.equal(got2[:, :nh], got[:, :nh])
+
+
 def test_pyramid_alignconv_and_refine(rng):
     """pyramid-packed fam_refine + AlignConv against the per-level entry points and the oracle"""
     from s2anet_amd import pyramid as P
