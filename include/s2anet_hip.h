@@ -240,6 +240,18 @@ int s2a_align_conv_forward(const void* x, const float* anchors, const void* weig
  *   wh_ratio_clip = 1e-6) straight from the NCHW/NHWC prediction map:
  *   bbox_pred[B,5,H,W] (dtype/layout) -> refined[B,H,W,5] f32.
  * ------------------------------------------------------------------------- */
+/* Candidate selection of get_bboxes for the whole batch on pyramid-packed predictions (models/head.py:684-717):
+ * per level and image sigmoid -> max over classes -> top-k (max_per_level = 2000) only where H*W > k, levels
+ * concatenated, final decode (wh_ratio_clip 16/1000).  cls[P,64] / reg[P,64] f16 (first num_classes / 5 columns),
+ * anchors[P,5] f32 -> bboxes[B,n,5], scores[B,n,num_classes] f32 with n = s2a_pyramid_candidates_count; sel[B,n] int32
+ * scratch receives the packed row of every candidate.  Ties at the k-th score: lowest positions first (the stock
+ * top-k leaves them unspecified); candidates of a level come in position order.  Levels above 24576 positions that
+ * need a top-k are refused (use the per-level path). */
+int64_t s2a_pyramid_candidates_count(const s2a_pyramid* pyr, int64_t max_per_level);
+int s2a_pyramid_candidates(const void* cls, const void* reg, const float* anchors, int64_t batch,
+                           const s2a_pyramid* pyr, int num_classes, int64_t max_per_level, float wh_ratio_clip,
+                           float* bboxes, float* scores, int32_t* sel, s2a_stream_t stream);
+
 /* Output side (val.py:40-52): rotated_box_to_poly_single (utils/general.py:886-921) + cv2.boxPoints for a
  * whole batch: boxes rows (x,y,w,h,angle[,score...]) with row_stride floats -> polys[n,8] f32. */
 int s2a_rbox_to_poly(const float* boxes, int64_t n, int64_t row_stride, float* polys, s2a_stream_t stream);

@@ -100,6 +100,8 @@ SYMBOLS = {
     "s2a_stem_packed_elems": (c_i64, []),
     "s2a_stem_pack_weight_f16": (c_int, [c_vp, c_vp, c_vp]),
     "s2a_stem_u8_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp]),
+    "s2a_pyramid_candidates_count": (c_i64, [ctypes.POINTER(Pyramid), c_i64]),
+    "s2a_pyramid_candidates": (c_int, [c_vp, c_vp, c_vp, c_i64, ctypes.POINTER(Pyramid), c_int, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "s2a_rbox_to_poly": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "s2a_delta2bbox_rotated": (c_int, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
     "s2a_fam_refine_anchors": (c_int, [c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_int, c_int,

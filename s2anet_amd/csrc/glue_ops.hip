@@ -272,6 +272,187 @@ extern "C" int s2a_fam_refine_anchors_pyramid(const void* pred, int64_t row_stri
   return S2A_OK;
 }
 
+// ---------------------------------------------------------------- candidate selection of get_bboxes, all levels
+// get_bboxes_single_img (models/head.py:684-717) for the whole batch on pyramid-packed predictions: per level and
+// image, sigmoid -> max over classes -> top-k (k = 2000) only where H*W > k (:697-705); levels concatenated
+// (:712-714); final decode (:717, wh_ratio_clip 16/1000).  Two kernels instead of ~25 stock launches:
+//  k_pyr_topk: one workgroup per (image, level): exact k-th largest key by a two-pass radix select on 16-bit keys
+//   held in LDS (key = order-preserving image of max_c logit; sigmoid is monotonic), then an index-order
+//   compaction (ties at the threshold: lowest positions first) -> packed row indices;
+//  k_pyr_gather: one thread per selected row: f16 sigmoid of the class logits (as the stock half sigmoid: float
+//   math, rounded to half), decode of the box against its refined anchor.
+namespace s2a {
+namespace {
+constexpr int kTopkThreads = 1024;
+constexpr int kTopkMaxN = 24576;     // positions of one level of one image held in LDS as 16-bit keys (48 KB)
+
+struct CandLevels {
+  int n, batch, num_classes, k;
+  int HW[8], pix0[8], out0[8];       // positions per image, first packed row, first output slot of the level
+};
+
+__device__ __forceinline__ unsigned short f16_key(_Float16 v) {
+  unsigned short u = __builtin_bit_cast(unsigned short, v);
+  return (u & 0x8000u) ? (unsigned short)~u : (unsigned short)(u | 0x8000u);
+}
+
+__global__ __launch_bounds__(kTopkThreads) void k_pyr_topk(const _Float16* __restrict__ cls, CandLevels lv,
+                                                           int64_t n_out, int32_t* __restrict__ sel) {
+  __shared__ unsigned short s_key[kTopkMaxN];
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_part[kTopkThreads];
+  __shared__ unsigned s_T, s_need_eq;
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int HW = lv.HW[l], k = lv.k;
+  const int64_t row0 = (int64_t)lv.pix0[l] + (int64_t)b * HW;
+  int32_t* out = sel + (int64_t)b * n_out + lv.out0[l];
+  if (HW <= k || k <= 0) {                        // whole level (head.py:697: top-k only when H*W > k)
+    for (int i = tid; i < HW; i += kTopkThreads) out[i] = (int32_t)(row0 + i);
+    return;
+  }
+  for (int i = tid; i < HW; i += kTopkThreads) {
+    const _Float16* r = cls + (row0 + i) * 64;
+    _Float16 m = r[0];
+    for (int c = 1; c < lv.num_classes; c++) m = r[c] > m ? r[c] : m;
+    s_key[i] = f16_key(m);
+  }
+  // pass 1: high byte
+  if (tid < 256) s_hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < HW; i += kTopkThreads) atomicAdd(&s_hist[s_key[i] >> 8], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    unsigned cum = 0;
+    int bin = 255;
+    for (; bin > 0; bin--) {
+      if (cum + s_hist[bin] >= (unsigned)k) break;
+      cum += s_hist[bin];
+    }
+    s_T = (unsigned)bin << 8;
+    s_need_eq = (unsigned)k - cum;                 // still needed from this bin
+  }
+  __syncthreads();
+  const unsigned hi = s_T >> 8, need1 = s_need_eq;
+  __syncthreads();
+  // pass 2: low byte inside the bin
+  if (tid < 256) s_hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < HW; i += kTopkThreads)
+    if ((unsigned)(s_key[i] >> 8) == hi) atomicAdd(&s_hist[s_key[i] & 255u], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    unsigned cum = 0;
+    int bin = 255;
+    for (; bin > 0; bin--) {
+      if (cum + s_hist[bin] >= need1) break;
+      cum += s_hist[bin];
+    }
+    s_T = (hi << 8) | (unsigned)bin;               // the k-th largest key
+    s_need_eq = need1 - cum;                       // how many rows equal to it are taken (lowest positions first)
+  }
+  __syncthreads();
+  const unsigned T = s_T, need_eq = s_need_eq;
+  // index-order compaction: contiguous chunk per thread, two running counts (selected so far, equals so far)
+  const int per = (HW + kTopkThreads - 1) / kTopkThreads;
+  const int i0 = tid * per, i1 = min(HW, i0 + per);
+  unsigned gt = 0, eq = 0;
+  for (int i = i0; i < i1; i++) {
+    gt += s_key[i] > T;
+    eq += s_key[i] == T;
+  }
+  s_part[tid] = (gt << 16) | eq;                   // both < 65536
+  __syncthreads();
+  // exclusive scan of the 1024 partials (Hillis-Steele in LDS; packed halves cannot carry: totals <= 32768)
+  for (int off = 1; off < kTopkThreads; off <<= 1) {
+    unsigned v = tid >= off ? s_part[tid - off] : 0u;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  const unsigned incl = s_part[tid];
+  unsigned gt0 = (incl >> 16) - gt, eq0 = (incl & 0xffffu) - eq;
+  for (int i = i0; i < i1; i++) {
+    const unsigned key = s_key[i];
+    if (key > T) {
+      out[gt0 + min(eq0, need_eq)] = (int32_t)(row0 + i);
+      gt0++;
+    } else if (key == T) {
+      if (eq0 < need_eq) out[gt0 + eq0] = (int32_t)(row0 + i);
+      eq0++;
+    }
+  }
+}
+
+__global__ void k_pyr_gather(const _Float16* __restrict__ cls, const _Float16* __restrict__ reg,
+                             const float* __restrict__ anchors, const int32_t* __restrict__ sel, int64_t total,
+                             int num_classes, float max_ratio, float* __restrict__ bboxes,
+                             float* __restrict__ scores) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t row = sel[e];
+  const _Float16* c = cls + row * 64;
+  for (int k = 0; k < num_classes; k++) {
+    const float x = (float)c[k];
+    scores[e * num_classes + k] = (float)(_Float16)(1.f / (1.f + expf(-x)));      // half sigmoid, then .float()
+  }
+  const _Float16* d16 = reg + row * 64;
+  float r[5], d[5], o[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    r[k] = anchors[row * 5 + k];
+    d[k] = (float)d16[k];
+  }
+  decode_one(r, d, max_ratio, o);
+#pragma unroll
+  for (int k = 0; k < 5; k++) bboxes[e * 5 + k] = o[k];
+}
+
+int cand_levels(const s2a_pyramid* pyr, int64_t batch, int num_classes, int64_t k, CandLevels* lv, int64_t* n_out) {
+  if (!pyr || pyr->n_levels < 1 || pyr->n_levels > 8) return -1;
+  *lv = CandLevels{};
+  lv->n = pyr->n_levels; lv->batch = (int)batch; lv->num_classes = num_classes; lv->k = (int)k;
+  int64_t pix = 0, out = 0;
+  for (int i = 0; i < lv->n; i++) {
+    const int64_t hw = (int64_t)pyr->height[i] * pyr->width[i];
+    if (hw < 1 || hw >= (1ll << 31)) return -1;
+    if (k > 0 && hw > k && hw > kTopkMaxN) return -2;
+    lv->HW[i] = (int)hw; lv->pix0[i] = (int)pix; lv->out0[i] = (int)out;
+    pix += batch * hw;
+    out += (k > 0 && hw > k) ? k : hw;
+    if (pix >= (1ll << 31)) return -1;
+  }
+  *n_out = out;
+  return 0;
+}
+}  // namespace
+}  // namespace s2a
+
+extern "C" int64_t s2a_pyramid_candidates_count(const s2a_pyramid* pyr, int64_t max_per_level) {
+  CandLevels lv; int64_t n = 0;
+  return cand_levels(pyr, 1, 1, max_per_level, &lv, &n) == 0 ? n : -1;
+}
+
+extern "C" int s2a_pyramid_candidates(const void* cls, const void* reg, const float* anchors, int64_t batch,
+                                      const s2a_pyramid* pyr, int num_classes, int64_t max_per_level,
+                                      float wh_ratio_clip, float* bboxes, float* scores, int32_t* sel,
+                                      s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && num_classes >= 1 && num_classes <= 64 && wh_ratio_clip > 0, "pyramid_candidates: bad argument");
+  CandLevels lv; int64_t n = 0;
+  const int rc = cand_levels(pyr, batch, num_classes, max_per_level, &lv, &n);
+  S2A_CHECK_ARG(rc != -2, "pyramid_candidates: a level with more than 24576 positions needs the per-level path");
+  S2A_CHECK_ARG(rc == 0, "pyramid_candidates: bad level table");
+  if (batch == 0 || n == 0) return S2A_OK;
+  S2A_CHECK_ARG(cls && reg && anchors && bboxes && scores && sel, "pyramid_candidates: NULL tensor");
+  hipStream_t st = as_stream(stream);
+  k_pyr_topk<<<dim3((unsigned)lv.n, (unsigned)batch), kTopkThreads, 0, st>>>((const _Float16*)cls, lv, n, sel);
+  const int64_t total = batch * n;
+  const float max_ratio = (float)std::fabs(std::log((double)wh_ratio_clip));
+  k_pyr_gather<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const _Float16*)cls, (const _Float16*)reg, anchors, sel,
+                                                               total, num_classes, max_ratio, bboxes, scores);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
 // rotated_box_to_poly_single (utils/general.py:886-921) for a whole batch: angle in [-pi/4, 3pi/4) -> the
 // OpenCV convention (degrees in [0, 90], edges swapped above 90), then cv2.boxPoints.  boxPoints is OpenCV's
 // RotatedRect::points (third-party, not in the reference tree; OpenCV 4.x modules/core/src/types.cpp), restated:

@@ -60,6 +60,16 @@ def _conv_relu(cin, cout):
                          nn.ReLU(inplace=True))
 
 
+class PyramidPred(tuple):
+    """the (fam_cls, fam_bbox, odm_cls, odm_bbox, refine_anchor) per-level lists of forward(), plus the
+    pyramid-packed buffers they are views of (for the fused candidate selection)"""
+
+    def __new__(cls, layout, odm_cls, odm_bbox, anchors, *lists):
+        self = super().__new__(cls, lists)
+        self.packed = (layout, odm_cls, odm_bbox, anchors)
+        return self
+
+
 class S2ANetHead(nn.Module):
     def __init__(self, num_classes, in_channels=256, feat_channels=256, stacked_convs=2,
                  with_orconv=True, anchor_scales=(4,), featmap_strides=(8, 16, 32, 64, 128),
@@ -177,7 +187,8 @@ class S2ANetHead(nn.Module):
         w, b, o = self.odm_reg_head.packed_args()
         odm_bbox = P.conv3x3(layout, tower(self.odm_reg_ls, or_feat), w, b, o, relu=False)  # [P,64], 5 used
         n = len(layout.sizes)
-        return ([layout.level(fam_cls, l, self.num_classes) for l in range(n)] if fam_cls is not None else [None] * n,
+        return PyramidPred(layout, odm_cls, odm_bbox, anchors,
+                           [layout.level(fam_cls, l, self.num_classes) for l in range(n)] if fam_cls is not None else [None] * n,
                 [layout.level(fam_bbox, l, 5) for l in range(n)],
                 [layout.level(odm_cls, l, self.num_classes) for l in range(n)],
                 [layout.level(odm_bbox, l, 5) for l in range(n)],
@@ -221,7 +232,12 @@ class S2ANetHead(nn.Module):
 
     def get_bboxes_batched(self, p, max_candidates=None):
         """-> dets[B,max_per_img,6], labels[B,max_per_img] (-1 padded), counts[B]; no host sync"""
-        bboxes, scores = self.candidates(p)
+        fused = None
+        if isinstance(p, PyramidPred) and not os.environ.get("S2A_NO_FUSED_CANDIDATES"):
+            from . import pyramid as P
+            layout, cls, reg, anc = p.packed
+            fused = P.candidates(layout, cls, reg, anc, self.num_classes, self.max_before_nms_per_level)
+        bboxes, scores = fused[:2] if fused is not None else self.candidates(p)
         return batched_multiclass_nms_rotated(bboxes, scores, self.score_thres_before_nms,
                                               self.iou_thres_nms, self.max_per_img, max_candidates)
 

@@ -127,3 +127,21 @@ def rot_inv_pool(x, n_orientation=8):
         _lib.check(L.s2a_rot_inv_pool(_lib.ptr(x), 1, x.shape[1], x.shape[0], n_orientation, _lib.dtype_code(x),
                                       _lib.LAYOUT_NHWC, _lib.ptr(out), _lib.stream_ptr(x.device)))
     return out
+
+
+def candidates(layout, cls, reg, anchors, num_classes, max_per_level=2000, wh_ratio_clip=16 / 1000):
+    """get_bboxes' candidate selection for the whole batch (s2a_pyramid_candidates): packed predictions ->
+    bboxes[B,n,5] f32, scores[B,n,C] f32; None when a level is too large for the fused top-k"""
+    L = _lib.lib()
+    n = L.s2a_pyramid_candidates_count(ctypes.byref(layout.c), int(max_per_level))
+    if n < 0 or any(h * w > max_per_level > 0 and h * w > 24576 for h, w in layout.sizes):
+        return None
+    B = layout.batch
+    bboxes = torch.empty((B, n, 5), dtype=torch.float32, device=cls.device)
+    scores = torch.empty((B, n, num_classes), dtype=torch.float32, device=cls.device)
+    sel = torch.empty((B, n), dtype=torch.int32, device=cls.device)
+    with torch.cuda.device(cls.device):
+        _lib.check(L.s2a_pyramid_candidates(_lib.ptr(cls), _lib.ptr(reg), _lib.ptr(anchors), B, ctypes.byref(layout.c),
+                                            int(num_classes), int(max_per_level), float(wh_ratio_clip), _lib.ptr(bboxes),
+                                            _lib.ptr(scores), _lib.ptr(sel), _lib.stream_ptr(cls.device)))
+    return bboxes, scores, sel

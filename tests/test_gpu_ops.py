@@ -892,3 +892,48 @@ def test_head_on_concurrent_streams_matches_serial():
     assert int(ref[0][2].sum()) > 100
     for (d, l, c), (rd, rl, rc) in zip(outs, ref):
         assert torch.equal(c, rc) and torch.equal(l, rl) and torch.equal(d, rd)
+
+
+def test_pyramid_candidates_vs_stock_path():
+    """fused per-level top-k + sigmoid + decode (two kernels) against the stock-op path of S2ANetHead.candidates:
+    same candidate set per level (distinct scores -> no tie at the k-th place), same boxes and scores"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.head import S2ANetHead
+    from s2anet_amd.pyramid import PyramidLayout
+    layout = PyramidLayout(2, [(64, 80), (32, 40), (16, 20), (8, 10), (4, 5)], (8, 16, 32, 64, 128))   # 5120 / 1280 / ... positions
+    g = torch.Generator().manual_seed(9)
+    C = 15
+    cls = torch.zeros(layout.pixels, 64)
+    # distinct max logits per position: a random permutation of a fine grid, exactly representable in f16
+    base = (torch.randperm(layout.pixels, generator=g).float() - layout.pixels / 2) / 2048.0
+    cls[:, :C] = base[:, None] - torch.rand(layout.pixels, C, generator=g) * 0.5
+    cls[torch.arange(layout.pixels), torch.randint(0, C, (layout.pixels,), generator=g)] = base
+    cls = cls.half().to(dev())
+    reg = torch.zeros(layout.pixels, 64)
+    reg[:, :5] = torch.randn(layout.pixels, 5, generator=g) * 0.3
+    reg = reg.half().to(dev())
+    anc = torch.rand(layout.pixels, 5, generator=g) * torch.tensor([1000.0, 1000, 80, 80, 2.0]) + torch.tensor([0.0, 0, 8, 8, -0.7])
+    anc = anc.to(dev())
+    head = S2ANetHead(C).to(dev())
+    k = head.max_before_nms_per_level
+    bb, sc, sel = P.candidates(layout, cls, reg, anc, C, k)
+    n = len(layout.sizes)
+    p = (None, None, [layout.level(cls, l, C) for l in range(n)], [layout.level(reg, l, 5) for l in range(n)],
+         [layout.rows(anc, l).view(layout.batch, *layout.sizes[l], 5) for l in range(n)])
+    with torch.no_grad():
+        rb, rs = head.candidates(p)
+    assert bb.shape == rb.shape and sc.shape == rs.shape
+    # the stock path orders a top-k level by score, the fused one by position: compare as sets per (image, level)
+    off = 0
+    for l, (h, w) in enumerate(layout.sizes):
+        m = min(h * w, k)
+        for b in range(layout.batch):
+            a = torch.cat([bb[b, off:off + m], sc[b, off:off + m]], 1)
+            r = torch.cat([rb[b, off:off + m], rs[b, off:off + m]], 1)
+            ka = a[:, 5:].max(1)[0].argsort()
+            kr = r[:, 5:].max(1)[0].argsort()
+            assert torch.allclose(a[ka], r[kr], rtol=1e-5, atol=1e-5), (l, b)
+        off += m
+    # positions come in ascending order inside a level and stay inside the image's rows of that level
+    s0 = sel[:, :min(64 * 80, k)]
+    assert (s0[:, 1:] > s0[:, :-1]).all()
