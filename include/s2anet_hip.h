@@ -240,6 +240,14 @@ int s2a_align_conv_forward(const void* x, const float* anchors, const void* weig
  *   wh_ratio_clip = 1e-6) straight from the NCHW/NHWC prediction map:
  *   bbox_pred[B,5,H,W] (dtype/layout) -> refined[B,H,W,5] f32.
  * ------------------------------------------------------------------------- */
+/* level table of a pyramid-packed buffer (layout: see "Pyramid-packed head launches" below) */
+typedef struct s2a_pyramid {
+  int32_t n_levels;     /* 1..8 */
+  int32_t height[8];
+  int32_t width[8];
+  float stride[8];      /* FPN stride of the level (AlignConv / anchor generation) */
+} s2a_pyramid;
+
 /* Candidate selection of get_bboxes for the whole batch on pyramid-packed predictions (models/head.py:684-717):
  * per level and image sigmoid -> max over classes -> top-k (max_per_level = 2000) only where H*W > k, levels
  * concatenated, final decode (wh_ratio_clip 16/1000).  cls[P,64] / reg[P,64] f16 (first num_classes / 5 columns),
@@ -314,12 +322,6 @@ int s2a_conv1x1_add_up2_f16(const void* x, const void* weight_frag, const void* 
  *                                   on every level, stride[l] = the level's anchor stride
  *   s2a_fam_refine_anchors_pyramid = s2a_fam_refine_anchors on every level; pred rows have
  *                                   row_stride f16 columns of which the first 5 are the deltas */
-typedef struct s2a_pyramid {
-  int32_t n_levels;     /* 1..8 */
-  int32_t height[8];
-  int32_t width[8];
-  float stride[8];      /* FPN stride of the level (AlignConv / anchor generation) */
-} s2a_pyramid;
 int64_t s2a_pyramid_pixels(const s2a_pyramid* pyr, int64_t batch);
 int s2a_conv3x3_pyramid_f16(const void* x, const void* weight_frag, const void* bias, const void* residual,
                             void* out, int64_t batch, int64_t channels, int64_t out_channels, int relu,

@@ -402,6 +402,16 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
   PairQueue Q{s_q, &s_count, s_base};
   if (threadIdx.x == 0) s_count = 0;
   const uint32_t S = *num_seg;
+  // few segments (the per-image x class case): the two prefix arrays the tile locate searches go to LDS once, so
+  // a locate is a handful of LDS reads instead of ~8 dependent global loads (the launch is latency-bound there)
+  __shared__ unsigned long long s_toff[512];
+  __shared__ uint32_t s_sst[512];
+  if (S < 511) {
+    for (uint32_t i = threadIdx.x; i <= S; i += kThreads) { s_toff[i] = tile_off[i]; s_sst[i] = seg_start[i]; }
+    __syncthreads();
+    tile_off = s_toff;
+    seg_start = s_sst;
+  }
   const unsigned long long T = tile_off[S];
   const unsigned long long chunk = (T + gridDim.x - 1) / gridDim.x;
   unsigned long long tile = (unsigned long long)blockIdx.x * chunk;

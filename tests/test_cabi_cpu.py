@@ -58,3 +58,12 @@ def test_module_surface_matches_reference_names():
     assert (oc.indices.numpy() == g["orconv_indices_1_8"]).all()
     oc8 = S.ORConv2d(16, 2, kernel_size=3, padding=1, arf_config=(8, 8))
     assert (oc8.indices.numpy() == g["orconv_indices_8_8"]).all()
+
+
+def test_header_is_self_contained_c():
+    """include/s2anet_hip.h compiles on its own as C and as C++ (declaration order, no missing types)"""
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "s2anet_hip.h")
+    for lang, cc in (("c", "gcc"), ("c++", "g++")):
+        r = subprocess.run([cc, "-fsyntax-only", "-x", lang, "-Wall", hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
