@@ -588,9 +588,19 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
     const bool cached = nwords <= kScanCacheWords;
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < B; c += kThreads) s_remv[c] = 0ull;
+    // middle-sized segment (a dominant class of an image: ~2000 rows): its mask does not fit, but the two words
+    // the serial chain waits for do -- every row's DIAGONAL word and its word-occupancy word go to LDS up front,
+    // leaving one global latency per block (the mask words of the kept rows) instead of three
+    const bool semi = !cached && occ != nullptr && B <= 64 && 2ull * ns <= kScanCacheWords;
     if (cached) {
       for (uint32_t i = threadIdx.x; i < nwords; i += kThreads) s_mask[i] = M[i];
       M = s_mask;   // (generic pointer: LDS from here on)
+    } else if (semi) {
+      const unsigned long long seg_off0 = mask_off[s];
+      for (uint32_t i = threadIdx.x; i < ns; i += kThreads) {
+        s_mask[i] = M[(unsigned long long)i * B + (i >> 6)];
+        s_mask[ns + i] = occ[((seg_off0 + (unsigned long long)i * B) >> 6) + st + i];
+      }
     }
     __syncthreads();
     unsigned char* s_rows = reinterpret_cast<unsigned char*>(s_keep + 1);   // kept rows of the block (64 B)
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
       if (wave == 0) {
         uint32_t rowl = b * 64 + lane;
         bool valid = rowl < ns;
-        unsigned long long d = valid ? M[(unsigned long long)rowl * B + b] : 0ull;
+        unsigned long long d = valid ? (semi ? s_mask[rowl] : M[(unsigned long long)rowl * B + b]) : 0ull;
         const unsigned long long r0 = s_remv[b];
         // the running remove word lives in SGPRs (it is wave-uniform): the 64-step greedy resolve is
         // then a chain of scalar bit tests, one v_readlane pair per step
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
         for (uint32_t item = threadIdx.x; item < (uint32_t)nk * OW; item += kThreads) {
           const uint32_t k = item / OW, q = item % OW;
           const uint32_t rowl = b * 64 + s_rows[k];
-          unsigned long long o = occ[((seg_off + (unsigned long long)rowl * B) >> 6) + st + rowl + q];
+          unsigned long long o = semi ? s_mask[ns + rowl] : occ[((seg_off + (unsigned long long)rowl * B) >> 6) + st + rowl + q];
           if (q < (b >> 6)) o = 0ull;
           else if (q == (b >> 6)) o &= ~((2ull << (b & 63)) - 1ull);
           while (o) {
