@@ -22,6 +22,12 @@
 //                                an independent torch formulation and by the
 //                                zero-offset == conv2d identity: "parity
 //                                unpinned" beyond that.
+//   * deformable conv backward : same situation: pinned to autograd of the
+//                                independent torch formulation (parity unpinned
+//                                against the reference itself)
+//   * ARF backward, polygon NMS (py_cpu_nms_poly_fast), assign_labels, voc_eval,
+//     mergesingle              : vs the reference's own CPU op / Python scripts
+//                                run here (golden fixtures, identical results)
 //
 // Build: make -C oracle   (g++ -O2 -ffp-contract=off; x86-64 baseline has no
 // FMA so this matches how the reference's CPU extension is compiled).
