@@ -217,6 +217,33 @@ class S2ANet(nn.Module):
         return self.head.get_bboxes_batched(self.features_to_pred(x), max_candidates)
 
 
+def load_reference_checkpoint(model, weights, map_location="cpu"):
+    """val.py:153-183: a ``.pth`` file (or an already loaded dict) with a ``"state_dict"`` entry is
+    matched to the model's own entries BY POSITION (the official-code checkpoints use other key
+    names; ``intersect_dicts`` zips the two ordered dicts and asserts equal length), then loaded
+    strictly.  A dict with a ``"model"`` entry holds a module (or its state_dict): loaded by name.
+    Call before ``fold_batchnorm`` / ``fuse_epilogues`` (they keep values, not the BN entries)."""
+    ckpt = torch.load(weights, map_location=map_location, weights_only=False) \
+        if isinstance(weights, (str, os.PathLike)) else weights
+    own = model.state_dict()
+    if "state_dict" in ckpt:
+        src = ckpt["state_dict"]
+        if len(src) != len(own):
+            raise AssertionError(f"checkpoint has {len(src)} entries, the model {len(own)}")
+        mapped = {}
+        for (k1, v1), (k2, v2) in zip(own.items(), src.items()):
+            if tuple(v1.shape) != tuple(v2.shape):
+                raise RuntimeError(f"size mismatch for {k1} <- {k2}: {tuple(v2.shape)} vs {tuple(v1.shape)}")
+            mapped[k1] = v2
+        model.load_state_dict(mapped, strict=True)
+    elif "model" in ckpt:
+        src = ckpt["model"]
+        model.load_state_dict(src.state_dict() if hasattr(src, "state_dict") else src, strict=True)
+    else:
+        raise KeyError("checkpoint holds neither 'state_dict' nor 'model' (val.py:155,182)")
+    return model
+
+
 def fold_batchnorm(model):
     """inference-time conv+BN folding (BN in eval mode is an affine map): fewer passes over HBM"""
     def fold(conv, bn):

@@ -67,3 +67,28 @@ def test_reference_python_imports_against_aliases():
         for k in [k for k in sys.modules if k.split(".")[0] in ("models", "utils", "cv2", "torchvision")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_reference_checkpoint_loads_by_position(tmp_path):
+    """val.py:153-183: official-code checkpoints are matched entry by entry, not by name"""
+    import collections
+    import torch
+    from s2anet_amd.detector import S2ANet, load_reference_checkpoint
+    torch.manual_seed(3)
+    src = S2ANet(15)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+    renamed = collections.OrderedDict((f"module.{i}", v) for i, (k, v) in enumerate(src.state_dict().items()))
+    path = tmp_path / "official.pth"
+    torch.save({"state_dict": renamed, "meta": {}}, path)
+    dst = load_reference_checkpoint(S2ANet(15), str(path))
+    for (k1, v1), (k2, v2) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    dst2 = load_reference_checkpoint(S2ANet(15), {"model": src.state_dict()})
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst2.state_dict().values()))
+    short = collections.OrderedDict(list(renamed.items())[:-1])
+    with pytest.raises(AssertionError):
+        load_reference_checkpoint(S2ANet(15), {"state_dict": short})
+    with pytest.raises(KeyError):
+        load_reference_checkpoint(S2ANet(15), {"weights": {}})
