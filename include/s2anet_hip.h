@@ -305,6 +305,16 @@ int s2a_deformable_col2im(const void* columns, const void* offset, float* grad_i
 int s2a_deformable_col2im_coord(const void* columns, const void* im, const void* offset, void* grad_offset,
                                 const s2a_dcn_params* p, s2a_stream_t stream);
 
+/* A bottleneck's conv2 + conv3 in one launch (models/backbone.py:56-83 with the BatchNorms folded):
+ *   out = relu(W3 . relu(conv3x3(x; W2) + b2) + b3 + residual)        x [B,H,W,64] -> out [B,H,W,256], f16 NHWC
+ * The 64-map intermediate never leaves the workgroup (LDS); results are bit-identical to s2a_conv_nhwc_f16 (3x3,
+ * ReLU) followed by s2a_conv_nhwc_f16 (1x1, residual, ReLU).  weight_frag / tail_weight_frag from
+ * s2a_conv_pack_weight_f16 (ksize 3 / 1); residual may be NULL.  channels = mid_channels = 64, out_channels = 256. */
+int s2a_conv3x3_tail1x1_f16(const void* x, const void* weight_frag, const void* bias, const void* tail_weight_frag,
+                            const void* tail_bias, const void* residual, void* out, int64_t batch, int64_t channels,
+                            int64_t mid_channels, int64_t out_channels, int64_t height, int64_t width,
+                            s2a_stream_t stream);
+
 /* FPN top-down step in one launch (models/neck.py:67-79): out[B,H,W,O] = conv1x1(x[B,H,W,C]) + bias +
  * nearest-2x-upsample(coarse[B,H/2,W/2,O]); f16 channels-last, H and W even, C and O multiples of 64. */
 int s2a_conv1x1_add_up2_f16(const void* x, const void* weight_frag, const void* bias, const void* coarse,

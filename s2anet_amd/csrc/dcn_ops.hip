@@ -1088,11 +1088,17 @@ struct ConvExtra {
   const _Float16* head_b;      // its bias (>= 32 entries)
   _Float16* head_out;          // [P, 64] (columns 0..31 written)
   int store_main;              // 0: the tower's own output is not needed (only the head reads it)
+  // TAIL kernels only: the 1x1 convolution that follows (a bottleneck's conv3, models/backbone.py:60-83) applied to
+  // the staged tile: out2 = relu(W2 . relu(conv + bias) + bias2 + residual2), 256 maps
+  const _Float16* tail_w;      // fragment-order 1x1 filter [256][64]
+  const _Float16* tail_b;      // [256]
+  const _Float16* tail_res;    // [P, 256] or null
+  _Float16* tail_out;          // [P, 256]
 };
 
 // SD = spatial stride of the 3x3 form (1, or 2: the down-sampling conv2 of a stage's first bottleneck; output tile
 // 4 x 16 positions from a 9 x 33-pixel patch, two 32-position tiles per wave)
-template <int TAPS, int OG, int PH = 1, int SD = 1>
+template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false>
 struct ConvCfg {
   static constexpr int kTH = SD == 2 ? 4 : 8 * PH;                     // tile rows (TAPS 9)
   static constexpr int kPos = SD == 2 ? 64 : 128 * PH;                 // output positions per workgroup
@@ -1107,11 +1113,14 @@ struct ConvCfg {
   static constexpr bool kWLds = PH == 2 && TAPS == 9 && OG == 4;
   static constexpr int kWBuf = 32768;
   static constexpr int kLoop = 2 * kPatchBytes + (kWLds ? 2 * kWBuf : 0);
-  static constexpr int kLds = (kLoop > kPos * kOutRowB) ? kLoop : kPos * kOutRowB;
+  static constexpr int kLds0 = (kLoop > kPos * kOutRowB) ? kLoop : kPos * kOutRowB;
+  static constexpr int kTailRowB = 528;                                // staged 256-map row of the fused 1x1
+  static constexpr int kLds = (TAIL && kPos * kTailRowB > kLds0) ? kPos * kTailRowB : kLds0;
+  static constexpr int kBiasBytes = TAIL ? 1024 : 512;
   static constexpr int kJ = (kDma + kWaves - 1) / kWaves;             // DMA pieces per wave
 };
 
-template <int TAPS, int OG, int PH = 1, int SD = 1>
+template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false>
 __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _Float16* __restrict__ x_,
                                                      const _Float16* __restrict__ wfrag,
                                                      const _Float16* __restrict__ bias,
@@ -1123,9 +1132,10 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   _Float16* pool_out_ = ex.pool_out;
   using T = _Float16;
   using V = f16x8;
-  using Cfg = ConvCfg<TAPS, OG, PH, SD>;
+  using Cfg = ConvCfg<TAPS, OG, PH, SD, TAIL>;
   constexpr int NT = Cfg::kNT;        // 32-position tiles per wave
   static_assert(NT >= 1, "unsupported tile / group combination");
+  static_assert(!TAIL || (TAPS == 9 && OG == 1 && SD == 1), "the fused 1x1 tail follows a 64-map 3x3/s1");
   constexpr int WPG = 4 / OG;         // waves per out-channel group (inside a 128-position block)
   constexpr int kThreads_ = 256 * PH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1197,6 +1207,16 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   T* s_bias = reinterpret_cast<T*>(smem + Cfg::kLds);
   T bias_v = (T)0.f;
   if (bias && tid < Oloc) bias_v = bias[o0 + tid];   // in flight with the first patch / weights
+  T tail_bias_v = (T)0.f;
+  V wt[2][4];                                        // TAIL: this wave's 64 x 64 block of the 1x1 filter
+  if constexpr (TAIL) {
+    if (tid < 256) tail_bias_v = ex.tail_b[tid];
+    const V* tp = reinterpret_cast<const V*>(ex.tail_w) + lane + (int64_t)wave4 * 8 * 64;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) wt[a][kk] = tp[(a * 4 + kk) * 64];
+  }
   auto patch_issue = [&](int cc) {
     char* P = smem + (cc & 1) * Cfg::kPatchBytes;
 #pragma unroll
@@ -1306,6 +1326,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   patch_issue(0);
   load_w(0, wA);
   if (tid < 64 * OG) s_bias[tid] = bias_v;
+  if constexpr (TAIL) { if (tid < 256) s_bias[64 + tid] = tail_bias_v; }
   __syncthreads();   // (the compiler drains the DMA with vmcnt(0) before the barrier)
   if constexpr (TAPS == 9) {
     for (int cc = 0; cc < CC; cc++) {
@@ -1378,6 +1399,72 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       }
   }
   __syncthreads();
+  if constexpr (TAIL) {
+    // ---- fused 1x1 (64 -> 256) on the staged tile: wave w = out maps 64w..64w+63 x the 128 positions of its block,
+    // B fragments from the staged rows (144-byte stride: conflict-free), accumulation order = the stand-alone 1x1's
+    f32x16 acc3[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc3[a][b][r] = 0.f;
+    const char* brow = s_out + (128 * blk + (lane & 31)) * Cfg::kOutRowB + (lane >> 5) * 16;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      V pf[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) pf[b] = *reinterpret_cast<const V*>(brow + b * 32 * Cfg::kOutRowB + kk * 32);
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          acc3[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt[a][kk], pf[b], acc3[a][b], 0, 0, 0);
+    }
+    // residual vectors of the whole tile in flight before the tile is re-staged (issuing them at kernel start was
+    // slower: they queue ahead of the patch and the filters on the in-order memory path)
+    constexpr int NI2 = Cfg::kPos * 32 / kThreads_;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(ex.tail_res ? ex.tail_res : ex.tail_out), 0, (int)((uint64_t)Ntot * 256 * 2), 0x00020000);
+    unsigned off2[NI2];
+    V r2[NI2];
+#pragma unroll
+    for (int i = 0; i < NI2; i++) {
+      const int idx = tid + kThreads_ * i, pos = idx >> 5, col = idx & 31;
+      const int64_t gp = tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot);
+      off2[i] = gp >= 0 ? (unsigned)((gp * 256 + col * 8) * 2) : 0x80000000u;
+      r2[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(ex.tail_res ? off2[i] : 0x80000000u), 0, 0));
+    }
+    __syncthreads();                       // every wave has read its B fragments: the tile may be overwritten
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        using h4 = __attribute__((ext_vector_type(4))) _Float16;
+        const int och = wave4 * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
+        const h4 bq = *reinterpret_cast<const h4*>(s_bias + 64 + och);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          h4 v4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v4[e] = (_Float16)(acc3[a][b][rq * 4 + e] + (float)bq[e]);
+          *reinterpret_cast<h4*>(s_out + (128 * blk + 32 * b + (lane & 31)) * Cfg::kTailRowB + och * 2) = v4;
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI2; i++) {
+      const int idx = tid + kThreads_ * i, pos = idx >> 5, col = idx & 31;
+      V v = *reinterpret_cast<const V*>(s_out + pos * Cfg::kTailRowB + col * 16);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float f = (float)v[e] + (float)r2[i][e];
+        v[e] = (_Float16)fmaxf(f, 0.f);
+      }
+      if (off2[i] != 0x80000000u) *reinterpret_cast<V*>(reinterpret_cast<char*>(ex.tail_out) + off2[i]) = v;
+    }
+    return;
+  }
   constexpr int VPR = 8 * OG;                     // 16-byte vectors per output row
   constexpr int NI = (Cfg::kPos * VPR) / kThreads_;
   if (residual) {
@@ -1779,20 +1866,20 @@ extern "C" int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count
 
 namespace s2a {
 namespace {
-template <int TAPS, int OG, int PH = 1, int SD = 1>
+template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false>
 int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
                 _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
                 hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0, int res_up = 0,
                 ConvExtra ex = ConvExtra{nullptr, nullptr, nullptr, nullptr, 1}) {
-  using Cfg = ConvCfg<TAPS, OG, PH, SD>;
+  using Cfg = ConvCfg<TAPS, OG, PH, SD, TAIL>;
   const int64_t Ntot = B * (int64_t)Ho * Wo;
   int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + Cfg::kTH - 1) / Cfg::kTH) : (Ntot + Cfg::kPos - 1) / Cfg::kPos;
   LevelTab lt = {};
   if (levels) { lt = *levels; tiles = level_tiles; }
   dim3 grid((unsigned)tiles, (unsigned)((O + 64 * OG - 1) / (64 * OG)));
-  auto kern = k_conv_f16<TAPS, OG, PH, SD>;
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + 512));
-  kern<<<grid, 256 * PH, Cfg::kLds + 512, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
+  auto kern = k_conv_f16<TAPS, OG, PH, SD, TAIL>;
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + Cfg::kBiasBytes));
+  kern<<<grid, 256 * PH, Cfg::kLds + Cfg::kBiasBytes, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
                                      (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up, ex);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
@@ -1835,6 +1922,31 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
   if (ksize == 3) return og == 4 ? S2A_CONV(9, 4) : (og == 2 ? S2A_CONV(9, 2) : S2A_CONV(9, 1));
   return og == 4 ? S2A_CONV(1, 4) : (og == 2 ? S2A_CONV(1, 2) : S2A_CONV(1, 1));
 #undef S2A_CONV
+}
+
+extern "C" int s2a_conv3x3_tail1x1_f16(const void* x, const void* weight_frag, const void* bias,
+                                       const void* tail_weight_frag, const void* tail_bias, const void* residual,
+                                       void* out, int64_t batch, int64_t channels, int64_t mid_channels,
+                                       int64_t out_channels, int64_t height, int64_t width, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && height > 0 && width > 0, "conv3x3_tail1x1: bad shape");
+  S2A_CHECK_ARG(channels == 64 && mid_channels == 64 && out_channels == 256,
+                "conv3x3_tail1x1: built for the 64 -> 64 -> 256 bottleneck tail");
+  S2A_CHECK_ARG((uint64_t)batch * height * width * out_channels * 2 < (1ull << 31) && height < 32000 && width < 32000,
+                "conv3x3_tail1x1: tensor too large for 32-bit offsets");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(x && weight_frag && bias && tail_weight_frag && tail_bias && out, "conv3x3_tail1x1: NULL tensor");
+  S2A_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight_frag % 16) == 0 &&
+                ((uintptr_t)tail_weight_frag % 16) == 0 && ((uintptr_t)bias % 8) == 0 && ((uintptr_t)tail_bias % 8) == 0 &&
+                ((uintptr_t)residual % 16) == 0, "conv3x3_tail1x1: tensors must be 16-byte aligned");
+  ConvExtra ex{};
+  ex.store_main = 0;
+  ex.tail_w = (const _Float16*)tail_weight_frag;
+  ex.tail_b = (const _Float16*)tail_bias;
+  ex.tail_res = (const _Float16*)residual;
+  ex.tail_out = (_Float16*)out;
+  return launch_conv<9, 1, 1, 1, true>((const _Float16*)x, (const _Float16*)weight_frag, (const _Float16*)bias, nullptr,
+                                       (_Float16*)out, batch, 64, (int)height, (int)width, (int)height, (int)width, 1, 64,
+                                       1, as_stream(stream), nullptr, 0, 0, ex);
 }
 
 extern "C" int s2a_conv1x1_add_up2_f16(const void* x, const void* weight_frag, const void* bias, const void* coarse,

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import FusedConv2d
+from .fused import FusedConv2d, bottleneck_tail, bottleneck_tail_ok
 from .head import S2ANetHead
 
 
@@ -36,10 +36,12 @@ class BottleNeck(nn.Module):
     def forward(self, x):
         residual = x
         if isinstance(self.conv3, FusedConv2d):           # BN folded, epilogues fused (inference)
-            out = self.conv2(self.conv1(x))
+            out = self.conv1(x)
             if self.downsample is not None:
                 residual = self.downsample(x)
-            return self.conv3(out, residual)              # relu(conv3 + bias + residual) in one pass
+            if bottleneck_tail_ok(out, self.conv2, self.conv3, residual):
+                return bottleneck_tail(out, self.conv2, self.conv3, residual)   # conv2 + conv3 + residual: one launch
+            return self.conv3(self.conv2(out), residual)  # relu(conv3 + bias + residual) in one pass
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))

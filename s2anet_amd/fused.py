@@ -98,6 +98,36 @@ def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, 
     return out if O_real == out_channels else out[:, :O_real]
 
 
+def bottleneck_tail_ok(x, conv2, conv3, residual):
+    """the 64 -> 64 (3x3/s1) -> 256 (1x1) tail of a layer-1 bottleneck fits s2a_conv3x3_tail1x1_f16"""
+    import os
+    return (not torch.is_grad_enabled() and not os.environ.get("S2A_NO_FUSED_TAIL") and
+            isinstance(conv2, FusedConv2d) and isinstance(conv3, FusedConv2d) and
+            conv2.in_channels == 64 and conv2.out_channels == 64 and conv3.out_channels == 256 and
+            conv2.fuse_relu and conv3.fuse_relu and conv2.bias is not None and conv3.bias is not None and
+            own_conv_ok(x, 64, 64, conv2.kernel_size, conv2.stride, conv2.padding, conv2.dilation, conv2.groups) and
+            tuple(conv2.kernel_size) == (3, 3) and tuple(conv2.stride) == (1, 1) and
+            tuple(conv3.kernel_size) == (1, 1) and tuple(conv3.stride) == (1, 1) and
+            x.shape[0] * x.shape[2] * x.shape[3] * 512 < (1 << 31) and
+            (residual is None or (residual.dtype == torch.float16 and residual.shape[1] == 256 and
+                                  residual.shape[2:] == x.shape[2:] and
+                                  residual.is_contiguous(memory_format=torch.channels_last))))
+
+
+def bottleneck_tail(x, conv2, conv3, residual=None):
+    """relu(conv3(relu(conv2(x))) + residual) in ONE kernel (models/backbone.py:72-83, BN folded): the 64-map
+    intermediate stays in LDS; bit-identical to the two separate launches"""
+    B, C, H, W = x.shape
+    out = torch.empty((B, 256, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    w2, b2, _ = conv2.packed_args()
+    w3, b3, _ = conv3.packed_args()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().s2a_conv3x3_tail1x1_f16(_lib.ptr(x), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(w3), _lib.ptr(b3),
+                                                      _lib.ptr(residual), _lib.ptr(out), B, 64, 64, 256, H, W,
+                                                      _lib.stream_ptr(x.device)))
+    return out
+
+
 def conv1x1_add_up2(x, packed_weight, bias, coarse, out_channels):
     """FPN top-down step (models/neck.py:67-79) in one launch:
     conv1x1(x) + bias + nearest-2x-upsample(coarse); x[B,C,H,W], coarse[B,O,H/2,W/2] f16 channels-last"""

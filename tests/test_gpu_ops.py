@@ -435,6 +435,55 @@ def test_own_conv3x3_stride2_vs_torch():
         assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, ((B, C, H, W, O), err.max().item())
 
 
+def test_bottleneck_tail_fused_matches_two_launches(monkeypatch):
+    """conv2 (3x3 64->64) + conv3 (1x1 64->256) + residual + ReLU of a layer-1 bottleneck in one launch
+    (s2a_conv3x3_tail1x1_f16): bit-identical to the two stand-alone launches, close to torch fp32; ragged sizes
+    (partial tiles), with and without a residual; the detector block takes the fused route"""
+    from s2anet_amd.fused import FusedConv2d, bottleneck_tail, bottleneck_tail_ok, conv_f16
+    from s2anet_amd.detector import BottleNeck
+    g = torch.Generator().manual_seed(21)
+    for (B, H, W, with_res) in ((2, 64, 96, True), (1, 37, 51, True), (3, 9, 17, False), (1, 128, 128, True)):
+        x = torch.randn(B, 64, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        c2 = FusedConv2d(64, 64, 3, padding=1, relu=True).to(dev()).half()
+        c3 = FusedConv2d(64, 256, 1, relu=True).to(dev()).half()
+        with torch.no_grad():
+            c2.weight.copy_(torch.randn(64, 64, 3, 3, generator=g) * 0.05); c2.bias.copy_(torch.randn(64, generator=g) * 0.1)
+            c3.weight.copy_(torch.randn(256, 64, 1, 1, generator=g) * 0.1); c3.bias.copy_(torch.randn(256, generator=g) * 0.1)
+            res = (torch.randn(B, 256, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+                   if with_res else None)
+            assert bottleneck_tail_ok(x, c2, c3, res) or B * ((H + 7) // 8) * ((W + 15) // 16) < 64
+            fused = bottleneck_tail(x, c2, c3, res)
+            w2, b2, _ = c2.packed_args(); w3, b3, _ = c3.packed_args()
+            two = conv_f16(conv_f16(x, w2, b2, 64, 3, 1, True), w3, b3, 256, 1, 1, True, res)
+            assert torch.equal(fused, two), (B, H, W, (fused.float() - two.float()).abs().max().item())
+            m = torch.relu(torch.nn.functional.conv2d(x.float(), c2.weight.float(), c2.bias.float(), padding=1)).half().float()
+            ref = torch.nn.functional.conv2d(m, c3.weight.float(), c3.bias.float())
+            ref = torch.relu(ref + (res.float() if with_res else 0))
+            err = (fused.float() - ref).abs()
+            assert err.max().item() < 3e-2 and err.mean().item() < 2e-3, (B, H, W, err.max().item())
+    # the detector's block: fused route == separate launches
+    blk = BottleNeck(256, 64).to(dev())
+    with torch.no_grad():
+        for bn in (blk.bn1, blk.bn2, blk.bn3):
+            bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5)
+    blk.eval().half()
+    # fold by hand (fold_batchnorm expects a whole detector)
+    def fold(conv, bn):
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        f = torch.nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, bias=True).to(dev()).half()
+        f.weight.data = conv.weight * scale.view(-1, 1, 1, 1); f.bias.data = (0 - bn.running_mean) * scale + bn.bias
+        return FusedConv2d.from_conv(f, relu=True)
+    blk.conv1, blk.bn1 = fold(blk.conv1, blk.bn1), torch.nn.Identity()
+    blk.conv2, blk.bn2 = fold(blk.conv2, blk.bn2), torch.nn.Identity()
+    blk.conv3, blk.bn3 = fold(blk.conv3, blk.bn3), torch.nn.Identity()
+    x = torch.randn(2, 256, 64, 64, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        a = blk(x)
+        monkeypatch.setenv("S2A_NO_FUSED_TAIL", "1")
+        b = blk(x)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape", [(2, 256, 16, 16, 15, 3), (8, 256, 8, 8, 5, 3), (2, 256, 40, 24, 5, 1), (1, 256, 128, 128, 15, 1)])
 def test_narrow_prediction_heads(shape):
     """5 / 15-map prediction heads (head.py:205-222) on the own conv kernel with zero-padded filters;
