@@ -1110,9 +1110,11 @@ struct ConvCfg {
   static constexpr int kPatchBytes = kDma * 1024;
   static constexpr int kOutRowB = OG * 128 + 16;                      // staged output row (bytes)
   // PH = 2 (TAPS 9, OG 4): the filter of a tap (32 KB) is staged through LDS once per workgroup, two buffers
-  static constexpr bool kWLds = PH == 2 && TAPS == 9 && OG == 4;
-  static constexpr int kWBuf = 32768;
-  static constexpr int kLoop = 2 * kPatchBytes + (kWLds ? 2 * kWBuf : 0);
+  static constexpr bool kWLds = PH == 2 && TAPS == 9;
+  static constexpr int kWBuf = OG * 8192;
+  static constexpr int kLoop0 = 2 * kPatchBytes + (kWLds ? 2 * kWBuf : 0);
+  // (OG 1 with the filter through LDS: room for all nine taps behind the first patch buffer)
+  static constexpr int kLoop = (kWLds && OG == 1 && kPatchBytes + 9 * 8192 > kLoop0) ? kPatchBytes + 9 * 8192 : kLoop0;
   static constexpr int kLds0 = (kLoop > kPos * kOutRowB) ? kLoop : kPos * kOutRowB;
   static constexpr int kTailRowB = 528;                                // staged 256-map row of the fused 1x1
   static constexpr int kLds = (TAIL && kPos * kTailRowB > kLds0) ? kPos * kTailRowB : kLds0;
@@ -1283,10 +1285,10 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(wfrag), 0, (int)((uint64_t)O * (uint64_t)(CC * 64) * 9 * 2), 0x00020000);
     const int wbase = (o0 / 64) * 8192;
-    auto w_issue = [&](int s) {
+    auto w_issue = [&](int s) {      // 8 * OG pieces of 1 KB over the eight waves
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int piece = wave_u * 4 + j;
+      for (int j = 0; j < OG; j++) {
+        const int piece = wave_u * OG + j;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wb + (s & 1) * Cfg::kWBuf + piece * 1024),
                                                  16, piece * 1024 + lane * 16, s * G * 8192 + wbase, 0, 0);
       }
@@ -1307,9 +1309,27 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a], pf[b], acc[a][b], 0, 0, 0);
       }
     };
+    if (OG == 1 && CC == 1) {
+      // 64 input maps, one out-channel group: the WHOLE 3x3 filter (9 x 8 KB) goes into LDS at once (over the second
+      // patch buffer, which a one-chunk layer never uses) -- one memory latency per tile instead of one per tap
+      // (eight MFMAs per wave and tap cannot cover an L2 round trip), and no barrier inside the tile
+      char* wall = smem + Cfg::kPatchBytes;
+      patch_issue(0);
+#pragma unroll
+      for (int t = 0; t < 9; t++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wall + t * 8192 + wave_u * 1024),
+                                                 16, wave_u * 1024 + lane * 16, t * G * 8192 + wbase, 0, 0);
+      if (tid < 64) s_bias[tid] = bias_v;
+      if constexpr (TAIL) { if (tid < 256) s_bias[64 + tid] = tail_bias_v; }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 9; t++) compute_wl(smem, t, wall + t * 8192);
+      __syncthreads();
+    } else {
     patch_issue(0);
     w_issue(0);
     if (tid < 64 * OG) s_bias[tid] = bias_v;
+    if constexpr (TAIL) { if (tid < 256) s_bias[64 + tid] = tail_bias_v; }
     __syncthreads();
     for (int cc = 0; cc < CC; cc++) {
       const char* Pc = smem + (cc & 1) * Cfg::kPatchBytes;
@@ -1321,6 +1341,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
         compute_wl(Pc, t, wb + (s & 1) * Cfg::kWBuf);
         __syncthreads();     // drains this tap's DMAs (vmcnt(0)) and frees the buffers they will overwrite next
       }
+    }
     }
   } else {
   patch_issue(0);
@@ -1919,6 +1940,21 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
     return launch_conv<9, 2, 1, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 2,
                                    (int)out_channels, relu, st);
   }
+  if (ksize == 3 && og < 4 && channels % 64 == 0) {
+    // narrow 3x3 layers (the 64- and 128-map conv2 of the trunk's first stages): the four waves of an 8 x 16 tile
+    // re-load the same filter fragments (4x / 2x the bytes into the CU); 16 x 16 tiles with the filter of each tap
+    // staged once per workgroup through LDS when there are enough tiles to fill the chip.  S2A_CONV_PH_NARROW=1|2
+    const int64_t tiles16 = batch * ((Wo + 15) / 16) * ((Ho + 15) / 16) * ((out_channels + 64 * og - 1) / (64 * og));
+    int ph = tiles16 >= 256 ? 2 : 1;
+    if (const char* f = getenv("S2A_CONV_PH_NARROW")) ph = atoi(f) == 2 ? 2 : 1;
+    if (ph == 2) {
+      if (og == 2)
+        return launch_conv<9, 2, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 1,
+                                    (int)out_channels, relu, st);
+      return launch_conv<9, 1, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 1,
+                                  (int)out_channels, relu, st);
+    }
+  }
   if (ksize == 3) return og == 4 ? S2A_CONV(9, 4) : (og == 2 ? S2A_CONV(9, 2) : S2A_CONV(9, 1));
   return og == 4 ? S2A_CONV(1, 4) : (og == 2 ? S2A_CONV(1, 2) : S2A_CONV(1, 1));
 #undef S2A_CONV
@@ -1944,6 +1980,12 @@ extern "C" int s2a_conv3x3_tail1x1_f16(const void* x, const void* weight_frag, c
   ex.tail_b = (const _Float16*)tail_bias;
   ex.tail_res = (const _Float16*)residual;
   ex.tail_out = (_Float16*)out;
+  int ph = batch * ((width + 15) / 16) * ((height + 15) / 16) >= 256 ? 2 : 1;
+  if (const char* f = getenv("S2A_CONV_PH_NARROW")) ph = atoi(f) == 2 ? 2 : 1;
+  if (ph == 2)
+    return launch_conv<9, 1, 2, 1, true>((const _Float16*)x, (const _Float16*)weight_frag, (const _Float16*)bias, nullptr,
+                                         (_Float16*)out, batch, 64, (int)height, (int)width, (int)height, (int)width, 1,
+                                         64, 1, as_stream(stream), nullptr, 0, 0, ex);
   return launch_conv<9, 1, 1, 1, true>((const _Float16*)x, (const _Float16*)weight_frag, (const _Float16*)bias, nullptr,
                                        (_Float16*)out, batch, 64, (int)height, (int)width, (int)height, (int)width, 1, 64,
                                        1, as_stream(stream), nullptr, 0, 0, ex);

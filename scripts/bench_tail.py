@@ -20,7 +20,16 @@ res = torch.relu(torch.randn(B, 256, H, W, generator=g)).to(dev).half().contiguo
 c2 = FusedConv2d(64, 64, 3, padding=1, relu=True).to(dev).half()
 c3 = FusedConv2d(64, 256, 1, relu=True).to(dev).half()
 w2, b2, _ = c2.packed_args(); w3, b3, _ = c3.packed_args()
+x2 = torch.relu(torch.randn(B, 128, 128, 128, generator=g)).to(dev).half().contiguous(memory_format=torch.channels_last)
+c4 = FusedConv2d(128, 128, 3, padding=1, relu=True).to(dev).half()
+w4, b4, _ = c4.packed_args()
 with torch.no_grad():
+    for ph in ("1", "2"):
+        os.environ["S2A_CONV_PH_NARROW"] = ph
+        print(json.dumps({"ph": ph, "conv 64->64 @256^2": timeit(lambda: conv_f16(x, w2, b2, 64, 3, 1, True)),
+                          "conv 128->128 @128^2": timeit(lambda: conv_f16(x2, w4, b4, 128, 3, 1, True)),
+                          "fused tail": timeit(lambda: bottleneck_tail(x, c2, c3, res))}))
+    del os.environ["S2A_CONV_PH_NARROW"]
     t_f = timeit(lambda: bottleneck_tail(x, c2, c3, res))
     t_a = timeit(lambda: conv_f16(x, w2, b2, 64, 3, 1, True))
     m = conv_f16(x, w2, b2, 64, 3, 1, True)

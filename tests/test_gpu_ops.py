@@ -435,6 +435,36 @@ def test_own_conv3x3_stride2_vs_torch():
         assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, ((B, C, H, W, O), err.max().item())
 
 
+def test_narrow_conv3x3_filter_through_lds_matches(monkeypatch):
+    """64- and 128-map 3x3 layers on 16 x 16 tiles with the filter staged through LDS (S2A_CONV_PH_NARROW=2) are
+    bit-identical to the 8 x 16 form, ragged sizes included; same for the fused bottleneck tail"""
+    from s2anet_amd.fused import FusedConv2d, bottleneck_tail, conv_f16, conv_pack_weight
+    g = torch.Generator().manual_seed(5)
+    for (B, C, H, W, O) in ((2, 64, 40, 56, 64), (1, 128, 33, 47, 128), (2, 64, 16, 16, 128), (1, 192, 20, 20, 64)):
+        x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(O, C, 3, 3, generator=g) * 0.04).to(dev()).half()
+        b = torch.randn(O, generator=g).to(dev()).half()
+        r = torch.randn(B, O, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        wp = conv_pack_weight(w)
+        outs = {}
+        for ph in ("1", "2"):
+            monkeypatch.setenv("S2A_CONV_PH_NARROW", ph)
+            outs[ph] = (conv_f16(x, wp, b, O, 3, 1, True), conv_f16(x, wp, b, O, 3, 1, True, r))
+        assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][1], outs["2"][1]), (B, C, H, W, O)
+        ref = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), b.float(), padding=1))
+        assert (outs["2"][0].float() - ref).abs().max().item() < 3e-2
+    c2 = FusedConv2d(64, 64, 3, padding=1, relu=True).to(dev()).half()
+    c3 = FusedConv2d(64, 256, 1, relu=True).to(dev()).half()
+    x = torch.randn(2, 64, 37, 51, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+    res = torch.randn(2, 256, 37, 51, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        monkeypatch.setenv("S2A_CONV_PH_NARROW", "1")
+        a = bottleneck_tail(x, c2, c3, res)
+        monkeypatch.setenv("S2A_CONV_PH_NARROW", "2")
+        b2 = bottleneck_tail(x, c2, c3, res)
+    assert torch.equal(a, b2)
+
+
 def test_bottleneck_tail_fused_matches_two_launches(monkeypatch):
     """conv2 (3x3 64->64) + conv3 (1x1 64->256) + residual + ReLU of a layer-1 bottleneck in one launch
     (s2a_conv3x3_tail1x1_f16): bit-identical to the two stand-alone launches, close to torch fp32; ragged sizes
