@@ -1244,10 +1244,16 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   };
   // per N-tile b: byte offset of this lane's position (tap (0,0)) and k-half inside the patch;
   // the rest of a fragment address is a compile-time immediate (tap, kk)
+  // lane -> position inside a 32-position tile.  3x3 / stride 1: a tile is two patch rows of 16 pixels, 18 pixels =
+  // 162 sixteen-byte slots apart; ds_read_b128 serves lanes {0-3,12-15,20-27} (and the three like groups) in one
+  // cycle only if their slots differ mod 16, and the second row's x = 4..11 land 2 slots-classes off the first row's
+  // -> every group was 2-way conflicted (SQ_LDS_BANK_CONFLICT = half of the LDS cycles).  Rotating the second
+  // row's pixels by two lanes makes all sixteen classes distinct; the epilogue uses the same map.
+  const int lp = (TAPS == 9 && SD == 1) ? ((lane & 16) | (((lane & 15) - ((lane >> 3) & 2)) & 15)) : (lane & 31);
   int fbase[NT];
 #pragma unroll
   for (int b = 0; b < NT; b++) {
-    int pl = 128 * blk + 32 * (sub * NT + b) + (lane & 31);
+    int pl = 128 * blk + 32 * (sub * NT + b) + lp;
     int pix = TAPS == 9 ? SD * ((pl >> 4) * Cfg::kPW + (pl & 15)) : pl;
     fbase[b] = pix * kRowBytes + (lane >> 5) * 16;
   }
@@ -1414,7 +1420,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
             if (relu && !residual) v = fmaxf(v, 0.f);
             v4[e] = (_Float16)v;
           }
-          int pos = 128 * blk + 32 * (sub * NT + b) + (lane & 31);
+          int pos = 128 * blk + 32 * (sub * NT + b) + lp;
           *reinterpret_cast<h4*>(s_out + pos * Cfg::kOutRowB + och * 2) = v4;
         }
       }
@@ -1956,6 +1962,18 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
     }
   }
   if (ksize == 3) return og == 4 ? S2A_CONV(9, 4) : (og == 2 ? S2A_CONV(9, 2) : S2A_CONV(9, 1));
+  if (og == 4) {
+    // small maps (64^2 / 32^2 at batch 8): 128-position tiles give at most one workgroup per CU, and one workgroup's
+    // chunk pipeline is latency-bound (32 MFMAs per wave between two memory round trips) -- 64-position tiles fill
+    // the chip (2048 -> 512 and 2048 -> 256 on 32^2: 35 -> 26 us, 34 -> 23 us; no gain once every CU has a workgroup).  (ConvCfg<1, 4, 1, 2>: SD = 2 selects the 64-position tile; the spatial
+    // stride of a 1x1 is the cstride argument.)  S2A_CONV1_HALF=0|1
+    const int64_t wgs128 = ((int64_t)batch * Ho * Wo + 127) / 128 * (out_channels / 256);
+    bool half = wgs128 < 256;   // measured: a win only while the 128-position grid leaves CUs empty
+    if (const char* f = getenv("S2A_CONV1_HALF")) half = atoi(f) != 0;
+    if (half)
+      return launch_conv<1, 4, 1, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, stride,
+                                     (int)out_channels, relu, st);
+  }
   return og == 4 ? S2A_CONV(1, 4) : (og == 2 ? S2A_CONV(1, 2) : S2A_CONV(1, 1));
 #undef S2A_CONV
 }

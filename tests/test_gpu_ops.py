@@ -465,6 +465,26 @@ def test_narrow_conv3x3_filter_through_lds_matches(monkeypatch):
     assert torch.equal(a, b2)
 
 
+def test_conv1x1_half_tiles_match(monkeypatch):
+    """1x1 layers on 64-position tiles (small maps: more workgroups per CU) == the 128-position form, bit for bit"""
+    from s2anet_amd.fused import conv_f16, conv_pack_weight
+    g = torch.Generator().manual_seed(9)
+    for (B, C, H, W, O, st) in ((2, 1024, 24, 40, 256, 1), (1, 256, 33, 47, 1024, 1), (2, 512, 32, 32, 1024, 2), (3, 64, 5, 9, 256, 1)):
+        x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(O, C, 1, 1, generator=g) * 0.04).to(dev()).half()
+        b = torch.randn(O, generator=g).to(dev()).half()
+        Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+        r = torch.randn(B, O, Ho, Wo, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        wp = conv_pack_weight(w)
+        outs = {}
+        for half in ("0", "1"):
+            monkeypatch.setenv("S2A_CONV1_HALF", half)
+            outs[half] = (conv_f16(x, wp, b, O, 1, st, False), conv_f16(x, wp, b, O, 1, st, True, r))
+        assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1]), (B, C, H, W, O, st)
+        ref = torch.nn.functional.conv2d(x.float(), w.float(), b.float(), stride=st)
+        assert (outs["1"][0].float() - ref).abs().max().item() < 6e-2
+
+
 def test_bottleneck_tail_fused_matches_two_launches(monkeypatch):
     """conv2 (3x3 64->64) + conv3 (1x1 64->256) + residual + ReLU of a layer-1 bottleneck in one launch
     (s2a_conv3x3_tail1x1_f16): bit-identical to the two stand-alone launches, close to torch fp32; ragged sizes
