@@ -1064,6 +1064,325 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   }
 }
 
+// ------------------------------------------------------------------ persistent AlignConv
+// k_dcn_patch<NHWC, anchors> for the pyramid-packed launch, as a PERSISTENT kernel: one workgroup per CU walks tiles
+// bid, bid + grid, ...  A tile of the plain kernel spends ~17 % of its time before the first and after the last MFMA
+// (anchor / patch / filter round trips in a row, then the table, the first column tile, the output tile), and with
+// one 153 KB workgroup per CU nothing overlaps it.  Here the next tile's anchors (MFMA waves) and first patch chunk
+// (loader waves; written to the patch buffer the last chunk does not use) are fetched while the current tile's main
+// loop runs, the filter fragments of stage 0 come from the wrapped-around prefetch of the last stage, and the next
+// tile's anchor contexts are computed while the output tile is stored -- what is left between two main loops is the
+// table build, one column tile and four barriers.  Needs an even number of 64-channel chunks (the next tile's chunk 0
+// and the last chunk of this one must sit in different buffers).  LDS: [table][patch 0][B 0|1][patch 1]; the output
+// tile is staged over B and the head of patch 1, the contexts live in the tail of patch 1.
+// Arithmetic, staging and store order per tile are those of k_dcn_patch: results are bit-identical.
+__global__ __launch_bounds__(512, 2) void k_dcn_patch_persist(const _Float16* __restrict__ x_,
+                                                              const float* __restrict__ src_,
+                                                              const _Float16* __restrict__ wfrag,
+                                                              _Float16* __restrict__ out_, int C, int O, int relu,
+                                                              LevelTab lt, int ntiles) {
+  using T = _Float16;
+  using V = f16x8;
+  constexpr int NPOS = 128, NT = 4, ITEMS = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  PTap* s_tab = reinterpret_cast<PTap*>(smem);
+  char* s_P0 = smem + 128 * 9 * 16;
+  char* s_B = s_P0 + kPatchBytes;
+  char* s_P1 = s_B + 2 * 128 * kRowBytes;
+  char* s_out = s_B;                                                   // 128 x 528 B = 67584 <= 36864 + 49152
+  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_P1 + 40960);       // behind the staged tile (30720 B into patch 1)
+  static_assert(128 * kOutRow <= 2 * 128 * kRowBytes + 40960 && 40960 + 128 * (int)sizeof(AnchorCtx) <= kPatchBytes, "LDS map");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int o0 = blockIdx.y * kMaxO;
+  const int Oloc = min(kMaxO, O - o0);
+  const int CC = C / 64;
+  const int nstage = 9 * CC;
+  const int G = O / 64;
+  const unsigned row_bytes = (unsigned)C * 2;
+
+  struct Geo {
+    const T* x; const float* src; T* out;
+    int H, W, HW, Ntot, bimg, tile, ty0, tx0, oy, ox;
+    float stride;
+  };
+  auto make_geo = [&](int lin) -> Geo {
+    Geo g;
+    int tile = (int)xcd_remap((unsigned)lin, (unsigned)ntiles);
+    int t0 = 0, p0 = 0;
+    g.H = lt.H[0]; g.W = lt.W[0]; g.stride = lt.stride[0];
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; i++)
+      if (i < lt.n && tile >= lt.tile0[i]) {
+        t0 = lt.tile0[i]; p0 = lt.pix0[i]; g.H = lt.H[i]; g.W = lt.W[i]; g.stride = lt.stride[i];
+      }
+    tile -= t0;
+    g.HW = g.H * g.W;
+    g.Ntot = lt.batch * g.HW;
+    g.x = x_ + (int64_t)p0 * C;
+    g.out = out_ + (int64_t)p0 * O;
+    g.src = src_ + (int64_t)p0 * 5;
+    const int txn = (g.W + 15) / 16, tyn = (g.H + 7) / 8;
+    g.bimg = tile / (txn * tyn);
+    const int trem = tile % (txn * tyn);
+    g.ty0 = (trem / txn) * 8; g.tx0 = (trem % txn) * 16;
+    g.oy = g.ty0 - kHalo; g.ox = g.tx0 - kHalo;
+    g.tile = tile;
+    return g;
+  };
+
+  // ---- loader side: patch element v = L + 256*i: pixel v>>3, 16-byte channel group v&7
+  const int L = tid - 256;
+  unsigned pvoff[12];
+  V pv[12];
+  auto patch_offsets = [&](const Geo& g) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      int v = L + 256 * i, p = v >> 3, q = v & 7;
+      int yy = g.oy + p / kPW, xx = g.ox + p % kPW;
+      bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+      pvoff[i] = in ? (unsigned)(g.bimg * g.HW + yy * g.W + xx) * row_bytes + q * 16 : 0x80000000u;
+    }
+  };
+  auto patch_issue = [&](const Geo& g, int cc) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.x), 0, (int)((unsigned)g.Ntot * row_bytes), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 12; i++) pv[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, (int)pvoff[i], cc * 128, 0));
+  };
+  auto patch_write = [&](int cc) {
+    char* P = (cc & 1) ? s_P1 : s_P0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) *reinterpret_cast<V*>(P + (L + 256 * i) * 16) = pv[i];
+  };
+
+  // ---- MFMA side: filter fragments; anchors of the tile's 128 positions (threads 0..127; branch-free bounds-checked
+  // loads, zeros outside the image = the neutral context of k_dcn_patch)
+  const int g = min(o0 / 64 + (wave & 3), G - 1);
+  const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
+  V wA[2][4], wB[2][4];
+  auto load_w = [&](int st, V (&wv)[2][4]) {
+    const V* p = wf_base + ((int64_t)st * G + g) * 8 * 64;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
+  };
+  float anc[5];
+  auto anchors_issue = [&](const Geo& gg) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gg.src), 0, (int)((unsigned)gg.Ntot * 20u), 0x00020000);
+    const int y = gg.ty0 + ((tid & 127) >> 4), xq = gg.tx0 + (tid & 15);
+    const bool ok = tid < NPOS && y < gg.H && xq < gg.W;
+    const unsigned off = ok ? (unsigned)(gg.bimg * gg.HW + y * gg.W + xq) * 20u : 0x80000000u;
+#pragma unroll
+    for (int k = 0; k < 5; k++) anc[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 4 * k, 0));
+  };
+
+  int lin = blockIdx.x;
+  const int gstep = gridDim.x;
+  Geo cur = make_geo(lin);
+
+  // ---- first tile: everything in flight at once; contexts and patch chunk 0 into LDS
+  if (wave >= 4) {
+    patch_offsets(cur);
+    patch_issue(cur, 0);
+    patch_write(0);
+  } else {
+    anchors_issue(cur);
+    if (tid < NPOS) s_ctx[tid] = anchor_ctx(anc, cur.stride);
+  }
+  __syncthreads();
+
+  const bool wave_active = wave < 4 && wave * 64 < Oloc;
+  for (;;) {
+    const int H = cur.H, W = cur.W, HW = cur.HW, oy = cur.oy, ox = cur.ox, ty0 = cur.ty0, tx0 = cur.tx0;
+    const bool has_next = lin + gstep < ntiles;
+    // filter fragments of stage 0 (L2-resident): in flight under the table build.  (Keeping them from a wrapped-around
+    // prefetch of the previous tile's last stage costs 32 registers on the loader side of the loop -> scratch spills.)
+    if (wave < 4) load_w(0, wA);
+
+    // ---- sampling table (anchor contexts are in s_ctx; patch chunk 0 is in patch buffer 0)
+    for (int e = tid; e < NPOS * 9; e += 512) {
+      int pl = e / 9, t = e % 9;
+      int y = ty0 + (pl >> 4), xq = tx0 + (pl & 15);
+      PTap tp;
+      tp.y = (short)oy;
+      tp.x = (short)ox;
+      tp.flags = 1u;
+#pragma unroll
+      for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
+      if (y < H && xq < W) {
+        int ky = t / 3, kx = t % 3;
+        float off_y, off_x;
+        anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
+        float h_im = (float)(y - 1 + ky) + off_y;
+        float w_im = (float)(xq - 1 + kx) + off_x;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+          int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+          bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+          tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
+          tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
+          tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
+          tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
+          tp.y = (short)h_low;
+          tp.x = (short)w_low;
+          bool in = h_low >= oy && h_low + 1 <= oy + kPH - 1 && w_low >= ox && w_low + 1 <= ox + kPW - 1;
+          tp.flags = in ? 1u : 0u;
+        }
+      }
+      s_tab[e] = tp;
+    }
+    __syncthreads();                   // #1 table ready (s_ctx is dead)
+
+    if (wave < 4) {
+      // ===================== MFMA waves =====================
+      f32x16 acc[2][NT];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+      if (has_next) {                            // next tile's anchors: land long before the main loop ends
+        const Geo nxt = make_geo(lin + gstep);
+        anchors_issue(nxt);
+      }
+      auto compute = [&](int st, const V (&wv)[2][4]) {
+        if (!wave_active) return;
+        const char* prow = s_B + (st & 1) * (128 * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          V pf[NT];
+#pragma unroll
+          for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < NT; b++)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], pf[b], acc[a][b], 0, 0, 0);
+        }
+      };
+      __syncthreads();  // #2 stage 0 columns in LDS
+      for (int st = 0; st < nstage; st += 2) {   // nstage is even (CC is)
+        load_w(st + 1, wB);
+        compute(st, wA);
+        __syncthreads();
+        load_w(min(st + 2, nstage - 1), wA);
+        compute(st + 1, wB);
+        __syncthreads();
+      }
+      // output tile -> LDS (B tiles + head of patch 1: every wave is past its last read of them).  Done inside this
+      // branch so that the accumulators are not live on the loader side of the persistent loop.
+      if (wave_active) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < NT; b++)
+#pragma unroll
+            for (int rq = 0; rq < 4; rq++) {
+              using h4 = __attribute__((ext_vector_type(4))) _Float16;
+              h4 v4;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                float v = acc[a][b][rq * 4 + e];
+                if (relu) v = fmaxf(v, 0.f);
+                v4[e] = (_Float16)v;
+              }
+              int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
+              int pos = 32 * b + (lane & 31);
+              *reinterpret_cast<h4*>(s_out + pos * kOutRow + och * 2) = v4;
+            }
+      }
+      if (has_next && tid < NPOS) {       // contexts of the next tile (its anchors arrived during the main loop)
+        const Geo nxt = make_geo(lin + gstep);
+        s_ctx[tid] = anchor_ctx(anc, nxt.stride);
+      }
+    } else {
+      // ===================== loader waves =====================
+      const int64_t pix_base = (int64_t)cur.bimg * HW;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(cur.x), 0, (int)((unsigned)cur.Ntot * row_bytes), 0x00020000);
+      auto produce = [&](int st) {  // columns of stage st -> B[st&1]
+        const int t = st % 9, cc = st / 9;
+        const char* P = (cc & 1) ? s_P1 : s_P0;
+        char* Bm = s_B + (st & 1) * (128 * kRowBytes);
+        PTap tp[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) tp[it] = s_tab[((L + 256 * it) >> 3) * 9 + t];
+        V c[ITEMS][4];
+        bool any_out = false;
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+          const int q = (L + 256 * it) & 7;
+          int py = min(max((int)tp[it].y - oy, 0), kPH - 2), px = min(max((int)tp[it].x - ox, 0), kPW - 2);
+          const char* b0 = P + (py * kPW + px) * 128 + q * 16;
+          c[it][0] = *reinterpret_cast<const V*>(b0);
+          c[it][1] = *reinterpret_cast<const V*>(b0 + 128);
+          c[it][2] = *reinterpret_cast<const V*>(b0 + kPW * 128);
+          c[it][3] = *reinterpret_cast<const V*>(b0 + kPW * 128 + 128);
+          any_out |= !(tp[it].flags & 1u);
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+          const int item = L + 256 * it, pl = item >> 3, q = item & 7;
+          const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
+          *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_pk(c[it], cw);
+        }
+        if (any_out) {  // rare: a corner left the patch -> global gather for that (position, tap)
+          for (int it = 0; it < ITEMS; it++) {
+            if (tp[it].flags & 1u) continue;
+            const int item = L + 256 * it, pl = item >> 3, q = item & 7;
+            V g4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              int yy = min(max((int)tp[it].y + (k >> 1), 0), H - 1), xx = min(max((int)tp[it].x + (k & 1), 0), W - 1);
+              unsigned vo = (unsigned)((pix_base + (int64_t)yy * W + xx) * row_bytes + q * 16);
+              g4[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, cc * 128, 0));
+            }
+            const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
+            *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_pk(g4, cw);
+          }
+        }
+      };
+      patch_offsets(cur);
+      patch_issue(cur, 1);      // CC >= 2
+      produce(0);
+      __syncthreads();  // #2 stage 0 columns in LDS
+      for (int st = 0; st < nstage; st++) {
+        const int sn = st + 1;          // stage produced while stage st is consumed
+        if (sn < nstage) {
+          const int t = sn % 9, cc = sn / 9;
+          // chunk cc+1 -> its buffer (loads issued >= 3 stages ago); in the last chunk that is chunk 0 of the NEXT tile
+          if (t == 4 && (cc + 1 < CC || has_next)) patch_write(cc + 1);
+          produce(sn);
+          if (t == 8) {
+            if (cc + 2 < CC) patch_issue(cur, cc + 2);      // next-next chunk: lands during the next chunk
+            else if (cc + 2 == CC && has_next) {           // chunk 0 of the next tile
+              const Geo nxt = make_geo(lin + gstep);
+              patch_offsets(nxt);
+              patch_issue(nxt, 0);
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+
+    // ===================== epilogue: 512-byte rows of the staged tile stored
+    __syncthreads();   // E1
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      int idx = tid + 512 * i, pos = idx >> 5, col = idx & 31;
+      int64_t gp = tile_pos(cur.tile, pos, 8, H, W, HW, cur.Ntot);
+      if (gp >= 0 && col * 8 < Oloc)
+        *reinterpret_cast<V*>(cur.out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
+    }
+    if (!has_next) break;
+    lin += gstep;
+    cur = make_geo(lin);
+    __syncthreads();   // E2: the staged tile has been read -> B tiles reusable
+  }
+}
+
 // ------------------------------------------------------------------ regular convolutions (f16)
 // The conv towers of S2ANetHead (models/head.py:163-222: fam_reg_ls, fam_cls_ls, odm_reg_ls,
 // odm_cls_ls, or_conv — nine 256->256 3x3 convolutions per FPN level) are the patch-staged
@@ -2163,6 +2482,29 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
   hipStream_t st = as_stream(stream);
   // s2a_dcn_pack_weight (f16) = stage-major layout followed by the MFMA-fragment layout
   const _Float16* wfrag = (const _Float16*)weight_packed + (size_t)out_channels * channels * 9;
+  // persistent form (one workgroup per CU walking tiles, next tile's anchors / patch prefetched): bit-identical, but
+  // measured SLOWER on MI355X this round (245 vs 232 us on the bench's launch): the loop-carried state pushes the
+  // kernel over 256 VGPRs / 104 SGPRs (scratch + lane spills) and the per-tile level lookup sits on the barrier path.
+  // Opt-in (S2A_DCN_PERSIST=1) until that is fixed.
+  bool persist = false;
+  if (const char* f = getenv("S2A_DCN_PERSIST")) persist = atoi(f) != 0;
+  if (persist && channels % 128 == 0) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      S2A_HIP(hipGetDevice(&dev));
+      S2A_HIP(hipGetDeviceProperties(&prop, dev));
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    auto pk = k_dcn_patch_persist;
+    dim3 pgrid((unsigned)std::min<int64_t>(tiles, n_cu), (unsigned)((out_channels + kMaxO - 1) / kMaxO));
+    S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
+    pk<<<pgrid, 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, (int)channels, (int)out_channels,
+                                     relu, lt, (int)tiles);
+    S2A_LAUNCH_CHECK();
+    return S2A_OK;
+  }
   auto kern = k_dcn_patch<true, 1>;
   dim3 grid((unsigned)tiles, (unsigned)((out_channels + kMaxO - 1) / kMaxO));
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));

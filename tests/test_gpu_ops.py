@@ -701,6 +701,37 @@ def test_pyramid_alignconv_and_refine(rng):
         assert np.abs(got - ref).max() < 3e-2
 
 
+def test_pyramid_alignconv_persistent_matches_plain(monkeypatch):
+    """the persistent form of the pyramid-packed AlignConv (one workgroup per CU walking tiles, next tile prefetched)
+    is bit-identical to the one-tile-per-workgroup kernel: more tiles than CUs, ragged level sizes, wild anchors
+    (corners leaving the LDS patch take the global-gather path)"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.alignconv import pack_weight
+    B, C = 3, 256
+    sizes = [(96, 136), (48, 68), (24, 34), (12, 17), (6, 9)]
+    strides = (8, 16, 32, 64, 128)
+    lay = P.PyramidLayout(B, sizes, strides)
+    g = torch.Generator().manual_seed(77)
+    x = torch.relu(torch.randn(lay.pixels, C, generator=g)).to(dev()).half()
+    anchors = []
+    for (h, w), st in zip(sizes, strides):
+        ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        a = torch.stack([xs * st + 0.5 * (st - 1) + torch.randn(h, w, generator=g) * st * 0.7,
+                         ys * st + 0.5 * (st - 1) + torch.randn(h, w, generator=g) * st * 0.7,
+                         4 * st * torch.exp(torch.randn(h, w, generator=g) * 0.6),
+                         4 * st * torch.exp(torch.randn(h, w, generator=g) * 0.6),
+                         torch.rand(h, w, generator=g) * 3.14159 - 0.785], -1).float()
+        anchors.append(a.unsqueeze(0).expand(B, -1, -1, -1).reshape(-1, 5))
+    anchors = torch.cat(anchors).to(dev()).contiguous()
+    wp = pack_weight((torch.randn(256, C, 3, 3, generator=g) * 0.02).to(dev()).half(), torch.float16)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("S2A_DCN_PERSIST", mode)
+        outs[mode] = P.align_conv(lay, x, anchors, wp, 256).clone()
+    assert torch.equal(outs["0"], outs["1"]), (outs["0"].float() - outs["1"].float()).abs().max().item()
+    assert outs["1"].float().abs().sum().item() > 0
+
+
 def test_detector_pyramid_path_matches_per_level(monkeypatch):
     """the whole head on the pyramid-packed path == the per-level path (library kernels on the small levels)"""
     from s2anet_amd.detector import build_synthetic_detector
