@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs2anet_hip.so")
+LIB_PATH = os.environ.get("S2A_LIB_PATH") or os.path.join(_HERE, "libs2anet_hip.so")   # override: A/B builds
 
 OK, EINVAL, EWORKSPACE, EHIP, ENOTIMPL = 0, -1, -2, -3, -4
 DTYPE_F32, DTYPE_F16 = 0, 1

@@ -858,7 +858,10 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         tp.y = (short)h_low;
         tp.x = (short)w_low;
         bool in = h_low >= oy && h_low + 1 <= oy + kPH - 1 && w_low >= ox && w_low + 1 <= ox + kPW - 1;
-        tp.flags = in ? 1u : 0u;
+        // bits 31..1: byte offset of the top-left corner inside a patch buffer (clamped for corners that left the
+        // patch: those items are redone from global memory) -- the loader adds it instead of re-deriving it per stage
+        const int py = min(max(h_low - oy, 0), kPH - 2), px = min(max(w_low - ox, 0), kPW - 2);
+        tp.flags = (in ? 1u : 0u) | ((unsigned)((py * kPW + px) * 128) << 1);
       }
     }
     s_tab[e] = tp;
@@ -937,29 +940,34 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
       for (int i = 0; i < 12; i++) *reinterpret_cast<V*>(P + (L + 256 * i) * 16) = pv[i];
     };
-    auto produce = [&](int s) {  // columns of stage s -> B[s&1]
-      if (S2A_ABL & 2) return;
+    // The operands of a stage (4 table entries, 16 corner vectors per thread) are FETCHED one stage ahead -- right
+    // after the previous stage's columns have been written, so their LDS latency (table read, then the dependent
+    // corner reads) runs under the barrier wait instead of in front of the blend.
+    PTap tp[ITEMS];
+    V c[ITEMS][4];
+    auto fetch = [&](int s) {
       const int t = s % 9, cc = s / 9;
-      const char* P = s_patch + (cc & 1) * kPatchBytes;
-      char* Bm = s_B + (s & 1) * (128 * kRowBytes);
-      // batched so that the LDS latencies overlap: 4 table reads, then 16 patch reads, then 4 blends
-      PTap tp[ITEMS];
+      const char* P = s_patch + (cc & 1) * kPatchBytes + (L & 7) * 16;   // (item & 7 = L & 7 for every item)
 #pragma unroll
-      for (int it = 0; it < ITEMS; it++) tp[it] = s_tab[((L + 256 * it) >> 3) * 9 + t];
-      V c[ITEMS][4];
-      bool any_out = false;
+      for (int it = 0; it < ITEMS; it++)      // one 16-byte read per entry
+        tp[it] = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[((L + 256 * it) >> 3) * 9 + t]));
 #pragma unroll
       for (int it = 0; it < ITEMS; it++) {
-        const int q = (L + 256 * it) & 7;
-        // out-of-patch items read a clamped (wrong) location here and are redone below
-        int py = min(max((int)tp[it].y - oy, 0), kPH - 2), px = min(max((int)tp[it].x - ox, 0), kPW - 2);
-        const char* b0 = P + (py * kPW + px) * 128 + q * 16;
+        // out-of-patch items read a clamped (wrong) location here and are redone in produce()
+        const char* b0 = P + (tp[it].flags >> 1);
         c[it][0] = *reinterpret_cast<const V*>(b0);
         c[it][1] = *reinterpret_cast<const V*>(b0 + 128);
         c[it][2] = *reinterpret_cast<const V*>(b0 + kPW * 128);
         c[it][3] = *reinterpret_cast<const V*>(b0 + kPW * 128 + 128);
-        any_out |= !(tp[it].flags & 1u);
       }
+    };
+    auto produce = [&](int s) {  // columns of stage s (operands fetched before) -> B[s&1]
+      if (S2A_ABL & 2) return;
+      const int cc = s / 9;
+      char* Bm = s_B + (s & 1) * (128 * kRowBytes);
+      bool any_out = false;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) any_out |= !(tp[it].flags & 1u);
 #pragma unroll
       for (int it = 0; it < ITEMS; it++) {
         const int item = L + 256 * it, pl = item >> 3, q = item & 7;
@@ -985,7 +993,9 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     };
 
     if (CC > 1) patch_issue(1);
+    fetch(0);
     produce(0);
+    if (nstage > 1) fetch(1);
     S2A_STAMP_AT(6);
     __syncthreads();  // #2 stage 0 columns in LDS
     S2A_STAMP_AT(3);
@@ -999,6 +1009,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         if (t == 4 && cc + 1 < CC) patch_write(cc + 1);   // loads issued >= 3 stages ago
         produce(sn);
         if (t == 8 && cc + 2 < CC) patch_issue(cc + 2);   // next-next chunk: lands during the next chunk
+        if (sn + 1 < nstage) fetch(sn + 1);               // (chunk of stage sn+1: written >= 4 stages ago)
       }
       S2A_TOC(t_work); S2A_TIC();
       __syncthreads();
