@@ -182,8 +182,8 @@ def measure_conv_tower(model, cap, iters=100):
             "flops_per_launch": flops}
 
 
-def cpu_baseline(seed, candidates):
-    """ONE chip through the same pipeline on the host cores (fp32): torch CPU convolutions for the
+def cpu_baseline(seed, candidates, chips=3):
+    """`chips` chips (one after the other, ~10-15 s) through the same pipeline on the host cores (fp32): torch CPU convolutions for the
     carrier and the plain conv layers of the head, the oracle for AlignConv / ARF / pooling /
     decode, and the reference's own CPU ml_nms_rotated (oracle/_ref) when it is present."""
     import numpy as np
@@ -196,7 +196,7 @@ def cpu_baseline(seed, candidates):
     for mod in m.modules():
         if mod.__class__.__name__ == "BottleNeck":
             mod.bn3.weight.data.fill_(0.25)
-    img = torch.randint(0, 256, (1, 3, CHIP, CHIP), dtype=torch.uint8)
+    imgs = torch.randint(0, 256, (chips, 3, CHIP, CHIP), dtype=torch.uint8)
     ncores = min(os.cpu_count() or 1, 16)              # the GPU box's CPU share for one GPU
     torch.set_num_threads(ncores)
     try:
@@ -207,54 +207,58 @@ def cpu_baseline(seed, candidates):
     ref_nms = ref.ml_nms_rotated()
     h = m.head
     t0 = time.time()
-    with torch.no_grad():
-        feats = m.neck(m.backbone(img.float() / 255.0))
-        sc_l, de_l, an_l = [], [], []
-        for x, s in zip(feats, m.stride):
-            fam_bbox = h.fam_reg_head(h.fam_reg_ls(x))
-            h.fam_cls_head(h.fam_cls_ls(x))
-            H, W = x.shape[-2:]
-            anchors = oracle.grid_anchors(H, W, s)
-            refined = oracle.delta2bbox_rotated(anchors, fam_bbox[0].permute(1, 2, 0).reshape(-1, 5).numpy(), 1e-6)
-            off = oracle.align_offsets(refined, H, W, s)[None]
-            al = oracle.deform_conv_forward(x.numpy(), off, h.align_conv.deform_conv.weight.numpy(), relu=True)
-            arf = torch.from_numpy(oracle.arf_forward(h.or_conv.weight.numpy(), h.or_conv.indices.numpy()))
-            or_feat = F.conv2d(torch.from_numpy(al), arf, h.or_conv.bias, padding=1)
-            pooled = torch.from_numpy(oracle.rot_inv_pool(or_feat.numpy(), 8))
-            cls = h.odm_cls_head(h.odm_cls_ls(pooled))
-            reg = h.odm_reg_head(h.odm_reg_ls(or_feat))
-            sc = cls[0].permute(1, 2, 0).reshape(-1, NUM_CLASSES).sigmoid()
-            de = reg[0].permute(1, 2, 0).reshape(-1, 5)
-            an = torch.from_numpy(refined)
-            if sc.shape[0] > 2000:
-                top = sc.max(1)[0].topk(2000)[1]
-                sc, de, an = sc[top], de[top], an[top]
-            sc_l.append(sc), de_l.append(de), an_l.append(an)
-        scores, deltas, anc = torch.cat(sc_l), torch.cat(de_l), torch.cat(an_l)
-        # same candidate load as the GPU run: threshold at the quantile that yields `candidates`
-        k = min(candidates, scores.numel() - 1)
-        thr = torch.topk(scores.reshape(-1), k + 1)[0][-1].item()
-        boxes = oracle.delta2bbox_rotated(anc.numpy(), deltas.numpy())
-        mask = scores > thr
-        idx = mask.nonzero()
-        cb = torch.from_numpy(boxes)[idx[:, 0]].contiguous()
-        cs = scores[mask].contiguous()
-        cl = idx[:, 1].float().contiguous()
-        t_nms0 = time.time()
-        if ref_nms is not None:
-            keep = ref_nms(cb, cs, cl, 0.5)
-            kind = "reference"
-        else:
-            keep = oracle.ml_nms_rotated(cb.numpy(), cs.numpy(), cl.numpy(), 0.5, rule=oracle.RULE_GE,
-                                         sort_mode=oracle.SORT_CPU)
-            kind = "port"
-        t_nms = time.time() - t_nms0
+    t_nms, n_cand, n_keep = 0.0, 0, 0
+    for ci in range(chips):
+      img = imgs[ci:ci + 1]
+      with torch.no_grad():
+          feats = m.neck(m.backbone(img.float() / 255.0))
+          sc_l, de_l, an_l = [], [], []
+          for x, s in zip(feats, m.stride):
+              fam_bbox = h.fam_reg_head(h.fam_reg_ls(x))
+              h.fam_cls_head(h.fam_cls_ls(x))
+              H, W = x.shape[-2:]
+              anchors = oracle.grid_anchors(H, W, s)
+              refined = oracle.delta2bbox_rotated(anchors, fam_bbox[0].permute(1, 2, 0).reshape(-1, 5).numpy(), 1e-6)
+              off = oracle.align_offsets(refined, H, W, s)[None]
+              al = oracle.deform_conv_forward(x.numpy(), off, h.align_conv.deform_conv.weight.numpy(), relu=True)
+              arf = torch.from_numpy(oracle.arf_forward(h.or_conv.weight.numpy(), h.or_conv.indices.numpy()))
+              or_feat = F.conv2d(torch.from_numpy(al), arf, h.or_conv.bias, padding=1)
+              pooled = torch.from_numpy(oracle.rot_inv_pool(or_feat.numpy(), 8))
+              cls = h.odm_cls_head(h.odm_cls_ls(pooled))
+              reg = h.odm_reg_head(h.odm_reg_ls(or_feat))
+              sc = cls[0].permute(1, 2, 0).reshape(-1, NUM_CLASSES).sigmoid()
+              de = reg[0].permute(1, 2, 0).reshape(-1, 5)
+              an = torch.from_numpy(refined)
+              if sc.shape[0] > 2000:
+                  top = sc.max(1)[0].topk(2000)[1]
+                  sc, de, an = sc[top], de[top], an[top]
+              sc_l.append(sc), de_l.append(de), an_l.append(an)
+          scores, deltas, anc = torch.cat(sc_l), torch.cat(de_l), torch.cat(an_l)
+          # same candidate load as the GPU run: threshold at the quantile that yields `candidates`
+          k = min(candidates, scores.numel() - 1)
+          thr = torch.topk(scores.reshape(-1), k + 1)[0][-1].item()
+          boxes = oracle.delta2bbox_rotated(anc.numpy(), deltas.numpy())
+          mask = scores > thr
+          idx = mask.nonzero()
+          cb = torch.from_numpy(boxes)[idx[:, 0]].contiguous()
+          cs = scores[mask].contiguous()
+          cl = idx[:, 1].float().contiguous()
+          t_nms0 = time.time()
+          if ref_nms is not None:
+              keep = ref_nms(cb, cs, cl, 0.5)
+              kind = "reference"
+          else:
+              keep = oracle.ml_nms_rotated(cb.numpy(), cs.numpy(), cl.numpy(), 0.5, rule=oracle.RULE_GE,
+                                           sort_mode=oracle.SORT_CPU)
+              kind = "port"
+          t_nms += time.time() - t_nms0
+          n_cand += int(cb.shape[0]); n_keep += len(keep)
     sec = time.time() - t0
     return {
-        "value": round(1.0 / sec, 4), "unit": "chips/s", "cores": ncores, "kind": kind,
-        "sample": "1 chip 1024x1024, fp32, %d NMS candidates: torch-CPU convolutions + oracle AlignConv/ARF/"
-                  "pooling/decode (OpenMP) + %s ml_nms_rotated (1 thread, %.2f s of %.2f s); kept %d"
-                  % (int(cb.shape[0]), "reference CPU" if kind == "reference" else "oracle", t_nms, sec, len(keep)),
+        "value": round(chips / sec, 4), "unit": "chips/s", "cores": ncores, "kind": kind,
+        "sample": "%d chips 1024x1024 one after the other, fp32, %d NMS candidates per chip: torch-CPU convolutions + "
+                  "oracle AlignConv/ARF/pooling/decode (OpenMP) + %s ml_nms_rotated (1 thread, %.2f s of %.2f s); kept %d per chip"
+                  % (chips, n_cand // chips, "reference CPU" if kind == "reference" else "oracle", t_nms, sec, n_keep // chips),
     }
 
 
