@@ -46,6 +46,21 @@ __device__ __forceinline__ uint32_t float_sortable(float f) {
 }
 
 // ---------------------------------------------------------------- pre-pass
+// both box sets of box_iou_rotated in one launch; the first threads also reset the per-chunk pair counters
+__global__ void k_prep_boxes2(const float* __restrict__ b1, int64_t n, PreBox* __restrict__ o1,
+                              const float* __restrict__ b2, int64_t m, PreBox* __restrict__ o2,
+                              unsigned long long* __restrict__ counters, int ncounters) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncounters) counters[i] = 0ull;
+  if (i < n) {
+    const float* b = b1 + 5 * i;
+    o1[i] = make_prebox(b[0], b[1], b[2], b[3], b[4], 0.f);
+  } else if (i < n + m) {
+    const float* b = b2 + 5 * (i - n);
+    o2[i - n] = make_prebox(b[0], b[1], b[2], b[3], b[4], 0.f);
+  }
+}
+
 __global__ void k_prep_boxes(const float* __restrict__ boxes5, int64_t n, PreBox* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -90,14 +105,17 @@ __device__ __forceinline__ void queue_flush(PairQueue& Q, uint2* __restrict__ gq
 
 // ================================================================= box_iou_rotated
 // CULL: workgroup = 1024 columns (4 per lane: one 16-byte store per lane per row) x up to 64 rows.
-// Every element of the tile is stored here as 0.0f — exact for culled pairs; the ~1 % that survive
+// Every element of the tile is stored here as 0.0f -- exact for culled pairs; the ~1 % that survive
 // the cull are also queued and overwritten by the heavy pass (same stream, later kernel).  Row boxes
-// are staged in LDS and read one iteration ahead so no row waits on a load.  HBM-write-bound.
+// are staged in LDS and read one iteration ahead so no row waits on a load.  HBM-write-bound, so the
+// kernel keeps its LDS small (18 KB: eight workgroups = 32 waves per CU; the first version staged the column
+// boxes as well, 76 KB = two workgroups per CU, and reached a quarter of the write bandwidth).
+// Queue discipline: every decision that all threads must take alike is taken through __syncthreads_or -- a
+// plain read of an LDS counter after a barrier is NOT uniform (a fast wave may already be pushing again).
 constexpr int kIouRowsPerWg = 64;
-constexpr int kIouQueue = 3072;      // LDS pair queue of this kernel (survivors of BOTH tests)
-constexpr int kIouFlushAt = 2048;
-constexpr int kIouQ1 = 6144;         // first-stage queue: circle-test survivors, (row << 10 | column) per entry
-constexpr int kIouQ1FlushAt = 4096;  // <= 2048 pushes per two rows on top of this
+constexpr int kIouQueue = 1024;      // LDS pair queue (survivors of BOTH tests); a drain batch adds <= 256
+constexpr int kIouQ1 = 3072;         // first-stage queue: circle-test survivors, (row << 10 | column) per entry
+constexpr int kIouQ1DrainAt = 1024;  // <= 2048 pushes per two rows on top of this
 
 __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict__ P1,
                                                        const PreBox* __restrict__ P2,
@@ -109,7 +127,6 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
   __shared__ uint2 s_q[kIouQueue];
   __shared__ unsigned s_count, s_base[2], s_cnt1;
   __shared__ PreBox s_rows[kIouRowsPerWg];
-  __shared__ PreBox s_cols[kThreads * 4];
   __shared__ unsigned short s_q1[kIouQ1];
   PairQueue Q{s_q, &s_count, s_base};
   if (threadIdx.x == 0) { s_count = 0; s_cnt1 = 0; }
@@ -124,7 +141,6 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
   for (int k = 0; k < 4; k++) {
     PreBox b = {};
     if (j0 + k < m) b = P2[j0 + k];
-    s_cols[threadIdx.x * 4 + k] = b;
     bx[k] = b.x; by[k] = b.y; br[k] = b.r;
   }
   const bool vec_ok = (j0 + 3 < m) && ((m & 3) == 0);   // 16-byte aligned full group
@@ -132,17 +148,21 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
 
   // Second stage, dense: every lane takes one circle-test survivor from the LDS queue and runs the
   // separating-axis test on it (a wave with ANY surviving lane used to run the SAT for all its lanes: 86 % of
-  // the iterations at a 3 % survival rate -- that, not the 4 B/pair of output, set the kernel's time).
+  // the iterations at a 3 % survival rate).  Column boxes come from global memory here (L2-resident, ~3 % of the
+  // pairs).  Called by all threads, after a barrier that made the first-stage pushes visible.
   auto drain_q1 = [&]() {
-    const unsigned cnt1 = s_cnt1;                          // uniform (read after a barrier)
-    for (unsigned e = threadIdx.x; e < cnt1; e += kThreads) {
-      const unsigned v = s_q1[e], r = v >> 10, jl = v & 1023u;
-      if (!sat_disjoint(s_rows[r], s_cols[jl]))
-        queue_push(Q, (unsigned)(rbeg + r - row0), (unsigned)(jw + jl));
+    const unsigned cnt1 = s_cnt1;                          // stable: nobody pushes to s_q1 during a drain
+    for (unsigned e0 = 0; e0 < cnt1; e0 += kThreads) {     // uniform trip count
+      if (__syncthreads_or(s_count > kIouQueue - kThreads)) queue_flush(Q, gq, gcount, cap);
+      const unsigned e = e0 + threadIdx.x;
+      if (e < cnt1) {
+        const unsigned v = s_q1[e], r = v >> 10, jl = v & 1023u;
+        const PreBox B = P2[jw + jl];
+        if (!sat_disjoint(s_rows[r], B)) queue_push(Q, (unsigned)(rbeg + r - row0), (unsigned)(jw + jl));
+      }
     }
-    __syncthreads();
+    __syncthreads();                                       // all entries consumed
     if (threadIdx.x == 0) s_cnt1 = 0;
-    if (s_count > kIouFlushAt - 1024) queue_flush(Q, gq, gcount, cap);   // uniform
     __syncthreads();
   };
 
@@ -166,9 +186,8 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
       for (int k = 0; k < 4; k++)
         if (j0 + k < m) dst[k] = 0.f;
     }
-    if ((r & 1) == 1) {          // <= 2048 pushes per two rows: neither queue can overflow
-      __syncthreads();
-      if (s_cnt1 > kIouQ1FlushAt) drain_q1();              // uniform
+    if ((r & 1) == 1) {          // <= 2048 pushes per two rows: the first-stage queue cannot overflow
+      if (__syncthreads_or(s_cnt1 > kIouQ1DrainAt)) drain_q1();
     }
   }
   __syncthreads();
@@ -179,14 +198,27 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
 // HEAVY: dense list, one pair per lane, persistent grid
 __global__ __launch_bounds__(kThreads) void k_iou_heavy(const PreBox* __restrict__ P1,
                                                         const PreBox* __restrict__ P2,
-                                                        int64_t row0, int64_t m,
+                                                        int64_t row0, int64_t row1, int64_t m,
                                                         float* __restrict__ out,
                                                         const uint2* __restrict__ gq,
                                                         const unsigned long long* __restrict__ gcount,
                                                         unsigned long long cap) {
   __shared__ float2 s_pts[24 * kThreads];
   unsigned long long total = *gcount;
-  if (total > cap) total = cap;
+  if (total > cap) {
+    // Overflow fallback: the pair list of this chunk did not fit (extremely dense inputs).  Recompute the whole chunk
+    // pair by pair (the divergence that the list avoids is irrelevant when most pairs are heavy anyway).
+    const int64_t all = (row1 - row0) * m;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < all; e += (int64_t)gridDim.x * kThreads) {
+      int64_t i = row0 + e / m, j = e % m;
+      PreBox A = P1[i], B = P2[j];
+      float v = 0.f;
+      if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B))
+        v = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
+      out[i * m + j] = v;
+    }
+    return;
+  }
   for (unsigned long long e = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; e < total;
        e += (unsigned long long)gridDim.x * kThreads) {
     uint2 ij = gq[e];
@@ -207,27 +239,6 @@ __global__ __launch_bounds__(kThreads) void k_iou_pairs(const float* __restrict_
   PreBox A = make_prebox(a[0], a[1], a[2], a[3], a[4], 0.f);
   PreBox B = make_prebox(b[0], b[1], b[2], b[3], b[4], 0.f);
   out[i] = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
-}
-
-// Overflow fallback: the pair list of a chunk did not fit (extremely dense inputs).  Recompute the
-// whole chunk pair by pair (the divergence that the list avoids is irrelevant when most pairs are
-// heavy anyway).  Exits immediately in the normal case.
-__global__ __launch_bounds__(kThreads) void k_iou_direct(const PreBox* __restrict__ P1,
-                                                         const PreBox* __restrict__ P2, int64_t row0,
-                                                         int64_t row1, int64_t m, float* __restrict__ out,
-                                                         const unsigned long long* __restrict__ gcount,
-                                                         unsigned long long cap) {
-  if (*gcount <= cap) return;
-  __shared__ float2 s_pts[24 * kThreads];
-  const int64_t total = (row1 - row0) * m;
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
-    int64_t i = row0 + e / m, j = e % m;
-    PreBox A = P1[i], B = P2[j];
-    float v = 0.f;
-    if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B))
-      v = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
-    out[i * m + j] = v;
-  }
 }
 
 constexpr unsigned long long kIouQueueCap = 32ull << 20;  // 32 Mi pairs = 256 MiB
@@ -470,8 +481,9 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
       }
     }
     if (has_next && threadIdx.x < 64) s_col[cur ^ 1][threadIdx.x] = nb;
-    __syncthreads();
-    if (s_count > kFlushAt) queue_flush(Q, gq, gcount, cap);
+    // (uniform decision through the barrier's OR: a plain read of s_count after a barrier can differ between waves,
+    // a fast one may already be pushing pairs of the next tile)
+    if (__syncthreads_or(s_count > kFlushAt)) queue_flush(Q, gq, gcount, cap);
     cur ^= 1;
     t = tn;
   }
@@ -991,20 +1003,17 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   unsigned long long cap = (workspace_bytes - cv.off) / sizeof(uint2);
   uint2* gq = reinterpret_cast<uint2*>(static_cast<char*>(workspace) + cv.off);
   // rows per chunk: sized for up to 1/4 of the pairs surviving the cull (DOTA-like inputs: ~1 %);
-  // a denser chunk overflows the list and is recomputed by k_iou_direct
+  // a denser chunk overflows the list and is recomputed pair by pair inside k_iou_heavy
   int64_t rows_per_chunk = (int64_t)std::min<unsigned long long>((unsigned long long)n, 4 * (cap / (unsigned long long)m));
   rows_per_chunk = std::max<int64_t>(256, rows_per_chunk / 256 * 256);
   int64_t chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
   S2A_CHECK_ARG(chunks <= 512, "box_iou_rotated: workspace too small for %lld x %lld", (long long)n, (long long)m);
-  k_prep_boxes<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(boxes1, n, P1);
-  k_prep_boxes<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(boxes2, m, P2);
-  S2A_HIP(hipMemsetAsync(counters, 0, 512 * sizeof(unsigned long long), st));
+  k_prep_boxes2<<<(unsigned)((std::max<int64_t>(n + m, 512) + 255) / 256), 256, 0, st>>>(boxes1, n, P1, boxes2, m, P2, counters, 512);
   for (int64_t c = 0; c < chunks; c++) {
     int64_t r0 = c * rows_per_chunk, r1 = std::min(n, r0 + rows_per_chunk);
     dim3 grid((unsigned)((m + kThreads * 4 - 1) / (kThreads * 4)), (unsigned)((r1 - r0 + kIouRowsPerWg - 1) / kIouRowsPerWg));
     k_iou_cull<<<grid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
-    k_iou_heavy<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, m, ious, gq, counters + c, cap);
-    k_iou_direct<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, counters + c, cap);
+    k_iou_heavy<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
   }
   S2A_LAUNCH_CHECK();
   return S2A_OK;

@@ -73,6 +73,22 @@ def test_iou_dense_overlap_chunks(rng):
     assert (bits(out) != bits(ref)).sum() == 0
 
 
+def test_iou_dense_overlap_wide(rng):
+    """every pair of a 1200 x 2100 problem overlapping: full 1024-column workgroups whose circle- and SAT-survivor
+    queues fill and drain many times per tile (queue capacity / flush discipline of k_iou_cull)"""
+    import s2anet_amd as S
+    b1, b2 = rand_rboxes(rng, 1200, span=25, lo=30, hi=60), rand_rboxes(rng, 2100, span=25, lo=30, hi=60)
+    out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
+    ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU)
+    assert (out > 0).mean() > 0.95
+    assert (bits(out) != bits(ref)).sum() == 0
+    # half dense, half sparse columns: both paths inside one workgroup
+    b2[1000:, :2] += 5000.0
+    out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
+    ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU)
+    assert (bits(out) != bits(ref)).sum() == 0 and (out[:, 1000:] == 0).all()
+
+
 # ------------------------------------------------------------------ NMS
 @pytest.mark.parametrize("thr", [0.1, 0.5])
 def test_nms_golden_keep_bitexact(thr):
