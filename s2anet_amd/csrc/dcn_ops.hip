@@ -244,10 +244,12 @@ __device__ __forceinline__ f16x8 blend_pk(const f16x8 (&v)[4], const float (&w)[
   for (int e = 0; e < 4; e++) {
     f16x2 a0 = {v[0][2 * e], v[0][2 * e + 1]}, a1 = {v[1][2 * e], v[1][2 * e + 1]};
     f16x2 a2 = {v[2][2 * e], v[2][2 * e + 1]}, a3 = {v[3][2 * e], v[3][2 * e + 1]};
+    // explicit FMAs: with plain `w1 * a1 + acc` the compiler is free to fuse EITHER product of a sum of two products
+    // into the add, and picks differently between instantiations (1-ulp differences between tile shapes)
     f16x2 acc = w0 * a0;
-    acc = w1 * a1 + acc;
-    acc = w2 * a2 + acc;
-    acc = w3 * a3 + acc;
+    acc = __builtin_elementwise_fma(w1, a1, acc);
+    acc = __builtin_elementwise_fma(w2, a2, acc);
+    acc = __builtin_elementwise_fma(w3, a3, acc);
     r[2 * e] = acc[0];
     r[2 * e + 1] = acc[1];
   }
@@ -729,23 +731,33 @@ __global__ void k_pack_weight_frag(const _Float16* __restrict__ w, int O, int C,
 
 constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs + 16 B pad
 
-template <bool OUT_NHWC, int SRC>
+// TH = rows of the position tile: 8 (128 positions), or 4 (64 positions: the half tiles that finish a pyramid launch
+// whose last round would leave most CUs idle; tile index = tile_base + block / 2, upper / lower half = block & 1)
+template <bool OUT_NHWC, int SRC, int TH = 8>
 __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict__ x_,
                                                       const float* __restrict__ src_,
                                                       const _Float16* __restrict__ wfrag,
                                                       _Float16* __restrict__ out_, int64_t Ntot_, int C,
                                                       int H_, int W_, int O, float stride_, int relu,
-                                                      unsigned x_bytes_, LevelTab lt) {
+                                                      unsigned x_bytes_, LevelTab lt, int tile_base = 0) {
   using T = _Float16;
   using V = f16x8;
-  constexpr int NPOS = 128, NT = 4, ITEMS = 4;
+  constexpr int NPOS = TH * 16, NT = NPOS / 32, ITEMS = NPOS / 32;
+  constexpr int kPHt = TH + 2 * kHalo;                 // patch rows
+  constexpr int kPatchBytesT = kPHt * kPW * 128;
+  constexpr int NPV = kPHt * kPW * 8 / 256;            // 16-byte patch vectors per loader thread (12 | 9)
+  static_assert(TH == 8 || TH == 4, "tile height");
+  static_assert(kPHt * kPW * 8 % 256 == 0, "patch vectors must divide among the loader threads");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PTap* s_tab = reinterpret_cast<PTap*>(smem);
-  char* s_B = smem + 128 * 9 * 16;
-  char* s_patch = s_B + 2 * 128 * kRowBytes;
+  char* s_B = smem + NPOS * 9 * 16;
+  char* s_patch = s_B + 2 * NPOS * kRowBytes;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int half = TH == 4 ? (int)(tile & 1) : 0;
+  if (TH == 4) tile >>= 1;
+  tile += tile_base;
   const T* x = x_;
   const float* src = src_;
   T* out = out_;
@@ -771,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   const int txn = (W + 15) / 16, tyn = (H + 7) / 8;
   const int64_t bimg = tile / (txn * tyn);
   const int trem = (int)(tile % (txn * tyn));
-  const int ty0 = (trem / txn) * 8, tx0 = (trem % txn) * 16;
+  const int ty0 = (trem / txn) * 8 + 4 * half, tx0 = (trem % txn) * 16;
   const int oy = ty0 - kHalo, ox = tx0 - kHalo;
   const int o0 = blockIdx.y * kMaxO;
   const int Oloc = min(kMaxO, O - o0);
@@ -786,11 +798,11 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   // under the table build).  patch element v = L + 256*i: pixel v>>3, 16-byte channel group v&7;
   // out-of-image pixels get an out-of-range offset -> the bounds-checked load returns zeros.
   const int L = tid - 256;
-  unsigned pvoff[12];
-  V pv[12];
+  unsigned pvoff[NPV];
+  V pv[NPV];
   if (wave >= 4) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < NPV; i++) {
       int v = L + 256 * i, p = v >> 3, q = v & 7;
       int yy = oy + p / kPW, xx = ox + p % kPW;
       bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
@@ -857,10 +869,10 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
         tp.y = (short)h_low;
         tp.x = (short)w_low;
-        bool in = h_low >= oy && h_low + 1 <= oy + kPH - 1 && w_low >= ox && w_low + 1 <= ox + kPW - 1;
+        bool in = h_low >= oy && h_low + 1 <= oy + kPHt - 1 && w_low >= ox && w_low + 1 <= ox + kPW - 1;
         // bits 31..1: byte offset of the top-left corner inside a patch buffer (clamped for corners that left the
         // patch: those items are redone from global memory) -- the loader adds it instead of re-deriving it per stage
-        const int py = min(max(h_low - oy, 0), kPH - 2), px = min(max(w_low - ox, 0), kPW - 2);
+        const int py = min(max(h_low - oy, 0), kPHt - 2), px = min(max(w_low - ox, 0), kPW - 2);
         tp.flags = (in ? 1u : 0u) | ((unsigned)((py * kPW + px) * 128) << 1);
       }
     }
@@ -868,7 +880,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   }
   if (wave >= 4) {  // first patch -> LDS
 #pragma unroll
-    for (int i = 0; i < 12; i++) *reinterpret_cast<V*>(s_patch + (L + 256 * i) * 16) = pv[i];
+    for (int i = 0; i < NPV; i++) *reinterpret_cast<V*>(s_patch + (L + 256 * i) * 16) = pv[i];
   }
   S2A_STAMP_AT(1);
   __syncthreads();  // #1 table + patch 0 ready (s_ctx is dead from here on)
@@ -886,7 +898,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
     auto compute = [&](int s, const V (&wv)[2][4]) {
       if (!wave_active || (S2A_ABL & 4)) return;
-      const char* prow = s_B + (s & 1) * (128 * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
+      const char* prow = s_B + (s & 1) * (NPOS * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         V pf[NT];
@@ -930,15 +942,15 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     // ===================== loader waves =====================
     auto patch_issue = [&](int cc) {
 #pragma unroll
-      for (int i = 0; i < 12; i++) {
+      for (int i = 0; i < NPV; i++) {
         u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)pvoff[i], cc * 128, 0);
         pv[i] = __builtin_bit_cast(V, d);
       }
     };
     auto patch_write = [&](int cc) {
-      char* P = s_patch + (cc & 1) * kPatchBytes;
+      char* P = s_patch + (cc & 1) * kPatchBytesT;
 #pragma unroll
-      for (int i = 0; i < 12; i++) *reinterpret_cast<V*>(P + (L + 256 * i) * 16) = pv[i];
+      for (int i = 0; i < NPV; i++) *reinterpret_cast<V*>(P + (L + 256 * i) * 16) = pv[i];
     };
     // The operands of a stage (4 table entries, 16 corner vectors per thread) are FETCHED one stage ahead -- right
     // after the previous stage's columns have been written, so their LDS latency (table read, then the dependent
@@ -947,7 +959,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     V c[ITEMS][4];
     auto fetch = [&](int s) {
       const int t = s % 9, cc = s / 9;
-      const char* P = s_patch + (cc & 1) * kPatchBytes + (L & 7) * 16;   // (item & 7 = L & 7 for every item)
+      const char* P = s_patch + (cc & 1) * kPatchBytesT + (L & 7) * 16;   // (item & 7 = L & 7 for every item)
 #pragma unroll
       for (int it = 0; it < ITEMS; it++)      // one 16-byte read per entry
         tp[it] = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[((L + 256 * it) >> 3) * 9 + t]));
@@ -964,7 +976,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     auto produce = [&](int s) {  // columns of stage s (operands fetched before) -> B[s&1]
       if (S2A_ABL & 2) return;
       const int cc = s / 9;
-      char* Bm = s_B + (s & 1) * (128 * kRowBytes);
+      char* Bm = s_B + (s & 1) * (NPOS * kRowBytes);
       bool any_out = false;
 #pragma unroll
       for (int it = 0; it < ITEMS; it++) any_out |= !(tp[it].flags & 1u);
@@ -1021,6 +1033,11 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 
   S2A_STAMP_AT(4);
   // ===================== epilogue =====================
+  auto out_pos = [&](int pos) -> int64_t {       // linear position b*H*W + y*W + x of tile position pos, -1 outside
+    const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
+    const int64_t gpos = bimg * HW + (int64_t)y * W + xq;
+    return (y < H && xq < W && gpos < Ntot) ? gpos : -1;
+  };
   if ((S2A_ABL & 1) && relu != 12345) return;
   if constexpr (OUT_NHWC) {
     // Stage the 128 x 256 tile through LDS (the patch buffers are free now) and store whole
@@ -1048,9 +1065,9 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < NPOS / 16; i++) {
       int idx = tid + 512 * i, pos = idx >> 5, col = idx & 31;
-      int64_t gp = tile_pos(tile, pos, 8, H, W, HW, Ntot);
+      int64_t gp = out_pos(pos);
       if (gp >= 0 && col * 8 < Oloc)
         *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
     }
@@ -1066,7 +1083,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
           float v = acc[a][b][r];
           if (relu) v = fmaxf(v, 0.f);
           int och = o0 + wave * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          int64_t gp = tile_pos(tile, 32 * b + (lane & 31), 8, H, W, HW, Ntot);
+          int64_t gp = out_pos(32 * b + (lane & 31));
           if (gp >= 0) {
             int64_t bi = gp / HW, p = gp % HW;
             out[(bi * O + och) * HW + p] = (T)v;
@@ -2043,7 +2060,7 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
       S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));        \
       kern<<<grid, 512, kPatchLds, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, relu, \
-                                         (unsigned)x_bytes, LevelTab{});                          \
+                                         (unsigned)x_bytes, LevelTab{}, 0);                       \
     }                                                                                             \
   } while (0)
 #define S2A_DCN_PICK(NHWC, SRC) do { if (patch_ok) S2A_DCN_LAUNCH_PATCH(NHWC, SRC); else if (ws_use) S2A_DCN_LAUNCH_WS(NHWC, SRC); else if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
@@ -2517,10 +2534,37 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
     return S2A_OK;
   }
   auto kern = k_dcn_patch<true, 1>;
-  dim3 grid((unsigned)tiles, (unsigned)((out_channels + kMaxO - 1) / kMaxO));
+  const unsigned ogroups = (unsigned)((out_channels + kMaxO - 1) / kMaxO);
+  // One 153 KB workgroup per CU: a launch runs in rounds of n_cu tiles.  When the last round would fill less than
+  // half of the chip (the bench's 1 368 tiles on 256 CUs: 5 rounds + 88 tiles), those tiles can run as twice as many
+  // 4 x 16 half tiles in a second launch -- half a round instead of a whole one.  Bit-identical; measured gain only
+  // 1.2 % (236.9 -> 234.1 us: a half tile costs ~60 % of a full one and the second launch has its own ramp), so it
+  // is opt-in (S2A_DCN_TAIL=1) and the roofline figure stays one kernel = one launch.
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    S2A_HIP(hipGetDevice(&dev));
+    S2A_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  int64_t full = tiles, rem = 0;
+  const char* tl = getenv("S2A_DCN_TAIL");
+  if (ogroups == 1 && tiles > n_cu && (tiles % n_cu) * 2 <= n_cu && tl && atoi(tl) != 0) {
+    rem = tiles % n_cu;
+    full = tiles - rem;
+  }
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
-  kern<<<grid, 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels, lt.H[0], lt.W[0],
-                                     (int)out_channels, lt.stride[0], relu, 0u, lt);
+  kern<<<dim3((unsigned)full, ogroups), 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
+                                                              lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu, 0u, lt, 0);
+  if (rem > 0) {
+    constexpr int kHalfLds = 64 * 9 * 16 + 2 * 64 * kRowBytes + 2 * (4 + 2 * kHalo) * kPW * 128;
+    auto kh = k_dcn_patch<true, 1, 4>;
+    S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds));
+    kh<<<dim3((unsigned)(2 * rem), ogroups), 512, kHalfLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
+                                                                  lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu, 0u, lt,
+                                                                  (int)full);
+  }
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

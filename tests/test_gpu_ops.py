@@ -748,6 +748,39 @@ def test_pyramid_alignconv_persistent_matches_plain(monkeypatch):
     assert outs["1"].float().abs().sum().item() > 0
 
 
+def test_pyramid_alignconv_half_tile_tail_matches(monkeypatch):
+    """a launch whose last round would leave most CUs idle finishes with 4 x 16 half tiles (second launch): same bits
+    as the single launch of 8 x 16 tiles; levels with odd row counts (half tiles past the image bottom) included"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.alignconv import pack_weight
+    B, C = 2, 256
+    sizes = [(128, 128), (64, 64), (30, 34), (13, 17), (6, 9)]
+    strides = (8, 16, 32, 64, 128)
+    lay = P.PyramidLayout(B, sizes, strides)
+    g = torch.Generator().manual_seed(78)
+    x = torch.relu(torch.randn(lay.pixels, C, generator=g)).to(dev()).half()
+    anchors = []
+    for (h, w), st in zip(sizes, strides):
+        ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        a = torch.stack([xs * st + 0.5 * (st - 1) + torch.randn(h, w, generator=g) * st * 0.5,
+                         ys * st + 0.5 * (st - 1) + torch.randn(h, w, generator=g) * st * 0.5,
+                         4 * st * torch.exp(torch.randn(h, w, generator=g) * 0.5),
+                         4 * st * torch.exp(torch.randn(h, w, generator=g) * 0.5),
+                         torch.rand(h, w, generator=g) * 3.14159 - 0.785], -1).float()
+        anchors.append(a.unsqueeze(0).expand(B, -1, -1, -1).reshape(-1, 5))
+    anchors = torch.cat(anchors).to(dev()).contiguous()
+    wp = pack_weight((torch.randn(256, C, 3, 3, generator=g) * 0.02).to(dev()).half(), torch.float16)
+    tiles = sum(B * ((h + 7) // 8) * ((w + 15) // 16) for h, w in sizes)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert tiles > ncu and (tiles % ncu) * 2 <= ncu, (tiles, ncu)      # the tail path is taken (S2A_DCN_TAIL=1)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("S2A_DCN_TAIL", mode)
+        outs[mode] = P.align_conv(lay, x, anchors, wp, 256).clone()
+    assert torch.equal(outs["0"], outs["1"]), (outs["0"].float() - outs["1"].float()).abs().max().item()
+    assert outs["1"].float().abs().sum().item() > 0
+
+
 def test_detector_pyramid_path_matches_per_level(monkeypatch):
     """the whole head on the pyramid-packed path == the per-level path (library kernels on the small levels)"""
     from s2anet_amd.detector import build_synthetic_detector
