@@ -276,8 +276,8 @@ extern "C" int s2a_fam_refine_anchors_pyramid(const void* pred, int64_t row_stri
 // get_bboxes_single_img (models/head.py:684-717) for the whole batch on pyramid-packed predictions: per level and
 // image, sigmoid -> max over classes -> top-k (k = 2000) only where H*W > k (:697-705); levels concatenated
 // (:712-714); final decode (:717, wh_ratio_clip 16/1000).  Two kernels instead of ~25 stock launches:
-//  k_pyr_topk: one workgroup per (image, level): exact k-th largest key by a two-pass radix select on 16-bit keys
-//   held in LDS (key = order-preserving image of max_c logit; sigmoid is monotonic), then an index-order
+//  k_pyr_keys + k_pyr_topk: one workgroup per (image, level): exact k-th largest key by a bitwise radix select on
+//   16-bit keys held in LDS (key = order-preserving image of max_c logit; sigmoid is monotonic), then an index-order
 //   compaction (ties at the threshold: lowest positions first) -> packed row indices;
 //  k_pyr_gather: one thread per selected row: f16 sigmoid of the class logits (as the stock half sigmoid: float
 //   math, rounded to half), decode of the box against its refined anchor.
@@ -296,8 +296,28 @@ __device__ __forceinline__ unsigned short f16_key(_Float16 v) {
   return (u & 0x8000u) ? (unsigned short)~u : (unsigned short)(u | 0x8000u);
 }
 
+// key = order-preserving image of max_c logit for every packed row, one thread per row, the whole chip at once (one
+// workgroup per (image, level) pulling its level's rows -- 2 MB of 128-byte lines for P3 -- through ONE CU took 40 us)
+__global__ __launch_bounds__(256) void k_pyr_keys(const _Float16* __restrict__ cls, int64_t rows, int num_classes,
+                                                  unsigned short* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  using V8 = __attribute__((ext_vector_type(8))) _Float16;
+  const V8* r = reinterpret_cast<const V8*>(cls + i * 64);
+  const int nvec = (num_classes + 7) / 8;
+  _Float16 m = r[0][0];
+  for (int v = 0; v < nvec; v++) {
+    const V8 x = r[v];
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+      if (v * 8 + c < num_classes) m = x[c] > m ? x[c] : m;
+  }
+  keys[i] = f16_key(m);
+}
+
 __global__ __launch_bounds__(kTopkThreads) void k_pyr_topk(const _Float16* __restrict__ cls, CandLevels lv,
-                                                           int64_t n_out, int32_t* __restrict__ sel) {
+                                                           int64_t n_out, int32_t* __restrict__ sel,
+                                                           const unsigned short* __restrict__ keys) {
   __shared__ unsigned short s_key[kTopkMaxN];
   __shared__ unsigned s_hist[256];
   __shared__ unsigned s_part[kTopkThreads];
@@ -310,51 +330,76 @@ __global__ __launch_bounds__(kTopkThreads) void k_pyr_topk(const _Float16* __res
     for (int i = tid; i < HW; i += kTopkThreads) out[i] = (int32_t)(row0 + i);
     return;
   }
-  for (int i = tid; i < HW; i += kTopkThreads) {
-    const _Float16* r = cls + (row0 + i) * 64;
-    _Float16 m = r[0];
-    for (int c = 1; c < lv.num_classes; c++) m = r[c] > m ? r[c] : m;
-    s_key[i] = f16_key(m);
-  }
-  // pass 1: high byte
-  if (tid < 256) s_hist[tid] = 0;
-  __syncthreads();
-  for (int i = tid; i < HW; i += kTopkThreads) atomicAdd(&s_hist[s_key[i] >> 8], 1u);
-  __syncthreads();
-  if (tid == 0) {
-    unsigned cum = 0;
-    int bin = 255;
-    for (; bin > 0; bin--) {
-      if (cum + s_hist[bin] >= (unsigned)k) break;
-      cum += s_hist[bin];
+  // per-position max over the class maps: rows are 128-byte aligned, the classes sit in the first (num_classes + 7) / 8
+  // 16-byte vectors; four positions per thread in flight (scalar 2-byte loads, one position at a time, took 165 us
+  // for the 16 384 positions of a P3 level: the whole kernel was that loop)
+  using V8 = __attribute__((ext_vector_type(8))) _Float16;
+  const int nvec = (lv.num_classes + 7) / 8;
+  if (keys) {                                      // precomputed by k_pyr_keys
+    for (int i = tid; i < HW; i += kTopkThreads) s_key[i] = keys[row0 + i];
+  } else if (nvec > 2) {                           // more than 16 classes: plain loop
+    for (int i = tid; i < HW; i += kTopkThreads) {
+      const _Float16* r = cls + (row0 + i) * 64;
+      _Float16 m = r[0];
+      for (int c = 1; c < lv.num_classes; c++) m = r[c] > m ? r[c] : m;
+      s_key[i] = f16_key(m);
     }
-    s_T = (unsigned)bin << 8;
-    s_need_eq = (unsigned)k - cum;                 // still needed from this bin
-  }
-  __syncthreads();
-  const unsigned hi = s_T >> 8, need1 = s_need_eq;
-  __syncthreads();
-  // pass 2: low byte inside the bin
-  if (tid < 256) s_hist[tid] = 0;
-  __syncthreads();
-  for (int i = tid; i < HW; i += kTopkThreads)
-    if ((unsigned)(s_key[i] >> 8) == hi) atomicAdd(&s_hist[s_key[i] & 255u], 1u);
-  __syncthreads();
-  if (tid == 0) {
-    unsigned cum = 0;
-    int bin = 255;
-    for (; bin > 0; bin--) {
-      if (cum + s_hist[bin] >= need1) break;
-      cum += s_hist[bin];
+  } else
+  for (int i = tid; i < HW; i += 4 * kTopkThreads) {
+    V8 v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int iu = min(i + u * kTopkThreads, HW - 1);
+      const V8* r = reinterpret_cast<const V8*>(cls + (row0 + iu) * 64);
+      v[u][0] = r[0];
+      v[u][1] = nvec > 1 ? r[1] : r[0];
     }
-    s_T = (hi << 8) | (unsigned)bin;               // the k-th largest key
-    s_need_eq = need1 - cum;                       // how many rows equal to it are taken (lowest positions first)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int iu = i + u * kTopkThreads;
+      if (iu >= HW) break;
+      _Float16 m = v[u][0][0];
+#pragma unroll
+      for (int c = 1; c < 16; c++) {
+        const _Float16 x = c < 8 ? v[u][0][c] : v[u][1][c - 8];
+        if (c < lv.num_classes) m = x > m ? x : m;
+      }
+      s_key[iu] = f16_key(m);
+    }
   }
+  __syncthreads();
+  // exact k-th largest key by a bitwise radix select, most significant bit first: every thread keeps its contiguous
+  // chunk of keys in registers and counts the keys that match the prefix found so far with the next bit set; one
+  // barrier per bit (wave sums through DPP shuffles, 16 partials in LDS, double-buffered).  (Two byte-wide histogram
+  // passes with LDS atomics took 50 us on clustered scores: most positions of a level share one high byte.)
+  constexpr int kPerMax = kTopkMaxN / kTopkThreads;          // 24
+  const int per = (HW + kTopkThreads - 1) / kTopkThreads;
+  const int i0 = tid * per, i1 = min(HW, i0 + per);
+  unsigned kreg[kPerMax];
+#pragma unroll
+  for (int j = 0; j < kPerMax; j++) kreg[j] = (i0 + j < i1) ? (unsigned)s_key[i0 + j] : 0x10000u;   // 0x10000: never matches
+  unsigned prefix = 0, need = (unsigned)k;
+  unsigned* s_cnt = s_hist;                                   // [2][16]
+  for (int bit = 15; bit >= 0; bit--) {
+    const unsigned cand = prefix | (1u << bit), mask = (0xffffu << bit) & 0xffffu;
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kPerMax; j++) cnt += ((kreg[j] & (mask | 0x10000u)) == cand) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    unsigned* sc = s_cnt + (bit & 1) * 16;
+    if ((tid & 63) == 0) sc[tid >> 6] = cnt;
+    __syncthreads();
+    unsigned tot = 0;
+#pragma unroll
+    for (int w = 0; w < kTopkThreads / 64; w++) tot += sc[w];
+    if (tot >= need) prefix = cand;        // the k-th largest key has this bit set
+    else need -= tot;                      // all keys with this bit set (under the prefix) are above it
+  }
+  if (tid == 0) { s_T = prefix; s_need_eq = need; }   // need = how many rows equal to the k-th key are taken
   __syncthreads();
   const unsigned T = s_T, need_eq = s_need_eq;
   // index-order compaction: contiguous chunk per thread, two running counts (selected so far, equals so far)
-  const int per = (HW + kTopkThreads - 1) / kTopkThreads;
-  const int i0 = tid * per, i1 = min(HW, i0 + per);
   unsigned gt = 0, eq = 0;
   for (int i = i0; i < i1; i++) {
     gt += s_key[i] > T;
@@ -444,8 +489,16 @@ extern "C" int s2a_pyramid_candidates(const void* cls, const void* reg, const fl
   if (batch == 0 || n == 0) return S2A_OK;
   S2A_CHECK_ARG(cls && reg && anchors && bboxes && scores && sel, "pyramid_candidates: NULL tensor");
   hipStream_t st = as_stream(stream);
-  k_pyr_topk<<<dim3((unsigned)lv.n, (unsigned)batch), kTopkThreads, 0, st>>>((const _Float16*)cls, lv, n, sel);
   const int64_t total = batch * n;
+  // keys of all rows first, in the scores buffer (written only by k_pyr_gather afterwards) when it is large enough
+  int64_t rows = 0;
+  for (int i = 0; i < lv.n; i++) rows += batch * (int64_t)lv.HW[i];
+  const unsigned short* keys = nullptr;
+  if (rows * (int64_t)sizeof(unsigned short) <= total * num_classes * (int64_t)sizeof(float) && ((uintptr_t)cls % 16) == 0) {
+    k_pyr_keys<<<(unsigned)((rows + 255) / 256), 256, 0, st>>>((const _Float16*)cls, rows, num_classes, (unsigned short*)scores);
+    keys = (const unsigned short*)scores;
+  }
+  k_pyr_topk<<<dim3((unsigned)lv.n, (unsigned)batch), kTopkThreads, 0, st>>>((const _Float16*)cls, lv, n, sel, keys);
   const float max_ratio = (float)std::fabs(std::log((double)wh_ratio_clip));
   k_pyr_gather<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const _Float16*)cls, (const _Float16*)reg, anchors, sel,
                                                                total, num_classes, max_ratio, bboxes, scores);

@@ -1073,6 +1073,42 @@ def test_head_on_concurrent_streams_matches_serial():
         assert torch.equal(c, rc) and torch.equal(l, rl) and torch.equal(d, rd)
 
 
+def test_pyramid_topk_ties_and_sizes():
+    """the per-(image, level) select on heavily tied keys (a handful of distinct logits): exactly k rows, every row
+    above the k-th key, the k-th key's rows in ascending position order, positions ascending; levels at, below and
+    above k; 17+ classes take the generic key loop"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.pyramid import PyramidLayout
+    g = torch.Generator().manual_seed(31)
+    for C, sizes, k in ((15, [(96, 96), (45, 45), (44, 45), (5, 7)], 2000), (20, [(70, 90), (10, 10)], 333), (3, [(150, 160)], 2000)):
+        layout = PyramidLayout(2, sizes, tuple(8 * 2 ** i for i in range(len(sizes))))
+        cls = torch.full((layout.pixels, 64), 9.0)                   # columns >= C must be ignored
+        cls[:, :C] = (torch.randint(-3, 4, (layout.pixels, C), generator=g).float() * 0.25)
+        cls = cls.half().to(dev())
+        reg = torch.zeros(layout.pixels, 64).half().to(dev())
+        anc = (torch.rand(layout.pixels, 5, generator=g) * 50 + 8).to(dev())
+        out = P.candidates(layout, cls, reg, anc, C, k)
+        assert out is not None
+        sel = out[2].cpu().numpy()
+        key = cls[:, :C].float().max(1)[0].cpu().numpy()
+        off = 0
+        for l, (h, w) in enumerate(sizes):
+            hw, m = h * w, min(h * w, k)
+            for b in range(layout.batch):
+                r0 = layout.pix0[l] + b * hw
+                got = sel[b, off:off + m]
+                assert (np.diff(got) > 0).all() and got.min() >= r0 and got.max() < r0 + hw, (C, l, b)
+                kl = key[r0:r0 + hw]
+                if hw <= k:
+                    assert np.array_equal(got, np.arange(r0, r0 + hw))
+                    continue
+                T = np.sort(kl)[::-1][k - 1]
+                above = np.nonzero(kl > T)[0]
+                equal = np.nonzero(kl == T)[0][:k - len(above)]          # lowest positions first
+                assert np.array_equal(got, np.sort(np.concatenate([above, equal])) + r0), (C, l, b)
+            off += m
+
+
 def test_pyramid_candidates_vs_stock_path():
     """fused per-level top-k + sigmoid + decode (two kernels) against the stock-op path of S2ANetHead.candidates:
     same candidate set per level (distinct scores -> no tie at the k-th place), same boxes and scores"""
