@@ -1445,10 +1445,12 @@ struct ConvExtra {
 
 // SD = spatial stride of the 3x3 form (1, or 2: the down-sampling conv2 of a stage's first bottleneck; output tile
 // 4 x 16 positions from a 9 x 33-pixel patch, two 32-position tiles per wave)
-template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false>
+// HT = 1: 4 x 16 tile of a stride-1 3x3 (64 positions) for maps so small that 8 x 16 tiles leave CUs idle or give every
+// CU a single workgroup (one wave per SIMD: nothing covers the weight / patch round trips)
+template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false, int HT = 0>
 struct ConvCfg {
-  static constexpr int kTH = SD == 2 ? 4 : 8 * PH;                     // tile rows (TAPS 9)
-  static constexpr int kPos = SD == 2 ? 64 : 128 * PH;                 // output positions per workgroup
+  static constexpr int kTH = (SD == 2 || HT) ? 4 : 8 * PH;             // tile rows (TAPS 9)
+  static constexpr int kPos = (SD == 2 || HT) ? 64 : 128 * PH;         // output positions per workgroup
   static constexpr int kWaves = 4 * PH;
   static constexpr int kPW = SD == 2 ? 33 : kCPW;                      // patch width in pixels
   static constexpr int kNT = (kPos / 32) * OG / 4 / PH;                // 32-position tiles per wave
@@ -1469,7 +1471,7 @@ struct ConvCfg {
   static constexpr int kJ = (kDma + kWaves - 1) / kWaves;             // DMA pieces per wave
 };
 
-template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false>
+template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false, int HT = 0>
 __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _Float16* __restrict__ x_,
                                                      const _Float16* __restrict__ wfrag,
                                                      const _Float16* __restrict__ bias,
@@ -1481,9 +1483,10 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   _Float16* pool_out_ = ex.pool_out;
   using T = _Float16;
   using V = f16x8;
-  using Cfg = ConvCfg<TAPS, OG, PH, SD, TAIL>;
+  using Cfg = ConvCfg<TAPS, OG, PH, SD, TAIL, HT>;
   constexpr int NT = Cfg::kNT;        // 32-position tiles per wave
   static_assert(NT >= 1, "unsupported tile / group combination");
+  static_assert(!HT || (TAPS == 9 && PH == 1 && SD == 1 && !TAIL), "half tiles: plain 3x3 / stride 1");
   static_assert(!TAIL || (TAPS == 9 && OG == 1 && SD == 1), "the fused 1x1 tail follows a 64-map 3x3/s1");
   constexpr int WPG = 4 / OG;         // waves per out-channel group (inside a 128-position block)
   constexpr int kThreads_ = 256 * PH;
@@ -2240,18 +2243,18 @@ extern "C" int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count
 
 namespace s2a {
 namespace {
-template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false>
+template <int TAPS, int OG, int PH = 1, int SD = 1, bool TAIL = false, int HT = 0>
 int launch_conv(const _Float16* x, const _Float16* wfrag, const _Float16* bias, const _Float16* residual,
                 _Float16* out, int64_t B, int C, int H, int W, int Ho, int Wo, int cstride, int O, int relu,
                 hipStream_t st, const LevelTab* levels = nullptr, int64_t level_tiles = 0, int res_up = 0,
                 ConvExtra ex = ConvExtra{nullptr, nullptr, nullptr, nullptr, 1}) {
-  using Cfg = ConvCfg<TAPS, OG, PH, SD, TAIL>;
+  using Cfg = ConvCfg<TAPS, OG, PH, SD, TAIL, HT>;
   const int64_t Ntot = B * (int64_t)Ho * Wo;
   int64_t tiles = TAPS == 9 ? B * ((Wo + 15) / 16) * ((Ho + Cfg::kTH - 1) / Cfg::kTH) : (Ntot + Cfg::kPos - 1) / Cfg::kPos;
   LevelTab lt = {};
   if (levels) { lt = *levels; tiles = level_tiles; }
   dim3 grid((unsigned)tiles, (unsigned)((O + 64 * OG - 1) / (64 * OG)));
-  auto kern = k_conv_f16<TAPS, OG, PH, SD, TAIL>;
+  auto kern = k_conv_f16<TAPS, OG, PH, SD, TAIL, HT>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds + Cfg::kBiasBytes));
   kern<<<grid, 256 * PH, Cfg::kLds + Cfg::kBiasBytes, st>>>(x, wfrag, bias, residual, out, Ntot, C, H, W, Ho, Wo, cstride, O, relu,
                                      (unsigned)((uint64_t)B * H * W * C * 2), lt, res_up, ex);
@@ -2306,6 +2309,21 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
                                     (int)out_channels, relu, st);
       return launch_conv<9, 1, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 1,
                                   (int)out_channels, relu, st);
+    }
+  }
+  if (ksize == 3 && og >= 2) {
+    // small maps (32^2 at batch 8): fewer 8 x 16 workgroups than CUs -> 4 x 16 tiles (512 -> 512 on 32^2: 54 -> 44 us,
+    // 256 -> 256 on 32^2: 28 -> 19 us; once every CU has a workgroup the smaller tile loses: 256 -> 256 on 64^2
+    // 39.5 -> 43 us).  S2A_CONV3_HALF=0|1
+    const int64_t wgs128 = batch * ((Wo + 15) / 16) * ((Ho + 7) / 8) * ((out_channels + 64 * og - 1) / (64 * og));
+    bool half = wgs128 < 256;
+    if (const char* f = getenv("S2A_CONV3_HALF")) half = atoi(f) != 0;
+    if (half) {
+      if (og == 4)
+        return launch_conv<9, 4, 1, 1, false, 1>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 1,
+                                                 (int)out_channels, relu, st);
+      return launch_conv<9, 2, 1, 1, false, 1>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 1,
+                                               (int)out_channels, relu, st);
     }
   }
   if (ksize == 3) return og == 4 ? S2A_CONV(9, 4) : (og == 2 ? S2A_CONV(9, 2) : S2A_CONV(9, 1));

@@ -501,6 +501,26 @@ def test_conv1x1_half_tiles_match(monkeypatch):
         assert (outs["1"][0].float() - ref).abs().max().item() < 6e-2
 
 
+def test_conv3x3_half_tiles_match(monkeypatch):
+    """3x3 / stride 1 layers on 4 x 16 tiles (small maps) == the 8 x 16 form, bit for bit; with residual; ragged sizes"""
+    from s2anet_amd.fused import conv_f16, conv_pack_weight
+    g = torch.Generator().manual_seed(10)
+    for (B, C, H, W, O) in ((2, 256, 24, 40, 256), (1, 512, 13, 19, 512), (2, 128, 17, 16, 128), (1, 64, 9, 33, 384)):
+        x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(O, C, 3, 3, generator=g) * 0.03).to(dev()).half()
+        b = torch.randn(O, generator=g).to(dev()).half()
+        r = torch.randn(B, O, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        wp = conv_pack_weight(w)
+        outs = {}
+        monkeypatch.setenv("S2A_CONV_PH_NARROW", "1")
+        for half in ("0", "1"):
+            monkeypatch.setenv("S2A_CONV3_HALF", half)
+            outs[half] = (conv_f16(x, wp, b, O, 3, 1, True), conv_f16(x, wp, b, O, 3, 1, False, r))
+        assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1]), (B, C, H, W, O)
+        ref = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), b.float(), padding=1))
+        assert (outs["1"][0].float() - ref).abs().max().item() < 6e-2
+
+
 def test_bottleneck_tail_fused_matches_two_launches(monkeypatch):
     """conv2 (3x3 64->64) + conv3 (1x1 64->256) + residual + ReLU of a layer-1 bottleneck in one launch
     (s2a_conv3x3_tail1x1_f16): bit-identical to the two stand-alone launches, close to torch fp32; ragged sizes
