@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import FusedConv2d, bottleneck_tail, bottleneck_tail_ok
+from .fused import FusedConv2d, bottleneck_chain_ok, bottleneck_tail, bottleneck_tail_ok
 from .head import S2ANetHead
 
 
@@ -34,14 +34,25 @@ class BottleNeck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        return self.forward_chain(x)[0]
+
+    def forward_chain(self, x, pre=None, nxt=None):
+        """-> (block output, the NEXT block's conv1 output or None).  pre = this block's conv1 output when the previous
+        block's tail kernel already produced it; nxt = the next block (run_blocks)."""
         residual = x
         if isinstance(self.conv3, FusedConv2d):           # BN folded, epilogues fused (inference)
-            out = self.conv1(x)
+            out = pre if pre is not None else self.conv1(x)
             if self.downsample is not None:
                 residual = self.downsample(x)
-            if bottleneck_tail_ok(out, self.conv2, self.conv3, residual):
-                return bottleneck_tail(out, self.conv2, self.conv3, residual)   # conv2 + conv3 + residual: one launch
-            return self.conv3(self.conv2(out), residual)  # relu(conv3 + bias + residual) in one pass
+            if bottleneck_tail_ok(out, self.conv2, self.conv3, residual):   # conv2 + conv3 + residual: one launch
+                if isinstance(nxt, BottleNeck) and bottleneck_chain_ok(nxt.conv1):
+                    return bottleneck_tail(out, self.conv2, self.conv3, residual, nxt.conv1)
+                return bottleneck_tail(out, self.conv2, self.conv3, residual), None
+            return self.conv3(self.conv2(out), residual), None  # relu(conv3 + bias + residual) in one pass
+        return self._forward_plain(x), None
+
+    def _forward_plain(self, x):
+        residual = x
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
@@ -86,10 +97,24 @@ class DetectorBackbone(nn.Module):
         layers += [BottleNeck(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    @staticmethod
+    def run_blocks(seq, x):
+        """a stage's bottlenecks one after the other; a block's tail kernel may hand the next block its conv1 output"""
+        pre = None
+        for i, blk in enumerate(seq):
+            if not isinstance(blk, BottleNeck):
+                x, pre = blk(x), None
+                continue
+            x, pre = blk.forward_chain(x, pre, seq[i + 1] if i + 1 < len(seq) else None)
+        return x
+
     def forward(self, x):
         outs = []
         for i, m in enumerate(self.backbone):
-            x = m(x)
+            if i == 1:
+                x = self.run_blocks(m[1], m[0](x))
+            else:
+                x = self.run_blocks(m, x) if i >= 2 else m(x)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)
@@ -114,10 +139,10 @@ class DetectorBackbone(nn.Module):
         if getattr(self, "_stem_key", None) != key:
             self._stem_key, self._stem_w = key, stem_pack_weight(w)
             self._stem_b = None if conv.bias is None else conv.bias.detach().to(torch.float16).contiguous()
-        x = self.backbone[1][1](stem_u8(imgs_u8, self._stem_w, self._stem_b, divisor))
+        x = self.run_blocks(self.backbone[1][1], stem_u8(imgs_u8, self._stem_w, self._stem_b, divisor))
         outs = [x] if 1 in self.out_indices else []
         for i in range(2, len(self.backbone)):
-            x = self.backbone[i](x)
+            x = self.run_blocks(self.backbone[i], x)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)

@@ -547,6 +547,22 @@ def test_bottleneck_tail_fused_matches_two_launches(monkeypatch):
             ref = torch.relu(ref + (res.float() if with_res else 0))
             err = (fused.float() - ref).abs()
             assert err.max().item() < 3e-2 and err.mean().item() < 2e-3, (B, H, W, err.max().item())
+    # the next block's conv1 chained onto the tail kernel: both outputs bit-identical to the separate launches
+    c1n = FusedConv2d(256, 64, 1, relu=True).to(dev()).half()
+    for (B, H, W) in ((2, 64, 96), (1, 37, 51), (1, 128, 128)):
+        x = torch.randn(B, 64, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        res = torch.randn(B, 256, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            c1n.weight.copy_(torch.randn(256 * 64, generator=g).view(64, 256, 1, 1) * 0.05)
+            c1n.bias.copy_(torch.randn(64, generator=g) * 0.1)
+            for ph in ("1", "2"):
+                monkeypatch.setenv("S2A_CONV_PH_NARROW", ph)
+                y, m1 = bottleneck_tail(x, c2, c3, res, c1n)
+                y0 = bottleneck_tail(x, c2, c3, res)
+                wc, bc, _ = c1n.packed_args()
+                m0 = conv_f16(y0, wc, bc, 64, 1, 1, True)
+                assert torch.equal(y, y0) and torch.equal(m1, m0), (B, H, W, ph, (m1.float() - m0.float()).abs().max().item())
+        monkeypatch.delenv("S2A_CONV_PH_NARROW")
     # the detector's block: fused route == separate launches
     blk = BottleNeck(256, 64).to(dev())
     with torch.no_grad():
@@ -568,6 +584,19 @@ def test_bottleneck_tail_fused_matches_two_launches(monkeypatch):
         monkeypatch.setenv("S2A_NO_FUSED_TAIL", "1")
         b = blk(x)
     assert torch.equal(a, b)
+    monkeypatch.delenv("S2A_NO_FUSED_TAIL")
+    # a stage of two such blocks: the first block's tail hands the second its conv1 output
+    from s2anet_amd.detector import DetectorBackbone
+    import copy
+    blk2 = copy.deepcopy(blk)
+    with torch.no_grad():
+        blk2.conv1.weight.mul_(0.7); blk2.conv3.bias.add_(0.05)
+        seq = torch.nn.Sequential(blk, blk2)
+        a = DetectorBackbone.run_blocks(seq, x)
+        monkeypatch.setenv("S2A_NO_TAIL_CHAIN", "1")
+        b = DetectorBackbone.run_blocks(seq, x)
+        c = seq(x)
+    assert torch.equal(a, b) and torch.equal(a, c)
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 16, 16, 15, 3), (8, 256, 8, 8, 5, 3), (2, 256, 40, 24, 5, 1), (1, 256, 128, 128, 15, 1)])
