@@ -40,6 +40,8 @@ PEAK_HBM_GBS = 8000.0
 # HBM bytes of ONE pyramid-packed AlignConv launch (f16, batch 8), from rocprofv3 PMC passes over this
 # command (scripts/pmc_bench.sh -> profiles/r01_alignconv_pyramid_pmc.txt): 2 x FETCH_SIZE + WRITE_SIZE
 ALIGN_PYRAMID_TRAFFIC = 256.2e6
+# same for ONE pyramid-packed tower-conv launch (profiles/r01_conv_tower_hbm_pmc.txt): 2 x FETCH_SIZE + the output
+TOWER_PYRAMID_TRAFFIC = 210.0e6
 
 
 def parse():
@@ -178,8 +180,10 @@ def measure_conv_tower(model, cap, iters=100):
                       "%d positions, f16)" % layout.pixels,
             "timing": "%d back-to-back launches of the step's own launch, alone on the GPU" % iters,
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(sec * 1e6, 1),
-            "flops_per_launch": flops}
+            "frac": round(ach / PEAK_F16_TFLOPS, 4),
+            "traffic": TOWER_PYRAMID_TRAFFIC if layout.pixels == 8 * 21824 else None,
+            "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops,
+            "hbm_algorithmic_bytes_per_launch": int(layout.pixels * 512 * 2 + 256 * 2304 * 2)}
 
 
 def cpu_baseline(seed, candidates, chips=3):
