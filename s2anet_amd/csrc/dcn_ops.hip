@@ -2368,6 +2368,16 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
                                   (int)out_channels, relu, st);
     }
   }
+  if (ksize == 3 && og == 4 && channels % 64 == 0) {
+    // large maps (FPN's 3x3 on P3: 128^2 at batch 8): 16 x 16 tiles with the filter through LDS, as the pyramid-packed
+    // towers -- when they still fill the chip twice.  S2A_CONV_PH=1|2
+    const int64_t tiles16 = batch * ((Wo + 15) / 16) * ((Ho + 15) / 16) * (out_channels / 256);
+    int ph = tiles16 >= 512 ? 2 : 1;
+    if (const char* f = getenv("S2A_CONV_PH")) ph = atoi(f) == 2 ? 2 : 1;
+    if (ph == 2)
+      return launch_conv<9, 4, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, 1,
+                                  (int)out_channels, relu, st);
+  }
   if (ksize == 3 && og >= 2) {
     // small maps (32^2 at batch 8): fewer 8 x 16 workgroups than CUs -> 4 x 16 tiles (512 -> 512 on 32^2: 54 -> 44 us,
     // 256 -> 256 on 32^2: 28 -> 19 us; once every CU has a workgroup the smaller tile loses: 256 -> 256 on 64^2

@@ -501,6 +501,24 @@ def test_conv1x1_half_tiles_match(monkeypatch):
         assert (outs["1"][0].float() - ref).abs().max().item() < 6e-2
 
 
+def test_conv3x3_wide_layer_filter_through_lds_matches(monkeypatch):
+    """single-level 256-map 3x3 on 16 x 16 tiles with the filter through LDS (S2A_CONV_PH=2) == 8 x 16 tiles"""
+    from s2anet_amd.fused import conv_f16, conv_pack_weight
+    g = torch.Generator().manual_seed(12)
+    for (B, C, H, W, O) in ((1, 256, 40, 72, 256), (2, 128, 33, 31, 512)):
+        x = torch.randn(B, C, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(O, C, 3, 3, generator=g) * 0.03).to(dev()).half()
+        b = torch.randn(O, generator=g).to(dev()).half()
+        r = torch.randn(B, O, H, W, generator=g).to(dev()).half().contiguous(memory_format=torch.channels_last)
+        wp = conv_pack_weight(w)
+        outs = {}
+        for ph in ("1", "2"):
+            monkeypatch.setenv("S2A_CONV_PH", ph)
+            monkeypatch.setenv("S2A_CONV3_HALF", "0")
+            outs[ph] = (conv_f16(x, wp, b, O, 3, 1, True), conv_f16(x, wp, b, O, 3, 1, True, r))
+        assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][1], outs["2"][1]), (B, C, H, W, O)
+
+
 def test_conv3x3_half_tiles_match(monkeypatch):
     """3x3 / stride 1 layers on 4 x 16 tiles (small maps) == the 8 x 16 form, bit for bit; with residual; ragged sizes"""
     from s2anet_amd.fused import conv_f16, conv_pack_weight
