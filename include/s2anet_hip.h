@@ -310,12 +310,12 @@ int s2a_deformable_col2im_coord(const void* columns, const void* im, const void*
  * The 64-map intermediate never leaves the workgroup (LDS); results are bit-identical to s2a_conv_nhwc_f16 (3x3,
  * ReLU) followed by s2a_conv_nhwc_f16 (1x1, residual, ReLU).  weight_frag / tail_weight_frag from
  * s2a_conv_pack_weight_f16 (ksize 3 / 1); residual may be NULL.  channels = mid_channels = 64, out_channels = 256.
- * chain_*: optionally the NEXT bottleneck's conv1 (1x1, 256 -> 64, + bias + ReLU) applied to the finished output
- * tile in the same launch: chain_out [B,H,W,64] = relu(Wc . out + bc), bit-identical to a separate s2a_conv_nhwc_f16;
- * all three NULL = not computed. */
+ * chain_*: optionally the NEXT bottleneck's conv1 (1x1, 256 -> chain_channels = 64 or 128, + bias + ReLU) applied to
+ * the finished output tile in the same launch: chain_out [B,H,W,chain_channels] = relu(Wc . out + bc), bit-identical
+ * to a separate s2a_conv_nhwc_f16; all three pointers NULL = not computed. */
 int s2a_conv3x3_tail1x1_f16(const void* x, const void* weight_frag, const void* bias, const void* tail_weight_frag,
                             const void* tail_bias, const void* residual, void* out, const void* chain_weight_frag,
-                            const void* chain_bias, void* chain_out, int64_t batch, int64_t channels,
+                            const void* chain_bias, void* chain_out, int64_t chain_channels, int64_t batch, int64_t channels,
                             int64_t mid_channels, int64_t out_channels, int64_t height, int64_t width,
                             s2a_stream_t stream);
 

@@ -87,7 +87,7 @@ SYMBOLS = {
     "s2a_deformable_im2col": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(DcnParams), c_vp]),
     "s2a_deformable_col2im": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(DcnParams), c_vp]),
     "s2a_deformable_col2im_coord": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(DcnParams), c_vp]),
-    "s2a_conv3x3_tail1x1_f16": (c_int, [c_vp] * 10 + [c_i64] * 6 + [c_vp]),
+    "s2a_conv3x3_tail1x1_f16": (c_int, [c_vp] * 10 + [c_i64] * 7 + [c_vp]),
     "s2a_conv1x1_add_up2_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "s2a_pyramid_pixels": (c_i64, [ctypes.POINTER(Pyramid), c_i64]),
     "s2a_conv3x3_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,

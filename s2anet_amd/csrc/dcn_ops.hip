@@ -1442,9 +1442,10 @@ struct ConvExtra {
   const _Float16* tail_res;    // [P, 256] or null
   _Float16* tail_out;          // [P, 256]
   // ... and optionally the NEXT bottleneck's conv1 (1x1, 256 -> 64, + bias + ReLU) on the finished output tile
-  const _Float16* chain_w;     // fragment-order 1x1 filter [64][256] or null
-  const _Float16* chain_b;     // [64]
-  _Float16* chain_out;         // [P, 64]
+  const _Float16* chain_w;     // fragment-order 1x1 filter [chain_O][256] or null
+  const _Float16* chain_b;     // [chain_O]
+  _Float16* chain_out;         // [P, chain_O]
+  int chain_O;                 // 64 | 128
 };
 
 // SD = spatial stride of the 3x3 form (1, or 2: the down-sampling conv2 of a stage's first bottleneck; output tile
@@ -1846,19 +1847,23 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       if (ex.chain_w) *reinterpret_cast<V*>(s_out + pos * Cfg::kTailRowB + col * 16) = v;   // finished rows back to LDS
     }
     if (ex.chain_w) {
-      // ---- the next block's conv1 on the finished 256-map tile: out3 = relu(W . y + b), 64 maps.  wave = (m-tile
-      // wave & 1, two 32-position tiles); B fragments from the staged rows (528-byte stride: conflict-free), the 16
-      // filter fragments of the m-tile straight from L2; K order = the stand-alone 1x1 kernel's (chunk, k-step).
-      const int mt = wave & 1, nt0 = (wave >> 1) * 2;
+      // ---- the next block's conv1 on the finished 256-map tile: out3 = relu(W . y + b), 64 maps (same stage) or 128
+      // (first block of the next stage).  wave = (m-tile, a run of 32-position tiles); B fragments from the staged
+      // rows (528-byte stride: conflict-free), the 16 filter fragments of the m-tile straight from L2; K order =
+      // the stand-alone 1x1 kernel's (chunk, k-step).
+      const int O3 = ex.chain_O, MT = O3 / 32;                       // 2 | 4 m-tiles
+      const int nper = (Cfg::kPos / 32) * MT / Cfg::kWaves;          // 32-position tiles per wave: 2 | 4
+      const int mt = wave % MT, nt0 = (wave / MT) * nper;
+      const int G3 = O3 / 64;
       V aw[16];
-      const V* cwp = reinterpret_cast<const V*>(ex.chain_w) + lane + mt * 4 * 64;
+      const V* cwp = reinterpret_cast<const V*>(ex.chain_w) + lane + ((mt >> 1) * 8 + (mt & 1) * 4) * 64;
 #pragma unroll
       for (int c4 = 0; c4 < 4; c4++)
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) aw[c4 * 4 + kk] = cwp[(c4 * 8 + kk) * 64];
-      f32x16 c2[2];
+        for (int kk = 0; kk < 4; kk++) aw[c4 * 4 + kk] = cwp[(c4 * G3 * 8 + kk) * 64];
+      f32x16 c2[4];
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+      for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) c2[j][r] = 0.f;
       __syncthreads();                     // the whole finished tile is in LDS
@@ -1867,34 +1872,37 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const V bf = *reinterpret_cast<const V*>(s_out + (32 * (nt0 + j) + (lane & 31)) * Cfg::kTailRowB +
-                                                     (c4 * 64 + kk * 16 + (lane >> 5) * 8) * 2);
-            c2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[c4 * 4 + kk], bf, c2[j], 0, 0, 0);
-          }
+          for (int j = 0; j < 4; j++)
+            if (j < nper) {
+              const V bf = *reinterpret_cast<const V*>(s_out + (32 * (nt0 + j) + (lane & 31)) * Cfg::kTailRowB +
+                                                       (c4 * 64 + kk * 16 + (lane >> 5) * 8) * 2);
+              c2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[c4 * 4 + kk], bf, c2[j], 0, 0, 0);
+            }
       __syncthreads();                     // every wave has read its B fragments: the tile area is free again
-      // 64-map tile -> LDS rows (144-byte stride) -> whole 128-byte rows stored 16 B per lane (8-byte stores straight
-      // from the MFMA layout cost more than the GEMM)
+      // tile -> LDS rows (O3 * 2 + 16 bytes) -> whole rows stored 16 B per lane (8-byte stores straight from the MFMA
+      // layout cost more than the GEMM)
+      const int rowb = O3 * 2 + 16;
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+      for (int j = 0; j < 4; j++)
+        if (j < nper) {
 #pragma unroll
-        for (int rq = 0; rq < 4; rq++) {
-          using h4 = __attribute__((ext_vector_type(4))) _Float16;
-          const int och = mt * 32 + 8 * rq + 4 * (lane >> 5);
-          const h4 bq = *reinterpret_cast<const h4*>(ex.chain_b + och);
-          h4 v4;
+          for (int rq = 0; rq < 4; rq++) {
+            using h4 = __attribute__((ext_vector_type(4))) _Float16;
+            const int och = mt * 32 + 8 * rq + 4 * (lane >> 5);
+            const h4 bq = *reinterpret_cast<const h4*>(ex.chain_b + och);
+            h4 v4;
 #pragma unroll
-          for (int e = 0; e < 4; e++) v4[e] = (_Float16)fmaxf(c2[j][rq * 4 + e] + (float)bq[e], 0.f);
-          *reinterpret_cast<h4*>(s_out + (32 * (nt0 + j) + (lane & 31)) * kRowBytes + och * 2) = v4;
+            for (int e = 0; e < 4; e++) v4[e] = (_Float16)fmaxf(c2[j][rq * 4 + e] + (float)bq[e], 0.f);
+            *reinterpret_cast<h4*>(s_out + (32 * (nt0 + j) + (lane & 31)) * rowb + och * 2) = v4;
+          }
         }
       __syncthreads();
-      constexpr int NI3 = Cfg::kPos * 8 / kThreads_;
-#pragma unroll
-      for (int i = 0; i < NI3; i++) {
-        const int idx = tid + kThreads_ * i, pos = idx >> 3, col = idx & 7;
+      const int vpr = O3 / 8;                                          // 16-byte vectors per row: 8 | 16
+      for (int idx = tid; idx < Cfg::kPos * vpr; idx += kThreads_) {
+        const int pos = idx / vpr, col = idx % vpr;
         const int64_t gp = tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot);
         if (gp >= 0)
-          *reinterpret_cast<V*>(ex.chain_out + gp * 64 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kRowBytes + col * 16);
+          *reinterpret_cast<V*>(ex.chain_out + gp * O3 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * rowb + col * 16);
       }
     }
     return;
@@ -2413,7 +2421,7 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
 extern "C" int s2a_conv3x3_tail1x1_f16(const void* x, const void* weight_frag, const void* bias,
                                        const void* tail_weight_frag, const void* tail_bias, const void* residual,
                                        void* out, const void* chain_weight_frag, const void* chain_bias, void* chain_out,
-                                       int64_t batch, int64_t channels, int64_t mid_channels,
+                                       int64_t chain_channels, int64_t batch, int64_t channels, int64_t mid_channels,
                                        int64_t out_channels, int64_t height, int64_t width, s2a_stream_t stream) {
   S2A_CHECK_ARG(batch >= 0 && height > 0 && width > 0, "conv3x3_tail1x1: bad shape");
   S2A_CHECK_ARG(channels == 64 && mid_channels == 64 && out_channels == 256,
@@ -2433,11 +2441,13 @@ extern "C" int s2a_conv3x3_tail1x1_f16(const void* x, const void* weight_frag, c
   ex.tail_out = (_Float16*)out;
   if (chain_weight_frag || chain_bias || chain_out) {
     S2A_CHECK_ARG(chain_weight_frag && chain_bias && chain_out, "conv3x3_tail1x1: chain filter, bias and output go together");
+    S2A_CHECK_ARG(chain_channels == 64 || chain_channels == 128, "conv3x3_tail1x1: the chained 1x1 has 64 or 128 maps");
     S2A_CHECK_ARG(((uintptr_t)chain_weight_frag % 16) == 0 && ((uintptr_t)chain_bias % 8) == 0 && ((uintptr_t)chain_out % 16) == 0,
                   "conv3x3_tail1x1: chain tensors must be 16-byte aligned");
     ex.chain_w = (const _Float16*)chain_weight_frag;
     ex.chain_b = (const _Float16*)chain_bias;
     ex.chain_out = (_Float16*)chain_out;
+    ex.chain_O = (int)chain_channels;
   }
   int ph = batch * ((width + 15) / 16) * ((height + 15) / 16) >= 256 ? 2 : 1;
   if (const char* f = getenv("S2A_CONV_PH_NARROW")) ph = atoi(f) == 2 ? 2 : 1;

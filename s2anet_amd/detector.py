@@ -98,26 +98,31 @@ class DetectorBackbone(nn.Module):
         return nn.Sequential(*layers)
 
     @staticmethod
-    def run_blocks(seq, x):
-        """a stage's bottlenecks one after the other; a block's tail kernel may hand the next block its conv1 output"""
-        pre = None
+    def run_blocks(seq, x, pre=None, after=None, with_pre=False):
+        """a stage's bottlenecks one after the other; a block's tail kernel may hand the next block its conv1 output.
+        pre = conv1 output for the first block (from the previous stage's last tail), after = the block that follows
+        the stage; with_pre -> (x, conv1 output for `after` or None)"""
         for i, blk in enumerate(seq):
             if not isinstance(blk, BottleNeck):
                 x, pre = blk(x), None
                 continue
-            x, pre = blk.forward_chain(x, pre, seq[i + 1] if i + 1 < len(seq) else None)
-        return x
+            x, pre = blk.forward_chain(x, pre, seq[i + 1] if i + 1 < len(seq) else after)
+        return (x, pre) if with_pre else x
 
-    def forward(self, x):
-        outs = []
-        for i, m in enumerate(self.backbone):
-            if i == 1:
-                x = self.run_blocks(m[1], m[0](x))
-            else:
-                x = self.run_blocks(m, x) if i >= 2 else m(x)
+    def _stages(self, x):
+        """layer1 .. layer4 on the pooled stem output"""
+        outs, pre = [], None
+        for i in range(1, len(self.backbone)):
+            seq = self.backbone[i][1] if i == 1 else self.backbone[i]
+            after = self.backbone[i + 1][0] if i + 1 < len(self.backbone) else None
+            x, pre = self.run_blocks(seq, x, pre, after, with_pre=True)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)
+
+    def forward(self, x):
+        assert 0 not in self.out_indices
+        return self._stages(self.backbone[1][0](self.backbone[0](x)))
 
     def stem_fusable(self, imgs_u8):
         """uint8 channels-last batch + BN-folded stem: /255, conv1, ReLU and the max-pool run as one kernel"""
@@ -139,13 +144,7 @@ class DetectorBackbone(nn.Module):
         if getattr(self, "_stem_key", None) != key:
             self._stem_key, self._stem_w = key, stem_pack_weight(w)
             self._stem_b = None if conv.bias is None else conv.bias.detach().to(torch.float16).contiguous()
-        x = self.run_blocks(self.backbone[1][1], stem_u8(imgs_u8, self._stem_w, self._stem_b, divisor))
-        outs = [x] if 1 in self.out_indices else []
-        for i in range(2, len(self.backbone)):
-            x = self.run_blocks(self.backbone[i], x)
-            if i in self.out_indices:
-                outs.append(x)
-        return tuple(outs)
+        return self._stages(stem_u8(imgs_u8, self._stem_w, self._stem_b, divisor))
 
 
 class FPN(nn.Module):

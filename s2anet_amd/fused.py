@@ -115,10 +115,11 @@ def bottleneck_tail_ok(x, conv2, conv3, residual):
 
 
 def bottleneck_chain_ok(conv1):
-    """the next block's conv1 can ride on the tail kernel: 1x1, 256 -> 64, bias, ReLU"""
+    """the next block's conv1 can ride on the tail kernel: 1x1, 256 -> 64 (same stage) or 128 (first block of the
+    next stage), bias, ReLU"""
     import os
     return (isinstance(conv1, FusedConv2d) and not os.environ.get("S2A_NO_TAIL_CHAIN") and
-            conv1.in_channels == 256 and conv1.out_channels == 64 and tuple(conv1.kernel_size) == (1, 1) and
+            conv1.in_channels == 256 and conv1.out_channels in (64, 128) and tuple(conv1.kernel_size) == (1, 1) and
             tuple(conv1.stride) == (1, 1) and tuple(conv1.padding) == (0, 0) and conv1.groups == 1 and
             conv1.fuse_relu and conv1.bias is not None and conv1.weight.dtype == torch.float16)
 
@@ -134,11 +135,13 @@ def bottleneck_tail(x, conv2, conv3, residual=None, chain=None):
     wc = bc = nxt = None
     if chain is not None:
         wc, bc, _ = chain.packed_args()
-        nxt = torch.empty((B, 64, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+        nxt = torch.empty((B, chain.out_channels, H, W), dtype=torch.float16, device=x.device,
+                          memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().s2a_conv3x3_tail1x1_f16(_lib.ptr(x), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(w3), _lib.ptr(b3),
                                                       _lib.ptr(residual), _lib.ptr(out), _lib.ptr(wc), _lib.ptr(bc),
-                                                      _lib.ptr(nxt), B, 64, 64, 256, H, W, _lib.stream_ptr(x.device)))
+                                                      _lib.ptr(nxt), 0 if chain is None else chain.out_channels,
+                                                      B, 64, 64, 256, H, W, _lib.stream_ptr(x.device)))
     return out if chain is None else (out, nxt)
 
 
