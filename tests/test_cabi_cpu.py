@@ -67,3 +67,43 @@ def test_header_is_self_contained_c():
     for lang, cc in (("c", "gcc"), ("c++", "g++")):
         r = subprocess.run([cc, "-fsyntax-only", "-x", lang, "-Wall", hdr], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_argument_checks_return_codes_without_touching_the_gpu():
+    """bad shapes / NULL tensors / misalignment are refused with S2A_EINVAL and a message (the reference's TORCH_CHECK
+    -> RuntimeError convention) before any HIP call: checkable on a box without a GPU"""
+    import ctypes
+    from s2anet_amd import _lib
+    L = _lib.lib()
+    z = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)          # never dereferenced: the checks fail first
+    odd = ctypes.c_void_p(18)          # misaligned
+    def msg():
+        return L.s2a_last_error().decode()
+    # conv: channel counts, kernel size, stride, alignment, NULL
+    assert L.s2a_conv_nhwc_f16(one, one, one, z, one, 1, 48, 8, 8, 64, 3, 1, 1, z) == -1 and "multiple of 64" in msg()
+    assert L.s2a_conv_nhwc_f16(one, one, one, z, one, 1, 64, 8, 8, 64, 5, 1, 1, z) == -1 and "kernel size" in msg()
+    assert L.s2a_conv_nhwc_f16(one, one, one, z, one, 1, 64, 8, 8, 64, 3, 3, 1, z) == -1 and "stride" in msg()
+    assert L.s2a_conv_nhwc_f16(z, one, one, z, one, 1, 64, 8, 8, 64, 3, 1, 1, z) == -1 and "NULL" in msg()
+    assert L.s2a_conv_nhwc_f16(odd, one, one, z, one, 1, 64, 8, 8, 64, 3, 1, 1, z) == -1 and "aligned" in msg()
+    assert L.s2a_conv_nhwc_f16(one, one, one, z, one, 0, 64, 8, 8, 64, 3, 1, 1, z) == 0           # empty batch: nothing to do
+    # fused bottleneck tail: only the 64 -> 64 -> 256 form; chain arguments go together
+    assert L.s2a_conv3x3_tail1x1_f16(one, one, one, one, one, z, one, z, z, z, 0, 1, 128, 64, 256, 8, 8, z) == -1
+    assert "64 -> 64 -> 256" in msg()
+    assert L.s2a_conv3x3_tail1x1_f16(one, one, one, one, one, z, one, one, z, z, 64, 1, 64, 64, 256, 8, 8, z) == -1
+    assert "go together" in msg()
+    assert L.s2a_conv3x3_tail1x1_f16(one, one, one, one, one, z, one, one, one, one, 96, 1, 64, 64, 256, 8, 8, z) == -1
+    assert "64 or 128" in msg()
+    # pyramid launches: level table
+    pyr = _lib.Pyramid()
+    pyr.n_levels = 0
+    assert L.s2a_pyramid_pixels(ctypes.byref(pyr), 1) == -1
+    pyr.n_levels = 2
+    pyr.height[0], pyr.width[0], pyr.stride[0] = 8, 8, 8.0
+    pyr.height[1], pyr.width[1], pyr.stride[1] = 2, 2, 16.0
+    assert L.s2a_pyramid_pixels(ctypes.byref(pyr), 3) == 3 * (64 + 4)
+    rc = L.s2a_align_conv_pyramid_f16(one, ctypes.cast(one, ctypes.POINTER(ctypes.c_float)), one, one, 1, 256, 256, 1,
+                                      ctypes.byref(pyr), z)
+    assert rc == -1 and "smaller than kernel" in msg()          # deform_conv_cuda.cpp:100-103 (shape_check)
+    # IoU workspace
+    assert L.s2a_box_iou_rotated_workspace_bytes(10, 10) > 0
