@@ -340,6 +340,37 @@ def test_alignconv_fused_vs_oracle(rng):
     assert (out >= 0).all() and (out == 0).mean() > 0.2
 
 
+def test_error_conventions_on_gpu():
+    """misuse raises what the reference raises: RuntimeError for shape_check / TORCH_CHECK failures
+    (deform_conv_cuda.cpp:62-150, box_iou_rotated.h, nms_rotated_cuda.cu:80-82), ValueError for non-4-D input,
+    AssertionError for a batch not divisible by the im2col step (deform_conv.py:26-29,58-63)"""
+    import s2anet_amd as S
+    conv = S.DeformConv(8, 16, 3, padding=1).to(dev())
+    x = torch.zeros(2, 8, 10, 12, device=dev())
+    with pytest.raises(RuntimeError):
+        conv(x, torch.zeros(2, 16, 10, 12, device=dev()))                 # offset channels != 2 * 9 * groups
+    with pytest.raises(RuntimeError):
+        conv(x, torch.zeros(2, 18, 9, 12, device=dev()))                  # offset spatial size != output size
+    with pytest.raises(RuntimeError):
+        conv(torch.zeros(2, 6, 10, 12, device=dev()), torch.zeros(2, 18, 10, 12, device=dev()))   # input planes
+    with pytest.raises(RuntimeError):
+        conv(x, torch.zeros(1, 18, 10, 12, device=dev()))                 # batch of offset
+    with pytest.raises(ValueError):
+        S.deform_conv(x[0], torch.zeros(1, 18, 10, 12, device=dev()), conv.weight)
+    with pytest.raises(AssertionError):
+        S.deform_conv(torch.zeros(3, 8, 10, 12, device=dev()), torch.zeros(3, 18, 10, 12, device=dev()), conv.weight,
+                      1, 1, 1, 1, 1, 2)                                  # 3 % im2col_step(2) != 0
+    b5 = torch.rand(7, 5, device=dev()) + 1
+    with pytest.raises(RuntimeError):
+        S.box_iou_rotated(b5[:, :4], b5)
+    with pytest.raises(RuntimeError):
+        S.ml_nms_rotated(b5, torch.rand(6, device=dev()), torch.zeros(7, device=dev()), 0.5)
+    with pytest.raises(RuntimeError):
+        S.ml_nms_rotated(b5, torch.rand(7, device=dev()), torch.zeros(5, device=dev()), 0.5)
+    assert S.box_iou_rotated(b5[:0], b5).shape == (0, 7)                  # empty inputs are not errors
+    assert S.ml_nms_rotated(b5[:0], b5[:0, 0], b5[:0, 0], 0.5).shape == (0,)
+
+
 def test_fused_conv_epilogue(rng):
     from s2anet_amd.fused import FusedConv2d, bias_act_
     for dt, tol in ((torch.float16, 2e-3), (torch.float32, 1e-6)):
