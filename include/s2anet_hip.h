@@ -169,6 +169,16 @@ int s2a_arf_backward(const uint8_t* indices, const void* grad_output, int64_t n_
                      int n_orientation, int kh, int kw, int n_rotation, int dtype, void* grad_input,
                      s2a_stream_t stream);
 
+/* orn_cuda.rie_forward(feature[B,C,1,1], nOrientation) -> (mainDirection uint8[B,C/nOri], aligned[B,C,1,1]) and
+ * orn_cuda.rie_backward(mainDirection, gradOutput[B,C,1,1], nOrientation) -> gradInput (models/orn/src/vision.cpp:10-11,
+ * RotationInvariantEncoding.h:11-34, cuda/RotationInvariantEncoding_cuda.cu:20-84): main direction = first index of
+ * the strict maximum of each group of nOri values, group rotated so that it comes first; backward rotates back.
+ * float32.  Not used by the S2ANet model itself (exported by the module the model imports). */
+int s2a_rie_forward(const void* feature, int64_t batch, int64_t channels, int n_orientation, int dtype,
+                    uint8_t* main_direction, void* aligned, s2a_stream_t stream);
+int s2a_rie_backward(const uint8_t* main_direction, const void* grad_output, int64_t batch, int64_t features,
+                     int n_orientation, int dtype, void* grad_input, s2a_stream_t stream);
+
 /* RotationInvariantPooling.forward (models/orn/functions/rotation_invariant_pooling.py:19-27):
  * x[B,C,H,W] -> out[B,C/nOri,H,W] = max over each group of nOri consecutive channels. */
 int s2a_rot_inv_pool(const void* x, int64_t batch, int64_t channels, int64_t hw, int n_orientation,

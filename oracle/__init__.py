@@ -281,6 +281,30 @@ def arf_backward(indices, grad_output):
     return out
 
 
+def rie_forward(feature, n_ori):
+    """RIE_forward restated (models/orn/src/cpu/RotationInvariantEncoding_cpu.cpp:6-45): feature [B,C,1,1] ->
+    (mainDirection uint8 [B,C/nOri], aligned): first index of the strict maximum of each group, group rotated so that it
+    comes first.  numpy (integer / copy work)."""
+    f = _f32(feature)
+    B, C = f.shape[:2]
+    g = f.reshape(B, C // n_ori, n_ori)
+    d = np.argmax(g, axis=2).astype(np.uint8)                     # argmax = first maximum = the `>` loop
+    l = np.arange(n_ori)[None, None, :]
+    src = (l + d[..., None]) % n_ori                              # aligned[a] = src[(a + d) % n]
+    return d, np.take_along_axis(g, src, axis=2).reshape(f.shape)
+
+
+def rie_backward(main_direction, grad_output, n_ori):
+    """RIE_backward restated (:47-76): gradInput[(l + d) % n] = gradOutput[l]"""
+    g = _f32(grad_output)
+    d = np.asarray(main_direction, np.int64)
+    B, F = d.shape
+    gg = g.reshape(B, F, n_ori)
+    a = np.arange(n_ori)[None, None, :]
+    src = (a - d[..., None]) % n_ori                              # gradInput[a] = gradOutput[(a - d) % n]
+    return np.take_along_axis(gg, src, axis=2).reshape(g.shape)
+
+
 def rot_inv_pool(x, n_ori=8):
     x = _f32(x)
     B, C, H, W = x.shape

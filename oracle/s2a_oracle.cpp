@@ -25,6 +25,7 @@
 //   * deformable conv backward : same situation: pinned to autograd of the
 //                                independent torch formulation (parity unpinned
 //                                against the reference itself)
+//   * RIE forward / backward (numpy, oracle/__init__.py) : vs the reference's CPU op (rie_small.npz)
 //   * ARF backward, polygon NMS (py_cpu_nms_poly_fast), assign_labels, voc_eval,
 //     mergesingle              : vs the reference's own CPU op / Python scripts
 //                                run here (golden fixtures, identical results)

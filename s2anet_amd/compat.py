@@ -42,8 +42,8 @@ def build_modules():
     o = types.ModuleType("models.orn.orn_cuda")
     o.arf_forward = orn.arf_forward                                       # vision.cpp:7-12
     o.arf_backward = orn.arf_backward                                     # vision.cpp:9
-    for n in ("rie_forward", "rie_backward"):
-        setattr(o, n, _not_impl(n))
+    o.rie_forward = orn.rie_forward                                       # vision.cpp:10
+    o.rie_backward = orn.rie_backward                                     # vision.cpp:11
     m[o.__name__] = o
     b = types.ModuleType("utils.box_iou_rotated.box_iou_rotated_cuda")
     b.box_iou_rotated = rotated.box_iou_rotated                           # box_iou_rotated.h:40-42

@@ -167,6 +167,65 @@ extern "C" int s2a_arf_backward(const uint8_t* indices, const void* grad_output,
   return S2A_OK;
 }
 
+// ---------------------------------------------------------------- rotation-invariant encoding
+// orn_cuda.rie_forward / rie_backward (models/orn/src/cuda/RotationInvariantEncoding_cuda.cu:20-57,60-84; CPU twin
+// cpu/RotationInvariantEncoding_cpu.cpp:6-45,47-76): per (batch, feature) group of nOri values the main direction
+// = FIRST index of the strict maximum (start value -FLT_MAX), values rotated so that it comes first;
+// backward rotates the gradient back.  One thread per group.
+namespace s2a {
+namespace {
+__global__ void k_rie_forward(const float* __restrict__ f, int64_t groups, int n_ori, uint8_t* __restrict__ dir,
+                              float* __restrict__ aligned) {
+  for (int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * blockDim.x) {
+    const float* src = f + gidx * n_ori;
+    float mx = -3.402823466e+38F;
+    int d = 0;              // (the reference leaves the direction uninitialised when nothing exceeds -FLT_MAX)
+    for (int l = 0; l < n_ori; l++) {
+      const float v = src[l];
+      if (v > mx) { mx = v; d = l; }
+    }
+    dir[gidx] = (uint8_t)d;
+    for (int l = 0; l < n_ori; l++) aligned[gidx * n_ori + (l - d + n_ori) % n_ori] = src[l];
+  }
+}
+
+__global__ void k_rie_backward(const uint8_t* __restrict__ dir, const float* __restrict__ g, int64_t groups, int n_ori,
+                               float* __restrict__ gin) {
+  for (int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * blockDim.x) {
+    const int d = dir[gidx];
+    for (int l = 0; l < n_ori; l++) gin[gidx * n_ori + (l + d) % n_ori] = g[gidx * n_ori + l];
+  }
+}
+}  // namespace
+}  // namespace s2a
+
+extern "C" int s2a_rie_forward(const void* feature, int64_t batch, int64_t channels, int n_orientation, int dtype,
+                               uint8_t* main_direction, void* aligned, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels >= 0 && n_orientation > 0 && n_orientation <= 255, "rie_forward: bad shape");
+  S2A_CHECK_ARG(channels % n_orientation == 0, "rie_forward: channels %% nOrientation != 0");
+  S2A_CHECK_ARG(dtype == S2A_DTYPE_F32, "rie_forward: float32 only (the reference dispatches float / double)");
+  const int64_t groups = batch * (channels / n_orientation);
+  if (groups == 0) return S2A_OK;
+  S2A_CHECK_ARG(feature && main_direction && aligned, "rie_forward: NULL tensor");
+  k_rie_forward<<<grid_cap(groups), 256, 0, as_stream(stream)>>>((const float*)feature, groups, n_orientation,
+                                                                 main_direction, (float*)aligned);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+extern "C" int s2a_rie_backward(const uint8_t* main_direction, const void* grad_output, int64_t batch, int64_t features,
+                                int n_orientation, int dtype, void* grad_input, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && features >= 0 && n_orientation > 0 && n_orientation <= 255, "rie_backward: bad shape");
+  S2A_CHECK_ARG(dtype == S2A_DTYPE_F32, "rie_backward: float32 only (the reference dispatches float / double)");
+  const int64_t groups = batch * features;
+  if (groups == 0) return S2A_OK;
+  S2A_CHECK_ARG(main_direction && grad_output && grad_input, "rie_backward: NULL tensor");
+  k_rie_backward<<<grid_cap(groups), 256, 0, as_stream(stream)>>>(main_direction, (const float*)grad_output, groups,
+                                                                  n_orientation, (float*)grad_input);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
 extern "C" int s2a_rot_inv_pool(const void* x, int64_t batch, int64_t channels, int64_t hw,
                                 int n_orientation, int dtype, int layout, void* out,
                                 s2a_stream_t stream) {

@@ -63,6 +63,81 @@ def arf_backward(indices, grad_output):
     return out
 
 
+def rie_forward(feature, n_orientation):
+    """orn_cuda.rie_forward(feature[B,C,1,1], nOrientation) -> (mainDirection uint8[B,C/nOri], aligned[B,C,1,1])
+    (models/orn/src/vision.cpp:10, RotationInvariantEncoding.h:11-22); float32"""
+    _lib.require_cuda(feature)
+    if feature.dim() != 4:
+        raise RuntimeError("only supports a batch of RIEs.")                       # AT_ASSERTM of the reference
+    if feature.shape[2] != 1 or feature.shape[3] != 1:
+        raise RuntimeError("mH x mW should be 1x1.")
+    if feature.dtype != torch.float32:
+        raise RuntimeError("rie_forward: float32 features only")
+    f = feature.contiguous()
+    B, C = f.shape[:2]
+    n = int(n_orientation)
+    direction = torch.empty((B, C // n), dtype=torch.uint8, device=f.device)
+    aligned = torch.zeros_like(f)
+    with torch.cuda.device(f.device):
+        _lib.check(_lib.lib().s2a_rie_forward(_lib.ptr(f), B, C, n, _lib.dtype_code(f), _lib.ptr(direction),
+                                              _lib.ptr(aligned), _lib.stream_ptr(f.device)))
+    return direction, aligned
+
+
+def rie_backward(main_direction, grad_output, n_orientation):
+    """orn_cuda.rie_backward(mainDirection uint8[B,F], gradOutput[B,F*nOri,1,1], nOrientation) -> gradInput"""
+    _lib.require_cuda(main_direction, grad_output)
+    if grad_output.dtype != torch.float32:
+        raise RuntimeError("rie_backward: float32 gradients only")
+    d = main_direction.contiguous()
+    if d.dtype != torch.uint8:
+        d = d.byte()
+    g = grad_output.contiguous()
+    B, F = d.shape
+    out = torch.zeros_like(g)
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().s2a_rie_backward(_lib.ptr(d), _lib.ptr(g), B, F, int(n_orientation), _lib.dtype_code(g),
+                                               _lib.ptr(out), _lib.stream_ptr(g.device)))
+    return out
+
+
+class _RotationInvariantEncoding(torch.autograd.Function):
+    """models/orn/functions/rotation_invariant_encoding.py:11-38"""
+
+    @staticmethod
+    def forward(ctx, input, nOrientation, return_direction=False):
+        ctx.nOrientation = nOrientation
+        ctx.return_direction = return_direction
+        mainDirection, output = rie_forward(input, nOrientation)
+        if return_direction:
+            ctx.save_for_backward(input, mainDirection)
+            ctx.mark_non_differentiable(mainDirection)
+            return output, mainDirection
+        ctx.save_for_backward(input)
+        ctx.mainDirection = mainDirection
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output, *unused):
+        if ctx.return_direction:
+            _, mainDirection = ctx.saved_tensors
+        else:
+            mainDirection = ctx.mainDirection
+        return rie_backward(mainDirection, grad_output.contiguous(), ctx.nOrientation), None, None
+
+
+class RotationInvariantEncoding(torch.nn.Module):
+    """models/orn/functions/rotation_invariant_encoding.py:41-49"""
+
+    def __init__(self, nOrientation, return_direction=False):
+        super().__init__()
+        self.nOrientation = nOrientation
+        self.return_direction = return_direction
+
+    def forward(self, input):
+        return _RotationInvariantEncoding.apply(input, self.nOrientation, self.return_direction)
+
+
 class _ActiveRotatingFilter(torch.autograd.Function):
     """models/orn/functions/active_rotating_filter.py:11-34"""
 

@@ -152,6 +152,24 @@ def gen_arf_backward():
     np.savez_compressed(os.path.join(OUT, "arf_backward_small.npz"), **out)
 
 
+def gen_rie():
+    """RotationInvariantEncoding forward / backward from the reference's CPU op (own rng: other fixtures unchanged)"""
+    rng = np.random.default_rng(8642)
+    orn = ref.orn()
+    out = {}
+    for tag, (B, F, n) in (("a", (3, 5, 8)), ("b", (2, 7, 4))):
+        f = rng.standard_normal((B, F * n, 1, 1)).astype(np.float32)
+        f[0, :n, 0, 0] = 0.25                                    # a tie: the first index wins
+        f[1, n:2 * n, 0, 0] = np.float32(-1e30)                  # all equal and very negative
+        d, al = orn.rie_forward(torch.from_numpy(f), n)
+        g = rng.standard_normal((B, F * n, 1, 1)).astype(np.float32)
+        gi = orn.rie_backward(d, torch.from_numpy(g), n)
+        out[f"f_{tag}"], out[f"n_{tag}"] = f, np.int64(n)
+        out[f"dir_{tag}"], out[f"aligned_{tag}"] = d.numpy(), al.numpy()
+        out[f"gout_{tag}"], out[f"gin_{tag}"] = g, gi.numpy()
+    np.savez_compressed(os.path.join(OUT, "rie_small.npz"), **out)
+
+
 def gen_merge_nms():
     """chip-merge polygon NMS from the reference's own script (DOTA_devkit/ResultMerge_multi_process.py),
     imported in place with the SWIG polyiou module built into oracle/_ref and a stub for shapely"""
@@ -438,4 +456,5 @@ if __name__ == "__main__":
     gen_assign_labels()
     gen_voc_eval()
     gen_merge_file()
+    gen_rie()
     print("done ->", OUT)

@@ -709,6 +709,29 @@ def test_arf_backward_and_autograd(rng):
     assert torch.allclose(oc.weight.grad, S.arf_backward(oc.indices, w_exp.grad), rtol=1e-5, atol=1e-5)
 
 
+def test_rie_forward_backward(rng):
+    """orn_cuda.rie_forward / rie_backward on the GPU: golden (reference CPU op) + oracle on a larger case + autograd"""
+    from s2anet_amd.orn import rie_forward, rie_backward, RotationInvariantEncoding
+    g = golden("rie_small.npz")
+    for tag in ("a", "b"):
+        n = int(g[f"n_{tag}"])
+        d, al = rie_forward(cu(g[f"f_{tag}"]), n)
+        assert d.dtype == torch.uint8 and np.array_equal(d.cpu().numpy(), g[f"dir_{tag}"])
+        assert np.array_equal(al.cpu().numpy(), g[f"aligned_{tag}"])
+        assert np.array_equal(rie_backward(cu(g[f"dir_{tag}"]), cu(g[f"gout_{tag}"]), n).cpu().numpy(), g[f"gin_{tag}"])
+    f = rng.standard_normal((700, 1024 * 8, 1, 1)).astype(np.float32)      # more groups than one grid pass covers
+    d, al = rie_forward(cu(f), 8)
+    rd, ral = oracle.rie_forward(f, 8)
+    assert np.array_equal(d.cpu().numpy(), rd) and np.array_equal(al.cpu().numpy(), ral)
+    x = cu(f[:4, :64]).requires_grad_(True)
+    y, direction = RotationInvariantEncoding(8, return_direction=True)(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    assert np.array_equal(x.grad.cpu().numpy(), oracle.rie_backward(direction.cpu().numpy(), w.cpu().numpy(), 8))
+    with pytest.raises(RuntimeError):
+        rie_forward(cu(f[:2, :16, :, 0]), 8)
+
+
 def test_polyiou_pairs_bitexact(rng):
     from s2anet_amd.rotated import polyiou_pairs
     g = golden("iou_256.npz")

@@ -116,6 +116,19 @@ def test_arf_backward_matches_reference():
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
 
 
+def test_rie_matches_reference():
+    """RotationInvariantEncoding forward / backward restated in numpy == the reference's CPU op (ties: first index;
+    the all-equal group keeps direction 0)"""
+    g = golden("rie_small.npz")
+    for tag in ("a", "b"):
+        n = int(g[f"n_{tag}"])
+        d, al = oracle.rie_forward(g[f"f_{tag}"], n)
+        assert np.array_equal(d, g[f"dir_{tag}"]) and np.array_equal(al, g[f"aligned_{tag}"])
+        assert np.array_equal(oracle.rie_backward(g[f"dir_{tag}"], g[f"gout_{tag}"], n), g[f"gin_{tag}"])
+        # backward is the inverse rotation of forward
+        assert np.array_equal(oracle.rie_backward(d, al, n), g[f"f_{tag}"])
+
+
 def test_dcn_backward_oracle_matches_autograd_of_independent_formulation():
     """parity unpinned against the reference itself (CUDA only); pinned to autograd of the torch formulation"""
     g = golden("dcn_backward_small.npz")
