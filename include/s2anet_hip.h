@@ -215,6 +215,14 @@ int s2a_deform_conv_forward(const void* input, const void* weight, const void* o
                             void* output, const s2a_dcn_params* p, void* workspace,
                             size_t workspace_bytes, s2a_stream_t stream);
 
+/* deform_conv_cuda.modulated_deform_conv_cuda_forward (models/dcn/src/deform_conv_cuda.cpp:491-570, kernel
+ * deform_conv_cuda_kernel.cu:467-632; DCNv2): as s2a_deform_conv_forward with every sampled value multiplied by
+ * mask[B, dg*kH*kW, Ho, Wo] and bias[O] (may be NULL) added after the contraction.  NCHW, any kernel size / stride /
+ * padding / dilation / groups; offset and mask in the input's dtype.  One thread per output element (the S2ANet
+ * model does not use this operator; it is exported by the module the model imports).  The backward is not built. */
+int s2a_modulated_deform_conv_forward(const void* input, const void* weight, const void* bias, const void* offset,
+                                      const void* mask, void* output, const s2a_dcn_params* p, s2a_stream_t stream);
+
 /* AlignConv.get_offset (models/alignconv.py:30-87), batched: anchors[B,H*W,5] f32 (pixels,
  * radians) -> offset[B,2*k*k,H,W] f32 (k = 3). */
 int s2a_align_offsets(const float* anchors, int64_t batch, int64_t height, int64_t width,

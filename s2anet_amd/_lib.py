@@ -69,6 +69,7 @@ SYMBOLS = {
     "s2a_arf_forward": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp,
                                 c_vp]),
     "s2a_arf_backward": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "s2a_modulated_deform_conv_forward": (c_int, [c_vp] * 6 + [ctypes.POINTER(DcnParams), c_vp]),
     "s2a_rie_forward": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     "s2a_rie_backward": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp]),
     "s2a_rot_inv_pool": (c_int, [c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp]),

@@ -6,8 +6,8 @@ PyTorch-ROCm without building any of its CUDA sources.
     import s2anet_amd.compat as compat; compat.install()
     sys.path.insert(0, "/path/to/S2ANet"); from models.head import S2ANetHead   # reference code
 
-Functions the model never calls (modulated DCN, PS-RoI pooling, RIE) exist so that imports succeed and
-raise NotImplementedError when called.
+Functions the model never calls and that are not built (modulated DCN backward, PS-RoI pooling) exist so that imports
+succeed and raise NotImplementedError when called.
 """
 import sys
 import types
@@ -32,8 +32,8 @@ def build_modules():
     d.deform_conv_forward_cuda = dcn.deform_conv_forward_cuda            # deform_conv_cuda.cpp:689-690
     d.deform_conv_backward_input_cuda = dcn.deform_conv_backward_input_cuda            # :691-693
     d.deform_conv_backward_parameters_cuda = dcn.deform_conv_backward_parameters_cuda  # :694-696
-    for n in ("modulated_deform_conv_cuda_forward", "modulated_deform_conv_cuda_backward"):
-        setattr(d, n, _not_impl(n))                                       # :697-701
+    d.modulated_deform_conv_cuda_forward = dcn.modulated_deform_conv_cuda_forward      # :697-699
+    d.modulated_deform_conv_cuda_backward = _not_impl("modulated_deform_conv_cuda_backward")   # :700-701
     m[d.__name__] = d
     p = types.ModuleType("models.dcn.deform_pool_cuda")
     for n in ("deform_psroi_pooling_cuda_forward", "deform_psroi_pooling_cuda_backward"):

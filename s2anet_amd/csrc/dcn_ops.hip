@@ -2019,10 +2019,15 @@ constexpr int mfma_lds_bytes() { return NPOS * 9 * 32 + 2 * (kMaxO + NPOS) * kRo
 // ------------------------------------------------------------------ generic fallback
 // Any stride / padding / dilation / groups / deformable groups / channel count, NCHW only.
 // One thread per output element; used when the shape is not the AlignConv fast-path shape.
+// mask / bias: the modulated form (DCNv2: modulated_deformable_im2col_gpu_kernel, deform_conv_cuda_kernel.cu:570-632:
+// every sampled value is multiplied by mask[b, dg, tap, ho, wo]; bias added after the contraction,
+// deform_conv_cuda.cpp:566-568); both null = plain deformable convolution.
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void k_dcn_generic(const T* __restrict__ x, const TO* __restrict__ offset,
                                                      const T* __restrict__ w, T* __restrict__ out,
-                                                     s2a_dcn_params p, int Ho, int Wo) {
+                                                     s2a_dcn_params p, int Ho, int Wo,
+                                                     const T* __restrict__ mask = nullptr,
+                                                     const T* __restrict__ bias = nullptr) {
   const int64_t total = p.batch * p.out_channels * Ho * Wo;
   const int Cg = (int)(p.channels / p.group), Og = (int)(p.out_channels / p.group);
   const int cpdg = (int)(p.channels / p.deformable_group);
@@ -2042,6 +2047,7 @@ __global__ __launch_bounds__(256) void k_dcn_generic(const T* __restrict__ x, co
       int dg = c / cpdg;
       const T* plane = x + (b * p.channels + c) * (int64_t)H * W;
       const TO* offp = offset + (b * p.deformable_group + dg) * 2 * p.kH * p.kW * (int64_t)Ho * Wo;
+      const T* maskp = mask ? mask + (b * p.deformable_group + dg) * p.kH * p.kW * (int64_t)Ho * Wo : nullptr;
       for (int i = 0; i < p.kH; i++)
         for (int j = 0; j < p.kW; j++) {
           int t = i * p.kW + j;
@@ -2061,10 +2067,12 @@ __global__ __launch_bounds__(256) void k_dcn_generic(const T* __restrict__ x, co
             if (h_high <= H - 1 && w_high <= W - 1) v4 = (float)plane[h_high * W + w_high];
             v = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
           }
+          if (maskp) v *= (float)maskp[((int64_t)t * Ho + ho) * Wo + wo];
           if (sizeof(T) == 2) v = (float)(T)v;  // f16 columns, as the f16 fast path
           acc += (float)w[(((int64_t)o * Cg + cl) * p.kH + i) * p.kW + j] * v;
         }
     }
+    if (bias) acc += (float)bias[o];
     if (p.relu) acc = fmaxf(acc, 0.f);
     out[e] = (T)acc;
   }
@@ -2233,6 +2241,37 @@ extern "C" int s2a_deform_conv_forward(const void* input, const void* weight, co
     k_dcn_generic<_Float16, float><<<g, 256, 0, st>>>((const _Float16*)input, (const float*)offset, (const _Float16*)weight, (_Float16*)output, p, (int)Ho, (int)Wo);
   else
     k_dcn_generic<_Float16, _Float16><<<g, 256, 0, st>>>((const _Float16*)input, (const _Float16*)offset, (const _Float16*)weight, (_Float16*)output, p, (int)Ho, (int)Wo);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+extern "C" int s2a_modulated_deform_conv_forward(const void* input, const void* weight, const void* bias,
+                                                 const void* offset, const void* mask, void* output,
+                                                 const s2a_dcn_params* pp, s2a_stream_t stream) {
+  S2A_CHECK_ARG(pp != nullptr, "modulated_deform_conv: NULL params");
+  const s2a_dcn_params p = *pp;
+  S2A_CHECK_ARG(p.kW > 0 && p.kH > 0 && p.dW > 0 && p.dH > 0 && p.dilationW > 0 && p.dilationH > 0,
+                "modulated_deform_conv: kernel size, stride and dilation must be positive");
+  S2A_CHECK_ARG(p.group > 0 && p.deformable_group > 0 && p.channels % p.group == 0 && p.out_channels % p.group == 0 &&
+                p.channels % p.deformable_group == 0, "Input shape and kernel channels wont match");
+  S2A_CHECK_ARG(p.dtype == S2A_DTYPE_F32 || p.dtype == S2A_DTYPE_F16, "modulated_deform_conv: dtype");
+  S2A_CHECK_ARG(p.offset_dtype == p.dtype, "modulated_deform_conv: offset and mask share the input dtype");
+  S2A_CHECK_ARG(p.layout == S2A_LAYOUT_NCHW, "modulated_deform_conv: NCHW only");
+  const int64_t Ho = (p.height + 2 * p.padH - (p.dilationH * (p.kH - 1) + 1)) / p.dH + 1;
+  const int64_t Wo = (p.width + 2 * p.padW - (p.dilationW * (p.kW - 1) + 1)) / p.dW + 1;
+  S2A_CHECK_ARG(Ho >= 1 && Wo >= 1, "modulated_deform_conv: output size is too small");
+  if (p.batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(input && weight && offset && mask && output, "modulated_deform_conv: NULL tensor");
+  hipStream_t st = as_stream(stream);
+  const int64_t total = p.batch * p.out_channels * Ho * Wo;
+  unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 65535);
+  if (p.dtype == S2A_DTYPE_F32)
+    k_dcn_generic<float, float><<<g, 256, 0, st>>>((const float*)input, (const float*)offset, (const float*)weight,
+                                                   (float*)output, p, (int)Ho, (int)Wo, (const float*)mask, (const float*)bias);
+  else
+    k_dcn_generic<_Float16, _Float16><<<g, 256, 0, st>>>((const _Float16*)input, (const _Float16*)offset, (const _Float16*)weight,
+                                                         (_Float16*)output, p, (int)Ho, (int)Wo, (const _Float16*)mask,
+                                                         (const _Float16*)bias);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -109,6 +109,45 @@ def _bwd_common(input, offset, gradOutput, weight_like, kW, kH, dW, dH, padW, pa
     return x, off, go, (B, C, H, W, O, Ho, Wo), params
 
 
+def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h, kernel_w,
+                                       stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group,
+                                       deformable_group, with_bias):
+    """Same positional signature as the reference pybind function (models/dcn/src/deform_conv_cuda.cpp:491-497; note
+    H-before-W here, unlike deform_conv_forward_cuda).  ``output`` is caller-allocated and filled in place; ``ones`` /
+    ``columns`` are accepted and ignored.  Returns None as the reference (void)."""
+    _lib.require_cuda(input, weight, offset, mask, output)
+    if not input.is_contiguous():
+        raise RuntimeError("input tensor has to be contiguous")               # TORCH_CHECK :498
+    if not weight.is_contiguous():
+        raise RuntimeError("weight tensor has to be contiguous")
+    B, C, H, W = input.shape
+    O, Ck, kh, kw = weight.shape
+    if kh != kernel_h or kw != kernel_w:
+        raise RuntimeError("Input shape and kernel shape wont match: (%d x %d vs %d x %d)." % (kernel_h, kernel_w, kh, kw))
+    if C != Ck * group:
+        raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (C, Ck * group))
+    Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) // stride_h + 1
+    Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) // stride_w + 1
+    if tuple(offset.shape) != (B, deformable_group * 2 * kh * kw, Ho, Wo) or \
+            tuple(mask.shape) != (B, deformable_group * kh * kw, Ho, Wo):
+        raise RuntimeError("offset / mask shape does not match the output size")
+    if output.numel() != B * O * Ho * Wo:
+        raise RuntimeError("output has the wrong number of elements")
+    x = input
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    off = offset.to(x.dtype).contiguous()
+    msk = mask.to(x.dtype).contiguous()
+    b = bias.to(x.dtype).contiguous() if (with_bias and bias is not None and bias.numel()) else None
+    out = output if (output.is_contiguous() and output.dtype == x.dtype) else torch.empty((B, O, Ho, Wo), dtype=x.dtype, device=x.device)
+    p = _lib.DcnParams(B, C, H, W, O, kernel_w, kernel_h, stride_w, stride_h, pad_w, pad_h, dilation_w, dilation_h, group,
+                       deformable_group, _lib.dtype_code(x), _lib.dtype_code(off), _lib.LAYOUT_NCHW, 0)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().s2a_modulated_deform_conv_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(off),
+                                                                _lib.ptr(msk), _lib.ptr(out), p, _lib.stream_ptr(x.device)))
+    if out is not output:
+        output.view(B, O, Ho, Wo).copy_(out)
+
+
 def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH,
                                     dW, dH, padW, padH, dilationW, dilationH, group, deformable_group,
                                     im2col_step):

@@ -24,9 +24,14 @@ def test_alias_modules_have_reference_names():
     assert list(inspect.signature(d.deform_conv_backward_parameters_cuda).parameters) == [
         "input", "offset", "gradOutput", "gradWeight", "columns", "ones", "kW", "kH", "dW", "dH", "padW", "padH",
         "dilationW", "dilationH", "group", "deformable_group", "scale", "im2col_step"]
-    for n in ("modulated_deform_conv_cuda_forward", "modulated_deform_conv_cuda_backward"):
-        with pytest.raises(NotImplementedError):
-            getattr(d, n)()
+    # modulated (DCNv2) forward: pybind signature of deform_conv_cuda.cpp:491-497; its backward is not built
+    assert list(inspect.signature(d.modulated_deform_conv_cuda_forward).parameters) == [
+        "input", "weight", "bias", "ones", "offset", "mask", "output", "columns", "kernel_h", "kernel_w", "stride_h",
+        "stride_w", "pad_h", "pad_w", "dilation_h", "dilation_w", "group", "deformable_group", "with_bias"]
+    with pytest.raises(NotImplementedError):
+        d.modulated_deform_conv_cuda_backward()
+    for n in ("rie_forward", "rie_backward"):
+        assert callable(getattr(mods["models.orn.orn_cuda"], n))
     assert callable(mods["models.orn.orn_cuda"].arf_forward) and callable(mods["models.orn.orn_cuda"].arf_backward)
     assert callable(mods["utils.box_iou_rotated.box_iou_rotated_cuda"].box_iou_rotated)
     assert callable(mods["utils.nms_rotated.nms_rotated_cuda"].nms_rotated)

@@ -709,6 +709,82 @@ def test_arf_backward_and_autograd(rng):
     assert torch.allclose(oc.weight.grad, S.arf_backward(oc.indices, w_exp.grad), rtol=1e-5, atol=1e-5)
 
 
+def test_modulated_deform_conv_forward_vs_torch_formulation(rng):
+    """deform_conv_cuda.modulated_deform_conv_cuda_forward (DCNv2): no runnable reference (CUDA only) -> checked against
+    an independent torch formulation (explicit 4-corner gather x mask, einsum with the grouped filter, + bias) in
+    float64; groups, deformable groups, stride 2 / dilation 2 / 5x3 kernels; mask == 1 and bias == 0 reproduce the
+    plain deformable convolution"""
+    from s2anet_amd.dcn import modulated_deform_conv_cuda_forward, deform_conv_forward_cuda
+
+    def ref(x, w, b, off, msk, stride, pad, dil, group, dg):
+        B, C, H, W = x.shape
+        O, Cg, kh, kw = w.shape
+        Ho = (H + 2 * pad[0] - (dil[0] * (kh - 1) + 1)) // stride[0] + 1
+        Wo = (W + 2 * pad[1] - (dil[1] * (kw - 1) + 1)) // stride[1] + 1
+        xd, cols = x.double(), []
+        ys = torch.arange(Ho, dtype=torch.float64).view(1, Ho, 1) * stride[0] - pad[0]
+        xs = torch.arange(Wo, dtype=torch.float64).view(1, 1, Wo) * stride[1] - pad[1]
+        cpg = C // dg
+        for c in range(C):
+            g_ = c // cpg
+            taps = []
+            for i in range(kh):
+                for j in range(kw):
+                    t = i * kw + j
+                    hy = ys + i * dil[0] + off[:, g_ * 2 * kh * kw + 2 * t].double()
+                    wx = xs + j * dil[1] + off[:, g_ * 2 * kh * kw + 2 * t + 1].double()
+                    ok = (hy > -1) & (wx > -1) & (hy < H) & (wx < W)
+                    h0, w0 = torch.floor(hy), torch.floor(wx)
+                    lh, lw = hy - h0, wx - w0
+                    val = torch.zeros_like(hy)
+                    for (dy, dx, wt) in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw), (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+                        yy, xx = (h0 + dy).long(), (w0 + dx).long()
+                        inside = (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
+                        v = xd[:, c][torch.arange(B).view(B, 1, 1), yy.clamp(0, H - 1), xx.clamp(0, W - 1)]
+                        val = val + torch.where(inside, wt * v, torch.zeros_like(v))
+                    taps.append(torch.where(ok, val, torch.zeros_like(val)) * msk[:, g_ * kh * kw + t].double())
+            cols.append(torch.stack(taps, 1))                      # [B, kh*kw, Ho, Wo]
+        col = torch.stack(cols, 1)                                 # [B, C, kh*kw, Ho, Wo]
+        Og = O // group
+        out = torch.zeros(B, O, Ho, Wo, dtype=torch.float64)
+        for g_ in range(group):
+            out[:, g_ * Og:(g_ + 1) * Og] = torch.einsum("ock,bckhw->bohw", w[g_ * Og:(g_ + 1) * Og].double().reshape(Og, Cg, kh * kw),
+                                                         col[:, g_ * Cg:(g_ + 1) * Cg])
+        return out + (b.double().view(1, -1, 1, 1) if b is not None else 0)
+
+    g = torch.Generator().manual_seed(4)
+    cases = [(2, 8, 9, 11, 6, (3, 3), (1, 1), (1, 1), (1, 1), 1, 1, True),
+             (1, 8, 12, 10, 8, (3, 3), (2, 2), (1, 1), (1, 1), 2, 2, True),
+             (2, 4, 10, 13, 4, (5, 3), (1, 1), (2, 1), (2, 2), 1, 4, False)]
+    for (B, C, H, W, O, k, st, pd, dl, group, dg, with_bias) in cases:
+        x = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(O, C // group, *k, generator=g) * 0.2
+        b = torch.randn(O, generator=g) if with_bias else None
+        Ho = (H + 2 * pd[0] - (dl[0] * (k[0] - 1) + 1)) // st[0] + 1
+        Wo = (W + 2 * pd[1] - (dl[1] * (k[1] - 1) + 1)) // st[1] + 1
+        off = torch.randn(B, dg * 2 * k[0] * k[1], Ho, Wo, generator=g) * 1.5
+        msk = torch.rand(B, dg * k[0] * k[1], Ho, Wo, generator=g)
+        out = torch.empty(B, O, Ho, Wo, device=dev())
+        r = modulated_deform_conv_cuda_forward(cu(x), cu(w), cu(b) if with_bias else torch.empty(0, device=dev()), None,
+                                               cu(off), cu(msk), out, None, k[0], k[1], st[0], st[1], pd[0], pd[1],
+                                               dl[0], dl[1], group, dg, with_bias)
+        assert r is None
+        want = ref(x, w, b, off, msk, st, pd, dl, group, dg)
+        assert (out.cpu().double() - want).abs().max().item() < 2e-4, (B, C, H, W, O, k)
+    # mask of ones, no bias == the plain deformable convolution of the same library
+    B, C, H, W, O = 2, 8, 9, 11, 6
+    x, w = torch.randn(B, C, H, W, generator=g), torch.randn(O, C, 3, 3, generator=g) * 0.2
+    off = torch.randn(B, 18, H, W, generator=g)
+    o1, o2 = torch.empty(B, O, H, W, device=dev()), torch.empty(B, O, H, W, device=dev())
+    modulated_deform_conv_cuda_forward(cu(x), cu(w), torch.empty(0, device=dev()), None, cu(off), torch.ones(B, 9, H, W, device=dev()),
+                                       o1, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, False)
+    deform_conv_forward_cuda(cu(x), cu(w), cu(off), o2, None, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 64)
+    assert torch.equal(o1, o2)
+    with pytest.raises(RuntimeError):
+        modulated_deform_conv_cuda_forward(cu(x), cu(w), torch.empty(0, device=dev()), None, cu(off), torch.ones(B, 8, H, W, device=dev()),
+                                           o1, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, False)
+
+
 def test_rie_forward_backward(rng):
     """orn_cuda.rie_forward / rie_backward on the GPU: golden (reference CPU op) + oracle on a larger case + autograd"""
     from s2anet_amd.orn import rie_forward, rie_backward, RotationInvariantEncoding
