@@ -35,8 +35,8 @@ namespace s2a {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kLdsQueue = 6144;      // entries per workgroup queue
-constexpr int kFlushAt = 2048;       // flush when more than this is pending
+constexpr int kLdsQueue = 1024;      // entries per workgroup queue; a dense-stage batch adds at most 256
+constexpr int kFlushAt = kLdsQueue - 256;
 constexpr int kPersistentGrid = 1024;
 constexpr unsigned kScanCacheWords = 6144;  // 48 KB of suppression mask cached in LDS per segment
 
@@ -408,10 +408,12 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
                                                        unsigned long long* __restrict__ gcount,
                                                        unsigned long long cap) {
   __shared__ uint2 s_q[kLdsQueue];
-  __shared__ unsigned s_count, s_base[2];
+  __shared__ unsigned s_count, s_base[2], s_cnt1[2];
   __shared__ PreBox s_col[2][64];
+  __shared__ PreBox s_row[64];                 // the row block's boxes for the dense second stage
+  __shared__ unsigned short s_q1[4096];        // circle-test survivors of the current tile: row << 6 | column
   PairQueue Q{s_q, &s_count, s_base};
-  if (threadIdx.x == 0) s_count = 0;
+  if (threadIdx.x == 0) { s_count = 0; s_cnt1[0] = 0; s_cnt1[1] = 0; }
   const uint32_t S = *num_seg;
   // few segments (the per-image x class case): the two prefix arrays the tile locate searches go to LDS once, so
   // a locate is a handful of LDS reads instead of ~8 dependent global loads (the launch is latency-bound there)
@@ -444,46 +446,63 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
   if (tile >= tend) { __syncthreads(); queue_flush(Q, gq, gcount, cap); return; }
   TileRef t = locate_tile(tile, tile_off, seg_start, S);
   if (threadIdx.x < 64) s_col[0][threadIdx.x] = col_box(t);
+  // column boxes are requested TWO tiles ahead (one tile of tests, ~1 k cycles, does not cover a global round trip:
+  // the kernel ran at ~11 k cycles per tile): nb1 = boxes of tile + 1 (already in flight), nb2 = boxes of tile + 2
+  TileRef t1 = t;
+  PreBox nb1 = {};
+  if (tile + 1 < tend) {
+    t1 = advance(t, tile + 1);
+    if (threadIdx.x < 64) nb1 = col_box(t1);
+  }
   __syncthreads();
   int cur = 0;
   uint32_t a_seg = 0xffffffffu, a_rb = 0xffffffffu;
   PreBox a = {};
   for (; tile < tend; tile++) {
     const bool has_next = tile + 1 < tend;
-    TileRef tn = t;
-    PreBox nb = {};
-    if (has_next) {
-      tn = advance(t, tile + 1);
-      if (threadIdx.x < 64) nb = col_box(tn);          // in flight under this tile's tests
+    const TileRef tn = t1;
+    const PreBox nb = nb1;
+    if (tile + 2 < tend) {
+      t1 = advance(t1, tile + 2);
+      if (threadIdx.x < 64) nb1 = col_box(t1);         // in flight under two tiles of tests
     }
     const uint32_t il = t.rb * 64 + row;
     if (a_seg != t.seg_start || a_rb != t.rb) {         // (uniform) new row block
       a_seg = t.seg_start; a_rb = t.rb;
       if (il < t.ns) a = sorted[t.seg_start + il];
+      if (quarter == 0) s_row[row] = a;                 // read by the dense stage (after the barrier below)
     }
+    // Stage 1: the cheap circle test for all 16 columns of a thread; survivors go to an LDS list.
+    // Stage 2, dense: every lane takes ONE survivor and runs the separating-axis test on it.  (Run in place, a wave
+    // with any surviving lane paid for the SAT of all its lanes, max-popcount times per tile: at 200 k rows the SAT
+    // made up two thirds of the kernel's 47 VALU operations per pair.)
+    const int par = (int)(tile & 1);
     if (il < t.ns) {
-      // two passes: the cheap circle test for all 16 columns first (a bit per survivor), then the separating-
-      // axis test only on the survivors -- about 3 % of the pairs, so the second loop runs max-popcount (2-4)
-      // times per wave instead of once per column (a wave with ANY surviving lane used to pay for the SAT)
-      unsigned m16 = 0;
 #pragma unroll
       for (int c = 0; c < 16; c++) {
         const int cc = quarter * 16 + c;
         const uint32_t jl = t.cb * 64 + cc;
-        if (jl < t.ns && jl > il && !surely_disjoint(a.x, a.y, a.r, s_col[cur][cc].x, s_col[cur][cc].y, s_col[cur][cc].r))
-          m16 |= 1u << c;
-      }
-      while (m16) {
-        const int c = __builtin_ctz(m16);
-        m16 &= m16 - 1;
-        const int cc = quarter * 16 + c;
-        if (!sat_disjoint(a, s_col[cur][cc])) queue_push(Q, t.seg_start + il, t.seg_start + t.cb * 64 + cc);
+        if (jl < t.ns && jl > il && !surely_disjoint(a.x, a.y, a.r, s_col[cur][cc].x, s_col[cur][cc].y, s_col[cur][cc].r)) {
+          const unsigned p = atomicAdd(&s_cnt1[par], 1u);
+          s_q1[p] = (unsigned short)((row << 6) | cc);
+        }
       }
     }
     if (has_next && threadIdx.x < 64) s_col[cur ^ 1][threadIdx.x] = nb;
-    // (uniform decision through the barrier's OR: a plain read of s_count after a barrier can differ between waves,
-    // a fast one may already be pushing pairs of the next tile)
-    if (__syncthreads_or(s_count > kFlushAt)) queue_flush(Q, gq, gcount, cap);
+    __syncthreads();                                    // survivor list, s_row and the next column block are in place
+    if (threadIdx.x == 0) s_cnt1[par ^ 1] = 0;          // the next tile's counter (nobody touches it in this phase)
+    const unsigned cnt1 = s_cnt1[par];                  // stable: no pushes to the list during the dense stage
+    for (unsigned e0 = 0; e0 < cnt1; e0 += kThreads) {  // uniform trip count
+      // (uniform decision through the barrier's OR: a plain read of s_count after a barrier can differ between waves)
+      if (__syncthreads_or(s_count > kFlushAt)) queue_flush(Q, gq, gcount, cap);
+      const unsigned e = e0 + threadIdx.x;
+      if (e < cnt1) {
+        const unsigned v = s_q1[e], r = v >> 6, cc = v & 63u;
+        if (!sat_disjoint(s_row[r], s_col[cur][cc]))
+          queue_push(Q, t.seg_start + t.rb * 64 + r, t.seg_start + t.cb * 64 + cc);
+      }
+    }
+    __syncthreads();                                    // dense stage done: lists and s_col[cur] may be reused
     cur ^= 1;
     t = tn;
   }
