@@ -105,6 +105,31 @@ def test_nms_golden_keep_bitexact(thr):
     assert np.array_equal(k1, g[f"sc_keep_ge_{thr}"])
 
 
+@pytest.mark.parametrize("thr", [0.03, 0.06, 0.1, 0.3, 0.5, 0.7])
+def test_nms_area_ratio_shortcut_is_exact(rng, thr):
+    """the cull kernel drops pairs whose area ratio cannot reach the threshold (IoU <= min / max) before the dense IoU
+    pass: keep lists must stay those of the oracle for every threshold, with widely spread sizes, concentric boxes
+    whose ratio sits right at the threshold, and very thin boxes (for which the shortcut is switched off)"""
+    import s2anet_amd as S
+    n = 2500
+    d = rand_rboxes(rng, n, span=300, lo=2, hi=120)
+    d[: n // 4, 2] *= rng.uniform(0.01, 0.05, n // 4).astype(np.float32)            # very thin
+    # concentric pairs with area ratio thr * (1 +- small): the shortcut's margin must not flip them
+    m = 300
+    base = rand_rboxes(rng, m, span=300, lo=30, hi=80)
+    inner = base.copy()
+    f = np.sqrt(thr * (1 + rng.uniform(-0.03, 0.03, m))).astype(np.float32)
+    inner[:, 2] *= f
+    inner[:, 3] *= f
+    d = np.concatenate([d, base, inner]).astype(np.float32)
+    s = distinct_scores(rng, d.shape[0])
+    lab = rng.integers(0, 3, d.shape[0]).astype(np.float32)
+    lab[n:n + m] = lab[n + m:]                                                     # the pairs share a label
+    k = S.ml_nms_rotated(cu(d), cu(s), cu(lab), float(thr)).cpu().numpy()
+    ref = oracle.ml_nms_rotated(d, s, lab, float(thr), rule=oracle.RULE_GT, sort_mode=oracle.SORT_GPU, cull=True)
+    assert np.array_equal(k, ref)
+
+
 def test_nms_four_box_case_and_wrapper_quirks():
     import s2anet_amd as S
     from s2anet_amd.rotated import nms_rotated_raw
