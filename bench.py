@@ -2,21 +2,28 @@
 """bench.py — throughput of the S2ANet dense-inference hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 from a bare shell: this process launches N ranks itself (one fresh child process per GPU, before anything
+here touches the GPU) and relays rank 0's JSON line; under ``python -m torch.distributed.run --nproc-per-node N``
+(WORLD_SIZE already set) it simply is one of the ranks.
 
 One "step" = one pass of the whole inference hot path over one batch of synthetic input PER GPU:
-8 device-resident uint8 1024x1024 chips -> /255 -> fp16 R-50-FPN S2ANet (backbone/FPN = MIOpen
-convolutions, the carrier; head ops = this repo's HIP kernels: fused anchor refine, AlignConv on
-the matrix cores, cached ARF expansion, rotation-invariant pooling, batched decode, segmented
-on-device rotated ml-NMS) -> padded detections [8,2000,6]+labels+counts on the device.  With N > 1
-every rank runs its own 8 chips (weak scaling: BASELINE.json configs[3] = batch 64 over 8 GPUs)
-and the step ends with ONE RCCL all-gather of the padded detections.
+8 device-resident uint8 1024x1024 chips -> fused stem (/255, 7x7/2 conv, ReLU, max-pool: one kernel) -> fp16
+R-50 trunk and FPN on this repo's own MFMA convolution kernels (bias / residual / ReLU fused; MIOpen only for FPN's
+two tiny stride-2 extra levels) -> S2ANet head, every layer ONE launch for all five FPN levels (pyramid-packed):
+fused anchor refine, AlignConv (anchors -> sampling -> 3x3 contraction on the matrix cores), cached ARF expansion +
+ORConv with the rotation-invariant pooling in its epilogue, batched top-k / decode, segmented on-device rotated
+ml-NMS -> padded detections [8,2000,6] + labels + counts on the device.  With N > 1 every rank runs its own 8 chips
+(weak scaling: BASELINE.json configs[3] = batch 64 over 8 GPUs) and the step ends with ONE RCCL all-gather of the
+padded detections.
 
 Prints ONE JSON line (rank 0).  `value` = chips/s over all ranks, inputs resident in HBM.
-`roofline` = the dominant hand-written kernel (AlignConv at the P3 level of the same batch)
-timed live with HIP events on the stream it is launched on; `cpu_baseline` = the same
-pipeline for ONE chip on the host cores (torch CPU convolutions + the oracle's AlignConv +
-the reference's own CPU ml_nms_rotated when oracle/_ref is present).
+`roofline` = the dominant hand-written kernel — the pyramid-packed AlignConv launch of the same batch, exactly as
+the step issues it — timed live with HIP events on the stream it is launched on; `roofline.traffic` comes from the
+recorded rocprofv3 PMC passes over this command (profiles/rNN_traffic.json, written by scripts/pmc_bench.sh) and is
+null + `traffic_stale` when the kernel sources changed since.  `cpu_baseline` = the same pipeline for a few chips
+on the host cores (oracle/pipeline.py: torch CPU convolutions + the oracle's AlignConv / ARF / pooling / decode +
+the reference's own CPU ml_nms_rotated when oracle/_ref is present), with the per-stage seconds as fields.
 """
 import argparse
 import json
@@ -37,11 +44,39 @@ NUM_CLASSES = 15
 PEAK_F16_TFLOPS = 2500.0   # dense MFMA f16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-# HBM bytes of ONE pyramid-packed AlignConv launch (f16, batch 8), from rocprofv3 PMC passes over this
-# command (scripts/pmc_bench.sh -> profiles/r01_alignconv_pyramid_pmc.txt): 2 x FETCH_SIZE + WRITE_SIZE
-ALIGN_PYRAMID_TRAFFIC = 256.2e6
-# same for ONE pyramid-packed tower-conv launch (profiles/r01_conv_tower_hbm_pmc.txt): 2 x FETCH_SIZE + the output
-TOWER_PYRAMID_TRAFFIC = 210.0e6
+
+
+def traffic_json():
+    """newest profiles/rNN_traffic.json (one per round, written by scripts/pmc_bench.sh on the GPU box)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    return found[-1] if found else None
+
+
+def _sha16(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        with open(os.path.join(ROOT, p), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(key, batch, pixels):
+    """HBM bytes per launch of a kernel as the rocprofv3 PMC passes over this very command recorded them
+    (scripts/pmc_bench.sh -> scripts/pmc_summary.py --json -> profiles/rNN_traffic.json: 2 x FETCH_SIZE as the gfx950
+    correction prescribes + WRITE_SIZE, averaged over the kernel's dispatches).  A record is only valid for the
+    kernel sources and launch shape it was taken on: otherwise (None, True) = unknown and stale."""
+    try:
+        with open(traffic_json()) as f:
+            rec = json.load(f)["kernels"][key]
+        if rec.get("batch") != batch or rec.get("pixels") != pixels:
+            return None, True
+        if rec.get("source_sha16") != _sha16(rec["sources"]):
+            return None, True
+        return float(rec["bytes"]), False
+    except (OSError, KeyError, ValueError, TypeError):          # no record (TypeError: no file at all)
+        return None, True
 
 
 def parse():
@@ -148,17 +183,15 @@ def measure_alignconv(model, batch, dtype, cap, iters=100):
     alg_bytes = npos * C * es + npos * O * es + O * C * 9 * es + npos * 5 * 4   # in + out + weight + anchors
     peak = PEAK_F16_TFLOPS if dtype == torch.float16 else PEAK_F32_TFLOPS
     ach = flops / sec / 1e12
-    # HBM traffic per launch: rocprofv3 PMC passes over this very command (FETCH_SIZE x2 as the gfx950
-    # correction prescribes + WRITE_SIZE, averaged over the k_dcn_patch launches; profiles/r01_alignconv_pyramid_pmc.txt)
-    # -- a recorded measurement, not collected live; valid for the default f16 batch-8 pyramid launch only
-    traffic = ALIGN_PYRAMID_TRAFFIC if (cap is not None and es == 2 and batch == 8 and npos == 8 * 21824) else None
+    # HBM traffic per launch: a recorded measurement (PMC passes cannot run inside this process), see recorded_traffic
+    traffic, stale = recorded_traffic("align_conv_pyramid", batch, npos) if (cap is not None and es == 2) else (None, True)
     return {
         "kernel": "%s (fused AlignConv: anchors -> sampling -> 3x3 contraction -> ReLU; %s, batch %d, %s)"
                   % (kname, shape, batch, "f16" if es == 2 else "f32"),
         "timing": "%d back-to-back launches of the step's own launch on one stream, alone on the GPU (HIP events); inside "
                   "the timed region the kernels of the batches in flight overlap and each takes longer" % iters,
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(ach / peak, 4), "traffic": traffic,
+        "frac": round(ach / peak, 4), "traffic": traffic, "traffic_stale": stale,
         "avg_launch_us": round(sec * 1e6, 1),
         "flops_per_launch": flops,
         "hbm_algorithmic_bytes_per_launch": alg_bytes,
@@ -176,25 +209,24 @@ def measure_conv_tower(model, cap, iters=100):
     sec = _time_launches(lambda: P.conv3x3(layout, x, w, b, o, relu=True), iters)
     flops = 2.0 * 256 * 2304 * layout.pixels
     ach = flops / sec / 1e12
+    traffic, stale = recorded_traffic("conv_tower_pyramid", layout.batch, layout.pixels)
     return {"kernel": "k_conv_f16<9,4,2> (head conv tower 3x3 256->256 + bias + ReLU; five FPN levels pyramid-packed, "
                       "%d positions, f16)" % layout.pixels,
             "timing": "%d back-to-back launches of the step's own launch, alone on the GPU" % iters,
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F16_TFLOPS, 4),
-            "traffic": TOWER_PYRAMID_TRAFFIC if layout.pixels == 8 * 21824 else None,
+            "traffic": traffic, "traffic_stale": stale,
             "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops,
             "hbm_algorithmic_bytes_per_launch": int(layout.pixels * 512 * 2 + 256 * 2304 * 2)}
 
 
 def cpu_baseline(seed, candidates, chips=3):
-    """`chips` chips (one after the other, ~10-15 s) through the same pipeline on the host cores (fp32): torch CPU convolutions for the
-    carrier and the plain conv layers of the head, the oracle for AlignConv / ARF / pooling /
-    decode, and the reference's own CPU ml_nms_rotated (oracle/_ref) when it is present."""
-    import numpy as np
+    """`chips` chips (one after the other, ~10-15 s) through the same pipeline on the host cores (fp32):
+    oracle/pipeline.py = torch CPU convolutions for the carrier and the plain conv layers of the head, the oracle
+    for AlignConv / ARF / pooling / decode, and the reference's own CPU ml_nms_rotated (oracle/_ref) when present."""
     import oracle
-    from oracle import ref
+    from oracle import pipeline, ref
     from s2anet_amd.detector import S2ANet
-    import torch.nn.functional as F
     torch.manual_seed(seed)
     m = S2ANet(num_classes=NUM_CLASSES).eval()
     for mod in m.modules():
@@ -209,109 +241,180 @@ def cpu_baseline(seed, candidates, chips=3):
     except OSError:
         pass
     ref_nms = ref.ml_nms_rotated()
-    h = m.head
-    t0 = time.time()
+    kind = "reference" if ref_nms is not None else "port"
+    timers = {"oracle_ops_s": 0.0}
+    t0 = time.perf_counter()
     t_nms, n_cand, n_keep = 0.0, 0, 0
     for ci in range(chips):
-      img = imgs[ci:ci + 1]
-      with torch.no_grad():
-          feats = m.neck(m.backbone(img.float() / 255.0))
-          sc_l, de_l, an_l = [], [], []
-          for x, s in zip(feats, m.stride):
-              fam_bbox = h.fam_reg_head(h.fam_reg_ls(x))
-              h.fam_cls_head(h.fam_cls_ls(x))
-              H, W = x.shape[-2:]
-              anchors = oracle.grid_anchors(H, W, s)
-              refined = oracle.delta2bbox_rotated(anchors, fam_bbox[0].permute(1, 2, 0).reshape(-1, 5).numpy(), 1e-6)
-              off = oracle.align_offsets(refined, H, W, s)[None]
-              al = oracle.deform_conv_forward(x.numpy(), off, h.align_conv.deform_conv.weight.numpy(), relu=True)
-              arf = torch.from_numpy(oracle.arf_forward(h.or_conv.weight.numpy(), h.or_conv.indices.numpy()))
-              or_feat = F.conv2d(torch.from_numpy(al), arf, h.or_conv.bias, padding=1)
-              pooled = torch.from_numpy(oracle.rot_inv_pool(or_feat.numpy(), 8))
-              cls = h.odm_cls_head(h.odm_cls_ls(pooled))
-              reg = h.odm_reg_head(h.odm_reg_ls(or_feat))
-              sc = cls[0].permute(1, 2, 0).reshape(-1, NUM_CLASSES).sigmoid()
-              de = reg[0].permute(1, 2, 0).reshape(-1, 5)
-              an = torch.from_numpy(refined)
-              if sc.shape[0] > 2000:
-                  top = sc.max(1)[0].topk(2000)[1]
-                  sc, de, an = sc[top], de[top], an[top]
-              sc_l.append(sc), de_l.append(de), an_l.append(an)
-          scores, deltas, anc = torch.cat(sc_l), torch.cat(de_l), torch.cat(an_l)
-          # same candidate load as the GPU run: threshold at the quantile that yields `candidates`
-          k = min(candidates, scores.numel() - 1)
-          thr = torch.topk(scores.reshape(-1), k + 1)[0][-1].item()
-          boxes = oracle.delta2bbox_rotated(anc.numpy(), deltas.numpy())
-          mask = scores > thr
-          idx = mask.nonzero()
-          cb = torch.from_numpy(boxes)[idx[:, 0]].contiguous()
-          cs = scores[mask].contiguous()
-          cl = idx[:, 1].float().contiguous()
-          t_nms0 = time.time()
-          if ref_nms is not None:
-              keep = ref_nms(cb, cs, cl, 0.5)
-              kind = "reference"
-          else:
-              keep = oracle.ml_nms_rotated(cb.numpy(), cs.numpy(), cl.numpy(), 0.5, rule=oracle.RULE_GE,
-                                           sort_mode=oracle.SORT_CPU)
-              kind = "port"
-          t_nms += time.time() - t_nms0
-          n_cand += int(cb.shape[0]); n_keep += len(keep)
-    sec = time.time() - t0
+        _, levels = pipeline.forward_chip(m, imgs[ci:ci + 1], timers=timers)
+        tp = time.perf_counter()
+        scores, deltas, anc, _, _ = pipeline.select_candidates(levels, 2000)
+        # same candidate load as the GPU run: threshold at the quantile that yields `candidates`
+        sc = torch.from_numpy(scores)
+        k = min(candidates, sc.numel() - 1)
+        thr = torch.topk(sc.reshape(-1), k + 1)[0][-1].item()
+        boxes = oracle.delta2bbox_rotated(anc, deltas)
+        mask = sc > thr
+        idx = mask.nonzero()
+        cb = torch.from_numpy(boxes)[idx[:, 0]].contiguous()
+        cs = sc[mask].contiguous()
+        cl = idx[:, 1].float().contiguous()
+        timers["oracle_ops_s"] += time.perf_counter() - tp
+        t_nms0 = time.perf_counter()
+        if ref_nms is not None:
+            keep = ref_nms(cb, cs, cl, 0.5)
+        else:
+            keep = oracle.ml_nms_rotated(cb.numpy(), cs.numpy(), cl.numpy(), 0.5, rule=oracle.RULE_GE,
+                                         sort_mode=oracle.SORT_CPU)
+        t_nms += time.perf_counter() - t_nms0
+        n_cand += int(cb.shape[0]); n_keep += len(keep)
+    sec = time.perf_counter() - t0
     return {
         "value": round(chips / sec, 4), "unit": "chips/s", "cores": ncores, "kind": kind,
-        "sample": "%d chips 1024x1024 one after the other, fp32, %d NMS candidates per chip: torch-CPU convolutions + "
-                  "oracle AlignConv/ARF/pooling/decode (OpenMP) + %s ml_nms_rotated (1 thread, %.2f s of %.2f s); kept %d per chip"
-                  % (chips, n_cand // chips, "reference CPU" if kind == "reference" else "oracle", t_nms, sec, n_keep // chips),
+        "sample": "%d chips 1024x1024 one after the other, fp32, %d NMS candidates per chip, kept %d per chip: torch-CPU "
+                  "convolutions (%d threads) + oracle AlignConv/ARF/pooling/decode (OpenMP, %d threads) + %s ml_nms_rotated "
+                  "(1 thread: the reference's CPU op is serial)"
+                  % (chips, n_cand // chips, n_keep // chips, ncores, ncores, "reference CPU" if kind == "reference" else "oracle"),
+        "chips": chips, "total_s": round(sec, 3),
+        "conv_s": round(sec - timers["oracle_ops_s"] - t_nms, 3), "conv_threads": ncores,
+        "oracle_ops_s": round(timers["oracle_ops_s"], 3), "oracle_ops_threads": ncores,
+        "nms_s": round(t_nms, 3), "nms_threads": 1, "nms_candidates_per_chip": n_cand // chips,
     }
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(n):
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, exactly what torch.distributed.run would set) and relay rank 0's stdout.  Nothing
+    in THIS process has touched the GPU (importing torch does not), and the children are started, never exec'ed
+    into.  Returns the exit code: non-zero if any rank failed (the others are then stopped by their PIDs)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode("utf-8", "replace"))
+            sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for o in sorted(live):
+                    procs[o].terminate()
+        time.sleep(0.05)
+    th.join(timeout=10)
+    return rc
+
+
+class StubDetector:
+    """S2A_BENCH_STUB=1 (tests/test_bench_launcher.py): stands in for the detector so that the launcher, the
+    process-group bring-up, the step loop, the DetectionGather slots and the JSON line run on a box without a GPU
+    (gloo, CPU tensors).  Its output is a fixed function of the rank; the line it produces is marked "stub"."""
+
+    class _Head:
+        max_per_img = 50
+
+    def __init__(self, rank, batch, device):
+        self.head = self._Head()
+        g = torch.Generator().manual_seed(100 + rank)
+        K = self.head.max_per_img
+        self.counts = torch.randint(0, K + 1, (batch,), generator=g, dtype=torch.int32).to(device)
+        self.dets = torch.rand(batch, K, 6, generator=g).to(device)
+        self.labels = torch.randint(0, NUM_CLASSES, (batch, K), generator=g, dtype=torch.int32).to(device)
+        for b in range(batch):
+            self.dets[b, self.counts[b]:] = 0
+            self.labels[b, self.counts[b]:] = -1
+        self.ovf = torch.zeros(2, dtype=torch.int64, device=device)
+
+    def detect(self, imgs, max_candidates=None, return_overflow=False):
+        return (self.dets, self.labels, self.counts, self.ovf) if return_overflow else (self.dets, self.labels, self.counts)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    ndev = torch.cuda.device_count()
-    local_rank = local_rank % max(ndev, 1)     # rehearsal on a 1-GPU box: all ranks share cuda:0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    assert args.gpus == world, "--gpus must equal the number of launched ranks (WORLD_SIZE=%d)" % world
+    stub = bool(os.environ.get("S2A_BENCH_STUB"))
+    if stub:
+        if os.environ.get("S2A_BENCH_STUB_FAIL_RANK") == str(rank):     # launcher test: a rank that dies at start-up
+            sys.exit(3)
+        dev = torch.device("cpu")
+        args.streams, args.graph = 1, False
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)     # rehearsal on a 1-GPU box: all ranks share cuda:0
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # nccl == RCCL on ROCm.  S2A_BENCH_BACKEND=gloo is only for rehearsing the multi-rank code
         # path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device).
-        backend = os.environ.get("S2A_BENCH_BACKEND", "nccl")
+        backend = os.environ.get("S2A_BENCH_BACKEND", "gloo" if stub else "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert args.gpus == world, "--gpus must equal the number of launched ranks"
 
-    from s2anet_amd.detector import build_synthetic_detector
     from s2anet_amd.gather import DetectionGather
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
-    torch.backends.cudnn.benchmark = True
-    model = build_synthetic_detector(num_classes=NUM_CLASSES, seed=1234, dtype=dtype, device=dev,
-                                     compute_fam_cls=not args.no_fam_cls)
+    if os.environ.get("S2A_BENCH_CUDNN_BENCHMARK"):     # A/B only: MIOpen's exhaustive find for the two library layers
+        torch.backends.cudnn.benchmark = True
     B = args.batch
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    imgs = torch.randint(0, 256, (B, 3, CHIP, CHIP), dtype=torch.uint8, generator=g).to(dev)
-    imgs = imgs.contiguous(memory_format=torch.channels_last)
-    got = calibrate_cls_bias(model, imgs, args.candidates)
+    if stub:
+        model, imgs, got = StubDetector(rank, B, dev), None, 0.0
+    else:
+        from s2anet_amd.detector import build_synthetic_detector
+        model = build_synthetic_detector(num_classes=NUM_CLASSES, seed=1234, dtype=dtype, device=dev,
+                                         compute_fam_cls=not args.no_fam_cls)
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        imgs = torch.randint(0, 256, (B, 3, CHIP, CHIP), dtype=torch.uint8, generator=g).to(dev)
+        imgs = imgs.contiguous(memory_format=torch.channels_last)
+        got = calibrate_cls_bias(model, imgs, args.candidates)
     max_cand = int(min(B * 5344 * NUM_CLASSES, max(4 * args.candidates * B, 65536)))
-    # one gather object (output buffer) per batch in flight
-    gathers = [DetectionGather(world, B, model.head.max_per_img, dev) for _ in range(max(args.streams, 1))] if world > 1 else None
+    nslots = max(args.streams, 1)
+    # one gather object (output buffer) and one overflow accumulator per batch in flight
+    gathers = [DetectionGather(world, B, model.head.max_per_img, dev) for _ in range(nslots)] if world > 1 else None
+    dropped = [torch.zeros((), dtype=torch.int64, device=dev) for _ in range(nslots)]
     slot = [0]
 
     def step():
-        dets, labels, counts = model.detect(imgs, max_candidates=max_cand)
+        dets, labels, counts, ovf = model.detect(imgs, max_candidates=max_cand, return_overflow=True)
+        dropped[slot[0] % nslots].add_(ovf[1])     # candidates the static cap cut (must stay 0); same stream, no sync
         if gathers is not None:
-            return gathers[slot[0] % len(gathers)](dets, labels, counts)
+            return gathers[slot[0] % nslots](dets, labels, counts)
         return dets, labels, counts
 
     for _ in range(max(args.warmup, 1)):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     runner = step
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     if streams:
@@ -320,7 +423,7 @@ def main():
             with torch.cuda.stream(st):
                 for _ in range(2):
                     out = step()
-        torch.cuda.synchronize()
+        sync()
         turn = [0]
 
         def runner():
@@ -334,10 +437,10 @@ def main():
             out = step()
         runner = graph.replay
         runner()
-        torch.cuda.synchronize()
+        sync()
     elif args.graph:
         # one captured graph per stream (own workspaces / gather slot), replayed round-robin: the host issues one
-        # launch per batch instead of ~175
+        # launch per batch instead of ~140
         graphs = []
         for k, st in enumerate(streams):
             slot[0] = k
@@ -345,7 +448,7 @@ def main():
             with torch.cuda.graph(g_, stream=st):
                 out = step()
             graphs.append(g_)
-        torch.cuda.synchronize()
+        sync()
         gturn = [0]
 
         def runner():
@@ -355,23 +458,27 @@ def main():
             gturn[0] += 1
         for _ in range(len(streams)):
             runner()
-        torch.cuda.synchronize()
+        sync()
 
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    # outside the timed region: the static candidate cap must not have cut a single row in any step (the reference
+    # never drops a candidate, utils/bbox_nms_rotated.py:29-40) -- one host read
+    n_dropped = int(sum(int(d.item()) for d in dropped))
+    assert n_dropped == 0, "max_candidates=%d dropped %d NMS candidates: raise the cap" % (max_cand, n_dropped)
 
     counts = out[2].reshape(-1)
     result = {
@@ -390,16 +497,26 @@ def main():
             "chips_per_gpu_per_step": B, "global_batch": world * B, "num_classes": NUM_CLASSES,
             "weights": "seeded random init of the reference architecture; odm_cls bias calibrated",
             "nms_candidates_per_chip": round(got, 1), "detections_per_chip": round(counts.float().mean().item(), 1),
+            "nms_candidate_cap": max_cand, "nms_candidates_dropped": n_dropped,
             "fam_cls_branch": not args.no_fam_cls, "hip_graph": bool(args.graph), "batches_in_flight": args.streams,
             "parallelism": "dp%d (one process per GPU)" % world,
         },
     }
+    if stub:
+        # the gathered batch must be the rank-major concatenation of what every rank's stub produced
+        exp = [StubDetector(r, B, dev) for r in range(world)]
+        ok = (torch.equal(out[0], torch.cat([e.dets for e in exp])) and torch.equal(out[1], torch.cat([e.labels for e in exp]))
+              and torch.equal(out[2], torch.cat([e.counts for e in exp])))
+        result["stub"] = True
+        result["gather_equals_concatenation"] = bool(ok)
+        result["data"] = "stub detector (launcher / gather rehearsal, not a measurement)"
     if rank == 0:
-        cap = capture_head_operands(model, imgs)
-        result["roofline"] = measure_alignconv(model, B, dtype, cap)
-        if cap is not None:
-            result["roofline_conv_tower"] = measure_conv_tower(model, cap)
-        if world == 1 and not args.no_cpu_baseline:
+        if not stub:
+            cap = capture_head_operands(model, imgs)
+            result["roofline"] = measure_alignconv(model, B, dtype, cap)
+            if cap is not None:
+                result["roofline_conv_tower"] = measure_conv_tower(model, cap)
+        if world == 1 and not args.no_cpu_baseline and not stub:
             try:
                 result["cpu_baseline"] = cpu_baseline(1234, args.candidates)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number

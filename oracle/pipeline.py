@@ -1,0 +1,129 @@
+"""CPU restatement of BASELINE configs[2] for ONE chip: R-50-FPN S2ANet inference, image -> detections.
+
+TEST INFRASTRUCTURE (same rule as the rest of ``oracle/``): imported only by ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py:cpu_baseline``.  The product path never comes here.
+
+What it follows (reference file:line):
+  * models/detector.py:28-37     backbone -> FPN -> head (the carrier's stock convolutions run as torch CPU convs)
+  * models/head.py:296-348       forward_single: FAM towers -> fam_bbox_decode -> AlignConv -> ORConv ->
+                                 RotationInvariantPooling -> ODM towers / heads
+  * models/head.py:27-52         fam_bbox_decode (wh_ratio_clip 1e-6)            -> oracle.delta2bbox_rotated
+  * models/alignconv.py:30-98    get_offset + DeformConv + ReLU                   -> oracle.align_offsets / deform_conv_forward
+  * models/orn/modules/ORConv.py:77-82, functions/rotation_invariant_pooling.py:19-27 -> oracle.arf_forward / rot_inv_pool
+  * models/head.py:684-725       get_bboxes_single_img: sigmoid, max over classes, topk(2000) where H*W > 2000,
+                                 concatenate levels, rboxes_decode, multiclass_nms_rotated
+  * utils/bbox_nms_rotated.py:5-64 multiclass_nms_rotated                          -> oracle.multiclass_nms_rotated
+
+``model`` is an (unfused, CPU, float32) ``s2anet_amd.detector.S2ANet``: that class only supplies the layer
+structure and the parameters (names as the reference's); every op with the reference's own arithmetic is the oracle's.
+"""
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import oracle
+
+
+def head_level(h, x, stride, with_fam_cls=True, timers=None):
+    """forward_single (models/head.py:296-348) for one image and one level, float32 on the CPU.
+    x[1,256,H,W] -> dict(refined[H*W,5], align[1,256,H,W], or_feat, pooled, cls_feat, cls[H*W,C] logits, reg[H*W,5]).
+    timers: dict; 'oracle_ops_s' accumulates the seconds spent in the oracle's ops (AlignConv, ARF, pooling, decode)"""
+    H, W = x.shape[-2:]
+    fam_bbox = h.fam_reg_head(h.fam_reg_ls(x))
+    if with_fam_cls:
+        h.fam_cls_head(h.fam_cls_ls(x))                       # evaluated and discarded at inference (head.py:306)
+    t0 = time.perf_counter()
+    anchors = oracle.grid_anchors(H, W, stride)
+    refined = oracle.delta2bbox_rotated(anchors, fam_bbox[0].permute(1, 2, 0).reshape(-1, 5).numpy(), 1e-6)
+    off = oracle.align_offsets(refined, H, W, stride)[None]
+    al = oracle.deform_conv_forward(x.numpy(), off, h.align_conv.deform_conv.weight.numpy(), relu=True)
+    arf = torch.from_numpy(oracle.arf_forward(h.or_conv.weight.numpy(), h.or_conv.indices.numpy()))
+    t1 = time.perf_counter()
+    or_feat = F.conv2d(torch.from_numpy(al), arf, h.or_conv.bias, padding=1)
+    t2 = time.perf_counter()
+    pooled = torch.from_numpy(oracle.rot_inv_pool(or_feat.numpy(), 8))
+    if timers is not None:
+        timers["oracle_ops_s"] = timers.get("oracle_ops_s", 0.0) + (t1 - t0) + (time.perf_counter() - t2)
+    cls_feat = h.odm_cls_ls(pooled)
+    cls = h.odm_cls_head(cls_feat)
+    reg = h.odm_reg_head(h.odm_reg_ls(or_feat))
+    C = cls.shape[1]
+    return dict(size=(H, W), stride=stride, refined=refined, fam_bbox=fam_bbox, align=al, or_feat=or_feat, pooled=pooled,
+                cls_feat=cls_feat, cls=cls[0].permute(1, 2, 0).reshape(-1, C).numpy().copy(),
+                reg=reg[0].permute(1, 2, 0).reshape(-1, 5).numpy().copy())
+
+
+@torch.no_grad()
+def forward_chip(model, img_u8, with_fam_cls=True, timers=None):
+    """img_u8[1,3,H,W] uint8 -> (feats: the five FPN maps, levels: head_level dicts).  /255 as val.py:246-247"""
+    assert img_u8.dtype == torch.uint8 and img_u8.shape[0] == 1
+    feats = model.neck(model.backbone(img_u8.float() / 255.0))
+    return feats, [head_level(model.head, x, s, with_fam_cls, timers) for x, s in zip(feats, model.stride)]
+
+
+def sigmoid_f32(x):
+    x = np.asarray(x, np.float32)
+    return (np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32)
+
+
+def select_candidates(levels, k=2000, half_scores=False):
+    """head.py:697-714: per level sigmoid -> max over classes -> top-k where H*W > k; levels concatenated.
+    Rows of a top-k'd level are listed by ascending position (the GPU path's order; the reference lists them by
+    descending score — the order does not change the NMS result for distinct scores); ties at the k-th place take
+    the lowest positions.  half_scores: sigmoid rounded to f16 (the reference's .half() model, val.py:126).
+    -> scores[n,C], deltas[n,5], anchors[n,5], rows[n] (position inside the level), level_of[n]"""
+    sc_l, de_l, an_l, rows_l, lev_l = [], [], [], [], []
+    for li, lv in enumerate(levels):
+        sc = sigmoid_f32(lv["cls"])
+        if half_scores:
+            sc = sc.astype(np.float16).astype(np.float32)
+        n = sc.shape[0]
+        rows = np.arange(n)
+        if k > 0 and n > k:
+            key = lv["cls"].max(1) if half_scores else sc.max(1)     # the half path selects on the logits (monotonic)
+            rows = np.sort(np.argsort(-key, kind="stable")[:k])
+        sc_l.append(sc[rows]), de_l.append(lv["reg"][rows]), an_l.append(lv["refined"][rows])
+        rows_l.append(rows), lev_l.append(np.full(rows.shape, li))
+    return (np.concatenate(sc_l), np.concatenate(de_l).astype(np.float32), np.concatenate(an_l).astype(np.float32),
+            np.concatenate(rows_l), np.concatenate(lev_l))
+
+
+def postprocess(levels, k=2000, score_thr=0.05, iou_thr=0.5, max_per_img=2000, rule=oracle.RULE_GT,
+                sort_mode=oracle.SORT_GPU, half_scores=False):
+    """get_bboxes_single_img (head.py:684-725) -> (dets[K,6], labels[K] float32, bboxes[n,5], scores[n,C])"""
+    scores, deltas, anc, _, _ = select_candidates(levels, k, half_scores)
+    bboxes = oracle.delta2bbox_rotated(anc, deltas)
+    dets, labels = oracle.multiclass_nms_rotated(bboxes, scores, score_thr, iou_thr, max_per_img, rule=rule,
+                                                 sort_mode=sort_mode)
+    return dets, labels, bboxes, scores
+
+
+@torch.no_grad()
+def calibrate_classifier(model, levels, target_candidates, logit_std=1.5, k=2000, score_thr=0.05, slack=200):
+    """Random N(0,0.01) weights give score 0.01 everywhere (bias init -4.595, head.py:232) and no detection.
+    Scale odm_cls_head.weight so the logits spread with std `logit_std`, shift the bias so that about
+    `target_candidates` (box, class) scores of the selected rows exceed `score_thr`; recompute levels[*]['cls'].
+    Deterministic (CPU only); the caller copies the two parameters to the model under test."""
+    head = model.head.odm_cls_head
+    raw = np.concatenate([lv["cls"].reshape(-1) for lv in levels])
+    head.weight.mul_(float(logit_std / max(raw.std(), 1e-6)))
+
+    def recompute():
+        for lv in levels:
+            c = head(lv["cls_feat"])
+            lv["cls"] = c[0].permute(1, 2, 0).reshape(-1, c.shape[1]).numpy().copy()
+    recompute()
+    scores = select_candidates(levels, k)[0]
+    logits = np.log(scores / (1 - scores)).reshape(-1)
+    srt = np.sort(logits)[::-1]
+    kk = int(min(max(target_candidates, 1), logits.size - 1))
+    # the threshold goes into the WIDEST gap between consecutive logits within `slack` ranks of the target, halfway: the
+    # float noise of another implementation of the same network then cannot move a score across it
+    lo, hi = max(kk - slack, 1), min(kk + slack, logits.size - 1)
+    kk = lo + int(np.argmax(srt[lo - 1:hi - 1] - srt[lo:hi]))
+    q = 0.5 * (float(srt[kk - 1]) + float(srt[kk]))
+    head.bias.add_(float(np.log(score_thr / (1 - score_thr)) - q))
+    recompute()
+    return int((select_candidates(levels, k)[0] > score_thr).sum())

@@ -230,17 +230,20 @@ class S2ANet(nn.Module):
         return tuple(map(list, zip(*per_level)))
 
     @torch.no_grad()
-    def detect(self, imgs_u8, max_candidates=None):
+    def detect(self, imgs_u8, max_candidates=None, return_overflow=False):
         """device-resident uint8 batch [B,3,H,W] -> (dets[B,2000,6], labels[B,2000], counts[B]).
-        /255 normalisation as val.py:246-247; no host synchronisation anywhere."""
+        /255 normalisation as val.py:246-247; no host synchronisation anywhere.
+        max_candidates caps the (box, class) rows the batch's NMS considers (static shapes); the reference never
+        drops one, so with return_overflow=True a fourth result int64[2] = [candidates found, candidates dropped]
+        comes back on the device (dropped must be 0 for reference-equal results)."""
         if self.backbone.stem_fusable(imgs_u8):
             return self.head.get_bboxes_batched(
-                self.features_to_pred(imgs_u8, self.backbone.forward_u8(imgs_u8, 255.0)), max_candidates)
+                self.features_to_pred(imgs_u8, self.backbone.forward_u8(imgs_u8, 255.0)), max_candidates, return_overflow)
         dt = next(self.parameters()).dtype
         x = imgs_u8.to(dt).div_(255.0)
         if imgs_u8.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        return self.head.get_bboxes_batched(self.features_to_pred(x), max_candidates)
+        return self.head.get_bboxes_batched(self.features_to_pred(x), max_candidates, return_overflow)
 
 
 def load_reference_checkpoint(model, weights, map_location="cpu"):

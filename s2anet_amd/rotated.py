@@ -185,7 +185,7 @@ def multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, max_per_
 
 
 def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, max_per_img=2000,
-                                   max_candidates=None):
+                                   max_candidates=None, return_overflow=False):
     """Whole-batch multiclass rotated NMS with NO host synchronisation.
 
     bboxes[B,n,5] f32, scores[B,n,C] -> dets[B,max_per_img,6] (x,y,w,h,a,score; zero padded),
@@ -195,7 +195,11 @@ def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, 
     listed by descending score and truncated to max_per_img.
 
     Static shapes: at most ``max_candidates`` (default n*C, i.e. lossless) candidates per
-    batch are considered; the candidate list is compacted on the device.
+    batch are considered; the candidate list is compacted on the device.  The reference never
+    drops a candidate (utils/bbox_nms_rotated.py:29-40), so a cap that is too small must not pass
+    silently: ``return_overflow=True`` adds a fourth result ``overflow`` = int64[2] on the device,
+    ``[candidates found, candidates dropped]`` (dropped > 0 <=> the cap cut rows; still no host sync —
+    the caller reads it when it synchronises anyway).
     """
     _lib.require_cuda(bboxes, scores)
     B, n, C = scores.shape
@@ -230,4 +234,6 @@ def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, 
     dets = torch.cat([cboxes[kidx], cscores[kidx][..., None]], dim=-1)
     dets = torch.where(ok[..., None], dets, torch.zeros_like(dets))
     labels = torch.where(ok, cls[kidx], torch.full_like(keep, -1))
+    if return_overflow:
+        return dets, labels, counts, torch.cat([ncand, (ncand - cap).clamp_(min=0)])
     return dets, labels, counts

@@ -948,16 +948,20 @@ def test_pyramid_alignconv_and_refine(rng):
         ref = align_conv_forward(xl, a_ref, w, st, relu=True)
         got = layout.level(out, l)
         assert (got.float() - ref.float()).abs().max().item() < 3e-2
-    # smallest level against the CPU oracle (f32 math on the same f16 inputs)
-    l = 4
-    H, W = layout.sizes[l]
-    a = layout.rows(anchors, l).view(layout.batch, H * W, 5).cpu().numpy()
-    xl = layout.level(x, l).float().cpu().numpy()
-    for bi in range(layout.batch):
-        off = oracle.align_offsets(a[bi], H, W, layout.strides[l])
-        ref = oracle.deform_conv_forward(np.ascontiguousarray(xl[bi:bi + 1]), off[None], w.float().cpu().numpy(), relu=True)
-        got = layout.level(out, l)[bi:bi + 1].float().cpu().numpy()
-        assert np.abs(got - ref).max() < 3e-2
+    # the packed launch against the CPU oracle (f16-rounded columns, f32 sums, on the same f16 inputs): the two LARGE
+    # levels (the ones the benchmark's time goes to: many tiles per image, tiles that straddle the image border) and
+    # the smallest one (a single partial tile)
+    wf = w.float().cpu().numpy()
+    for l in (0, 1, 4):
+        H, W = layout.sizes[l]
+        a = layout.rows(anchors, l).view(layout.batch, H * W, 5).cpu().numpy()
+        xl = layout.level(x, l).float().cpu().numpy()
+        for bi in range(layout.batch):
+            off = oracle.align_offsets(a[bi], H, W, layout.strides[l])
+            ref = oracle.deform_conv_forward(np.ascontiguousarray(xl[bi:bi + 1]), off[None], wf, f16_cols=True, relu=True)
+            got = layout.level(out, l)[bi:bi + 1].float().cpu().numpy()
+            err = np.abs(got - ref)
+            assert err.max() < 2e-2 and err.mean() < 2e-3, (l, bi, err.max(), err.mean())
 
 
 def test_pyramid_alignconv_persistent_matches_plain(monkeypatch):
