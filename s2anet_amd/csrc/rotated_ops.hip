@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -117,6 +118,7 @@ constexpr int kIouQueue = 1024;      // LDS pair queue (survivors of BOTH tests)
 constexpr int kIouQ1 = 3072;         // first-stage queue: circle-test survivors, (row << 10 | column) per entry
 constexpr int kIouQ1DrainAt = 1024;  // <= 2048 pushes per two rows on top of this
 
+template <bool STORE>
 __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict__ P1,
                                                        const PreBox* __restrict__ P2,
                                                        int64_t row0, int64_t row1, int64_t m,
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
     const float ax = Ai.x, ay = Ai.y, ar = Ai.r;
     if (r + 1 < nrows) Ai = s_rows[r + 1];   // next row's box while this one is processed
     const int64_t i = rbeg + r;
+    (void)i; (void)vec_ok;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (j0 + k < m && !surely_disjoint(ax, ay, ar, bx[k], by[k], br[k])) {
@@ -178,13 +181,15 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
         s_q1[p] = (unsigned short)((r << 10) | (threadIdx.x * 4 + k));
       }
     }
-    float* dst = out + i * m + j0;
-    if (vec_ok) {
-      *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
+    if (STORE) {
+      float* dst = out + i * m + j0;
+      if (vec_ok) {
+        *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (j0 + k < m) dst[k] = 0.f;
+        for (int k = 0; k < 4; k++)
+          if (j0 + k < m) dst[k] = 0.f;
+      }
     }
     if ((r & 1) == 1) {          // <= 2048 pushes per two rows: the first-stage queue cannot overflow
       if (__syncthreads_or(s_cnt1 > kIouQ1DrainAt)) drain_q1();
@@ -195,37 +200,59 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
   queue_flush(Q, gq, gcount, cap);
 }
 
-// HEAVY: dense list, one pair per lane, persistent grid
+// HEAVY: dense list, one pair per lane, persistent grid.  Values go to a compact buffer (vals[e] for pair e): this pass
+// runs while the zero-fill of the output is still in flight on the side stream, so it must not touch `out`.
 __global__ __launch_bounds__(kThreads) void k_iou_heavy(const PreBox* __restrict__ P1,
-                                                        const PreBox* __restrict__ P2,
-                                                        int64_t row0, int64_t row1, int64_t m,
-                                                        float* __restrict__ out,
+                                                        const PreBox* __restrict__ P2, int64_t row0,
                                                         const uint2* __restrict__ gq,
                                                         const unsigned long long* __restrict__ gcount,
-                                                        unsigned long long cap) {
+                                                        unsigned long long cap, float* __restrict__ vals) {
   __shared__ float2 s_pts[24 * kThreads];
-  unsigned long long total = *gcount;
-  if (total > cap) {
-    // Overflow fallback: the pair list of this chunk did not fit (extremely dense inputs).  Recompute the whole chunk
-    // pair by pair (the divergence that the list avoids is irrelevant when most pairs are heavy anyway).
-    const int64_t all = (row1 - row0) * m;
-    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < all; e += (int64_t)gridDim.x * kThreads) {
-      int64_t i = row0 + e / m, j = e % m;
-      PreBox A = P1[i], B = P2[j];
-      float v = 0.f;
-      if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B))
-        v = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
-      out[i * m + j] = v;
-    }
-    return;
-  }
+  const unsigned long long total = *gcount;
+  if (total > cap) return;       // list overflow: k_iou_scatter recomputes the chunk directly
   for (unsigned long long e = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; e < total;
        e += (unsigned long long)gridDim.x * kThreads) {
     uint2 ij = gq[e];
     PreBox A = P1[row0 + ij.x];
     PreBox B = P2[ij.y];
-    out[(row0 + ij.x) * m + ij.y] = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
+    vals[e] = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
   }
+}
+
+// after the join with the zero-fill: out[i, j] = vals[e] for the listed pairs.  Overflow fallback: the pair list of this
+// chunk did not fit (extremely dense inputs) -> recompute the whole chunk pair by pair (the divergence that the list
+// avoids is irrelevant when most pairs are heavy anyway).
+__global__ __launch_bounds__(kThreads) void k_iou_scatter(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
+                                                          int64_t row0, int64_t row1, int64_t m,
+                                                          float* __restrict__ out, const uint2* __restrict__ gq,
+                                                          const unsigned long long* __restrict__ gcount,
+                                                          unsigned long long cap, const float* __restrict__ vals) {
+  __shared__ float2 s_pts[24 * kThreads];
+  const unsigned long long total = *gcount;
+  if (total > cap) {
+    const int64_t all = (row1 - row0) * m;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < all; e += (int64_t)gridDim.x * kThreads) {
+      int64_t i = row0 + e / m, j = e % m;
+      PreBox A = P1[i], B = P2[j];
+      if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B))
+        out[i * m + j] = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
+    }
+    return;
+  }
+  for (unsigned long long e = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; e < total;
+       e += (unsigned long long)gridDim.x * kThreads) {
+    const uint2 ij = gq[e];
+    out[(row0 + ij.x) * m + ij.y] = vals[e];
+  }
+}
+
+// 16 bytes per lane, grid-stride: 7 TB/s on MI355X (profiles/r02_nms_200k_pmc_before.txt, k_zero_words)
+__global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ out, unsigned long long n) {
+  const unsigned long long n4 = n / 4, stride = (unsigned long long)gridDim.x * 256;
+  float4* o4 = reinterpret_cast<float4*>(out);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = 0.f;
 }
 
 __global__ __launch_bounds__(kThreads) void k_iou_pairs(const float* __restrict__ b1,
@@ -244,6 +271,27 @@ __global__ __launch_bounds__(kThreads) void k_iou_pairs(const float* __restrict_
 constexpr unsigned long long kIouQueueCap = 32ull << 20;  // 32 Mi pairs = 256 MiB
 
 // ================================================================= NMS
+// Pipeline of one call (all on the device, no host synchronisation):
+//   1. sort rows by (group, score desc) and then stably by segment (label / image x class)         [rocPRIM radix sorts]
+//   2. per segment: sort its rows along a Morton curve of the box centres; 64-row spatial blocks, bounding box of the
+//      (inflated) circumscribed circles of each block
+//   3. TILE FILTER: upper-triangle 64 x 64 tiles of a segment whose two block bounding boxes are apart hold only
+//      exact-zero pairs -> dropped; the others go to a tile list (boxes of a 1024^2 chip only ever overlap their spatial
+//      neighbours: 83 % of the tiles of BASELINE config 5 go away here; with all-pairs tiles in score order the cull
+//      was VALU-bound on 1.33e9 circle tests: profiles/r02_nms_200k_pmc_before.txt)
+//   4. CULL over the tile list: circle test for every pair of a tile, survivors -> LDS list -> dense second stage
+//      (separating axes + IoU upper bound, rbox_geom.hpp:nms_pair_skippable) -> pair list (score positions i < j)
+//   5. DENSE IoU pass over the pair list, all lanes busy; pairs with IoU > thr (reference GPU rule, strict) become EDGES
+//      i -> j ("i suppresses j if i is kept")
+//   6. RESOLVE the greedy order by parallel rounds over the edge list instead of a serial scan of a bitmask (which ran one
+//      workgroup per segment at 0.25 waves/CU): a row is KEPT once all its in-neighbours are removed, REMOVED once one
+//      of them is kept; every round settles at least the first unsettled row of each chain, so the result is exactly
+//      the reference's host loop (ml_nms cuda.cu:120-131); 4-6 rounds on detector-like and on random inputs; a
+//      single-workgroup kernel finishes chains that are longer than the fixed number of launched rounds
+//   7. keep flags -> compaction in score order.
+// No N x N/64 suppression mask exists any more (the reference's is 5.0 GB at 200 k rows and goes to the host; round 1
+// kept a 334 MB per-segment one on the device).  If the pair or edge list overflows (pathologically dense inputs), a
+// memory-free direct greedy kernel redoes the segments (slow, exact).
 __global__ void k_nms_keys(const float* __restrict__ scores, const int32_t* __restrict__ groups,
                            const int32_t* __restrict__ seg_ids, uint32_t num_groups, int64_t n,
                            unsigned long long* __restrict__ key1, int32_t* __restrict__ idx) {
@@ -254,6 +302,7 @@ __global__ void k_nms_keys(const float* __restrict__ scores, const int32_t* __re
   key1[i] = (g << 32) | (unsigned long long)(~float_sortable(scores[i]));
   idx[i] = (int32_t)i;
 }
+
 
 // segment key of every row, gathered into global (group, score) order.
 // labels (float, ml-NMS) -> canonical bit pattern; segment ids (int) -> the id; neither -> 0.
@@ -274,12 +323,14 @@ __global__ void k_nms_segkeys(const float* __restrict__ labels, const int32_t* _
   key2[p] = k;
 }
 
+
 __global__ void k_nms_heads(const uint32_t* __restrict__ key2s, int64_t n,
                             uint32_t* __restrict__ head) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   head[p] = (p == 0 || key2s[p] != key2s[p - 1]) ? 1u : 0u;
 }
+
 
 // seg_start[s] for every run head; the last thread publishes S and the sentinel
 __global__ void k_nms_seg_start(const uint32_t* __restrict__ head, const uint32_t* __restrict__ segidx1,
@@ -295,74 +346,6 @@ __global__ void k_nms_seg_start(const uint32_t* __restrict__ head, const uint32_
   }
 }
 
-// per segment: words of mask and number of upper-triangle tiles (0 beyond S), arrays of n+1
-__global__ void k_nms_seg_sizes(const uint32_t* __restrict__ seg_start,
-                                const uint32_t* __restrict__ num_seg,
-                                const uint32_t* __restrict__ key2s, uint32_t ignore_key,
-                                int use_ignore, int64_t n, unsigned long long* __restrict__ words,
-                                unsigned long long* __restrict__ tiles,
-                                uint32_t* __restrict__ nblk) {
-  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s > n) return;
-  unsigned long long w = 0, t = 0, nb = 0;
-  if (s < *num_seg) {
-    unsigned long long ns = seg_start[s + 1] - seg_start[s];
-    bool ignored = use_ignore && key2s[seg_start[s]] == ignore_key;
-    nb = ignored ? 0 : (ns + 63) / 64;
-    w = ns * nb;
-    t = nb * (nb + 1) / 2;
-  }
-  words[s] = w;
-  tiles[s] = t;
-  nblk[s] = (uint32_t)nb;
-}
-
-__global__ void k_nms_pos_meta(const float* __restrict__ dets5, const int32_t* __restrict__ perm_seg,
-                               const uint32_t* __restrict__ segidx1,
-                               const uint32_t* __restrict__ seg_start,
-                               const unsigned long long* __restrict__ mask_off,
-                               const uint32_t* __restrict__ nblk, int64_t n,
-                               PreBox* __restrict__ sorted, uint32_t* __restrict__ local_idx,
-                               unsigned long long* __restrict__ row_base) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  uint32_t s = segidx1[p] - 1;
-  uint32_t st = seg_start[s];
-  uint32_t nb = nblk[s];
-  uint32_t loc = (uint32_t)p - st;
-  local_idx[p] = loc;
-  row_base[p] = mask_off[s] + (unsigned long long)loc * nb;
-  const float* b = dets5 + 5 * (int64_t)perm_seg[p];
-  sorted[p] = make_prebox(b[0], b[1], b[2], b[3], b[4], (float)s);
-}
-
-__global__ void k_zero_words(unsigned long long* __restrict__ mask,
-                             const unsigned long long* __restrict__ total_ptr,
-                             unsigned long long bound) {
-  unsigned long long total = *total_ptr;
-  if (total > bound) total = bound;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (unsigned long long)gridDim.x * blockDim.x)
-    mask[i] = 0ull;
-}
-
-// Word-occupancy bitmap of the suppression mask: bit w of a row's occupancy says "mask word w of this row is
-// non-zero".  The mask of a big segment is sparse (a box overlaps few others), and the greedy scan only has to
-// OR the non-zero words of the rows it keeps -- instead of sweeping every word of every kept row from HBM.
-// Row p (sorted position) owns occupancy words [ (row_base[p] >> 6) + p, ... + ceil(B/64) ): consecutive rows
-// are floor(B/64)+1 apart, so the ranges never overlap.
-__host__ __device__ inline unsigned long long occ_words_for(unsigned long long mask_words, unsigned long long n) {
-  return mask_words / 64 + n + 64;
-}
-__global__ void k_zero_occ(unsigned long long* __restrict__ occ, const unsigned long long* __restrict__ total_ptr,
-                           unsigned long long bound, unsigned long long n) {
-  unsigned long long total = *total_ptr;
-  if (total > bound) total = bound;
-  const unsigned long long cnt = total / 64 + n + 64;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt;
-       i += (unsigned long long)gridDim.x * blockDim.x)
-    occ[i] = 0ull;
-}
 
 struct TileRef {
   uint32_t seg_start, ns, rb, cb;
@@ -371,12 +354,14 @@ struct TileRef {
 // tile id -> (segment, row block, col block >= row block)
 __device__ __forceinline__ TileRef locate_tile(unsigned long long tile,
                                                const unsigned long long* __restrict__ tile_off,
-                                               const uint32_t* __restrict__ seg_start, uint32_t S) {
+                                               const uint32_t* __restrict__ seg_start, uint32_t S,
+                                               uint32_t* seg_index = nullptr) {
   uint32_t lo = 0, hi = S;  // last s with tile_off[s] <= tile
   while (hi - lo > 1) {
     uint32_t mid = (lo + hi) >> 1;
     if (tile_off[mid] <= tile) lo = mid; else hi = mid;
   }
+  if (seg_index) *seg_index = lo;
   TileRef t;
   t.seg_start = seg_start[lo];
   t.ns = seg_start[lo + 1] - t.seg_start;
@@ -395,202 +380,6 @@ __device__ __forceinline__ TileRef locate_tile(unsigned long long tile,
   return t;
 }
 
-// CULL over upper-triangle tiles (persistent grid).  thread = (row = tid&63, 16 columns).  Every workgroup
-// walks a CONTIGUOUS run of tile ids: inside a segment consecutive ids share their row block (the 64 row boxes
-// stay in registers) and only step the column block, whose 64 boxes are fetched one tile ahead into the other
-// half of a double-buffered LDS array -- one barrier per tile and no exposed load latency (the per-tile
-// locate + two barriers + cold loads of the first version made the 200 k-row case latency-bound: 3.8 ms).
-__global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict__ sorted,
-                                                       const uint32_t* __restrict__ seg_start,
-                                                       const uint32_t* __restrict__ num_seg,
-                                                       const unsigned long long* __restrict__ tile_off,
-                                                       uint2* __restrict__ gq,
-                                                       unsigned long long* __restrict__ gcount,
-                                                       unsigned long long cap, float thr) {
-  __shared__ uint2 s_q[kLdsQueue];
-  __shared__ unsigned s_count, s_base[2], s_cnt1[2];
-  __shared__ PreBox s_col[2][64];
-  __shared__ PreBox s_row[64];                 // the row block's boxes for the dense second stage
-  __shared__ unsigned short s_q1[4096];        // circle-test survivors of the current tile: row << 6 | column
-  PairQueue Q{s_q, &s_count, s_base};
-  if (threadIdx.x == 0) { s_count = 0; s_cnt1[0] = 0; s_cnt1[1] = 0; }
-  const uint32_t S = *num_seg;
-  // few segments (the per-image x class case): the two prefix arrays the tile locate searches go to LDS once, so
-  // a locate is a handful of LDS reads instead of ~8 dependent global loads (the launch is latency-bound there)
-  __shared__ unsigned long long s_toff[512];
-  __shared__ uint32_t s_sst[512];
-  if (S < 511) {
-    for (uint32_t i = threadIdx.x; i <= S; i += kThreads) { s_toff[i] = tile_off[i]; s_sst[i] = seg_start[i]; }
-    __syncthreads();
-    tile_off = s_toff;
-    seg_start = s_sst;
-  }
-  const unsigned long long T = tile_off[S];
-  const unsigned long long chunk = (T + gridDim.x - 1) / gridDim.x;
-  unsigned long long tile = (unsigned long long)blockIdx.x * chunk;
-  const unsigned long long tend = min(T, tile + chunk);
-  const int row = threadIdx.x & 63, quarter = threadIdx.x >> 6;
-  auto col_box = [&](const TileRef& t) {
-    PreBox b = {};
-    uint32_t jl = t.cb * 64 + threadIdx.x;
-    if (jl < t.ns) b = sorted[t.seg_start + jl];
-    return b;
-  };
-  // next tile id -> its (segment, row block, column block): a step of the column block while the row of the
-  // triangle lasts, a fresh locate otherwise (new row block or new segment)
-  auto advance = [&](const TileRef& t, unsigned long long next_tile) {
-    const uint32_t Bt = (t.ns + 63) / 64;
-    if (t.cb + 1 < Bt) { TileRef n = t; n.cb = t.cb + 1; return n; }
-    return locate_tile(next_tile, tile_off, seg_start, S);
-  };
-  if (tile >= tend) { __syncthreads(); queue_flush(Q, gq, gcount, cap); return; }
-  TileRef t = locate_tile(tile, tile_off, seg_start, S);
-  if (threadIdx.x < 64) s_col[0][threadIdx.x] = col_box(t);
-  // column boxes are requested TWO tiles ahead (one tile of tests, ~1 k cycles, does not cover a global round trip:
-  // the kernel ran at ~11 k cycles per tile): nb1 = boxes of tile + 1 (already in flight), nb2 = boxes of tile + 2
-  TileRef t1 = t;
-  PreBox nb1 = {};
-  if (tile + 1 < tend) {
-    t1 = advance(t, tile + 1);
-    if (threadIdx.x < 64) nb1 = col_box(t1);
-  }
-  __syncthreads();
-  int cur = 0;
-  uint32_t a_seg = 0xffffffffu, a_rb = 0xffffffffu;
-  PreBox a = {};
-  for (; tile < tend; tile++) {
-    const bool has_next = tile + 1 < tend;
-    const TileRef tn = t1;
-    const PreBox nb = nb1;
-    if (tile + 2 < tend) {
-      t1 = advance(t1, tile + 2);
-      if (threadIdx.x < 64) nb1 = col_box(t1);         // in flight under two tiles of tests
-    }
-    const uint32_t il = t.rb * 64 + row;
-    if (a_seg != t.seg_start || a_rb != t.rb) {         // (uniform) new row block
-      a_seg = t.seg_start; a_rb = t.rb;
-      if (il < t.ns) a = sorted[t.seg_start + il];
-      if (quarter == 0) s_row[row] = a;                 // read by the dense stage (after the barrier below)
-    }
-    // Stage 1: the cheap circle test for all 16 columns of a thread; survivors go to an LDS list.
-    // Stage 2, dense: every lane takes ONE survivor and runs the separating-axis test on it.  (Run in place, a wave
-    // with any surviving lane paid for the SAT of all its lanes, max-popcount times per tile: at 200 k rows the SAT
-    // made up two thirds of the kernel's 47 VALU operations per pair.)
-    const int par = (int)(tile & 1);
-    if (il < t.ns) {
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        const int cc = quarter * 16 + c;
-        const uint32_t jl = t.cb * 64 + cc;
-        if (jl < t.ns && jl > il && !surely_disjoint(a.x, a.y, a.r, s_col[cur][cc].x, s_col[cur][cc].y, s_col[cur][cc].r)) {
-          const unsigned p = atomicAdd(&s_cnt1[par], 1u);
-          s_q1[p] = (unsigned short)((row << 6) | cc);
-        }
-      }
-    }
-    if (has_next && threadIdx.x < 64) s_col[cur ^ 1][threadIdx.x] = nb;
-    __syncthreads();                                    // survivor list, s_row and the next column block are in place
-    if (threadIdx.x == 0) s_cnt1[par ^ 1] = 0;          // the next tile's counter (nobody touches it in this phase)
-    const unsigned cnt1 = s_cnt1[par];                  // stable: no pushes to the list during the dense stage
-    for (unsigned e0 = 0; e0 < cnt1; e0 += kThreads) {  // uniform trip count
-      // (uniform decision through the barrier's OR: a plain read of s_count after a barrier can differ between waves)
-      if (__syncthreads_or(s_count > kFlushAt)) queue_flush(Q, gq, gcount, cap);
-      const unsigned e = e0 + threadIdx.x;
-      if (e < cnt1) {
-        const unsigned v = s_q1[e], r = v >> 6, cc = v & 63u;
-        const PreBox& A = s_row[r];
-        const PreBox& B = s_col[cur][cc];
-        // IoU = I / (a1 + a2 - I) <= min(a1, a2) / max(a1, a2) because I <= min(a1, a2): a pair whose area ratio is
-        // below the threshold can never set a suppression bit, whatever its overlap -- skip the dense IoU pass for it.
-        // Only where the evaluated IoU is trustworthy to well under the 1 % margin: the bigger box not thinner than
-        // 1:20 (the polygon area of the reference loses ~64 eps D^2 absolute), positive areas, threshold > 0.05.
-        const float aa = A.w * A.h, ab = B.w * B.h;
-        const bool a_big = aa >= ab;
-        const float bw = a_big ? A.w : B.w, bh = a_big ? A.h : B.h;
-        const bool ratio_skip = thr > 0.05f && fminf(aa, ab) > 0.f && fminf(bw, bh) >= 0.05f * fmaxf(bw, bh) &&
-                                fminf(aa, ab) < 0.99f * thr * fmaxf(aa, ab);
-        if (!ratio_skip && !sat_disjoint(A, B))
-          queue_push(Q, t.seg_start + t.rb * 64 + r, t.seg_start + t.cb * 64 + cc);
-      }
-    }
-    __syncthreads();                                    // dense stage done: lists and s_col[cur] may be reused
-    cur ^= 1;
-    t = tn;
-  }
-  queue_flush(Q, gq, gcount, cap);
-}
-
-__global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict__ sorted,
-                                                        const uint32_t* __restrict__ local_idx,
-                                                        const unsigned long long* __restrict__ row_base,
-                                                        float thr, const uint2* __restrict__ gq,
-                                                        const unsigned long long* __restrict__ gcount,
-                                                        unsigned long long cap,
-                                                        unsigned long long* __restrict__ mask,
-                                                        const unsigned long long* __restrict__ words_total,
-                                                        unsigned long long words_bound,
-                                                        unsigned long long* __restrict__ occ) {
-  __shared__ float2 s_pts[24 * kThreads];
-  if (*words_total > words_bound) return;  // caller's per-segment promise broken: see k_nms_scan
-  unsigned long long total = *gcount;
-  if (total > cap) total = cap;
-  for (unsigned long long e = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; e < total;
-       e += (unsigned long long)gridDim.x * kThreads) {
-    uint2 ij = gq[e];
-    PreBox A = sorted[ij.x];  // higher score first: same argument order as the reference
-    PreBox B = sorted[ij.y];
-    float v = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
-    if (v > thr) {  // reference GPU rule: strict (ml_nms cuda.cu:63-64)
-      uint32_t jl = local_idx[ij.y];
-      const unsigned long long rb = row_base[ij.x];
-      atomicOr(&mask[rb + (jl >> 6)], 1ull << (jl & 63));
-      if (occ) atomicOr(&occ[(rb >> 6) + ij.x + (jl >> 12)], 1ull << ((jl >> 6) & 63));
-    }
-  }
-}
-
-// Overflow fallback (pair list did not fit): evaluate every tile directly.  Correct for any
-// density; only reached by pathological inputs (e.g. hundreds of thousands of stacked boxes).
-__global__ __launch_bounds__(kThreads) void k_nms_direct(const PreBox* __restrict__ sorted,
-                                                         const uint32_t* __restrict__ seg_start,
-                                                         const uint32_t* __restrict__ num_seg,
-                                                         const unsigned long long* __restrict__ tile_off,
-                                                         const unsigned long long* __restrict__ row_base,
-                                                         float thr,
-                                                         const unsigned long long* __restrict__ gcount,
-                                                         unsigned long long cap,
-                                                         unsigned long long* __restrict__ mask,
-                                                         const unsigned long long* __restrict__ words_total,
-                                                         unsigned long long words_bound,
-                                                         unsigned long long* __restrict__ occ) {
-  if (*gcount <= cap || *words_total > words_bound) return;
-  __shared__ float2 s_pts[24 * kThreads];
-  const uint32_t S = *num_seg;
-  const unsigned long long T = tile_off[S];
-  const int row = threadIdx.x & 63, quarter = threadIdx.x >> 6;
-  for (unsigned long long tile = blockIdx.x; tile < T; tile += gridDim.x) {
-    TileRef t = locate_tile(tile, tile_off, seg_start, S);
-    uint32_t il = t.rb * 64 + row;
-    if (il >= t.ns) continue;
-    PreBox A = sorted[t.seg_start + il];
-    unsigned long long bits = 0;
-    for (int c = 0; c < 16; c++) {
-      int cc = quarter * 16 + c;
-      uint32_t jl = t.cb * 64 + cc;
-      if (jl < t.ns && jl > il) {
-        PreBox B = sorted[t.seg_start + jl];
-        if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B) &&
-            rbox_iou<kThreads>(A, B, s_pts + threadIdx.x) > thr)
-          bits |= 1ull << cc;
-      }
-    }
-    if (bits) {
-      const unsigned long long rb = row_base[t.seg_start + il];
-      atomicOr(&mask[rb + t.cb], bits);
-      if (occ) atomicOr(&occ[(rb >> 6) + t.seg_start + il + (t.cb >> 6)], 1ull << (t.cb & 63));
-    }
-  }
-}
 
 // Greedy scan, one workgroup per segment at a time (persistent over segments).
 // Equivalent to the reference's host loop (ml_nms cuda.cu:120-131) restricted to a segment.
@@ -721,6 +510,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
   }
 }
 
+
 __global__ void k_nms_flags_glob(const uint8_t* __restrict__ keep_orig,
                                  const int32_t* __restrict__ perm_glob, int64_t n,
                                  uint8_t* __restrict__ flag_glob) {
@@ -789,28 +579,532 @@ __global__ void k_zero_u8(uint8_t* p, int64_t n) {
   if (i < n) p[i] = 0;
 }
 
+
+// per segment: number of 64-row blocks and of upper-triangle tiles (0 for the ignored-rows segment), arrays of n+1
+__global__ void k_nms_seg_sizes(const uint32_t* __restrict__ seg_start,
+                                const uint32_t* __restrict__ num_seg,
+                                const uint32_t* __restrict__ key2s, uint32_t ignore_key,
+                                int use_ignore, int64_t n, unsigned long long* __restrict__ tiles,
+                                uint32_t* __restrict__ nblk) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > n) return;
+  unsigned long long t = 0, nb = 0;
+  if (s < *num_seg) {
+    unsigned long long ns = seg_start[s + 1] - seg_start[s];
+    bool ignored = use_ignore && key2s[seg_start[s]] == ignore_key;
+    nb = ignored ? 0 : (ns + 63) / 64;
+    t = nb * (nb + 1) / 2;
+  }
+  tiles[s] = t;
+  nblk[s] = (uint32_t)nb;
+}
+
+// device-side scalars of one call
+struct NmsCounters {
+  unsigned long long pairs;      // cull survivors (true total, may exceed the list)
+  unsigned long long edges;      // pairs with IoU > thr (true total)
+  unsigned long long tiles;      // tiles that passed the filter (true total)
+  unsigned long long alive_list; // edges handed to the clean-up kernel
+  uint32_t status;               // bit 0: a list overflowed -> direct greedy fallback ran
+  uint32_t bbox[4];              // min x, min y (init 0xffffffff), max x, max y (init 0) of the centres, sortable
+  uint32_t alive[16];            // edges still between two unsettled rows after round r
+};
+
+// rows in (segment, score) order: pre-processed boxes (label slot = segment index), initial state, bounding box of
+// all finite centres (for the Morton quantisation)
+__global__ void k_nms_pos_meta(const float* __restrict__ dets5, const int32_t* __restrict__ perm_seg,
+                               const uint32_t* __restrict__ segidx1, const uint32_t* __restrict__ nblk, int64_t n,
+                               PreBox* __restrict__ sorted, uint8_t* __restrict__ state, NmsCounters* __restrict__ C) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t lx = 0xffffffffu, ly = 0xffffffffu, hx = 0u, hy = 0u;
+  if (p < n) {
+    const uint32_t s = segidx1[p] - 1;
+    const float* b = dets5 + 5 * (int64_t)perm_seg[p];
+    sorted[p] = make_prebox(b[0], b[1], b[2], b[3], b[4], __uint_as_float(s));
+    state[p] = nblk[s] == 0 ? 2 : 0;             // rows of the ignored segment are never kept
+    if (isfinite(b[0]) && isfinite(b[1])) {
+      lx = hx = float_sortable(b[0]);
+      ly = hy = float_sortable(b[1]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lx = min(lx, (uint32_t)__shfl_xor((int)lx, o)); ly = min(ly, (uint32_t)__shfl_xor((int)ly, o));
+    hx = max(hx, (uint32_t)__shfl_xor((int)hx, o)); hy = max(hy, (uint32_t)__shfl_xor((int)hy, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (lx != 0xffffffffu) { atomicMin(&C->bbox[0], lx); atomicMax(&C->bbox[2], hx); }
+    if (ly != 0xffffffffu) { atomicMin(&C->bbox[1], ly); atomicMax(&C->bbox[3], hy); }
+  }
+}
+
+__device__ __forceinline__ float sortable_float(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every other bit of 20
+  v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+// spatial key of every row: (segment index, 20-bit Morton code of the centre on a 1024 x 1024 grid over the bounding box)
+__global__ void k_nms_spkeys(const PreBox* __restrict__ sorted, const NmsCounters* __restrict__ C, int64_t n,
+                             unsigned long long* __restrict__ key3, uint32_t* __restrict__ val) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const PreBox b = sorted[p];
+  const float x0 = sortable_float(C->bbox[0]), y0 = sortable_float(C->bbox[1]);
+  const float x1 = sortable_float(C->bbox[2]), y1 = sortable_float(C->bbox[3]);
+  const float sx = x1 > x0 ? 1023.f / (x1 - x0) : 0.f, sy = y1 > y0 ? 1023.f / (y1 - y0) : 0.f;
+  float qx = (b.x - x0) * sx, qy = (b.y - y0) * sy;
+  qx = qx >= 0.f ? fminf(qx, 1023.f) : 0.f;      // NaN -> 0
+  qy = qy >= 0.f ? fminf(qy, 1023.f) : 0.f;
+  const uint32_t m = spread10((uint32_t)qx) | (spread10((uint32_t)qy) << 1);
+  key3[p] = ((unsigned long long)__float_as_uint(b.label) << 20) | m;
+  val[p] = (uint32_t)p;
+}
+
+// slot of block `blk` of segment s in the block-bounding-box arrays: consecutive segments never collide because
+// seg_start[s + 1] >= seg_start[s] + 64 * (nblk - 1) + 1
+__device__ __forceinline__ uint32_t block_slot(uint32_t seg_start_s, uint32_t s, uint32_t blk) {
+  return (seg_start_s >> 6) + s + blk;
+}
+__host__ __device__ inline size_t block_slots_for(size_t n) { return n / 64 + n + 2; }
+
+// rows in SPATIAL order: box copy (label slot = its score position), bounding box of every 64-row block of the inflated
+// circumscribed circles (atomics on order-preserving integers; one per wave and slot in the common case)
+__global__ void k_nms_spgather(const PreBox* __restrict__ sorted, const uint32_t* __restrict__ perm_sp,
+                               const uint32_t* __restrict__ seg_start, int64_t n, PreBox* __restrict__ sp_box,
+                               uint2* __restrict__ lo, uint2* __restrict__ hi) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint32_t slot = 0xffffffffu, lx = 0xffffffffu, ly = 0xffffffffu, hx = 0, hy = 0;
+  if (q < n) {
+    const uint32_t p = perm_sp[q];
+    PreBox b = sorted[p];
+    const uint32_t s = __float_as_uint(b.label);
+    b.label = __uint_as_float(p);
+    sp_box[q] = b;
+    const uint32_t st = seg_start[s];
+    slot = block_slot(st, s, ((uint32_t)q - st) >> 6);
+    // margin of surely_disjoint per box (sum of two of these >= its (ar + br) * 1.002 + 1e-3), plus 1e-3 for the
+    // rounding of x -+ r at chip-sized coordinates; non-finite boxes overlap everything (evaluated, never culled)
+    const float rr = b.r * 1.002f + 2e-3f;
+    float x0 = b.x - rr, x1 = b.x + rr, y0 = b.y - rr, y1 = b.y + rr;
+    if (!(isfinite(x0) && isfinite(x1) && isfinite(y0) && isfinite(y1))) {
+      x0 = y0 = -__builtin_inff(); x1 = y1 = __builtin_inff();
+    }
+    lx = float_sortable(x0); ly = float_sortable(y0); hx = float_sortable(x1); hy = float_sortable(y1);
+  }
+  // a wave covers at most two slots unless segments are tiny: reduce the lanes of the first lane's slot and of the last
+  // lane's slot by shuffles, everybody else (rare) goes alone
+  const uint32_t s_first = (uint32_t)__shfl((int)slot, 0), s_last = (uint32_t)__shfl((int)slot, 63);
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const uint32_t sg = g == 0 ? s_first : s_last;
+    if (g == 1 && s_last == s_first) break;
+    if (sg == 0xffffffffu) continue;
+    const bool in = slot == sg;
+    uint32_t a = in ? lx : 0xffffffffu, b = in ? ly : 0xffffffffu, c = in ? hx : 0u, d = in ? hy : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a = min(a, (uint32_t)__shfl_xor((int)a, o)); b = min(b, (uint32_t)__shfl_xor((int)b, o));
+      c = max(c, (uint32_t)__shfl_xor((int)c, o)); d = max(d, (uint32_t)__shfl_xor((int)d, o));
+    }
+    if (lane == (g == 0 ? 0 : 63)) {
+      atomicMin(&lo[sg].x, a); atomicMin(&lo[sg].y, b); atomicMax(&hi[sg].x, c); atomicMax(&hi[sg].y, d);
+    }
+  }
+  if (slot != 0xffffffffu && slot != s_first && slot != s_last) {
+    atomicMin(&lo[slot].x, lx); atomicMin(&lo[slot].y, ly); atomicMax(&hi[slot].x, hx); atomicMax(&hi[slot].y, hy);
+  }
+}
+
+__global__ void k_nms_init_slots(uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots,
+                                 NmsCounters* __restrict__ C) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { C->bbox[0] = C->bbox[1] = 0xffffffffu; C->bbox[2] = C->bbox[3] = 0u; }   // (after the memset of C)
+  if (i >= slots) return;
+  lo[i] = make_uint2(0xffffffffu, 0xffffffffu);
+  hi[i] = make_uint2(0u, 0u);
+}
+
+// TILE FILTER: one thread per upper-triangle tile (grid-stride over the device-side total); tiles whose two block
+// bounding boxes overlap are appended to the list (wave-aggregated).  Order-preserving integers compare like the floats.
+__global__ __launch_bounds__(kThreads) void k_nms_tile_filter(const uint32_t* __restrict__ seg_start,
+                                                              const uint32_t* __restrict__ num_seg,
+                                                              const unsigned long long* __restrict__ tile_off,
+                                                              const uint2* __restrict__ lo, const uint2* __restrict__ hi,
+                                                              TileRef* __restrict__ tiles, NmsCounters* __restrict__ C,
+                                                              unsigned long long tile_cap) {
+  const uint32_t S = *num_seg;
+  const unsigned long long T = tile_off[S];
+  const int lane = threadIdx.x & 63;
+  for (unsigned long long t0 = (unsigned long long)blockIdx.x * kThreads; t0 < T; t0 += (unsigned long long)gridDim.x * kThreads) {
+    const unsigned long long t = t0 + threadIdx.x;
+    bool take = false;
+    TileRef tr = {};
+    if (t < T) {
+      uint32_t sidx = 0;
+      tr = locate_tile(t, tile_off, seg_start, S, &sidx);
+      const uint32_t a = block_slot(tr.seg_start, sidx, tr.rb), b = block_slot(tr.seg_start, sidx, tr.cb);
+      const uint2 la = lo[a], ha = hi[a], lb = lo[b], hb = hi[b];
+      take = tr.rb == tr.cb || (la.x <= hb.x && lb.x <= ha.x && la.y <= hb.y && lb.y <= ha.y);
+    }
+    const unsigned long long bal = __ballot(take);
+    if (bal) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&C->tiles, (unsigned long long)__popcll(bal));
+      base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+      if (take) {
+        const unsigned long long dst = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (dst < tile_cap) tiles[dst] = tr;
+      }
+    }
+  }
+}
+
+// CULL over the tile list (persistent grid, every workgroup a contiguous run of list entries).
+// thread = (row = tid & 63, 16 columns).  Stage 1: circle test of every pair of the tile against the column boxes in
+// LDS, survivors -> LDS list.  Stage 2, dense: every lane takes ONE survivor: separating axes + IoU upper bound
+// (nms_pair_skippable).  What is left goes to the pair list as (score position of the higher-scored box, of the lower).
+// The boxes of the next tile are fetched while the current one is tested (double-buffered LDS).
+__global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict__ sp_box,
+                                                       const TileRef* __restrict__ tiles,
+                                                       NmsCounters* __restrict__ C, unsigned long long tile_cap,
+                                                       uint2* __restrict__ gq, unsigned long long cap, float thr) {
+  __shared__ uint2 s_q[kLdsQueue];
+  __shared__ unsigned s_count, s_base[2], s_cnt1[2];
+  __shared__ PreBox s_col[2][64];
+  __shared__ PreBox s_row[2][64];
+  __shared__ unsigned short s_q1[4096];        // circle-test survivors of the current tile: row << 6 | column
+  PairQueue Q{s_q, &s_count, s_base};
+  if (threadIdx.x == 0) { s_count = 0; s_cnt1[0] = 0; s_cnt1[1] = 0; }
+  unsigned long long* gcount = &C->pairs;
+  const unsigned long long L = min(C->tiles, tile_cap);   // (an overflowing tile list sets the status bit: fallback)
+  const unsigned long long chunk = (L + gridDim.x - 1) / gridDim.x;
+  unsigned long long e = (unsigned long long)blockIdx.x * chunk;
+  const unsigned long long eend = min(L, e + chunk);
+  const int row = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+  if (e >= eend) { __syncthreads(); queue_flush(Q, gq, gcount, cap); return; }
+  auto fetch = [&](const TileRef& t) {          // threads 0-63: column box, 64-127: row box of tile t
+    PreBox b = {};
+    if (threadIdx.x < 128) {
+      const uint32_t l = (threadIdx.x < 64 ? t.cb : t.rb) * 64 + (threadIdx.x & 63);
+      if (l < t.ns) b = sp_box[t.seg_start + l];
+    }
+    return b;
+  };
+  TileRef t = tiles[e];
+  {
+    const PreBox b = fetch(t);
+    if (threadIdx.x < 64) s_col[0][threadIdx.x] = b; else if (threadIdx.x < 128) s_row[0][threadIdx.x - 64] = b;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; e < eend; e++) {
+    const bool has_next = e + 1 < eend;
+    TileRef tn = t;
+    PreBox nb = {};
+    if (has_next) { tn = tiles[e + 1]; nb = fetch(tn); }     // in flight under this tile's tests
+    const uint32_t il = t.rb * 64 + row;
+    const int par = (int)(e & 1);
+    if (il < t.ns) {
+      const PreBox a = s_row[cur][row];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const int cc = quarter * 16 + c;
+        const uint32_t jl = t.cb * 64 + cc;
+        if (jl < t.ns && (t.cb != t.rb || jl > il) &&
+            !surely_disjoint(a.x, a.y, a.r, s_col[cur][cc].x, s_col[cur][cc].y, s_col[cur][cc].r)) {
+          const unsigned p = atomicAdd(&s_cnt1[par], 1u);
+          s_q1[p] = (unsigned short)((row << 6) | cc);
+        }
+      }
+    }
+    if (has_next) {
+      if (threadIdx.x < 64) s_col[cur ^ 1][threadIdx.x] = nb; else if (threadIdx.x < 128) s_row[cur ^ 1][threadIdx.x - 64] = nb;
+    }
+    __syncthreads();                                    // survivor list and the next tile's boxes are in place
+    if (threadIdx.x == 0) s_cnt1[par ^ 1] = 0;          // the next tile's counter (nobody touches it in this phase)
+    const unsigned cnt1 = s_cnt1[par];                  // stable: no pushes to the list during the dense stage
+    for (unsigned e0 = 0; e0 < cnt1; e0 += kThreads) {  // uniform trip count
+      // (uniform decision through the barrier's OR: a plain read of s_count after a barrier can differ between waves)
+      if (__syncthreads_or(s_count > kFlushAt)) queue_flush(Q, gq, gcount, cap);
+      const unsigned x = e0 + threadIdx.x;
+      if (x < cnt1) {
+        const unsigned v = s_q1[x], r = v >> 6, cc = v & 63u;
+        const PreBox& A = s_row[cur][r];
+        const PreBox& B = s_col[cur][cc];
+        if (!nms_pair_skippable(A, B, thr)) {
+          const unsigned pa = __float_as_uint(A.label), pb = __float_as_uint(B.label);
+          queue_push(Q, min(pa, pb), max(pa, pb));
+        }
+      }
+    }
+    __syncthreads();                                    // dense stage done: lists and the current buffers may be reused
+    cur ^= 1;
+    t = tn;
+  }
+  queue_flush(Q, gq, gcount, cap);
+}
+
+// DENSE IoU pass: one pair per lane; pairs above the threshold become edges (wave-aggregated append)
+__global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict__ sorted, float thr,
+                                                        const uint2* __restrict__ gq, NmsCounters* __restrict__ C,
+                                                        unsigned long long cap, uint2* __restrict__ edges,
+                                                        unsigned long long ecap) {
+  __shared__ float2 s_pts[24 * kThreads];
+  const unsigned long long total = min(C->pairs, cap);
+  const int lane = threadIdx.x & 63;
+  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
+  for (unsigned long long e0 = (unsigned long long)blockIdx.x * kThreads; e0 < total; e0 += stride) {
+    const unsigned long long e = e0 + threadIdx.x;
+    bool hit = false;
+    uint2 ij = make_uint2(0, 0);
+    if (e < total) {
+      ij = gq[e];
+      const PreBox A = sorted[ij.x];  // higher score first: same argument order as the reference
+      const PreBox B = sorted[ij.y];
+      hit = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x) > thr;  // reference GPU rule: strict (ml_nms cuda.cu:63-64)
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (bal) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&C->edges, (unsigned long long)__popcll(bal));
+      base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+      if (hit) {
+        const unsigned long long dst = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (dst < ecap) edges[dst] = ij;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- greedy order by rounds over the edge list
+// state[p]: 0 open, 1 kept, 2 removed (sticky).  A row that is still open is UNSETTLED exactly when an edge from another
+// unsettled row blocked it in the latest round (blocked[r & 1][p] == r); open and not blocked == kept (all its
+// in-neighbours are removed).  Round r reads the round r-1 view and writes the round r one; the two blocked arrays
+// alternate so that a round never overwrites the marks it reads.  Rows that nobody blocks any more stay kept without
+// ever being touched again, so nothing has to be materialised between rounds.
+constexpr int kNmsRounds = 6;       // launched rounds (4-6 settle random and detector-like inputs); the rest: clean-up kernel
+enum : uint32_t { kOpen = 0, kKept = 1, kRemoved = 2 };
+
+__device__ __forceinline__ uint32_t nms_view(const uint8_t* __restrict__ state, const uint8_t* __restrict__ blocked,
+                                             int64_t n, int r, uint32_t p) {
+  const uint32_t st = state[p];
+  if (st != kOpen) return st;
+  if (r == 0) return kOpen;                                   // before the first round every row is unsettled
+  return blocked[(int64_t)(r & 1) * n + p] == (uint8_t)r ? kOpen : kKept;
+}
+
+// one round over all edges; r = 1 .. kNmsRounds.  alive[r] = edges between two rows that are unsettled after this round.
+// The last launched round also lists those edges for the clean-up kernel.
+__global__ __launch_bounds__(kThreads) void k_nms_round(const uint2* __restrict__ edges, NmsCounters* __restrict__ C,
+                                                        unsigned long long ecap, uint8_t* __restrict__ state,
+                                                        uint8_t* __restrict__ blocked, int64_t n, int r,
+                                                        uint2* __restrict__ alive_list, unsigned long long alive_cap) {
+  if (r > 1 && C->alive[r - 1] == 0) return;                  // settled already
+  const unsigned long long E = min(C->edges, ecap);
+  unsigned cnt = 0;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
+  for (unsigned long long e0 = (unsigned long long)blockIdx.x * kThreads; e0 < E; e0 += stride) {
+    const unsigned long long e = e0 + threadIdx.x;
+    bool live = false;
+    uint2 ij = make_uint2(0, 0);
+    if (e < E) {
+      ij = edges[e];
+      const uint32_t sj = nms_view(state, blocked, n, r - 1, ij.y);
+      if (sj == kOpen) {
+        const uint32_t si = nms_view(state, blocked, n, r - 1, ij.x);
+        if (si == kKept) state[ij.y] = (uint8_t)kRemoved;
+        else if (si == kOpen) { blocked[(int64_t)(r & 1) * n + ij.y] = (uint8_t)r; live = true; }
+      }
+    }
+    cnt += live ? 1u : 0u;
+    if (alive_list) {
+      const unsigned long long bal = __ballot(live);
+      if (bal) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&C->alive_list, (unsigned long long)__popcll(bal));
+        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+        if (live) {
+          const unsigned long long dst = base + __popcll(bal & ((1ull << lane) - 1ull));
+          if (dst < alive_cap) alive_list[dst] = ij;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0 && cnt) atomicAdd(&C->alive[r], cnt);
+}
+
+// CLEAN-UP: chains longer than the launched rounds (rare; adversarially long alternating chains): ONE workgroup goes on
+// with the edges that were still alive after the last launched round.  It first writes the implicit "open and not
+// blocked == kept" view out as explicit states, so that no round stamp is needed from here on, and then runs classic
+// rounds with barriers: (A) kept source -> target removed, (B) open source and open target -> target blocked,
+// (C) open and not blocked -> kept, (D) drop the edges whose target is settled or whose source is removed (in place: a
+// survivor is always written at or before its own slot) -- until the list is empty.  Every open row always has an
+// in-edge in the list from an open or kept row, so (C) reaches it; at the end no row is open.
+__global__ __launch_bounds__(1024) void k_nms_cleanup(NmsCounters* __restrict__ C, uint8_t* __restrict__ state,
+                                                      uint8_t* __restrict__ blocked, int64_t n,
+                                                      uint2* __restrict__ list, unsigned long long list_cap,
+                                                      const uint2* __restrict__ edges, unsigned long long ecap) {
+  if (C->alive[kNmsRounds] == 0) return;
+  __shared__ unsigned s_wave[16], s_tot;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t p = threadIdx.x; p < n; p += 1024) {
+    const uint32_t v = nms_view(state, blocked, n, kNmsRounds, (uint32_t)p);
+    blocked[p] = 0;                           // array 0 becomes the plain "blocked this round" flag
+    if (v == kKept) state[p] = (uint8_t)kKept;
+  }
+  // the list overflowed (more alive edges than the buffer): walk ALL edges every round instead, without compaction
+  const bool all = C->alive_list > list_cap;
+  const uint2* src = all ? edges : list;
+  unsigned long long cnt = all ? min(C->edges, ecap) : C->alive_list;
+  __threadfence_block();
+  __syncthreads();
+  for (;;) {
+    for (unsigned long long e = threadIdx.x; e < cnt; e += 1024) {          // (A)
+      const uint2 ij = src[e];
+      if (state[ij.x] == kKept && state[ij.y] == kOpen) state[ij.y] = (uint8_t)kRemoved;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (unsigned long long e = threadIdx.x; e < cnt; e += 1024) {          // (B)
+      const uint2 ij = src[e];
+      if (state[ij.x] == kOpen && state[ij.y] == kOpen) blocked[ij.y] = 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (unsigned long long e = threadIdx.x; e < cnt; e += 1024) {          // (C)
+      const uint2 ij = src[e];
+      if (state[ij.y] == kOpen && blocked[ij.y] == 0) state[ij.y] = (uint8_t)kKept;
+    }
+    __threadfence_block();
+    __syncthreads();
+    unsigned kept_total = 0;                                                  // (D)
+    for (unsigned long long e0 = 0; e0 < cnt; e0 += 1024) {
+      const unsigned long long e = e0 + threadIdx.x;
+      bool live = false;
+      uint2 ij = make_uint2(0, 0);
+      if (e < cnt) {
+        ij = src[e];
+        live = state[ij.y] == kOpen && state[ij.x] != kRemoved;
+        if (live) blocked[ij.y] = 0;          // reset for the next round (only open rows carry a mark)
+      }
+      const unsigned long long bal = __ballot(live);
+      if (lane == 0) s_wave[wave] = (unsigned)__popcll(bal);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned acc = 0;
+        for (int w = 0; w < 16; w++) { const unsigned c = s_wave[w]; s_wave[w] = acc; acc += c; }
+        s_tot = acc;
+      }
+      __syncthreads();
+      if (live && !all) list[kept_total + s_wave[wave] + __popcll(bal & ((1ull << lane) - 1ull))] = ij;
+      kept_total += s_tot;
+      __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (kept_total == 0) break;
+    if (!all) cnt = kept_total;
+  }
+}
+
+// FALLBACK (a list overflowed: pathologically dense input): the plain definition of greedy NMS, one workgroup per
+// segment, no lists -- for every row in score order that is still open: keep it and test all later open rows against it.
+// Serial over the kept rows; only ever reached when nearly everything overlaps, i.e. when few rows are kept.
+__global__ __launch_bounds__(kThreads) void k_nms_greedy_direct(const PreBox* __restrict__ sorted,
+                                                                const uint32_t* __restrict__ seg_start,
+                                                                const uint32_t* __restrict__ num_seg,
+                                                                const uint32_t* __restrict__ nblk,
+                                                                NmsCounters* __restrict__ C, unsigned long long cap,
+                                                                unsigned long long ecap, unsigned long long tile_cap,
+                                                                uint8_t* __restrict__ state, float thr) {
+  if (!(C->pairs > cap || C->edges > ecap || C->tiles > tile_cap)) return;
+  __shared__ float2 s_pts[24 * kThreads];
+  __shared__ unsigned s_next;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&C->status, 1u);
+  const uint32_t S = *num_seg;
+  for (uint32_t s = blockIdx.x; s < S; s += gridDim.x) {
+    const uint32_t st = seg_start[s], ns = seg_start[s + 1] - st;
+    if (nblk[s] == 0) continue;                       // ignored rows: stay removed
+    for (uint32_t i = threadIdx.x; i < ns; i += kThreads) state[st + i] = (uint8_t)kOpen;
+    __syncthreads();
+    uint32_t from = 0;
+    for (;;) {
+      if (threadIdx.x == 0) s_next = 0xffffffffu;
+      __syncthreads();
+      // first open row at or after `from` (rows are only ever closed behind the scan front)
+      for (uint32_t i = from + threadIdx.x; i < ns; i += kThreads) {
+        if (state[st + i] == kOpen) { atomicMin(&s_next, i); break; }
+      }
+      __syncthreads();
+      const uint32_t i = s_next;
+      __syncthreads();
+      if (i == 0xffffffffu) break;
+      const PreBox A = sorted[st + i];
+      if (threadIdx.x == 0) state[st + i] = (uint8_t)kKept;
+      for (uint32_t j = i + 1 + threadIdx.x; j < ns; j += kThreads) {
+        if (state[st + j] != kOpen) continue;
+        const PreBox B = sorted[st + j];
+        if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B) &&
+            rbox_iou<kThreads>(A, B, s_pts + threadIdx.x) > thr)
+          state[st + j] = (uint8_t)kRemoved;
+      }
+      from = i + 1;
+      __syncthreads();
+    }
+  }
+}
+
+// keep flag of every row in the caller's order
+__global__ void k_nms_finish(const uint8_t* __restrict__ state, const uint8_t* __restrict__ blocked,
+                             const NmsCounters* __restrict__ C, const int32_t* __restrict__ perm_seg, int64_t n,
+                             uint8_t* __restrict__ keep_orig) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t v;
+  if ((C->status & 1u) || C->alive[kNmsRounds] != 0) {
+    v = state[p];                    // the fallback / the clean-up kernel settled every row explicitly
+  } else {
+    int r = kNmsRounds;              // the view after the first launched round that left no edge alive
+    for (int k = 1; k <= kNmsRounds; k++)
+      if (C->alive[k] == 0) { r = k; break; }
+    v = nms_view(state, blocked, n, r, (uint32_t)p);
+  }
+  keep_orig[perm_seg[p]] = v == kKept ? 1 : 0;
+}
+
 // ---------------------------------------------------------------- NMS workspace plan
 struct NmsPlan {
   size_t rocprim_bytes;
-  unsigned long long mask_words;  // bound
-  unsigned long long queue_cap;
-  uint32_t max_blocks;
+  unsigned long long queue_cap;   // pair list (cull survivors)
+  unsigned long long edge_cap;    // edges (pairs above the threshold)
+  unsigned long long tile_cap;    // tiles that pass the bounding-box filter
 };
 
 struct NmsBuffers {
-  unsigned long long *key1a, *key1b;
+  unsigned long long *key1a, *key1b, *key3b;
   int32_t *idxa, *perm_glob, *perm_seg;
-  uint32_t *key2a, *key2s, *head, *segidx1, *seg_start, *num_seg, *local_idx, *nblk;
-  unsigned long long *words, *tiles, *mask_off, *tile_off, *row_base, *gcount, *mask, *occ;
-  PreBox* sorted;
-  uint2* gq;
-  uint8_t *keep_orig, *flag_glob;
+  uint32_t *key2a, *key2s, *head, *segidx1, *seg_start, *num_seg, *nblk, *perm_sp;
+  unsigned long long *tiles_per_seg, *tile_off;
+  NmsCounters* C;
+  PreBox *sorted, *sp_box;
+  uint2 *lo, *hi;
+  TileRef* tiles;
+  uint2 *gq, *edges;
+  uint8_t *keep_orig, *flag_glob, *state, *blocked;
   void* rp_temp;
 };
 
 int nms_plan(int64_t n, int64_t max_seg_rows, NmsPlan* plan) {
   if (max_seg_rows <= 0 || max_seg_rows > n) max_seg_rows = n;
-  size_t a = 0, b = 0, c = 0, d = 0, e = 0;
+  size_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
   unsigned long long* k64 = nullptr;
   int32_t* i32 = nullptr;
   uint32_t* u32 = nullptr;
@@ -822,53 +1116,63 @@ int nms_plan(int64_t n, int64_t max_seg_rows, NmsPlan* plan) {
             rocprim::radix_sort_pairs(nullptr, b, u32, u32, i32, i32, sz, 0, 32, s0) == hipSuccess &&
             rocprim::inclusive_scan(nullptr, c, u32, u32, sz, rocprim::plus<uint32_t>(), s0) == hipSuccess &&
             rocprim::exclusive_scan(nullptr, d, k64, k64, 0ull, sz + 1, rocprim::plus<unsigned long long>(), s0) == hipSuccess &&
-            rocprim::select(nullptr, e, i32, u8, i64, i64, sz, s0) == hipSuccess;
+            rocprim::select(nullptr, e, i32, u8, i64, i64, sz, s0) == hipSuccess &&
+            rocprim::radix_sort_pairs(nullptr, f, k64, k64, u32, u32, sz, 0, 64, s0) == hipSuccess;
   if (!ok) {
     // no device visible (size query on a CPU-only host): generous closed-form bound —
     // double-buffered keys+values plus histograms
     (void)hipGetLastError();
-    a = b = c = d = e = 0;
+    a = b = c = d = e = f = 0;
     a = sz * 32 + (8u << 20);
   }
-  plan->rocprim_bytes = std::max(std::max(std::max(a, b), std::max(c, d)), e);
-  unsigned long long nb = ((unsigned long long)max_seg_rows + 63) / 64;
-  plan->mask_words = (unsigned long long)n * nb;
-  plan->max_blocks = (uint32_t)nb;
-  // pair list: all same-segment pairs when small, else 8 Mi entries + 64/row
+  plan->rocprim_bytes = std::max(std::max(std::max(a, b), std::max(c, d)), std::max(e, f));
+  // pair list: all same-segment pairs when small, else 16 Mi entries + 256/row
   unsigned long long all_pairs = (unsigned long long)n * (unsigned long long)max_seg_rows / 2 + 64;
   unsigned long long want = (16ull << 20) + 256ull * (unsigned long long)n;
   plan->queue_cap = std::min(all_pairs, want);
+  plan->edge_cap = std::min(plan->queue_cap, (8ull << 20) + 64ull * (unsigned long long)n);
+  // tiles: single-block segments give one tile each (<= n); the others hold at most n/32 + 2 blocks together
+  unsigned long long nb = ((unsigned long long)max_seg_rows + 63) / 64;
+  plan->tile_cap = std::min<unsigned long long>((unsigned long long)n + ((unsigned long long)n / 32 + 2) * (nb + 1) / 2, 32ull << 20);
   return 0;
 }
 
-void nms_carve(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
+// everything except the three lists (tiles, pairs, edges)
+void nms_carve_fixed(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
   size_t sz = (size_t)n;
   B->key1a = cv.take<unsigned long long>(sz);
   B->key1b = cv.take<unsigned long long>(sz);
+  B->key3b = cv.take<unsigned long long>(sz);
   B->idxa = cv.take<int32_t>(sz);
   B->perm_glob = cv.take<int32_t>(sz);
   B->perm_seg = cv.take<int32_t>(sz);
+  B->perm_sp = cv.take<uint32_t>(sz);
   B->key2a = cv.take<uint32_t>(sz);
   B->key2s = cv.take<uint32_t>(sz);
   B->head = cv.take<uint32_t>(sz);
   B->segidx1 = cv.take<uint32_t>(sz);
   B->seg_start = cv.take<uint32_t>(sz + 1);
   B->num_seg = cv.take<uint32_t>(4);
-  B->local_idx = cv.take<uint32_t>(sz);
   B->nblk = cv.take<uint32_t>(sz + 1);
-  B->words = cv.take<unsigned long long>(sz + 1);
-  B->tiles = cv.take<unsigned long long>(sz + 1);
-  B->mask_off = cv.take<unsigned long long>(sz + 1);
+  B->tiles_per_seg = cv.take<unsigned long long>(sz + 1);
   B->tile_off = cv.take<unsigned long long>(sz + 1);
-  B->row_base = cv.take<unsigned long long>(sz);
-  B->gcount = cv.take<unsigned long long>(4);
+  B->C = cv.take<NmsCounters>(1);
   B->sorted = cv.take<PreBox>(sz);
+  B->sp_box = cv.take<PreBox>(sz);
+  B->lo = cv.take<uint2>(block_slots_for(sz));
+  B->hi = cv.take<uint2>(block_slots_for(sz));
   B->keep_orig = cv.take<uint8_t>(sz);
   B->flag_glob = cv.take<uint8_t>(sz);
+  B->state = cv.take<uint8_t>(sz);
+  B->blocked = cv.take<uint8_t>(2 * sz);
   B->rp_temp = cv.take<char>(pl.rocprim_bytes);
+}
+
+void nms_carve(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
+  nms_carve_fixed(cv, n, pl, B);
+  B->tiles = cv.take<TileRef>(pl.tile_cap);
+  B->edges = cv.take<uint2>(pl.edge_cap);
   B->gq = cv.take<uint2>(pl.queue_cap);
-  B->mask = cv.take<unsigned long long>(pl.mask_words + occ_words_for(pl.mask_words, (unsigned long long)n));
-  B->occ = B->mask ? B->mask + pl.mask_words : nullptr;
 }
 
 inline unsigned grid_for(int64_t n, int threads = 256) { return (unsigned)((n + threads - 1) / threads); }
@@ -906,35 +1210,34 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   S2A_HIP(rocprim::inclusive_scan(B.rp_temp, rpb, B.head, B.segidx1, sz, rocprim::plus<uint32_t>(), st));
   k_nms_seg_start<<<g, 256, 0, st>>>(B.head, B.segidx1, n, B.seg_start, B.num_seg);
   k_nms_seg_sizes<<<grid_for(n + 1), 256, 0, st>>>(B.seg_start, B.num_seg, B.key2s, ignore_key,
-                                                   seg_ids != nullptr, n, B.words, B.tiles, B.nblk);
+                                                   seg_ids != nullptr, n, B.tiles_per_seg, B.nblk);
   rpb = pl.rocprim_bytes;
-  S2A_HIP(rocprim::exclusive_scan(B.rp_temp, rpb, B.words, B.mask_off, 0ull, sz + 1,
+  S2A_HIP(rocprim::exclusive_scan(B.rp_temp, rpb, B.tiles_per_seg, B.tile_off, 0ull, sz + 1,
                                   rocprim::plus<unsigned long long>(), st));
+  S2A_HIP(hipMemsetAsync(B.C, 0, sizeof(NmsCounters), st));
+  S2A_HIP(hipMemsetAsync(B.blocked, 0, 2 * sz, st));
+  const size_t slots = block_slots_for(sz);
+  k_nms_init_slots<<<grid_for((int64_t)slots), 256, 0, st>>>(B.lo, B.hi, slots, B.C);
+  k_nms_pos_meta<<<g, 256, 0, st>>>(dets, B.perm_seg, B.segidx1, B.nblk, n, B.sorted, B.state, B.C);
+  // spatial order inside every segment (key1a and idxa are free again)
+  uint32_t* val3a = reinterpret_cast<uint32_t*>(B.idxa);
+  k_nms_spkeys<<<g, 256, 0, st>>>(B.sorted, B.C, n, B.key1a, val3a);
+  const unsigned segbits = seg_ids ? bits_for((uint64_t)num_segments_hint + 1) : (labels ? bits_for((uint64_t)n) : 1);
   rpb = pl.rocprim_bytes;
-  S2A_HIP(rocprim::exclusive_scan(B.rp_temp, rpb, B.tiles, B.tile_off, 0ull, sz + 1,
-                                  rocprim::plus<unsigned long long>(), st));
-  k_nms_pos_meta<<<g, 256, 0, st>>>(dets, B.perm_seg, B.segidx1, B.seg_start, B.mask_off, B.nblk, n, B.sorted,
-                                    B.local_idx, B.row_base);
-  S2A_HIP(hipMemsetAsync(B.gcount, 0, 32, st));  // [0] pair count, [1] status word
-  S2A_HIP(hipMemsetAsync(B.keep_orig, 0, sz, st));
-  // total words = mask_off[S]; S is only known on the device: index through num_seg inside
-  // the kernels.  k_zero_words needs the total: mask_off is an exclusive scan over n+1 entries
-  // whose tail is constant (= total), so entry n holds it.
-  k_zero_words<<<kPersistentGrid, 256, 0, st>>>(B.mask, B.mask_off + n, pl.mask_words);
-  k_zero_occ<<<kPersistentGrid, 256, 0, st>>>(B.occ, B.mask_off + n, pl.mask_words, (unsigned long long)n);
-  k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.tile_off, B.gq,
-                                                   B.gcount, pl.queue_cap, thr);
-  k_nms_heavy<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, B.local_idx, B.row_base, thr, B.gq,
-                                                    B.gcount, pl.queue_cap, B.mask, B.mask_off + n,
-                                                    pl.mask_words, B.occ);
-  k_nms_direct<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.tile_off,
-                                                     B.row_base, thr, B.gcount, pl.queue_cap, B.mask,
-                                                     B.mask_off + n, pl.mask_words, B.occ);
-  size_t lds = ((size_t)pl.max_blocks + 10 + kScanCacheWords) * sizeof(unsigned long long);
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_nms_scan<<<512, kThreads, lds, st>>>(B.mask, B.seg_start, B.num_seg, B.mask_off, B.nblk, B.perm_seg,
-                                         B.keep_orig, pl.max_blocks, B.mask_off + n, pl.mask_words,
-                                         reinterpret_cast<uint32_t*>(B.gcount + 1), B.occ);
+  S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp, rpb, B.key1a, B.key3b, val3a, B.perm_sp, sz, 0, 20 + segbits, st));
+  k_nms_spgather<<<g, 256, 0, st>>>(B.sorted, B.perm_sp, B.seg_start, n, B.sp_box, B.lo, B.hi);
+  k_nms_tile_filter<<<kPersistentGrid, kThreads, 0, st>>>(B.seg_start, B.num_seg, B.tile_off, B.lo, B.hi, B.tiles, B.C,
+                                                          pl.tile_cap);
+  k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(B.sp_box, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+  k_nms_heavy<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
+  // the pair list is dead after the dense pass: its memory takes the alive-edge list of the last launched round
+  for (int r = 1; r <= kNmsRounds; r++)
+    k_nms_round<<<512, kThreads, 0, st>>>(B.edges, B.C, pl.edge_cap, B.state, B.blocked, n, r,
+                                          r == kNmsRounds ? B.gq : nullptr, pl.queue_cap);
+  k_nms_cleanup<<<1, 1024, 0, st>>>(B.C, B.state, B.blocked, n, B.gq, pl.queue_cap, B.edges, pl.edge_cap);
+  k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.nblk, B.C, pl.queue_cap, pl.edge_cap,
+                                                pl.tile_cap, B.state, thr);
+  k_nms_finish<<<g, 256, 0, st>>>(B.state, B.blocked, B.C, B.perm_seg, n, B.keep_orig);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -961,18 +1264,14 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
   }
   S2A_CHECK_ARG(dets && scores && keep, "nms_rotated: NULL tensor");
   NmsPlan pl;
-  // honour a smaller workspace by shrinking the per-segment bound the caller promised
-  int64_t max_seg = n;
-  S2A_CHECK_ARG(nms_plan(n, max_seg, &pl) == 0, "nms_rotated: rocprim size query failed");
+  S2A_CHECK_ARG(nms_plan(n, n, &pl) == 0, "nms_rotated: rocprim size query failed");
   Carver cv(ws, ws_bytes);
   NmsBuffers B;
   nms_carve(cv, n, pl, &B);
-  if (cv.off > ws_bytes || !B.mask) {
+  if (cv.off > ws_bytes || !B.gq) {
     set_error("nms_rotated: workspace too small (%zu < %zu)", ws_bytes, cv.off);
     return S2A_EWORKSPACE;
   }
-  S2A_CHECK_ARG(((size_t)pl.max_blocks + 10 + kScanCacheWords) * 8 <= 112 * 1024,
-                "nms_rotated: more than 524k rows in one segment is not supported");
   int rc = nms_core(dets, scores, labels, nullptr, nullptr, n, 0, 1, thr, pl, B, st);
   if (rc != S2A_OK) return rc;
   k_nms_flags_glob<<<grid_for(n), 256, 0, st>>>(B.keep_orig, B.perm_glob, n, B.flag_glob);
@@ -1011,8 +1310,38 @@ extern "C" size_t s2a_box_iou_rotated_workspace_bytes(int64_t n, int64_t m) {
   if (n <= 0 || m <= 0) return 256;
   unsigned long long pairs = (unsigned long long)n * (unsigned long long)m;
   unsigned long long cap = std::max<unsigned long long>(std::min<unsigned long long>(pairs, kIouQueueCap), (unsigned long long)m * 256);
-  return align_up((size_t)(n + m) * sizeof(PreBox)) * 2 + align_up(cap * sizeof(uint2)) + 4096;
+  return align_up((size_t)(n + m) * sizeof(PreBox)) * 2 + align_up(cap * (sizeof(uint2) + sizeof(float))) + 8192;
 }
+
+namespace s2a {
+namespace {
+// One side stream + fork / join events per device, created on first use: the zero-fill of a large IoU matrix runs there
+// while the caller's stream finds and evaluates the overlapping pairs.  The fork / join is the event pattern that stream
+// capture understands, so a captured call replays with the same concurrency.  The mutex covers the enqueue sequence
+// (events are re-recorded per call).
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+std::mutex g_side_mutex;
+SideStream g_side[64];
+
+int side_stream(SideStream** out) {
+  int dev = 0;
+  S2A_HIP(hipGetDevice(&dev));
+  S2A_CHECK_ARG(dev >= 0 && dev < 64, "device index out of range");
+  SideStream& ss = g_side[dev];
+  if (!ss.s) {
+    S2A_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    S2A_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+    S2A_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+  }
+  *out = &ss;
+  return S2A_OK;
+}
+constexpr unsigned long long kIouForkBytes = 8ull << 20;   // smaller outputs: one stream, zero-fill fused into the cull
+}  // namespace
+}  // namespace s2a
 
 extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* boxes2, int64_t m,
                                    float* ious, void* workspace, size_t workspace_bytes,
@@ -1026,24 +1355,47 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   PreBox* P1 = cv.take<PreBox>((size_t)n);
   PreBox* P2 = cv.take<PreBox>((size_t)m);
   unsigned long long* counters = cv.take<unsigned long long>(512);
-  if (!P1 || !P2 || !counters || cv.off + (size_t)m * 256 * sizeof(uint2) > workspace_bytes) {
+  if (!P1 || !P2 || !counters || cv.off + (size_t)m * 256 * (sizeof(uint2) + sizeof(float)) + 512 > workspace_bytes) {
     set_error("box_iou_rotated: workspace too small (%zu bytes)", workspace_bytes);
     return S2A_EWORKSPACE;
   }
-  unsigned long long cap = (workspace_bytes - cv.off) / sizeof(uint2);
+  unsigned long long cap = (workspace_bytes - cv.off - 256) / (sizeof(uint2) + sizeof(float));
   uint2* gq = reinterpret_cast<uint2*>(static_cast<char*>(workspace) + cv.off);
+  float* vals = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up(cv.off + cap * sizeof(uint2)) );
+  cap = std::min<unsigned long long>(cap, (workspace_bytes - (size_t)(reinterpret_cast<char*>(vals) - static_cast<char*>(workspace))) / sizeof(float));
   // rows per chunk: sized for up to 1/4 of the pairs surviving the cull (DOTA-like inputs: ~1 %);
-  // a denser chunk overflows the list and is recomputed pair by pair inside k_iou_heavy
+  // a denser chunk overflows the list and is recomputed pair by pair in k_iou_scatter
   int64_t rows_per_chunk = (int64_t)std::min<unsigned long long>((unsigned long long)n, 4 * (cap / (unsigned long long)m));
   rows_per_chunk = std::max<int64_t>(256, rows_per_chunk / 256 * 256);
   int64_t chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
   S2A_CHECK_ARG(chunks <= 512, "box_iou_rotated: workspace too small for %lld x %lld", (long long)n, (long long)m);
+  // Large outputs are write-bound (4 B per pair, ~1 % of DOTA-like pairs overlap): the zero-fill of the whole matrix
+  // runs on a side stream at the full store rate while this stream finds the overlapping pairs and evaluates them into a
+  // compact buffer; after the join a small kernel drops the values into place.  (Round 1 stored the zeros from the cull
+  // kernel -- 4 TB/s beside its circle tests -- and ran the dense pass after it: 212 us at 10 k x 10 k.)
+  const bool fork = (unsigned long long)n * (unsigned long long)m * 4ull >= kIouForkBytes;
+  SideStream* ss = nullptr;
+  std::unique_lock<std::mutex> lock(g_side_mutex, std::defer_lock);
+  if (fork) {
+    lock.lock();
+    int rc = side_stream(&ss);
+    if (rc != S2A_OK) return rc;
+    S2A_HIP(hipEventRecord(ss->fork, st));
+    S2A_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+    k_fill_zero<<<2048, 256, 0, ss->s>>>(ious, (unsigned long long)n * (unsigned long long)m);
+    S2A_HIP(hipEventRecord(ss->join, ss->s));
+  }
   k_prep_boxes2<<<(unsigned)((std::max<int64_t>(n + m, 512) + 255) / 256), 256, 0, st>>>(boxes1, n, P1, boxes2, m, P2, counters, 512);
   for (int64_t c = 0; c < chunks; c++) {
     int64_t r0 = c * rows_per_chunk, r1 = std::min(n, r0 + rows_per_chunk);
     dim3 grid((unsigned)((m + kThreads * 4 - 1) / (kThreads * 4)), (unsigned)((r1 - r0 + kIouRowsPerWg - 1) / kIouRowsPerWg));
-    k_iou_cull<<<grid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
-    k_iou_heavy<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
+    if (fork)
+      k_iou_cull<false><<<grid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
+    else
+      k_iou_cull<true><<<grid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
+    k_iou_heavy<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, gq, counters + c, cap, vals);
+    if (fork && c == 0) S2A_HIP(hipStreamWaitEvent(st, ss->join, 0));
+    k_iou_scatter<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap, vals);
   }
   S2A_LAUNCH_CHECK();
   return S2A_OK;
@@ -1337,38 +1689,30 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
   S2A_CHECK_ARG(dets && scores && segment_ids, "nms_rotated_segmented: NULL tensor");
   NmsPlan pl;
   S2A_CHECK_ARG(nms_plan(n, n, &pl) == 0, "nms_rotated_segmented: rocprim size query failed");
-  // the caller may have sized the workspace with a tighter per-segment bound: accept any
-  // workspace that holds the fixed part and give the rest to mask + pair list
+  // the caller may have sized the workspace with a tighter per-segment bound (s2a_nms_rotated_workspace_bytes(n,
+  // max_segment_rows)): accept any workspace that holds the fixed part and split the rest over the three lists --
+  // tiles, edges, pairs, each capped at what n rows in ONE segment could need.  A list that turns out too small is
+  // not an error: the direct greedy kernel then redoes the segments (slow, exact).
   Carver cv(workspace, workspace_bytes);
   NmsBuffers B;
-  NmsPlan fixed = pl;
-  fixed.queue_cap = 0;
-  fixed.mask_words = 0;
-  nms_carve(cv, n, fixed, &B);
-  if (cv.off + (1u << 20) > workspace_bytes) {
+  nms_carve_fixed(cv, n, pl, &B);
+  if (cv.off + (1u << 20) > workspace_bytes || !B.rp_temp) {
     set_error("nms_rotated_segmented: workspace too small (%zu bytes)", workspace_bytes);
     return S2A_EWORKSPACE;
   }
-  size_t rest = workspace_bytes - cv.off;
-  size_t want_q = (size_t)pl.queue_cap * sizeof(uint2),
-         want_m = (size_t)(pl.mask_words + occ_words_for(pl.mask_words, (unsigned long long)n)) * 8;
-  size_t qbytes = std::min(want_q, rest / 4);
-  qbytes = qbytes / 256 * 256;
-  size_t mbytes = std::min(want_m, (rest - qbytes) / 256 * 256);
+  size_t rest = (workspace_bytes - cv.off) / 256 * 256;
+  char* base = static_cast<char*>(workspace) + cv.off;
+  const size_t tbytes = std::min((size_t)pl.tile_cap * sizeof(TileRef), rest / 6) / 256 * 256;
+  const size_t ebytes = std::min((size_t)pl.edge_cap * sizeof(uint2), (rest - tbytes) / 3) / 256 * 256;
+  const size_t qbytes = std::min((size_t)pl.queue_cap * sizeof(uint2), rest - tbytes - ebytes) / 256 * 256;
+  pl.tile_cap = tbytes / sizeof(TileRef);
+  pl.edge_cap = ebytes / sizeof(uint2);
   pl.queue_cap = qbytes / sizeof(uint2);
-  {
-    // mbytes hold the mask AND its word-occupancy bitmap (mask_words / 64 + n + 64 words)
-    const unsigned long long W = mbytes / 8, fixed_occ = (unsigned long long)n + 64;
-    pl.mask_words = W > fixed_occ ? (W - fixed_occ) * 64 / 65 : 0;
-  }
-  B.gq = reinterpret_cast<uint2*>(static_cast<char*>(workspace) + cv.off);
-  B.mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + cv.off + qbytes);
-  B.occ = B.mask + pl.mask_words;
-  // the mask bound must cover n * ceil(max_seg/64): recover the implied max segment size
-  unsigned long long nb = pl.mask_words / (unsigned long long)n;
-  S2A_CHECK_ARG(nb >= 1, "nms_rotated_segmented: workspace too small for the suppression mask");
-  pl.max_blocks = (uint32_t)std::min<unsigned long long>(nb, ((unsigned long long)n + 63) / 64);
-  S2A_CHECK_ARG(((size_t)pl.max_blocks + 10 + kScanCacheWords) * 8 <= 112 * 1024, "nms_rotated_segmented: segment too large");
+  S2A_CHECK_ARG(pl.tile_cap >= 64 && pl.edge_cap >= 1024 && pl.queue_cap >= 1024,
+                "nms_rotated_segmented: workspace too small for the pair / edge / tile lists");
+  B.tiles = reinterpret_cast<TileRef*>(base);
+  B.edges = reinterpret_cast<uint2*>(base + tbytes);
+  B.gq = reinterpret_cast<uint2*>(base + tbytes + ebytes);
   int rc = nms_core(dets, scores, nullptr, segment_ids, group_ids, n, (uint32_t)num_segments,
                     (uint32_t)num_groups, iou_threshold, pl, B, st);
   if (rc != S2A_OK) return rc;

@@ -130,6 +130,135 @@ def test_nms_area_ratio_shortcut_is_exact(rng, thr):
     assert np.array_equal(k, ref)
 
 
+def test_nms_long_chain_needs_more_rounds_than_launched(rng):
+    """a chain of boxes in which every box overlaps only its successor above the threshold (shift 0.3 w: IoU 0.54 with
+    the next, 0.25 with the one after) and scores fall along the chain: the greedy result alternates keep / drop and the
+    decision of box k depends on box k - 1 -- hundreds of dependent rounds, far more than the launched ones, so the
+    single-workgroup clean-up kernel finishes it.  Several chains with different labels, some reversed (scores RISE
+    along the chain: everything but the ends of the overlaps is decided in the first round), plus random clutter."""
+    import s2anet_amd as S
+    boxes, scores, labels = [], [], []
+    for c, (length, rev) in enumerate([(700, False), (333, True), (64, False), (65, False), (2, False), (1500, False)]):
+        k = np.arange(length, dtype=np.float32)
+        b = np.stack([100 + 0.3 * 40 * k, np.full(length, 50.0 + 200 * c, np.float32), np.full(length, 40.0, np.float32),
+                      np.full(length, 20.0, np.float32), np.zeros(length, np.float32)], 1).astype(np.float32)
+        sc = np.linspace(0.9, 0.1, length).astype(np.float32) + np.float32(c) * np.float32(1e-4)
+        boxes.append(b), scores.append(sc[::-1] if rev else sc), labels.append(np.full(length, c % 3, np.float32))
+    clutter = rand_rboxes(rng, 2000, span=3000)
+    boxes.append(clutter), scores.append(rng.uniform(0.05, 0.95, 2000).astype(np.float32)), labels.append(rng.integers(0, 3, 2000).astype(np.float32))
+    d, s, lab = np.concatenate(boxes), np.concatenate(scores), np.concatenate(labels)
+    s = (s + np.arange(len(s), dtype=np.float32) * np.float32(1e-7)).astype(np.float32)      # distinct
+    assert len(np.unique(s)) == len(s)
+    keep = S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.5).cpu().numpy()
+    ref = oracle.ml_nms_rotated(d, s, lab, 0.5)
+    assert np.array_equal(keep, ref)
+    first = np.arange(700)
+    assert np.isin(first[::2], keep).all() and not np.isin(first[1::2], keep).any()          # the alternating pattern
+
+
+def test_nms_list_overflow_takes_the_direct_path(rng):
+    """a workspace sized for sparse segments (s2a_nms_rotated_workspace_bytes(n, 1)) on an input in which nearly every
+    pair overlaps: pair and edge lists overflow, the direct greedy kernel redoes the segments -- same keep flags as the
+    oracle, no error, nothing silently dropped"""
+    import ctypes
+    from s2anet_amd import _lib
+    L = _lib.lib()
+    n, nseg = 2500, 3
+    d = rand_rboxes(rng, n, span=60, lo=30, hi=80)                                           # everything piles up
+    s = distinct_scores(rng, n)
+    seg = rng.integers(0, nseg, n).astype(np.int32)
+    seg[rng.integers(0, n, 50)] = -1                                                         # some ignored rows
+    D, Sc, Sg = cu(d), cu(s), cu(seg)
+    flags = torch.zeros(n, dtype=torch.uint8, device=dev())
+    small = L.s2a_nms_rotated_workspace_bytes(n, 1)
+    big = L.s2a_nms_rotated_workspace_bytes(n, n)
+    assert small < big
+    out = {}
+    for name, nbytes in (("small", small), ("big", big)):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+        _lib.check(L.s2a_nms_rotated_segmented(_lib.ptr(D), _lib.ptr(Sc), _lib.ptr(Sg), None, n, nseg, 1, 0.3,
+                                               _lib.ptr(flags), None, None, 0, _lib.ptr(ws), ws.numel(),
+                                               _lib.stream_ptr(dev())))
+        out[name] = flags.cpu().numpy().astype(bool)
+    ref = np.zeros(n, bool)
+    for c in range(nseg):
+        idx = np.nonzero(seg == c)[0]
+        ref[idx[oracle.nms_rotated(d[idx], s[idx], 0.3)]] = True
+    assert np.array_equal(out["big"], ref) and np.array_equal(out["small"], ref)
+    assert ref.sum() < n // 10 and not ref[seg < 0].any()
+
+
+@pytest.mark.parametrize("thr", [0.1, 0.3, 0.5, 0.75])
+def test_nms_iou_upper_bound_prefilter_is_exact(rng, thr):
+    """pairs whose IoU sits right at the threshold, where the projected-overlap bound is tight (same-size boxes shifted
+    along an edge, slightly rotated, nested boxes, crosses): the pre-filter (rbox_geom.hpp:nms_pair_skippable) may only
+    drop pairs that the full evaluation would not have suppressed -> keep lists identical to the oracle"""
+    import s2anet_amd as S
+    m = 1500
+    w, h = rng.uniform(10, 60, m).astype(np.float32), rng.uniform(10, 60, m).astype(np.float32)
+    cx, cy = (np.arange(m) % 40 * 200.0).astype(np.float32), (np.arange(m) // 40 * 200.0).astype(np.float32)
+    ang = rng.uniform(-0.7, 2.3, m).astype(np.float32)
+    a = np.stack([cx, cy, w, h, ang], 1)
+    # partner: shifted along the box's own w axis so that the IoU of two equal boxes, (w - t) / (w + t), lands within
+    # +-2 % of thr; a third of them also shrunk (nested: IoU = area ratio) or turned by a small angle
+    eps = rng.uniform(-0.02, 0.02, m).astype(np.float32)
+    t = w * (1 - thr * (1 + eps)) / (1 + thr * (1 + eps))
+    b = a.copy()
+    b[:, 0] += t * np.cos(ang)
+    b[:, 1] += t * np.sin(ang)
+    kind = np.arange(m) % 3
+    nest = kind == 1
+    b[nest, :2] = a[nest, :2]
+    b[nest, 2] = a[nest, 2] * np.sqrt(thr * (1 + eps[nest]))
+    b[nest, 3] = a[nest, 3] * np.sqrt(thr * (1 + eps[nest]))
+    b[kind == 2, 4] += rng.uniform(-0.05, 0.05, int((kind == 2).sum())).astype(np.float32)
+    d = np.concatenate([a, b]).astype(np.float32)
+    s = distinct_scores(rng, 2 * m)
+    lab = np.zeros(2 * m, np.float32)
+    keep = S.ml_nms_rotated(cu(d), cu(s), cu(lab), thr).cpu().numpy()
+    ref = oracle.ml_nms_rotated(d, s, lab, thr)
+    assert np.array_equal(keep, ref)
+    assert m + m // 4 < len(ref) < 2 * m - m // 4                                            # both outcomes occur often
+
+
+def test_nms_spatial_filter_degenerate_geometry(rng):
+    """the block bounding-box filter must never drop a pair the reference would evaluate: all centres identical
+    (zero-size bounding box), a huge coordinate range with a dense cluster in one Morton cell, non-finite boxes (a NaN
+    IoU never suppresses, as in the reference), one row per segment, and boxes much larger than the blocks' extent"""
+    import s2anet_amd as S
+    # identical centres, different sizes / angles
+    n = 700
+    d = rand_rboxes(rng, n, span=1.0)
+    d[:, :2] = 512.0
+    s, lab = distinct_scores(rng, n), rng.integers(0, 2, n).astype(np.float32)
+    assert np.array_equal(S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.5).cpu().numpy(), oracle.ml_nms_rotated(d, s, lab, 0.5))
+    # one far outlier stretches the quantisation grid: the cluster collapses into a single cell
+    d = rand_rboxes(rng, 3000, span=300)
+    d[0, :2] = 1e7
+    s, lab = distinct_scores(rng, 3000), rng.integers(0, 4, 3000).astype(np.float32)
+    assert np.array_equal(S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.4).cpu().numpy(), oracle.ml_nms_rotated(d, s, lab, 0.4))
+    # non-finite rows: kept (nothing can suppress them, they suppress nothing)
+    d = rand_rboxes(rng, 500, span=100)
+    d[5, 0], d[17, 2], d[40, 4], d[77, 1] = np.nan, np.nan, np.nan, np.inf
+    s, lab = distinct_scores(rng, 500), np.zeros(500, np.float32)
+    keep = S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.3).cpu().numpy()
+    ok = np.ones(500, bool)
+    ok[[5, 17, 40, 77]] = False
+    ref = oracle.ml_nms_rotated(d[ok], s[ok], lab[ok], 0.3)
+    assert np.isin([5, 17, 40, 77], keep).all()
+    assert np.array_equal(keep[~np.isin(keep, [5, 17, 40, 77])], np.nonzero(ok)[0][ref])
+    # every row its own label: nothing is ever compared
+    d = rand_rboxes(rng, 300, span=20)
+    s, lab = distinct_scores(rng, 300), np.arange(300, dtype=np.float32)
+    keep = S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.1).cpu().numpy()
+    assert np.array_equal(keep, np.argsort(-s, kind="stable"))
+    # boxes far larger than a block's extent, single class (nms_rotated)
+    d = rand_rboxes(rng, 2000, span=2000, lo=200, hi=1500)
+    s = distinct_scores(rng, 2000)
+    from s2anet_amd.rotated import nms_rotated_raw
+    assert np.array_equal(nms_rotated_raw(cu(d), cu(s), 0.6).cpu().numpy(), oracle.nms_rotated(d, s, 0.6))
+
+
 def test_nms_four_box_case_and_wrapper_quirks():
     import s2anet_amd as S
     from s2anet_amd.rotated import nms_rotated_raw
