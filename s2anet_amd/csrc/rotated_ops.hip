@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 
@@ -244,6 +245,15 @@ __global__ __launch_bounds__(kThreads) void k_iou_scatter(const PreBox* __restri
     const uint2 ij = gq[e];
     out[(row0 + ij.x) * m + ij.y] = vals[e];
   }
+}
+
+// small fills by a kernel: hipMemsetAsync nodes of a captured graph were not replayed correctly (ROCm 7.2; see nms_core)
+__global__ void k_fill_u32(uint32_t* __restrict__ p, uint32_t v, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) p[i] = v;
+}
+inline void fill_u32(void* p, uint32_t v, size_t count, hipStream_t st) {
+  if (count) k_fill_u32<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(static_cast<uint32_t*>(p), v, count);
 }
 
 // 16 bytes per lane, grid-stride: 7 TB/s on MI355X (profiles/r02_nms_200k_pmc_before.txt, k_zero_words)
@@ -600,14 +610,16 @@ __global__ void k_nms_seg_sizes(const uint32_t* __restrict__ seg_start,
 }
 
 // device-side scalars of one call
-struct NmsCounters {
+struct NmsCounters {              // (everything in front of bbox is zeroed, bbox initialised, by k_nms_init_slots)
   unsigned long long pairs;      // cull survivors (true total, may exceed the list)
   unsigned long long edges;      // pairs with IoU > thr (true total)
   unsigned long long tiles;      // tiles that passed the filter (true total)
   unsigned long long alive_list; // edges handed to the clean-up kernel
   uint32_t status;               // bit 0: a list overflowed -> direct greedy fallback ran
-  uint32_t bbox[4];              // min x, min y (init 0xffffffff), max x, max y (init 0) of the centres, sortable
   uint32_t alive[16];            // edges still between two unsettled rows after round r
+  uint32_t bbox[64][4];          // 64 partial {min x, min y (init 0xffffffff), max x, max y (init 0)} of the centres, as
+                                 // order-preserving integers; a workgroup adds to slot blockIdx % 64 (one address for
+                                 // all 3 k waves of a 200 k-row call serialised the atomics: 147 us)
 };
 
 // rows in (segment, score) order: pre-processed boxes (label slot = segment index), initial state, bounding box of
@@ -633,8 +645,9 @@ __global__ void k_nms_pos_meta(const float* __restrict__ dets5, const int32_t* _
     hx = max(hx, (uint32_t)__shfl_xor((int)hx, o)); hy = max(hy, (uint32_t)__shfl_xor((int)hy, o));
   }
   if ((threadIdx.x & 63) == 0) {
-    if (lx != 0xffffffffu) { atomicMin(&C->bbox[0], lx); atomicMax(&C->bbox[2], hx); }
-    if (ly != 0xffffffffu) { atomicMin(&C->bbox[1], ly); atomicMax(&C->bbox[3], hy); }
+    uint32_t* bb = C->bbox[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63];
+    if (lx != 0xffffffffu) { atomicMin(&bb[0], lx); atomicMax(&bb[2], hx); }
+    if (ly != 0xffffffffu) { atomicMin(&bb[1], ly); atomicMax(&bb[3], hy); }
   }
 }
 
@@ -651,10 +664,17 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every
 __global__ void k_nms_spkeys(const PreBox* __restrict__ sorted, const NmsCounters* __restrict__ C, int64_t n,
                              unsigned long long* __restrict__ key3, uint32_t* __restrict__ val) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t s_bb[4];
+  if (threadIdx.x < 4) {
+    uint32_t v = C->bbox[0][threadIdx.x];
+    for (int k = 1; k < 64; k++) v = threadIdx.x < 2 ? min(v, C->bbox[k][threadIdx.x]) : max(v, C->bbox[k][threadIdx.x]);
+    s_bb[threadIdx.x] = v;
+  }
+  __syncthreads();
   if (p >= n) return;
   const PreBox b = sorted[p];
-  const float x0 = sortable_float(C->bbox[0]), y0 = sortable_float(C->bbox[1]);
-  const float x1 = sortable_float(C->bbox[2]), y1 = sortable_float(C->bbox[3]);
+  const float x0 = sortable_float(s_bb[0]), y0 = sortable_float(s_bb[1]);
+  const float x1 = sortable_float(s_bb[2]), y1 = sortable_float(s_bb[3]);
   const float sx = x1 > x0 ? 1023.f / (x1 - x0) : 0.f, sy = y1 > y0 ? 1023.f / (y1 - y0) : 0.f;
   float qx = (b.x - x0) * sx, qy = (b.y - y0) * sy;
   qx = qx >= 0.f ? fminf(qx, 1023.f) : 0.f;      // NaN -> 0
@@ -721,9 +741,11 @@ __global__ void k_nms_spgather(const PreBox* __restrict__ sorted, const uint32_t
 }
 
 __global__ void k_nms_init_slots(uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots,
-                                 NmsCounters* __restrict__ C) {
+                                 NmsCounters* __restrict__ C, uint8_t* __restrict__ blocked, size_t nblocked) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) { C->bbox[0] = C->bbox[1] = 0xffffffffu; C->bbox[2] = C->bbox[3] = 0u; }   // (after the memset of C)
+  if (i < offsetof(NmsCounters, bbox) / 4) reinterpret_cast<uint32_t*>(C)[i] = 0u;      // counters, status, alive[]
+  if (i < nblocked) blocked[i] = 0;
+  if (i < 64) { C->bbox[i][0] = C->bbox[i][1] = 0xffffffffu; C->bbox[i][2] = C->bbox[i][3] = 0u; }
   if (i >= slots) return;
   lo[i] = make_uint2(0xffffffffu, 0xffffffffu);
   hi[i] = make_uint2(0u, 0u);
@@ -737,6 +759,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_tile_filter(const uint32_t* __
                                                               const uint2* __restrict__ lo, const uint2* __restrict__ hi,
                                                               TileRef* __restrict__ tiles, NmsCounters* __restrict__ C,
                                                               unsigned long long tile_cap) {
+  __shared__ unsigned s_w[kThreads / 64];
+  __shared__ unsigned long long s_base;
   const uint32_t S = *num_seg;
   const unsigned long long T = tile_off[S];
   const int lane = threadIdx.x & 63;
@@ -751,16 +775,21 @@ __global__ __launch_bounds__(kThreads) void k_nms_tile_filter(const uint32_t* __
       const uint2 la = lo[a], ha = hi[a], lb = lo[b], hb = hi[b];
       take = tr.rb == tr.cb || (la.x <= hb.x && lb.x <= ha.x && la.y <= hb.y && lb.y <= ha.y);
     }
+    // one global atomic per workgroup and sweep (one per wave put ~5 k atomics on a single address: 40 us)
     const unsigned long long bal = __ballot(take);
-    if (bal) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(&C->tiles, (unsigned long long)__popcll(bal));
-      base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
-      if (take) {
-        const unsigned long long dst = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (dst < tile_cap) tiles[dst] = tr;
-      }
+    if (lane == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned tot = 0;
+      for (int w = 0; w < kThreads / 64; w++) { const unsigned c = s_w[w]; s_w[w] = tot; tot += c; }
+      s_base = tot ? atomicAdd(&C->tiles, (unsigned long long)tot) : 0ull;
     }
+    __syncthreads();
+    if (take) {
+      const unsigned long long dst = s_base + s_w[threadIdx.x >> 6] + __popcll(bal & ((1ull << lane) - 1ull));
+      if (dst < tile_cap) tiles[dst] = tr;
+    }
+    __syncthreads();
   }
 }
 
@@ -849,14 +878,28 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
   queue_flush(Q, gq, gcount, cap);
 }
 
-// DENSE IoU pass: one pair per lane; pairs above the threshold become edges (wave-aggregated append)
+// DENSE IoU pass: one pair per lane; pairs above the threshold become edges.  Every wave stages its edges in a private
+// LDS buffer and publishes them with ONE global atomic per flush (an atomic per wave and sweep -- ~20 k on one address at
+// 200 k rows -- made the pass atomic-bound); a wave is synchronous, so the staging needs no barrier.
+constexpr int kEdgeStage = 128;      // staged edges per wave (1 KB: 48 + 4 KB of LDS keep three workgroups per CU)
 __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict__ sorted, float thr,
                                                         const uint2* __restrict__ gq, NmsCounters* __restrict__ C,
                                                         unsigned long long cap, uint2* __restrict__ edges,
                                                         unsigned long long ecap) {
   __shared__ float2 s_pts[24 * kThreads];
+  __shared__ uint2 s_stage[kThreads / 64][kEdgeStage];
   const unsigned long long total = min(C->pairs, cap);
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint2* stage = s_stage[wave];
+  unsigned staged = 0;                 // wave-uniform
+  auto flush = [&]() {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&C->edges, (unsigned long long)staged);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+    for (unsigned k = lane; k < staged; k += 64)
+      if (base + k < ecap) edges[base + k] = stage[k];
+    staged = 0;
+  };
   const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
   for (unsigned long long e0 = (unsigned long long)blockIdx.x * kThreads; e0 < total; e0 += stride) {
     const unsigned long long e = e0 + threadIdx.x;
@@ -869,16 +912,11 @@ __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict
       hit = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x) > thr;  // reference GPU rule: strict (ml_nms cuda.cu:63-64)
     }
     const unsigned long long bal = __ballot(hit);
-    if (bal) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(&C->edges, (unsigned long long)__popcll(bal));
-      base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
-      if (hit) {
-        const unsigned long long dst = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (dst < ecap) edges[dst] = ij;
-      }
-    }
+    if (hit) stage[staged + __popcll(bal & ((1ull << lane) - 1ull))] = ij;
+    staged += (unsigned)__popcll(bal);
+    if (staged + 64 > kEdgeStage) flush();
   }
+  if (staged) flush();
 }
 
 // ---------------------------------------------------------------- greedy order by rounds over the edge list
@@ -887,7 +925,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict
 // in-neighbours are removed).  Round r reads the round r-1 view and writes the round r one; the two blocked arrays
 // alternate so that a round never overwrites the marks it reads.  Rows that nobody blocks any more stay kept without
 // ever being touched again, so nothing has to be materialised between rounds.
-constexpr int kNmsRounds = 6;       // launched rounds (4-6 settle random and detector-like inputs); the rest: clean-up kernel
+constexpr int kNmsRounds = 8;       // launched rounds (4-6 settle detector-like inputs, 7-8 the longest chains among 200 k
+                                    // random rows); the rest: clean-up kernel
 enum : uint32_t { kOpen = 0, kKept = 1, kRemoved = 2 };
 
 __device__ __forceinline__ uint32_t nms_view(const uint8_t* __restrict__ state, const uint8_t* __restrict__ blocked,
@@ -904,7 +943,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_round(const uint2* __restrict_
                                                         unsigned long long ecap, uint8_t* __restrict__ state,
                                                         uint8_t* __restrict__ blocked, int64_t n, int r,
                                                         uint2* __restrict__ alive_list, unsigned long long alive_cap) {
-  if (r > 1 && C->alive[r - 1] == 0) return;                  // settled already
+  if (r > 1 && C->alive[r - 1] == 0) return;                  // settled already (uniform: before any barrier)
   const unsigned long long E = min(C->edges, ecap);
   unsigned cnt = 0;
   const int lane = threadIdx.x & 63;
@@ -938,13 +977,32 @@ __global__ __launch_bounds__(kThreads) void k_nms_round(const uint2* __restrict_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  if (lane == 0 && cnt) atomicAdd(&C->alive[r], cnt);
+  __shared__ unsigned s_cnt[kThreads / 64];
+  if (lane == 0) s_cnt[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {               // one atomic per workgroup
+    unsigned tot = 0;
+    for (int w = 0; w < kThreads / 64; w++) tot += s_cnt[w];
+    if (tot) atomicAdd(&C->alive[r], tot);
+  }
 }
 
+// writes the implicit "open and not blocked == kept" view after the last launched round out as explicit states (only
+// when the clean-up kernel has work to do); array 0 of `blocked` becomes the plain "blocked this round" flag
+__global__ void k_nms_materialize(const NmsCounters* __restrict__ C, uint8_t* __restrict__ state,
+                                  uint8_t* __restrict__ blocked, int64_t n) {
+  if (C->alive[kNmsRounds] == 0) return;
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t v = nms_view(state, blocked, n, kNmsRounds, (uint32_t)p);
+  blocked[p] = 0;            // (kNmsRounds is even: the view reads array 0 at this very index, before the write)
+  if (v == kKept) state[p] = (uint8_t)kKept;
+}
+static_assert(kNmsRounds % 2 == 0 && kNmsRounds < 15, "k_nms_materialize / NmsCounters::alive assume this");
+
 // CLEAN-UP: chains longer than the launched rounds (rare; adversarially long alternating chains): ONE workgroup goes on
-// with the edges that were still alive after the last launched round.  It first writes the implicit "open and not
-// blocked == kept" view out as explicit states, so that no round stamp is needed from here on, and then runs classic
-// rounds with barriers: (A) kept source -> target removed, (B) open source and open target -> target blocked,
+// with the edges that were still alive after the last launched round.  k_nms_materialize has written the implicit view
+// out as explicit states, so no round stamp is needed from here on; classic rounds with barriers: (A) kept source -> target removed, (B) open source and open target -> target blocked,
 // (C) open and not blocked -> kept, (D) drop the edges whose target is settled or whose source is removed (in place: a
 // survivor is always written at or before its own slot) -- until the list is empty.  Every open row always has an
 // in-edge in the list from an open or kept row, so (C) reaches it; at the end no row is open.
@@ -955,11 +1013,6 @@ __global__ __launch_bounds__(1024) void k_nms_cleanup(NmsCounters* __restrict__ 
   if (C->alive[kNmsRounds] == 0) return;
   __shared__ unsigned s_wave[16], s_tot;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t p = threadIdx.x; p < n; p += 1024) {
-    const uint32_t v = nms_view(state, blocked, n, kNmsRounds, (uint32_t)p);
-    blocked[p] = 0;                           // array 0 becomes the plain "blocked this round" flag
-    if (v == kKept) state[p] = (uint8_t)kKept;
-  }
   // the list overflowed (more alive edges than the buffer): walk ALL edges every round instead, without compaction
   const bool all = C->alive_list > list_cap;
   const uint2* src = all ? edges : list;
@@ -1214,10 +1267,10 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   rpb = pl.rocprim_bytes;
   S2A_HIP(rocprim::exclusive_scan(B.rp_temp, rpb, B.tiles_per_seg, B.tile_off, 0ull, sz + 1,
                                   rocprim::plus<unsigned long long>(), st));
-  S2A_HIP(hipMemsetAsync(B.C, 0, sizeof(NmsCounters), st));
-  S2A_HIP(hipMemsetAsync(B.blocked, 0, 2 * sz, st));
+  // (zeroed by kernels, not hipMemsetAsync: memset nodes of a captured graph were not replayed correctly from the second
+  // launch on with ROCm 7.2 -- counters kept their old values; tests/test_gpu_e2e.py::test_detect_hip_graph_replay_equals_eager)
   const size_t slots = block_slots_for(sz);
-  k_nms_init_slots<<<grid_for((int64_t)slots), 256, 0, st>>>(B.lo, B.hi, slots, B.C);
+  k_nms_init_slots<<<grid_for((int64_t)std::max(slots, 2 * sz)), 256, 0, st>>>(B.lo, B.hi, slots, B.C, B.blocked, 2 * sz);
   k_nms_pos_meta<<<g, 256, 0, st>>>(dets, B.perm_seg, B.segidx1, B.nblk, n, B.sorted, B.state, B.C);
   // spatial order inside every segment (key1a and idxa are free again)
   uint32_t* val3a = reinterpret_cast<uint32_t*>(B.idxa);
@@ -1232,8 +1285,9 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   k_nms_heavy<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
   // the pair list is dead after the dense pass: its memory takes the alive-edge list of the last launched round
   for (int r = 1; r <= kNmsRounds; r++)
-    k_nms_round<<<512, kThreads, 0, st>>>(B.edges, B.C, pl.edge_cap, B.state, B.blocked, n, r,
+    k_nms_round<<<256, kThreads, 0, st>>>(B.edges, B.C, pl.edge_cap, B.state, B.blocked, n, r,
                                           r == kNmsRounds ? B.gq : nullptr, pl.queue_cap);
+  k_nms_materialize<<<g, 256, 0, st>>>(B.C, B.state, B.blocked, n);
   k_nms_cleanup<<<1, 1024, 0, st>>>(B.C, B.state, B.blocked, n, B.gq, pl.queue_cap, B.edges, pl.edge_cap);
   k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.nblk, B.C, pl.queue_cap, pl.edge_cap,
                                                 pl.tile_cap, B.state, thr);
@@ -1366,7 +1420,7 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   // rows per chunk: sized for up to 1/4 of the pairs surviving the cull (DOTA-like inputs: ~1 %);
   // a denser chunk overflows the list and is recomputed pair by pair in k_iou_scatter
   int64_t rows_per_chunk = (int64_t)std::min<unsigned long long>((unsigned long long)n, 4 * (cap / (unsigned long long)m));
-  rows_per_chunk = std::max<int64_t>(256, rows_per_chunk / 256 * 256);
+  if (rows_per_chunk < n) rows_per_chunk = std::max<int64_t>(256, rows_per_chunk / 256 * 256);   // (else: one chunk)
   int64_t chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
   S2A_CHECK_ARG(chunks <= 512, "box_iou_rotated: workspace too small for %lld x %lld", (long long)n, (long long)m);
   // Large outputs are write-bound (4 B per pair, ~1 % of DOTA-like pairs overlap): the zero-fill of the whole matrix
@@ -1533,14 +1587,14 @@ extern "C" int s2a_assign_labels(const float* anchors, int64_t num_anchors, cons
   }
   int rc = s2a_box_iou_rotated(anchors, M, gt_boxes, N, ious, iw, iou_ws, stream);
   if (rc != S2A_OK) return rc;
-  S2A_HIP(hipMemsetAsync(gt_key, 0, (size_t)N * 4, st));
+  fill_u32(gt_key, 0u, (size_t)N, st);
   const unsigned gr = (unsigned)((M + 3) / 4);
   k_assign_rows<<<gr, 256, 0, st>>>(anchors, ious, M, N, img_h, img_w, pos_iou_thr, neg_iou_thr, filter_invalid_anchors,
                                     filter_invalid_ious, assign_gt_ids);
   dim3 gc((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256));
   k_assign_colmax<<<gc, 64, 0, st>>>(ious, M, N, gt_key);
   if (!gt_max_assign_all) {
-    S2A_HIP(hipMemsetAsync(gt_arg, 0x7f, (size_t)N * 4, st));
+    fill_u32(gt_arg, 0x7f7f7f7fu, (size_t)N, st);
     k_assign_colarg<<<gc, 64, 0, st>>>(ious, M, N, gt_key, gt_arg);
   }
   k_assign_cols<<<gr, 256, 0, st>>>(ious, M, N, min_pos_iou_thr, gt_key, gt_max_assign_all ? nullptr : gt_arg, assign_gt_ids);
@@ -1564,11 +1618,86 @@ extern "C" int s2a_box_iou_rotated_pairs(const float* boxes1, const float* boxes
 // `cap` slots; unused slots are padding rows (segment id -1, ignored by the segmented NMS).
 namespace s2a {
 namespace {
-struct ScoreAbove {
-  const float* s;
-  float thr;
-  __device__ uint8_t operator()(int i) const { return s[i] > thr ? 1 : 0; }
-};
+// Ordered compaction of the flat indices with score > thr (row-major order == the reference's boolean-mask order,
+// utils/bbox_nms_rotated.py:29-40), three plain kernels: per-block counts, scan of the block counts by one workgroup,
+// ordered scatter.  (rocprim::select did this in round 1; its partition kernel takes a by-value closure argument that
+// the ROCm 7.2 runtime mishandles when a captured HIP graph containing it is replayed a second time inside a larger
+// graph -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; detect() has to
+// replay from a graph, so the capturable path does not go through it.)
+constexpr int kCandItems = 8, kCandBlock = 256 * kCandItems;
+
+__device__ __forceinline__ unsigned cand_flags(const float* __restrict__ scores, float thr, int64_t base, int64_t total) {
+  unsigned f = 0;
+#pragma unroll
+  for (int k = 0; k < kCandItems; k++)
+    if (base + k < total && scores[base + k] > thr) f |= 1u << k;
+  return f;
+}
+
+__global__ __launch_bounds__(256) void k_cand_count(const float* __restrict__ scores, float thr, int64_t total,
+                                                    uint32_t* __restrict__ block_cnt) {
+  __shared__ unsigned s_w[4];
+  const int64_t base = (int64_t)blockIdx.x * kCandBlock + (int64_t)threadIdx.x * kCandItems;
+  unsigned c = __popc(cand_flags(scores, thr, base, total));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of nb block counts in place (one workgroup, 1024 per sweep with a running carry); total -> count
+__global__ __launch_bounds__(1024) void k_cand_scan(uint32_t* __restrict__ block_cnt, int64_t nb,
+                                                    unsigned long long* __restrict__ count) {
+  __shared__ unsigned s_w[16];
+  __shared__ unsigned long long s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+    const int64_t b = b0 + threadIdx.x;
+    const unsigned v = b < nb ? block_cnt[b] : 0u;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += s_w[w];
+    const unsigned long long carry = s_carry;
+    if (b < nb) block_cnt[b] = (uint32_t)(carry + wbase + incl - v);     // < 2^31 (total is)
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_cand_scatter(const float* __restrict__ scores, float thr, int64_t total,
+                                                      const uint32_t* __restrict__ block_off,
+                                                      int32_t* __restrict__ sel) {
+  __shared__ unsigned s_w[4];
+  const int64_t base = (int64_t)blockIdx.x * kCandBlock + (int64_t)threadIdx.x * kCandItems;
+  const unsigned f = cand_flags(scores, thr, base, total);
+  const unsigned c = __popc(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  unsigned off = block_off[blockIdx.x] + incl - c;
+  for (int w = 0; w < wave; w++) off += s_w[w];
+#pragma unroll
+  for (int k = 0; k < kCandItems; k++)
+    if (f & (1u << k)) sel[off++] = (int32_t)(base + k);
+}
 
 __global__ void k_gather_candidates(const float* __restrict__ boxes5, const float* __restrict__ scores,
                                     const int32_t* __restrict__ sel, const unsigned long long* __restrict__ count,
@@ -1593,16 +1722,8 @@ __global__ void k_gather_candidates(const float* __restrict__ boxes5, const floa
 }  // namespace s2a
 
 extern "C" size_t s2a_multiclass_candidates_workspace_bytes(int64_t total) {
-  size_t tb = 0;
-  hipStream_t s0 = nullptr;
-  int32_t* i32 = nullptr;
-  unsigned long long* cnt = nullptr;
-  uint8_t* f = nullptr;
-  if (rocprim::select(nullptr, tb, i32, f, i32, cnt, (size_t)std::max<int64_t>(total, 1), s0) != hipSuccess) {
-    (void)hipGetLastError();
-    tb = (size_t)total * 8 + (1u << 20);
-  }
-  return align_up(tb) + align_up((size_t)total * 4) + align_up((size_t)total) + 1024;
+  const size_t t = (size_t)std::max<int64_t>(total, 1);
+  return align_up(t * 4) + align_up(((t + kCandBlock - 1) / kCandBlock + 1) * 4) + 1024;
 }
 
 extern "C" int s2a_multiclass_candidates(const float* boxes, const float* scores, int64_t batch,
@@ -1616,31 +1737,23 @@ extern "C" int s2a_multiclass_candidates(const float* boxes, const float* scores
   S2A_CHECK_ARG(out_boxes && out_scores && out_seg && out_grp && out_cls && count_dev, "multiclass_candidates: NULL output");
   hipStream_t st = as_stream(stream);
   if (total == 0) {
-    S2A_HIP(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
-    S2A_HIP(hipMemsetAsync(out_seg, 0xff, (size_t)cap * 4, st));
-    S2A_HIP(hipMemsetAsync(out_grp, 0xff, (size_t)cap * 4, st));
+    fill_u32(count_dev, 0u, 2, st);
+    fill_u32(out_seg, 0xffffffffu, (size_t)cap, st);
+    fill_u32(out_grp, 0xffffffffu, (size_t)cap, st);
     return S2A_OK;
   }
   S2A_CHECK_ARG(boxes && scores, "multiclass_candidates: NULL input");
   Carver cv(workspace, workspace_bytes);
+  const int64_t nb = (total + kCandBlock - 1) / kCandBlock;
   int32_t* sel = cv.take<int32_t>((size_t)total);
-  size_t tb = 0;
-  {
-    hipStream_t s0 = nullptr;
-    int32_t* i32 = nullptr;
-    unsigned long long* cnt = nullptr;
-    uint8_t* f = nullptr;
-    S2A_HIP(rocprim::select(nullptr, tb, i32, f, i32, cnt, (size_t)total, s0));
-  }
-  char* temp = cv.take<char>(tb);
-  if (!sel || !temp) {
+  uint32_t* blk = cv.take<uint32_t>((size_t)nb + 1);
+  if (!sel || !blk) {
     set_error("multiclass_candidates: workspace too small (%zu bytes)", workspace_bytes);
     return S2A_EWORKSPACE;
   }
-  rocprim::counting_iterator<int32_t> ids(0);
-  auto flags = rocprim::make_transform_iterator(ids, ScoreAbove{scores, score_thr});
-  S2A_HIP(rocprim::select(temp, tb, ids, flags, sel, reinterpret_cast<unsigned long long*>(count_dev),
-                          (size_t)total, st));
+  k_cand_count<<<(unsigned)nb, 256, 0, st>>>(scores, score_thr, total, blk);
+  k_cand_scan<<<1, 1024, 0, st>>>(blk, nb, reinterpret_cast<unsigned long long*>(count_dev));
+  k_cand_scatter<<<(unsigned)nb, 256, 0, st>>>(scores, score_thr, total, blk, sel);
   k_gather_candidates<<<(unsigned)((cap + 255) / 256), 256, 0, st>>>(
       boxes, scores, sel, reinterpret_cast<const unsigned long long*>(count_dev), cap, (int)n,
       (int)num_classes, out_boxes, out_scores, out_seg, out_grp, out_cls);
@@ -1681,8 +1794,8 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
                 "nms_rotated_segmented: keep needs group_counts and max_per_group");
   if (n == 0) {
     if (keep) {
-      S2A_HIP(hipMemsetAsync(keep, 0xff, (size_t)num_groups * max_per_group * sizeof(int32_t), st));
-      S2A_HIP(hipMemsetAsync(group_counts, 0, (size_t)num_groups * sizeof(int32_t), st));
+      fill_u32(keep, 0xffffffffu, (size_t)num_groups * max_per_group, st);
+      fill_u32(group_counts, 0u, (size_t)num_groups, st);
     }
     return S2A_OK;
   }
@@ -1696,7 +1809,7 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
   Carver cv(workspace, workspace_bytes);
   NmsBuffers B;
   nms_carve_fixed(cv, n, pl, &B);
-  if (cv.off + (1u << 20) > workspace_bytes || !B.rp_temp) {
+  if (cv.off + (48u << 10) > workspace_bytes || !B.rp_temp) {
     set_error("nms_rotated_segmented: workspace too small (%zu bytes)", workspace_bytes);
     return S2A_EWORKSPACE;
   }

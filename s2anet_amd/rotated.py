@@ -232,8 +232,8 @@ def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, 
     ok = keep >= 0
     kidx = keep.clamp(min=0).to(torch.int64)
     dets = torch.cat([cboxes[kidx], cscores[kidx][..., None]], dim=-1)
-    dets = torch.where(ok[..., None], dets, torch.zeros_like(dets))
-    labels = torch.where(ok, cls[kidx], torch.full_like(keep, -1))
+    dets = torch.where(ok[..., None], dets, 0.0)        # (scalars: no zeros_like / memset node in a captured graph)
+    labels = torch.where(ok, cls[kidx], -1)
     if return_overflow:
         return dets, labels, counts, torch.cat([ncand, (ncand - cap).clamp_(min=0)])
     return dets, labels, counts
