@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -626,13 +627,19 @@ struct NmsCounters {              // (everything in front of bbox is zeroed, bbo
 // all finite centres (for the Morton quantisation)
 __global__ void k_nms_pos_meta(const float* __restrict__ dets5, const int32_t* __restrict__ perm_seg,
                                const uint32_t* __restrict__ segidx1, const uint32_t* __restrict__ nblk, int64_t n,
-                               PreBox* __restrict__ sorted, uint8_t* __restrict__ state, NmsCounters* __restrict__ C) {
+                               PreBox* __restrict__ sorted, uint8_t* __restrict__ state, NmsCounters* __restrict__ C,
+                               PreBox* __restrict__ sp_box_identity) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t lx = 0xffffffffu, ly = 0xffffffffu, hx = 0u, hy = 0u;
   if (p < n) {
     const uint32_t s = segidx1[p] - 1;
     const float* b = dets5 + 5 * (int64_t)perm_seg[p];
-    sorted[p] = make_prebox(b[0], b[1], b[2], b[3], b[4], __uint_as_float(s));
+    PreBox pb = make_prebox(b[0], b[1], b[2], b[3], b[4], __uint_as_float(s));
+    sorted[p] = pb;
+    if (sp_box_identity) {                       // small segments: no spatial order, blocks in score order
+      pb.label = __uint_as_float((uint32_t)p);
+      sp_box_identity[p] = pb;
+    }
     state[p] = nblk[s] == 0 ? 2 : 0;             // rows of the ignored segment are never kept
     if (isfinite(b[0]) && isfinite(b[1])) {
       lx = hx = float_sortable(b[0]);
@@ -741,12 +748,14 @@ __global__ void k_nms_spgather(const PreBox* __restrict__ sorted, const uint32_t
 }
 
 __global__ void k_nms_init_slots(uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots,
-                                 NmsCounters* __restrict__ C, uint8_t* __restrict__ blocked, size_t nblocked) {
+                                 NmsCounters* __restrict__ C, uint8_t* __restrict__ blocked, size_t nblocked,
+                                 uint32_t* __restrict__ seg_cnt, size_t nseg_cnt) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < offsetof(NmsCounters, bbox) / 4) reinterpret_cast<uint32_t*>(C)[i] = 0u;      // counters, status, alive[]
   if (i < nblocked) blocked[i] = 0;
+  if (i < nseg_cnt) seg_cnt[i] = 0u;
   if (i < 64) { C->bbox[i][0] = C->bbox[i][1] = 0xffffffffu; C->bbox[i][2] = C->bbox[i][3] = 0u; }
-  if (i >= slots) return;
+  if (i >= slots || !lo) return;
   lo[i] = make_uint2(0xffffffffu, 0xffffffffu);
   hi[i] = make_uint2(0u, 0u);
 }
@@ -771,9 +780,12 @@ __global__ __launch_bounds__(kThreads) void k_nms_tile_filter(const uint32_t* __
     if (t < T) {
       uint32_t sidx = 0;
       tr = locate_tile(t, tile_off, seg_start, S, &sidx);
-      const uint32_t a = block_slot(tr.seg_start, sidx, tr.rb), b = block_slot(tr.seg_start, sidx, tr.cb);
-      const uint2 la = lo[a], ha = hi[a], lb = lo[b], hb = hi[b];
-      take = tr.rb == tr.cb || (la.x <= hb.x && lb.x <= ha.x && la.y <= hb.y && lb.y <= ha.y);
+      take = true;                                  // (lo == nullptr: no spatial order, every tile is tested)
+      if (lo && tr.rb != tr.cb) {
+        const uint32_t a = block_slot(tr.seg_start, sidx, tr.rb), b = block_slot(tr.seg_start, sidx, tr.cb);
+        const uint2 la = lo[a], ha = hi[a], lb = lo[b], hb = hi[b];
+        take = la.x <= hb.x && lb.x <= ha.x && la.y <= hb.y && lb.y <= ha.y;
+      }
     }
     // one global atomic per workgroup and sweep (one per wave put ~5 k atomics on a single address: 40 us)
     const unsigned long long bal = __ballot(take);
@@ -925,8 +937,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict
 // in-neighbours are removed).  Round r reads the round r-1 view and writes the round r one; the two blocked arrays
 // alternate so that a round never overwrites the marks it reads.  Rows that nobody blocks any more stay kept without
 // ever being touched again, so nothing has to be materialised between rounds.
-constexpr int kNmsRounds = 8;       // launched rounds (4-6 settle detector-like inputs, 7-8 the longest chains among 200 k
-                                    // random rows); the rest: clean-up kernel
+constexpr int kNmsRounds = 4;       // launched rounds over ALL edges (each leaves ~10 x fewer edges alive); what is still alive
+                                    // then is bucketed by segment and finished inside one workgroup per segment
 enum : uint32_t { kOpen = 0, kKept = 1, kRemoved = 2 };
 
 __device__ __forceinline__ uint32_t nms_view(const uint8_t* __restrict__ state, const uint8_t* __restrict__ blocked,
@@ -988,7 +1000,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_round(const uint2* __restrict_
 }
 
 // writes the implicit "open and not blocked == kept" view after the last launched round out as explicit states (only
-// when the clean-up kernel has work to do); array 0 of `blocked` becomes the plain "blocked this round" flag
+// when edges are still alive); the two `blocked` arrays become plain "blocked this round" flags
 __global__ void k_nms_materialize(const NmsCounters* __restrict__ C, uint8_t* __restrict__ state,
                                   uint8_t* __restrict__ blocked, int64_t n) {
   if (C->alive[kNmsRounds] == 0) return;
@@ -996,75 +1008,183 @@ __global__ void k_nms_materialize(const NmsCounters* __restrict__ C, uint8_t* __
   if (p >= n) return;
   const uint32_t v = nms_view(state, blocked, n, kNmsRounds, (uint32_t)p);
   blocked[p] = 0;            // (kNmsRounds is even: the view reads array 0 at this very index, before the write)
+  blocked[n + p] = 0;        // both arrays become plain "blocked this round" flags
   if (v == kKept) state[p] = (uint8_t)kKept;
 }
 static_assert(kNmsRounds % 2 == 0 && kNmsRounds < 15, "k_nms_materialize / NmsCounters::alive assume this");
 
-// CLEAN-UP: chains longer than the launched rounds (rare; adversarially long alternating chains): ONE workgroup goes on
-// with the edges that were still alive after the last launched round.  k_nms_materialize has written the implicit view
-// out as explicit states, so no round stamp is needed from here on; classic rounds with barriers: (A) kept source -> target removed, (B) open source and open target -> target blocked,
-// (C) open and not blocked -> kept, (D) drop the edges whose target is settled or whose source is removed (in place: a
-// survivor is always written at or before its own slot) -- until the list is empty.  Every open row always has an
-// in-edge in the list from an open or kept row, so (C) reaches it; at the end no row is open.
-__global__ __launch_bounds__(1024) void k_nms_cleanup(NmsCounters* __restrict__ C, uint8_t* __restrict__ state,
-                                                      uint8_t* __restrict__ blocked, int64_t n,
-                                                      uint2* __restrict__ list, unsigned long long list_cap,
-                                                      const uint2* __restrict__ edges, unsigned long long ecap) {
+// ---- FINISH per segment: chains longer than the launched rounds (dense detector outputs: tens of dependent rounds).
+// The edges that are still alive are bucketed by segment (count, scan, scatter) and every segment that has some is
+// finished by ONE workgroup with the rows' states, the round flags and the edge list in LDS, so that a round costs two
+// short passes and two barriers instead of a kernel launch.  Explicit states (k_nms_materialize ran): a round is
+//   pass 1: kept source -> target removed; open source and open target -> target flagged;
+//   pass 2: open and not flagged -> kept; edges whose target is still open stay (also when their source was removed
+//           in pass 1: the target is then decided next round), the others are dropped; the flags of the other array are
+//           cleared for the rows that stay open.
+// Every open row always has an edge in its segment's list, so it is reached; the loop ends when the list is empty.
+// Segments too large for LDS (> kSegRows rows or > kSegEdges alive edges) run the same loop on the global arrays.
+// (wave-aggregated: the alive list comes in segment-coherent runs, and the counters of a detector batch -- ~120
+// segments -- share a handful of cache lines: one atomic per edge serialised at the L2 channel, 143 us)
+__device__ __forceinline__ unsigned seg_aggregate(bool valid, uint32_t seg, uint32_t* __restrict__ counters) {
+  // returns this lane's slot: old counter value + rank among the lanes of the same segment; one atomic per distinct segment
+  const int lane = threadIdx.x & 63;
+  unsigned slot = 0;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const uint32_t s0 = (uint32_t)__shfl((int)seg, leader);
+    const unsigned long long same = __ballot(valid && seg == s0) & todo;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&counters[s0], (unsigned)__popcll(same));
+    base = (unsigned)__shfl((int)base, leader);
+    if (valid && seg == s0) slot = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return slot;
+}
+
+__global__ __launch_bounds__(kThreads) void k_nms_alive_count(const NmsCounters* __restrict__ C,
+                                                              const uint2* __restrict__ alive, unsigned long long alive_cap,
+                                                              const PreBox* __restrict__ sorted,
+                                                              uint32_t* __restrict__ seg_cnt) {
   if (C->alive[kNmsRounds] == 0) return;
-  __shared__ unsigned s_wave[16], s_tot;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the list overflowed (more alive edges than the buffer): walk ALL edges every round instead, without compaction
-  const bool all = C->alive_list > list_cap;
-  const uint2* src = all ? edges : list;
-  unsigned long long cnt = all ? min(C->edges, ecap) : C->alive_list;
-  __threadfence_block();
+  const unsigned long long A = min(C->alive_list, alive_cap);
+  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
+  for (unsigned long long e0 = (unsigned long long)blockIdx.x * kThreads; e0 < A; e0 += stride) {
+    const unsigned long long e = e0 + threadIdx.x;
+    const bool valid = e < A;
+    const uint32_t seg = valid ? __float_as_uint(sorted[alive[e].x].label) : 0u;
+    (void)seg_aggregate(valid, seg, seg_cnt);
+  }
+}
+
+// exclusive scan of the per-segment counts in place (one workgroup); seg_cur = a second copy for the scatter cursors
+__global__ __launch_bounds__(1024) void k_nms_alive_scan(const NmsCounters* __restrict__ C,
+                                                         const uint32_t* __restrict__ num_seg,
+                                                         uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_cur) {
+  if (C->alive[kNmsRounds] == 0) return;
+  __shared__ unsigned s_w[16];
+  __shared__ unsigned s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  for (;;) {
-    for (unsigned long long e = threadIdx.x; e < cnt; e += 1024) {          // (A)
-      const uint2 ij = src[e];
-      if (state[ij.x] == kKept && state[ij.y] == kOpen) state[ij.y] = (uint8_t)kRemoved;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t S = *num_seg;
+  for (uint32_t b0 = 0; b0 <= S; b0 += 1024) {           // S + 1 entries: entry S ends up holding the total
+    const uint32_t b = b0 + threadIdx.x;
+    const unsigned v = b < S ? seg_cnt[b] : 0u;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
     }
-    __threadfence_block();
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    for (unsigned long long e = threadIdx.x; e < cnt; e += 1024) {          // (B)
-      const uint2 ij = src[e];
-      if (state[ij.x] == kOpen && state[ij.y] == kOpen) blocked[ij.y] = 1;
-    }
-    __threadfence_block();
+    unsigned wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += s_w[w];
+    const unsigned carry = s_carry;
+    if (b <= S) { seg_cnt[b] = carry + wbase + incl - v; seg_cur[b] = carry + wbase + incl - v; }
     __syncthreads();
-    for (unsigned long long e = threadIdx.x; e < cnt; e += 1024) {          // (C)
-      const uint2 ij = src[e];
-      if (state[ij.y] == kOpen && blocked[ij.y] == 0) state[ij.y] = (uint8_t)kKept;
-    }
-    __threadfence_block();
+    if (threadIdx.x == 1023) s_carry = carry + wbase + incl;
     __syncthreads();
-    unsigned kept_total = 0;                                                  // (D)
-    for (unsigned long long e0 = 0; e0 < cnt; e0 += 1024) {
-      const unsigned long long e = e0 + threadIdx.x;
-      bool live = false;
-      uint2 ij = make_uint2(0, 0);
-      if (e < cnt) {
-        ij = src[e];
-        live = state[ij.y] == kOpen && state[ij.x] != kRemoved;
-        if (live) blocked[ij.y] = 0;          // reset for the next round (only open rows carry a mark)
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_nms_alive_scatter(const NmsCounters* __restrict__ C,
+                                                                const uint2* __restrict__ alive, unsigned long long alive_cap,
+                                                                const PreBox* __restrict__ sorted,
+                                                                uint32_t* __restrict__ seg_cur, uint2* __restrict__ bucketed) {
+  if (C->alive[kNmsRounds] == 0) return;
+  const unsigned long long A = min(C->alive_list, alive_cap);
+  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
+  for (unsigned long long e0 = (unsigned long long)blockIdx.x * kThreads; e0 < A; e0 += stride) {
+    const unsigned long long e = e0 + threadIdx.x;
+    const bool valid = e < A;
+    uint2 ij = make_uint2(0, 0);
+    if (valid) ij = alive[e];
+    const uint32_t seg = valid ? __float_as_uint(sorted[ij.x].label) : 0u;
+    const unsigned slot = seg_aggregate(valid, seg, seg_cur);
+    if (valid) bucketed[slot] = ij;
+  }
+}
+
+constexpr int kSegRows = 8192, kSegEdges = 4096;     // 8 + 16 KB of states / flags, 2 x 32 KB of edges
+
+__global__ __launch_bounds__(kThreads) void k_nms_finish_segments(const NmsCounters* __restrict__ C,
+                                                                  const uint32_t* __restrict__ seg_start,
+                                                                  const uint32_t* __restrict__ num_seg,
+                                                                  const uint32_t* __restrict__ seg_off,
+                                                                  uint2* __restrict__ bucketed,
+                                                                  uint8_t* __restrict__ state,
+                                                                  uint8_t* __restrict__ blocked, int64_t n,
+                                                                  int force_global) {
+  if (C->alive[kNmsRounds] == 0) return;
+  __shared__ uint8_t s_state[kSegRows];
+  __shared__ uint8_t s_flag[2][kSegRows];
+  __shared__ uint2 s_edges[2][kSegEdges];
+  __shared__ unsigned s_n;
+  const uint32_t S = *num_seg;
+  for (uint32_t s = blockIdx.x; s < S; s += gridDim.x) {
+    const uint32_t e0 = seg_off[s], cnt0 = seg_off[s + 1] - e0;
+    if (cnt0 == 0) continue;                                  // (uniform)
+    const uint32_t st = seg_start[s], ns = seg_start[s + 1] - st;
+    const bool lds = !force_global && ns <= (uint32_t)kSegRows && cnt0 <= (uint32_t)kSegEdges;
+    uint8_t* St = lds ? s_state : state + st;                 // generic pointers: LDS or global
+    uint8_t* F[2] = {lds ? s_flag[0] : blocked + st, lds ? s_flag[1] : blocked + n + st};
+    uint2* E[2] = {lds ? s_edges[0] : bucketed + e0, lds ? s_edges[1] : nullptr};
+    __syncthreads();
+    if (lds) {
+      for (uint32_t i = threadIdx.x; i < ns; i += kThreads) { s_state[i] = state[st + i]; s_flag[0][i] = 0; s_flag[1][i] = 0; }
+      for (uint32_t e = threadIdx.x; e < cnt0; e += kThreads) {
+        const uint2 ij = bucketed[e0 + e];
+        s_edges[0][e] = make_uint2(ij.x - st, ij.y - st);
       }
-      const unsigned long long bal = __ballot(live);
-      if (lane == 0) s_wave[wave] = (unsigned)__popcll(bal);
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        unsigned acc = 0;
-        for (int w = 0; w < 16; w++) { const unsigned c = s_wave[w]; s_wave[w] = acc; acc += c; }
-        s_tot = acc;
+    } else {
+      for (uint32_t e = threadIdx.x; e < cnt0; e += kThreads) {      // local indices in place
+        const uint2 ij = bucketed[e0 + e];
+        bucketed[e0 + e] = make_uint2(ij.x - st, ij.y - st);
       }
-      __syncthreads();
-      if (live && !all) list[kept_total + s_wave[wave] + __popcll(bal & ((1ull << lane) - 1ull))] = ij;
-      kept_total += s_tot;
-      __syncthreads();
     }
     __threadfence_block();
     __syncthreads();
-    if (kept_total == 0) break;
-    if (!all) cnt = kept_total;
+    uint32_t cnt = cnt0;
+    int cur = 0, f = 0;
+    for (;;) {
+      const uint2* Ein = E[cur];
+      for (uint32_t e = threadIdx.x; e < cnt; e += kThreads) {        // pass 1
+        const uint2 ij = Ein[e];
+        if (St[ij.y] == kOpen) {
+          const uint32_t si = St[ij.x];
+          if (si == kKept) St[ij.y] = (uint8_t)kRemoved;
+          else if (si == kOpen) F[f][ij.y] = 1;
+        }
+      }
+      if (threadIdx.x == 0) s_n = 0;
+      __threadfence_block();
+      __syncthreads();
+      uint2* Eout = E[cur ^ 1];
+      for (uint32_t e = threadIdx.x; e < cnt; e += kThreads) {        // pass 2
+        const uint2 ij = Ein[e];
+        if (St[ij.y] == kOpen) {
+          if (F[f][ij.y] == 0) {
+            St[ij.y] = (uint8_t)kKept;
+          } else {
+            F[f ^ 1][ij.y] = 0;
+            const unsigned pos = atomicAdd(&s_n, 1u);
+            if (Eout) Eout[pos] = ij;
+          }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      const uint32_t live = s_n;
+      __syncthreads();
+      if (live == 0) break;
+      if (Eout) { cnt = live; cur ^= 1; }                     // (global path: no second list, all edges again)
+      f ^= 1;
+    }
+    if (lds)
+      for (uint32_t i = threadIdx.x; i < ns; i += kThreads) state[st + i] = s_state[i];
   }
 }
 
@@ -1152,6 +1272,7 @@ struct NmsBuffers {
   TileRef* tiles;
   uint2 *gq, *edges;
   uint8_t *keep_orig, *flag_glob, *state, *blocked;
+  uint32_t *seg_cnt, *seg_cur;
   void* rp_temp;
 };
 
@@ -1218,6 +1339,8 @@ void nms_carve_fixed(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
   B->flag_glob = cv.take<uint8_t>(sz);
   B->state = cv.take<uint8_t>(sz);
   B->blocked = cv.take<uint8_t>(2 * sz);
+  B->seg_cnt = cv.take<uint32_t>(sz + 2);
+  B->seg_cur = cv.take<uint32_t>(sz + 2);
   B->rp_temp = cv.take<char>(pl.rocprim_bytes);
 }
 
@@ -1270,16 +1393,27 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   // (zeroed by kernels, not hipMemsetAsync: memset nodes of a captured graph were not replayed correctly from the second
   // launch on with ROCm 7.2 -- counters kept their old values; tests/test_gpu_e2e.py::test_detect_hip_graph_replay_equals_eager)
   const size_t slots = block_slots_for(sz);
-  k_nms_init_slots<<<grid_for((int64_t)std::max(slots, 2 * sz)), 256, 0, st>>>(B.lo, B.hi, slots, B.C, B.blocked, 2 * sz);
-  k_nms_pos_meta<<<g, 256, 0, st>>>(dets, B.perm_seg, B.segidx1, B.nblk, n, B.sorted, B.state, B.C);
-  // spatial order inside every segment (key1a and idxa are free again)
-  uint32_t* val3a = reinterpret_cast<uint32_t*>(B.idxa);
-  k_nms_spkeys<<<g, 256, 0, st>>>(B.sorted, B.C, n, B.key1a, val3a);
-  const unsigned segbits = seg_ids ? bits_for((uint64_t)num_segments_hint + 1) : (labels ? bits_for((uint64_t)n) : 1);
-  rpb = pl.rocprim_bytes;
-  S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp, rpb, B.key1a, B.key3b, val3a, B.perm_sp, sz, 0, 20 + segbits, st));
-  k_nms_spgather<<<g, 256, 0, st>>>(B.sorted, B.perm_sp, B.seg_start, n, B.sp_box, B.lo, B.hi);
-  k_nms_tile_filter<<<kPersistentGrid, kThreads, 0, st>>>(B.seg_start, B.num_seg, B.tile_off, B.lo, B.hi, B.tiles, B.C,
+  // The Morton order + bounding-box tile filter pays when segments are big (thousands of rows: most tiles of a segment
+  // are far apart); for many small segments (a detector batch: ~300 rows per image and class) it is a third sort and
+  // two passes of pure overhead, every tile is tested anyway -> blocks in score order, no filter
+  bool spatial = (seg_ids ? (uint64_t)n / std::max<uint32_t>(num_segments_hint, 1u) : (uint64_t)n) > 4096;
+  if (const char* e = std::getenv("S2A_NMS_SPATIAL")) spatial = e[0] == '1';          // A/B and test switch
+  const char* e_lds = std::getenv("S2A_NMS_FINISH_GLOBAL");                          // test switch: finish on the global arrays
+  const int force_global = e_lds && e_lds[0] == '1';
+  uint2* lo = spatial ? B.lo : nullptr;
+  k_nms_init_slots<<<grid_for((int64_t)std::max(spatial ? slots : (size_t)0, 2 * sz)), 256, 0, st>>>(lo, B.hi, slots, B.C, B.blocked, 2 * sz,
+                                                                                B.seg_cnt, sz + 2);
+  k_nms_pos_meta<<<g, 256, 0, st>>>(dets, B.perm_seg, B.segidx1, B.nblk, n, B.sorted, B.state, B.C, spatial ? nullptr : B.sp_box);
+  if (spatial) {
+    // spatial order inside every segment (key1a and idxa are free again)
+    uint32_t* val3a = reinterpret_cast<uint32_t*>(B.idxa);
+    k_nms_spkeys<<<g, 256, 0, st>>>(B.sorted, B.C, n, B.key1a, val3a);
+    const unsigned segbits = seg_ids ? bits_for((uint64_t)num_segments_hint + 1) : (labels ? bits_for((uint64_t)n) : 1);
+    rpb = pl.rocprim_bytes;
+    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp, rpb, B.key1a, B.key3b, val3a, B.perm_sp, sz, 0, 20 + segbits, st));
+    k_nms_spgather<<<g, 256, 0, st>>>(B.sorted, B.perm_sp, B.seg_start, n, B.sp_box, B.lo, B.hi);
+  }
+  k_nms_tile_filter<<<kPersistentGrid, kThreads, 0, st>>>(B.seg_start, B.num_seg, B.tile_off, lo, B.hi, B.tiles, B.C,
                                                           pl.tile_cap);
   k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(B.sp_box, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
   k_nms_heavy<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
@@ -1287,8 +1421,14 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   for (int r = 1; r <= kNmsRounds; r++)
     k_nms_round<<<256, kThreads, 0, st>>>(B.edges, B.C, pl.edge_cap, B.state, B.blocked, n, r,
                                           r == kNmsRounds ? B.gq : nullptr, pl.queue_cap);
+  // still-alive edges (listed by the last launched round in the dead pair list): by segment into the edge buffer (the full
+  // edge list is dead now), then one workgroup per segment; all five kernels return at once when nothing is alive
   k_nms_materialize<<<g, 256, 0, st>>>(B.C, B.state, B.blocked, n);
-  k_nms_cleanup<<<1, 1024, 0, st>>>(B.C, B.state, B.blocked, n, B.gq, pl.queue_cap, B.edges, pl.edge_cap);
+  k_nms_alive_count<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, B.sorted, B.seg_cnt);
+  k_nms_alive_scan<<<1, 1024, 0, st>>>(B.C, B.num_seg, B.seg_cnt, B.seg_cur);
+  k_nms_alive_scatter<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, B.sorted, B.seg_cur, B.edges);
+  k_nms_finish_segments<<<512, kThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.seg_cnt, B.edges, B.state, B.blocked, n,
+                                                  force_global);
   k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.nblk, B.C, pl.queue_cap, pl.edge_cap,
                                                 pl.tile_cap, B.state, thr);
   k_nms_finish<<<g, 256, 0, st>>>(B.state, B.blocked, B.C, B.perm_seg, n, B.keep_orig);

@@ -37,18 +37,8 @@ if which in ("f32", "both"):
     K = int(c[0])
     print("  GPU: %d detections, candidates %s ; CPU: %d detections, candidates %d" % (K, ovf.cpu().tolist(), len(dets_c), int((sc_c > 0.05).sum())))
     gd, gl = d[0, :K].cpu().numpy(), l[0, :K].cpu().numpy()
-    if K == len(dets_c):
-        m = T._match(gd, gl, dets_c, labels_c.astype(np.int32))
-        if m is None:
-            print("  no label-preserving matching")
-        else:
-            pairs, wb, ws = m
-            size = np.maximum(dets_c[[j for _, j in pairs], 2:4].max(1), 1.0)
-            rel = max(float((np.abs(dets_c[j, :4] - gd[i, :4]) / size[k]).max()) for k, (i, j) in enumerate(pairs))
-            moved = sum(1 for i, j in pairs if i != j)
-            print("  matched all: worst box abs %.3e rel %.3e, worst score %.3e, order swaps %d" % (wb, rel, ws, moved))
-    else:
-        print("  label multisets equal:", np.array_equal(np.sort(gl), np.sort(labels_c.astype(np.int32))))
+    pairs, lg, lc = T._match(gd, gl, dets_c, labels_c.astype(np.int32))
+    print("  matched %d, unmatched GPU %d / CPU %d, order swaps %d" % (len(pairs), len(lg), len(lc), sum(1 for i, j in pairs if i != j)))
     # margins on the CPU side: how close decisions are to their thresholds
     sc = sc_c.reshape(-1)
     print("  min |score - 0.05| = %.3e ; scores within 1e-5 of thr: %d" % (np.abs(sc - 0.05).min(), int((np.abs(sc - 0.05) < 1e-5).sum())))
