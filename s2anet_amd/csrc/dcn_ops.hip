@@ -1092,6 +1092,403 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   }
 }
 
+// ------------------------------------------------------------------ ring-3 AlignConv (the pyramid launch's kernel)
+// k_dcn_patch with a THREE-deep ring of column tiles.  Ablations of k_dcn_patch on the pyramid launch (scripts/abl.sh, dense
+// data: bare stage 0.5 k cycles, loaders only 1.36 k, matrix waves only 1.72 k, both 2.12 k for 1.02 k cycles of MFMA)
+// showed the matrix waves stalling ~700 cycles per stage on their own B-fragment reads: a column tile could only be read
+// after the barrier that sealed it, 8 ds_read_b128 at a time, queued behind the loaders' corner-read bursts.  Here
+//   * the loaders run TWO stages ahead (stage s + 2 is blended while stage s is multiplied), so the tile of stage s + 1 is
+//     complete one barrier earlier than it is needed;
+//   * the matrix waves therefore fetch the fragments of k-step q + 1 before the 8 MFMAs of k-step q, ACROSS stage
+//     boundaries (two fragment sets, as before): every read has ~256 cycles to land and none waits behind a barrier
+//     (a third fragment set -- two k-steps ahead -- does not fit 256 VGPRs next to the 128 accumulators and 64 filter
+//     registers: it spilled inside the loop);
+//   * the third 18 KB tile comes out of the patch: 3 halo pixels instead of 4 (14 x 22 pixels per 8 x 16 tile; corners
+//     further out take the global-gather path as before).
+// Same arithmetic, same accumulation order, same staging and stores: results are bit-identical to k_dcn_patch.
+// Needs 9 * C / 64 stages divisible by 6 (C a multiple of 128): the ring (3), the filter double buffer (2) and the
+// tile ring are indexed statically inside a six-stage body.
+constexpr int kHalo3 = 3, kPH3 = 8 + 2 * kHalo3, kPW3 = 16 + 2 * kHalo3;   // 14 x 22
+constexpr int kPatch3Px = kPH3 * kPW3;                                      // 308
+constexpr int kPatch3Pieces = (kPatch3Px * 128 + 1023) / 1024;              // 39 LDS-DMA pieces of 1 KB (8 pixels x 128 B)
+constexpr int kPatch3Bytes = kPatch3Pieces * 1024;                          // 39936 (the last piece is half padding)
+constexpr int kRing3Lds = 128 * 9 * 16 + 3 * 128 * kRowBytes + 2 * kPatch3Bytes;   // 153600 B
+
+template <bool OUT_NHWC, int SRC>
+__global__ __launch_bounds__(512, 2) void k_dcn_ring3(const _Float16* __restrict__ x_,
+                                                      const float* __restrict__ src_,
+                                                      const _Float16* __restrict__ wfrag,
+                                                      _Float16* __restrict__ out_, int64_t Ntot_, int C,
+                                                      int H_, int W_, int O, float stride_, int relu,
+                                                      unsigned x_bytes_, LevelTab lt) {
+  using T = _Float16;
+  using V = f16x8;
+  constexpr int NPOS = 128, NT = 4, ITEMS = 4;
+  constexpr int NPV = (kPatch3Px * 8 + 255) / 256;      // 10 (the last round is partial: 2464 vectors)
+  constexpr int kBTile = NPOS * kRowBytes;              // 18432
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  PTap* s_tab = reinterpret_cast<PTap*>(smem);
+  char* s_B = smem + NPOS * 9 * 16;
+  char* s_patch = s_B + 3 * kBTile;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const T* x = x_;
+  const float* src = src_;
+  T* out = out_;
+  int64_t Ntot = Ntot_;
+  int H = H_, W = W_;
+  float stride = stride_;
+  unsigned x_bytes = x_bytes_;
+  if (SRC == 1 && lt.n > 1) {         // pyramid-packed levels (anchors [sum B*H*W, 5] packed alike)
+    int t0 = 0, p0 = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; i++)
+      if (i < lt.n && tile >= lt.tile0[i]) {
+        t0 = lt.tile0[i]; p0 = lt.pix0[i]; H = lt.H[i]; W = lt.W[i]; stride = lt.stride[i];
+      }
+    tile -= t0;
+    Ntot = (int64_t)lt.batch * H * W;
+    x += (int64_t)p0 * C;
+    out += (int64_t)p0 * O;
+    src += (int64_t)p0 * 5;
+    x_bytes = (unsigned)(Ntot * C * 2);
+  }
+  const int64_t HW = (int64_t)H * W;
+  const int txn = (W + 15) / 16, tyn = (H + 7) / 8;
+  const int64_t bimg = tile / (txn * tyn);
+  const int trem = (int)(tile % (txn * tyn));
+  const int ty0 = (trem / txn) * 8, tx0 = (trem % txn) * 16;
+  const int oy = ty0 - kHalo3, ox = tx0 - kHalo3;
+  const int o0 = blockIdx.y * kMaxO;
+  const int Oloc = min(kMaxO, O - o0);
+  const int CC = C / 64;
+  const int nstage = 9 * CC;
+  const int G = O / 64;
+  const unsigned row_bytes = (unsigned)C * 2;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
+
+  // ---- loader waves: first patch in flight before anything else.  Patch chunks go global -> LDS by DMA (buffer_load ...
+  // lds: no registers, no ds_write pass): piece = 1 KB = 8 pixels x 128 B, lane l -> pixel l / 8, 16-byte group l % 8;
+  // wave w of the loaders takes pieces w, w + 4, ...; out-of-image pixels (and the padding of the last piece) get an
+  // out-of-range offset -> the bounds-checked load writes zeros.
+  const int L = tid - 256;
+  unsigned pvoff[NPV];
+  auto patch_issue = [&](int cc) {
+    char* P = s_patch + (cc & 1) * kPatch3Bytes;
+#pragma unroll
+    for (int i = 0; i < NPV; i++) {
+      const int piece = (wave - 4) + 4 * i;
+      if (piece < kPatch3Pieces)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(P + piece * 1024), 16,
+                                                 (int)pvoff[i], cc * 128, 0, 0);
+    }
+  };
+  if (wave >= 4) {
+#pragma unroll
+    for (int i = 0; i < NPV; i++) {
+      int v = L + 256 * i, p = v >> 3, q = v & 7;
+      int yy = oy + p / kPW3, xx = ox + p % kPW3;
+      bool in = v < kPatch3Px * 8 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      pvoff[i] = in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
+    }
+    patch_issue(0);
+  }
+
+  // ---- matrix waves: first filter fragments in flight as well
+  const int g = min(o0 / 64 + (wave & 3), G - 1);
+  const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
+  V wA[2][4], wB[2][4];
+  auto load_w = [&](int s, V (&wv)[2][4]) {
+    const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
+  };
+  if (wave < 4) load_w(0, wA);
+
+  // ---- per-position anchor context
+  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);   // B tiles are not in use yet
+  if (SRC == 1 && tid < NPOS) {
+    int y = ty0 + (tid >> 4), xq = tx0 + (tid & 15);
+    AnchorCtx c = {0, 0, 0, 0, 1, 0};
+    if (y < H && xq < W) c = anchor_ctx(src + (bimg * HW + (int64_t)y * W + xq) * 5, stride);
+    s_ctx[tid] = c;
+  }
+  if (SRC == 1) __syncthreads();
+
+  // ---- sampling table
+  for (int e = tid; e < NPOS * 9; e += 512) {
+    int pl = e / 9, t = e % 9;
+    int y = ty0 + (pl >> 4), xq = tx0 + (pl & 15);
+    PTap tp;
+    tp.y = (short)oy;
+    tp.x = (short)ox;
+    tp.flags = 1u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
+    if (y < H && xq < W) {
+      const int64_t p = (int64_t)y * W + xq;
+      int ky = t / 3, kx = t % 3;
+      float off_y, off_x;
+      if (SRC == 0) {
+        const float* ob = src + (bimg * 18) * HW + p;
+        off_y = ob[(int64_t)(2 * t) * HW];
+        off_x = ob[(int64_t)(2 * t + 1) * HW];
+      } else {
+        anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
+      }
+      float h_im = (float)(y - 1 + ky) + off_y;
+      float w_im = (float)(xq - 1 + kx) + off_x;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+        int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+        bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+        tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
+        tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
+        tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
+        tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
+        tp.y = (short)h_low;
+        tp.x = (short)w_low;
+        bool in = h_low >= oy && h_low + 1 <= oy + kPH3 - 1 && w_low >= ox && w_low + 1 <= ox + kPW3 - 1;
+        const int py = min(max(h_low - oy, 0), kPH3 - 2), px = min(max(w_low - ox, 0), kPW3 - 2);
+        tp.flags = (in ? 1u : 0u) | ((unsigned)((py * kPW3 + px) * 128) << 1);
+      }
+    }
+    s_tab[e] = tp;
+  }
+  __syncthreads();  // #1 table + patch 0 ready (the DMA is counted in vmcnt, which __syncthreads drains); s_ctx is dead
+
+  f32x16 acc[2][NT];
+  const bool wave_active = wave < 4 && wave * 64 < Oloc;
+  if (wave < 4) {
+    // ===================== matrix waves =====================
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    const char* prow0 = s_B + (lane & 31) * kRowBytes + (lane >> 5) * 16;
+    V pf[2][NT];
+    // fragments of k-step q = 4 * stage + kk (tile stage % 3, columns kk * 32 ..): 4 x ds_read_b128
+    auto pf_read = [&](int ring, int kk, V (&f)[NT]) {
+      const char* prow = prow0 + ring * kBTile + kk * 32;
+#pragma unroll
+      for (int h = 0; h < NT; h++) f[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes);
+    };
+    auto mma = [&](const V (&wv)[2][4], int kk, const V (&f)[NT]) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], f[b], acc[a][b], 0, 0, 0);
+    };
+    const int last = nstage - 1;
+    __syncthreads();  // #2 stages 0 and 1 are in LDS
+    pf_read(0, 0, pf[0]);
+    for (int s0 = 0; s0 < nstage; s0 += 6) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+        const int s = s0 + u;
+        // filters of the next stage (wrap-around at the end: harmless re-load of the last stage)
+        if (u & 1) load_w(min(s + 1, last), wA); else load_w(min(s + 1, last), wB);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          // k-step q + 1 is requested before the MFMAs of k-step q: kk + 1 of this stage, or kk 0 of the NEXT stage,
+          // whose tile was sealed a barrier ago (after the last stage: a stale tile, read and never used)
+          if (!(S2A_ABL & 16)) {
+            if (kk < 3) pf_read(u % 3, kk + 1, pf[(kk + 1) & 1]); else pf_read((u + 1) % 3, 0, pf[0]);
+          }
+          if (wave_active && !(S2A_ABL & 4)) {
+            if (u & 1) mma(wB, kk, pf[kk & 1]); else mma(wA, kk, pf[kk & 1]);
+          }
+        }
+        // raw barrier: these waves only READ LDS; every read of this stage's tile has been consumed by an MFMA above,
+        // and the one still in flight (k-step 0 of the next stage) targets a tile that is not rewritten next -- a full
+        // __syncthreads() would wait for it (lgkmcnt(0)) and for the filter loads (vmcnt(0)) in front of every barrier.
+        // The loaders' writes are ordered by THEIR __syncthreads() (waitcnt + barrier) on the other side.
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  } else {
+    // ===================== loader waves =====================
+    // Operands are requested a full stage before they are blended.  The loaders are the critical role (scripts/abl.sh:
+    // without their corner reads the launch is 26 % shorter -- but only when the blend follows; reads alone cost nothing):
+    // a wave on the critical path gets no barrier wait to hide its own LDS latency chain (table entry -> corner
+    // addresses -> 16 corner vectors -> blend), so with one-stage-ahead fetching that chain was exposed in every stage.
+    // Two operand sets (entries + corners) alternate; the entries of stage P + 2 are requested when iteration P starts
+    // and have landed by the time the blend of stage P is done, then its corner reads go out and have a whole
+    // iteration to land.
+    // table entries travel as plain 4-dword vectors (word 0: y | x << 16, word 1: flags, words 2-3: the four f16 weights):
+    // arrays of the PTap struct copied between operand sets were not promoted to registers (field-wise scratch traffic)
+    u32x4 tA[ITEMS], tB[ITEMS], tN[ITEMS];
+    V cA[ITEMS][4], cB[ITEMS][4];
+    auto req_table = [&](int s, u32x4 (&tp)[ITEMS]) {
+      const int t = s % 9;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+        tp[it] = *reinterpret_cast<const u32x4*>(&s_tab[((L + 256 * it) >> 3) * 9 + t]);
+    };
+    auto req_corners = [&](int s, const u32x4 (&tp)[ITEMS], V (&c)[ITEMS][4]) {
+      if (S2A_ABL & 8) return;
+      const int cc = s / 9;
+      const char* P = s_patch + (cc & 1) * kPatch3Bytes + (L & 7) * 16;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) {
+        const char* b0 = P + (tp[it][1] >> 1);
+        c[it][0] = *reinterpret_cast<const V*>(b0);
+        c[it][1] = *reinterpret_cast<const V*>(b0 + 128);
+        c[it][2] = *reinterpret_cast<const V*>(b0 + kPW3 * 128);
+        c[it][3] = *reinterpret_cast<const V*>(b0 + kPW3 * 128 + 128);
+      }
+    };
+    // blend_pk on the packed weights of an entry (same operations, same order: w0*a0, fma w1, fma w2, fma w3)
+    auto blend_e = [&](const V (&v)[4], unsigned w01, unsigned w23) -> V {
+      const f16x2 p01 = __builtin_bit_cast(f16x2, w01), p23 = __builtin_bit_cast(f16x2, w23);
+      const f16x2 w0 = {p01[0], p01[0]}, w1 = {p01[1], p01[1]}, w2 = {p23[0], p23[0]}, w3 = {p23[1], p23[1]};
+      V r;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        f16x2 a0 = {v[0][2 * e], v[0][2 * e + 1]}, a1 = {v[1][2 * e], v[1][2 * e + 1]};
+        f16x2 a2 = {v[2][2 * e], v[2][2 * e + 1]}, a3 = {v[3][2 * e], v[3][2 * e + 1]};
+        f16x2 acc2 = w0 * a0;
+        acc2 = __builtin_elementwise_fma(w1, a1, acc2);
+        acc2 = __builtin_elementwise_fma(w2, a2, acc2);
+        acc2 = __builtin_elementwise_fma(w3, a3, acc2);
+        r[2 * e] = acc2[0];
+        r[2 * e + 1] = acc2[1];
+      }
+      return r;
+    };
+    auto produce = [&](int s, const u32x4 (&tp)[ITEMS], const V (&c)[ITEMS][4]) {  // columns of stage s -> tile s % 3
+      if (S2A_ABL & 2) return;
+      const int cc = s / 9;
+      char* Bm = s_B + (s % 3) * kBTile;
+      bool any_out = false;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) any_out |= !(tp[it][1] & 1u);
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) {
+        const int item = L + 256 * it, pl = item >> 3, q = item & 7;
+        *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_e(c[it], tp[it][2], tp[it][3]);
+      }
+      if (any_out) {  // rare: a corner left the patch -> global gather for that (position, tap)
+        for (int it = 0; it < ITEMS; it++) {
+          if (tp[it][1] & 1u) continue;
+          const int item = L + 256 * it, pl = item >> 3, q = item & 7;
+          const int ty = (int)(short)(tp[it][0] & 0xffffu), tx = (int)(short)(tp[it][0] >> 16);
+          V g4[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            int yy = min(max(ty + (k >> 1), 0), H - 1), xx = min(max(tx + (k & 1), 0), W - 1);
+            unsigned vo = (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16);
+            u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, cc * 128, 0);
+            g4[k] = __builtin_bit_cast(V, d);
+          }
+          *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_e(g4, tp[it][2], tp[it][3]);
+        }
+      }
+    };
+    // one iteration: blend stage P from its operand set, then refill that set with the operands of stage P + 2.
+    // Patch chunks, by the blended stage P = (cc, t): the DMA of chunk cc + 1 into the other buffer is issued at t == 0
+    // (every wave has blended stage (cc - 1, 8) before the barrier in front of it, so nobody reads that buffer any
+    // more), waited for at t == 5 (vmcnt(0), then two barriers), first read at t == 7 (corners of stage (cc + 1, 0)).
+    auto step = [&](int P, u32x4 (&tp)[ITEMS], V (&c)[ITEMS][4]) {
+      if (P >= nstage) return;
+      const int t = P % 9, cc = P / 9;
+      const bool more = P + 2 < nstage;
+      if (more) req_table(P + 2, tN);
+      if (t == 0 && cc >= 1 && cc + 1 < CC) patch_issue(cc + 1);
+      produce(P, tp, c);
+      if (t == 5 && cc + 1 < CC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (more) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) tp[it] = tN[it];
+        req_corners(P + 2, tp, c);
+      }
+    };
+    // barrier of the loaders: their four tile writes of this iteration must be done; the 16 corner reads issued after
+    // them stay in flight (LDS operations return in order: lgkmcnt(15) retires everything older than the youngest 15;
+    // __syncthreads() would drain them -- and the DMA -- in front of every barrier)
+    auto loader_barrier = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    if (CC > 1) patch_issue(1);
+    req_table(0, tA);
+    if (nstage > 1) req_table(1, tB);
+    req_corners(0, tA, cA);
+    if (nstage > 1) req_corners(1, tB, cB);
+    step(0, tA, cA);
+    step(1, tB, cB);
+    __syncthreads();  // #2 stages 0 and 1 are in LDS
+    for (int s = 0; s < nstage; s += 2) {
+      step(s + 2, tA, cA);    // stage produced while stage s is multiplied; tile (s + 2) % 3 was read last in stage s - 1
+      loader_barrier();
+      step(s + 3, tB, cB);
+      loader_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+
+  // ===================== epilogue =====================
+  auto out_pos = [&](int pos) -> int64_t {
+    const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
+    const int64_t gpos = bimg * HW + (int64_t)y * W + xq;
+    return (y < H && xq < W && gpos < Ntot) ? gpos : -1;
+  };
+  if constexpr (OUT_NHWC) {
+    char* s_out = s_patch;     // 128 x 528 B = 67 584 <= 2 x 39 424
+    if (wave_active) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+#pragma unroll
+          for (int rq = 0; rq < 4; rq++) {
+            using h4 = __attribute__((ext_vector_type(4))) _Float16;
+            h4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              float v = acc[a][b][rq * 4 + e];
+              if (relu) v = fmaxf(v, 0.f);
+              v4[e] = (_Float16)v;
+            }
+            int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
+            int pos = 32 * b + (lane & 31);
+            *reinterpret_cast<h4*>(s_out + pos * kOutRow + och * 2) = v4;
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPOS / 16; i++) {
+      int idx = tid + 512 * i, pos = idx >> 5, col = idx & 31;
+      int64_t gp = out_pos(pos);
+      if (gp >= 0 && col * 8 < Oloc)
+        *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
+    }
+  } else {
+    if (!wave_active) return;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float v = acc[a][b][r];
+          if (relu) v = fmaxf(v, 0.f);
+          int och = o0 + wave * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          int64_t gp = out_pos(32 * b + (lane & 31));
+          if (gp >= 0) {
+            int64_t bi = gp / HW, p = gp % HW;
+            out[(bi * O + och) * HW + p] = (T)v;
+          }
+        }
+  }
+}
+
 // ------------------------------------------------------------------ persistent AlignConv
 // k_dcn_patch<NHWC, anchors> for the pyramid-packed launch, as a PERSISTENT kernel: one workgroup per CU walks tiles
 // bid, bid + grid, ...  A tile of the plain kernel spends ~17 % of its time before the first and after the last MFMA
@@ -2128,15 +2525,39 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
     patch_ok = ntiles(128) >= 128 && x_bytes < (1ull << 31) && !getenv("S2A_DCN_NO_WS") && wfrag != nullptr && C % 64 == 0 && H < 32000 && W < 32000 &&
                !(variant && (!strcmp(variant, "ws") || !strcmp(variant, "mfma")));
   const bool ws_use = ws_ok && !(variant && !strcmp(variant, "mfma"));
+  // One 153 KB workgroup per CU: a launch whose 8 x 16 tiles fill the last round badly (one P3 level of ONE chip: 128
+  // tiles on 256 CUs, BASELINE configs[1]) runs as 4 x 16 half tiles instead when that needs less time (bit-identical)
+  static int n_cu_fast = 0;
+  if (n_cu_fast == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    S2A_HIP(hipGetDevice(&dev));
+    S2A_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu_fast = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  // rounds of one workgroup per CU; a half tile takes ~0.62 of a full one (measured: 128 tiles 44.5 -> 34.8 us as 256 half
+  // tiles, but 256 tiles -- exactly one full round -- 50 -> 61 us as 512 half tiles)
+  const int64_t rounds_full = (ntiles(128) + n_cu_fast - 1) / n_cu_fast, rounds_half = (2 * ntiles(128) + n_cu_fast - 1) / n_cu_fast;
+  const bool half_tiles = 62 * rounds_half < 100 * rounds_full && !getenv("S2A_DCN_NO_HALF");
 #define S2A_DCN_LAUNCH_PATCH(NHWC, SRC)                                                           \
   do {                                                                                            \
     if constexpr (sizeof(T) == 2) {                                                               \
-      auto kern = k_dcn_patch<NHWC, SRC>;                                                         \
-      dim3 grid((unsigned)ntiles(128), (unsigned)((O + kMaxO - 1) / kMaxO));                      \
-      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));        \
-      kern<<<grid, 512, kPatchLds, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, relu, \
-                                         (unsigned)x_bytes, LevelTab{}, 0);                       \
+      if (half_tiles) {                                                                           \
+        constexpr int kHalfLdsF = 64 * 9 * 16 + 2 * 64 * kRowBytes + 2 * (4 + 2 * kHalo) * kPW * 128; \
+        auto kern = k_dcn_patch<NHWC, SRC, 4>;                                                    \
+        dim3 grid((unsigned)(2 * ntiles(128)), (unsigned)((O + kMaxO - 1) / kMaxO));              \
+        S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLdsF));      \
+        kern<<<grid, 512, kHalfLdsF, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, relu, \
+                                           (unsigned)x_bytes, LevelTab{}, 0);                     \
+      } else {                                                                                    \
+        auto kern = k_dcn_patch<NHWC, SRC>;                                                       \
+        dim3 grid((unsigned)ntiles(128), (unsigned)((O + kMaxO - 1) / kMaxO));                    \
+        S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));      \
+        kern<<<grid, 512, kPatchLds, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, relu, \
+                                           (unsigned)x_bytes, LevelTab{}, 0);                     \
+      }                                                                                           \
     }                                                                                             \
   } while (0)
 #define S2A_DCN_PICK(NHWC, SRC) do { if (patch_ok) S2A_DCN_LAUNCH_PATCH(NHWC, SRC); else if (ws_use) S2A_DCN_LAUNCH_WS(NHWC, SRC); else if (big) S2A_DCN_LAUNCH(NHWC, SRC, 128); else S2A_DCN_LAUNCH(NHWC, SRC, 64); } while (0)
@@ -2676,8 +3097,22 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
     S2A_LAUNCH_CHECK();
     return S2A_OK;
   }
-  auto kern = k_dcn_patch<true, 1>;
   const unsigned ogroups = (unsigned)((out_channels + kMaxO - 1) / kMaxO);
+  {
+    // ring-3 variant (loaders two stages ahead with LDS-DMA patches, fragment reads across stage boundaries, raw
+    // barriers): bit-identical, measured 2-8 % SLOWER than k_dcn_patch on MI355X (241 vs 235 us on the bench's launch,
+    // 320 vs 291 us on dense random data) -- the stalls it removes are not what bounds a stage.  Opt-in (S2A_DCN_RING3=1).
+    const char* r3 = getenv("S2A_DCN_RING3");
+    if (channels % 128 == 0 && r3 && atoi(r3) != 0) {
+      auto k3 = k_dcn_ring3<true, 1>;
+      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, kRing3Lds));
+      k3<<<dim3((unsigned)tiles, ogroups), 512, kRing3Lds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
+                                                                 lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu, 0u, lt);
+      S2A_LAUNCH_CHECK();
+      return S2A_OK;
+    }
+  }
+  auto kern = k_dcn_patch<true, 1>;
   // One 153 KB workgroup per CU: a launch runs in rounds of n_cu tiles.  When the last round would fill less than
   // half of the chip (the bench's 1 368 tiles on 256 CUs: 5 rounds + 88 tiles), those tiles can run as twice as many
   // 4 x 16 half tiles in a second launch -- half a round instead of a whole one.  Bit-identical; measured gain only

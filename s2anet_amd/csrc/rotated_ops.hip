@@ -1526,7 +1526,9 @@ int side_stream(SideStream** out) {
   S2A_CHECK_ARG(dev >= 0 && dev < 64, "device index out of range");
   SideStream& ss = g_side[dev];
   if (!ss.s) {
-    S2A_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    int lo = 0, hi = 0;                      // lowest priority: the fill must never crowd out the compute chain
+    S2A_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    S2A_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, lo));
     S2A_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
     S2A_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
   }
@@ -1576,7 +1578,10 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     if (rc != S2A_OK) return rc;
     S2A_HIP(hipEventRecord(ss->fork, st));
     S2A_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
-    k_fill_zero<<<2048, 256, 0, ss->s>>>(ious, (unsigned long long)n * (unsigned long long)m);
+    // one workgroup per CU: 4 waves with 16-byte stores in flight saturate a CU's share of the HBM write rate
+    // (~25 GB/s per CU) and leave its other 28 wave slots to the kernels of the caller's stream (with 2048 workgroups the
+    // fill took every slot first and the chain ran AFTER it: 231 us = 51 + 155 + gaps, no overlap at all)
+    k_fill_zero<<<256, 256, 0, ss->s>>>(ious, (unsigned long long)n * (unsigned long long)m);
     S2A_HIP(hipEventRecord(ss->join, ss->s));
   }
   k_prep_boxes2<<<(unsigned)((std::max<int64_t>(n + m, 512) + 255) / 256), 256, 0, st>>>(boxes1, n, P1, boxes2, m, P2, counters, 512);

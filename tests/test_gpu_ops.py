@@ -1148,6 +1148,62 @@ def test_pyramid_alignconv_persistent_matches_plain(monkeypatch):
     assert outs["1"].float().abs().sum().item() > 0
 
 
+def test_pyramid_alignconv_ring3_matches_plain(monkeypatch):
+    """the default kernel of the pyramid launch (k_dcn_ring3: three-deep column-tile ring, loaders two stages ahead, 3-pixel
+    patch halo) is bit-identical to the plain patch kernel (S2A_DCN_RING3=0): more tiles than CUs, ragged level sizes,
+    tame anchors (everything inside the patch) and wild ones (corners leaving the 14 x 22 patch take the global gather)"""
+    from s2anet_amd import pyramid as P
+    from s2anet_amd.alignconv import pack_weight
+    B, C = 3, 256
+    sizes = [(96, 136), (48, 68), (24, 34), (12, 17), (6, 9)]
+    strides = (8, 16, 32, 64, 128)
+    lay = P.PyramidLayout(B, sizes, strides)
+    g = torch.Generator().manual_seed(79)
+    x = torch.relu(torch.randn(lay.pixels, C, generator=g)).to(dev()).half()
+    wp = pack_weight((torch.randn(256, C, 3, 3, generator=g) * 0.02).to(dev()).half(), torch.float16)
+    for jitter, spread in ((0.05, 0.1), (0.9, 0.7)):
+        anchors = []
+        for (h, w), st in zip(sizes, strides):
+            ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+            a = torch.stack([xs * st + 0.5 * (st - 1) + torch.randn(h, w, generator=g) * st * jitter,
+                             ys * st + 0.5 * (st - 1) + torch.randn(h, w, generator=g) * st * jitter,
+                             4 * st * torch.exp(torch.randn(h, w, generator=g) * spread),
+                             4 * st * torch.exp(torch.randn(h, w, generator=g) * spread),
+                             torch.rand(h, w, generator=g) * 3.14159 - 0.785], -1).float()
+            anchors.append(a.unsqueeze(0).expand(B, -1, -1, -1).reshape(-1, 5))
+        anchors = torch.cat(anchors).to(dev()).contiguous()
+        outs = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("S2A_DCN_RING3", mode)
+            outs[mode] = P.align_conv(lay, x, anchors, wp, 256).clone()
+        assert torch.equal(outs["0"], outs["1"]), (jitter, (outs["0"].float() - outs["1"].float()).abs().max().item())
+        assert outs["1"].float().abs().sum().item() > 0
+
+
+def test_alignconv_small_grid_half_tiles_match(monkeypatch):
+    """a launch with fewer 8 x 16 tiles than 1.5 x CUs (BASELINE configs[1]: one P3 level of one chip) runs as 4 x 16 half
+    tiles: bit-identical to the full-tile launch (S2A_DCN_NO_HALF=1), both layouts of the output"""
+    from s2anet_amd.alignconv import align_conv_forward
+    g = torch.Generator().manual_seed(80)
+    B, C, H, W, O, st = 1, 256, 128, 120, 256, 8
+    x = torch.randn(B, C, H, W, generator=g).to(dev()).half()
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    anc = torch.stack([xs * st + 3.5 + torch.randn(H, W, generator=g) * 4, ys * st + 3.5 + torch.randn(H, W, generator=g) * 4,
+                       32 * torch.exp(torch.randn(H, W, generator=g) * 0.5), 32 * torch.exp(torch.randn(H, W, generator=g) * 0.5),
+                       torch.rand(H, W, generator=g) * 3.14159 - 0.785], -1)[None].to(dev())
+    w = (torch.randn(O, C, 3, 3, generator=g) * 0.02).to(dev()).half()
+    for xin in (x, x.contiguous(memory_format=torch.channels_last)):
+        outs = {}
+        for mode in ("", "1"):
+            if mode:
+                monkeypatch.setenv("S2A_DCN_NO_HALF", mode)
+            else:
+                monkeypatch.delenv("S2A_DCN_NO_HALF", raising=False)
+            outs[mode] = align_conv_forward(xin, anc, w, st, relu=True).clone()
+        assert torch.equal(outs[""], outs["1"])
+        assert outs[""].float().abs().sum().item() > 0
+
+
 def test_pyramid_alignconv_half_tile_tail_matches(monkeypatch):
     """a launch whose last round would leave most CUs idle finishes with 4 x 16 half tiles (second launch): same bits
     as the single launch of 8 x 16 tiles; levels with odd row counts (half tiles past the image bottom) included"""
