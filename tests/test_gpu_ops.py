@@ -90,6 +90,39 @@ def test_iou_dense_overlap_wide(rng):
 
 
 # ------------------------------------------------------------------ NMS
+def test_iou_grid_path_exotic_inputs(rng, monkeypatch):
+    """large outputs (>= 8 MB) can find their overlapping pairs through a uniform grid over the second set (S2A_IOU_GRID=1,
+    opt-in: slower on MI355X than the all-pairs cull, kept as a measured alternative): same bits as the all-pairs cull
+    and as the oracle with (a) one huge column (its radius inflates every row's
+    search range), (b) non-finite columns and rows (evaluated, never culled: NaN in, NaN out, as the reference),
+    (c) all centres on one point (degenerate bounding box), (d) a far outlier that squeezes everything into one cell"""
+    import s2anet_amd as S
+    n, m = 1500, 1600
+    for case in ("huge", "nonfinite", "point", "outlier"):
+        b1, b2 = rand_rboxes(rng, n, span=600), rand_rboxes(rng, m, span=600)
+        if case == "huge":
+            b2[7, 2:4] = (3000.0, 2500.0)
+        elif case == "nonfinite":
+            b2[3, 0], b2[11, 2], b2[500, 4], b2[900, 1] = np.nan, np.nan, np.nan, np.inf
+            b1[5, 1], b1[77, 3] = np.nan, np.inf
+        elif case == "point":
+            b1[:, :2], b2[:, :2] = 300.0, 300.0
+        else:
+            b2[0, :2] = 4e6
+        ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU)
+        plain = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
+        monkeypatch.setenv("S2A_IOU_GRID", "1")
+        got = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
+        monkeypatch.delenv("S2A_IOU_GRID")
+        # the two pair finders must agree bit for bit, NaN patterns included (same evaluation of whatever survives)
+        assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)), case
+        # and every pair of FINITE boxes equals the oracle (what a non-finite box yields -- NaN or 0 -- is pinned by
+        # nothing in the reference: its CUDA op was never run on such input; here they are evaluated, never culled)
+        fin = np.isfinite(b1).all(1)[:, None] & np.isfinite(b2).all(1)[None, :]
+        assert np.array_equal(got[fin].view(np.uint32), ref[fin].view(np.uint32)), case
+        assert (ref[fin] > 0).mean() > (0.5 if case == "point" else 0.005)
+
+
 @pytest.mark.parametrize("thr", [0.1, 0.5])
 def test_nms_golden_keep_bitexact(thr):
     import s2anet_amd as S
