@@ -4,7 +4,13 @@
 Derivations (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves;
 GRBM_GUI_ACTIVE is summed over the 8 XCDs -> kernel cycles = GRBM_GUI_ACTIVE / 8; clock = cycles / duration."""
 import collections, csv, glob, sys
-root, kernels = sys.argv[1], sys.argv[2:]
+import json
+args = sys.argv[1:]
+json_out = None
+if "--json" in args:
+    k = args.index("--json"); json_out = args[k + 1]; del args[k:k + 2]
+root, kernels = args[0], args[1:]
+summary = {}
 trace = (glob.glob(root + "/p1/*/*kernel_trace.csv") + glob.glob(root + "/p1/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(trace)))
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -47,3 +53,7 @@ for k in kernels:
         print(f"  LDS: bank-conflict cycles {c['SQ_LDS_BANK_CONFLICT']:.3g} of {c['SQ_LDS_IDX_ACTIVE']:.3g} LDS-array cycles = {c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'] * 100:4.1f} %; "
               f"LDS array busy {c['SQ_LDS_IDX_ACTIVE'] / (cycles * CUS) * 100:4.1f} % of CU cycles")
     print(f"  HBM: FETCH_SIZE {c['FETCH_SIZE']:.0f} KiB (x2 on gfx950 for wide reads), WRITE_SIZE {c['WRITE_SIZE']:.0f} KiB per dispatch")
+    summary[k] = {"us": round(us, 1), "waves_per_cu": round(waves_in_flight / CUS, 2), "occupancy_pct": round(waves_in_flight / CUS / MAXW * 100, 1),
+                  "valu_util_pct": round(c['SQ_ACTIVE_INST_VALU'] * 4 / simd_cycles * 100, 1), "theoretical_waves_per_cu": limit}
+if json_out:
+    json.dump(summary, open(json_out, "w"), indent=1)
