@@ -110,8 +110,11 @@ int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64_t* keep, i
  * Ties in score are broken by ascending original index (the reference leaves them to
  * torch's unstable sort).
  *
- * Everything — sort, suppression mask, greedy scan, compaction — runs on the device;
- * the reference's device->host copy of the mask (cuda.cu:109) does not exist here.
+ * Everything — sort, pair finding, exact IoU, greedy resolution, compaction — runs on the
+ * device; the reference's N x N/64 mask and its device->host copy (cuda.cu:109) do not exist here:
+ * suppressing pairs are kept as a list.  s2a_nms_rotated_workspace_bytes() sizes the lists for
+ * dense inputs; a SMALLER workspace (>= the fixed part + 48 KB) is accepted, and a call whose
+ * lists fill up finishes on a slower memory-free kernel with the same keep list.
  * labels may be NULL (single class).  keep must hold n int64.  *count_dev (device
  * int64) receives K; if host_count != NULL the call synchronises the stream once and
  * stores K there (the reference call shape needs K on the host to size its result).

@@ -1,7 +1,9 @@
 """Carrier network for the end-to-end configs: R-50 backbone (C3-C5) + FPN (P3-P7) + S2ANetHead.
 
-The backbone and neck are stock ``torch.nn`` convolutions executed by MIOpen (no
-custom arithmetic there, out of scope for hand-written kernels).  Structure follows
+The backbone and neck carry no custom arithmetic: their layers are ``torch.nn`` modules that hold
+the parameters, and at f16 inference every 1x1 / 3x3 convolution of them runs on this package's own ``k_conv_f16``
+(BN folded, bias / residual / ReLU fused; `fused.py`) - only FPN's two stride-2 extra levels go to the library.
+Structure follows
 models/backbone.py:37-175,283-354 and models/neck.py:5-96 (same module/parameter names, so a
 reference ``state_dict`` loads), but the constructor is OFFLINE: no torchvision download
 (backbone.py:241-255); weights are seeded random (kaiming for ResNet backbone.py:134-140,
