@@ -36,6 +36,9 @@ namespace s2a {
 namespace {
 
 // S2A_ABL: compile-time ablation switches for timing experiments only (never set in a shipped build)
+#ifndef S2A_MPIPE
+#define S2A_MPIPE 1
+#endif
 #ifndef S2A_ABL
 #define S2A_ABL 0
 #endif
@@ -919,6 +922,50 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     int s = 0;
     unsigned long long t_tic = 0, t_work = 0, t_wait = 0;
     (void)t_tic; (void)t_work; (void)t_wait;
+#if S2A_MPIPE
+    // B fragments one k-step AHEAD of the MFMAs that use them (two register sets), also across the stage boundary: the
+    // stage's barrier sits in front of the LAST k-step, after all four reads of the current tile have been issued and
+    // have landed -- behind it the next tile is sealed and its first fragments are requested under the last 2*NT MFMAs.
+    // (The plain form read 2 k-steps and waited for them at once: two exposed LDS round trips per stage plus one behind
+    // the barrier.)  Same MFMAs in the same order: bit-identical.
+    V p0[NT], p1[NT];
+    // (no branch on wave_active in here: a wave without out-channels computes on clamped filter fragments and drops the
+    // result in the epilogue -- a branch would split the basic block and hipcc's waitcnt pass then waits for ALL LDS
+    // reads at every join, the prefetched ones included)
+    auto bfrag = [&](int st, int kk, V (&pf)[NT]) {
+      const char* prow = s_B + (st & 1) * (NPOS * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
+#pragma unroll
+      for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
+    };
+    auto mma = [&](const V (&wv)[2][4], int kk, const V (&pf)[NT]) {
+      if (S2A_ABL & 4) return;
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], pf[b], acc[a][b], 0, 0, 0);
+    };
+    auto stage = [&](int st, const V (&wv)[2][4]) {
+      bfrag(st, 1, p1); __builtin_amdgcn_sched_barrier(0);
+      mma(wv, 0, p0);   __builtin_amdgcn_sched_barrier(0);
+      bfrag(st, 2, p0); __builtin_amdgcn_sched_barrier(0);
+      mma(wv, 1, p1);   __builtin_amdgcn_sched_barrier(0);
+      bfrag(st, 3, p1); __builtin_amdgcn_sched_barrier(0);
+      mma(wv, 2, p0);   __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // tile st+1 sealed; this tile's buffer is free for the loaders (all its reads have landed)
+      bfrag(min(st + 1, last), 0, p0); __builtin_amdgcn_sched_barrier(0);   // (last stage: a dead re-read)
+      mma(wv, 3, p1);   __builtin_amdgcn_sched_barrier(0);
+    };
+    bfrag(0, 0, p0);
+    if (S2A_ABL & 32) load_w(1, wB);     // timing only: the filter fragments of stages 0 / 1 serve every stage
+    for (; s + 1 < nstage; s += 2) {
+      if (!(S2A_ABL & 32)) load_w(s + 1, wB);
+      stage(s, wA);
+      if (!(S2A_ABL & 32)) load_w(min(s + 2, last), wA);
+      stage(s + 1, wB);
+    }
+    if (s < nstage) stage(s, wA);
+#else
     for (; s + 1 < nstage; s += 2) {
       S2A_TIC();
       load_w(s + 1, wB);
@@ -938,6 +985,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     }
     S2A_STAMP_VAL(6, t_work);
     S2A_STAMP_VAL(7, t_wait);
+#endif
   } else {
     // ===================== loader waves =====================
     auto patch_issue = [&](int cc) {
@@ -2089,6 +2137,10 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     if (tid < 64 * OG) s_bias[tid] = bias_v;
     if constexpr (TAIL) { if (tid < 256) s_bias[64 + tid] = tail_bias_v; }
     __syncthreads();
+    // (Measured dead end, round 2: fragments one k-step ahead in two register sets across taps, the barrier in front of
+    // the tap's last k-step with counted vmcnt, DMAs issued behind it -- bit-identical and within noise of this form,
+    // 219-225 vs 222 us: at two waves per SIMD the partner wave already covers these waits.  Timing-only ablations of
+    // that form: no filter DMA in the loop -7 %, no patch DMA 0 %, no barrier -3 %, neither -11 %.)
     for (int cc = 0; cc < CC; cc++) {
       const char* Pc = smem + (cc & 1) * Cfg::kPatchBytes;
 #pragma unroll
