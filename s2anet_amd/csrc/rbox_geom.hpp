@@ -142,9 +142,14 @@ __device__ __forceinline__ void prebox_vertices(float xc, float yc, const PreBox
 }
 
 // Full IoU of two pre-processed boxes.  `pts` points at THIS thread's slot of an LDS
-// array float2[24][NT]; element i of the thread is pts[i * NT].
-template <int NT>
-__device__ float rbox_iou(const PreBox& A, const PreBox& B, float2* pts) {
+// array float2[CAP][NT]; element i of the thread is pts[i * NT].
+// CAP = 24 is the reference's worst case (16 edge crossings + 8 contained vertices).  Two rectangles in general position
+// produce at most 8 candidate points (the vertices of their intersection polygon); a pass that gives every lane only 8
+// slots keeps three times as many waves resident (the algorithm is a chain of dependent LDS round trips: latency-bound
+// at 3 waves per SIMD).  With CAP < 24 a pair with more candidates sets *overflow and returns 0: the caller redoes it
+// with CAP = 24.  Same arithmetic in the same order either way.
+template <int NT, int CAP = 24>
+__device__ float rbox_iou(const PreBox& A, const PreBox& B, float2* pts, bool* overflow = nullptr) {
   // single_box_iou_rotated (:339-362): centre shift in double, areas in float
   float sumx = A.x + B.x, sumy = A.y + B.y;
   double shx = (double)sumx / 2.0, shy = (double)sumy / 2.0;
@@ -177,7 +182,7 @@ __device__ float rbox_iou(const PreBox& A, const PreBox& B, float2* pts) {
       float t1 = cross2(ebx[j], eby[j], dx, dy) / det;
       float t2 = cross2(eax[i], eay[i], dx, dy) / det;
       if (!parallel && t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
-        pts[n * NT] = make_float2(ax[i] + eax[i] * t1, ay[i] + eay[i] * t1);
+        if (CAP >= 24 || n < CAP) pts[n * NT] = make_float2(ax[i] + eax[i] * t1, ay[i] + eay[i] * t1);
         n++;
       }
     }
@@ -192,7 +197,7 @@ __device__ float rbox_iou(const PreBox& A, const PreBox& B, float2* pts) {
       float apab = dot2(apx, apy, ebx[0], eby[0]);
       float apad = -dot2(apx, apy, ebx[3], eby[3]);
       if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) {
-        pts[n * NT] = make_float2(ax[i], ay[i]);
+        if (CAP >= 24 || n < CAP) pts[n * NT] = make_float2(ax[i], ay[i]);
         n++;
       }
     }
@@ -207,10 +212,14 @@ __device__ float rbox_iou(const PreBox& A, const PreBox& B, float2* pts) {
       float apab = dot2(apx, apy, eax[0], eay[0]);
       float apad = -dot2(apx, apy, eax[3], eay[3]);
       if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) {
-        pts[n * NT] = make_float2(bx[i], by[i]);
+        if (CAP >= 24 || n < CAP) pts[n * NT] = make_float2(bx[i], by[i]);
         n++;
       }
     }
+  }
+  if (CAP < 24 && n > CAP) {
+    *overflow = true;
+    return 0.f;
   }
 
   float inter = 0.0f;

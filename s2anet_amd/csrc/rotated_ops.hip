@@ -206,6 +206,126 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
   queue_flush(Q, gq, gcount, cap);
 }
 
+// ---- pair finding beside a forked zero-fill (no stores here): ROW-major.  A thread keeps ONE row box in registers and
+// walks the workgroup's 256 columns, whose circle records are LDS broadcast reads (no vector memory, no barrier in the
+// loop; scalar loads were tried: 32 records = 128 SGPRs cannot be in flight at once); the verdicts of 32 columns collect in a per-lane bit mask, survivors go to a list
+// private to the wave, and as soon as it holds 64 the wave runs the separating-axis test on them with all lanes busy.
+// What survives both tests is staged per wave and published with one global atomic per workgroup.
+// (The column-major form above pays a workgroup barrier every two rows -- 2048 tests -- for its coalesced zero stores:
+// 88 us for the 1e8 circle tests of 10 k x 10 k, a quarter of the VALU rate.)
+// Circle test: (ax-bx)^2 + (ay-by)^2 > (1.002 ar + 1e-3 + 1.002 br)^2 -- surely_disjoint's margin with the two factors
+// hoisted into the row and the column record; NaNs compare false and are evaluated.
+constexpr int kCrCols = 256;                  // columns per workgroup (their boxes are staged in LDS for the second test)
+constexpr int kCrChunk = 32;                  // columns per mask word
+constexpr int kCrList = 64 * kCrChunk + 64;   // per-wave survivor list, u16 = row-in-wave << 8 | column-in-workgroup
+constexpr int kCrStage = 256;                 // per-wave staged pairs
+__global__ __launch_bounds__(kThreads) void k_iou_cull_rows(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
+                                                            int64_t row0, int64_t row1, int64_t m,
+                                                            uint2* __restrict__ gq,
+                                                            unsigned long long* __restrict__ gcount,
+                                                            unsigned long long cap) {
+  __shared__ PreBox s_rows[kThreads], s_cols[kCrCols];
+  __shared__ float4 s_circ[kCrCols];
+  __shared__ unsigned short s_list[kThreads / 64][kCrList];
+  __shared__ uint2 s_stage[kThreads / 64][kCrStage];
+  __shared__ unsigned s_n1[kThreads / 64], s_left[kThreads / 64];
+  __shared__ unsigned long long s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t rbeg = row0 + (int64_t)blockIdx.y * kThreads;
+  const int64_t row = rbeg + threadIdx.x;
+  const bool valid = row < row1;
+  PreBox A = {};
+  if (valid) A = P1[row];
+  s_rows[threadIdx.x] = A;                       // read back by this wave only
+  const float ax = A.x, ay = A.y, ar = A.r * 1.002f + 1e-3f;
+  const int64_t jw = (int64_t)blockIdx.x * kCrCols;
+  const int ncol = (int)min((int64_t)kCrCols, m - jw);
+  unsigned short* list = s_list[wave];
+  uint2* stage = s_stage[wave];
+  const PreBox* rows_w = s_rows + wave * 64;
+  if (lane == 0) s_n1[wave] = 0;
+  static_assert(kCrCols == kThreads, "one column box per thread");
+  {
+    const PreBox cb = threadIdx.x < ncol ? P2[jw + threadIdx.x] : PreBox{};
+    s_cols[threadIdx.x] = cb;
+    s_circ[threadIdx.x] = make_float4(cb.x, cb.y, cb.r * 1.002f, 0.f);
+  }
+  __syncthreads();                               // the only barrier in front of the final flush
+  unsigned n1 = 0, ns = 0;                       // wave-uniform: listed survivors, staged pairs
+  auto flush = [&]() {                           // rare: > 192 pairs of one wave inside 256 x 256 (dense inputs)
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(gcount, (unsigned long long)ns);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+    for (unsigned k = lane; k < ns; k += 64)
+      if (base + k < cap) gq[base + k] = stage[k];
+    ns = 0;
+  };
+  auto drain = [&](bool all) {                   // full groups of 64 from the top of the list; the rest stays in front
+    while (n1 >= 64u || (all && n1 > 0u)) {
+      const unsigned cnt = min(n1, 64u), base = n1 - cnt;
+      bool hit = false;
+      unsigned r = 0, c = 0;
+      if ((unsigned)lane < cnt) {
+        const unsigned v = list[base + lane];
+        r = v >> 8;
+        c = v & 255u;
+        hit = !sat_disjoint(rows_w[r], s_cols[c]);
+      }
+      const unsigned long long bal = __ballot(hit);
+      if (hit)
+        stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] =
+            make_uint2((unsigned)(rbeg + wave * 64 + r - row0), (unsigned)(jw + c));
+      ns += (unsigned)__popcll(bal);
+      n1 = base;
+      if (ns + 64 > kCrStage) flush();
+    }
+    if (lane == 0) s_n1[wave] = n1;
+  };
+  for (int jc = 0; jc < ncol; jc += kCrChunk) {
+    const float4* cp = s_circ + jc;              // uniform address: LDS broadcast reads, many in flight
+    unsigned mask = 0;
+    if (ncol - jc >= kCrChunk) {
+#pragma unroll
+      for (int jj = 0; jj < kCrChunk; jj++) {
+        const float4 c = cp[jj];
+        const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
+        mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
+      }
+    } else {
+      for (int jj = 0; jj < ncol - jc; jj++) {
+        const float4 c = cp[jj];
+        const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
+        mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
+      }
+    }
+    if (!valid) mask = 0;
+    while (mask) {
+      const unsigned b = (unsigned)__ffs((int)mask) - 1u;
+      mask &= mask - 1u;
+      const unsigned p = atomicAdd(&s_n1[wave], 1u);
+      list[p] = (unsigned short)(((unsigned)lane << 8) | (unsigned)(jc + b));
+    }
+    n1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_n1[wave]);
+    drain(false);
+  }
+  drain(true);
+  // leftovers of the four stages: one global atomic per workgroup
+  if (lane == 0) s_left[wave] = ns;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++) {
+    if (w < wave) before += s_left[w];
+    all += s_left[w];
+  }
+  if (all == 0) return;                // uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(gcount, (unsigned long long)all);
+  __syncthreads();
+  const unsigned long long base = s_base + before;
+  for (unsigned k = lane; k < ns; k += 64)
+    if (base + k < cap) gq[base + k] = stage[k];
+}
+
 // ---- pair finding for large problems: uniform grid over the second box set instead of all-pairs circle tests.
 // (The all-pairs cull is VALU-bound: 1e8 circle tests = 61-88 us at 10 k x 10 k, of which ~1 % survive.)  The columns are
 // binned by centre into a G x G grid over their bounding box (count, scan, scatter: cell-sorted copies of the boxes);
@@ -386,12 +506,19 @@ __global__ __launch_bounds__(kThreads) void k_iou_grid_query(const PreBox* __res
 
 // HEAVY: dense list, one pair per lane, persistent grid.  Values go to a compact buffer (vals[e] for pair e): this pass
 // runs while the zero-fill of the output is still in flight on the side stream, so it must not touch `out`.
+// Two passes: the first gives every lane 8 candidate-point slots (16 KB of LDS per workgroup instead of 48: the exact
+// IoU is a chain of dependent LDS round trips and was latency-bound at 3 waves per SIMD); a pair that produces more than
+// 8 candidates (shared edges, duplicates: never in general position) leaves a marker, and k_iou_scatter redoes the
+// marked pairs with the full 24 slots.  A genuine result with the marker's bits would only be recomputed to itself.
+constexpr int kIouCap = 8;
+constexpr uint32_t kIouRedo = 0x7fc5a5a5u;
+constexpr int kHeavyGrid = 2048;     // 8 workgroups per CU
 __global__ __launch_bounds__(kThreads) void k_iou_heavy(const PreBox* __restrict__ P1,
                                                         const PreBox* __restrict__ P2, int64_t row0,
                                                         const uint2* __restrict__ gq,
                                                         const unsigned long long* __restrict__ gcount,
                                                         unsigned long long cap, float* __restrict__ vals) {
-  __shared__ float2 s_pts[24 * kThreads];
+  __shared__ float2 s_pts[kIouCap * kThreads];
   const unsigned long long total = *gcount;
   if (total > cap) return;       // list overflow: k_iou_scatter recomputes the chunk directly
   for (unsigned long long e = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; e < total;
@@ -399,7 +526,9 @@ __global__ __launch_bounds__(kThreads) void k_iou_heavy(const PreBox* __restrict
     uint2 ij = gq[e];
     PreBox A = P1[row0 + ij.x];
     PreBox B = P2[ij.y];
-    vals[e] = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
+    bool redo = false;
+    const float v = rbox_iou<kThreads, kIouCap>(A, B, s_pts + threadIdx.x, &redo);
+    vals[e] = redo ? __uint_as_float(kIouRedo) : v;
   }
 }
 
@@ -426,7 +555,10 @@ __global__ __launch_bounds__(kThreads) void k_iou_scatter(const PreBox* __restri
   for (unsigned long long e = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; e < total;
        e += (unsigned long long)gridDim.x * kThreads) {
     const uint2 ij = gq[e];
-    out[(row0 + ij.x) * m + ij.y] = vals[e];
+    float v = vals[e];
+    if (__float_as_uint(v) == kIouRedo)      // more than 8 candidate points in the first pass: all 24 slots here
+      v = rbox_iou<kThreads>(P1[row0 + ij.x], P2[ij.y], s_pts + threadIdx.x);
+    out[(row0 + ij.x) * m + ij.y] = v;
   }
 }
 
@@ -1072,12 +1204,17 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
 // DENSE IoU pass: one pair per lane; pairs above the threshold become edges.  Every wave stages its edges in a private
 // LDS buffer and publishes them with ONE global atomic per flush (an atomic per wave and sweep -- ~20 k on one address at
 // 200 k rows -- made the pass atomic-bound); a wave is synchronous, so the staging needs no barrier.
-constexpr int kEdgeStage = 128;      // staged edges per wave (1 KB: 48 + 4 KB of LDS keep three workgroups per CU)
+constexpr int kEdgeStage = 128;      // staged edges per wave
+// REDO = false: every lane has 8 candidate-point slots (see k_iou_heavy); a pair that needs more is marked in place (top
+// bit of its first index -- positions are < 2^31) and REDO = true, the second launch, evaluates the marked pairs with 24.
+constexpr uint32_t kPairRedo = 0x80000000u;
+template <bool REDO>
 __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict__ sorted, float thr,
-                                                        const uint2* __restrict__ gq, NmsCounters* __restrict__ C,
+                                                        uint2* __restrict__ gq, NmsCounters* __restrict__ C,
                                                         unsigned long long cap, uint2* __restrict__ edges,
                                                         unsigned long long ecap) {
-  __shared__ float2 s_pts[24 * kThreads];
+  constexpr int CAP = REDO ? 24 : kIouCap;
+  __shared__ float2 s_pts[CAP * kThreads];
   __shared__ uint2 s_stage[kThreads / 64][kEdgeStage];
   const unsigned long long total = min(C->pairs, cap);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1098,16 +1235,43 @@ __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict
     uint2 ij = make_uint2(0, 0);
     if (e < total) {
       ij = gq[e];
-      const PreBox A = sorted[ij.x];  // higher score first: same argument order as the reference
-      const PreBox B = sorted[ij.y];
-      hit = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x) > thr;  // reference GPU rule: strict (ml_nms cuda.cu:63-64)
+      if (REDO) {
+        if (ij.x & kPairRedo) {
+          ij.x &= ~kPairRedo;
+          hit = rbox_iou<kThreads>(sorted[ij.x], sorted[ij.y], s_pts + threadIdx.x) > thr;
+        }
+      } else {
+        const PreBox A = sorted[ij.x];  // higher score first: same argument order as the reference
+        const PreBox B = sorted[ij.y];
+        bool redo = false;
+        hit = rbox_iou<kThreads, CAP>(A, B, s_pts + threadIdx.x, &redo) > thr;  // reference GPU rule: strict (ml_nms cuda.cu:63-64)
+        if (redo) gq[e].x = ij.x | kPairRedo;
+      }
     }
+    if (REDO && !__any(hit)) continue;    // (wave-uniform; the common case of the second launch)
     const unsigned long long bal = __ballot(hit);
     if (hit) stage[staged + __popcll(bal & ((1ull << lane) - 1ull))] = ij;
     staged += (unsigned)__popcll(bal);
     if (staged + 64 > kEdgeStage) flush();
   }
-  if (staged) flush();
+  // what is left in the four stages goes out with ONE atomic per workgroup (a final flush per wave was 8 k atomics on
+  // one address at 2048 workgroups: +25 us)
+  __shared__ unsigned s_left[kThreads / 64];
+  __shared__ unsigned long long s_base;
+  if (lane == 0) s_left[wave] = staged;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++) {
+    if (w < wave) before += s_left[w];
+    all += s_left[w];
+  }
+  if (all == 0) return;                // uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(&C->edges, (unsigned long long)all);
+  __syncthreads();
+  const unsigned long long base = s_base + before;
+  for (unsigned k = lane; k < staged; k += 64)
+    if (base + k < ecap) edges[base + k] = stage[k];
 }
 
 // ---------------------------------------------------------------- greedy order by rounds over the edge list
@@ -1595,7 +1759,8 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   k_nms_tile_filter<<<kPersistentGrid, kThreads, 0, st>>>(B.seg_start, B.num_seg, B.tile_off, lo, B.hi, B.tiles, B.C,
                                                           pl.tile_cap);
   k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(B.sp_box, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
-  k_nms_heavy<<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
+  k_nms_heavy<false><<<kHeavyGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
+  k_nms_heavy<true><<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
   // the pair list is dead after the dense pass: its memory takes the alive-edge list of the last launched round
   for (int r = 1; r <= kNmsRounds; r++)
     k_nms_round<<<256, kThreads, 0, st>>>(B.edges, B.C, pl.edge_cap, B.state, B.blocked, n, r,
@@ -1753,7 +1918,9 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   // runs on a side stream at the full store rate while this stream finds the overlapping pairs and evaluates them into a
   // compact buffer; after the join a small kernel drops the values into place.  (Round 1 stored the zeros from the cull
   // kernel -- 4 TB/s beside its circle tests -- and ran the dense pass after it: 212 us at 10 k x 10 k.)
-  const bool fork = (unsigned long long)n * (unsigned long long)m * 4ull >= kIouForkBytes;
+  const char* ef = getenv("S2A_IOU_FORK");                 // A/B: 0 = never fork, 1 = always
+  const bool fork = ef && (ef[0] == '0' || ef[0] == '1') ? ef[0] == '1'
+                                                           : (unsigned long long)n * (unsigned long long)m * 4ull >= kIouForkBytes;
   SideStream* ss = nullptr;
   std::unique_lock<std::mutex> lock(g_side_mutex, std::defer_lock);
   if (fork) {
@@ -1777,6 +1944,8 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   // bounding-box pass took 67 us); the VALU-bound all-pairs cull is what overlaps with the fill.
   const char* eg = getenv("S2A_IOU_GRID");
   const bool use_grid = fork && eg && eg[0] == '1';
+  const char* ec = getenv("S2A_IOU_CULL_COLS");            // A/B: the column-major cull beside the forked fill
+  const bool cull_cols = ec && ec[0] == '1';
   if (use_grid) {
     const unsigned gm = (unsigned)((m + 255) / 256);
     k_iou_grid_init<<<(kGridMax * kGridMax + 2 + 255) / 256, 256, 0, st>>>(grid);
@@ -1790,11 +1959,14 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     dim3 grid_c((unsigned)((m + kThreads * 4 - 1) / (kThreads * 4)), (unsigned)((r1 - r0 + kIouRowsPerWg - 1) / kIouRowsPerWg));
     if (use_grid)
       k_iou_grid_query<<<256, kThreads, 0, st>>>(P1, P2s, r0, r1, grid, G, gq, counters + c, cap);
+    else if (fork && !cull_cols)
+      k_iou_cull_rows<<<dim3((unsigned)((m + kCrCols - 1) / kCrCols), (unsigned)((r1 - r0 + kThreads - 1) / kThreads)),
+                        kThreads, 0, st>>>(P1, P2, r0, r1, m, gq, counters + c, cap);
     else if (fork)
       k_iou_cull<false><<<grid_c, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
     else
       k_iou_cull<true><<<grid_c, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
-    k_iou_heavy<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, gq, counters + c, cap, vals);
+    k_iou_heavy<<<kHeavyGrid, kThreads, 0, st>>>(P1, P2, r0, gq, counters + c, cap, vals);
     if (fork && c == 0) S2A_HIP(hipStreamWaitEvent(st, ss->join, 0));
     k_iou_scatter<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap, vals);
   }

@@ -221,6 +221,8 @@ if __name__ == "__main__":
         res.append(dcn_backward(8, dtype=torch.float32)); res.append(dcn_backward(8, dtype=torch.float16))
     if a.which in ("all", "poly"):
         res += poly_ops()
+    if a.which == "iou10k":
+        print(json.dumps(iou(10000, 10000)))
     if a.which == "nms200k":
         res.append(nms(200000))
     if a.which in ("all", "nms"):

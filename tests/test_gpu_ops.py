@@ -89,6 +89,40 @@ def test_iou_dense_overlap_wide(rng):
     assert (bits(out) != bits(ref)).sum() == 0 and (out[:, 1000:] == 0).all()
 
 
+def _degenerate_boxes(rng, n):
+    """boxes whose pairs produce MORE than 8 candidate points (duplicates, quarter-turn copies, shared edges and corners):
+    the dense IoU pass gives a lane 8 point slots and hands such pairs to the 24-slot redo path"""
+    base = rand_rboxes(rng, n // 4, span=60, lo=8, hi=30)
+    base[:, 4] = rng.choice(np.array([0.0, np.pi / 2, np.pi / 4, 0.3], np.float32), n // 4)
+    dup = base.copy()
+    turn = base.copy(); turn[:, 4] += np.float32(np.pi / 2); turn[:, [2, 3]] = turn[:, [3, 2]]      # same footprint
+    touch = base.copy(); touch[:, 0] += touch[:, 2] * np.cos(touch[:, 4]); touch[:, 1] += touch[:, 2] * np.sin(touch[:, 4])
+    return np.concatenate([base, dup, turn, touch]).astype(np.float32)
+
+
+def test_iou_pairs_with_many_candidate_points(rng):
+    import s2anet_amd as S
+    b1 = _degenerate_boxes(rng, 1600)
+    b2 = np.concatenate([b1[::2], rand_rboxes(rng, 800, span=60, lo=8, hi=30)])
+    out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()              # 10 MB: the forked path
+    ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU)
+    assert (bits(out) != bits(ref)).sum() == 0
+    assert (np.abs(out - 1.0) < 1e-5).sum() >= 400                      # the duplicates are there
+    small = S.box_iou_rotated(cu(b1[:300]), cu(b2[:200])).cpu().numpy()  # the fused (un-forked) path
+    assert (bits(small) != bits(ref[:300, :200])).sum() == 0
+
+
+def test_nms_with_duplicates_and_shared_edges(rng):
+    from s2anet_amd.rotated import ml_nms_rotated
+    d = _degenerate_boxes(rng, 4000)
+    sc = distinct_scores(rng, len(d))
+    lab = rng.integers(0, 3, len(d)).astype(np.float32)
+    for thr in (0.1, 0.5, 0.9):
+        keep = ml_nms_rotated(cu(d), cu(sc), cu(lab), thr).cpu().numpy()
+        ref = oracle.nms_rotated(d, sc, thr, labels=lab, rule=oracle.RULE_GT, sort_mode=oracle.SORT_GPU)
+        assert np.array_equal(keep, ref), thr
+
+
 # ------------------------------------------------------------------ NMS
 def test_iou_grid_path_exotic_inputs(rng, monkeypatch):
     """large outputs (>= 8 MB) can find their overlapping pairs through a uniform grid over the second set (S2A_IOU_GRID=1,
