@@ -42,6 +42,9 @@ constexpr int kThreads = 256;
 constexpr int kLdsQueue = 1024;      // entries per workgroup queue; a dense-stage batch adds at most 256
 constexpr int kFlushAt = kLdsQueue - 256;
 constexpr int kPersistentGrid = 1024;
+constexpr int kIouCap = 8;               // candidate-point slots per lane of the fast exact-IoU passes (rbox_iou)
+constexpr uint32_t kIouRedo = 0x7fc5a5a5u;   // marker of a pair that needs all 24 slots
+constexpr int kHeavyGrid = 2048;         // 8 workgroups per CU
 constexpr unsigned kScanCacheWords = 6144;  // 48 KB of suppression mask cached in LDS per segment
 
 __device__ __forceinline__ uint32_t float_sortable(float f) {
@@ -326,6 +329,170 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull_rows(const PreBox* __rest
     if (base + k < cap) gq[base + k] = stage[k];
 }
 
+// ---- large outputs in ONE launch: a workgroup owns a 256 x 256 tile of the matrix.  Each wave zero-fills its 64 rows of
+// the tile (1 KB per store instruction), then finds the pairs of those rows that can overlap exactly as k_iou_cull_rows
+// does (row box in registers, column circle records as LDS broadcast reads, 16-column verdict masks, wave-private
+// survivor list, separating-axis test with all lanes busy) and -- as soon as 64 pairs have passed both tests -- evaluates
+// them with the exact algorithm and stores the values into its own zeros.  No pair list in HBM, no second pass over the
+// output, no side stream; the store-bound, VALU-bound and latency-bound phases of different workgroups overlap by
+// themselves.  A pair with more than 8 candidate points (see rbox_iou) goes to a short global list that k_iou_redo
+// evaluates with 24 slots.  The zero stores of a wave precede its value stores in program order AND are drained
+// (vmcnt(0)) before the first value store.
+constexpr int kTileCols = 256;
+constexpr int kTChunk = 16;                   // columns per verdict mask
+constexpr int kTList = 64 * kTChunk + 64;     // per-wave survivor list (u16 = row-in-wave << 8 | column-in-tile)
+constexpr int kTStage = 128;                  // per-wave pairs awaiting the exact evaluation (same encoding)
+__global__ __launch_bounds__(kThreads) void k_iou_tile(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
+                                                       int64_t n, int64_t m, float* __restrict__ out,
+                                                       uint2* __restrict__ redo,
+                                                       unsigned long long* __restrict__ redo_count,
+                                                       unsigned long long redo_cap) {
+  __shared__ PreBox s_rows[kThreads], s_cols[kTileCols];
+  __shared__ float4 s_circ[kTileCols];
+  __shared__ unsigned short s_list[kThreads / 64][kTList];
+  __shared__ unsigned short s_stage[kThreads / 64][kTStage];
+  __shared__ float2 s_pts[kThreads / 64][kIouCap * 64];
+  __shared__ unsigned s_n1[kThreads / 64];
+  static_assert(kTileCols == kThreads, "one column box per thread");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t rbeg = (int64_t)blockIdx.y * kThreads;
+  const int64_t row = rbeg + threadIdx.x;
+  const bool valid = row < n;
+  const int64_t jw = (int64_t)blockIdx.x * kTileCols;
+  const int ncol = (int)min((int64_t)kTileCols, m - jw);
+  PreBox A = {};
+  if (valid) A = P1[row];
+  s_rows[threadIdx.x] = A;                       // read back by this wave only
+  {
+    const PreBox cb = threadIdx.x < ncol ? P2[jw + threadIdx.x] : PreBox{};
+    s_cols[threadIdx.x] = cb;
+    s_circ[threadIdx.x] = make_float4(cb.x, cb.y, cb.r * 1.002f, 0.f);
+  }
+  if (lane == 0) s_n1[wave] = 0;
+  __syncthreads();                               // the only barrier
+  const int64_t wr0 = rbeg + wave * 64;          // this wave's rows
+  {
+    const int nr = (int)max((int64_t)0, min((int64_t)64, n - wr0));
+    const int c0 = lane * 4;
+    float* o = out + wr0 * m + jw + c0;
+    if ((m & 3) == 0) {                          // rows are 16-byte aligned (and ncol is a multiple of 4)
+      if (c0 < ncol)
+        for (int r = 0; r < nr; r++) *reinterpret_cast<float4*>(o + (int64_t)r * m) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int r = 0; r < nr; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (c0 + k < ncol) o[(int64_t)r * m + k] = 0.f;
+    }
+  }
+  const float ax = A.x, ay = A.y, ar = A.r * 1.002f + 1e-3f;
+  unsigned short* list = s_list[wave];
+  unsigned short* stage = s_stage[wave];
+  float2* pts = s_pts[wave] + lane;
+  const PreBox* rows_w = s_rows + wave * 64;
+  unsigned n1 = 0, ns = 0;                       // wave-uniform: listed survivors, staged pairs
+  bool zeros_drained = false;                    // wave-uniform
+  auto exact = [&](unsigned base, unsigned cnt) {            // pairs stage[base .. base + cnt)
+    if (!zeros_drained) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      zeros_drained = true;
+    }
+    bool again = false;
+    unsigned i = 0, j = 0;
+    if ((unsigned)lane < cnt) {
+      const unsigned v = stage[base + lane], r = v >> 8, c = v & 255u;
+      i = (unsigned)(wr0 + r);
+      j = (unsigned)(jw + c);
+      const float iou = rbox_iou<64, kIouCap>(rows_w[r], s_cols[c], pts, &again);
+      if (!again) out[(int64_t)i * m + j] = iou;
+    }
+    const unsigned long long bal = __ballot(again);
+    if (bal) {                                   // rare; one atomic per wave
+      unsigned long long b = 0;
+      if (lane == 0) b = atomicAdd(redo_count, (unsigned long long)__popcll(bal));
+      b = ((unsigned long long)(uint32_t)__shfl((int)(b >> 32), 0) << 32) | (uint32_t)__shfl((int)(b & 0xffffffffu), 0);
+      const unsigned long long p = b + __popcll(bal & ((1ull << lane) - 1ull));
+      if (again && p < redo_cap) redo[p] = make_uint2(i, j);
+    }
+  };
+  auto drain = [&](bool all) {
+    while (n1 >= 64u || (all && n1 > 0u)) {
+      const unsigned cnt = min(n1, 64u), base = n1 - cnt;
+      bool hit = false;
+      unsigned v = 0;
+      if ((unsigned)lane < cnt) {
+        v = list[base + lane];
+        hit = !sat_disjoint(rows_w[v >> 8], s_cols[v & 255u]);
+      }
+      const unsigned long long bal = __ballot(hit);
+      if (hit) stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)v;
+      ns += (unsigned)__popcll(bal);
+      n1 = base;
+      if (ns >= 64u) {
+        ns -= 64u;
+        exact(ns, 64u);
+      }
+    }
+    if (lane == 0) s_n1[wave] = n1;
+  };
+  for (int jc = 0; jc < ncol; jc += kTChunk) {
+    const float4* cp = s_circ + jc;              // uniform address: LDS broadcast reads
+    unsigned mask = 0;
+    if (ncol - jc >= kTChunk) {
+#pragma unroll
+      for (int jj = 0; jj < kTChunk; jj++) {
+        const float4 c = cp[jj];
+        const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
+        mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
+      }
+    } else {
+      for (int jj = 0; jj < ncol - jc; jj++) {
+        const float4 c = cp[jj];
+        const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
+        mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
+      }
+    }
+    if (!valid) mask = 0;
+    while (mask) {
+      const unsigned b = (unsigned)__ffs((int)mask) - 1u;
+      mask &= mask - 1u;
+      const unsigned p = atomicAdd(&s_n1[wave], 1u);
+      list[p] = (unsigned short)(((unsigned)lane << 8) | (unsigned)(jc + b));
+    }
+    n1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_n1[wave]);
+    drain(false);
+  }
+  drain(true);
+  if (ns) exact(0, ns);
+}
+
+// the pairs k_iou_tile could not evaluate with 8 candidate-point slots.  List overflow (only inputs made of duplicates get
+// there): every pair of the matrix is recomputed directly.
+__global__ __launch_bounds__(kThreads) void k_iou_redo(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
+                                                       int64_t n, int64_t m, float* __restrict__ out,
+                                                       const uint2* __restrict__ redo,
+                                                       const unsigned long long* __restrict__ redo_count,
+                                                       unsigned long long redo_cap) {
+  __shared__ float2 s_pts[24 * kThreads];
+  const unsigned long long total = *redo_count;
+  if (total == 0) return;
+  if (total > redo_cap) {
+    const int64_t all = n * m;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < all; e += (int64_t)gridDim.x * kThreads) {
+      const int64_t i = e / m, j = e % m;
+      const PreBox A = P1[i], B = P2[j];
+      if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B))
+        out[e] = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
+    }
+    return;
+  }
+  for (unsigned long long e = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; e < total;
+       e += (unsigned long long)gridDim.x * kThreads) {
+    const uint2 ij = redo[e];
+    out[(int64_t)ij.x * m + ij.y] = rbox_iou<kThreads>(P1[ij.x], P2[ij.y], s_pts + threadIdx.x);
+  }
+}
+
 // ---- pair finding for large problems: uniform grid over the second box set instead of all-pairs circle tests.
 // (The all-pairs cull is VALU-bound: 1e8 circle tests = 61-88 us at 10 k x 10 k, of which ~1 % survive.)  The columns are
 // binned by centre into a G x G grid over their bounding box (count, scan, scatter: cell-sorted copies of the boxes);
@@ -510,9 +677,6 @@ __global__ __launch_bounds__(kThreads) void k_iou_grid_query(const PreBox* __res
 // IoU is a chain of dependent LDS round trips and was latency-bound at 3 waves per SIMD); a pair that produces more than
 // 8 candidates (shared edges, duplicates: never in general position) leaves a marker, and k_iou_scatter redoes the
 // marked pairs with the full 24 slots.  A genuine result with the marker's bits would only be recomputed to itself.
-constexpr int kIouCap = 8;
-constexpr uint32_t kIouRedo = 0x7fc5a5a5u;
-constexpr int kHeavyGrid = 2048;     // 8 workgroups per CU
 __global__ __launch_bounds__(kThreads) void k_iou_heavy(const PreBox* __restrict__ P1,
                                                         const PreBox* __restrict__ P2, int64_t row0,
                                                         const uint2* __restrict__ gq,
@@ -1918,9 +2082,24 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   // runs on a side stream at the full store rate while this stream finds the overlapping pairs and evaluates them into a
   // compact buffer; after the join a small kernel drops the values into place.  (Round 1 stored the zeros from the cull
   // kernel -- 4 TB/s beside its circle tests -- and ran the dense pass after it: 212 us at 10 k x 10 k.)
-  const char* ef = getenv("S2A_IOU_FORK");                 // A/B: 0 = never fork, 1 = always
-  const bool fork = ef && (ef[0] == '0' || ef[0] == '1') ? ef[0] == '1'
-                                                           : (unsigned long long)n * (unsigned long long)m * 4ull >= kIouForkBytes;
+  const bool big = (unsigned long long)n * (unsigned long long)m * 4ull >= kIouForkBytes;
+  const char* ef = getenv("S2A_IOU_FORK");                 // A/B (with S2A_IOU_TILE=0): 0 = never fork, 1 = always
+  const bool fork = ef && (ef[0] == '0' || ef[0] == '1') ? ef[0] == '1' : big;
+  // OPT-IN (S2A_IOU_TILE=1): ONE launch, k_iou_tile.  Bit-exact (tests force every path), measured: 48 vs 55 us at
+  // 21824 x 128 with 1 % of the pairs overlapping, but 245 vs 195 us at 10 k x 10 k (its workgroups no longer fit one
+  // resident round) and 552 vs 216 us for 21824 anchors x 300 ground-truth boxes, where most pairs overlap and the exact
+  // evaluation runs at the tile kernel's 12 waves per CU instead of the dense pass's 17-32.  The density is not known
+  // in advance, so the pipeline of separate passes below is the default.
+  const char* et = getenv("S2A_IOU_TILE");
+  const bool use_tile = et && et[0] == '1';
+  if (use_tile) {
+    k_prep_boxes2<<<(unsigned)((std::max<int64_t>(n + m, 512) + 255) / 256), 256, 0, st>>>(boxes1, n, P1, boxes2, m, P2, counters, 512);
+    k_iou_tile<<<dim3((unsigned)((m + kTileCols - 1) / kTileCols), (unsigned)((n + kThreads - 1) / kThreads)), kThreads, 0,
+                 st>>>(P1, P2, n, m, ious, gq, counters, cap);
+    k_iou_redo<<<kPersistentGrid / 2, kThreads, 0, st>>>(P1, P2, n, m, ious, gq, counters, cap);
+    S2A_LAUNCH_CHECK();
+    return S2A_OK;
+  }
   SideStream* ss = nullptr;
   std::unique_lock<std::mutex> lock(g_side_mutex, std::defer_lock);
   if (fork) {

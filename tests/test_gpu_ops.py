@@ -100,16 +100,32 @@ def _degenerate_boxes(rng, n):
     return np.concatenate([base, dup, turn, touch]).astype(np.float32)
 
 
-def test_iou_pairs_with_many_candidate_points(rng):
+@pytest.mark.parametrize("path", ["tile", "pipeline", "unforked"])
+def test_iou_pairs_with_many_candidate_points(rng, monkeypatch, path):
+    """every way box_iou_rotated can be evaluated: the single-launch tile kernel (default while its grid is resident at
+    once), the forked pipeline of separate passes (bigger problems) and the un-forked pipeline"""
     import s2anet_amd as S
+    monkeypatch.setenv("S2A_IOU_TILE", "1" if path == "tile" else "0")
+    monkeypatch.setenv("S2A_IOU_FORK", "0" if path == "unforked" else "1")
     b1 = _degenerate_boxes(rng, 1600)
-    b2 = np.concatenate([b1[::2], rand_rboxes(rng, 800, span=60, lo=8, hi=30)])
-    out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()              # 10 MB: the forked path
+    b2 = np.concatenate([b1[::2], rand_rboxes(rng, 803, span=60, lo=8, hi=30)])     # 1603 columns: unaligned rows
+    out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
     ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU)
     assert (bits(out) != bits(ref)).sum() == 0
     assert (np.abs(out - 1.0) < 1e-5).sum() >= 400                      # the duplicates are there
-    small = S.box_iou_rotated(cu(b1[:300]), cu(b2[:200])).cpu().numpy()  # the fused (un-forked) path
-    assert (bits(small) != bits(ref[:300, :200])).sum() == 0
+    out4 = S.box_iou_rotated(cu(b1), cu(b2[:1600])).cpu().numpy()       # 16-byte aligned rows
+    assert (bits(out4) != bits(ref[:, :1600])).sum() == 0
+
+
+@pytest.mark.parametrize("path", ["tile", "pipeline"])
+def test_iou_dense_overlap_both_paths(rng, monkeypatch, path):
+    import s2anet_amd as S
+    monkeypatch.setenv("S2A_IOU_TILE", "1" if path == "tile" else "0")
+    b1, b2 = rand_rboxes(rng, 900, span=25, lo=30, hi=60), rand_rboxes(rng, 2300, span=25, lo=30, hi=60)
+    b2[1500:, :2] += 5000.0
+    out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
+    ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU)
+    assert (bits(out) != bits(ref)).sum() == 0 and (out[:, 1500:] == 0).all() and (out[:, :1500] > 0).mean() > 0.95
 
 
 def test_nms_with_duplicates_and_shared_edges(rng):
