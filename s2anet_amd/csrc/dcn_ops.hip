@@ -756,7 +756,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   char* s_B = smem + NPOS * 9 * 16;
   char* s_patch = s_B + 2 * NPOS * kRowBytes;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (waves 0-3 = matrix: the older half wins issue
+                                                                   // arbitration; roles swapped measured 4 % slower)
   int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const int half = TH == 4 ? (int)(tile & 1) : 0;
   if (TH == 4) tile >>= 1;
