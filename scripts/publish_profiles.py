@@ -24,22 +24,32 @@ with open(os.path.join(P, "r02_alignconv_pyramid_pmc.txt"), "w") as f:
 # rocprofv3 PMC passes over `python bench.py --steps 4 --warmup 2 --no-cpu-baseline` (scripts/pmc_bench.sh, tree %s).
 # FETCH_SIZE / WRITE_SIZE in KiB; gfx950: FETCH_SIZE reads half of a wide coalesced read -> read bytes = 2 x %.0f KiB = %.1f MB,
 # WRITE_SIZE exact -> %.1f MB; traffic per launch = %.1f MB vs %.1f MB algorithmic (in + out + filter + anchors) = %.2fx
-# (unchanged from round 1: the kernel was not changed; see DESIGN.md section 4 for the ablations and the ring-3 variant).
+# (round 1: 256.2 MB; the matrix waves' fragment prefetch of this round does not change the traffic; DESIGN.md section 4).
 """ % (head, a["fetch_kib"], 2 * a["fetch_kib"] * 1024 / 1e6, a["write_kib"] * 1024 / 1e6, a["bytes"] / 1e6, alg / 1e6, a["bytes"] / alg))
 shutil.copy(os.path.join(G, "pmc_bench", "summary_k_conv_f16_9_4.txt"), os.path.join(P, "r02_conv_tower_pmc.txt"))
 
-# 3. NMS at 200 k rows: counters after the rework, memory-copy trace, kernel stats
+# 3. NMS at 200 k rows: counters after the rework, memory-copy trace, kernel stats (the report is regenerated here so that
+# the two instantiations of the dense pass -- 8-slot first launch, 24-slot redo -- are listed apart)
+NMS_KERNELS = ["k_nms_cull", "k_nms_heavy<false>", "k_nms_heavy<true>", "k_nms_tile_filter", "k_nms_round",
+               "k_nms_finish_segments", "k_nms_pos_meta"]
+rep = subprocess.run([sys.executable, os.path.join(R, "scripts", "nms_pmc_report.py"), os.path.join(G, "pmc_nms200k"),
+                      "--json", os.path.join(F, "nms_occupancy.json")] + NMS_KERNELS, capture_output=True, text=True)
+assert rep.returncode == 0, rep.stderr
+open(os.path.join(F, "nms_pmc_report.txt"), "w").write(rep.stdout)
+nms_ms = [json.loads(l)["ms"] for l in open(os.path.join(F, "ops_report.jsonl")) if l.startswith("{") and '"ml_nms_rotated"' in l and '"n": 200000' in l]
 with open(os.path.join(P, "r02_nms_200k_pmc.txt"), "w") as f:
     f.write("""# rotated ml-NMS at BASELINE configs[4] (200 000 rows x 15 labels, thr 0.5) AFTER the round-2 rework (tree %s); before:
 # r02_nms_200k_pmc_before.txt (2.79 ms per call; cull 1231 us at 14 waves/CU, scan 719 us at 0.25 waves/CU, dense pass 456 us).
 # Same command and counter sets: rocprofv3 --kernel-trace --pmc <set> -- python scripts/bench_ops.py --which nms200k
-# (scripts/pmc_cmd.sh, report by scripts/nms_pmc_report.py).  Whole call (HIP events, un-profiled): 0.91-0.93 ms.
+# (scripts/pmc_cmd.sh, report by scripts/nms_pmc_report.py).  Whole call (HIP events, un-profiled): %.2f ms.
 # What changed: Morton-sorted 64-row blocks + bounding-box tile filter (83 %% of the tiles never tested), separating axes + IoU
 # upper bound before the dense pass (7x fewer IoU evaluations), edge list resolved by parallel rounds (no suppression mask, no serial
 # scan), wave / workgroup aggregated atomics.  Device -> host traffic: the memory-copy trace below shows host -> device uploads of the
 # test inputs only (3 copies); no copy-engine transfer device -> host; the 8-byte keep count of the pybind-shaped entry point goes
 # through a shader copy, the segmented entry point of the detector returns nothing to the host.
-""" % head)
+# Dense IoU pass: k_nms_heavy<false> gives a lane 8 candidate-point slots (16 KB of LDS per workgroup; 98 -> 58 us), k_nms_heavy<true>
+# redoes the pairs that need the reference's 24.
+""" % (head, nms_ms[0] if nms_ms else float("nan")))
     f.write(cat(os.path.join(F, "nms_pmc_report.txt")))
     f.write("\n# rocprofv3 --kernel-trace --memory-copy-trace --stats, memory copy stats of the same command:\n")
     f.write(cat(os.path.join(F, "memcpy", "run_memory_copy_stats.csv")))
