@@ -736,8 +736,13 @@ constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs +
 
 // TH = rows of the position tile: 8 (128 positions), or 4 (64 positions: the half tiles that finish a pyramid launch
 // whose last round would leave most CUs idle; tile index = tile_base + block / 2, upper / lower half = block & 1)
-template <bool OUT_NHWC, int SRC, int TH = 8>
-__global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict__ x_,
+// DUO (TH = 4 only): a form that lets TWO workgroups share a CU -- <= 128 VGPRs (filter fragments in ONE register set,
+// refilled k-step by k-step right behind the MFMAs that read them) and 64.5 KB of LDS (ONE patch buffer: the next chunk's
+// patch waits in the loaders' registers and is written when the chunk's last tap has been fetched; the first tap of a
+// chunk is then fetched inside its own stage instead of one stage ahead).  One workgroup's table build, patch load,
+// epilogue and barrier waits then run under the other's MFMAs.  Same arithmetic and order: bit-identical.
+template <bool OUT_NHWC, int SRC, int TH = 8, bool DUO = false>
+__global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* __restrict__ x_,
                                                       const float* __restrict__ src_,
                                                       const _Float16* __restrict__ wfrag,
                                                       _Float16* __restrict__ out_, int64_t Ntot_, int C,
@@ -750,6 +755,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   constexpr int kPatchBytesT = kPHt * kPW * 128;
   constexpr int NPV = kPHt * kPW * 8 / 256;            // 16-byte patch vectors per loader thread (12 | 9)
   static_assert(TH == 8 || TH == 4, "tile height");
+  static_assert(!DUO || TH == 4, "two workgroups per CU: half tiles");
   static_assert(kPHt * kPW * 8 % 256 == 0, "patch vectors must divide among the loader threads");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PTap* s_tab = reinterpret_cast<PTap*>(smem);
@@ -958,6 +964,31 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       mma(wv, 3, p1);   __builtin_amdgcn_sched_barrier(0);
     };
     bfrag(0, 0, p0);
+    if constexpr (DUO) {
+      // one fragment set: the fragments of k-step kk of the NEXT stage are requested right behind the MFMAs of k-step
+      // kk of this one (three k-steps and the barrier of latency; the partner workgroup's matrix wave covers the rest)
+      auto load_wk = [&](int st, int kk) {
+        const V* p = wf_base + ((int64_t)st * G + g) * 8 * 64;
+#pragma unroll
+        for (int a = 0; a < 2; a++) wA[a][kk] = p[(a * 4 + kk) * 64];
+      };
+      for (; s < nstage; s++) {
+        const int sx = min(s + 1, last);
+        bfrag(s, 1, p1); __builtin_amdgcn_sched_barrier(0);
+        mma(wA, 0, p0);  __builtin_amdgcn_sched_barrier(0);
+        load_wk(sx, 0);  __builtin_amdgcn_sched_barrier(0);
+        bfrag(s, 2, p0); __builtin_amdgcn_sched_barrier(0);
+        mma(wA, 1, p1);  __builtin_amdgcn_sched_barrier(0);
+        load_wk(sx, 1);  __builtin_amdgcn_sched_barrier(0);
+        bfrag(s, 3, p1); __builtin_amdgcn_sched_barrier(0);
+        mma(wA, 2, p0);  __builtin_amdgcn_sched_barrier(0);
+        load_wk(sx, 2);  __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        bfrag(sx, 0, p0); __builtin_amdgcn_sched_barrier(0);
+        mma(wA, 3, p1);  __builtin_amdgcn_sched_barrier(0);
+        load_wk(sx, 3);  __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     if (S2A_ABL & 32) load_w(1, wB);     // timing only: the filter fragments of stages 0 / 1 serve every stage
     for (; s + 1 < nstage; s += 2) {
       if (!(S2A_ABL & 32)) load_w(s + 1, wB);
@@ -966,6 +997,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       stage(s + 1, wB);
     }
     if (s < nstage) stage(s, wA);
+    }
 #else
     for (; s + 1 < nstage; s += 2) {
       S2A_TIC();
@@ -997,7 +1029,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       }
     };
     auto patch_write = [&](int cc) {
-      char* P = s_patch + (cc & 1) * kPatchBytesT;
+      char* P = s_patch + (DUO ? 0 : (cc & 1)) * kPatchBytesT;
 #pragma unroll
       for (int i = 0; i < NPV; i++) *reinterpret_cast<V*>(P + (L + 256 * i) * 16) = pv[i];
     };
@@ -1008,7 +1040,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     V c[ITEMS][4];
     auto fetch = [&](int s) {
       const int t = s % 9, cc = s / 9;
-      const char* P = s_patch + (cc & 1) * kPatchBytesT + (L & 7) * 16;   // (item & 7 = L & 7 for every item)
+      const char* P = s_patch + (DUO ? 0 : (cc & 1)) * kPatchBytesT + (L & 7) * 16;   // (item & 7 = L & 7 for every item)
 #pragma unroll
       for (int it = 0; it < ITEMS; it++)      // one 16-byte read per entry
         tp[it] = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[((L + 256 * it) >> 3) * 9 + t]));
@@ -1067,10 +1099,21 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       S2A_TIC();
       if (sn < nstage) {
         const int t = sn % 9, cc = sn / 9;
+        if constexpr (DUO) {
+          if (t == 0) fetch(sn);                          // new chunk: its patch was sealed by the previous barrier
+          produce(sn);
+          if (t == 8) {                                   // every fetch of this chunk is behind a barrier: the buffer is free
+            if (cc + 1 < CC) patch_write(cc + 1);
+            if (cc + 2 < CC) patch_issue(cc + 2);
+          } else if (sn + 1 < nstage) {
+            fetch(sn + 1);
+          }
+        } else {
         if (t == 4 && cc + 1 < CC) patch_write(cc + 1);   // loads issued >= 3 stages ago
         produce(sn);
         if (t == 8 && cc + 2 < CC) patch_issue(cc + 2);   // next-next chunk: lands during the next chunk
         if (sn + 1 < nstage) fetch(sn + 1);               // (chunk of stage sn+1: written >= 4 stages ago)
+        }
       }
       S2A_TOC(t_work); S2A_TIC();
       __syncthreads();
@@ -3164,6 +3207,17 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
       S2A_LAUNCH_CHECK();
       return S2A_OK;
     }
+  }
+  if (const char* d = getenv("S2A_DCN_DUO"); d && atoi(d) != 0) {
+    // two half-tile workgroups per CU (k_dcn_patch<.., 4, DUO>): see the kernel's header
+    constexpr int kDuoLds = 64 * 9 * 16 + 2 * 64 * kRowBytes + (4 + 2 * kHalo) * kPW * 128;   // 64 512 B
+    auto kd = k_dcn_patch<true, 1, 4, true>;
+    S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, kDuoLds));
+    kd<<<dim3((unsigned)(2 * tiles), ogroups), 512, kDuoLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0,
+                                                                   (int)channels, lt.H[0], lt.W[0], (int)out_channels,
+                                                                   lt.stride[0], relu, 0u, lt, 0);
+    S2A_LAUNCH_CHECK();
+    return S2A_OK;
   }
   auto kern = k_dcn_patch<true, 1>;
   // One 153 KB workgroup per CU: a launch runs in rounds of n_cu tiles.  When the last round would fill less than

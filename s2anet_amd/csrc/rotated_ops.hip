@@ -218,17 +218,20 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
 // 88 us for the 1e8 circle tests of 10 k x 10 k, a quarter of the VALU rate.)
 // Circle test: (ax-bx)^2 + (ay-by)^2 > (1.002 ar + 1e-3 + 1.002 br)^2 -- surely_disjoint's margin with the two factors
 // hoisted into the row and the column record; NaNs compare false and are evaluated.
-constexpr int kCrCols = 256;                  // columns per workgroup (their boxes are staged in LDS for the second test)
-constexpr int kCrChunk = 32;                  // columns per mask word
+constexpr int kCrCols = 256;                  // columns per workgroup
+constexpr int kCrChunk = 16;                  // columns per verdict mask
 constexpr int kCrList = 64 * kCrChunk + 64;   // per-wave survivor list, u16 = row-in-wave << 8 | column-in-workgroup
 constexpr int kCrStage = 256;                 // per-wave staged pairs
+// LDS diet (25 KB per workgroup -> 24 waves per CU; the first version kept 50 KB and 12 waves and waited 68 % of the
+// time): ONE 32-byte record per column -- circle part first, so that the broadcast read of the circle test is its first
+// 16 bytes --, and the ROW box of a survivor comes out of the owning lane's registers by ds_bpermute instead of an LDS copy.
+struct alignas(16) ColRec { float x, y, rr, w, h, c2, s2, pad; };
 __global__ __launch_bounds__(kThreads) void k_iou_cull_rows(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
                                                             int64_t row0, int64_t row1, int64_t m,
                                                             uint2* __restrict__ gq,
                                                             unsigned long long* __restrict__ gcount,
                                                             unsigned long long cap) {
-  __shared__ PreBox s_rows[kThreads], s_cols[kCrCols];
-  __shared__ float4 s_circ[kCrCols];
+  __shared__ ColRec s_cols[kCrCols];
   __shared__ unsigned short s_list[kThreads / 64][kCrList];
   __shared__ uint2 s_stage[kThreads / 64][kCrStage];
   __shared__ unsigned s_n1[kThreads / 64], s_left[kThreads / 64];
@@ -239,19 +242,16 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull_rows(const PreBox* __rest
   const bool valid = row < row1;
   PreBox A = {};
   if (valid) A = P1[row];
-  s_rows[threadIdx.x] = A;                       // read back by this wave only
   const float ax = A.x, ay = A.y, ar = A.r * 1.002f + 1e-3f;
   const int64_t jw = (int64_t)blockIdx.x * kCrCols;
   const int ncol = (int)min((int64_t)kCrCols, m - jw);
   unsigned short* list = s_list[wave];
   uint2* stage = s_stage[wave];
-  const PreBox* rows_w = s_rows + wave * 64;
   if (lane == 0) s_n1[wave] = 0;
   static_assert(kCrCols == kThreads, "one column box per thread");
   {
     const PreBox cb = threadIdx.x < ncol ? P2[jw + threadIdx.x] : PreBox{};
-    s_cols[threadIdx.x] = cb;
-    s_circ[threadIdx.x] = make_float4(cb.x, cb.y, cb.r * 1.002f, 0.f);
+    s_cols[threadIdx.x] = ColRec{cb.x, cb.y, cb.r * 1.002f, cb.w, cb.h, cb.c2, cb.s2, 0.f};
   }
   __syncthreads();                               // the only barrier in front of the final flush
   unsigned n1 = 0, ns = 0;                       // wave-uniform: listed survivors, staged pairs
@@ -266,13 +266,18 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull_rows(const PreBox* __rest
   auto drain = [&](bool all) {                   // full groups of 64 from the top of the list; the rest stays in front
     while (n1 >= 64u || (all && n1 > 0u)) {
       const unsigned cnt = min(n1, 64u), base = n1 - cnt;
+      const bool mine = (unsigned)lane < cnt;
+      const unsigned v = mine ? (unsigned)list[base + lane] : 0u;
+      const unsigned r = v >> 8, c = v & 255u;
+      // the row box of survivor (r, c) sits in lane r's registers (all lanes take part in the permutes)
+      PreBox R;
+      R.x = __shfl(A.x, (int)r); R.y = __shfl(A.y, (int)r); R.w = __shfl(A.w, (int)r); R.h = __shfl(A.h, (int)r);
+      R.c2 = __shfl(A.c2, (int)r); R.s2 = __shfl(A.s2, (int)r); R.r = 0.f; R.label = 0.f;
       bool hit = false;
-      unsigned r = 0, c = 0;
-      if ((unsigned)lane < cnt) {
-        const unsigned v = list[base + lane];
-        r = v >> 8;
-        c = v & 255u;
-        hit = !sat_disjoint(rows_w[r], s_cols[c]);
+      if (mine) {
+        const ColRec q = s_cols[c];
+        const PreBox B = {q.x, q.y, q.w, q.h, q.c2, q.s2, 0.f, 0.f};
+        hit = !sat_disjoint(R, B);
       }
       const unsigned long long bal = __ballot(hit);
       if (hit)
@@ -285,18 +290,18 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull_rows(const PreBox* __rest
     if (lane == 0) s_n1[wave] = n1;
   };
   for (int jc = 0; jc < ncol; jc += kCrChunk) {
-    const float4* cp = s_circ + jc;              // uniform address: LDS broadcast reads, many in flight
+    const float4* cp = reinterpret_cast<const float4*>(s_cols + jc);   // uniform address: LDS broadcast reads of (x, y, rr, .)
     unsigned mask = 0;
     if (ncol - jc >= kCrChunk) {
 #pragma unroll
       for (int jj = 0; jj < kCrChunk; jj++) {
-        const float4 c = cp[jj];
+        const float4 c = cp[2 * jj];
         const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
         mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
       }
     } else {
       for (int jj = 0; jj < ncol - jc; jj++) {
-        const float4 c = cp[jj];
+        const float4 c = cp[2 * jj];
         const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
         mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
       }

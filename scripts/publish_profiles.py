@@ -56,6 +56,18 @@ with open(os.path.join(P, "r02_nms_200k_pmc.txt"), "w") as f:
     f.write("\n# per-kernel averages of one profiled run (scripts/prof_cmd.sh):\n")
     f.write(cat(os.path.join(F, "prof_nms.log")))
 
+# 3b. box_iou_rotated at 10 k x 10 k: counters of the kernels of one call and its timeline
+with open(os.path.join(P, "r02_iou_10k_pmc.txt"), "w") as f:
+    f.write("""# box_iou_rotated at 10 000 x 10 000 (BASELINE configs[0] shape; 1.1 %% of the pairs overlap), tree %s.
+# Counters: rocprofv3 --kernel-trace --pmc <set> -- python scripts/bench_ops.py --which iou10k (scripts/pmc_cmd.sh, report by
+# scripts/nms_pmc_report.py).  Timeline of ONE call (scripts/iou_timeline.sh; q2 = the forked zero-fill stream) at the end.
+# Reading (DESIGN.md section 4, "Round-2 IoU work"): the exact pass is VALU-bound since it runs with 8 candidate-point slots
+# per lane; the pair finder is not -- VALU about a third, the rest waiting -- at 12 and at 24 waves per CU alike.
+""" % head)
+    f.write(cat(os.path.join(F, "iou_pmc_report.txt")))
+    f.write("\n# timeline of one call (us from the start of the call):\n")
+    f.write(cat(os.path.join(F, "iou_timeline.txt")))
+
 # 4. bench: line, steady-state tables, kernel stats
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, "r02_bench_line.json"))
 for tag, out in (("r2final", "r02_bench_steady_state.txt"), ("r2final_s1", "r02_bench_steady_state_streams1.txt")):

@@ -1261,6 +1261,12 @@ def test_pyramid_alignconv_ring3_matches_plain(monkeypatch):
             outs[mode] = P.align_conv(lay, x, anchors, wp, 256).clone()
         assert torch.equal(outs["0"], outs["1"]), (jitter, (outs["0"].float() - outs["1"].float()).abs().max().item())
         assert outs["1"].float().abs().sum().item() > 0
+        # the two-workgroups-per-CU form (half tiles, one patch buffer, one rolling set of filter fragments)
+        monkeypatch.setenv("S2A_DCN_RING3", "0")
+        monkeypatch.setenv("S2A_DCN_DUO", "1")
+        duo = P.align_conv(lay, x, anchors, wp, 256).clone()
+        monkeypatch.setenv("S2A_DCN_DUO", "0")
+        assert torch.equal(outs["0"], duo), (jitter, (outs["0"].float() - duo.float()).abs().max().item())
 
 
 def test_alignconv_small_grid_half_tiles_match(monkeypatch):
