@@ -334,6 +334,98 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull_rows(const PreBox* __rest
     if (base + k < cap) gq[base + k] = stage[k];
 }
 
+// ---- the same pair finding with NO LDS traffic in the circle stage (k_iou_cull_rows spends ~250 LDS-pipe cycles per
+// 16-column chunk and wave: broadcast reads, per-lane atomics on the list counter, conflicted record reads).  Here a
+// wave owns 64 rows (lane = row) and walks its columns 64 at a time: lane j holds column j's box of the chunk in
+// registers, v_readlane hands column j's circle to all lanes as scalar operands (j is a compile-time constant in the
+// unrolled loop), the verdicts collect in a 64-bit mask per lane.  Second stage without a list: every lane walks its own
+// mask bits and fetches the column box from the owning lane by ds_bpermute (the crossbar, not the banks); the loop runs
+// max-popcount times (5-6 at DOTA-like densities).  Survivors of both tests are staged per wave, one global atomic per
+// workgroup at the end.  No barrier anywhere.
+__device__ __forceinline__ float lane_bcast(float v, int j) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+}
+template <int J0, int J1>
+__device__ __forceinline__ void circle_bits(float ax, float ay, float ar, float cx, float cy, float cr, unsigned& bits) {
+#pragma unroll
+  for (int j = J0; j < J1; j++) {
+    const float dx = ax - lane_bcast(cx, j), dy = ay - lane_bcast(cy, j), R = ar + lane_bcast(cr, j);
+    bits |= (dx * dx + dy * dy > R * R ? 0u : 1u) << (j - J0);
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_iou_cull_lanes(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
+                                                             int64_t row0, int64_t row1, int64_t m, int cols_per_wg,
+                                                             uint2* __restrict__ gq,
+                                                             unsigned long long* __restrict__ gcount,
+                                                             unsigned long long cap) {
+  __shared__ uint2 s_stage[kThreads / 64][kCrStage];
+  __shared__ unsigned s_left[kThreads / 64];
+  __shared__ unsigned long long s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wr0 = row0 + ((int64_t)blockIdx.y * (kThreads / 64) + wave) * 64;    // this wave's rows
+  const int64_t row = wr0 + lane;
+  const bool valid = row < row1;
+  PreBox A = {};
+  if (valid) A = P1[row];
+  const float ax = A.x, ay = A.y, ar = A.r * 1.002f + 1e-3f;
+  const int64_t jw = (int64_t)blockIdx.x * cols_per_wg;
+  const int64_t jend = min(m, jw + cols_per_wg);
+  uint2* stage = s_stage[wave];
+  unsigned ns = 0;                               // wave-uniform
+  auto flush = [&]() {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(gcount, (unsigned long long)ns);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+    for (unsigned k = lane; k < ns; k += 64)
+      if (base + k < cap) gq[base + k] = stage[k];
+    ns = 0;
+  };
+  PreBox Cn = {};                                // next chunk's column box of this lane (one chunk ahead)
+  if (jw + lane < jend) Cn = P2[jw + lane];
+  for (int64_t jc = jw; jc < jend; jc += 64) {
+    const PreBox C = Cn;
+    Cn = PreBox{};
+    if (jc + 64 + lane < jend) Cn = P2[jc + 64 + lane];
+    const int nc = (int)min((int64_t)64, jend - jc);
+    // a column beyond the end gets a circle no row can reach (NaN rows reach everything: masked below)
+    const float cx = C.x, cy = C.y, cr = lane < nc ? C.r * 1.002f : -3.0e38f;
+    unsigned lo = 0, hi = 0;
+    circle_bits<0, 32>(ax, ay, ar, cx, cy, cr, lo);
+    circle_bits<32, 64>(ax, ay, ar, cx, cy, cr, hi);
+    unsigned long long mask = ((unsigned long long)hi << 32) | lo;
+    if (nc < 64) mask &= (1ull << nc) - 1ull;
+    if (!valid) mask = 0;
+    while (__any(mask != 0ull)) {
+      const bool has = mask != 0ull;
+      const int j = has ? __ffsll((long long)mask) - 1 : 0;
+      if (has) mask &= mask - 1ull;
+      PreBox B;
+      B.x = __shfl(C.x, j); B.y = __shfl(C.y, j); B.w = __shfl(C.w, j); B.h = __shfl(C.h, j);
+      B.c2 = __shfl(C.c2, j); B.s2 = __shfl(C.s2, j); B.r = 0.f; B.label = 0.f;
+      const bool hit = has && !sat_disjoint(A, B);
+      const unsigned long long bal = __ballot(hit);
+      if (hit)
+        stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2((unsigned)(row - row0), (unsigned)(jc + j));
+      ns += (unsigned)__popcll(bal);
+      if (ns + 64 > kCrStage) flush();
+    }
+  }
+  if (lane == 0) s_left[wave] = ns;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++) {
+    if (w < wave) before += s_left[w];
+    all += s_left[w];
+  }
+  if (all == 0) return;                // uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(gcount, (unsigned long long)all);
+  __syncthreads();
+  const unsigned long long base = s_base + before;
+  for (unsigned k = lane; k < ns; k += 64)
+    if (base + k < cap) gq[base + k] = stage[k];
+}
+
 // ---- large outputs in ONE launch: a workgroup owns a 256 x 256 tile of the matrix.  Each wave zero-fills its 64 rows of
 // the tile (1 KB per store instruction), then finds the pairs of those rows that can overlap exactly as k_iou_cull_rows
 // does (row box in registers, column circle records as LDS broadcast reads, 16-column verdict masks, wave-private
@@ -741,11 +833,16 @@ inline void fill_u32(void* p, uint32_t v, size_t count, hipStream_t st) {
 }
 
 // 16 bytes per lane, grid-stride: 7 TB/s on MI355X (profiles/r02_nms_200k_pmc_before.txt, k_zero_words)
+// PACE > 0: s_sleep between the stores of a wave -- a fill that runs flat out saturates the memory system and every
+// dependent read of the kernels beside it takes ~10 us (the pair finder stretched from 59 to 110 us whatever it did)
+template <int PACE>
 __global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ out, unsigned long long n) {
   const unsigned long long n4 = n / 4, stride = (unsigned long long)gridDim.x * 256;
   float4* o4 = reinterpret_cast<float4*>(out);
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PACE > 0) __builtin_amdgcn_s_sleep(PACE);
+  }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = 0.f;
 }
 
@@ -2113,10 +2210,23 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     if (rc != S2A_OK) return rc;
     S2A_HIP(hipEventRecord(ss->fork, st));
     S2A_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
-    // one workgroup per CU: 4 waves with 16-byte stores in flight saturate a CU's share of the HBM write rate
-    // (~25 GB/s per CU) and leave its other 28 wave slots to the kernels of the caller's stream (with 2048 workgroups the
-    // fill took every slot first and the chain ran AFTER it: 231 us = 51 + 155 + gaps, no overlap at all)
-    k_fill_zero<<<256, 256, 0, ss->s>>>(ious, (unsigned long long)n * (unsigned long long)m);
+    // The fill is PACED (s_sleep between the stores of a wave): flat out it finishes 400 MB in 50-100 us but saturates the
+    // memory system, and every dependent read of the kernels beside it then takes ~10 us -- the pair finder stretched
+    // from 59 to 105-125 us whatever its design and whatever the fill's workgroup count (scripts/iou_fill_scan.sh).  At 512
+    // workgroups and s_sleep 12 it moves ~3.5 TB/s (113 us at 10 k x 10 k), ends before the chain beside it does (pair
+    // finding 62 + exact pass 60-65 us, both at their stand-alone speed) and the call takes ~157 us instead of ~195.
+    int fill_wgs = 512, pace = 12;
+    if (const char* fw = getenv("S2A_IOU_FILL_WGS")) fill_wgs = atoi(fw);     // measurements; 0 = no fill (wrong results)
+    if (const char* fp = getenv("S2A_IOU_FILL_PACE")) pace = atoi(fp);
+    const unsigned long long nm = (unsigned long long)n * (unsigned long long)m;
+    if (fill_wgs > 0) {
+      if (pace >= 12) k_fill_zero<12><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
+      else if (pace >= 8) k_fill_zero<8><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
+      else if (pace >= 6) k_fill_zero<6><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
+      else if (pace >= 4) k_fill_zero<4><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
+      else if (pace >= 2) k_fill_zero<2><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
+      else k_fill_zero<0><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
+    }
     S2A_HIP(hipEventRecord(ss->join, ss->s));
   }
   k_prep_boxes2<<<(unsigned)((std::max<int64_t>(n + m, 512) + 255) / 256), 256, 0, st>>>(boxes1, n, P1, boxes2, m, P2, counters, 512);
@@ -2130,6 +2240,8 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   const bool use_grid = fork && eg && eg[0] == '1';
   const char* ec = getenv("S2A_IOU_CULL_COLS");            // A/B: the column-major cull beside the forked fill
   const bool cull_cols = ec && ec[0] == '1';
+  const char* el = getenv("S2A_IOU_CULL_LANES");            // A/B: 0 = k_iou_cull_rows (LDS broadcast reads, survivor lists)
+  const bool cull_lanes = !(el && el[0] == '0') && !cull_cols;
   if (use_grid) {
     const unsigned gm = (unsigned)((m + 255) / 256);
     k_iou_grid_init<<<(kGridMax * kGridMax + 2 + 255) / 256, 256, 0, st>>>(grid);
@@ -2143,7 +2255,14 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     dim3 grid_c((unsigned)((m + kThreads * 4 - 1) / (kThreads * 4)), (unsigned)((r1 - r0 + kIouRowsPerWg - 1) / kIouRowsPerWg));
     if (use_grid)
       k_iou_grid_query<<<256, kThreads, 0, st>>>(P1, P2s, r0, r1, grid, G, gq, counters + c, cap);
-    else if (fork && !cull_cols)
+    else if (fork && cull_lanes) {
+      // columns per workgroup: enough workgroups for ~8 per CU, at least 256 columns each
+      const int64_t rwg = (r1 - r0 + kThreads - 1) / kThreads;
+      int64_t cw = 256;
+      while (cw < m && rwg * ((m + cw - 1) / cw) > 4096) cw *= 2;
+      k_iou_cull_lanes<<<dim3((unsigned)((m + cw - 1) / cw), (unsigned)rwg), kThreads, 0, st>>>(P1, P2, r0, r1, m, (int)cw, gq,
+                                                                                            counters + c, cap);
+    } else if (fork && !cull_cols)
       k_iou_cull_rows<<<dim3((unsigned)((m + kCrCols - 1) / kCrCols), (unsigned)((r1 - r0 + kThreads - 1) / kThreads)),
                         kThreads, 0, st>>>(P1, P2, r0, r1, m, gq, counters + c, cap);
     else if (fork)

@@ -100,13 +100,14 @@ def _degenerate_boxes(rng, n):
     return np.concatenate([base, dup, turn, touch]).astype(np.float32)
 
 
-@pytest.mark.parametrize("path", ["tile", "pipeline", "unforked"])
+@pytest.mark.parametrize("path", ["tile", "pipeline", "unforked", "lanes"])
 def test_iou_pairs_with_many_candidate_points(rng, monkeypatch, path):
     """every way box_iou_rotated can be evaluated: the single-launch tile kernel (default while its grid is resident at
     once), the forked pipeline of separate passes (bigger problems) and the un-forked pipeline"""
     import s2anet_amd as S
     monkeypatch.setenv("S2A_IOU_TILE", "1" if path == "tile" else "0")
     monkeypatch.setenv("S2A_IOU_FORK", "0" if path == "unforked" else "1")
+    monkeypatch.setenv("S2A_IOU_CULL_LANES", "1" if path == "lanes" else "0")
     b1 = _degenerate_boxes(rng, 1600)
     b2 = np.concatenate([b1[::2], rand_rboxes(rng, 803, span=60, lo=8, hi=30)])     # 1603 columns: unaligned rows
     out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
@@ -117,10 +118,11 @@ def test_iou_pairs_with_many_candidate_points(rng, monkeypatch, path):
     assert (bits(out4) != bits(ref[:, :1600])).sum() == 0
 
 
-@pytest.mark.parametrize("path", ["tile", "pipeline"])
+@pytest.mark.parametrize("path", ["tile", "pipeline", "lanes"])
 def test_iou_dense_overlap_both_paths(rng, monkeypatch, path):
     import s2anet_amd as S
     monkeypatch.setenv("S2A_IOU_TILE", "1" if path == "tile" else "0")
+    monkeypatch.setenv("S2A_IOU_CULL_LANES", "1" if path == "lanes" else "0")
     b1, b2 = rand_rboxes(rng, 900, span=25, lo=30, hi=60), rand_rboxes(rng, 2300, span=25, lo=30, hi=60)
     b2[1500:, :2] += 5000.0
     out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
