@@ -1467,6 +1467,124 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
   queue_flush(Q, gq, gcount, cap);
 }
 
+// The same cull with wave-private tile runs and no workgroup barrier (the structure of k_iou_cull_lanes): lane = row of
+// the tile's row block AND column of its column block, both boxes in registers (the next tile's are fetched one tile
+// ahead); column j's circle reaches all lanes through v_readlane; verdicts of 32 columns in a per-lane mask; every lane
+// reserves its list space with ONE LDS atomic per half tile and writes its survivors; the dense stage takes 64
+// survivors at a time, both boxes through ds_bpermute from the lanes that own them, nms_pair_skippable, ballot-compacted
+// into a per-wave stage of pairs; one global atomic per flush and one per workgroup at the end.
+constexpr int kNlList = 64 * 32;              // circle-test survivors of half a tile, u16 = row << 6 | column
+constexpr int kNlStage = 512;                 // per-wave staged pairs
+constexpr int64_t kNmsLanesRows = 49152;      // rows from which the one-wave-per-tile cull is the default
+__global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __restrict__ sp_box,
+                                                             const TileRef* __restrict__ tiles,
+                                                             NmsCounters* __restrict__ C, unsigned long long tile_cap,
+                                                             uint2* __restrict__ gq, unsigned long long cap, float thr) {
+  __shared__ unsigned short s_list[kThreads / 64][kNlList];
+  __shared__ uint2 s_stage[kThreads / 64][kNlStage];
+  __shared__ unsigned s_n[kThreads / 64], s_left[kThreads / 64];
+  __shared__ unsigned long long s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long* gcount = &C->pairs;
+  const unsigned long long L = min(C->tiles, tile_cap);   // (an overflowing tile list sets the status bit: fallback)
+  const unsigned long long nw = (unsigned long long)gridDim.x * (kThreads / 64);
+  const unsigned long long chunk = (L + nw - 1) / nw;
+  unsigned long long e = ((unsigned long long)blockIdx.x * (kThreads / 64) + wave) * chunk;
+  const unsigned long long eend = min(L, e + chunk);
+  unsigned short* list = s_list[wave];
+  uint2* stage = s_stage[wave];
+  unsigned ns = 0;                               // wave-uniform: staged pairs
+  auto flush = [&]() {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(gcount, (unsigned long long)ns);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+    for (unsigned k = lane; k < ns; k += 64)
+      if (base + k < cap) gq[base + k] = stage[k];
+    ns = 0;
+  };
+  auto load = [&](const TileRef& t, PreBox& R, PreBox& Cc) {
+    const uint32_t il = t.rb * 64 + lane, jl = t.cb * 64 + lane;
+    R = PreBox{};
+    Cc = PreBox{};
+    if (il < t.ns) R = sp_box[t.seg_start + il];
+    if (jl < t.ns) Cc = sp_box[t.seg_start + jl];
+  };
+  if (e < eend) {
+    TileRef t = tiles[e];
+    PreBox A, Cb;
+    load(t, A, Cb);
+    for (; e < eend; e++) {
+      TileRef tn = t;
+      PreBox An = {}, Cn = {};
+      if (e + 1 < eend) {                        // in flight under this tile's tests
+        tn = tiles[e + 1];
+        load(tn, An, Cn);
+      }
+      const bool rowvalid = t.rb * 64 + lane < t.ns;
+      const unsigned long long colvalid = __ballot(t.cb * 64 + lane < t.ns);
+      // upper triangle of a diagonal tile: column j > row lane
+      const unsigned long long tri = t.cb != t.rb ? ~0ull : (lane == 63 ? 0ull : ~((2ull << lane) - 1ull));
+      const float ax = A.x, ay = A.y, ar = A.r * 1.002f + 1e-3f;
+      const float cx = Cb.x, cy = Cb.y, cr = Cb.r * 1.002f;
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        unsigned bits = 0;
+        if (half == 0) circle_bits<0, 32>(ax, ay, ar, cx, cy, cr, bits);
+        else circle_bits<32, 64>(ax, ay, ar, cx, cy, cr, bits);
+        bits &= (unsigned)((colvalid & tri) >> (32 * half));
+        if (!rowvalid) bits = 0;
+        if (lane == 0) s_n[wave] = 0;
+        const unsigned cnt = (unsigned)__popc(bits);
+        unsigned off = 0;
+        if (cnt) off = atomicAdd(&s_n[wave], cnt);             // one reservation per lane (in order behind the reset)
+        while (bits) {
+          const unsigned b = (unsigned)__ffs((int)bits) - 1u;
+          bits &= bits - 1u;
+          list[off++] = (unsigned short)(((unsigned)lane << 6) | (32u * half + b));
+        }
+        unsigned n1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_n[wave]);
+        while (n1 > 0u) {                                        // the whole half tile: the boxes change with the tile
+          const unsigned g = min(n1, 64u), base = n1 - g;
+          const bool mine = (unsigned)lane < g;
+          const unsigned v = mine ? (unsigned)list[base + lane] : 0u;
+          const int r = (int)(v >> 6), c = (int)(v & 63u);
+          PreBox R, B;
+          R.x = __shfl(A.x, r); R.y = __shfl(A.y, r); R.w = __shfl(A.w, r); R.h = __shfl(A.h, r);
+          R.c2 = __shfl(A.c2, r); R.s2 = __shfl(A.s2, r); R.r = __shfl(A.r, r); R.label = __shfl(A.label, r);
+          B.x = __shfl(Cb.x, c); B.y = __shfl(Cb.y, c); B.w = __shfl(Cb.w, c); B.h = __shfl(Cb.h, c);
+          B.c2 = __shfl(Cb.c2, c); B.s2 = __shfl(Cb.s2, c); B.r = __shfl(Cb.r, c); B.label = __shfl(Cb.label, c);
+          const bool keep = mine && !nms_pair_skippable(R, B, thr);
+          const unsigned long long bal = __ballot(keep);
+          if (keep) {
+            const unsigned pa = __float_as_uint(R.label), pb = __float_as_uint(B.label);
+            stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(min(pa, pb), max(pa, pb));
+          }
+          ns += (unsigned)__popcll(bal);
+          n1 = base;
+          if (ns + 64 > kNlStage) flush();
+        }
+      }
+      t = tn;
+      A = An;
+      Cb = Cn;
+    }
+  }
+  if (lane == 0) s_left[wave] = ns;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++) {
+    if (w < wave) before += s_left[w];
+    all += s_left[w];
+  }
+  if (all == 0) return;                // uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(gcount, (unsigned long long)all);
+  __syncthreads();
+  const unsigned long long base = s_base + before;
+  for (unsigned k = lane; k < ns; k += 64)
+    if (base + k < cap) gq[base + k] = stage[k];
+}
+
 // DENSE IoU pass: one pair per lane; pairs above the threshold become edges.  Every wave stages its edges in a private
 // LDS buffer and publishes them with ONE global atomic per flush (an atomic per wave and sweep -- ~20 k on one address at
 // 200 k rows -- made the pass atomic-bound); a wave is synchronous, so the staging needs no barrier.
@@ -2024,7 +2142,16 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   }
   k_nms_tile_filter<<<kPersistentGrid, kThreads, 0, st>>>(B.seg_start, B.num_seg, B.tile_off, lo, B.hi, B.tiles, B.C,
                                                           pl.tile_cap);
-  k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(B.sp_box, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+  {
+    // one wave per tile pays off once there are tiles for every wave (200 k rows: 392 -> 335 us); with few tiles the four
+    // waves per tile of k_nms_cull finish a tile sooner (5 k / 20 k rows: 35 us less).  S2A_NMS_CULL_LANES=0|1 forces.
+    const char* nl = getenv("S2A_NMS_CULL_LANES");
+    const bool lanes = nl && (nl[0] == '0' || nl[0] == '1') ? nl[0] == '1' : n >= kNmsLanesRows;
+    if (!lanes)
+      k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(B.sp_box, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+    else
+      k_nms_cull_lanes<<<kPersistentGrid, kThreads, 0, st>>>(B.sp_box, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+  }
   k_nms_heavy<false><<<kHeavyGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
   k_nms_heavy<true><<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
   // the pair list is dead after the dense pass: its memory takes the alive-edge list of the last launched round
