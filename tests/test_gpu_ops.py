@@ -130,6 +130,24 @@ def test_iou_dense_overlap_both_paths(rng, monkeypatch, path):
     assert (bits(out) != bits(ref)).sum() == 0 and (out[:, 1500:] == 0).all() and (out[:, :1500] > 0).mean() > 0.95
 
 
+@pytest.mark.parametrize("lanes", ["0", "1"])
+def test_nms_both_cull_forms_vs_oracle(rng, monkeypatch, lanes):
+    """the four-waves-per-tile cull (small inputs) and the one-wave-per-tile cull (large ones), each forced on the same
+    clustered input with ragged segments (diagonal tiles, partly filled last blocks, invalid columns)"""
+    from s2anet_amd.rotated import ml_nms_rotated
+    monkeypatch.setenv("S2A_NMS_CULL_LANES", lanes)
+    n = 7001
+    d = rand_rboxes(rng, n, span=300, lo=6, hi=60)
+    d[:1500, :2] = d[:1500, :2] * 0.1 + 40.0            # a dense cluster: many survivors per tile
+    sc = distinct_scores(rng, n)
+    lab = rng.integers(0, 5, n).astype(np.float32)
+    lab[:40] = 7.0                                      # a segment smaller than one block
+    for thr in (0.3, 0.7):
+        keep = ml_nms_rotated(cu(d), cu(sc), cu(lab), thr).cpu().numpy()
+        ref = oracle.nms_rotated(d, sc, thr, labels=lab, rule=oracle.RULE_GT, sort_mode=oracle.SORT_GPU)
+        assert np.array_equal(keep, ref), (lanes, thr)
+
+
 def test_nms_with_duplicates_and_shared_edges(rng):
     from s2anet_amd.rotated import ml_nms_rotated
     d = _degenerate_boxes(rng, 4000)
