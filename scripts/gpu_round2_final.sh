@@ -15,12 +15,12 @@ python scripts/nms_pmc_report.py gpurun_out/pmc_nms200k --json $O/nms_occupancy.
 cat $O/memcpy/run_memory_copy_stats.csv 2>/dev/null | head -4
 bash scripts/prof_cmd.sh nms200k_stats scripts/bench_ops.py --which nms200k > $O/prof_nms.log 2>&1; tail -14 $O/prof_nms.log | cut -c1-140
 echo "== iou pmc + timeline"
-bash scripts/pmc_cmd.sh iou10k "scripts/bench_ops.py --which iou10k" "k_iou_cull_rows k_iou_heavy" \
+bash scripts/pmc_cmd.sh iou10k "scripts/bench_ops.py --which iou10k" "k_iou_cull_lanes k_iou_heavy" \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
   "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" \
   "SQ_BUSY_CU_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU" \
   "FETCH_SIZE" "WRITE_SIZE" > $O/iou_pmc.log 2>&1; echo "iou pmc rc=$?"
-python scripts/nms_pmc_report.py gpurun_out/pmc_iou10k k_iou_cull_rows k_iou_heavy k_fill_zero k_iou_scatter > $O/iou_pmc_report.txt 2>&1
+python scripts/nms_pmc_report.py gpurun_out/pmc_iou10k k_iou_cull_lanes k_iou_heavy k_fill_zero k_iou_scatter > $O/iou_pmc_report.txt 2>&1
 bash scripts/iou_timeline.sh > $O/iou_timeline.txt 2>&1; cat $O/iou_timeline.txt | cut -c1-120
 echo "== bench pmc"; bash scripts/pmc_bench.sh > $O/pmc_bench.log 2>&1; echo "pmc bench rc=$?"; cat gpurun_out/pmc_bench/traffic.json | head -c 900; echo
 echo "== steady state"; bash scripts/prof_bench.sh r2final > $O/prof_bench3.log 2>&1; head -3 $O/prof_bench3.log | cut -c1-160

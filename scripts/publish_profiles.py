@@ -42,7 +42,8 @@ with open(os.path.join(P, "r02_nms_200k_pmc.txt"), "w") as f:
 # r02_nms_200k_pmc_before.txt (2.79 ms per call; cull 1231 us at 14 waves/CU, scan 719 us at 0.25 waves/CU, dense pass 456 us).
 # Same command and counter sets: rocprofv3 --kernel-trace --pmc <set> -- python scripts/bench_ops.py --which nms200k
 # (scripts/pmc_cmd.sh, report by scripts/nms_pmc_report.py).  Whole call (HIP events, un-profiled): %.2f ms.
-# What changed: Morton-sorted 64-row blocks + bounding-box tile filter (83 %% of the tiles never tested), separating axes + IoU
+# What changed: Morton-sorted 64-row blocks + bounding-box tile filter (83 %% of the tiles never tested), one wave per tile in the cull
+# (boxes in registers, circles by v_readlane, no workgroup barrier: k_nms_cull_lanes), separating axes + IoU
 # upper bound before the dense pass (7x fewer IoU evaluations), edge list resolved by parallel rounds (no suppression mask, no serial
 # scan), wave / workgroup aggregated atomics.  Device -> host traffic: the memory-copy trace below shows host -> device uploads of the
 # test inputs only (3 copies); no copy-engine transfer device -> host; the 8-byte keep count of the pybind-shaped entry point goes
@@ -61,8 +62,9 @@ with open(os.path.join(P, "r02_iou_10k_pmc.txt"), "w") as f:
     f.write("""# box_iou_rotated at 10 000 x 10 000 (BASELINE configs[0] shape; 1.1 %% of the pairs overlap), tree %s.
 # Counters: rocprofv3 --kernel-trace --pmc <set> -- python scripts/bench_ops.py --which iou10k (scripts/pmc_cmd.sh, report by
 # scripts/nms_pmc_report.py).  Timeline of ONE call (scripts/iou_timeline.sh; q2 = the forked zero-fill stream) at the end.
-# Reading (DESIGN.md section 4, "Round-2 IoU work"): the exact pass is VALU-bound since it runs with 8 candidate-point slots
-# per lane; the pair finder is not -- VALU about a third, the rest waiting -- at 12 and at 24 waves per CU alike.
+# Reading (DESIGN.md section 4, "A saturating store stream ..."): the zero-fill is paced (s_sleep between its stores) so that the pair
+# finder (k_iou_cull_lanes: circles by v_readlane, no LDS traffic in the first stage) and the exact pass (8 candidate-point slots per
+# lane, VALU-bound) run beside it at their stand-alone speed; the call is bound by that chain, the 400 MB of stores are hidden.
 """ % head)
     f.write(cat(os.path.join(F, "iou_pmc_report.txt")))
     f.write("\n# timeline of one call (us from the start of the call):\n")
