@@ -1,11 +1,15 @@
 #!/bin/bash
-# timing-only ablations of the AlignConv kernels on the pyramid launch (rebuilds dcn_ops.o per variant ON THE GPU BOX's
-# copy).  S2A_ABL bits: 1 = no epilogue (plain kernel), 2 = loaders skip the blend, 4 = matrix waves skip the MFMAs,
+# timing-only ablations / compile-time A-B of the AlignConv and conv-tower kernels on the pyramid launch: every argument is
+# the EXTRA flag string of one build of dcn_ops.o ON THE GPU BOX's copy, e.g.
+#   bash scripts/abl.sh "-DS2A_ABL=0" "-DS2A_ABL=2" "-DS2A_MPIPE=0"
+# S2A_ABL bits: 1 = no epilogue (plain kernel), 2 = loaders skip the blend, 4 = matrix waves skip the MFMAs,
 # 8 = loaders skip their corner reads (ring-3 kernel), 16 = matrix waves skip their fragment reads (ring-3 kernel),
-# 32 = filter fragments loaded once (plain kernel, S2A_MPIPE form)
+# 32 = filter fragments loaded once (plain kernel, S2A_MPIPE form).  S2A_MPIPE=0: matrix waves without the fragment prefetch.
+# (Skipping LOADS is not a valid ablation: the compiler deletes the arithmetic that consumes undefined values.)
 cd $GRAFT_REPO_ROOT
 for a in "$@"; do
+  case "$a" in -D*) flags="$a";; *) flags="-DS2A_ABL=$a";; esac
   rm -f s2anet_amd/csrc/dcn_ops.o
-  make -C s2anet_amd/csrc -s EXTRA=-DS2A_ABL=$a 2>&1 | grep -E "error" | head -3
-  echo "ABL=$a $(timeout -k 10 200 python scripts/bench_pyr.py 2>&1 | grep alignconv_pyramid)"
+  make -C s2anet_amd/csrc -s EXTRA="$flags" 2>&1 | grep -E "error" | head -3
+  echo "[$flags] $(timeout -k 10 200 python scripts/bench_pyr.py 2>&1 | grep '"op"' | cut -c1-120 | tr '\n' ' ')"
 done
