@@ -991,9 +991,10 @@ __global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* 
     } else {
     if (S2A_ABL & 32) load_w(1, wB);     // timing only: the filter fragments of stages 0 / 1 serve every stage
     for (; s + 1 < nstage; s += 2) {
-      if (!(S2A_ABL & 32)) load_w(s + 1, wB);
+      // (64, timing only: the loads stay but always fetch stages 1 / 0 -- L1 hits: separates issue cost from L2 latency)
+      if (!(S2A_ABL & 32)) load_w((S2A_ABL & 64) ? 1 : s + 1, wB);
       stage(s, wA);
-      if (!(S2A_ABL & 32)) load_w(min(s + 2, last), wA);
+      if (!(S2A_ABL & 32)) load_w((S2A_ABL & 64) ? 0 : min(s + 2, last), wA);
       stage(s + 1, wB);
     }
     if (s < nstage) stage(s, wA);

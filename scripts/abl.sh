@@ -4,7 +4,7 @@
 #   bash scripts/abl.sh "-DS2A_ABL=0" "-DS2A_ABL=2" "-DS2A_MPIPE=0"
 # S2A_ABL bits: 1 = no epilogue (plain kernel), 2 = loaders skip the blend, 4 = matrix waves skip the MFMAs,
 # 8 = loaders skip their corner reads (ring-3 kernel), 16 = matrix waves skip their fragment reads (ring-3 kernel),
-# 32 = filter fragments loaded once (plain kernel, S2A_MPIPE form).  S2A_MPIPE=0: matrix waves without the fragment prefetch.
+# 32 = filter fragments loaded once, 64 = loaded every stage but from a fixed address (plain kernel, S2A_MPIPE form).  S2A_MPIPE=0: matrix waves without the fragment prefetch.
 # (Skipping LOADS is not a valid ablation: the compiler deletes the arithmetic that consumes undefined values.)
 cd $GRAFT_REPO_ROOT
 for a in "$@"; do
