@@ -137,13 +137,14 @@ def _match(gd, gl, cd, cl, tol_rel=1e-3, tol_score=1e-4):
     return pairs, left, np.nonzero(~used)[0].tolist()
 
 
-def test_config2_detect_f32_vs_cpu_pipeline():
-    """BASELINE configs[2] for one 1024 x 1024 chip, float32: image -> detections on the GPU (detect(): own f32 AlignConv
+@pytest.mark.parametrize("seed", [1234, 77])
+def test_config2_detect_f32_vs_cpu_pipeline(seed):
+    """BASELINE configs[2] for one 1024 x 1024 chip, float32 (two seeded networks / images): image -> detections on the GPU (detect(): own f32 AlignConv
     on the matrix cores, fused anchor refine, ARF, pooling, decode, on-device segmented ml-NMS; library f32 convolutions
     for the plain layers) against the CPU pipeline (torch CPU convolutions + the oracle's ops, `>` rule and GPU sort
     branch as the reference's CUDA op).  Same number of detections, same labels, boxes within 1e-3 relative to the
     box size, scores within 1e-4 (models/head.py:648-725)."""
-    cpu, gpu, img, feats, levels, ncand = _cpu_and_gpu_detectors(torch.float32)
+    cpu, gpu, img, feats, levels, ncand = _cpu_and_gpu_detectors(torch.float32, seed=seed)
     assert 2000 < ncand < 3000
     dets_c, labels_c, bboxes_c, scores_c = pipeline.postprocess(levels)
     with torch.no_grad():
