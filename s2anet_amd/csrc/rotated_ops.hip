@@ -209,139 +209,18 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
   queue_flush(Q, gq, gcount, cap);
 }
 
-// ---- pair finding beside a forked zero-fill (no stores here): ROW-major.  A thread keeps ONE row box in registers and
-// walks the workgroup's 256 columns, whose circle records are LDS broadcast reads (no vector memory, no barrier in the
-// loop; scalar loads were tried: 32 records = 128 SGPRs cannot be in flight at once); the verdicts of 32 columns collect in a per-lane bit mask, survivors go to a list
-// private to the wave, and as soon as it holds 64 the wave runs the separating-axis test on them with all lanes busy.
-// What survives both tests is staged per wave and published with one global atomic per workgroup.
-// (The column-major form above pays a workgroup barrier every two rows -- 2048 tests -- for its coalesced zero stores:
-// 88 us for the 1e8 circle tests of 10 k x 10 k, a quarter of the VALU rate.)
-// Circle test: (ax-bx)^2 + (ay-by)^2 > (1.002 ar + 1e-3 + 1.002 br)^2 -- surely_disjoint's margin with the two factors
-// hoisted into the row and the column record; NaNs compare false and are evaluated.
-constexpr int kCrCols = 256;                  // columns per workgroup
-constexpr int kCrChunk = 16;                  // columns per verdict mask
-constexpr int kCrList = 64 * kCrChunk + 64;   // per-wave survivor list, u16 = row-in-wave << 8 | column-in-workgroup
+// ---- pair finding beside a forked zero-fill (no stores here), with NO LDS traffic in its first stage.  A wave owns 64
+// rows (lane = row) and walks its columns 64 at a time: lane j holds column j's box of the chunk in registers, v_readlane
+// hands column j's circle to all lanes as scalar operands (j is a compile-time constant in the unrolled loop), the
+// verdicts collect in a 64-bit mask per lane.  Second stage without a list: every lane walks its own mask bits and fetches
+// the column box from the owning lane by ds_bpermute (the crossbar, not the banks); the loop runs max-popcount times
+// (5-6 at DOTA-like densities).  Survivors of both tests are staged per wave, one global atomic per workgroup at the end.
+// No barrier in the loop.  Circle test: (ax-bx)^2 + (ay-by)^2 > (1.002 ar + 1e-3 + 1.002 br)^2 -- surely_disjoint's
+// margin with the two factors hoisted into the row and the column; NaNs compare false and are evaluated.
+// (Forms that were built, tested bit-exact, measured and removed again -- DESIGN.md section 4 has the numbers: circle
+// records as LDS broadcast reads with per-wave survivor lists (59 us alone became 79), the same on half the LDS, a dense
+// second stage fed from a list, a grid-binned finder, and one launch per 256 x 256 tile that also fills and evaluates.)
 constexpr int kCrStage = 256;                 // per-wave staged pairs
-// LDS diet (25 KB per workgroup -> 24 waves per CU; the first version kept 50 KB and 12 waves and waited 68 % of the
-// time): ONE 32-byte record per column -- circle part first, so that the broadcast read of the circle test is its first
-// 16 bytes --, and the ROW box of a survivor comes out of the owning lane's registers by ds_bpermute instead of an LDS copy.
-struct alignas(16) ColRec { float x, y, rr, w, h, c2, s2, pad; };
-__global__ __launch_bounds__(kThreads) void k_iou_cull_rows(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
-                                                            int64_t row0, int64_t row1, int64_t m,
-                                                            uint2* __restrict__ gq,
-                                                            unsigned long long* __restrict__ gcount,
-                                                            unsigned long long cap) {
-  __shared__ ColRec s_cols[kCrCols];
-  __shared__ unsigned short s_list[kThreads / 64][kCrList];
-  __shared__ uint2 s_stage[kThreads / 64][kCrStage];
-  __shared__ unsigned s_n1[kThreads / 64], s_left[kThreads / 64];
-  __shared__ unsigned long long s_base;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t rbeg = row0 + (int64_t)blockIdx.y * kThreads;
-  const int64_t row = rbeg + threadIdx.x;
-  const bool valid = row < row1;
-  PreBox A = {};
-  if (valid) A = P1[row];
-  const float ax = A.x, ay = A.y, ar = A.r * 1.002f + 1e-3f;
-  const int64_t jw = (int64_t)blockIdx.x * kCrCols;
-  const int ncol = (int)min((int64_t)kCrCols, m - jw);
-  unsigned short* list = s_list[wave];
-  uint2* stage = s_stage[wave];
-  if (lane == 0) s_n1[wave] = 0;
-  static_assert(kCrCols == kThreads, "one column box per thread");
-  {
-    const PreBox cb = threadIdx.x < ncol ? P2[jw + threadIdx.x] : PreBox{};
-    s_cols[threadIdx.x] = ColRec{cb.x, cb.y, cb.r * 1.002f, cb.w, cb.h, cb.c2, cb.s2, 0.f};
-  }
-  __syncthreads();                               // the only barrier in front of the final flush
-  unsigned n1 = 0, ns = 0;                       // wave-uniform: listed survivors, staged pairs
-  auto flush = [&]() {                           // rare: > 192 pairs of one wave inside 256 x 256 (dense inputs)
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(gcount, (unsigned long long)ns);
-    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
-    for (unsigned k = lane; k < ns; k += 64)
-      if (base + k < cap) gq[base + k] = stage[k];
-    ns = 0;
-  };
-  auto drain = [&](bool all) {                   // full groups of 64 from the top of the list; the rest stays in front
-    while (n1 >= 64u || (all && n1 > 0u)) {
-      const unsigned cnt = min(n1, 64u), base = n1 - cnt;
-      const bool mine = (unsigned)lane < cnt;
-      const unsigned v = mine ? (unsigned)list[base + lane] : 0u;
-      const unsigned r = v >> 8, c = v & 255u;
-      // the row box of survivor (r, c) sits in lane r's registers (all lanes take part in the permutes)
-      PreBox R;
-      R.x = __shfl(A.x, (int)r); R.y = __shfl(A.y, (int)r); R.w = __shfl(A.w, (int)r); R.h = __shfl(A.h, (int)r);
-      R.c2 = __shfl(A.c2, (int)r); R.s2 = __shfl(A.s2, (int)r); R.r = 0.f; R.label = 0.f;
-      bool hit = false;
-      if (mine) {
-        const ColRec q = s_cols[c];
-        const PreBox B = {q.x, q.y, q.w, q.h, q.c2, q.s2, 0.f, 0.f};
-        hit = !sat_disjoint(R, B);
-      }
-      const unsigned long long bal = __ballot(hit);
-      if (hit)
-        stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] =
-            make_uint2((unsigned)(rbeg + wave * 64 + r - row0), (unsigned)(jw + c));
-      ns += (unsigned)__popcll(bal);
-      n1 = base;
-      if (ns + 64 > kCrStage) flush();
-    }
-    if (lane == 0) s_n1[wave] = n1;
-  };
-  for (int jc = 0; jc < ncol; jc += kCrChunk) {
-    const float4* cp = reinterpret_cast<const float4*>(s_cols + jc);   // uniform address: LDS broadcast reads of (x, y, rr, .)
-    unsigned mask = 0;
-    if (ncol - jc >= kCrChunk) {
-#pragma unroll
-      for (int jj = 0; jj < kCrChunk; jj++) {
-        const float4 c = cp[2 * jj];
-        const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
-        mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
-      }
-    } else {
-      for (int jj = 0; jj < ncol - jc; jj++) {
-        const float4 c = cp[2 * jj];
-        const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
-        mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
-      }
-    }
-    if (!valid) mask = 0;
-    while (mask) {
-      const unsigned b = (unsigned)__ffs((int)mask) - 1u;
-      mask &= mask - 1u;
-      const unsigned p = atomicAdd(&s_n1[wave], 1u);
-      list[p] = (unsigned short)(((unsigned)lane << 8) | (unsigned)(jc + b));
-    }
-    n1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_n1[wave]);
-    drain(false);
-  }
-  drain(true);
-  // leftovers of the four stages: one global atomic per workgroup
-  if (lane == 0) s_left[wave] = ns;
-  __syncthreads();
-  unsigned before = 0, all = 0;
-#pragma unroll
-  for (int w = 0; w < kThreads / 64; w++) {
-    if (w < wave) before += s_left[w];
-    all += s_left[w];
-  }
-  if (all == 0) return;                // uniform
-  if (threadIdx.x == 0) s_base = atomicAdd(gcount, (unsigned long long)all);
-  __syncthreads();
-  const unsigned long long base = s_base + before;
-  for (unsigned k = lane; k < ns; k += 64)
-    if (base + k < cap) gq[base + k] = stage[k];
-}
-
-// ---- the same pair finding with NO LDS traffic in the circle stage (k_iou_cull_rows spends ~250 LDS-pipe cycles per
-// 16-column chunk and wave: broadcast reads, per-lane atomics on the list counter, conflicted record reads).  Here a
-// wave owns 64 rows (lane = row) and walks its columns 64 at a time: lane j holds column j's box of the chunk in
-// registers, v_readlane hands column j's circle to all lanes as scalar operands (j is a compile-time constant in the
-// unrolled loop), the verdicts collect in a 64-bit mask per lane.  Second stage without a list: every lane walks its own
-// mask bits and fetches the column box from the owning lane by ds_bpermute (the crossbar, not the banks); the loop runs
-// max-popcount times (5-6 at DOTA-like densities).  Survivors of both tests are staged per wave, one global atomic per
-// workgroup at the end.  No barrier anywhere.
 __device__ __forceinline__ float lane_bcast(float v, int j) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
 }
@@ -424,348 +303,6 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull_lanes(const PreBox* __res
   const unsigned long long base = s_base + before;
   for (unsigned k = lane; k < ns; k += 64)
     if (base + k < cap) gq[base + k] = stage[k];
-}
-
-// ---- large outputs in ONE launch: a workgroup owns a 256 x 256 tile of the matrix.  Each wave zero-fills its 64 rows of
-// the tile (1 KB per store instruction), then finds the pairs of those rows that can overlap exactly as k_iou_cull_rows
-// does (row box in registers, column circle records as LDS broadcast reads, 16-column verdict masks, wave-private
-// survivor list, separating-axis test with all lanes busy) and -- as soon as 64 pairs have passed both tests -- evaluates
-// them with the exact algorithm and stores the values into its own zeros.  No pair list in HBM, no second pass over the
-// output, no side stream; the store-bound, VALU-bound and latency-bound phases of different workgroups overlap by
-// themselves.  A pair with more than 8 candidate points (see rbox_iou) goes to a short global list that k_iou_redo
-// evaluates with 24 slots.  The zero stores of a wave precede its value stores in program order AND are drained
-// (vmcnt(0)) before the first value store.
-constexpr int kTileCols = 256;
-constexpr int kTChunk = 16;                   // columns per verdict mask
-constexpr int kTList = 64 * kTChunk + 64;     // per-wave survivor list (u16 = row-in-wave << 8 | column-in-tile)
-constexpr int kTStage = 128;                  // per-wave pairs awaiting the exact evaluation (same encoding)
-__global__ __launch_bounds__(kThreads) void k_iou_tile(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
-                                                       int64_t n, int64_t m, float* __restrict__ out,
-                                                       uint2* __restrict__ redo,
-                                                       unsigned long long* __restrict__ redo_count,
-                                                       unsigned long long redo_cap) {
-  __shared__ PreBox s_rows[kThreads], s_cols[kTileCols];
-  __shared__ float4 s_circ[kTileCols];
-  __shared__ unsigned short s_list[kThreads / 64][kTList];
-  __shared__ unsigned short s_stage[kThreads / 64][kTStage];
-  __shared__ float2 s_pts[kThreads / 64][kIouCap * 64];
-  __shared__ unsigned s_n1[kThreads / 64];
-  static_assert(kTileCols == kThreads, "one column box per thread");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t rbeg = (int64_t)blockIdx.y * kThreads;
-  const int64_t row = rbeg + threadIdx.x;
-  const bool valid = row < n;
-  const int64_t jw = (int64_t)blockIdx.x * kTileCols;
-  const int ncol = (int)min((int64_t)kTileCols, m - jw);
-  PreBox A = {};
-  if (valid) A = P1[row];
-  s_rows[threadIdx.x] = A;                       // read back by this wave only
-  {
-    const PreBox cb = threadIdx.x < ncol ? P2[jw + threadIdx.x] : PreBox{};
-    s_cols[threadIdx.x] = cb;
-    s_circ[threadIdx.x] = make_float4(cb.x, cb.y, cb.r * 1.002f, 0.f);
-  }
-  if (lane == 0) s_n1[wave] = 0;
-  __syncthreads();                               // the only barrier
-  const int64_t wr0 = rbeg + wave * 64;          // this wave's rows
-  {
-    const int nr = (int)max((int64_t)0, min((int64_t)64, n - wr0));
-    const int c0 = lane * 4;
-    float* o = out + wr0 * m + jw + c0;
-    if ((m & 3) == 0) {                          // rows are 16-byte aligned (and ncol is a multiple of 4)
-      if (c0 < ncol)
-        for (int r = 0; r < nr; r++) *reinterpret_cast<float4*>(o + (int64_t)r * m) = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      for (int r = 0; r < nr; r++)
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (c0 + k < ncol) o[(int64_t)r * m + k] = 0.f;
-    }
-  }
-  const float ax = A.x, ay = A.y, ar = A.r * 1.002f + 1e-3f;
-  unsigned short* list = s_list[wave];
-  unsigned short* stage = s_stage[wave];
-  float2* pts = s_pts[wave] + lane;
-  const PreBox* rows_w = s_rows + wave * 64;
-  unsigned n1 = 0, ns = 0;                       // wave-uniform: listed survivors, staged pairs
-  bool zeros_drained = false;                    // wave-uniform
-  auto exact = [&](unsigned base, unsigned cnt) {            // pairs stage[base .. base + cnt)
-    if (!zeros_drained) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      zeros_drained = true;
-    }
-    bool again = false;
-    unsigned i = 0, j = 0;
-    if ((unsigned)lane < cnt) {
-      const unsigned v = stage[base + lane], r = v >> 8, c = v & 255u;
-      i = (unsigned)(wr0 + r);
-      j = (unsigned)(jw + c);
-      const float iou = rbox_iou<64, kIouCap>(rows_w[r], s_cols[c], pts, &again);
-      if (!again) out[(int64_t)i * m + j] = iou;
-    }
-    const unsigned long long bal = __ballot(again);
-    if (bal) {                                   // rare; one atomic per wave
-      unsigned long long b = 0;
-      if (lane == 0) b = atomicAdd(redo_count, (unsigned long long)__popcll(bal));
-      b = ((unsigned long long)(uint32_t)__shfl((int)(b >> 32), 0) << 32) | (uint32_t)__shfl((int)(b & 0xffffffffu), 0);
-      const unsigned long long p = b + __popcll(bal & ((1ull << lane) - 1ull));
-      if (again && p < redo_cap) redo[p] = make_uint2(i, j);
-    }
-  };
-  auto drain = [&](bool all) {
-    while (n1 >= 64u || (all && n1 > 0u)) {
-      const unsigned cnt = min(n1, 64u), base = n1 - cnt;
-      bool hit = false;
-      unsigned v = 0;
-      if ((unsigned)lane < cnt) {
-        v = list[base + lane];
-        hit = !sat_disjoint(rows_w[v >> 8], s_cols[v & 255u]);
-      }
-      const unsigned long long bal = __ballot(hit);
-      if (hit) stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)v;
-      ns += (unsigned)__popcll(bal);
-      n1 = base;
-      if (ns >= 64u) {
-        ns -= 64u;
-        exact(ns, 64u);
-      }
-    }
-    if (lane == 0) s_n1[wave] = n1;
-  };
-  for (int jc = 0; jc < ncol; jc += kTChunk) {
-    const float4* cp = s_circ + jc;              // uniform address: LDS broadcast reads
-    unsigned mask = 0;
-    if (ncol - jc >= kTChunk) {
-#pragma unroll
-      for (int jj = 0; jj < kTChunk; jj++) {
-        const float4 c = cp[jj];
-        const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
-        mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
-      }
-    } else {
-      for (int jj = 0; jj < ncol - jc; jj++) {
-        const float4 c = cp[jj];
-        const float dx = ax - c.x, dy = ay - c.y, R = ar + c.z;
-        mask |= (dx * dx + dy * dy > R * R ? 0u : 1u) << jj;
-      }
-    }
-    if (!valid) mask = 0;
-    while (mask) {
-      const unsigned b = (unsigned)__ffs((int)mask) - 1u;
-      mask &= mask - 1u;
-      const unsigned p = atomicAdd(&s_n1[wave], 1u);
-      list[p] = (unsigned short)(((unsigned)lane << 8) | (unsigned)(jc + b));
-    }
-    n1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_n1[wave]);
-    drain(false);
-  }
-  drain(true);
-  if (ns) exact(0, ns);
-}
-
-// the pairs k_iou_tile could not evaluate with 8 candidate-point slots.  List overflow (only inputs made of duplicates get
-// there): every pair of the matrix is recomputed directly.
-__global__ __launch_bounds__(kThreads) void k_iou_redo(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
-                                                       int64_t n, int64_t m, float* __restrict__ out,
-                                                       const uint2* __restrict__ redo,
-                                                       const unsigned long long* __restrict__ redo_count,
-                                                       unsigned long long redo_cap) {
-  __shared__ float2 s_pts[24 * kThreads];
-  const unsigned long long total = *redo_count;
-  if (total == 0) return;
-  if (total > redo_cap) {
-    const int64_t all = n * m;
-    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < all; e += (int64_t)gridDim.x * kThreads) {
-      const int64_t i = e / m, j = e % m;
-      const PreBox A = P1[i], B = P2[j];
-      if (!surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B))
-        out[e] = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x);
-    }
-    return;
-  }
-  for (unsigned long long e = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; e < total;
-       e += (unsigned long long)gridDim.x * kThreads) {
-    const uint2 ij = redo[e];
-    out[(int64_t)ij.x * m + ij.y] = rbox_iou<kThreads>(P1[ij.x], P2[ij.y], s_pts + threadIdx.x);
-  }
-}
-
-// ---- pair finding for large problems: uniform grid over the second box set instead of all-pairs circle tests.
-// (The all-pairs cull is VALU-bound: 1e8 circle tests = 61-88 us at 10 k x 10 k, of which ~1 % survive.)  The columns are
-// binned by centre into a G x G grid over their bounding box (count, scan, scatter: cell-sorted copies of the boxes);
-// a wave then takes a row and visits only the cells its circle -- inflated by the LARGEST column radius -- can reach:
-// per grid row ONE contiguous segment of the cell-sorted array, 64 candidates per sweep.  Exact: rows and columns go
-// through the same monotone cell function, so a column with |dx| <= R or |dy| <= R can never fall outside the visited
-// range; whatever is skipped is farther than the circle test's own margin.  Non-finite columns sit in an extra cell that
-// every row visits; a non-finite row visits everything (such pairs are evaluated, never culled, as in the reference).
-constexpr int kGridMax = 64;
-struct IouGrid {                      // device-side header of the grid (workspace)
-  uint32_t bbox[64][4];               // partial {min x, min y, max x, max y} of the finite column centres, sortable
-  uint32_t rmax[64];                  // partial maxima of the column radii, sortable
-  uint32_t cell_cnt[kGridMax * kGridMax + 2];     // counts, then (after the scan) start offsets; [G*G] = the wild cell
-  uint32_t cell_cur[kGridMax * kGridMax + 2];
-};
-
-__global__ void k_iou_grid_init(IouGrid* __restrict__ g) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 64) { g->bbox[i][0] = g->bbox[i][1] = 0xffffffffu; g->bbox[i][2] = g->bbox[i][3] = 0u; g->rmax[i] = 0u; }
-  if (i < kGridMax * kGridMax + 2) { g->cell_cnt[i] = 0u; g->cell_cur[i] = 0u; }
-}
-
-__global__ void k_iou_grid_bbox(const PreBox* __restrict__ P2, int64_t m, IouGrid* __restrict__ g) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t lx = 0xffffffffu, ly = 0xffffffffu, hx = 0u, hy = 0u, rm = 0u;
-  if (j < m) {
-    const PreBox b = P2[j];
-    if (isfinite(b.x) && isfinite(b.y) && isfinite(b.r)) {
-      lx = hx = float_sortable(b.x); ly = hy = float_sortable(b.y);
-      rm = float_sortable(fabsf(b.r));
-    } else {
-      rm = float_sortable(__builtin_inff());       // (a non-finite column also makes every row visit everything)
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    lx = min(lx, (uint32_t)__shfl_xor((int)lx, o)); ly = min(ly, (uint32_t)__shfl_xor((int)ly, o));
-    hx = max(hx, (uint32_t)__shfl_xor((int)hx, o)); hy = max(hy, (uint32_t)__shfl_xor((int)hy, o));
-    rm = max(rm, (uint32_t)__shfl_xor((int)rm, o));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 63;
-    if (lx != 0xffffffffu) { atomicMin(&g->bbox[slot][0], lx); atomicMax(&g->bbox[slot][2], hx);
-                             atomicMin(&g->bbox[slot][1], ly); atomicMax(&g->bbox[slot][3], hy); }
-    atomicMax(&g->rmax[slot], rm);
-  }
-}
-
-struct GridGeom { float x0, y0, ix, iy, rmax; int G; };
-__device__ __forceinline__ GridGeom grid_geom(const IouGrid* __restrict__ g, int G) {
-  uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0u, b3 = 0u, rm = 0u;
-  for (int k = 0; k < 64; k++) {
-    b0 = min(b0, g->bbox[k][0]); b1 = min(b1, g->bbox[k][1]); b2 = max(b2, g->bbox[k][2]); b3 = max(b3, g->bbox[k][3]);
-    rm = max(rm, g->rmax[k]);
-  }
-  GridGeom q;
-  q.G = G;
-  const float x1 = sortable_float(b2), y1 = sortable_float(b3);
-  q.x0 = sortable_float(b0); q.y0 = sortable_float(b1);
-  q.ix = x1 > q.x0 ? (float)G / (x1 - q.x0) : 0.f;
-  q.iy = y1 > q.y0 ? (float)G / (y1 - q.y0) : 0.f;
-  q.rmax = rm ? sortable_float(rm) : 0.f;
-  return q;
-}
-// the ONE cell function (monotone non-decreasing in v): used for the columns' cells and for the rows' ranges alike
-__device__ __forceinline__ int grid_cell(float v, float v0, float inv, int G) {
-  const float c = (v - v0) * inv;
-  return c >= 0.f ? (int)fminf(c, (float)(G - 1)) : 0;       // NaN -> 0 (callers handle non-finite boxes before)
-}
-
-__global__ void k_iou_grid_count(const PreBox* __restrict__ P2, int64_t m, IouGrid* __restrict__ g, int G,
-                                 uint32_t* __restrict__ cell_of) {
-  __shared__ GridGeom s_q;
-  if (threadIdx.x == 0) s_q = grid_geom(g, G);
-  __syncthreads();
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  const PreBox b = P2[j];
-  uint32_t c = (uint32_t)(G * G);                                  // wild cell
-  if (isfinite(b.x) && isfinite(b.y) && isfinite(b.r))
-    c = (uint32_t)(grid_cell(b.y, s_q.y0, s_q.iy, G) * G + grid_cell(b.x, s_q.x0, s_q.ix, G));
-  cell_of[j] = c;
-  atomicAdd(&g->cell_cnt[c], 1u);
-}
-
-__global__ __launch_bounds__(1024) void k_iou_grid_scan(IouGrid* __restrict__ g, int ncell) {   // ncell = G*G + 1 (<= 4097)
-  __shared__ unsigned s_w[16];
-  __shared__ unsigned s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b0 = 0; b0 <= ncell; b0 += 1024) {
-    const int b = b0 + threadIdx.x;
-    const unsigned v = b < ncell ? g->cell_cnt[b] : 0u;
-    unsigned incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    unsigned wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += s_w[w];
-    const unsigned carry = s_carry;
-    if (b <= ncell) { g->cell_cnt[b] = carry + wbase + incl - v; g->cell_cur[b] = carry + wbase + incl - v; }
-    __syncthreads();
-    if (threadIdx.x == 1023) s_carry = carry + wbase + incl;
-    __syncthreads();
-  }
-}
-
-__global__ void k_iou_grid_scatter(const PreBox* __restrict__ P2, int64_t m, IouGrid* __restrict__ g,
-                                   const uint32_t* __restrict__ cell_of, PreBox* __restrict__ P2s) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  PreBox b = P2[j];
-  b.label = __uint_as_float((uint32_t)j);                          // original column index
-  P2s[atomicAdd(&g->cell_cur[cell_of[j]], 1u)] = b;
-}
-
-// QUERY: one row per wave and sweep; circle test, then separating axes; survivors are staged per wave in LDS and
-// published with one global atomic per flush (wave-synchronous: no barrier).  Rows [row0, row1) of P1.
-constexpr int kIouStage = 1024;
-__global__ __launch_bounds__(kThreads) void k_iou_grid_query(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2s,
-                                                             int64_t row0, int64_t row1, const IouGrid* __restrict__ g,
-                                                             int G, uint2* __restrict__ gq,
-                                                             unsigned long long* __restrict__ gcount,
-                                                             unsigned long long cap) {
-  __shared__ uint2 s_stage[kThreads / 64][kIouStage];
-  __shared__ GridGeom s_q;
-  if (threadIdx.x == 0) s_q = grid_geom(g, G);
-  __syncthreads();
-  const GridGeom q = s_q;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint2* stage = s_stage[wave];
-  unsigned staged = 0;
-  auto flush = [&]() {
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(gcount, (unsigned long long)staged);
-    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
-    for (unsigned k = lane; k < staged; k += 64)
-      if (base + k < cap) gq[base + k] = stage[k];
-    staged = 0;
-  };
-  const uint32_t* cs = g->cell_cnt;                                 // start offsets after the scan
-  const int64_t nwaves = (int64_t)gridDim.x * (kThreads / 64);
-  for (int64_t i = row0 + (int64_t)blockIdx.x * (kThreads / 64) + wave; i < row1; i += nwaves) {
-    const PreBox A = P1[i];
-    int cx0 = 0, cx1 = G - 1, cy0 = 0, cy1 = G - 1;
-    const float R = (fabsf(A.r) + q.rmax) * 1.002f + 2e-3f;         // >= the circle test's (ar + br) * 1.002 + 1e-3
-    if (isfinite(A.x) && isfinite(A.y) && isfinite(R)) {
-      cx0 = grid_cell(A.x - R, q.x0, q.ix, G); cx1 = grid_cell(A.x + R, q.x0, q.ix, G);
-      cy0 = grid_cell(A.y - R, q.y0, q.iy, G); cy1 = grid_cell(A.y + R, q.y0, q.iy, G);
-    }
-    for (int cy = cy0; cy <= cy1 + 1; cy++) {                       // the extra turn: the wild cell
-      uint32_t e0, e1;
-      if (cy <= cy1) { e0 = cs[cy * G + cx0]; e1 = cs[cy * G + cx1 + 1]; }
-      else { e0 = cs[G * G]; e1 = cs[G * G + 1]; }
-      for (uint32_t e = e0; e < e1; e += 64) {                      // (wave-uniform bounds)
-        const uint32_t k = e + lane;
-        bool hit = false;
-        uint32_t j = 0;
-        if (k < e1) {
-          const PreBox B = P2s[k];
-          j = __float_as_uint(B.label);
-          hit = !surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B);
-        }
-        const unsigned long long bal = __ballot(hit);
-        if (hit) stage[staged + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2((unsigned)(i - row0), j);
-        staged += (unsigned)__popcll(bal);
-        if (staged + 64 > kIouStage) flush();
-      }
-    }
-  }
-  if (staged) flush();
 }
 
 // HEAVY: dense list, one pair per lane, persistent grid.  Values go to a compact buffer (vals[e] for pair e): this pass
@@ -2241,8 +1778,7 @@ extern "C" size_t s2a_box_iou_rotated_workspace_bytes(int64_t n, int64_t m) {
   if (n <= 0 || m <= 0) return 256;
   unsigned long long pairs = (unsigned long long)n * (unsigned long long)m;
   unsigned long long cap = std::max<unsigned long long>(std::min<unsigned long long>(pairs, kIouQueueCap), (unsigned long long)m * 256);
-  return align_up((size_t)(n + m) * sizeof(PreBox)) * 2 + align_up(cap * (sizeof(uint2) + sizeof(float))) + 8192 +
-         align_up(sizeof(IouGrid)) + align_up((size_t)m * 4) + align_up((size_t)m * sizeof(PreBox));
+  return align_up((size_t)(n + m) * sizeof(PreBox)) * 2 + align_up(cap * (sizeof(uint2) + sizeof(float))) + 8192;
 }
 
 namespace s2a {
@@ -2289,10 +1825,7 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   PreBox* P1 = cv.take<PreBox>((size_t)n);
   PreBox* P2 = cv.take<PreBox>((size_t)m);
   unsigned long long* counters = cv.take<unsigned long long>(512);
-  IouGrid* grid = cv.take<IouGrid>(1);
-  uint32_t* cell_of = cv.take<uint32_t>((size_t)m);
-  PreBox* P2s = cv.take<PreBox>((size_t)m);
-  if (!P1 || !P2 || !counters || !grid || !cell_of || !P2s ||
+  if (!P1 || !P2 || !counters ||
       cv.off + (size_t)m * 256 * (sizeof(uint2) + sizeof(float)) + 512 > workspace_bytes) {
     set_error("box_iou_rotated: workspace too small (%zu bytes)", workspace_bytes);
     return S2A_EWORKSPACE;
@@ -2312,23 +1845,8 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   // compact buffer; after the join a small kernel drops the values into place.  (Round 1 stored the zeros from the cull
   // kernel -- 4 TB/s beside its circle tests -- and ran the dense pass after it: 212 us at 10 k x 10 k.)
   const bool big = (unsigned long long)n * (unsigned long long)m * 4ull >= kIouForkBytes;
-  const char* ef = getenv("S2A_IOU_FORK");                 // A/B (with S2A_IOU_TILE=0): 0 = never fork, 1 = always
+  const char* ef = getenv("S2A_IOU_FORK");                 // A/B: 0 = never fork, 1 = always
   const bool fork = ef && (ef[0] == '0' || ef[0] == '1') ? ef[0] == '1' : big;
-  // OPT-IN (S2A_IOU_TILE=1): ONE launch, k_iou_tile.  Bit-exact (tests force every path), measured: 48 vs 55 us at
-  // 21824 x 128 with 1 % of the pairs overlapping, but 245 vs 195 us at 10 k x 10 k (its workgroups no longer fit one
-  // resident round) and 552 vs 216 us for 21824 anchors x 300 ground-truth boxes, where most pairs overlap and the exact
-  // evaluation runs at the tile kernel's 12 waves per CU instead of the dense pass's 17-32.  The density is not known
-  // in advance, so the pipeline of separate passes below is the default.
-  const char* et = getenv("S2A_IOU_TILE");
-  const bool use_tile = et && et[0] == '1';
-  if (use_tile) {
-    k_prep_boxes2<<<(unsigned)((std::max<int64_t>(n + m, 512) + 255) / 256), 256, 0, st>>>(boxes1, n, P1, boxes2, m, P2, counters, 512);
-    k_iou_tile<<<dim3((unsigned)((m + kTileCols - 1) / kTileCols), (unsigned)((n + kThreads - 1) / kThreads)), kThreads, 0,
-                 st>>>(P1, P2, n, m, ious, gq, counters, cap);
-    k_iou_redo<<<kPersistentGrid / 2, kThreads, 0, st>>>(P1, P2, n, m, ious, gq, counters, cap);
-    S2A_LAUNCH_CHECK();
-    return S2A_OK;
-  }
   SideStream* ss = nullptr;
   std::unique_lock<std::mutex> lock(g_side_mutex, std::defer_lock);
   if (fork) {
@@ -2357,41 +1875,19 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     S2A_HIP(hipEventRecord(ss->join, ss->s));
   }
   k_prep_boxes2<<<(unsigned)((std::max<int64_t>(n + m, 512) + 255) / 256), 256, 0, st>>>(boxes1, n, P1, boxes2, m, P2, counters, 512);
-  // large problems: pair finding through a uniform grid over the second set (see k_iou_grid_query); cells of ~16 boxes
-  const int G = std::max(1, std::min(kGridMax, (int)std::sqrt((double)m / 16.0)));
-  // OPT-IN (S2A_IOU_GRID=1): correct (tests/test_gpu_ops.py::test_iou_grid_path_exotic_inputs) but measured SLOWER on
-  // MI355X -- 309 vs 215 us at 10 k x 10 k: the query is latency-bound (1024 waves walking cell segments with dependent
-  // loads, 96 us) and every kernel with dependent memory operations crawls beside the 7 TB/s zero-fill (the 40-workgroup
-  // bounding-box pass took 67 us); the VALU-bound all-pairs cull is what overlaps with the fill.
-  const char* eg = getenv("S2A_IOU_GRID");
-  const bool use_grid = fork && eg && eg[0] == '1';
-  const char* ec = getenv("S2A_IOU_CULL_COLS");            // A/B: the column-major cull beside the forked fill
+  const char* ec = getenv("S2A_IOU_CULL_COLS");            // A/B: round 1's column-major cull beside the forked fill
   const bool cull_cols = ec && ec[0] == '1';
-  const char* el = getenv("S2A_IOU_CULL_LANES");            // A/B: 0 = k_iou_cull_rows (LDS broadcast reads, survivor lists)
-  const bool cull_lanes = !(el && el[0] == '0') && !cull_cols;
-  if (use_grid) {
-    const unsigned gm = (unsigned)((m + 255) / 256);
-    k_iou_grid_init<<<(kGridMax * kGridMax + 2 + 255) / 256, 256, 0, st>>>(grid);
-    k_iou_grid_bbox<<<gm, 256, 0, st>>>(P2, m, grid);
-    k_iou_grid_count<<<gm, 256, 0, st>>>(P2, m, grid, G, cell_of);
-    k_iou_grid_scan<<<1, 1024, 0, st>>>(grid, G * G + 1);
-    k_iou_grid_scatter<<<gm, 256, 0, st>>>(P2, m, grid, cell_of, P2s);
-  }
   for (int64_t c = 0; c < chunks; c++) {
     int64_t r0 = c * rows_per_chunk, r1 = std::min(n, r0 + rows_per_chunk);
     dim3 grid_c((unsigned)((m + kThreads * 4 - 1) / (kThreads * 4)), (unsigned)((r1 - r0 + kIouRowsPerWg - 1) / kIouRowsPerWg));
-    if (use_grid)
-      k_iou_grid_query<<<256, kThreads, 0, st>>>(P1, P2s, r0, r1, grid, G, gq, counters + c, cap);
-    else if (fork && cull_lanes) {
+    if (fork && !cull_cols) {
       // columns per workgroup: enough workgroups for ~8 per CU, at least 256 columns each
       const int64_t rwg = (r1 - r0 + kThreads - 1) / kThreads;
       int64_t cw = 256;
       while (cw < m && rwg * ((m + cw - 1) / cw) > 4096) cw *= 2;
       k_iou_cull_lanes<<<dim3((unsigned)((m + cw - 1) / cw), (unsigned)rwg), kThreads, 0, st>>>(P1, P2, r0, r1, m, (int)cw, gq,
                                                                                             counters + c, cap);
-    } else if (fork && !cull_cols)
-      k_iou_cull_rows<<<dim3((unsigned)((m + kCrCols - 1) / kCrCols), (unsigned)((r1 - r0 + kThreads - 1) / kThreads)),
-                        kThreads, 0, st>>>(P1, P2, r0, r1, m, gq, counters + c, cap);
+    }
     else if (fork)
       k_iou_cull<false><<<grid_c, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
     else

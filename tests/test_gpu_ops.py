@@ -100,14 +100,14 @@ def _degenerate_boxes(rng, n):
     return np.concatenate([base, dup, turn, touch]).astype(np.float32)
 
 
-@pytest.mark.parametrize("path", ["tile", "pipeline", "unforked", "lanes"])
+@pytest.mark.parametrize("path", ["forked", "unforked", "cols"])
 def test_iou_pairs_with_many_candidate_points(rng, monkeypatch, path):
-    """every way box_iou_rotated can be evaluated: the single-launch tile kernel (default while its grid is resident at
-    once), the forked pipeline of separate passes (bigger problems) and the un-forked pipeline"""
+    """every way box_iou_rotated is evaluated: forked (paced zero-fill beside the readlane pair finder; the default from
+    8 MB of output), un-forked (the column-major cull stores the zeros itself; small outputs), and the column-major cull
+    beside the fill (A/B switch)"""
     import s2anet_amd as S
-    monkeypatch.setenv("S2A_IOU_TILE", "1" if path == "tile" else "0")
     monkeypatch.setenv("S2A_IOU_FORK", "0" if path == "unforked" else "1")
-    monkeypatch.setenv("S2A_IOU_CULL_LANES", "1" if path == "lanes" else "0")
+    monkeypatch.setenv("S2A_IOU_CULL_COLS", "1" if path == "cols" else "0")
     b1 = _degenerate_boxes(rng, 1600)
     b2 = np.concatenate([b1[::2], rand_rboxes(rng, 803, span=60, lo=8, hi=30)])     # 1603 columns: unaligned rows
     out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
@@ -118,11 +118,11 @@ def test_iou_pairs_with_many_candidate_points(rng, monkeypatch, path):
     assert (bits(out4) != bits(ref[:, :1600])).sum() == 0
 
 
-@pytest.mark.parametrize("path", ["tile", "pipeline", "lanes"])
+@pytest.mark.parametrize("path", ["forked", "unforked", "cols"])
 def test_iou_dense_overlap_both_paths(rng, monkeypatch, path):
     import s2anet_amd as S
-    monkeypatch.setenv("S2A_IOU_TILE", "1" if path == "tile" else "0")
-    monkeypatch.setenv("S2A_IOU_CULL_LANES", "1" if path == "lanes" else "0")
+    monkeypatch.setenv("S2A_IOU_FORK", "0" if path == "unforked" else "1")
+    monkeypatch.setenv("S2A_IOU_CULL_COLS", "1" if path == "cols" else "0")
     b1, b2 = rand_rboxes(rng, 900, span=25, lo=30, hi=60), rand_rboxes(rng, 2300, span=25, lo=30, hi=60)
     b2[1500:, :2] += 5000.0
     out = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
@@ -160,12 +160,10 @@ def test_nms_with_duplicates_and_shared_edges(rng):
 
 
 # ------------------------------------------------------------------ NMS
-def test_iou_grid_path_exotic_inputs(rng, monkeypatch):
-    """large outputs (>= 8 MB) can find their overlapping pairs through a uniform grid over the second set (S2A_IOU_GRID=1,
-    opt-in: slower on MI355X than the all-pairs cull, kept as a measured alternative): same bits as the all-pairs cull
-    and as the oracle with (a) one huge column (its radius inflates every row's
-    search range), (b) non-finite columns and rows (evaluated, never culled: NaN in, NaN out, as the reference),
-    (c) all centres on one point (degenerate bounding box), (d) a far outlier that squeezes everything into one cell"""
+def test_iou_exotic_inputs_all_pair_finders(rng, monkeypatch):
+    """large outputs (>= 8 MB: the forked path with the readlane pair finder) against the un-forked pipeline and the
+    column-major finder beside the fill, and against the oracle, with (a) one huge column, (b) non-finite columns and rows
+    (evaluated, never culled: NaN in, NaN out), (c) all centres on one point, (d) a far outlier"""
     import s2anet_amd as S
     n, m = 1500, 1600
     for case in ("huge", "nonfinite", "point", "outlier"):
@@ -180,12 +178,15 @@ def test_iou_grid_path_exotic_inputs(rng, monkeypatch):
         else:
             b2[0, :2] = 4e6
         ref = oracle.box_iou_rotated(b1, b2, sort_mode=oracle.SORT_GPU)
-        plain = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
-        monkeypatch.setenv("S2A_IOU_GRID", "1")
         got = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
-        monkeypatch.delenv("S2A_IOU_GRID")
-        # the two pair finders must agree bit for bit, NaN patterns included (same evaluation of whatever survives)
-        assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)), case
+        for env in ({"S2A_IOU_FORK": "0"}, {"S2A_IOU_CULL_COLS": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            other = S.box_iou_rotated(cu(b1), cu(b2)).cpu().numpy()
+            for k in env:
+                monkeypatch.delenv(k)
+            # the pair finders must agree bit for bit, NaN patterns included (same evaluation of whatever survives)
+            assert np.array_equal(got.view(np.uint32), other.view(np.uint32)), (case, env)
         # and every pair of FINITE boxes equals the oracle (what a non-finite box yields -- NaN or 0 -- is pinned by
         # nothing in the reference: its CUDA op was never run on such input; here they are evaluated, never culled)
         fin = np.isfinite(b1).all(1)[:, None] & np.isfinite(b2).all(1)[None, :]
