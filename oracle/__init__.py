@@ -78,6 +78,9 @@ def lib():
         L.orc_deform_conv_forward.restype = None
         L.orc_deform_conv_forward.argtypes = [f32p, f32p, f32p, i64, i64, i64, i64, i64,
                                               ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, f32p]
+        L.orc_deform_conv_forward_half.restype = None
+        L.orc_deform_conv_forward_half.argtypes = [f32p, f32p, f32p, i64, i64, i64, i64, i64,
+                                                   ci, ci, ci, ci, ci, ci, ci, ci, ci, f32p]
         L.orc_round_f16.restype = ctypes.c_float
         L.orc_round_f16.argtypes = [ctypes.c_float]
         _lib = L
@@ -326,6 +329,24 @@ def deform_conv_forward(x, offset, weight, stride=(1, 1), padding=(1, 1), dilati
                                   stride[0], stride[1], padding[0], padding[1],
                                   dilation[0], dilation[1], groups, deformable_groups,
                                   int(f16_cols), int(relu), _p(out))
+    return out
+
+
+def deform_conv_forward_half(x, offset, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), relu=False):
+    """the reference's scalar_t = Half instantiation (models/dcn/deform_conv.py:45-46 casts the offsets to the input's
+    dtype; deform_conv_cuda_kernel.cu:83-114,221-228 then compute h_im / w_im, the bilinear weights and the blend in
+    c10::Half, every operation rounded to binary16).  x, weight: binary16-representable float32; offset: float32 (rounded
+    inside).  groups = deformable_groups = 1.  -> out float32 holding binary16 values"""
+    x, offset, weight = _f32(x), _f32(offset), _f32(weight)
+    B, C, H, W = x.shape
+    O, _, kH, kW = weight.shape
+    Ho = (H + 2 * padding[0] - (dilation[0] * (kH - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (kW - 1) + 1)) // stride[1] + 1
+    assert offset.shape == (B, 2 * kH * kW, Ho, Wo), offset.shape
+    assert np.array_equal(x, x.astype(np.float16).astype(np.float32)), "x must be binary16-representable"
+    out = np.empty((B, O, Ho, Wo), np.float32)
+    lib().orc_deform_conv_forward_half(_p(x), _p(offset), _p(weight), B, C, H, W, O, kH, kW, stride[0], stride[1],
+                                       padding[0], padding[1], dilation[0], dilation[1], int(relu), _p(out))
     return out
 
 

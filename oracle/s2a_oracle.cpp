@@ -647,6 +647,72 @@ void orc_deform_conv_forward(const float* x, const float* offset, const float* w
     }
 }
 
+// ----- the reference's HALF instantiation of the same forward (val.py:126 `.half()`) ------------------
+// scalar_t = c10::Half in deformable_im2col_gpu_kernel (deform_conv_cuda_kernel.cu:189-242) and
+// deformable_im2col_bilinear (:83-114); the offsets arrive already cast to the input's dtype
+// (models/dcn/deform_conv.py:45 `offset.type_as(input)`).  c10::Half arithmetic = convert both operands
+// to float, operate, round the result to binary16 (an int operand is converted to Half first, exact for
+// the magnitudes here) — so EVERY operation of the sampling is rounded to half:
+//   h_im = rh(float(h_in + i*dil) + off_h);  lh = rh(h - h_low);  hh = rh(1 - lh);  w1 = rh(hh*hw) ...
+//   val  = rh(rh(rh(rh(w1*v1) + rh(w2*v2)) + rh(w3*v3)) + rh(w4*v4))            (left to right, no FMA)
+// The bounds tests and floor() run on the half value widened to float.  The contraction is cuBLAS
+// half-in / float-accumulate (order unspecified): accumulated in double here, result rounded to half.
+// x / weight must hold binary16-representable values.  Used only to BOUND the product's f16 kernel
+// (which keeps coordinates in f32) against the reference's half semantics — tests/test_gpu_e2e.py.
+static inline float rh(float v) { return orc_round_f16(v); }
+static inline float bilinear_at_half(const float* plane, int H, int W, float h, float w) {
+  int h_low = (int)std::floor(h), w_low = (int)std::floor(w);
+  int h_high = h_low + 1, w_high = w_low + 1;
+  float lh = rh(h - rh((float)h_low)), lw = rh(w - rh((float)w_low));
+  float hh = rh(1.0f - lh), hw = rh(1.0f - lw);
+  float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+  if (h_low >= 0 && w_low >= 0) v1 = plane[h_low * W + w_low];
+  if (h_low >= 0 && w_high <= W - 1) v2 = plane[h_low * W + w_high];
+  if (h_high <= H - 1 && w_low >= 0) v3 = plane[h_high * W + w_low];
+  if (h_high <= H - 1 && w_high <= W - 1) v4 = plane[h_high * W + w_high];
+  float w1 = rh(hh * hw), w2 = rh(hh * lw), w3 = rh(lh * hw), w4 = rh(lh * lw);
+  float acc = rh(rh(w1 * v1) + rh(w2 * v2));
+  acc = rh(acc + rh(w3 * v3));
+  acc = rh(acc + rh(w4 * v4));
+  return acc;
+}
+
+void orc_deform_conv_forward_half(const float* x, const float* offset, const float* weight,
+                                  int64_t B, int64_t C, int64_t H, int64_t W, int64_t O,
+                                  int kH, int kW, int sH, int sW, int pH, int pW, int dH, int dW,
+                                  int relu, float* out) {
+  const int64_t Ho = (H + 2 * pH - (dH * (kH - 1) + 1)) / sH + 1;
+  const int64_t Wo = (W + 2 * pW - (dW * (kW - 1) + 1)) / sW + 1;
+  const int64_t K = C * kH * kW;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int64_t b = 0; b < B; b++)
+    for (int64_t ho = 0; ho < Ho; ho++) {
+      std::vector<float> col(K);
+      for (int64_t wo = 0; wo < Wo; wo++) {
+        const float* offp = offset + b * 2 * kH * kW * Ho * Wo;
+        for (int i = 0; i < kH; i++)
+          for (int j = 0; j < kW; j++) {
+            float oh = rh(offp[((2 * (i * kW + j)) * Ho + ho) * Wo + wo]);
+            float ow = rh(offp[((2 * (i * kW + j) + 1) * Ho + ho) * Wo + wo]);
+            float him = rh(rh((float)(ho * sH - pH + i * dH)) + oh);
+            float wim = rh(rh((float)(wo * sW - pW + j * dW)) + ow);
+            bool in = him > -1 && wim > -1 && him < H && wim < W;
+            for (int64_t c = 0; c < C; c++)
+              col[(c * kH + i) * kW + j] =
+                  in ? bilinear_at_half(x + (b * C + c) * H * W, (int)H, (int)W, him, wim) : 0.0f;
+          }
+        for (int64_t o = 0; o < O; o++) {
+          const float* wr = weight + o * K;
+          double acc = 0;
+          for (int64_t k = 0; k < K; k++) acc += (double)wr[k] * (double)col[k];
+          float r = rh((float)acc);
+          if (relu && r < 0) r = 0;
+          out[((b * O + o) * Ho + ho) * Wo + wo] = r;
+        }
+      }
+    }
+}
+
 // IEEE binary16 round-to-nearest-even of a float, returned as float.
 float orc_round_f16(float v) {
   uint32_t u;

@@ -61,3 +61,17 @@ int launch_nms_scan(const unsigned long long* mask, const uint32_t* seg_start, c
   } while (0)
 
 #define S2A_LAUNCH_CHECK() S2A_HIP(hipGetLastError())
+
+// Entry points that still issue hipMemsetAsync / rocprim::select (the drop-in nms_rotated / ml_nms_rotated / nms_poly
+// forms: they return a device count the host usually reads anyway) are NOT graph-safe on ROCm 7.2: they
+// refuse a capturing stream instead of producing a graph that misbehaves on its second replay.  The capturable
+// post-processing is s2a_nms_rotated_segmented / s2a_multiclass_candidates (own fill / count / scan / scatter kernels).
+#define S2A_REFUSE_CAPTURE(st, what)                                                                   \
+  do {                                                                                                 \
+    hipStreamCaptureStatus cs_ = hipStreamCaptureStatusNone;                                           \
+    if (hipStreamIsCapturing((st), &cs_) == hipSuccess && cs_ != hipStreamCaptureStatusNone) {         \
+      s2a::set_error(what ": this entry point is not HIP-graph capturable (memset nodes / rocprim::select); "  \
+                          "use s2a_nms_rotated_segmented on a capturing stream");                      \
+      return S2A_ENOTIMPL;                                                                             \
+    }                                                                                                  \
+  } while (0)

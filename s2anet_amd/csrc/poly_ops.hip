@@ -448,6 +448,7 @@ extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64
   S2A_CHECK_ARG(n >= 0 && n < (1ll << 31), "nms_poly: n out of range");
   S2A_CHECK_ARG(count_dev != nullptr, "nms_poly: count_dev must not be NULL");
   hipStream_t st = as_stream(stream);
+  S2A_REFUSE_CAPTURE(st, "nms_poly");
   if (n == 0) {
     S2A_HIP(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
     if (host_count) *host_count = 0;

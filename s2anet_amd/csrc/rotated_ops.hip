@@ -224,6 +224,14 @@ constexpr int kCrStage = 256;                 // per-wave staged pairs
 __device__ __forceinline__ float lane_bcast(float v, int j) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
 }
+// Hand-off of LDS data between the lanes of ONE wave (no workgroup barrier): the hardware issues a wave's LDS
+// operations in order, so all that is needed is that the COMPILER keeps the order too.  Wavefront-scope fences + the wave
+// barrier emit no instruction; they pin the order of the LDS stores / atomics before against the LDS loads after.
+__device__ __forceinline__ void wave_lds_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <int J0, int J1>
 __device__ __forceinline__ void circle_bits(float ax, float ay, float ar, float cx, float cy, float cr, unsigned& bits) {
 #pragma unroll
@@ -255,8 +263,10 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull_lanes(const PreBox* __res
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(gcount, (unsigned long long)ns);
     base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+    wave_lds_handoff();                          // other lanes' staged pairs
     for (unsigned k = lane; k < ns; k += 64)
       if (base + k < cap) gq[base + k] = stage[k];
+    wave_lds_handoff();                          // ... are read before the stage is written again
     ns = 0;
   };
   PreBox Cn = {};                                // next chunk's column box of this lane (one chunk ahead)
@@ -1035,8 +1045,10 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(gcount, (unsigned long long)ns);
     base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+    wave_lds_handoff();                          // other lanes' staged pairs
     for (unsigned k = lane; k < ns; k += 64)
       if (base + k < cap) gq[base + k] = stage[k];
+    wave_lds_handoff();                          // ... are read before the stage is written again
     ns = 0;
   };
   auto load = [&](const TileRef& t, PreBox& R, PreBox& Cc) {
@@ -1071,6 +1083,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
         bits &= (unsigned)((colvalid & tri) >> (32 * half));
         if (!rowvalid) bits = 0;
         if (lane == 0) s_n[wave] = 0;
+        wave_lds_handoff();                                      // the reset, then the reservations
         const unsigned cnt = (unsigned)__popc(bits);
         unsigned off = 0;
         if (cnt) off = atomicAdd(&s_n[wave], cnt);             // one reservation per lane (in order behind the reset)
@@ -1079,6 +1092,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
           bits &= bits - 1u;
           list[off++] = (unsigned short)(((unsigned)lane << 6) | (32u * half + b));
         }
+        wave_lds_handoff();                                      // every lane's list entries and the final count
         unsigned n1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_n[wave]);
         while (n1 > 0u) {                                        // the whole half tile: the boxes change with the tile
           const unsigned g = min(n1, 64u), base = n1 - g;
@@ -1100,6 +1114,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
           n1 = base;
           if (ns + 64 > kNlStage) flush();
         }
+        wave_lds_handoff();                                      // list read out before the next half tile rewrites it
       }
       t = tn;
       A = An;
@@ -1725,6 +1740,7 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
                hipStream_t st) {
   S2A_CHECK_ARG(n >= 0 && n < (1ll << 31), "nms_rotated: n out of range");
   S2A_CHECK_ARG(count_dev != nullptr, "nms_rotated: count_dev must not be NULL");
+  S2A_REFUSE_CAPTURE(st, "nms_rotated");
   if (n == 0) {
     S2A_HIP(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
     if (host_count) *host_count = 0;

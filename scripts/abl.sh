@@ -7,6 +7,9 @@
 # 32 = filter fragments loaded once, 64 = loaded every stage but from a fixed address (plain kernel, S2A_MPIPE form).  S2A_MPIPE=0: matrix waves without the fragment prefetch.
 # (Skipping LOADS is not a valid ablation: the compiler deletes the arithmetic that consumes undefined values.)
 cd $GRAFT_REPO_ROOT
+# whatever happens, the box is left with the DEFAULT build (the Makefile does not track EXTRA)
+restore() { rm -f s2anet_amd/csrc/dcn_ops.o; make -C s2anet_amd/csrc -s 2>&1 | grep -E "error" | head -3; }
+trap restore EXIT
 for a in "$@"; do
   case "$a" in -D*) flags="$a";; *) flags="-DS2A_ABL=$a";; esac
   rm -f s2anet_amd/csrc/dcn_ops.o

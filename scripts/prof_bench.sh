@@ -4,6 +4,8 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
+# a profiler-preloaded process must never spawn ranks (bench.py refuses too): single-rank profiling only
+for a in "$@"; do case "$prev$a" in --gpus[2-9]*|--gpus=[2-9]*|--gpus1[0-9]*) echo "prof_bench.sh: --gpus > 1 is refused under rocprofv3 (profile rank by rank)"; exit 2;; esac; prev=$a; done
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp

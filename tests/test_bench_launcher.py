@@ -8,6 +8,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _run(extra_env, *args):
@@ -34,6 +36,19 @@ def test_failed_rank_fails_the_launch():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "rank 1 exited with 3" in r.stderr
+
+
+def test_launcher_refuses_under_a_preloaded_profiler():
+    """rocprofv3 preloads its tool library, which initialises the GPU before main(): spawning ranks from such a process
+    is the hop that takes a box down.  bench.py must exit non-zero WITHOUT starting a child."""
+    import bench
+    assert bench.profiler_preloaded({"ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"})
+    assert bench.profiler_preloaded({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so.0"})
+    assert not bench.profiler_preloaded({"LD_PRELOAD": "/lib/libfoo.so"}) and not bench.profiler_preloaded({})
+    # HSA_TOOLS_LIB is only read when HSA initialises (never in this CPU process): safe to set for the subprocess
+    r = _run({"HSA_TOOLS_LIB": "librocprofiler-sdk-tool.so"}, "--gpus", "2", "--steps", "1", "--warmup", "1")
+    assert r.returncode == 4, (r.returncode, r.stderr[-500:])
+    assert "refusing to launch" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_under_torchrun_env_no_relaunch():
