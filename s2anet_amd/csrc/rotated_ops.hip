@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -430,94 +431,194 @@ constexpr unsigned long long kIouQueueCap = 32ull << 20;  // 32 Mi pairs = 256 M
 // No N x N/64 suppression mask exists any more (the reference's is 5.0 GB at 200 k rows and goes to the host; round 1
 // kept a 334 MB per-segment one on the device).  If the pair or edge list overflows (pathologically dense inputs), a
 // memory-free direct greedy kernel redoes the segments (slow, exact).
-__global__ void k_nms_keys(const float* __restrict__ scores, const int32_t* __restrict__ groups,
-                           const int32_t* __restrict__ seg_ids, uint32_t num_groups, int64_t n,
-                           unsigned long long* __restrict__ key1, int32_t* __restrict__ idx) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long g = groups ? (unsigned long long)(uint32_t)groups[i] : 0ull;
-  if (seg_ids && seg_ids[i] < 0) g = num_groups;  // ignored row: sorts behind every real group
-  key1[i] = (g << 32) | (unsigned long long)(~float_sortable(scores[i]));
-  idx[i] = (int32_t)i;
-}
+// device-side scalars of one call (zeroed by k_nms_prep)
+struct NmsCounters {
+  unsigned long long pairs;      // cull survivors (true total, may exceed the list)
+  unsigned long long edges;      // pairs with IoU > thr (true total)
+  unsigned long long tiles;      // tiles that passed the filter (true total)
+  unsigned long long alive_list; // edges handed to the clean-up kernel
+  unsigned long long tile_cursor;// next unclaimed entry of the tile list (k_nms_cull_lanes takes batches of tiles)
+  uint32_t status;               // bit 0: a list overflowed -> direct greedy fallback ran
+  uint32_t alive[16];            // edges still between two unsettled rows after round r
+};
 
-
-// segment key of every row, gathered into global (group, score) order.
-// labels (float, ml-NMS) -> canonical bit pattern; segment ids (int) -> the id; neither -> 0.
-__global__ void k_nms_segkeys(const float* __restrict__ labels, const int32_t* __restrict__ seg_ids,
-                              const int32_t* __restrict__ perm_glob, uint32_t ignore_key,
-                              int64_t n, uint32_t* __restrict__ key2) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  int32_t o = perm_glob[p];
-  uint32_t k = 0;
-  if (seg_ids) {
-    k = seg_ids[o] < 0 ? ignore_key : (uint32_t)seg_ids[o];
-  } else if (labels) {
-    float l = labels[o];
+// ---- PRELUDE (round 3).  Round 2 ran three rocPRIM sorts one after the other (global score order, stable regrouping by
+// segment, Morton order inside the segments) with a dozen 5 us kernels between them: ~300 us of launch latency at 200 k
+// rows (profiles/r02_nms_200k_timeline.txt).  Now ONE kernel builds all three 64-bit keys from the inputs,
+//   A = segment | score   (the order the greedy resolve works in),
+//   B = segment | Morton  (the spatial blocks of the cull; big segments only),
+//   C = group   | score   (the order of the output),
+// the three sorts are independent of each other and run SIDE BY SIDE (A on the caller's stream, B and C on two side
+// streams), and everything between the sort and the cull is three launches: segment boundaries by block counts
+// (k_nms_seg_count) + one fused pass (k_nms_pos_meta: prefix of the counts, in-block scan, seg_start, pre-processed boxes,
+// initial states, inverse permutation), the spatial gather, and a tile filter that needs no per-segment scan (one wave
+// per 64-row block walks that block's row of the upper triangle).
+__device__ __forceinline__ uint32_t nms_segkey(const float* __restrict__ labels, const int32_t* __restrict__ seg_ids,
+                                               uint32_t ignore_key, int64_t i) {
+  if (seg_ids) return seg_ids[i] < 0 ? ignore_key : (uint32_t)seg_ids[i];
+  if (labels) {
+    float l = labels[i];
     if (l == 0.0f) l = 0.0f;  // -0 == +0 in the reference's float compare
-    k = float_sortable(l);
+    return float_sortable(l);
   }
-  key2[p] = k;
+  return 0u;
 }
 
+constexpr int kPrepBlocks = 1024;     // upper bound of k_nms_prep's grid = number of bounding-box partials
+constexpr int kSegCountBlocks = 4096; // upper bound of the block-count arrays (segment heads, kept rows)
 
-__global__ void k_nms_heads(const uint32_t* __restrict__ key2s, int64_t n,
-                            uint32_t* __restrict__ head) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  head[p] = (p == 0 || key2s[p] != key2s[p - 1]) ? 1u : 0u;
+// block-wide sum of two values (256 threads); every thread gets both totals
+__device__ __forceinline__ void block_sum2(unsigned& a, unsigned& b) {
+  __shared__ unsigned s_a[4], s_b[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  __syncthreads();                               // (protects s_a / s_b against the previous use)
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  a = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+  b = s_b[0] + s_b[1] + s_b[2] + s_b[3];
 }
 
-
-// seg_start[s] for every run head; the last thread publishes S and the sentinel
-__global__ void k_nms_seg_start(const uint32_t* __restrict__ head, const uint32_t* __restrict__ segidx1,
-                                int64_t n, uint32_t* __restrict__ seg_start,
-                                uint32_t* __restrict__ num_seg) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  if (head[p]) seg_start[segidx1[p] - 1] = (uint32_t)p;
-  if (p == n - 1) {
-    uint32_t S = segidx1[p];
-    seg_start[S] = (uint32_t)n;
-    *num_seg = S;
+// keys of all three orders + the workspace initialisation (counters, round flags, block bounding boxes: by kernels, never
+// hipMemsetAsync -- DESIGN 5) + per-block partial bounding box of the finite centres (no atomics, so no init hazard)
+__global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ dets5, const float* __restrict__ scores,
+                                                  const float* __restrict__ labels, const int32_t* __restrict__ seg_ids,
+                                                  const int32_t* __restrict__ groups, uint32_t num_groups,
+                                                  uint32_t ignore_key, int64_t n, unsigned long long* __restrict__ keyA,
+                                                  unsigned long long* __restrict__ keyC, int32_t* __restrict__ idx,
+                                                  uint4* __restrict__ bbox_part, NmsCounters* __restrict__ C,
+                                                  uint32_t* __restrict__ blocked32, size_t nblocked32,
+                                                  uint32_t* __restrict__ seg_cnt, size_t nseg_cnt,
+                                                  uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots) {
+  const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i0 < sizeof(NmsCounters) / 4) reinterpret_cast<uint32_t*>(C)[i0] = 0u;
+  for (size_t i = i0; i < nblocked32; i += stride) blocked32[i] = 0u;
+  for (size_t i = i0; i < nseg_cnt; i += stride) seg_cnt[i] = 0u;
+  if (lo)
+    for (size_t i = i0; i < slots; i += stride) { lo[i] = make_uint2(0xffffffffu, 0xffffffffu); hi[i] = make_uint2(0u, 0u); }
+  uint32_t lx = 0xffffffffu, ly = 0xffffffffu, hx = 0u, hy = 0u;
+  for (size_t i = i0; i < (size_t)n; i += stride) {
+    const uint32_t sk = nms_segkey(labels, seg_ids, ignore_key, (int64_t)i);
+    unsigned long long g = groups ? (unsigned long long)(uint32_t)groups[i] : 0ull;
+    if (seg_ids && seg_ids[i] < 0) g = num_groups;   // ignored row: sorts behind every real group
+    const unsigned long long sc = (unsigned long long)(~float_sortable(scores[i]));
+    keyA[i] = ((unsigned long long)sk << 32) | sc;
+    if (keyC) keyC[i] = (g << 32) | sc;
+    idx[i] = (int32_t)i;
+    const float x = dets5[5 * i], y = dets5[5 * i + 1];
+    if (isfinite(x) && isfinite(y)) {
+      const uint32_t ux = float_sortable(x), uy = float_sortable(y);
+      lx = min(lx, ux); hx = max(hx, ux); ly = min(ly, uy); hy = max(hy, uy);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lx = min(lx, (uint32_t)__shfl_xor((int)lx, o)); ly = min(ly, (uint32_t)__shfl_xor((int)ly, o));
+    hx = max(hx, (uint32_t)__shfl_xor((int)hx, o)); hy = max(hy, (uint32_t)__shfl_xor((int)hy, o));
+  }
+  __shared__ uint4 s_bb[4];
+  if ((threadIdx.x & 63) == 0) s_bb[threadIdx.x >> 6] = make_uint4(lx, ly, hx, hy);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint4 r = s_bb[0];
+    for (int w = 1; w < 4; w++) {
+      r.x = min(r.x, s_bb[w].x); r.y = min(r.y, s_bb[w].y); r.z = max(r.z, s_bb[w].z); r.w = max(r.w, s_bb[w].w);
+    }
+    bbox_part[blockIdx.x] = r;
   }
 }
 
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every other bit of 20
+  v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+// spatial key of every row: (segment key, 20-bit Morton code of the centre on a 1024 x 1024 grid over the bounding box
+// of all finite centres).  Same segment key in the top bits as key A: both orders list the segments alike.
+__global__ __launch_bounds__(256) void k_nms_spkeys(const float* __restrict__ dets5,
+                                                    const unsigned long long* __restrict__ keyA,
+                                                    const uint4* __restrict__ bbox_part, int nparts, int64_t n,
+                                                    unsigned long long* __restrict__ keyB) {
+  __shared__ uint4 s_bb[4];
+  uint4 r = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+  for (int k = threadIdx.x; k < nparts; k += 256) {
+    const uint4 v = bbox_part[k];
+    r.x = min(r.x, v.x); r.y = min(r.y, v.y); r.z = max(r.z, v.z); r.w = max(r.w, v.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    r.x = min(r.x, (uint32_t)__shfl_xor((int)r.x, o)); r.y = min(r.y, (uint32_t)__shfl_xor((int)r.y, o));
+    r.z = max(r.z, (uint32_t)__shfl_xor((int)r.z, o)); r.w = max(r.w, (uint32_t)__shfl_xor((int)r.w, o));
+  }
+  if ((threadIdx.x & 63) == 0) s_bb[threadIdx.x >> 6] = r;
+  __syncthreads();
+  r = s_bb[0];
+  for (int w = 1; w < 4; w++) {
+    r.x = min(r.x, s_bb[w].x); r.y = min(r.y, s_bb[w].y); r.z = max(r.z, s_bb[w].z); r.w = max(r.w, s_bb[w].w);
+  }
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const float x0 = sortable_float(r.x), y0 = sortable_float(r.y), x1 = sortable_float(r.z), y1 = sortable_float(r.w);
+  const float sx = x1 > x0 ? 1023.f / (x1 - x0) : 0.f, sy = y1 > y0 ? 1023.f / (y1 - y0) : 0.f;
+  float qx = (dets5[5 * p] - x0) * sx, qy = (dets5[5 * p + 1] - y0) * sy;
+  qx = qx >= 0.f ? fminf(qx, 1023.f) : 0.f;      // NaN / nothing finite -> 0
+  qy = qy >= 0.f ? fminf(qy, 1023.f) : 0.f;
+  const uint32_t m = spread10((uint32_t)qx) | (spread10((uint32_t)qy) << 1);
+  keyB[p] = ((keyA[p] >> 32) << 20) | m;
+}
+
+// number of segment heads (rows whose segment key -- key >> shift -- differs from the row before) per block of `rows`
+// sorted rows, and the position + 1 of the block's last head (0: none) for the segment-start carry of k_nms_sp_meta
+__global__ __launch_bounds__(256) void k_nms_seg_count(const unsigned long long* __restrict__ keys, int shift, int64_t n,
+                                                       int rows, uint32_t* __restrict__ cnt,
+                                                       uint32_t* __restrict__ lasthead) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
+  unsigned c = 0, last = 0;
+  for (int64_t p = r0 + threadIdx.x; p < r1; p += 256)
+    if (p == 0 || (keys[p] >> shift) != (keys[p - 1] >> shift)) { c++; last = (unsigned)p + 1u; }
+  __shared__ unsigned s_last[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last = max(last, (unsigned)__shfl_xor((int)last, o));
+  if ((threadIdx.x & 63) == 0) s_last[threadIdx.x >> 6] = last;
+  unsigned dummy = 0;
+  block_sum2(c, dummy);                          // (its barriers also publish s_last)
+  if (threadIdx.x == 0) {
+    cnt[blockIdx.x] = c;
+    if (lasthead) lasthead[blockIdx.x] = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+  }
+}
+
+// offset of block b in an array of per-block counts (<= kSegCountBlocks of them) and the total
+__device__ __forceinline__ void count_prefix(const uint32_t* __restrict__ cnt, int nb, int b, unsigned& before,
+                                             unsigned& total) {
+  before = 0; total = 0;
+  for (int j = threadIdx.x; j < nb; j += 256) {
+    const unsigned c = cnt[j];
+    total += c;
+    if (j < b) before += c;
+  }
+  block_sum2(before, total);
+}
+
+// inclusive scan of one flag per thread over the 256 threads of the block; *block_total = number of set flags
+__device__ __forceinline__ unsigned block_scan_flag(bool f, unsigned* block_total) {
+  __shared__ unsigned s_w[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(f);
+  __syncthreads();
+  if (lane == 0) s_w[wave] = (unsigned)__popcll(bal);
+  __syncthreads();
+  unsigned base = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) base += w < wave ? s_w[w] : 0u;
+  *block_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  return base + (unsigned)__popcll(bal & ((2ull << lane) - 1ull));
+}
 
 struct TileRef {
   uint32_t seg_start, ns, rb, cb;
 };
-
-// tile id -> (segment, row block, col block >= row block)
-__device__ __forceinline__ TileRef locate_tile(unsigned long long tile,
-                                               const unsigned long long* __restrict__ tile_off,
-                                               const uint32_t* __restrict__ seg_start, uint32_t S,
-                                               uint32_t* seg_index = nullptr) {
-  uint32_t lo = 0, hi = S;  // last s with tile_off[s] <= tile
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (tile_off[mid] <= tile) lo = mid; else hi = mid;
-  }
-  if (seg_index) *seg_index = lo;
-  TileRef t;
-  t.seg_start = seg_start[lo];
-  t.ns = seg_start[lo + 1] - t.seg_start;
-  unsigned long long u = tile - tile_off[lo];
-  unsigned long long B = (t.ns + 63) / 64;
-  // rows before rb hold f(rb) = rb*B - rb*(rb-1)/2 tiles
-  double twoB1 = 2.0 * (double)B + 1.0;
-  long long rb = (long long)((twoB1 - sqrt(twoB1 * twoB1 - 8.0 * (double)u)) * 0.5);
-  if (rb < 0) rb = 0;
-  if (rb >= (long long)B) rb = (long long)B - 1;
-  auto f = [B](long long r) { return (unsigned long long)r * B - (unsigned long long)(r * (r - 1) / 2); };
-  while (rb > 0 && f(rb) > u) rb--;
-  while (rb + 1 < (long long)B && f(rb + 1) <= u) rb++;
-  t.rb = (uint32_t)rb;
-  t.cb = (uint32_t)(rb + (long long)(u - f(rb)));
-  return t;
-}
-
 
 // Greedy scan, one workgroup per segment at a time (persistent over segments).
 // Equivalent to the reference's host loop (ml_nms cuda.cu:120-131) restricted to a segment.
@@ -649,12 +750,36 @@ __global__ __launch_bounds__(kThreads) void k_nms_scan(const unsigned long long*
 }
 
 
-__global__ void k_nms_flags_glob(const uint8_t* __restrict__ keep_orig,
-                                 const int32_t* __restrict__ perm_glob, int64_t n,
-                                 uint8_t* __restrict__ flag_glob) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  flag_glob[p] = keep_orig[perm_glob[p]];
+// ---- keep list of the drop-in ops, in the output order (perm_glob = rows by descending score): kept rows per block,
+// then prefix + in-block scan + write (two launches; rocprim::select took four and a memset node)
+__global__ __launch_bounds__(256) void k_nms_keep_count(const uint8_t* __restrict__ keep_orig,
+                                                        const int32_t* __restrict__ perm_glob, int64_t n, int rows,
+                                                        uint32_t* __restrict__ cnt) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
+  unsigned c = 0, dummy = 0;
+  for (int64_t p = r0 + threadIdx.x; p < r1; p += 256) c += keep_orig[perm_glob[p]] ? 1u : 0u;
+  block_sum2(c, dummy);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = c;
+}
+__global__ __launch_bounds__(256) void k_nms_keep_write(const uint8_t* __restrict__ keep_orig,
+                                                        const int32_t* __restrict__ perm_glob, int64_t n, int rows,
+                                                        const uint32_t* __restrict__ cnt, int nb,
+                                                        int64_t* __restrict__ keep, int64_t* __restrict__ count_dev) {
+  unsigned before, total;
+  count_prefix(cnt, nb, blockIdx.x, before, total);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count_dev = (int64_t)total;
+  const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
+  unsigned running = before;
+  for (int64_t base = r0; base < r1; base += 256) {
+    const int64_t p = base + threadIdx.x;
+    int32_t o = 0;
+    bool f = false;
+    if (p < r1) { o = perm_glob[p]; f = keep_orig[o] != 0; }
+    unsigned tot;
+    const unsigned incl = block_scan_flag(f, &tot);
+    if (f) keep[running + incl - 1] = (int64_t)o;
+    running += tot;
+  }
 }
 
 // per-group compaction (batched detector): one workgroup per group
@@ -718,101 +843,47 @@ __global__ void k_zero_u8(uint8_t* p, int64_t n) {
 }
 
 
-// per segment: number of 64-row blocks and of upper-triangle tiles (0 for the ignored-rows segment), arrays of n+1
-__global__ void k_nms_seg_sizes(const uint32_t* __restrict__ seg_start,
-                                const uint32_t* __restrict__ num_seg,
-                                const uint32_t* __restrict__ key2s, uint32_t ignore_key,
-                                int use_ignore, int64_t n, unsigned long long* __restrict__ tiles,
-                                uint32_t* __restrict__ nblk) {
-  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s > n) return;
-  unsigned long long t = 0, nb = 0;
-  if (s < *num_seg) {
-    unsigned long long ns = seg_start[s + 1] - seg_start[s];
-    bool ignored = use_ignore && key2s[seg_start[s]] == ignore_key;
-    nb = ignored ? 0 : (ns + 63) / 64;
-    t = nb * (nb + 1) / 2;
-  }
-  tiles[s] = t;
-  nblk[s] = (uint32_t)nb;
-}
-
-// device-side scalars of one call
-struct NmsCounters {              // (everything in front of bbox is zeroed, bbox initialised, by k_nms_init_slots)
-  unsigned long long pairs;      // cull survivors (true total, may exceed the list)
-  unsigned long long edges;      // pairs with IoU > thr (true total)
-  unsigned long long tiles;      // tiles that passed the filter (true total)
-  unsigned long long alive_list; // edges handed to the clean-up kernel
-  uint32_t status;               // bit 0: a list overflowed -> direct greedy fallback ran
-  uint32_t alive[16];            // edges still between two unsettled rows after round r
-  uint32_t bbox[64][4];          // 64 partial {min x, min y (init 0xffffffff), max x, max y (init 0)} of the centres, as
-                                 // order-preserving integers; a workgroup adds to slot blockIdx % 64 (one address for
-                                 // all 3 k waves of a 200 k-row call serialised the atomics: 147 us)
-};
-
-// rows in (segment, score) order: pre-processed boxes (label slot = segment index), initial state, bounding box of
-// all finite centres (for the Morton quantisation)
-__global__ void k_nms_pos_meta(const float* __restrict__ dets5, const int32_t* __restrict__ perm_seg,
-                               const uint32_t* __restrict__ segidx1, const uint32_t* __restrict__ nblk, int64_t n,
-                               PreBox* __restrict__ sorted, uint8_t* __restrict__ state, NmsCounters* __restrict__ C,
-                               PreBox* __restrict__ sp_box_identity) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t lx = 0xffffffffu, ly = 0xffffffffu, hx = 0u, hy = 0u;
-  if (p < n) {
-    const uint32_t s = segidx1[p] - 1;
-    const float* b = dets5 + 5 * (int64_t)perm_seg[p];
-    PreBox pb = make_prebox(b[0], b[1], b[2], b[3], b[4], __uint_as_float(s));
-    sorted[p] = pb;
-    if (sp_box_identity) {                       // small segments: no spatial order, blocks in score order
-      pb.label = __uint_as_float((uint32_t)p);
-      sp_box_identity[p] = pb;
+// rows in (segment, score) order -- ONE pass behind the sort: segment index of every row (prefix of the block counts +
+// in-block scan of the head flags), seg_start[], num_seg, pre-processed boxes (label slot = segment index), initial
+// states (rows of the ignored segment are never kept), inverse permutation (original row -> score position)
+__global__ __launch_bounds__(256) void k_nms_pos_meta(const float* __restrict__ dets5,
+                                                      const unsigned long long* __restrict__ keyA_s,
+                                                      const int32_t* __restrict__ perm_seg,
+                                                      const uint32_t* __restrict__ cnt, int nb, int rows, int64_t n,
+                                                      uint32_t ignore_key, int use_ignore,
+                                                      uint32_t* __restrict__ segidx1, uint32_t* __restrict__ seg_start,
+                                                      uint32_t* __restrict__ num_seg, PreBox* __restrict__ sorted,
+                                                      uint8_t* __restrict__ state, uint32_t* __restrict__ inv) {
+  unsigned before, total;
+  count_prefix(cnt, nb, blockIdx.x, before, total);
+  if (seg_start && blockIdx.x == 0 && threadIdx.x == 0) { *num_seg = total; seg_start[total] = (uint32_t)n; }
+  const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
+  unsigned running = before;
+  for (int64_t base = r0; base < r1; base += 256) {
+    const int64_t p = base + threadIdx.x;
+    uint32_t sk = 0;
+    bool head = false;
+    if (p < r1) {
+      sk = (uint32_t)(keyA_s[p] >> 32);
+      head = p == 0 || sk != (uint32_t)(keyA_s[p - 1] >> 32);
     }
-    state[p] = nblk[s] == 0 ? 2 : 0;             // rows of the ignored segment are never kept
-    if (isfinite(b[0]) && isfinite(b[1])) {
-      lx = hx = float_sortable(b[0]);
-      ly = hy = float_sortable(b[1]);
+    unsigned tot;
+    const unsigned incl = block_scan_flag(head, &tot);
+    if (p < r1) {
+      const uint32_t s = running + incl - 1;
+      if (seg_start) {                             // (the spatial path takes segidx / seg_start from the B order)
+        segidx1[p] = s + 1;
+        if (head) seg_start[s] = (uint32_t)p;
+      }
+      const int32_t o = perm_seg[p];
+      const float* b = dets5 + 5 * (int64_t)o;
+      PreBox pb = make_prebox(b[0], b[1], b[2], b[3], b[4], __uint_as_float(s));
+      sorted[p] = pb;
+      inv[o] = (uint32_t)p;
+      state[p] = (use_ignore && sk == ignore_key) ? 2 : 0;
     }
+    running += tot;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    lx = min(lx, (uint32_t)__shfl_xor((int)lx, o)); ly = min(ly, (uint32_t)__shfl_xor((int)ly, o));
-    hx = max(hx, (uint32_t)__shfl_xor((int)hx, o)); hy = max(hy, (uint32_t)__shfl_xor((int)hy, o));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    uint32_t* bb = C->bbox[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63];
-    if (lx != 0xffffffffu) { atomicMin(&bb[0], lx); atomicMax(&bb[2], hx); }
-    if (ly != 0xffffffffu) { atomicMin(&bb[1], ly); atomicMax(&bb[3], hy); }
-  }
-}
-
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every other bit of 20
-  v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
-  v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
-  return v;
-}
-
-// spatial key of every row: (segment index, 20-bit Morton code of the centre on a 1024 x 1024 grid over the bounding box)
-__global__ void k_nms_spkeys(const PreBox* __restrict__ sorted, const NmsCounters* __restrict__ C, int64_t n,
-                             unsigned long long* __restrict__ key3, uint32_t* __restrict__ val) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  __shared__ uint32_t s_bb[4];
-  if (threadIdx.x < 4) {
-    uint32_t v = C->bbox[0][threadIdx.x];
-    for (int k = 1; k < 64; k++) v = threadIdx.x < 2 ? min(v, C->bbox[k][threadIdx.x]) : max(v, C->bbox[k][threadIdx.x]);
-    s_bb[threadIdx.x] = v;
-  }
-  __syncthreads();
-  if (p >= n) return;
-  const PreBox b = sorted[p];
-  const float x0 = sortable_float(s_bb[0]), y0 = sortable_float(s_bb[1]);
-  const float x1 = sortable_float(s_bb[2]), y1 = sortable_float(s_bb[3]);
-  const float sx = x1 > x0 ? 1023.f / (x1 - x0) : 0.f, sy = y1 > y0 ? 1023.f / (y1 - y0) : 0.f;
-  float qx = (b.x - x0) * sx, qy = (b.y - y0) * sy;
-  qx = qx >= 0.f ? fminf(qx, 1023.f) : 0.f;      // NaN -> 0
-  qy = qy >= 0.f ? fminf(qy, 1023.f) : 0.f;
-  const uint32_t m = spread10((uint32_t)qx) | (spread10((uint32_t)qy) << 1);
-  key3[p] = ((unsigned long long)__float_as_uint(b.label) << 20) | m;
-  val[p] = (uint32_t)p;
 }
 
 // slot of block `blk` of segment s in the block-bounding-box arrays: consecutive segments never collide because
@@ -822,111 +893,173 @@ __device__ __forceinline__ uint32_t block_slot(uint32_t seg_start_s, uint32_t s,
 }
 __host__ __device__ inline size_t block_slots_for(size_t n) { return n / 64 + n + 2; }
 
-// rows in SPATIAL order: box copy (label slot = its score position), bounding box of every 64-row block of the inflated
-// circumscribed circles (atomics on order-preserving integers; one per wave and slot in the common case)
-__global__ void k_nms_spgather(const PreBox* __restrict__ sorted, const uint32_t* __restrict__ perm_sp,
-                               const uint32_t* __restrict__ seg_start, int64_t n, PreBox* __restrict__ sp_box,
-                               uint2* __restrict__ lo, uint2* __restrict__ hi) {
-  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  uint32_t slot = 0xffffffffu, lx = 0xffffffffu, ly = 0xffffffffu, hx = 0, hy = 0;
-  if (q < n) {
-    const uint32_t p = perm_sp[q];
-    PreBox b = sorted[p];
-    const uint32_t s = __float_as_uint(b.label);
-    b.label = __uint_as_float(p);
-    sp_box[q] = b;
-    const uint32_t st = seg_start[s];
-    slot = block_slot(st, s, ((uint32_t)q - st) >> 6);
-    // margin of surely_disjoint per box (sum of two of these >= its (ar + br) * 1.002 + 1e-3), plus 1e-3 for the
-    // rounding of x -+ r at chip-sized coordinates; non-finite boxes overlap everything (evaluated, never culled)
-    const float rr = b.r * 1.002f + 2e-3f;
-    float x0 = b.x - rr, x1 = b.x + rr, y0 = b.y - rr, y1 = b.y + rr;
-    if (!(isfinite(x0) && isfinite(x1) && isfinite(y0) && isfinite(y1))) {
-      x0 = y0 = -__builtin_inff(); x1 = y1 = __builtin_inff();
-    }
-    lx = float_sortable(x0); ly = float_sortable(y0); hx = float_sortable(x1); hy = float_sortable(y1);
-  }
-  // a wave covers at most two slots unless segments are tiny: reduce the lanes of the first lane's slot and of the last
-  // lane's slot by shuffles, everybody else (rare) goes alone
-  const uint32_t s_first = (uint32_t)__shfl((int)slot, 0), s_last = (uint32_t)__shfl((int)slot, 63);
+// rows in SPATIAL order (sort B: segment | Morton) -- ONE pass behind that sort, on the critical path of the call: segment
+// index of every row, seg_start[], num_seg (prefix of the block counts + in-block scan), the row's pre-processed box,
+// and the bounding box of every 64-row block of the inflated circumscribed circles (atomics on order-preserving integers;
+// one per wave and slot in the common case).  The start of a row's segment -- needed for its block slot -- is the running
+// maximum of the head positions: carried in from the blocks before (lasthead[]) and scanned inside the block.
+__global__ __launch_bounds__(256) void k_nms_sp_meta(const float* __restrict__ dets5,
+                                                     const unsigned long long* __restrict__ keyB_s,
+                                                     const int32_t* __restrict__ perm_sp,
+                                                     const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lasthead,
+                                                     int nb, int rows, int64_t n, uint32_t* __restrict__ segidxq,
+                                                     uint32_t* __restrict__ seg_start, uint32_t* __restrict__ num_seg,
+                                                     PreBox* __restrict__ sp_box, uint2* __restrict__ lo,
+                                                     uint2* __restrict__ hi) {
+  unsigned before, total;
+  count_prefix(cnt, nb, blockIdx.x, before, total);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *num_seg = total; seg_start[total] = (uint32_t)n; }
+  __shared__ unsigned s_m[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned carry = 0;                            // (position + 1) of the last head before this block's rows
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) carry = max(carry, lasthead[j]);
 #pragma unroll
-  for (int g = 0; g < 2; g++) {
-    const uint32_t sg = g == 0 ? s_first : s_last;
-    if (g == 1 && s_last == s_first) break;
-    if (sg == 0xffffffffu) continue;
-    const bool in = slot == sg;
-    uint32_t a = in ? lx : 0xffffffffu, b = in ? ly : 0xffffffffu, c = in ? hx : 0u, d = in ? hy : 0u;
+  for (int o = 32; o > 0; o >>= 1) carry = max(carry, (unsigned)__shfl_xor((int)carry, o));
+  __syncthreads();
+  if (lane == 0) s_m[wave] = carry;
+  __syncthreads();
+  carry = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+  const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
+  unsigned running = before;
+  for (int64_t base = r0; base < r1; base += 256) {
+    const int64_t q = base + threadIdx.x;
+    bool head = false;
+    if (q < r1) head = q == 0 || (keyB_s[q] >> 20) != (keyB_s[q - 1] >> 20);
+    unsigned tot;
+    const unsigned incl = block_scan_flag(head, &tot);
+    // inclusive max-scan of the head positions (+ 1) over the block
+    unsigned m = head ? (unsigned)q + 1u : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      a = min(a, (uint32_t)__shfl_xor((int)a, o)); b = min(b, (uint32_t)__shfl_xor((int)b, o));
-      c = max(c, (uint32_t)__shfl_xor((int)c, o)); d = max(d, (uint32_t)__shfl_xor((int)d, o));
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)m, o);
+      if (lane >= o) m = max(m, t);
     }
-    if (lane == (g == 0 ? 0 : 63)) {
-      atomicMin(&lo[sg].x, a); atomicMin(&lo[sg].y, b); atomicMax(&hi[sg].x, c); atomicMax(&hi[sg].y, d);
+    __syncthreads();
+    if (lane == 63) s_m[wave] = m;
+    __syncthreads();
+    unsigned wm = carry;
+#pragma unroll
+    for (int w = 0; w < 4; w++) wm = w < wave ? max(wm, s_m[w]) : wm;
+    m = max(m, wm);
+    carry = max(carry, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
+    uint32_t slot = 0xffffffffu, lx = 0xffffffffu, ly = 0xffffffffu, hx = 0, hy = 0;
+    if (q < r1) {
+      const uint32_t sidx = running + incl - 1, st = m - 1u;
+      segidxq[q] = sidx + 1;
+      if (head) seg_start[sidx] = (uint32_t)q;
+      const float* d = dets5 + 5 * (int64_t)perm_sp[q];
+      const PreBox b = make_prebox(d[0], d[1], d[2], d[3], d[4], __uint_as_float((uint32_t)q));
+      sp_box[q] = b;
+      slot = block_slot(st, sidx, ((uint32_t)q - st) >> 6);
+      // margin of surely_disjoint per box (sum of two of these >= its (ar + br) * 1.002 + 1e-3), plus 1e-3 for the
+      // rounding of x -+ r at chip-sized coordinates; non-finite boxes overlap everything (evaluated, never culled)
+      const float rr = b.r * 1.002f + 2e-3f;
+      float x0 = b.x - rr, x1 = b.x + rr, y0 = b.y - rr, y1 = b.y + rr;
+      if (!(isfinite(x0) && isfinite(x1) && isfinite(y0) && isfinite(y1))) {
+        x0 = y0 = -__builtin_inff(); x1 = y1 = __builtin_inff();
+      }
+      lx = float_sortable(x0); ly = float_sortable(y0); hx = float_sortable(x1); hy = float_sortable(y1);
     }
-  }
-  if (slot != 0xffffffffu && slot != s_first && slot != s_last) {
-    atomicMin(&lo[slot].x, lx); atomicMin(&lo[slot].y, ly); atomicMax(&hi[slot].x, hx); atomicMax(&hi[slot].y, hy);
+    running += tot;
+    // a wave covers at most two slots unless segments are tiny: reduce the lanes of the first lane's slot and of the last
+    // lane's slot by shuffles, everybody else (rare) goes alone
+    const uint32_t s_first = (uint32_t)__shfl((int)slot, 0), s_last = (uint32_t)__shfl((int)slot, 63);
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const uint32_t sg = g == 0 ? s_first : s_last;
+      if (g == 1 && s_last == s_first) break;
+      if (sg == 0xffffffffu) continue;
+      const bool in = slot == sg;
+      uint32_t a = in ? lx : 0xffffffffu, b = in ? ly : 0xffffffffu, c = in ? hx : 0u, d = in ? hy : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        a = min(a, (uint32_t)__shfl_xor((int)a, o)); b = min(b, (uint32_t)__shfl_xor((int)b, o));
+        c = max(c, (uint32_t)__shfl_xor((int)c, o)); d = max(d, (uint32_t)__shfl_xor((int)d, o));
+      }
+      if (lane == (g == 0 ? 0 : 63)) {
+        atomicMin(&lo[sg].x, a); atomicMin(&lo[sg].y, b); atomicMax(&hi[sg].x, c); atomicMax(&hi[sg].y, d);
+      }
+    }
+    if (slot != 0xffffffffu && slot != s_first && slot != s_last) {
+      atomicMin(&lo[slot].x, lx); atomicMin(&lo[slot].y, ly); atomicMax(&hi[slot].x, hx); atomicMax(&hi[slot].y, hy);
+    }
   }
 }
 
-__global__ void k_nms_init_slots(uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots,
-                                 NmsCounters* __restrict__ C, uint8_t* __restrict__ blocked, size_t nblocked,
-                                 uint32_t* __restrict__ seg_cnt, size_t nseg_cnt) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < offsetof(NmsCounters, bbox) / 4) reinterpret_cast<uint32_t*>(C)[i] = 0u;      // counters, status, alive[]
-  if (i < nblocked) blocked[i] = 0;
-  if (i < nseg_cnt) seg_cnt[i] = 0u;
-  if (i < 64) { C->bbox[i][0] = C->bbox[i][1] = 0xffffffffu; C->bbox[i][2] = C->bbox[i][3] = 0u; }
-  if (i >= slots || !lo) return;
-  lo[i] = make_uint2(0xffffffffu, 0xffffffffu);
-  hi[i] = make_uint2(0u, 0u);
-}
-
-// TILE FILTER: one thread per upper-triangle tile (grid-stride over the device-side total); tiles whose two block
-// bounding boxes overlap are appended to the list (wave-aggregated).  Order-preserving integers compare like the floats.
-__global__ __launch_bounds__(kThreads) void k_nms_tile_filter(const uint32_t* __restrict__ seg_start,
-                                                              const uint32_t* __restrict__ num_seg,
-                                                              const unsigned long long* __restrict__ tile_off,
+// TILE FILTER: a wave looks at 64 consecutive rows; every row that opens a 64-row block of its segment hands that block's
+// row of the upper triangle to the whole wave (lane = column block): tiles whose two block bounding boxes overlap are
+// staged per wave and published with one global atomic per workgroup (a flush per wave in between when a stage fills).
+// No per-segment tile counts, no scan, no search: the round-2 form needed both and three launches in front of it.
+constexpr int kTfStage = 512;
+__global__ __launch_bounds__(kThreads) void k_nms_tile_filter(const uint32_t* __restrict__ segidx1,
+                                                              const uint32_t* __restrict__ seg_start,
+                                                              const unsigned long long* __restrict__ keys, int shift,
+                                                              uint32_t ignore_key, int use_ignore, int64_t n,
                                                               const uint2* __restrict__ lo, const uint2* __restrict__ hi,
                                                               TileRef* __restrict__ tiles, NmsCounters* __restrict__ C,
                                                               unsigned long long tile_cap) {
-  __shared__ unsigned s_w[kThreads / 64];
+  __shared__ TileRef s_stage[kThreads / 64][kTfStage];
+  __shared__ unsigned s_left[kThreads / 64];
   __shared__ unsigned long long s_base;
-  const uint32_t S = *num_seg;
-  const unsigned long long T = tile_off[S];
-  const int lane = threadIdx.x & 63;
-  for (unsigned long long t0 = (unsigned long long)blockIdx.x * kThreads; t0 < T; t0 += (unsigned long long)gridDim.x * kThreads) {
-    const unsigned long long t = t0 + threadIdx.x;
-    bool take = false;
-    TileRef tr = {};
-    if (t < T) {
-      uint32_t sidx = 0;
-      tr = locate_tile(t, tile_off, seg_start, S, &sidx);
-      take = true;                                  // (lo == nullptr: no spatial order, every tile is tested)
-      if (lo && tr.rb != tr.cb) {
-        const uint32_t a = block_slot(tr.seg_start, sidx, tr.rb), b = block_slot(tr.seg_start, sidx, tr.cb);
-        const uint2 la = lo[a], ha = hi[a], lb = lo[b], hb = hi[b];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  TileRef* stage = s_stage[wave];
+  unsigned ns = 0;                               // wave-uniform: staged tiles
+  auto flush = [&]() {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&C->tiles, (unsigned long long)ns);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+    wave_lds_handoff();
+    for (unsigned k = lane; k < ns; k += 64)
+      if (base + k < tile_cap) tiles[base + k] = stage[k];
+    wave_lds_handoff();
+    ns = 0;
+  };
+  const int64_t p = ((int64_t)blockIdx.x * (kThreads / 64) + wave) * 64 + lane;
+  uint32_t s = 0, st = 0, nrows = 0;
+  bool opens = false;
+  if (p < n && !(use_ignore && (uint32_t)(keys[p] >> shift) == ignore_key)) {   // (the ignored segment has no tiles)
+    s = segidx1[p] - 1;
+    st = seg_start[s];
+    nrows = seg_start[s + 1] - st;
+    opens = (((uint32_t)p - st) & 63u) == 0u;
+  }
+  unsigned long long todo = __ballot(opens);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const uint32_t bs = (uint32_t)__shfl((int)s, src), bst = (uint32_t)__shfl((int)st, src);
+    const uint32_t bn = (uint32_t)__shfl((int)nrows, src);
+    const uint32_t rb = (((uint32_t)__shfl((int)(uint32_t)p, src)) - bst) >> 6, B = (bn + 63) >> 6;
+    uint2 la = make_uint2(0, 0), ha = make_uint2(0, 0);
+    if (lo) { const uint32_t a = block_slot(bst, bs, rb); la = lo[a]; ha = hi[a]; }
+    for (uint32_t c0 = rb; c0 < B; c0 += 64) {
+      const uint32_t cb = c0 + lane;
+      bool take = cb < B;
+      if (take && lo && cb != rb) {
+        const uint32_t b = block_slot(bst, bs, cb);
+        const uint2 lb = lo[b], hb = hi[b];
         take = la.x <= hb.x && lb.x <= ha.x && la.y <= hb.y && lb.y <= ha.y;
       }
+      const unsigned long long bal = __ballot(take);
+      if (take) stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] = TileRef{bst, bn, rb, cb};
+      ns += (unsigned)__popcll(bal);
+      if (ns + 64 > kTfStage) flush();
     }
-    // one global atomic per workgroup and sweep (one per wave put ~5 k atomics on a single address: 40 us)
-    const unsigned long long bal = __ballot(take);
-    if (lane == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(bal);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned tot = 0;
-      for (int w = 0; w < kThreads / 64; w++) { const unsigned c = s_w[w]; s_w[w] = tot; tot += c; }
-      s_base = tot ? atomicAdd(&C->tiles, (unsigned long long)tot) : 0ull;
-    }
-    __syncthreads();
-    if (take) {
-      const unsigned long long dst = s_base + s_w[threadIdx.x >> 6] + __popcll(bal & ((1ull << lane) - 1ull));
-      if (dst < tile_cap) tiles[dst] = tr;
-    }
-    __syncthreads();
   }
+  if (lane == 0) s_left[wave] = ns;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++) {
+    if (w < wave) before += s_left[w];
+    all += s_left[w];
+  }
+  if (all == 0) return;                // uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(&C->tiles, (unsigned long long)all);
+  __syncthreads();
+  const unsigned long long base = s_base + before;
+  for (unsigned k = lane; k < ns; k += 64)
+    if (base + k < tile_cap) tiles[base + k] = stage[k];
 }
 
 // CULL over the tile list (persistent grid, every workgroup a contiguous run of list entries).
@@ -1001,10 +1134,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
         const unsigned v = s_q1[x], r = v >> 6, cc = v & 63u;
         const PreBox& A = s_row[cur][r];
         const PreBox& B = s_col[cur][cc];
-        if (!nms_pair_skippable(A, B, thr)) {
-          const unsigned pa = __float_as_uint(A.label), pb = __float_as_uint(B.label);
-          queue_push(Q, min(pa, pb), max(pa, pb));
-        }
+        if (!nms_pair_skippable(A, B, thr))          // pair = the two POSITIONS in the cull's row order (row block first)
+          queue_push(Q, t.seg_start + t.rb * 64 + r, t.seg_start + t.cb * 64 + cc);
       }
     }
     __syncthreads();                                    // dense stage done: lists and the current buffers may be reused
@@ -1023,6 +1154,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
 constexpr int kNlList = 64 * 32;              // circle-test survivors of half a tile, u16 = row << 6 | column
 constexpr int kNlStage = 512;                 // per-wave staged pairs
 constexpr int64_t kNmsLanesRows = 49152;      // rows from which the one-wave-per-tile cull is the default
+constexpr int kNlBatch = 8;                   // tiles a wave claims per visit to the cursor
 __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __restrict__ sp_box,
                                                              const TileRef* __restrict__ tiles,
                                                              NmsCounters* __restrict__ C, unsigned long long tile_cap,
@@ -1034,10 +1166,6 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long* gcount = &C->pairs;
   const unsigned long long L = min(C->tiles, tile_cap);   // (an overflowing tile list sets the status bit: fallback)
-  const unsigned long long nw = (unsigned long long)gridDim.x * (kThreads / 64);
-  const unsigned long long chunk = (L + nw - 1) / nw;
-  unsigned long long e = ((unsigned long long)blockIdx.x * (kThreads / 64) + wave) * chunk;
-  const unsigned long long eend = min(L, e + chunk);
   unsigned short* list = s_list[wave];
   uint2* stage = s_stage[wave];
   unsigned ns = 0;                               // wave-uniform: staged pairs
@@ -1058,7 +1186,15 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
     if (il < t.ns) R = sp_box[t.seg_start + il];
     if (jl < t.ns) Cc = sp_box[t.seg_start + jl];
   };
-  if (e < eend) {
+  // Tiles differ by an order of magnitude in what survives their circle tests, and a static split of the list left half
+  // of the waves idle in the second half of the launch (8.2 of 16 waves per CU on average, profiles/r02_nms_200k_pmc.txt):
+  // every wave now CLAIMS batches of kNlBatch tiles from a device-wide cursor until the list is empty.
+  for (;;) {
+    unsigned long long e = 0;
+    if (lane == 0) e = atomicAdd(&C->tile_cursor, (unsigned long long)kNlBatch);
+    e = ((unsigned long long)(uint32_t)__shfl((int)(e >> 32), 0) << 32) | (uint32_t)__shfl((int)(e & 0xffffffffu), 0);
+    if (e >= L) break;                           // wave-uniform
+    const unsigned long long eend = min(L, e + (unsigned long long)kNlBatch);
     TileRef t = tiles[e];
     PreBox A, Cb;
     load(t, A, Cb);
@@ -1101,15 +1237,14 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
           const int r = (int)(v >> 6), c = (int)(v & 63u);
           PreBox R, B;
           R.x = __shfl(A.x, r); R.y = __shfl(A.y, r); R.w = __shfl(A.w, r); R.h = __shfl(A.h, r);
-          R.c2 = __shfl(A.c2, r); R.s2 = __shfl(A.s2, r); R.r = __shfl(A.r, r); R.label = __shfl(A.label, r);
+          R.c2 = __shfl(A.c2, r); R.s2 = __shfl(A.s2, r); R.r = 0.f; R.label = 0.f;
           B.x = __shfl(Cb.x, c); B.y = __shfl(Cb.y, c); B.w = __shfl(Cb.w, c); B.h = __shfl(Cb.h, c);
-          B.c2 = __shfl(Cb.c2, c); B.s2 = __shfl(Cb.s2, c); B.r = __shfl(Cb.r, c); B.label = __shfl(Cb.label, c);
+          B.c2 = __shfl(Cb.c2, c); B.s2 = __shfl(Cb.s2, c); B.r = 0.f; B.label = 0.f;
           const bool keep = mine && !nms_pair_skippable(R, B, thr);
           const unsigned long long bal = __ballot(keep);
-          if (keep) {
-            const unsigned pa = __float_as_uint(R.label), pb = __float_as_uint(B.label);
-            stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(min(pa, pb), max(pa, pb));
-          }
+          if (keep)                              // pair = the two POSITIONS in the cull's row order
+            stage[ns + __popcll(bal & ((1ull << lane) - 1ull))] =
+                make_uint2(t.seg_start + t.rb * 64 + (unsigned)r, t.seg_start + t.cb * 64 + (unsigned)c);
           ns += (unsigned)__popcll(bal);
           n1 = base;
           if (ns + 64 > kNlStage) flush();
@@ -1145,7 +1280,8 @@ constexpr int kEdgeStage = 128;      // staged edges per wave
 // bit of its first index -- positions are < 2^31) and REDO = true, the second launch, evaluates the marked pairs with 24.
 constexpr uint32_t kPairRedo = 0x80000000u;
 template <bool REDO>
-__global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict__ sorted, float thr,
+__global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict__ boxes, const int32_t* __restrict__ perm_sp,
+                                                        const uint32_t* __restrict__ inv, float thr,
                                                         uint2* __restrict__ gq, NmsCounters* __restrict__ C,
                                                         unsigned long long cap, uint2* __restrict__ edges,
                                                         unsigned long long ecap) {
@@ -1170,18 +1306,23 @@ __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict
     bool hit = false;
     uint2 ij = make_uint2(0, 0);
     if (e < total) {
-      ij = gq[e];
-      if (REDO) {
-        if (ij.x & kPairRedo) {
-          ij.x &= ~kPairRedo;
-          hit = rbox_iou<kThreads>(sorted[ij.x], sorted[ij.y], s_pts + threadIdx.x) > thr;
+      // the pair list holds positions in the cull's row order (boxes[]); the greedy order is the SCORE position:
+      // inv[original row] (spatial order) or the position itself (blocks in score order)
+      uint2 q = gq[e];
+      const bool marked = (q.x & kPairRedo) != 0u;
+      q.x &= ~kPairRedo;
+      if (!REDO || marked) {
+        ij = perm_sp ? make_uint2(inv[perm_sp[q.x]], inv[perm_sp[q.y]]) : q;
+        if (ij.y < ij.x) { const uint32_t t = ij.x; ij.x = ij.y; ij.y = t; const uint32_t u = q.x; q.x = q.y; q.y = u; }
+        const PreBox A = boxes[q.x];    // higher score first: same argument order as the reference
+        const PreBox B = boxes[q.y];
+        if (REDO) {
+          hit = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x) > thr;
+        } else {
+          bool redo = false;
+          hit = rbox_iou<kThreads, CAP>(A, B, s_pts + threadIdx.x, &redo) > thr;  // reference GPU rule: strict (ml_nms cuda.cu:63-64)
+          if (redo) gq[e].x |= kPairRedo;
         }
-      } else {
-        const PreBox A = sorted[ij.x];  // higher score first: same argument order as the reference
-        const PreBox B = sorted[ij.y];
-        bool redo = false;
-        hit = rbox_iou<kThreads, CAP>(A, B, s_pts + threadIdx.x, &redo) > thr;  // reference GPU rule: strict (ml_nms cuda.cu:63-64)
-        if (redo) gq[e].x = ij.x | kPairRedo;
       }
     }
     if (REDO && !__any(hit)) continue;    // (wave-uniform; the common case of the second launch)
@@ -1473,7 +1614,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_finish_segments(const NmsCount
 __global__ __launch_bounds__(kThreads) void k_nms_greedy_direct(const PreBox* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ seg_start,
                                                                 const uint32_t* __restrict__ num_seg,
-                                                                const uint32_t* __restrict__ nblk,
+                                                                const unsigned long long* __restrict__ keyA_s,
+                                                                uint32_t ignore_key, int use_ignore,
                                                                 NmsCounters* __restrict__ C, unsigned long long cap,
                                                                 unsigned long long ecap, unsigned long long tile_cap,
                                                                 uint8_t* __restrict__ state, float thr) {
@@ -1484,7 +1626,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_greedy_direct(const PreBox* __
   const uint32_t S = *num_seg;
   for (uint32_t s = blockIdx.x; s < S; s += gridDim.x) {
     const uint32_t st = seg_start[s], ns = seg_start[s + 1] - st;
-    if (nblk[s] == 0) continue;                       // ignored rows: stay removed
+    if (use_ignore && (uint32_t)(keyA_s[st] >> 32) == ignore_key) continue;   // ignored rows: stay removed
     for (uint32_t i = threadIdx.x; i < ns; i += kThreads) state[st + i] = (uint8_t)kOpen;
     __syncthreads();
     uint32_t from = 0;
@@ -1532,53 +1674,84 @@ __global__ void k_nms_finish(const uint8_t* __restrict__ state, const uint8_t* _
   keep_orig[perm_seg[p]] = v == kKept ? 1 : 0;
 }
 
+// ---------------------------------------------------------------- side streams
+// Two side streams + fork / join events per (device, caller stream), created on first use.  box_iou_rotated runs the
+// zero-fill of a large output beside its pair finding; the NMS prelude runs its three independent sorts side by side.
+// Fork / join is the event pattern that stream capture understands.  Keyed by the caller's stream so that calls on
+// different streams (bench.py keeps three batches in flight) never queue behind each other's side work.
+struct SideSet {
+  int dev = -1;
+  hipStream_t caller = nullptr;
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+};
+std::mutex g_side_mutex;
+std::vector<SideSet*> g_sides;
+
+int side_set(hipStream_t caller, SideSet** out) {
+  int dev = 0;
+  S2A_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_side_mutex);
+  for (SideSet* e : g_sides)
+    if (e->dev == dev && e->caller == caller) { *out = e; return S2A_OK; }
+  SideSet* e = new SideSet();
+  e->dev = dev;
+  e->caller = caller;
+  // (default priority: a low-priority fill is starved by the persistent grids of the chain and then runs alone at the
+  // end, in front of the scatter -- 210 us instead of ~150)
+  for (int k = 0; k < 2; k++) {
+    S2A_HIP(hipStreamCreateWithFlags(&e->s[k], hipStreamNonBlocking));
+    S2A_HIP(hipEventCreateWithFlags(&e->join[k], hipEventDisableTiming));
+  }
+  S2A_HIP(hipEventCreateWithFlags(&e->fork, hipEventDisableTiming));
+  g_sides.push_back(e);
+  *out = e;
+  return S2A_OK;
+}
+
+inline bool stream_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 // ---------------------------------------------------------------- NMS workspace plan
 struct NmsPlan {
-  size_t rocprim_bytes;
+  size_t rocprim_bytes;           // scratch of ONE 64-bit-key pair sort (three of them: the sorts run side by side)
   unsigned long long queue_cap;   // pair list (cull survivors)
   unsigned long long edge_cap;    // edges (pairs above the threshold)
   unsigned long long tile_cap;    // tiles that pass the bounding-box filter
 };
 
 struct NmsBuffers {
-  unsigned long long *key1a, *key1b, *key3b;
-  int32_t *idxa, *perm_glob, *perm_seg;
-  uint32_t *key2a, *key2s, *head, *segidx1, *seg_start, *num_seg, *nblk, *perm_sp;
-  unsigned long long *tiles_per_seg, *tile_off;
+  unsigned long long *keyA, *keyA_s, *keyB, *keyB_s, *keyC, *keyC_s;
+  int32_t *idx, *perm_glob, *perm_seg, *perm_sp;
+  uint32_t *inv, *segidx1, *seg_start, *num_seg, *cnt, *cnt2, *cnt3, *lasthead;
+  uint4* bbox_part;
   NmsCounters* C;
   PreBox *sorted, *sp_box;
   uint2 *lo, *hi;
   TileRef* tiles;
   uint2 *gq, *edges;
-  uint8_t *keep_orig, *flag_glob, *state, *blocked;
+  uint8_t *keep_orig, *state, *blocked;
   uint32_t *seg_cnt, *seg_cur;
-  void* rp_temp;
+  void* rp_temp[3];
 };
 
 int nms_plan(int64_t n, int64_t max_seg_rows, NmsPlan* plan) {
   if (max_seg_rows <= 0 || max_seg_rows > n) max_seg_rows = n;
-  size_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
+  size_t a = 0;
   unsigned long long* k64 = nullptr;
   int32_t* i32 = nullptr;
-  uint32_t* u32 = nullptr;
-  uint8_t* u8 = nullptr;
-  int64_t* i64 = nullptr;
   size_t sz = (size_t)n;
-  hipStream_t s0 = nullptr;  // size queries only: nothing is launched
-  bool ok = rocprim::radix_sort_pairs(nullptr, a, k64, k64, i32, i32, sz, 0, 64, s0) == hipSuccess &&
-            rocprim::radix_sort_pairs(nullptr, b, u32, u32, i32, i32, sz, 0, 32, s0) == hipSuccess &&
-            rocprim::inclusive_scan(nullptr, c, u32, u32, sz, rocprim::plus<uint32_t>(), s0) == hipSuccess &&
-            rocprim::exclusive_scan(nullptr, d, k64, k64, 0ull, sz + 1, rocprim::plus<unsigned long long>(), s0) == hipSuccess &&
-            rocprim::select(nullptr, e, i32, u8, i64, i64, sz, s0) == hipSuccess &&
-            rocprim::radix_sort_pairs(nullptr, f, k64, k64, u32, u32, sz, 0, 64, s0) == hipSuccess;
+  hipStream_t s0 = nullptr;  // size query only: nothing is launched
+  bool ok = rocprim::radix_sort_pairs(nullptr, a, k64, k64, i32, i32, sz, 0, 64, s0) == hipSuccess;
   if (!ok) {
     // no device visible (size query on a CPU-only host): generous closed-form bound —
     // double-buffered keys+values plus histograms
     (void)hipGetLastError();
-    a = b = c = d = e = f = 0;
     a = sz * 32 + (8u << 20);
   }
-  plan->rocprim_bytes = std::max(std::max(std::max(a, b), std::max(c, d)), std::max(e, f));
+  plan->rocprim_bytes = a;
   // pair list: all same-segment pairs when small, else 16 Mi entries + 256/row
   unsigned long long all_pairs = (unsigned long long)n * (unsigned long long)max_seg_rows / 2 + 64;
   unsigned long long want = (16ull << 20) + 256ull * (unsigned long long)n;
@@ -1593,34 +1766,36 @@ int nms_plan(int64_t n, int64_t max_seg_rows, NmsPlan* plan) {
 // everything except the three lists (tiles, pairs, edges)
 void nms_carve_fixed(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
   size_t sz = (size_t)n;
-  B->key1a = cv.take<unsigned long long>(sz);
-  B->key1b = cv.take<unsigned long long>(sz);
-  B->key3b = cv.take<unsigned long long>(sz);
-  B->idxa = cv.take<int32_t>(sz);
+  B->keyA = cv.take<unsigned long long>(sz);
+  B->keyA_s = cv.take<unsigned long long>(sz);
+  B->keyB = cv.take<unsigned long long>(sz);
+  B->keyB_s = cv.take<unsigned long long>(sz);
+  B->keyC = cv.take<unsigned long long>(sz);
+  B->keyC_s = cv.take<unsigned long long>(sz);
+  B->idx = cv.take<int32_t>(sz);
   B->perm_glob = cv.take<int32_t>(sz);
   B->perm_seg = cv.take<int32_t>(sz);
-  B->perm_sp = cv.take<uint32_t>(sz);
-  B->key2a = cv.take<uint32_t>(sz);
-  B->key2s = cv.take<uint32_t>(sz);
-  B->head = cv.take<uint32_t>(sz);
+  B->perm_sp = cv.take<int32_t>(sz);
+  B->inv = cv.take<uint32_t>(sz);
   B->segidx1 = cv.take<uint32_t>(sz);
   B->seg_start = cv.take<uint32_t>(sz + 1);
   B->num_seg = cv.take<uint32_t>(4);
-  B->nblk = cv.take<uint32_t>(sz + 1);
-  B->tiles_per_seg = cv.take<unsigned long long>(sz + 1);
-  B->tile_off = cv.take<unsigned long long>(sz + 1);
+  B->cnt = cv.take<uint32_t>(kSegCountBlocks);
+  B->cnt2 = cv.take<uint32_t>(kSegCountBlocks);
+  B->cnt3 = cv.take<uint32_t>(kSegCountBlocks);
+  B->lasthead = cv.take<uint32_t>(kSegCountBlocks);
+  B->bbox_part = cv.take<uint4>(kPrepBlocks);
   B->C = cv.take<NmsCounters>(1);
   B->sorted = cv.take<PreBox>(sz);
   B->sp_box = cv.take<PreBox>(sz);
   B->lo = cv.take<uint2>(block_slots_for(sz));
   B->hi = cv.take<uint2>(block_slots_for(sz));
   B->keep_orig = cv.take<uint8_t>(sz);
-  B->flag_glob = cv.take<uint8_t>(sz);
   B->state = cv.take<uint8_t>(sz);
-  B->blocked = cv.take<uint8_t>(2 * sz);
+  B->blocked = cv.take<uint8_t>(2 * sz + 4);
   B->seg_cnt = cv.take<uint32_t>(sz + 2);
   B->seg_cur = cv.take<uint32_t>(sz + 2);
-  B->rp_temp = cv.take<char>(pl.rocprim_bytes);
+  for (int k = 0; k < 3; k++) B->rp_temp[k] = cv.take<char>(pl.rocprim_bytes);
 }
 
 void nms_carve(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
@@ -1632,46 +1807,18 @@ void nms_carve(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
 
 inline unsigned grid_for(int64_t n, int threads = 256) { return (unsigned)((n + threads - 1) / threads); }
 
-inline unsigned bits_for(uint64_t v) {
-  unsigned b = 1;
-  while (b < 32 && (1ull << b) <= v) b++;
-  return b;
-}
+// rows per block of the block-count kernels: 256 up to 1 Mi rows, then whatever keeps the block count <= kSegCountBlocks
+inline int count_rows(int64_t n) { return 256 * (int)((n + 256ll * kSegCountBlocks - 1) / (256ll * kSegCountBlocks)); }
 
-// shared core: everything up to keep_orig[]
+// shared core: everything up to keep_orig[].  On return the caller's stream has the (group, score) order of the OUTPUT
+// in B.perm_glob / B.keyC_s (joined from its side stream).
 int nms_core(const float* dets, const float* scores, const float* labels, const int32_t* seg_ids,
              const int32_t* group_ids, int64_t n, uint32_t num_segments_hint, uint32_t num_groups,
              float thr, const NmsPlan& pl, NmsBuffers& B, hipStream_t st) {
   size_t sz = (size_t)n;
-  size_t rpb = pl.rocprim_bytes;
   const unsigned g = grid_for(n);
-  k_nms_keys<<<g, 256, 0, st>>>(scores, group_ids, seg_ids, num_groups, n, B.key1a, B.idxa);
-  unsigned gbits = group_ids ? bits_for(num_groups) : 0;  // value num_groups = ignored rows
   const uint32_t ignore_key = num_segments_hint;           // one past the last real segment
-  S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp, rpb, B.key1a, B.key1b, B.idxa, B.perm_glob, sz, 0,
-                                    32 + gbits, st));
-  k_nms_segkeys<<<g, 256, 0, st>>>(labels, seg_ids, B.perm_glob, ignore_key, n, B.key2a);
-  unsigned sbits = seg_ids ? bits_for(num_segments_hint) : 32;
-  if (labels || seg_ids) {
-    rpb = pl.rocprim_bytes;
-    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp, rpb, B.key2a, B.key2s, B.perm_glob, B.perm_seg, sz,
-                                      0, sbits, st));
-  } else {
-    S2A_HIP(hipMemcpyAsync(B.key2s, B.key2a, sz * 4, hipMemcpyDeviceToDevice, st));
-    S2A_HIP(hipMemcpyAsync(B.perm_seg, B.perm_glob, sz * 4, hipMemcpyDeviceToDevice, st));
-  }
-  k_nms_heads<<<g, 256, 0, st>>>(B.key2s, n, B.head);
-  rpb = pl.rocprim_bytes;
-  S2A_HIP(rocprim::inclusive_scan(B.rp_temp, rpb, B.head, B.segidx1, sz, rocprim::plus<uint32_t>(), st));
-  k_nms_seg_start<<<g, 256, 0, st>>>(B.head, B.segidx1, n, B.seg_start, B.num_seg);
-  k_nms_seg_sizes<<<grid_for(n + 1), 256, 0, st>>>(B.seg_start, B.num_seg, B.key2s, ignore_key,
-                                                   seg_ids != nullptr, n, B.tiles_per_seg, B.nblk);
-  rpb = pl.rocprim_bytes;
-  S2A_HIP(rocprim::exclusive_scan(B.rp_temp, rpb, B.tiles_per_seg, B.tile_off, 0ull, sz + 1,
-                                  rocprim::plus<unsigned long long>(), st));
-  // (zeroed by kernels, not hipMemsetAsync: memset nodes of a captured graph were not replayed correctly from the second
-  // launch on with ROCm 7.2 -- counters kept their old values; tests/test_gpu_e2e.py::test_detect_hip_graph_replay_equals_eager)
-  const size_t slots = block_slots_for(sz);
+  const int use_ignore = seg_ids != nullptr;
   // The Morton order + bounding-box tile filter pays when segments are big (thousands of rows: most tiles of a segment
   // are far apart); for many small segments (a detector batch: ~300 rows per image and class) it is a third sort and
   // two passes of pure overhead, every tile is tested anyway -> blocks in score order, no filter
@@ -1679,33 +1826,95 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   if (const char* e = std::getenv("S2A_NMS_SPATIAL")) spatial = e[0] == '1';          // A/B and test switch
   const char* e_lds = std::getenv("S2A_NMS_FINISH_GLOBAL");                          // test switch: finish on the global arrays
   const int force_global = e_lds && e_lds[0] == '1';
+  // one segment and no groups (plain nms_rotated): order A is the output order
+  const bool need_c = labels != nullptr || seg_ids != nullptr || group_ids != nullptr;
   uint2* lo = spatial ? B.lo : nullptr;
-  k_nms_init_slots<<<grid_for((int64_t)std::max(spatial ? slots : (size_t)0, 2 * sz)), 256, 0, st>>>(lo, B.hi, slots, B.C, B.blocked, 2 * sz,
-                                                                                B.seg_cnt, sz + 2);
-  k_nms_pos_meta<<<g, 256, 0, st>>>(dets, B.perm_seg, B.segidx1, B.nblk, n, B.sorted, B.state, B.C, spatial ? nullptr : B.sp_box);
-  if (spatial) {
-    // spatial order inside every segment (key1a and idxa are free again)
-    uint32_t* val3a = reinterpret_cast<uint32_t*>(B.idxa);
-    k_nms_spkeys<<<g, 256, 0, st>>>(B.sorted, B.C, n, B.key1a, val3a);
-    const unsigned segbits = seg_ids ? bits_for((uint64_t)num_segments_hint + 1) : (labels ? bits_for((uint64_t)n) : 1);
-    rpb = pl.rocprim_bytes;
-    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp, rpb, B.key1a, B.key3b, val3a, B.perm_sp, sz, 0, 20 + segbits, st));
-    k_nms_spgather<<<g, 256, 0, st>>>(B.sorted, B.perm_sp, B.seg_start, n, B.sp_box, B.lo, B.hi);
+  const size_t slots = block_slots_for(sz);
+  const unsigned gp = (unsigned)std::min<size_t>(kPrepBlocks, std::max<size_t>(grid_for(n), 1));
+  const int rows = count_rows(n);
+  const int nb = (int)((n + rows - 1) / rows);
+  k_nms_prep<<<gp, 256, 0, st>>>(dets, scores, labels, seg_ids, group_ids, num_groups, ignore_key, n, B.keyA,
+                                 need_c ? B.keyC : nullptr, B.idx, B.bbox_part, B.C,
+                                 reinterpret_cast<uint32_t*>(B.blocked), (2 * sz + 3) / 4, B.seg_cnt, sz + 2, lo, B.hi, slots);
+  // A call is as long as its chain of LAUNCHES while the kernels are short (the host needs ~5 us per launch, a rocPRIM
+  // sort is nine of them): only what the cull needs is enqueued in front of it -- for big segments the spatial order B
+  // alone -- and the other sorts go to side streams AFTER the cull's launch, where the host has 300 us to spare:
+  //   spatial:      prep, B-keys, sort B, seg_count, sp_meta, tile filter, cull | side 0: sort A, seg_count, pos_meta
+  //                                                                              | side 1: sort C
+  //   score blocks: prep, sort A, seg_count, pos_meta, tile filter, cull        | side 1: sort C
+  // Under stream capture everything stays on the caller's stream (S2A_NMS_FORK=0 forces that form: A/B and tests).
+  bool fork = !stream_capturing(st);
+  if (const char* e = std::getenv("S2A_NMS_FORK")) fork = e[0] == '1';
+  SideSet* ss = nullptr;
+  if (fork && (spatial || need_c)) {
+    int rc = side_set(st, &ss);
+    if (rc != S2A_OK) return rc;
+    S2A_HIP(hipEventRecord(ss->fork, st));
   }
-  k_nms_tile_filter<<<kPersistentGrid, kThreads, 0, st>>>(B.seg_start, B.num_seg, B.tile_off, lo, B.hi, B.tiles, B.C,
-                                                          pl.tile_cap);
+  auto chain_a = [&](hipStream_t q, bool segs) -> int {      // score order: sorted[], inv[], state[] (+ segments)
+    size_t rpb = pl.rocprim_bytes;
+    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[0], rpb, B.keyA, B.keyA_s, B.idx, B.perm_seg, sz, 0, 64, q));
+    k_nms_seg_count<<<nb, 256, 0, q>>>(B.keyA_s, 32, n, rows, B.cnt, nullptr);
+    k_nms_pos_meta<<<nb, 256, 0, q>>>(dets, B.keyA_s, B.perm_seg, B.cnt, nb, rows, n, ignore_key, use_ignore, B.segidx1,
+                                      segs ? B.seg_start : nullptr, B.num_seg, B.sorted, B.state, B.inv);
+    return S2A_OK;
+  };
+  auto sort_c = [&](hipStream_t q) -> int {
+    size_t rpb = pl.rocprim_bytes;
+    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[2], rpb, B.keyC, B.keyC_s, B.idx, B.perm_glob, sz, 0, 64, q));
+    return S2A_OK;
+  };
+  const PreBox* cull_boxes = B.sorted;           // blocks in score order: the cull walks sorted[] itself
+  if (spatial) {
+    k_nms_spkeys<<<g, 256, 0, st>>>(dets, B.keyA, B.bbox_part, (int)gp, n, B.keyB);
+    size_t rpb = pl.rocprim_bytes;
+    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[1], rpb, B.keyB, B.keyB_s, B.idx, B.perm_sp, sz, 0, 52, st));
+    k_nms_seg_count<<<nb, 256, 0, st>>>(B.keyB_s, 20, n, rows, B.cnt2, B.lasthead);
+    k_nms_sp_meta<<<nb, 256, 0, st>>>(dets, B.keyB_s, B.perm_sp, B.cnt2, B.lasthead, nb, rows, n, B.segidx1, B.seg_start,
+                                      B.num_seg, B.sp_box, B.lo, B.hi);
+    k_nms_tile_filter<<<g, kThreads, 0, st>>>(B.segidx1, B.seg_start, B.keyB_s, 20, ignore_key, use_ignore, n, lo, B.hi,
+                                              B.tiles, B.C, pl.tile_cap);
+    cull_boxes = B.sp_box;
+  } else {
+    int rc = chain_a(st, true);
+    if (rc != S2A_OK) return rc;
+    k_nms_tile_filter<<<g, kThreads, 0, st>>>(B.segidx1, B.seg_start, B.keyA_s, 32, ignore_key, use_ignore, n, nullptr, B.hi,
+                                              B.tiles, B.C, pl.tile_cap);
+  }
   {
     // one wave per tile pays off once there are tiles for every wave (200 k rows: 392 -> 335 us); with few tiles the four
     // waves per tile of k_nms_cull finish a tile sooner (5 k / 20 k rows: 35 us less).  S2A_NMS_CULL_LANES=0|1 forces.
     const char* nl = getenv("S2A_NMS_CULL_LANES");
     const bool lanes = nl && (nl[0] == '0' || nl[0] == '1') ? nl[0] == '1' : n >= kNmsLanesRows;
     if (!lanes)
-      k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(B.sp_box, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+      k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(cull_boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
     else
-      k_nms_cull_lanes<<<kPersistentGrid, kThreads, 0, st>>>(B.sp_box, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+      k_nms_cull_lanes<<<kPersistentGrid, kThreads, 0, st>>>(cull_boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
   }
-  k_nms_heavy<false><<<kHeavyGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
-  k_nms_heavy<true><<<kPersistentGrid, kThreads, 0, st>>>(B.sorted, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
+  // behind the cull's launch: the score order (spatial path) and the output order
+  if (spatial) {
+    hipStream_t q = ss ? ss->s[0] : st;
+    if (ss) S2A_HIP(hipStreamWaitEvent(q, ss->fork, 0));
+    int rc = chain_a(q, false);
+    if (rc != S2A_OK) return rc;
+    if (ss) {
+      S2A_HIP(hipEventRecord(ss->join[0], q));
+      S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
+    }
+  }
+  if (need_c) {
+    hipStream_t q = ss ? ss->s[1] : st;
+    if (ss) S2A_HIP(hipStreamWaitEvent(q, ss->fork, 0));
+    int rc = sort_c(q);
+    if (rc != S2A_OK) return rc;
+    if (ss) S2A_HIP(hipEventRecord(ss->join[1], q));
+  } else {
+    B.perm_glob = B.perm_seg;
+    B.keyC_s = B.keyA_s;
+  }
+  const int32_t* rank_perm = spatial ? B.perm_sp : nullptr;
+  k_nms_heavy<false><<<kHeavyGrid, kThreads, 0, st>>>(cull_boxes, rank_perm, B.inv, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
+  k_nms_heavy<true><<<kPersistentGrid, kThreads, 0, st>>>(cull_boxes, rank_perm, B.inv, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
   // the pair list is dead after the dense pass: its memory takes the alive-edge list of the last launched round
   for (int r = 1; r <= kNmsRounds; r++)
     k_nms_round<<<256, kThreads, 0, st>>>(B.edges, B.C, pl.edge_cap, B.state, B.blocked, n, r,
@@ -1718,9 +1927,10 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   k_nms_alive_scatter<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, B.sorted, B.seg_cur, B.edges);
   k_nms_finish_segments<<<512, kThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.seg_cnt, B.edges, B.state, B.blocked, n,
                                                   force_global);
-  k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.nblk, B.C, pl.queue_cap, pl.edge_cap,
-                                                pl.tile_cap, B.state, thr);
+  k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.keyA_s, ignore_key, use_ignore, B.C,
+                                                pl.queue_cap, pl.edge_cap, pl.tile_cap, B.state, thr);
   k_nms_finish<<<g, 256, 0, st>>>(B.state, B.blocked, B.C, B.perm_seg, n, B.keep_orig);
+  if (ss && need_c) S2A_HIP(hipStreamWaitEvent(st, ss->join[1], 0));
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -1740,9 +1950,8 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
                hipStream_t st) {
   S2A_CHECK_ARG(n >= 0 && n < (1ll << 31), "nms_rotated: n out of range");
   S2A_CHECK_ARG(count_dev != nullptr, "nms_rotated: count_dev must not be NULL");
-  S2A_REFUSE_CAPTURE(st, "nms_rotated");
   if (n == 0) {
-    S2A_HIP(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
+    fill_u32(reinterpret_cast<uint32_t*>(count_dev), 0u, 2, st);
     if (host_count) *host_count = 0;
     return S2A_OK;
   }
@@ -1758,9 +1967,12 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
   }
   int rc = nms_core(dets, scores, labels, nullptr, nullptr, n, 0, 1, thr, pl, B, st);
   if (rc != S2A_OK) return rc;
-  k_nms_flags_glob<<<grid_for(n), 256, 0, st>>>(B.keep_orig, B.perm_glob, n, B.flag_glob);
-  size_t rpb = pl.rocprim_bytes;
-  S2A_HIP(rocprim::select(B.rp_temp, rpb, B.perm_glob, B.flag_glob, keep, count_dev, (size_t)n, st));
+  {
+    const int rows = count_rows(n);
+    const int nb = (int)((n + rows - 1) / rows);
+    k_nms_keep_count<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3);
+    k_nms_keep_write<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3, nb, keep, count_dev);
+  }
   S2A_LAUNCH_CHECK();
   if (host_count) {
     S2A_HIP(hipMemcpyAsync(host_count, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -1799,32 +2011,6 @@ extern "C" size_t s2a_box_iou_rotated_workspace_bytes(int64_t n, int64_t m) {
 
 namespace s2a {
 namespace {
-// One side stream + fork / join events per device, created on first use: the zero-fill of a large IoU matrix runs there
-// while the caller's stream finds and evaluates the overlapping pairs.  The fork / join is the event pattern that stream
-// capture understands, so a captured call replays with the same concurrency.  The mutex covers the enqueue sequence
-// (events are re-recorded per call).
-struct SideStream {
-  hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-};
-std::mutex g_side_mutex;
-SideStream g_side[64];
-
-int side_stream(SideStream** out) {
-  int dev = 0;
-  S2A_HIP(hipGetDevice(&dev));
-  S2A_CHECK_ARG(dev >= 0 && dev < 64, "device index out of range");
-  SideStream& ss = g_side[dev];
-  if (!ss.s) {
-    // (default priority: a low-priority fill is starved by the persistent grids of the chain and then runs alone at the
-    // end, in front of the scatter -- 210 us instead of ~150)
-    S2A_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
-    S2A_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
-    S2A_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
-  }
-  *out = &ss;
-  return S2A_OK;
-}
 constexpr unsigned long long kIouForkBytes = 8ull << 20;   // smaller outputs: one stream, zero-fill fused into the cull
 }  // namespace
 }  // namespace s2a
@@ -1863,14 +2049,14 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
   const bool big = (unsigned long long)n * (unsigned long long)m * 4ull >= kIouForkBytes;
   const char* ef = getenv("S2A_IOU_FORK");                 // A/B: 0 = never fork, 1 = always
   const bool fork = ef && (ef[0] == '0' || ef[0] == '1') ? ef[0] == '1' : big;
-  SideStream* ss = nullptr;
-  std::unique_lock<std::mutex> lock(g_side_mutex, std::defer_lock);
+  SideSet* ss = nullptr;
+  hipStream_t side = nullptr;
   if (fork) {
-    lock.lock();
-    int rc = side_stream(&ss);
+    int rc = side_set(st, &ss);
     if (rc != S2A_OK) return rc;
+    side = ss->s[0];
     S2A_HIP(hipEventRecord(ss->fork, st));
-    S2A_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+    S2A_HIP(hipStreamWaitEvent(side, ss->fork, 0));
     // The fill is PACED (s_sleep between the stores of a wave): flat out it finishes 400 MB in 50-100 us but saturates the
     // memory system, and every dependent read of the kernels beside it then takes ~10 us -- the pair finder stretched
     // from 59 to 105-125 us whatever its design and whatever the fill's workgroup count (scripts/iou_fill_scan.sh).  At 512
@@ -1881,14 +2067,14 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     if (const char* fp = getenv("S2A_IOU_FILL_PACE")) pace = atoi(fp);
     const unsigned long long nm = (unsigned long long)n * (unsigned long long)m;
     if (fill_wgs > 0) {
-      if (pace >= 12) k_fill_zero<12><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
-      else if (pace >= 8) k_fill_zero<8><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
-      else if (pace >= 6) k_fill_zero<6><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
-      else if (pace >= 4) k_fill_zero<4><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
-      else if (pace >= 2) k_fill_zero<2><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
-      else k_fill_zero<0><<<fill_wgs, 256, 0, ss->s>>>(ious, nm);
+      if (pace >= 12) k_fill_zero<12><<<fill_wgs, 256, 0, side>>>(ious, nm);
+      else if (pace >= 8) k_fill_zero<8><<<fill_wgs, 256, 0, side>>>(ious, nm);
+      else if (pace >= 6) k_fill_zero<6><<<fill_wgs, 256, 0, side>>>(ious, nm);
+      else if (pace >= 4) k_fill_zero<4><<<fill_wgs, 256, 0, side>>>(ious, nm);
+      else if (pace >= 2) k_fill_zero<2><<<fill_wgs, 256, 0, side>>>(ious, nm);
+      else k_fill_zero<0><<<fill_wgs, 256, 0, side>>>(ious, nm);
     }
-    S2A_HIP(hipEventRecord(ss->join, ss->s));
+    S2A_HIP(hipEventRecord(ss->join[0], side));
   }
   k_prep_boxes2<<<(unsigned)((std::max<int64_t>(n + m, 512) + 255) / 256), 256, 0, st>>>(boxes1, n, P1, boxes2, m, P2, counters, 512);
   const char* ec = getenv("S2A_IOU_CULL_COLS");            // A/B: round 1's column-major cull beside the forked fill
@@ -1909,7 +2095,7 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     else
       k_iou_cull<true><<<grid_c, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap);
     k_iou_heavy<<<kHeavyGrid, kThreads, 0, st>>>(P1, P2, r0, gq, counters + c, cap, vals);
-    if (fork && c == 0) S2A_HIP(hipStreamWaitEvent(st, ss->join, 0));
+    if (fork && c == 0) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
     k_iou_scatter<<<kPersistentGrid, kThreads, 0, st>>>(P1, P2, r0, r1, m, ious, gq, counters + c, cap, vals);
   }
   S2A_LAUNCH_CHECK();
@@ -2270,7 +2456,7 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
   Carver cv(workspace, workspace_bytes);
   NmsBuffers B;
   nms_carve_fixed(cv, n, pl, &B);
-  if (cv.off + (48u << 10) > workspace_bytes || !B.rp_temp) {
+  if (cv.off + (48u << 10) > workspace_bytes || !B.rp_temp[2]) {
     set_error("nms_rotated_segmented: workspace too small (%zu bytes)", workspace_bytes);
     return S2A_EWORKSPACE;
   }
@@ -2293,7 +2479,7 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
   if (keep_flags)
     S2A_HIP(hipMemcpyAsync(keep_flags, B.keep_orig, (size_t)n, hipMemcpyDeviceToDevice, st));
   if (keep) {
-    k_nms_group_compact<<<(unsigned)num_groups, 1024, 0, st>>>(B.key1b, B.perm_glob, B.keep_orig, n,
+    k_nms_group_compact<<<(unsigned)num_groups, 1024, 0, st>>>(B.keyC_s, B.perm_glob, B.keep_orig, n,
                                                                max_per_group, keep, group_counts);
   }
   S2A_LAUNCH_CHECK();

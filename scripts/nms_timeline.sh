@@ -16,5 +16,5 @@ torch.cuda.synchronize()
 PY
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O -o run -- python /tmp/nms_once.py > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
 T=$(ls $O/*kernel_trace.csv $O/*/*kernel_trace.csv 2>/dev/null | head -1)
-python $R/scripts/timeline.py $T k_nms_keys 5 1
+python $R/scripts/timeline.py $T k_nms_prep 5 1
 rm -f $T
