@@ -241,6 +241,28 @@ __device__ __forceinline__ void circle_bits(float ax, float ay, float ar, float 
     bits |= (dx * dx + dy * dy > R * R ? 0u : 1u) << (j - J0);
   }
 }
+// NMS first stage: circle test AND area-ratio test (|la - lc| <= lmax; NaN log-areas never drop a pair), see
+// k_nms_cull_lanes.  The column data ROTATES through the lanes (v_mov_b32_dpp wave_ror:1, one lane per step) instead of
+// being broadcast through v_readlane: the readlane form needs four SGPRs per column -- 128 live ones per half tile, which
+// hipcc spilled to VGPR lanes (250 v_writelane / v_readlane per tile) and padded with s_nop for the SGPR read hazard;
+// 22 vector instructions per test, 15 this way.  At step k a lane holds the column of lane (lane + k * dir) & 63, with
+// dir found by rotating the lane index once (no assumption about the direction of the rotation).
+__device__ __forceinline__ float dpp_ror1(float v) {
+  // (bound_ctrl set: every lane has a source in a full-wave rotation, and the compiler then needs no zero-initialised
+  // destination -- with `old = 0` it emitted a v_mov 0 in front of every rotation)
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, true));
+}
+template <int STEPS>
+__device__ __forceinline__ void nms_stage1_rot(float ax, float ay, float ar, float la, float& rx, float& ry, float& rr,
+                                               float& rl, float lmax, unsigned& bits) {
+#pragma unroll 4
+  for (int k = 0; k < STEPS; k++) {
+    const float dx = ax - rx, dy = ay - ry, R = ar + rr, dl = la - rl;
+    const bool drop = (__builtin_fmaf(dy, dy, dx * dx) > R * R) || (fabsf(dl) > lmax);
+    bits |= (drop ? 0u : 1u) << k;
+    rx = dpp_ror1(rx); ry = dpp_ror1(ry); rr = dpp_ror1(rr); rl = dpp_ror1(rl);
+  }
+}
 __global__ __launch_bounds__(kThreads) void k_iou_cull_lanes(const PreBox* __restrict__ P1, const PreBox* __restrict__ P2,
                                                              int64_t row0, int64_t row1, int64_t m, int cols_per_wg,
                                                              uint2* __restrict__ gq,
@@ -437,7 +459,7 @@ struct NmsCounters {
   unsigned long long edges;      // pairs with IoU > thr (true total)
   unsigned long long tiles;      // tiles that passed the filter (true total)
   unsigned long long alive_list; // edges handed to the clean-up kernel
-  unsigned long long tile_cursor;// next unclaimed entry of the tile list (k_nms_cull_lanes takes batches of tiles)
+  unsigned long long tile_cursor[8 * 16];   // next unclaimed tile of each eighth of the tile list, a cache line apart
   uint32_t status;               // bit 0: a list overflowed -> direct greedy fallback ran
   uint32_t alive[16];            // edges still between two unsettled rows after round r
 };
@@ -491,7 +513,7 @@ __global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ dets
                                                   uint32_t* __restrict__ seg_cnt, size_t nseg_cnt,
                                                   uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots) {
   const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i0 < sizeof(NmsCounters) / 4) reinterpret_cast<uint32_t*>(C)[i0] = 0u;
+  for (size_t i = i0; i < sizeof(NmsCounters) / 4; i += stride) reinterpret_cast<uint32_t*>(C)[i] = 0u;
   for (size_t i = i0; i < nblocked32; i += stride) blocked32[i] = 0u;
   for (size_t i = i0; i < nseg_cnt; i += stride) seg_cnt[i] = 0u;
   if (lo)
@@ -853,7 +875,7 @@ __global__ __launch_bounds__(256) void k_nms_pos_meta(const float* __restrict__ 
                                                       uint32_t ignore_key, int use_ignore,
                                                       uint32_t* __restrict__ segidx1, uint32_t* __restrict__ seg_start,
                                                       uint32_t* __restrict__ num_seg, PreBox* __restrict__ sorted,
-                                                      uint8_t* __restrict__ state, uint32_t* __restrict__ inv) {
+                                                      uint8_t* __restrict__ state, uint8_t* __restrict__ state_fb) {
   unsigned before, total;
   count_prefix(cnt, nb, blockIdx.x, before, total);
   if (seg_start && blockIdx.x == 0 && threadIdx.x == 0) { *num_seg = total; seg_start[total] = (uint32_t)n; }
@@ -879,8 +901,9 @@ __global__ __launch_bounds__(256) void k_nms_pos_meta(const float* __restrict__ 
       const float* b = dets5 + 5 * (int64_t)o;
       PreBox pb = make_prebox(b[0], b[1], b[2], b[3], b[4], __uint_as_float(s));
       sorted[p] = pb;
-      inv[o] = (uint32_t)p;
-      state[p] = (use_ignore && sk == ignore_key) ? 2 : 0;
+      const uint8_t st0 = (use_ignore && sk == ignore_key) ? 2 : 0;
+      if (state) state[p] = st0;
+      state_fb[p] = st0;
     }
     running += tot;
   }
@@ -894,17 +917,20 @@ __device__ __forceinline__ uint32_t block_slot(uint32_t seg_start_s, uint32_t s,
 __host__ __device__ inline size_t block_slots_for(size_t n) { return n / 64 + n + 2; }
 
 // rows in SPATIAL order (sort B: segment | Morton) -- ONE pass behind that sort, on the critical path of the call: segment
-// index of every row, seg_start[], num_seg (prefix of the block counts + in-block scan), the row's pre-processed box,
-// and the bounding box of every 64-row block of the inflated circumscribed circles (atomics on order-preserving integers;
+// index of every row, seg_start[], num_seg (prefix of the block counts + in-block scan), the row's pre-processed box, its
+// rank key and initial state, and the bounding box of every 64-row block of the inflated circumscribed circles (atomics on order-preserving integers;
 // one per wave and slot in the common case).  The start of a row's segment -- needed for its block slot -- is the running
 // maximum of the head positions: carried in from the blocks before (lasthead[]) and scanned inside the block.
 __global__ __launch_bounds__(256) void k_nms_sp_meta(const float* __restrict__ dets5,
                                                      const unsigned long long* __restrict__ keyB_s,
                                                      const int32_t* __restrict__ perm_sp,
                                                      const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lasthead,
-                                                     int nb, int rows, int64_t n, uint32_t* __restrict__ segidxq,
+                                                     int nb, int rows, int64_t n, const float* __restrict__ scores,
+                                                     uint32_t ignore_key, int use_ignore,
+                                                     uint32_t* __restrict__ segidxq,
                                                      uint32_t* __restrict__ seg_start, uint32_t* __restrict__ num_seg,
-                                                     PreBox* __restrict__ sp_box, uint2* __restrict__ lo,
+                                                     PreBox* __restrict__ sp_box, unsigned long long* __restrict__ rankkey,
+                                                     uint8_t* __restrict__ state, uint2* __restrict__ lo,
                                                      uint2* __restrict__ hi) {
   unsigned before, total;
   count_prefix(cnt, nb, blockIdx.x, before, total);
@@ -947,9 +973,14 @@ __global__ __launch_bounds__(256) void k_nms_sp_meta(const float* __restrict__ d
       const uint32_t sidx = running + incl - 1, st = m - 1u;
       segidxq[q] = sidx + 1;
       if (head) seg_start[sidx] = (uint32_t)q;
-      const float* d = dets5 + 5 * (int64_t)perm_sp[q];
-      const PreBox b = make_prebox(d[0], d[1], d[2], d[3], d[4], __uint_as_float((uint32_t)q));
+      const int32_t o = perm_sp[q];
+      const float* d = dets5 + 5 * (int64_t)o;
+      const PreBox b = make_prebox(d[0], d[1], d[2], d[3], d[4], __uint_as_float(sidx));   // label slot = segment index
       sp_box[q] = b;
+      // the greedy order of two rows = the order of these keys (descending score, then ascending original row: exactly
+      // the order of sort A) -- everything behind the cull works on spatial positions and never needs that sort
+      rankkey[q] = ((unsigned long long)(~float_sortable(scores[o])) << 32) | (uint32_t)o;
+      state[q] = (use_ignore && (uint32_t)(keyB_s[q] >> 20) == ignore_key) ? 2 : 0;
       slot = block_slot(st, sidx, ((uint32_t)q - st) >> 6);
       // margin of surely_disjoint per box (sum of two of these >= its (ar + br) * 1.002 + 1e-3), plus 1e-3 for the
       // rounding of x -+ r at chip-sized coordinates; non-finite boxes overlap everything (evaluated, never culled)
@@ -1151,10 +1182,18 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull(const PreBox* __restrict_
 // reserves its list space with ONE LDS atomic per half tile and writes its survivors; the dense stage takes 64
 // survivors at a time, both boxes through ds_bpermute from the lanes that own them, nms_pair_skippable, ballot-compacted
 // into a per-wave stage of pairs; one global atomic per flush and one per workgroup at the end.
+#ifdef S2A_MEASURE
+__device__ unsigned long long g_cull_dbg[8];   // measurement builds: cycles per phase summed over waves (+ tile / wave counts)
+#define CULL_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define CULL_ACC(acc, t1, t0) (acc) += (t1) - (t0)
+#else
+#define CULL_T(var) do {} while (0)
+#define CULL_ACC(acc, t1, t0) do {} while (0)
+#endif
 constexpr int kNlList = 64 * 32;              // circle-test survivors of half a tile, u16 = row << 6 | column
 constexpr int kNlStage = 512;                 // per-wave staged pairs
 constexpr int64_t kNmsLanesRows = 49152;      // rows from which the one-wave-per-tile cull is the default
-constexpr int kNlBatch = 8;                   // tiles a wave claims per visit to the cursor
+constexpr int kNlBatch = 4;                   // tiles a wave claims per visit to the cursor
 __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __restrict__ sp_box,
                                                              const TileRef* __restrict__ tiles,
                                                              NmsCounters* __restrict__ C, unsigned long long tile_cap,
@@ -1186,50 +1225,123 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
     if (il < t.ns) R = sp_box[t.seg_start + il];
     if (jl < t.ns) Cc = sp_box[t.seg_start + jl];
   };
-  // Tiles differ by an order of magnitude in what survives their circle tests, and a static split of the list left half
-  // of the waves idle in the second half of the launch (8.2 of 16 waves per CU on average, profiles/r02_nms_200k_pmc.txt):
-  // every wave now CLAIMS batches of kNlBatch tiles from a device-wide cursor until the list is empty.
-  for (;;) {
-    unsigned long long e = 0;
-    if (lane == 0) e = atomicAdd(&C->tile_cursor, (unsigned long long)kNlBatch);
-    e = ((unsigned long long)(uint32_t)__shfl((int)(e >> 32), 0) << 32) | (uint32_t)__shfl((int)(e & 0xffffffffu), 0);
-    if (e >= L) break;                           // wave-uniform
-    const unsigned long long eend = min(L, e + (unsigned long long)kNlBatch);
-    TileRef t = tiles[e];
-    PreBox A, Cb;
-    load(t, A, Cb);
-    for (; e < eend; e++) {
-      TileRef tn = t;
-      PreBox An = {}, Cn = {};
-      if (e + 1 < eend) {                        // in flight under this tile's tests
-        tn = tiles[e + 1];
-        load(tn, An, Cn);
+  // First stage = circumscribed circles AND the area ratio: IoU <= min(area) / max(area), so a pair whose areas differ by
+  // more than 1 / (0.99 thr) can never suppress (the same 1 % margin and the same sanity conditions as the bound in
+  // nms_pair_skippable, which contains this one) -- |log2 area_a - log2 area_c| > -log2(0.99 thr), one subtraction and one
+  // compare per pair with the column's log-area rotating along; a box outside the sanity conditions carries NaN and
+  // is never dropped.  On BASELINE config 5 it drops 58 % of the circle-test survivors before the 130-instruction second stage.
+  const float t99 = 0.99f * thr;
+  const float Lmax = thr > 0.05f ? -__log2f(t99) : __builtin_inff();
+  auto log_area = [](const PreBox& b) {
+    const float aw = fabsf(b.w), ah = fabsf(b.h), area = b.w * b.h;
+    const bool sane = area > 0.f && fminf(aw, ah) >= 0.05f * fmaxf(aw, ah);
+    return sane ? __log2f(area) : __builtin_nanf("");
+  };
+  auto bcast64 = [](unsigned long long v) {
+    return ((unsigned long long)(uint32_t)__shfl((int)(v >> 32), 0) << 32) | (uint32_t)__shfl((int)(v & 0xffffffffu), 0);
+  };
+  // direction of the lane rotation: the lane whose value arrives here after one step, relative to this lane (1 or 63)
+  const unsigned dir = ((unsigned)__builtin_amdgcn_mov_dpp(lane, 0x13C, 0xf, 0xf, true) - (unsigned)lane) & 63u;
+  unsigned long long a_claim = 0, a_s1 = 0, a_list = 0, a_s2 = 0, a_tiles = 0;
+  (void)a_claim; (void)a_s1; (void)a_list; (void)a_s2; (void)a_tiles;
+  CULL_T(t_begin);
+  // ---- the wave's stream of tiles.  The list is cut into 8 regions with a cursor each (own cache line): a wave starts on
+  // region blockIdx & 7 (the blocks that share an XCD under round-robin placement -- a speed heuristic, nothing depends on
+  // it) and moves on to the next region when one is empty, so a claim competes with an eighth of the waves.  (One cursor
+  // for all 4 k waves: 16 k atomics on one word = 180 us of serialised round trips, every claim queued for microseconds.)
+  // Claims are issued a batch ahead, tile references two tiles ahead, boxes one tile ahead: an in-order wave blocks at
+  // the FIRST use of a load, so each dependent step of the chain (claim -> TileRef -> boxes) gets a whole tile of work
+  // to hide behind.
+  unsigned cs = blockIdx.x & 7u, tries = 0;      // current region, regions found empty so far
+  unsigned long long idx = 0, bend = 0;          // current batch [idx, bend): idx is the tile last handed out
+  auto region_lo = [&](unsigned k) { return L * k / 8ull; };
+  auto claim = [&](unsigned k) {
+    unsigned long long v = 0;
+    if (lane == 0) v = atomicAdd(&C->tile_cursor[k * 16], (unsigned long long)kNlBatch);
+    return v;
+  };
+  unsigned long long pend = claim(cs);
+  constexpr unsigned long long kDone = ~0ull;
+  auto next_tile = [&]() -> unsigned long long {
+    if (idx + 1 < bend) return ++idx;
+    for (;;) {                                   // (wave-uniform: every value comes from a broadcast)
+      if (tries >= 8u) return kDone;
+      const unsigned long long v = bcast64(pend), lo = region_lo(cs), hi = region_lo(cs + 1);
+      if (lo + v < hi) {
+        idx = lo + v;
+        bend = min(hi, idx + (unsigned long long)kNlBatch);
+        pend = claim(cs);
+        return idx;
       }
+      cs = (cs + 1u) & 7u;
+      tries++;
+      if (tries < 8u) pend = claim(cs);
+    }
+  };
+  unsigned long long i0 = next_tile();
+  TileRef t = {}, t1 = {};
+  PreBox A = {}, Cb = {};
+  if (i0 != kDone) { t = tiles[i0]; load(t, A, Cb); }
+  unsigned long long i1 = i0 != kDone ? next_tile() : kDone;
+  if (i1 != kDone) t1 = tiles[i1];
+  while (i0 != kDone) {
+    {
+#ifdef S2A_MEASURE
+      unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
+      const unsigned long long i2 = i1 != kDone ? next_tile() : kDone;
+      TileRef t2 = {};
+      if (i2 != kDone) t2 = tiles[i2];           // two tiles ahead: not waited for in this iteration
+      PreBox An = {}, Cn = {};
+      if (i1 != kDone) load(t1, An, Cn);         // one tile ahead (t1 arrived during the previous tile)
+      const TileRef tn = t1;
+      const unsigned long long in1 = i1;
+      i1 = i2;
+      t1 = t2;
+#ifdef S2A_MEASURE
+      a_tiles++;
+#endif
+      CULL_T(tc1);
+      CULL_ACC(a_claim, tc1, tc0);
       const bool rowvalid = t.rb * 64 + lane < t.ns;
-      const unsigned long long colvalid = __ballot(t.cb * 64 + lane < t.ns);
-      // upper triangle of a diagonal tile: column j > row lane
-      const unsigned long long tri = t.cb != t.rb ? ~0ull : (lane == 63 ? 0ull : ~((2ull << lane) - 1ull));
+      const unsigned ncol = min(64u, t.ns - t.cb * 64);        // valid columns of the tile (the tile exists: >= 1)
+      const bool diag = t.cb == t.rb;                          // upper triangle of a diagonal tile: column > row lane
       const float ax = A.x, ay = A.y, ar = A.r * 1.002f + 1e-3f;
-      const float cx = Cb.x, cy = Cb.y, cr = Cb.r * 1.002f;
+      float rx = Cb.x, ry = Cb.y, rr = Cb.r * 1.002f, rl = log_area(Cb);   // rotate through the lanes, a step per test
+      const float la = log_area(A);
 #pragma unroll
       for (int half = 0; half < 2; half++) {
         unsigned bits = 0;
-        if (half == 0) circle_bits<0, 32>(ax, ay, ar, cx, cy, cr, bits);
-        else circle_bits<32, 64>(ax, ay, ar, cx, cy, cr, bits);
-        bits &= (unsigned)((colvalid & tri) >> (32 * half));
+        CULL_T(ts0);
+        nms_stage1_rot<32>(ax, ay, ar, la, rx, ry, rr, rl, Lmax, bits);
         if (!rowvalid) bits = 0;
+        CULL_T(ts1);
+        CULL_ACC(a_s1, ts1, ts0);
         if (lane == 0) s_n[wave] = 0;
         wave_lds_handoff();                                      // the reset, then the reservations
+        // bit b of this half = column (lane + (32 half + b) dir) & 63; columns beyond the segment and the lower triangle
+        // of a diagonal tile are dropped here, where only the survivors are looked at
+        unsigned keepbits = 0;
+        for (unsigned w = bits; w;) {
+          const unsigned b = (unsigned)__ffs((int)w) - 1u;
+          w &= w - 1u;
+          const unsigned c = ((unsigned)lane + (32u * half + b) * dir) & 63u;
+          if (c < ncol && (!diag || c > (unsigned)lane)) keepbits |= 1u << b;
+        }
+        bits = keepbits;
         const unsigned cnt = (unsigned)__popc(bits);
         unsigned off = 0;
         if (cnt) off = atomicAdd(&s_n[wave], cnt);             // one reservation per lane (in order behind the reset)
         while (bits) {
           const unsigned b = (unsigned)__ffs((int)bits) - 1u;
           bits &= bits - 1u;
-          list[off++] = (unsigned short)(((unsigned)lane << 6) | (32u * half + b));
+          const unsigned c = ((unsigned)lane + (32u * half + b) * dir) & 63u;
+          list[off++] = (unsigned short)(((unsigned)lane << 6) | c);
         }
         wave_lds_handoff();                                      // every lane's list entries and the final count
         unsigned n1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_n[wave]);
+        CULL_T(ts2);
+        CULL_ACC(a_list, ts2, ts1);
         while (n1 > 0u) {                                        // the whole half tile: the boxes change with the tile
           const unsigned g = min(n1, 64u), base = n1 - g;
           const bool mine = (unsigned)lane < g;
@@ -1250,12 +1362,22 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
           if (ns + 64 > kNlStage) flush();
         }
         wave_lds_handoff();                                      // list read out before the next half tile rewrites it
+        CULL_T(ts3);
+        CULL_ACC(a_s2, ts3, ts2);
       }
       t = tn;
       A = An;
       Cb = Cn;
+      i0 = in1;
     }
   }
+#ifdef S2A_MEASURE
+  if (lane == 0) {
+    atomicAdd(&g_cull_dbg[0], __builtin_amdgcn_s_memtime() - t_begin);
+    atomicAdd(&g_cull_dbg[1], a_claim); atomicAdd(&g_cull_dbg[2], a_s1); atomicAdd(&g_cull_dbg[3], a_list);
+    atomicAdd(&g_cull_dbg[4], a_s2); atomicAdd(&g_cull_dbg[5], a_tiles); atomicAdd(&g_cull_dbg[6], 1ull);
+  }
+#endif
   if (lane == 0) s_left[wave] = ns;
   __syncthreads();
   unsigned before = 0, all = 0;
@@ -1280,8 +1402,8 @@ constexpr int kEdgeStage = 128;      // staged edges per wave
 // bit of its first index -- positions are < 2^31) and REDO = true, the second launch, evaluates the marked pairs with 24.
 constexpr uint32_t kPairRedo = 0x80000000u;
 template <bool REDO>
-__global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict__ boxes, const int32_t* __restrict__ perm_sp,
-                                                        const uint32_t* __restrict__ inv, float thr,
+__global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict__ boxes,
+                                                        const unsigned long long* __restrict__ rankkey, float thr,
                                                         uint2* __restrict__ gq, NmsCounters* __restrict__ C,
                                                         unsigned long long cap, uint2* __restrict__ edges,
                                                         unsigned long long ecap) {
@@ -1306,16 +1428,16 @@ __global__ __launch_bounds__(kThreads) void k_nms_heavy(const PreBox* __restrict
     bool hit = false;
     uint2 ij = make_uint2(0, 0);
     if (e < total) {
-      // the pair list holds positions in the cull's row order (boxes[]); the greedy order is the SCORE position:
-      // inv[original row] (spatial order) or the position itself (blocks in score order)
+      // the pair list holds positions in the cull's row order (boxes[]); which of the two comes first in the greedy order
+      // is decided by the rank keys (spatial order) or by the positions themselves (blocks in score order)
       uint2 q = gq[e];
       const bool marked = (q.x & kPairRedo) != 0u;
       q.x &= ~kPairRedo;
       if (!REDO || marked) {
-        ij = perm_sp ? make_uint2(inv[perm_sp[q.x]], inv[perm_sp[q.y]]) : q;
-        if (ij.y < ij.x) { const uint32_t t = ij.x; ij.x = ij.y; ij.y = t; const uint32_t u = q.x; q.x = q.y; q.y = u; }
-        const PreBox A = boxes[q.x];    // higher score first: same argument order as the reference
-        const PreBox B = boxes[q.y];
+        const bool swap = rankkey ? rankkey[q.y] < rankkey[q.x] : q.y < q.x;
+        ij = swap ? make_uint2(q.y, q.x) : q;
+        const PreBox A = boxes[ij.x];   // higher score first: same argument order as the reference
+        const PreBox B = boxes[ij.y];
         if (REDO) {
           hit = rbox_iou<kThreads>(A, B, s_pts + threadIdx.x) > thr;
         } else {
@@ -1618,7 +1740,8 @@ __global__ __launch_bounds__(kThreads) void k_nms_greedy_direct(const PreBox* __
                                                                 uint32_t ignore_key, int use_ignore,
                                                                 NmsCounters* __restrict__ C, unsigned long long cap,
                                                                 unsigned long long ecap, unsigned long long tile_cap,
-                                                                uint8_t* __restrict__ state, float thr) {
+                                                                uint8_t* __restrict__ state /* score order: state_fb */,
+                                                                float thr) {
   if (!(C->pairs > cap || C->edges > ecap || C->tiles > tile_cap)) return;
   __shared__ float2 s_pts[24 * kThreads];
   __shared__ unsigned s_next;
@@ -1656,22 +1779,28 @@ __global__ __launch_bounds__(kThreads) void k_nms_greedy_direct(const PreBox* __
   }
 }
 
-// keep flag of every row in the caller's order
+// keep flag of every row in the caller's order.  state / blocked live in the cull's row order (perm = that order's
+// original rows); the direct fallback works in score order on its own array (state_fb, perm_seg).
 __global__ void k_nms_finish(const uint8_t* __restrict__ state, const uint8_t* __restrict__ blocked,
-                             const NmsCounters* __restrict__ C, const int32_t* __restrict__ perm_seg, int64_t n,
+                             const NmsCounters* __restrict__ C, const int32_t* __restrict__ perm,
+                             const uint8_t* __restrict__ state_fb, const int32_t* __restrict__ perm_seg, int64_t n,
                              uint8_t* __restrict__ keep_orig) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   uint32_t v;
-  if ((C->status & 1u) || C->alive[kNmsRounds] != 0) {
-    v = state[p];                    // the fallback / the clean-up kernel settled every row explicitly
+  if (C->status & 1u) {              // a list overflowed: k_nms_greedy_direct settled every row (score order)
+    keep_orig[perm_seg[p]] = state_fb[p] == kKept ? 1 : 0;
+    return;
+  }
+  if (C->alive[kNmsRounds] != 0) {
+    v = state[p];                    // the clean-up kernel settled every row explicitly
   } else {
     int r = kNmsRounds;              // the view after the first launched round that left no edge alive
     for (int k = 1; k <= kNmsRounds; k++)
       if (C->alive[k] == 0) { r = k; break; }
     v = nms_view(state, blocked, n, r, (uint32_t)p);
   }
-  keep_orig[perm_seg[p]] = v == kKept ? 1 : 0;
+  keep_orig[perm[p]] = v == kKept ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- side streams
@@ -1725,14 +1854,15 @@ struct NmsPlan {
 struct NmsBuffers {
   unsigned long long *keyA, *keyA_s, *keyB, *keyB_s, *keyC, *keyC_s;
   int32_t *idx, *perm_glob, *perm_seg, *perm_sp;
-  uint32_t *inv, *segidx1, *seg_start, *num_seg, *cnt, *cnt2, *cnt3, *lasthead;
+  uint32_t *segidx1, *seg_start, *num_seg, *cnt, *cnt2, *cnt3, *lasthead;
+  unsigned long long* rankkey;
   uint4* bbox_part;
   NmsCounters* C;
   PreBox *sorted, *sp_box;
   uint2 *lo, *hi;
   TileRef* tiles;
   uint2 *gq, *edges;
-  uint8_t *keep_orig, *state, *blocked;
+  uint8_t *keep_orig, *state, *state_fb, *blocked;
   uint32_t *seg_cnt, *seg_cur;
   void* rp_temp[3];
 };
@@ -1776,7 +1906,7 @@ void nms_carve_fixed(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
   B->perm_glob = cv.take<int32_t>(sz);
   B->perm_seg = cv.take<int32_t>(sz);
   B->perm_sp = cv.take<int32_t>(sz);
-  B->inv = cv.take<uint32_t>(sz);
+  B->rankkey = cv.take<unsigned long long>(sz);
   B->segidx1 = cv.take<uint32_t>(sz);
   B->seg_start = cv.take<uint32_t>(sz + 1);
   B->num_seg = cv.take<uint32_t>(4);
@@ -1792,6 +1922,7 @@ void nms_carve_fixed(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
   B->hi = cv.take<uint2>(block_slots_for(sz));
   B->keep_orig = cv.take<uint8_t>(sz);
   B->state = cv.take<uint8_t>(sz);
+  B->state_fb = cv.take<uint8_t>(sz);
   B->blocked = cv.take<uint8_t>(2 * sz + 4);
   B->seg_cnt = cv.take<uint32_t>(sz + 2);
   B->seg_cur = cv.take<uint32_t>(sz + 2);
@@ -1837,11 +1968,13 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
                                  need_c ? B.keyC : nullptr, B.idx, B.bbox_part, B.C,
                                  reinterpret_cast<uint32_t*>(B.blocked), (2 * sz + 3) / 4, B.seg_cnt, sz + 2, lo, B.hi, slots);
   // A call is as long as its chain of LAUNCHES while the kernels are short (the host needs ~5 us per launch, a rocPRIM
-  // sort is nine of them): only what the cull needs is enqueued in front of it -- for big segments the spatial order B
-  // alone -- and the other sorts go to side streams AFTER the cull's launch, where the host has 300 us to spare:
-  //   spatial:      prep, B-keys, sort B, seg_count, sp_meta, tile filter, cull | side 0: sort A, seg_count, pos_meta
-  //                                                                              | side 1: sort C
-  //   score blocks: prep, sort A, seg_count, pos_meta, tile filter, cull        | side 1: sort C
+  // sort is nine of them).  For big segments only the spatial order B is enqueued in front of the cull, and everything
+  // behind the cull works on SPATIAL positions (greedy direction from the rank keys): the score order A is needed by the
+  // overflow fallback alone and the output order C by the final compaction, so both go to side streams behind the cull's
+  // launch and are joined late:
+  //   spatial:      prep, B-keys, sort B, seg_count, sp_meta, filter, cull, exact pass, rounds ... | side 0: sort A, pos_meta
+  //                                                                                                 | side 1: sort C
+  //   score blocks: prep, sort A, seg_count, pos_meta, filter, cull, ...                            | side 1: sort C
   // Under stream capture everything stays on the caller's stream (S2A_NMS_FORK=0 forces that form: A/B and tests).
   bool fork = !stream_capturing(st);
   if (const char* e = std::getenv("S2A_NMS_FORK")) fork = e[0] == '1';
@@ -1851,12 +1984,13 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     if (rc != S2A_OK) return rc;
     S2A_HIP(hipEventRecord(ss->fork, st));
   }
-  auto chain_a = [&](hipStream_t q, bool segs) -> int {      // score order: sorted[], inv[], state[] (+ segments)
+  auto chain_a = [&](hipStream_t q, bool main_order) -> int {   // score order: sorted[], state_fb[] (+ segments, state)
     size_t rpb = pl.rocprim_bytes;
     S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[0], rpb, B.keyA, B.keyA_s, B.idx, B.perm_seg, sz, 0, 64, q));
     k_nms_seg_count<<<nb, 256, 0, q>>>(B.keyA_s, 32, n, rows, B.cnt, nullptr);
     k_nms_pos_meta<<<nb, 256, 0, q>>>(dets, B.keyA_s, B.perm_seg, B.cnt, nb, rows, n, ignore_key, use_ignore, B.segidx1,
-                                      segs ? B.seg_start : nullptr, B.num_seg, B.sorted, B.state, B.inv);
+                                      main_order ? B.seg_start : nullptr, B.num_seg, B.sorted,
+                                      main_order ? B.state : nullptr, B.state_fb);
     return S2A_OK;
   };
   auto sort_c = [&](hipStream_t q) -> int {
@@ -1864,43 +1998,46 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[2], rpb, B.keyC, B.keyC_s, B.idx, B.perm_glob, sz, 0, 64, q));
     return S2A_OK;
   };
-  const PreBox* cull_boxes = B.sorted;           // blocks in score order: the cull walks sorted[] itself
+  const PreBox* boxes = B.sorted;                // blocks in score order: the cull walks sorted[] itself
+  const unsigned long long* rankkey = nullptr;   // ... and a lower position IS the higher score
+  const int32_t* perm = B.perm_seg;              // original row of a position
   if (spatial) {
     k_nms_spkeys<<<g, 256, 0, st>>>(dets, B.keyA, B.bbox_part, (int)gp, n, B.keyB);
     size_t rpb = pl.rocprim_bytes;
     S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[1], rpb, B.keyB, B.keyB_s, B.idx, B.perm_sp, sz, 0, 52, st));
     k_nms_seg_count<<<nb, 256, 0, st>>>(B.keyB_s, 20, n, rows, B.cnt2, B.lasthead);
-    k_nms_sp_meta<<<nb, 256, 0, st>>>(dets, B.keyB_s, B.perm_sp, B.cnt2, B.lasthead, nb, rows, n, B.segidx1, B.seg_start,
-                                      B.num_seg, B.sp_box, B.lo, B.hi);
+    k_nms_sp_meta<<<nb, 256, 0, st>>>(dets, B.keyB_s, B.perm_sp, B.cnt2, B.lasthead, nb, rows, n, scores, ignore_key,
+                                      use_ignore, B.segidx1, B.seg_start, B.num_seg, B.sp_box, B.rankkey, B.state, B.lo, B.hi);
     k_nms_tile_filter<<<g, kThreads, 0, st>>>(B.segidx1, B.seg_start, B.keyB_s, 20, ignore_key, use_ignore, n, lo, B.hi,
                                               B.tiles, B.C, pl.tile_cap);
-    cull_boxes = B.sp_box;
+    boxes = B.sp_box;
+    rankkey = B.rankkey;
+    perm = B.perm_sp;
   } else {
     int rc = chain_a(st, true);
     if (rc != S2A_OK) return rc;
     k_nms_tile_filter<<<g, kThreads, 0, st>>>(B.segidx1, B.seg_start, B.keyA_s, 32, ignore_key, use_ignore, n, nullptr, B.hi,
                                               B.tiles, B.C, pl.tile_cap);
   }
+  uint2* pair_list = B.gq;                       // what the exact pass reads
+  unsigned long long pair_cap = pl.queue_cap;
   {
     // one wave per tile pays off once there are tiles for every wave (200 k rows: 392 -> 335 us); with few tiles the four
     // waves per tile of k_nms_cull finish a tile sooner (5 k / 20 k rows: 35 us less).  S2A_NMS_CULL_LANES=0|1 forces.
     const char* nl = getenv("S2A_NMS_CULL_LANES");
     const bool lanes = nl && (nl[0] == '0' || nl[0] == '1') ? nl[0] == '1' : n >= kNmsLanesRows;
     if (!lanes)
-      k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(cull_boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+      k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
     else
-      k_nms_cull_lanes<<<kPersistentGrid, kThreads, 0, st>>>(cull_boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+      k_nms_cull_lanes<<<kPersistentGrid, kThreads, 0, st>>>(boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
   }
-  // behind the cull's launch: the score order (spatial path) and the output order
+  // behind the cull's launch: the score order (spatial path: fallback only) and the output order
   if (spatial) {
     hipStream_t q = ss ? ss->s[0] : st;
     if (ss) S2A_HIP(hipStreamWaitEvent(q, ss->fork, 0));
     int rc = chain_a(q, false);
     if (rc != S2A_OK) return rc;
-    if (ss) {
-      S2A_HIP(hipEventRecord(ss->join[0], q));
-      S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
-    }
+    if (ss) S2A_HIP(hipEventRecord(ss->join[0], q));
   }
   if (need_c) {
     hipStream_t q = ss ? ss->s[1] : st;
@@ -1912,9 +2049,8 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     B.perm_glob = B.perm_seg;
     B.keyC_s = B.keyA_s;
   }
-  const int32_t* rank_perm = spatial ? B.perm_sp : nullptr;
-  k_nms_heavy<false><<<kHeavyGrid, kThreads, 0, st>>>(cull_boxes, rank_perm, B.inv, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
-  k_nms_heavy<true><<<kPersistentGrid, kThreads, 0, st>>>(cull_boxes, rank_perm, B.inv, thr, B.gq, B.C, pl.queue_cap, B.edges, pl.edge_cap);
+  k_nms_heavy<false><<<kHeavyGrid, kThreads, 0, st>>>(boxes, rankkey, thr, pair_list, B.C, pair_cap, B.edges, pl.edge_cap);
+  k_nms_heavy<true><<<kPersistentGrid, kThreads, 0, st>>>(boxes, rankkey, thr, pair_list, B.C, pair_cap, B.edges, pl.edge_cap);
   // the pair list is dead after the dense pass: its memory takes the alive-edge list of the last launched round
   for (int r = 1; r <= kNmsRounds; r++)
     k_nms_round<<<256, kThreads, 0, st>>>(B.edges, B.C, pl.edge_cap, B.state, B.blocked, n, r,
@@ -1922,14 +2058,15 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   // still-alive edges (listed by the last launched round in the dead pair list): by segment into the edge buffer (the full
   // edge list is dead now), then one workgroup per segment; all five kernels return at once when nothing is alive
   k_nms_materialize<<<g, 256, 0, st>>>(B.C, B.state, B.blocked, n);
-  k_nms_alive_count<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, B.sorted, B.seg_cnt);
+  k_nms_alive_count<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cnt);
   k_nms_alive_scan<<<1, 1024, 0, st>>>(B.C, B.num_seg, B.seg_cnt, B.seg_cur);
-  k_nms_alive_scatter<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, B.sorted, B.seg_cur, B.edges);
+  k_nms_alive_scatter<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cur, B.edges);
   k_nms_finish_segments<<<512, kThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.seg_cnt, B.edges, B.state, B.blocked, n,
                                                   force_global);
+  if (ss && spatial) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
   k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.keyA_s, ignore_key, use_ignore, B.C,
-                                                pl.queue_cap, pl.edge_cap, pl.tile_cap, B.state, thr);
-  k_nms_finish<<<g, 256, 0, st>>>(B.state, B.blocked, B.C, B.perm_seg, n, B.keep_orig);
+                                                pair_cap, pl.edge_cap, pl.tile_cap, B.state_fb, thr);
+  k_nms_finish<<<g, 256, 0, st>>>(B.state, B.blocked, B.C, perm, B.state_fb, B.perm_seg, n, B.keep_orig);
   if (ss && need_c) S2A_HIP(hipStreamWaitEvent(st, ss->join[1], 0));
   S2A_LAUNCH_CHECK();
   return S2A_OK;
@@ -1974,6 +2111,23 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
     k_nms_keep_write<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3, nb, keep, count_dev);
   }
   S2A_LAUNCH_CHECK();
+#ifdef S2A_MEASURE
+  if (getenv("S2A_NMS_DEBUG")) {                 // measurement builds only: the device-side totals of this call
+    NmsCounters h;
+    S2A_HIP(hipStreamSynchronize(st));
+    S2A_HIP(hipMemcpy(&h, B.C, sizeof(h), hipMemcpyDeviceToHost));
+    unsigned long long dbg[8] = {};
+    S2A_HIP(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(g_cull_dbg), sizeof(dbg)));
+    unsigned long long zero[8] = {};
+    S2A_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cull_dbg), zero, sizeof(zero)));
+    if (dbg[6])
+      fprintf(stderr, "[cull] waves %llu tiles %llu  cycles per wave: total %.0f  wait(claim+loads) %.0f  stage1 %.0f  list %.0f  stage2 %.0f\n",
+              dbg[6], dbg[5], (double)dbg[0] / dbg[6], (double)dbg[1] / dbg[6], (double)dbg[2] / dbg[6], (double)dbg[3] / dbg[6],
+              (double)dbg[4] / dbg[6]);
+    fprintf(stderr, "[nms] n %lld tiles %llu pairs %llu edges %llu alive_list %llu status %u alive %u %u %u %u\n", (long long)n,
+            h.tiles, h.pairs, h.edges, h.alive_list, h.status, h.alive[1], h.alive[2], h.alive[3], h.alive[4]);
+  }
+#endif
   if (host_count) {
     S2A_HIP(hipMemcpyAsync(host_count, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     S2A_HIP(hipStreamSynchronize(st));

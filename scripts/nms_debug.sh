@@ -1,0 +1,8 @@
+#!/bin/bash
+# measurement build (-DS2A_MEASURE) of rotated_ops on the GPU box's copy: device-side totals of one 200 k-row ml-NMS call
+cd $GRAFT_REPO_ROOT
+restore() { rm -f s2anet_amd/csrc/rotated_ops.o; make -C s2anet_amd/csrc -s 2>&1 | grep -E "error" | head -3; }
+trap restore EXIT
+rm -f s2anet_amd/csrc/rotated_ops.o
+make -C s2anet_amd/csrc -s EXTRA="-DS2A_MEASURE" 2>&1 | grep -E "error" | head -3
+S2A_NMS_DEBUG=1 python scripts/nms_once.py 2>&1 | grep "\[nms\]\|\[cull\]" | tail -4

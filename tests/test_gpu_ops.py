@@ -132,10 +132,12 @@ def test_iou_dense_overlap_both_paths(rng, monkeypatch, path):
 
 @pytest.mark.parametrize("lanes", ["0", "1"])
 def test_nms_both_cull_forms_vs_oracle(rng, monkeypatch, lanes):
-    """the four-waves-per-tile cull (small inputs) and the one-wave-per-tile cull (large ones), each forced on the same
+    """the four-waves-per-tile cull (small inputs, blocks in score order) and the one-wave-per-tile cull of large inputs
+    (spatial order, columns rotating through the lanes, area-ratio test in the first stage), each forced on the same
     clustered input with ragged segments (diagonal tiles, partly filled last blocks, invalid columns)"""
     from s2anet_amd.rotated import ml_nms_rotated
-    monkeypatch.setenv("S2A_NMS_CULL_LANES", lanes)
+    monkeypatch.setenv("S2A_NMS_CULL_LANES", "0" if lanes == "0" else "1")
+    monkeypatch.setenv("S2A_NMS_SPATIAL", "1" if lanes != "0" else "0")
     n = 7001
     d = rand_rboxes(rng, n, span=300, lo=6, hi=60)
     d[:1500, :2] = d[:1500, :2] * 0.1 + 40.0            # a dense cluster: many survivors per tile
