@@ -229,6 +229,9 @@ __device__ __forceinline__ float lane_bcast(float v, int j) {
 // operations in order, so all that is needed is that the COMPILER keeps the order too.  Wavefront-scope fences + the wave
 // barrier emit no instruction; they pin the order of the LDS stores / atomics before against the LDS loads after.
 __device__ __forceinline__ void wave_lds_handoff() {
+#ifdef S2A_ABL_NOFENCE
+  return;
+#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -459,7 +462,6 @@ struct NmsCounters {
   unsigned long long edges;      // pairs with IoU > thr (true total)
   unsigned long long tiles;      // tiles that passed the filter (true total)
   unsigned long long alive_list; // edges handed to the clean-up kernel
-  unsigned long long tile_cursor[8 * 16];   // next unclaimed tile of each eighth of the tile list, a cache line apart
   uint32_t status;               // bit 0: a list overflowed -> direct greedy fallback ran
   uint32_t alive[16];            // edges still between two unsettled rows after round r
 };
@@ -1193,7 +1195,6 @@ __device__ unsigned long long g_cull_dbg[8];   // measurement builds: cycles per
 constexpr int kNlList = 64 * 32;              // circle-test survivors of half a tile, u16 = row << 6 | column
 constexpr int kNlStage = 512;                 // per-wave staged pairs
 constexpr int64_t kNmsLanesRows = 49152;      // rows from which the one-wave-per-tile cull is the default
-constexpr int kNlBatch = 4;                   // tiles a wave claims per visit to the cursor
 __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __restrict__ sp_box,
                                                              const TileRef* __restrict__ tiles,
                                                              NmsCounters* __restrict__ C, unsigned long long tile_cap,
@@ -1237,46 +1238,24 @@ __global__ __launch_bounds__(kThreads) void k_nms_cull_lanes(const PreBox* __res
     const bool sane = area > 0.f && fminf(aw, ah) >= 0.05f * fmaxf(aw, ah);
     return sane ? __log2f(area) : __builtin_nanf("");
   };
-  auto bcast64 = [](unsigned long long v) {
-    return ((unsigned long long)(uint32_t)__shfl((int)(v >> 32), 0) << 32) | (uint32_t)__shfl((int)(v & 0xffffffffu), 0);
-  };
   // direction of the lane rotation: the lane whose value arrives here after one step, relative to this lane (1 or 63)
   const unsigned dir = ((unsigned)__builtin_amdgcn_mov_dpp(lane, 0x13C, 0xf, 0xf, true) - (unsigned)lane) & 63u;
   unsigned long long a_claim = 0, a_s1 = 0, a_list = 0, a_s2 = 0, a_tiles = 0;
   (void)a_claim; (void)a_s1; (void)a_list; (void)a_s2; (void)a_tiles;
   CULL_T(t_begin);
-  // ---- the wave's stream of tiles.  The list is cut into 8 regions with a cursor each (own cache line): a wave starts on
-  // region blockIdx & 7 (the blocks that share an XCD under round-robin placement -- a speed heuristic, nothing depends on
-  // it) and moves on to the next region when one is empty, so a claim competes with an eighth of the waves.  (One cursor
-  // for all 4 k waves: 16 k atomics on one word = 180 us of serialised round trips, every claim queued for microseconds.)
-  // Claims are issued a batch ahead, tile references two tiles ahead, boxes one tile ahead: an in-order wave blocks at
-  // the FIRST use of a load, so each dependent step of the chain (claim -> TileRef -> boxes) gets a whole tile of work
-  // to hide behind.
-  unsigned cs = blockIdx.x & 7u, tries = 0;      // current region, regions found empty so far
-  unsigned long long idx = 0, bend = 0;          // current batch [idx, bend): idx is the tile last handed out
-  auto region_lo = [&](unsigned k) { return L * k / 8ull; };
-  auto claim = [&](unsigned k) {
-    unsigned long long v = 0;
-    if (lane == 0) v = atomicAdd(&C->tile_cursor[k * 16], (unsigned long long)kNlBatch);
-    return v;
-  };
-  unsigned long long pend = claim(cs);
+  // ---- the wave's stream of tiles: wave w takes tiles w, w + W, w + 2 W ... of a grid with MANY more workgroups than fit
+  // on the chip (8 k workgroups: one or two tiles per wave at 200 k rows, at most one in a detector batch).  Tiles differ
+  // by an order of magnitude in cost; the hardware dispatcher starts the next workgroup wherever one retires, which
+  // balances the load without any cursor (a persistent grid claiming batches from atomic cursors spent half of its wave
+  // time waiting for claims and for the loads chained behind them: 32 k probing atomics at the end of every launch).
+  // Tile references are fetched two tiles ahead, boxes one tile ahead: an in-order wave blocks at the FIRST use of a load.
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * (kThreads / 64);
+  unsigned long long tnext = (unsigned long long)blockIdx.x * (kThreads / 64) + wave;
   constexpr unsigned long long kDone = ~0ull;
   auto next_tile = [&]() -> unsigned long long {
-    if (idx + 1 < bend) return ++idx;
-    for (;;) {                                   // (wave-uniform: every value comes from a broadcast)
-      if (tries >= 8u) return kDone;
-      const unsigned long long v = bcast64(pend), lo = region_lo(cs), hi = region_lo(cs + 1);
-      if (lo + v < hi) {
-        idx = lo + v;
-        bend = min(hi, idx + (unsigned long long)kNlBatch);
-        pend = claim(cs);
-        return idx;
-      }
-      cs = (cs + 1u) & 7u;
-      tries++;
-      if (tries < 8u) pend = claim(cs);
-    }
+    const unsigned long long r = tnext < L ? tnext : kDone;
+    tnext += nwaves;
+    return r;
   };
   unsigned long long i0 = next_tile();
   TileRef t = {}, t1 = {};
@@ -2029,7 +2008,7 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     if (!lanes)
       k_nms_cull<<<kPersistentGrid, kThreads, 0, st>>>(boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
     else
-      k_nms_cull_lanes<<<kPersistentGrid, kThreads, 0, st>>>(boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
+      k_nms_cull_lanes<<<8192, kThreads, 0, st>>>(boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
   }
   // behind the cull's launch: the score order (spatial path: fallback only) and the output order
   if (spatial) {
@@ -2082,6 +2061,25 @@ size_t nms_workspace_bytes(int64_t n, int64_t max_seg_rows) {
   return cv.off + 256;
 }
 
+#ifdef S2A_MEASURE
+static int nms_debug_dump(const NmsBuffers& B, int64_t n, hipStream_t st) {
+  if (!getenv("S2A_NMS_DEBUG")) return S2A_OK;   // measurement builds only: the device-side totals of this call
+  NmsCounters h;
+  S2A_HIP(hipStreamSynchronize(st));
+  S2A_HIP(hipMemcpy(&h, B.C, sizeof(h), hipMemcpyDeviceToHost));
+  unsigned long long dbg[8] = {};
+  S2A_HIP(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(g_cull_dbg), sizeof(dbg)));
+  unsigned long long zero[8] = {};
+  S2A_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cull_dbg), zero, sizeof(zero)));
+  if (dbg[6])
+    fprintf(stderr, "[cull] waves %llu tiles %llu  cycles per wave: total %.0f  wait(claim+loads) %.0f  stage1 %.0f  list %.0f  stage2 %.0f\n",
+            dbg[6], dbg[5], (double)dbg[0] / dbg[6], (double)dbg[1] / dbg[6], (double)dbg[2] / dbg[6], (double)dbg[3] / dbg[6],
+            (double)dbg[4] / dbg[6]);
+  fprintf(stderr, "[nms] n %lld tiles %llu pairs %llu edges %llu alive_list %llu status %u alive %u %u %u %u\n", (long long)n,
+          h.tiles, h.pairs, h.edges, h.alive_list, h.status, h.alive[1], h.alive[2], h.alive[3], h.alive[4]);
+  return S2A_OK;
+}
+#endif
 int nms_dropin(const float* dets, const float* scores, const float* labels, int64_t n, float thr,
                int64_t* keep, int64_t* count_dev, int64_t* host_count, void* ws, size_t ws_bytes,
                hipStream_t st) {
@@ -2112,21 +2110,7 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
   }
   S2A_LAUNCH_CHECK();
 #ifdef S2A_MEASURE
-  if (getenv("S2A_NMS_DEBUG")) {                 // measurement builds only: the device-side totals of this call
-    NmsCounters h;
-    S2A_HIP(hipStreamSynchronize(st));
-    S2A_HIP(hipMemcpy(&h, B.C, sizeof(h), hipMemcpyDeviceToHost));
-    unsigned long long dbg[8] = {};
-    S2A_HIP(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(g_cull_dbg), sizeof(dbg)));
-    unsigned long long zero[8] = {};
-    S2A_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cull_dbg), zero, sizeof(zero)));
-    if (dbg[6])
-      fprintf(stderr, "[cull] waves %llu tiles %llu  cycles per wave: total %.0f  wait(claim+loads) %.0f  stage1 %.0f  list %.0f  stage2 %.0f\n",
-              dbg[6], dbg[5], (double)dbg[0] / dbg[6], (double)dbg[1] / dbg[6], (double)dbg[2] / dbg[6], (double)dbg[3] / dbg[6],
-              (double)dbg[4] / dbg[6]);
-    fprintf(stderr, "[nms] n %lld tiles %llu pairs %llu edges %llu alive_list %llu status %u alive %u %u %u %u\n", (long long)n,
-            h.tiles, h.pairs, h.edges, h.alive_list, h.status, h.alive[1], h.alive[2], h.alive[3], h.alive[4]);
-  }
+  { int rc_ = nms_debug_dump(B, n, st); if (rc_ != S2A_OK) return rc_; }
 #endif
   if (host_count) {
     S2A_HIP(hipMemcpyAsync(host_count, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -2630,6 +2614,9 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
   int rc = nms_core(dets, scores, nullptr, segment_ids, group_ids, n, (uint32_t)num_segments,
                     (uint32_t)num_groups, iou_threshold, pl, B, st);
   if (rc != S2A_OK) return rc;
+#ifdef S2A_MEASURE
+  { int rc_ = nms_debug_dump(B, n, st); if (rc_ != S2A_OK) return rc_; }
+#endif
   if (keep_flags)
     S2A_HIP(hipMemcpyAsync(keep_flags, B.keep_orig, (size_t)n, hipMemcpyDeviceToDevice, st));
   if (keep) {
