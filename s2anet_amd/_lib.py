@@ -87,6 +87,7 @@ SYMBOLS = {
     "s2a_conv_nhwc_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int,
                                   c_int, c_vp]),
     "s2a_debug_read_stamps": (c_int, [c_vp, c_i64]),
+    "s2a_build_flags": (c_int, []),
     "s2a_deformable_im2col": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(DcnParams), c_vp]),
     "s2a_deformable_col2im": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(DcnParams), c_vp]),
     "s2a_deformable_col2im_coord": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(DcnParams), c_vp]),
@@ -137,6 +138,11 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        flags = L.s2a_build_flags()
+        if flags and not os.environ.get("S2A_ALLOW_MEASURE_BUILD"):
+            raise RuntimeError(
+                f"{LIB_PATH} holds an object compiled with a measurement / ablation switch (s2a_build_flags() = {flags:#x}): "
+                "rebuild with `make -C s2anet_amd/csrc` (scripts that build such objects set S2A_ALLOW_MEASURE_BUILD=1)")
         _lib = L
     return _lib
 

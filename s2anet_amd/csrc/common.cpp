@@ -15,3 +15,12 @@ const char* get_error() { return g_err; }
 
 extern "C" const char* s2a_last_error(void) { return s2a::get_error(); }
 extern "C" const char* s2a_version(void) { return "s2anet_hip 0.1 (gfx950)"; }
+
+// Non-zero when an object of this library was compiled with a measurement / ablation switch (scripts/abl.sh,
+// scripts/nms_debug.sh rebuild single objects with EXTRA=-D...): such a build may skip work or print diagnostics and
+// must never produce a reported number.  s2anet_amd/_lib.py refuses to load it unless S2A_ALLOW_MEASURE_BUILD=1.
+namespace s2a {
+int build_flags_dcn();
+int build_flags_rotated();
+}  // namespace s2a
+extern "C" int s2a_build_flags(void) { return s2a::build_flags_dcn() | (s2a::build_flags_rotated() << 16); }

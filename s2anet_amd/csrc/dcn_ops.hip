@@ -45,6 +45,18 @@ namespace {
 #ifndef S2A_STAMP
 #define S2A_STAMP 0
 #endif
+// measurement builds (-DS2A_MEASURE) only: S2A_DCN_DROP=x|w gives the wave-specialised kernel zero-record descriptors (the
+// loads are dropped, the instruction stream stays; OUTPUTS ARE WRONG) -- never compiled into a shipped library
+#ifdef S2A_MEASURE
+#define S2A_DCN_DROP_SWITCH(xb, wb)                     \
+  do {                                                  \
+    const char* drop = getenv("S2A_DCN_DROP");          \
+    if (drop && strchr(drop, 'x')) (xb) = 0;            \
+    if (drop && strchr(drop, 'w')) (wb) = 0;            \
+  } while (0)
+#else
+#define S2A_DCN_DROP_SWITCH(xb, wb) do {} while (0)
+#endif
 #if S2A_STAMP
 // diagnostic build only: per-workgroup phase stamps (s_memtime) into a buffer nothing else reads
 __device__ unsigned long long g_stamps[4096 * 16];
@@ -734,15 +746,10 @@ __global__ void k_pack_weight_frag(const _Float16* __restrict__ w, int O, int C,
 
 constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs + 16 B pad
 
-// TH = rows of the position tile: 8 (128 positions), or 4 (64 positions: the half tiles that finish a pyramid launch
-// whose last round would leave most CUs idle; tile index = tile_base + block / 2, upper / lower half = block & 1)
-// DUO (TH = 4 only): a form that lets TWO workgroups share a CU -- <= 128 VGPRs (filter fragments in ONE register set,
-// refilled k-step by k-step right behind the MFMAs that read them) and 64.5 KB of LDS (ONE patch buffer: the next chunk's
-// patch waits in the loaders' registers and is written when the chunk's last tap has been fetched; the first tap of a
-// chunk is then fetched inside its own stage instead of one stage ahead).  One workgroup's table build, patch load,
-// epilogue and barrier waits then run under the other's MFMAs.  Same arithmetic and order: bit-identical.
-template <bool OUT_NHWC, int SRC, int TH = 8, bool DUO = false>
-__global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* __restrict__ x_,
+// TH = rows of the position tile: 8 (128 positions), or 4 (64 positions: half tiles for launches that fill the chip badly,
+// e.g. one P3 level of one chip = 128 full tiles on 256 CUs; tile index = tile_base + block / 2, half = block & 1)
+template <bool OUT_NHWC, int SRC, int TH = 8>
+__global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict__ x_,
                                                       const float* __restrict__ src_,
                                                       const _Float16* __restrict__ wfrag,
                                                       _Float16* __restrict__ out_, int64_t Ntot_, int C,
@@ -755,7 +762,6 @@ __global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* 
   constexpr int kPatchBytesT = kPHt * kPW * 128;
   constexpr int NPV = kPHt * kPW * 8 / 256;            // 16-byte patch vectors per loader thread (12 | 9)
   static_assert(TH == 8 || TH == 4, "tile height");
-  static_assert(!DUO || TH == 4, "two workgroups per CU: half tiles");
   static_assert(kPHt * kPW * 8 % 256 == 0, "patch vectors must divide among the loader threads");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PTap* s_tab = reinterpret_cast<PTap*>(smem);
@@ -964,31 +970,6 @@ __global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* 
       mma(wv, 3, p1);   __builtin_amdgcn_sched_barrier(0);
     };
     bfrag(0, 0, p0);
-    if constexpr (DUO) {
-      // one fragment set: the fragments of k-step kk of the NEXT stage are requested right behind the MFMAs of k-step
-      // kk of this one (three k-steps and the barrier of latency; the partner workgroup's matrix wave covers the rest)
-      auto load_wk = [&](int st, int kk) {
-        const V* p = wf_base + ((int64_t)st * G + g) * 8 * 64;
-#pragma unroll
-        for (int a = 0; a < 2; a++) wA[a][kk] = p[(a * 4 + kk) * 64];
-      };
-      for (; s < nstage; s++) {
-        const int sx = min(s + 1, last);
-        bfrag(s, 1, p1); __builtin_amdgcn_sched_barrier(0);
-        mma(wA, 0, p0);  __builtin_amdgcn_sched_barrier(0);
-        load_wk(sx, 0);  __builtin_amdgcn_sched_barrier(0);
-        bfrag(s, 2, p0); __builtin_amdgcn_sched_barrier(0);
-        mma(wA, 1, p1);  __builtin_amdgcn_sched_barrier(0);
-        load_wk(sx, 1);  __builtin_amdgcn_sched_barrier(0);
-        bfrag(s, 3, p1); __builtin_amdgcn_sched_barrier(0);
-        mma(wA, 2, p0);  __builtin_amdgcn_sched_barrier(0);
-        load_wk(sx, 2);  __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        bfrag(sx, 0, p0); __builtin_amdgcn_sched_barrier(0);
-        mma(wA, 3, p1);  __builtin_amdgcn_sched_barrier(0);
-        load_wk(sx, 3);  __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
     if (S2A_ABL & 32) load_w(1, wB);     // timing only: the filter fragments of stages 0 / 1 serve every stage
     for (; s + 1 < nstage; s += 2) {
       // (64, timing only: the loads stay but always fetch stages 1 / 0 -- L1 hits: separates issue cost from L2 latency)
@@ -998,7 +979,6 @@ __global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* 
       stage(s + 1, wB);
     }
     if (s < nstage) stage(s, wA);
-    }
 #else
     for (; s + 1 < nstage; s += 2) {
       S2A_TIC();
@@ -1030,7 +1010,7 @@ __global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* 
       }
     };
     auto patch_write = [&](int cc) {
-      char* P = s_patch + (DUO ? 0 : (cc & 1)) * kPatchBytesT;
+      char* P = s_patch + (cc & 1) * kPatchBytesT;
 #pragma unroll
       for (int i = 0; i < NPV; i++) *reinterpret_cast<V*>(P + (L + 256 * i) * 16) = pv[i];
     };
@@ -1041,7 +1021,7 @@ __global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* 
     V c[ITEMS][4];
     auto fetch = [&](int s) {
       const int t = s % 9, cc = s / 9;
-      const char* P = s_patch + (DUO ? 0 : (cc & 1)) * kPatchBytesT + (L & 7) * 16;   // (item & 7 = L & 7 for every item)
+      const char* P = s_patch + (cc & 1) * kPatchBytesT + (L & 7) * 16;   // (item & 7 = L & 7 for every item)
 #pragma unroll
       for (int it = 0; it < ITEMS; it++)      // one 16-byte read per entry
         tp[it] = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[((L + 256 * it) >> 3) * 9 + t]));
@@ -1100,21 +1080,10 @@ __global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* 
       S2A_TIC();
       if (sn < nstage) {
         const int t = sn % 9, cc = sn / 9;
-        if constexpr (DUO) {
-          if (t == 0) fetch(sn);                          // new chunk: its patch was sealed by the previous barrier
-          produce(sn);
-          if (t == 8) {                                   // every fetch of this chunk is behind a barrier: the buffer is free
-            if (cc + 1 < CC) patch_write(cc + 1);
-            if (cc + 2 < CC) patch_issue(cc + 2);
-          } else if (sn + 1 < nstage) {
-            fetch(sn + 1);
-          }
-        } else {
         if (t == 4 && cc + 1 < CC) patch_write(cc + 1);   // loads issued >= 3 stages ago
         produce(sn);
         if (t == 8 && cc + 2 < CC) patch_issue(cc + 2);   // next-next chunk: lands during the next chunk
         if (sn + 1 < nstage) fetch(sn + 1);               // (chunk of stage sn+1: written >= 4 stages ago)
-        }
       }
       S2A_TOC(t_work); S2A_TIC();
       __syncthreads();
@@ -1182,722 +1151,6 @@ __global__ __launch_bounds__(512, DUO ? 4 : 2) void k_dcn_patch(const _Float16* 
             out[(bi * O + och) * HW + p] = (T)v;
           }
         }
-  }
-}
-
-// ------------------------------------------------------------------ ring-3 AlignConv (the pyramid launch's kernel)
-// k_dcn_patch with a THREE-deep ring of column tiles.  Ablations of k_dcn_patch on the pyramid launch (scripts/abl.sh, dense
-// data: bare stage 0.5 k cycles, loaders only 1.36 k, matrix waves only 1.72 k, both 2.12 k for 1.02 k cycles of MFMA)
-// showed the matrix waves stalling ~700 cycles per stage on their own B-fragment reads: a column tile could only be read
-// after the barrier that sealed it, 8 ds_read_b128 at a time, queued behind the loaders' corner-read bursts.  Here
-//   * the loaders run TWO stages ahead (stage s + 2 is blended while stage s is multiplied), so the tile of stage s + 1 is
-//     complete one barrier earlier than it is needed;
-//   * the matrix waves therefore fetch the fragments of k-step q + 1 before the 8 MFMAs of k-step q, ACROSS stage
-//     boundaries (two fragment sets, as before): every read has ~256 cycles to land and none waits behind a barrier
-//     (a third fragment set -- two k-steps ahead -- does not fit 256 VGPRs next to the 128 accumulators and 64 filter
-//     registers: it spilled inside the loop);
-//   * the third 18 KB tile comes out of the patch: 3 halo pixels instead of 4 (14 x 22 pixels per 8 x 16 tile; corners
-//     further out take the global-gather path as before).
-// Same arithmetic, same accumulation order, same staging and stores: results are bit-identical to k_dcn_patch.
-// Needs 9 * C / 64 stages divisible by 6 (C a multiple of 128): the ring (3), the filter double buffer (2) and the
-// tile ring are indexed statically inside a six-stage body.
-constexpr int kHalo3 = 3, kPH3 = 8 + 2 * kHalo3, kPW3 = 16 + 2 * kHalo3;   // 14 x 22
-constexpr int kPatch3Px = kPH3 * kPW3;                                      // 308
-constexpr int kPatch3Pieces = (kPatch3Px * 128 + 1023) / 1024;              // 39 LDS-DMA pieces of 1 KB (8 pixels x 128 B)
-constexpr int kPatch3Bytes = kPatch3Pieces * 1024;                          // 39936 (the last piece is half padding)
-constexpr int kRing3Lds = 128 * 9 * 16 + 3 * 128 * kRowBytes + 2 * kPatch3Bytes;   // 153600 B
-
-template <bool OUT_NHWC, int SRC>
-__global__ __launch_bounds__(512, 2) void k_dcn_ring3(const _Float16* __restrict__ x_,
-                                                      const float* __restrict__ src_,
-                                                      const _Float16* __restrict__ wfrag,
-                                                      _Float16* __restrict__ out_, int64_t Ntot_, int C,
-                                                      int H_, int W_, int O, float stride_, int relu,
-                                                      unsigned x_bytes_, LevelTab lt) {
-  using T = _Float16;
-  using V = f16x8;
-  constexpr int NPOS = 128, NT = 4, ITEMS = 4;
-  constexpr int NPV = (kPatch3Px * 8 + 255) / 256;      // 10 (the last round is partial: 2464 vectors)
-  constexpr int kBTile = NPOS * kRowBytes;              // 18432
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  PTap* s_tab = reinterpret_cast<PTap*>(smem);
-  char* s_B = smem + NPOS * 9 * 16;
-  char* s_patch = s_B + 3 * kBTile;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
-  const T* x = x_;
-  const float* src = src_;
-  T* out = out_;
-  int64_t Ntot = Ntot_;
-  int H = H_, W = W_;
-  float stride = stride_;
-  unsigned x_bytes = x_bytes_;
-  if (SRC == 1 && lt.n > 1) {         // pyramid-packed levels (anchors [sum B*H*W, 5] packed alike)
-    int t0 = 0, p0 = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxLevels; i++)
-      if (i < lt.n && tile >= lt.tile0[i]) {
-        t0 = lt.tile0[i]; p0 = lt.pix0[i]; H = lt.H[i]; W = lt.W[i]; stride = lt.stride[i];
-      }
-    tile -= t0;
-    Ntot = (int64_t)lt.batch * H * W;
-    x += (int64_t)p0 * C;
-    out += (int64_t)p0 * O;
-    src += (int64_t)p0 * 5;
-    x_bytes = (unsigned)(Ntot * C * 2);
-  }
-  const int64_t HW = (int64_t)H * W;
-  const int txn = (W + 15) / 16, tyn = (H + 7) / 8;
-  const int64_t bimg = tile / (txn * tyn);
-  const int trem = (int)(tile % (txn * tyn));
-  const int ty0 = (trem / txn) * 8, tx0 = (trem % txn) * 16;
-  const int oy = ty0 - kHalo3, ox = tx0 - kHalo3;
-  const int o0 = blockIdx.y * kMaxO;
-  const int Oloc = min(kMaxO, O - o0);
-  const int CC = C / 64;
-  const int nstage = 9 * CC;
-  const int G = O / 64;
-  const unsigned row_bytes = (unsigned)C * 2;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
-
-  // ---- loader waves: first patch in flight before anything else.  Patch chunks go global -> LDS by DMA (buffer_load ...
-  // lds: no registers, no ds_write pass): piece = 1 KB = 8 pixels x 128 B, lane l -> pixel l / 8, 16-byte group l % 8;
-  // wave w of the loaders takes pieces w, w + 4, ...; out-of-image pixels (and the padding of the last piece) get an
-  // out-of-range offset -> the bounds-checked load writes zeros.
-  const int L = tid - 256;
-  unsigned pvoff[NPV];
-  auto patch_issue = [&](int cc) {
-    char* P = s_patch + (cc & 1) * kPatch3Bytes;
-#pragma unroll
-    for (int i = 0; i < NPV; i++) {
-      const int piece = (wave - 4) + 4 * i;
-      if (piece < kPatch3Pieces)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(P + piece * 1024), 16,
-                                                 (int)pvoff[i], cc * 128, 0, 0);
-    }
-  };
-  if (wave >= 4) {
-#pragma unroll
-    for (int i = 0; i < NPV; i++) {
-      int v = L + 256 * i, p = v >> 3, q = v & 7;
-      int yy = oy + p / kPW3, xx = ox + p % kPW3;
-      bool in = v < kPatch3Px * 8 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      pvoff[i] = in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
-    }
-    patch_issue(0);
-  }
-
-  // ---- matrix waves: first filter fragments in flight as well
-  const int g = min(o0 / 64 + (wave & 3), G - 1);
-  const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
-  V wA[2][4], wB[2][4];
-  auto load_w = [&](int s, V (&wv)[2][4]) {
-    const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
-  };
-  if (wave < 4) load_w(0, wA);
-
-  // ---- per-position anchor context
-  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);   // B tiles are not in use yet
-  if (SRC == 1 && tid < NPOS) {
-    int y = ty0 + (tid >> 4), xq = tx0 + (tid & 15);
-    AnchorCtx c = {0, 0, 0, 0, 1, 0};
-    if (y < H && xq < W) c = anchor_ctx(src + (bimg * HW + (int64_t)y * W + xq) * 5, stride);
-    s_ctx[tid] = c;
-  }
-  if (SRC == 1) __syncthreads();
-
-  // ---- sampling table
-  for (int e = tid; e < NPOS * 9; e += 512) {
-    int pl = e / 9, t = e % 9;
-    int y = ty0 + (pl >> 4), xq = tx0 + (pl & 15);
-    PTap tp;
-    tp.y = (short)oy;
-    tp.x = (short)ox;
-    tp.flags = 1u;
-#pragma unroll
-    for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
-    if (y < H && xq < W) {
-      const int64_t p = (int64_t)y * W + xq;
-      int ky = t / 3, kx = t % 3;
-      float off_y, off_x;
-      if (SRC == 0) {
-        const float* ob = src + (bimg * 18) * HW + p;
-        off_y = ob[(int64_t)(2 * t) * HW];
-        off_x = ob[(int64_t)(2 * t + 1) * HW];
-      } else {
-        anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
-      }
-      float h_im = (float)(y - 1 + ky) + off_y;
-      float w_im = (float)(xq - 1 + kx) + off_x;
-      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
-        int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
-        bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
-        tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
-        tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
-        tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
-        tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
-        tp.y = (short)h_low;
-        tp.x = (short)w_low;
-        bool in = h_low >= oy && h_low + 1 <= oy + kPH3 - 1 && w_low >= ox && w_low + 1 <= ox + kPW3 - 1;
-        const int py = min(max(h_low - oy, 0), kPH3 - 2), px = min(max(w_low - ox, 0), kPW3 - 2);
-        tp.flags = (in ? 1u : 0u) | ((unsigned)((py * kPW3 + px) * 128) << 1);
-      }
-    }
-    s_tab[e] = tp;
-  }
-  __syncthreads();  // #1 table + patch 0 ready (the DMA is counted in vmcnt, which __syncthreads drains); s_ctx is dead
-
-  f32x16 acc[2][NT];
-  const bool wave_active = wave < 4 && wave * 64 < Oloc;
-  if (wave < 4) {
-    // ===================== matrix waves =====================
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < NT; b++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-    const char* prow0 = s_B + (lane & 31) * kRowBytes + (lane >> 5) * 16;
-    V pf[2][NT];
-    // fragments of k-step q = 4 * stage + kk (tile stage % 3, columns kk * 32 ..): 4 x ds_read_b128
-    auto pf_read = [&](int ring, int kk, V (&f)[NT]) {
-      const char* prow = prow0 + ring * kBTile + kk * 32;
-#pragma unroll
-      for (int h = 0; h < NT; h++) f[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes);
-    };
-    auto mma = [&](const V (&wv)[2][4], int kk, const V (&f)[NT]) {
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < NT; b++)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], f[b], acc[a][b], 0, 0, 0);
-    };
-    const int last = nstage - 1;
-    __syncthreads();  // #2 stages 0 and 1 are in LDS
-    pf_read(0, 0, pf[0]);
-    for (int s0 = 0; s0 < nstage; s0 += 6) {
-#pragma unroll
-      for (int u = 0; u < 6; u++) {
-        const int s = s0 + u;
-        // filters of the next stage (wrap-around at the end: harmless re-load of the last stage)
-        if (u & 1) load_w(min(s + 1, last), wA); else load_w(min(s + 1, last), wB);
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          // k-step q + 1 is requested before the MFMAs of k-step q: kk + 1 of this stage, or kk 0 of the NEXT stage,
-          // whose tile was sealed a barrier ago (after the last stage: a stale tile, read and never used)
-          if (!(S2A_ABL & 16)) {
-            if (kk < 3) pf_read(u % 3, kk + 1, pf[(kk + 1) & 1]); else pf_read((u + 1) % 3, 0, pf[0]);
-          }
-          if (wave_active && !(S2A_ABL & 4)) {
-            if (u & 1) mma(wB, kk, pf[kk & 1]); else mma(wA, kk, pf[kk & 1]);
-          }
-        }
-        // raw barrier: these waves only READ LDS; every read of this stage's tile has been consumed by an MFMA above,
-        // and the one still in flight (k-step 0 of the next stage) targets a tile that is not rewritten next -- a full
-        // __syncthreads() would wait for it (lgkmcnt(0)) and for the filter loads (vmcnt(0)) in front of every barrier.
-        // The loaders' writes are ordered by THEIR __syncthreads() (waitcnt + barrier) on the other side.
-        __builtin_amdgcn_s_barrier();
-      }
-    }
-  } else {
-    // ===================== loader waves =====================
-    // Operands are requested a full stage before they are blended.  The loaders are the critical role (scripts/abl.sh:
-    // without their corner reads the launch is 26 % shorter -- but only when the blend follows; reads alone cost nothing):
-    // a wave on the critical path gets no barrier wait to hide its own LDS latency chain (table entry -> corner
-    // addresses -> 16 corner vectors -> blend), so with one-stage-ahead fetching that chain was exposed in every stage.
-    // Two operand sets (entries + corners) alternate; the entries of stage P + 2 are requested when iteration P starts
-    // and have landed by the time the blend of stage P is done, then its corner reads go out and have a whole
-    // iteration to land.
-    // table entries travel as plain 4-dword vectors (word 0: y | x << 16, word 1: flags, words 2-3: the four f16 weights):
-    // arrays of the PTap struct copied between operand sets were not promoted to registers (field-wise scratch traffic)
-    u32x4 tA[ITEMS], tB[ITEMS], tN[ITEMS];
-    V cA[ITEMS][4], cB[ITEMS][4];
-    auto req_table = [&](int s, u32x4 (&tp)[ITEMS]) {
-      const int t = s % 9;
-#pragma unroll
-      for (int it = 0; it < ITEMS; it++)
-        tp[it] = *reinterpret_cast<const u32x4*>(&s_tab[((L + 256 * it) >> 3) * 9 + t]);
-    };
-    auto req_corners = [&](int s, const u32x4 (&tp)[ITEMS], V (&c)[ITEMS][4]) {
-      if (S2A_ABL & 8) return;
-      const int cc = s / 9;
-      const char* P = s_patch + (cc & 1) * kPatch3Bytes + (L & 7) * 16;
-#pragma unroll
-      for (int it = 0; it < ITEMS; it++) {
-        const char* b0 = P + (tp[it][1] >> 1);
-        c[it][0] = *reinterpret_cast<const V*>(b0);
-        c[it][1] = *reinterpret_cast<const V*>(b0 + 128);
-        c[it][2] = *reinterpret_cast<const V*>(b0 + kPW3 * 128);
-        c[it][3] = *reinterpret_cast<const V*>(b0 + kPW3 * 128 + 128);
-      }
-    };
-    // blend_pk on the packed weights of an entry (same operations, same order: w0*a0, fma w1, fma w2, fma w3)
-    auto blend_e = [&](const V (&v)[4], unsigned w01, unsigned w23) -> V {
-      const f16x2 p01 = __builtin_bit_cast(f16x2, w01), p23 = __builtin_bit_cast(f16x2, w23);
-      const f16x2 w0 = {p01[0], p01[0]}, w1 = {p01[1], p01[1]}, w2 = {p23[0], p23[0]}, w3 = {p23[1], p23[1]};
-      V r;
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        f16x2 a0 = {v[0][2 * e], v[0][2 * e + 1]}, a1 = {v[1][2 * e], v[1][2 * e + 1]};
-        f16x2 a2 = {v[2][2 * e], v[2][2 * e + 1]}, a3 = {v[3][2 * e], v[3][2 * e + 1]};
-        f16x2 acc2 = w0 * a0;
-        acc2 = __builtin_elementwise_fma(w1, a1, acc2);
-        acc2 = __builtin_elementwise_fma(w2, a2, acc2);
-        acc2 = __builtin_elementwise_fma(w3, a3, acc2);
-        r[2 * e] = acc2[0];
-        r[2 * e + 1] = acc2[1];
-      }
-      return r;
-    };
-    auto produce = [&](int s, const u32x4 (&tp)[ITEMS], const V (&c)[ITEMS][4]) {  // columns of stage s -> tile s % 3
-      if (S2A_ABL & 2) return;
-      const int cc = s / 9;
-      char* Bm = s_B + (s % 3) * kBTile;
-      bool any_out = false;
-#pragma unroll
-      for (int it = 0; it < ITEMS; it++) any_out |= !(tp[it][1] & 1u);
-#pragma unroll
-      for (int it = 0; it < ITEMS; it++) {
-        const int item = L + 256 * it, pl = item >> 3, q = item & 7;
-        *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_e(c[it], tp[it][2], tp[it][3]);
-      }
-      if (any_out) {  // rare: a corner left the patch -> global gather for that (position, tap)
-        for (int it = 0; it < ITEMS; it++) {
-          if (tp[it][1] & 1u) continue;
-          const int item = L + 256 * it, pl = item >> 3, q = item & 7;
-          const int ty = (int)(short)(tp[it][0] & 0xffffu), tx = (int)(short)(tp[it][0] >> 16);
-          V g4[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            int yy = min(max(ty + (k >> 1), 0), H - 1), xx = min(max(tx + (k & 1), 0), W - 1);
-            unsigned vo = (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16);
-            u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, cc * 128, 0);
-            g4[k] = __builtin_bit_cast(V, d);
-          }
-          *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_e(g4, tp[it][2], tp[it][3]);
-        }
-      }
-    };
-    // one iteration: blend stage P from its operand set, then refill that set with the operands of stage P + 2.
-    // Patch chunks, by the blended stage P = (cc, t): the DMA of chunk cc + 1 into the other buffer is issued at t == 0
-    // (every wave has blended stage (cc - 1, 8) before the barrier in front of it, so nobody reads that buffer any
-    // more), waited for at t == 5 (vmcnt(0), then two barriers), first read at t == 7 (corners of stage (cc + 1, 0)).
-    auto step = [&](int P, u32x4 (&tp)[ITEMS], V (&c)[ITEMS][4]) {
-      if (P >= nstage) return;
-      const int t = P % 9, cc = P / 9;
-      const bool more = P + 2 < nstage;
-      if (more) req_table(P + 2, tN);
-      if (t == 0 && cc >= 1 && cc + 1 < CC) patch_issue(cc + 1);
-      produce(P, tp, c);
-      if (t == 5 && cc + 1 < CC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (more) {
-#pragma unroll
-        for (int it = 0; it < ITEMS; it++) tp[it] = tN[it];
-        req_corners(P + 2, tp, c);
-      }
-    };
-    // barrier of the loaders: their four tile writes of this iteration must be done; the 16 corner reads issued after
-    // them stay in flight (LDS operations return in order: lgkmcnt(15) retires everything older than the youngest 15;
-    // __syncthreads() would drain them -- and the DMA -- in front of every barrier)
-    auto loader_barrier = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    };
-    if (CC > 1) patch_issue(1);
-    req_table(0, tA);
-    if (nstage > 1) req_table(1, tB);
-    req_corners(0, tA, cA);
-    if (nstage > 1) req_corners(1, tB, cB);
-    step(0, tA, cA);
-    step(1, tB, cB);
-    __syncthreads();  // #2 stages 0 and 1 are in LDS
-    for (int s = 0; s < nstage; s += 2) {
-      step(s + 2, tA, cA);    // stage produced while stage s is multiplied; tile (s + 2) % 3 was read last in stage s - 1
-      loader_barrier();
-      step(s + 3, tB, cB);
-      loader_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  }
-
-  // ===================== epilogue =====================
-  auto out_pos = [&](int pos) -> int64_t {
-    const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
-    const int64_t gpos = bimg * HW + (int64_t)y * W + xq;
-    return (y < H && xq < W && gpos < Ntot) ? gpos : -1;
-  };
-  if constexpr (OUT_NHWC) {
-    char* s_out = s_patch;     // 128 x 528 B = 67 584 <= 2 x 39 424
-    if (wave_active) {
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < NT; b++)
-#pragma unroll
-          for (int rq = 0; rq < 4; rq++) {
-            using h4 = __attribute__((ext_vector_type(4))) _Float16;
-            h4 v4;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              float v = acc[a][b][rq * 4 + e];
-              if (relu) v = fmaxf(v, 0.f);
-              v4[e] = (_Float16)v;
-            }
-            int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
-            int pos = 32 * b + (lane & 31);
-            *reinterpret_cast<h4*>(s_out + pos * kOutRow + och * 2) = v4;
-          }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NPOS / 16; i++) {
-      int idx = tid + 512 * i, pos = idx >> 5, col = idx & 31;
-      int64_t gp = out_pos(pos);
-      if (gp >= 0 && col * 8 < Oloc)
-        *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
-    }
-  } else {
-    if (!wave_active) return;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < NT; b++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          float v = acc[a][b][r];
-          if (relu) v = fmaxf(v, 0.f);
-          int och = o0 + wave * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          int64_t gp = out_pos(32 * b + (lane & 31));
-          if (gp >= 0) {
-            int64_t bi = gp / HW, p = gp % HW;
-            out[(bi * O + och) * HW + p] = (T)v;
-          }
-        }
-  }
-}
-
-// ------------------------------------------------------------------ persistent AlignConv
-// k_dcn_patch<NHWC, anchors> for the pyramid-packed launch, as a PERSISTENT kernel: one workgroup per CU walks tiles
-// bid, bid + grid, ...  A tile of the plain kernel spends ~17 % of its time before the first and after the last MFMA
-// (anchor / patch / filter round trips in a row, then the table, the first column tile, the output tile), and with
-// one 153 KB workgroup per CU nothing overlaps it.  Here the next tile's anchors (MFMA waves) and first patch chunk
-// (loader waves; written to the patch buffer the last chunk does not use) are fetched while the current tile's main
-// loop runs, the filter fragments of stage 0 come from the wrapped-around prefetch of the last stage, and the next
-// tile's anchor contexts are computed while the output tile is stored -- what is left between two main loops is the
-// table build, one column tile and four barriers.  Needs an even number of 64-channel chunks (the next tile's chunk 0
-// and the last chunk of this one must sit in different buffers).  LDS: [table][patch 0][B 0|1][patch 1]; the output
-// tile is staged over B and the head of patch 1, the contexts live in the tail of patch 1.
-// Arithmetic, staging and store order per tile are those of k_dcn_patch: results are bit-identical.
-__global__ __launch_bounds__(512, 2) void k_dcn_patch_persist(const _Float16* __restrict__ x_,
-                                                              const float* __restrict__ src_,
-                                                              const _Float16* __restrict__ wfrag,
-                                                              _Float16* __restrict__ out_, int C, int O, int relu,
-                                                              LevelTab lt, int ntiles) {
-  using T = _Float16;
-  using V = f16x8;
-  constexpr int NPOS = 128, NT = 4, ITEMS = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  PTap* s_tab = reinterpret_cast<PTap*>(smem);
-  char* s_P0 = smem + 128 * 9 * 16;
-  char* s_B = s_P0 + kPatchBytes;
-  char* s_P1 = s_B + 2 * 128 * kRowBytes;
-  char* s_out = s_B;                                                   // 128 x 528 B = 67584 <= 36864 + 49152
-  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_P1 + 40960);       // behind the staged tile (30720 B into patch 1)
-  static_assert(128 * kOutRow <= 2 * 128 * kRowBytes + 40960 && 40960 + 128 * (int)sizeof(AnchorCtx) <= kPatchBytes, "LDS map");
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int o0 = blockIdx.y * kMaxO;
-  const int Oloc = min(kMaxO, O - o0);
-  const int CC = C / 64;
-  const int nstage = 9 * CC;
-  const int G = O / 64;
-  const unsigned row_bytes = (unsigned)C * 2;
-
-  struct Geo {
-    const T* x; const float* src; T* out;
-    int H, W, HW, Ntot, bimg, tile, ty0, tx0, oy, ox;
-    float stride;
-  };
-  auto make_geo = [&](int lin) -> Geo {
-    Geo g;
-    int tile = (int)xcd_remap((unsigned)lin, (unsigned)ntiles);
-    int t0 = 0, p0 = 0;
-    g.H = lt.H[0]; g.W = lt.W[0]; g.stride = lt.stride[0];
-#pragma unroll
-    for (int i = 0; i < kMaxLevels; i++)
-      if (i < lt.n && tile >= lt.tile0[i]) {
-        t0 = lt.tile0[i]; p0 = lt.pix0[i]; g.H = lt.H[i]; g.W = lt.W[i]; g.stride = lt.stride[i];
-      }
-    tile -= t0;
-    g.HW = g.H * g.W;
-    g.Ntot = lt.batch * g.HW;
-    g.x = x_ + (int64_t)p0 * C;
-    g.out = out_ + (int64_t)p0 * O;
-    g.src = src_ + (int64_t)p0 * 5;
-    const int txn = (g.W + 15) / 16, tyn = (g.H + 7) / 8;
-    g.bimg = tile / (txn * tyn);
-    const int trem = tile % (txn * tyn);
-    g.ty0 = (trem / txn) * 8; g.tx0 = (trem % txn) * 16;
-    g.oy = g.ty0 - kHalo; g.ox = g.tx0 - kHalo;
-    g.tile = tile;
-    return g;
-  };
-
-  // ---- loader side: patch element v = L + 256*i: pixel v>>3, 16-byte channel group v&7
-  const int L = tid - 256;
-  unsigned pvoff[12];
-  V pv[12];
-  auto patch_offsets = [&](const Geo& g) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-      int v = L + 256 * i, p = v >> 3, q = v & 7;
-      int yy = g.oy + p / kPW, xx = g.ox + p % kPW;
-      bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-      pvoff[i] = in ? (unsigned)(g.bimg * g.HW + yy * g.W + xx) * row_bytes + q * 16 : 0x80000000u;
-    }
-  };
-  auto patch_issue = [&](const Geo& g, int cc) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.x), 0, (int)((unsigned)g.Ntot * row_bytes), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 12; i++) pv[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, (int)pvoff[i], cc * 128, 0));
-  };
-  auto patch_write = [&](int cc) {
-    char* P = (cc & 1) ? s_P1 : s_P0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) *reinterpret_cast<V*>(P + (L + 256 * i) * 16) = pv[i];
-  };
-
-  // ---- MFMA side: filter fragments; anchors of the tile's 128 positions (threads 0..127; branch-free bounds-checked
-  // loads, zeros outside the image = the neutral context of k_dcn_patch)
-  const int g = min(o0 / 64 + (wave & 3), G - 1);
-  const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
-  V wA[2][4], wB[2][4];
-  auto load_w = [&](int st, V (&wv)[2][4]) {
-    const V* p = wf_base + ((int64_t)st * G + g) * 8 * 64;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
-  };
-  float anc[5];
-  auto anchors_issue = [&](const Geo& gg) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gg.src), 0, (int)((unsigned)gg.Ntot * 20u), 0x00020000);
-    const int y = gg.ty0 + ((tid & 127) >> 4), xq = gg.tx0 + (tid & 15);
-    const bool ok = tid < NPOS && y < gg.H && xq < gg.W;
-    const unsigned off = ok ? (unsigned)(gg.bimg * gg.HW + y * gg.W + xq) * 20u : 0x80000000u;
-#pragma unroll
-    for (int k = 0; k < 5; k++) anc[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 4 * k, 0));
-  };
-
-  int lin = blockIdx.x;
-  const int gstep = gridDim.x;
-  Geo cur = make_geo(lin);
-
-  // ---- first tile: everything in flight at once; contexts and patch chunk 0 into LDS
-  if (wave >= 4) {
-    patch_offsets(cur);
-    patch_issue(cur, 0);
-    patch_write(0);
-  } else {
-    anchors_issue(cur);
-    if (tid < NPOS) s_ctx[tid] = anchor_ctx(anc, cur.stride);
-  }
-  __syncthreads();
-
-  const bool wave_active = wave < 4 && wave * 64 < Oloc;
-  for (;;) {
-    const int H = cur.H, W = cur.W, HW = cur.HW, oy = cur.oy, ox = cur.ox, ty0 = cur.ty0, tx0 = cur.tx0;
-    const bool has_next = lin + gstep < ntiles;
-    // filter fragments of stage 0 (L2-resident): in flight under the table build.  (Keeping them from a wrapped-around
-    // prefetch of the previous tile's last stage costs 32 registers on the loader side of the loop -> scratch spills.)
-    if (wave < 4) load_w(0, wA);
-
-    // ---- sampling table (anchor contexts are in s_ctx; patch chunk 0 is in patch buffer 0)
-    for (int e = tid; e < NPOS * 9; e += 512) {
-      int pl = e / 9, t = e % 9;
-      int y = ty0 + (pl >> 4), xq = tx0 + (pl & 15);
-      PTap tp;
-      tp.y = (short)oy;
-      tp.x = (short)ox;
-      tp.flags = 1u;
-#pragma unroll
-      for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
-      if (y < H && xq < W) {
-        int ky = t / 3, kx = t % 3;
-        float off_y, off_x;
-        anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
-        float h_im = (float)(y - 1 + ky) + off_y;
-        float w_im = (float)(xq - 1 + kx) + off_x;
-        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
-          int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-          float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
-          bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
-          tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
-          tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
-          tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
-          tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
-          tp.y = (short)h_low;
-          tp.x = (short)w_low;
-          bool in = h_low >= oy && h_low + 1 <= oy + kPH - 1 && w_low >= ox && w_low + 1 <= ox + kPW - 1;
-          tp.flags = in ? 1u : 0u;
-        }
-      }
-      s_tab[e] = tp;
-    }
-    __syncthreads();                   // #1 table ready (s_ctx is dead)
-
-    if (wave < 4) {
-      // ===================== MFMA waves =====================
-      f32x16 acc[2][NT];
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < NT; b++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-      if (has_next) {                            // next tile's anchors: land long before the main loop ends
-        const Geo nxt = make_geo(lin + gstep);
-        anchors_issue(nxt);
-      }
-      auto compute = [&](int st, const V (&wv)[2][4]) {
-        if (!wave_active) return;
-        const char* prow = s_B + (st & 1) * (128 * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          V pf[NT];
-#pragma unroll
-          for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
-#pragma unroll
-          for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < NT; b++)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], pf[b], acc[a][b], 0, 0, 0);
-        }
-      };
-      __syncthreads();  // #2 stage 0 columns in LDS
-      for (int st = 0; st < nstage; st += 2) {   // nstage is even (CC is)
-        load_w(st + 1, wB);
-        compute(st, wA);
-        __syncthreads();
-        load_w(min(st + 2, nstage - 1), wA);
-        compute(st + 1, wB);
-        __syncthreads();
-      }
-      // output tile -> LDS (B tiles + head of patch 1: every wave is past its last read of them).  Done inside this
-      // branch so that the accumulators are not live on the loader side of the persistent loop.
-      if (wave_active) {
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-          for (int b = 0; b < NT; b++)
-#pragma unroll
-            for (int rq = 0; rq < 4; rq++) {
-              using h4 = __attribute__((ext_vector_type(4))) _Float16;
-              h4 v4;
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                float v = acc[a][b][rq * 4 + e];
-                if (relu) v = fmaxf(v, 0.f);
-                v4[e] = (_Float16)v;
-              }
-              int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
-              int pos = 32 * b + (lane & 31);
-              *reinterpret_cast<h4*>(s_out + pos * kOutRow + och * 2) = v4;
-            }
-      }
-      if (has_next && tid < NPOS) {       // contexts of the next tile (its anchors arrived during the main loop)
-        const Geo nxt = make_geo(lin + gstep);
-        s_ctx[tid] = anchor_ctx(anc, nxt.stride);
-      }
-    } else {
-      // ===================== loader waves =====================
-      const int64_t pix_base = (int64_t)cur.bimg * HW;
-      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(cur.x), 0, (int)((unsigned)cur.Ntot * row_bytes), 0x00020000);
-      auto produce = [&](int st) {  // columns of stage st -> B[st&1]
-        const int t = st % 9, cc = st / 9;
-        const char* P = (cc & 1) ? s_P1 : s_P0;
-        char* Bm = s_B + (st & 1) * (128 * kRowBytes);
-        PTap tp[ITEMS];
-#pragma unroll
-        for (int it = 0; it < ITEMS; it++) tp[it] = s_tab[((L + 256 * it) >> 3) * 9 + t];
-        V c[ITEMS][4];
-        bool any_out = false;
-#pragma unroll
-        for (int it = 0; it < ITEMS; it++) {
-          const int q = (L + 256 * it) & 7;
-          int py = min(max((int)tp[it].y - oy, 0), kPH - 2), px = min(max((int)tp[it].x - ox, 0), kPW - 2);
-          const char* b0 = P + (py * kPW + px) * 128 + q * 16;
-          c[it][0] = *reinterpret_cast<const V*>(b0);
-          c[it][1] = *reinterpret_cast<const V*>(b0 + 128);
-          c[it][2] = *reinterpret_cast<const V*>(b0 + kPW * 128);
-          c[it][3] = *reinterpret_cast<const V*>(b0 + kPW * 128 + 128);
-          any_out |= !(tp[it].flags & 1u);
-        }
-#pragma unroll
-        for (int it = 0; it < ITEMS; it++) {
-          const int item = L + 256 * it, pl = item >> 3, q = item & 7;
-          const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
-          *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_pk(c[it], cw);
-        }
-        if (any_out) {  // rare: a corner left the patch -> global gather for that (position, tap)
-          for (int it = 0; it < ITEMS; it++) {
-            if (tp[it].flags & 1u) continue;
-            const int item = L + 256 * it, pl = item >> 3, q = item & 7;
-            V g4[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              int yy = min(max((int)tp[it].y + (k >> 1), 0), H - 1), xx = min(max((int)tp[it].x + (k & 1), 0), W - 1);
-              unsigned vo = (unsigned)((pix_base + (int64_t)yy * W + xx) * row_bytes + q * 16);
-              g4[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, cc * 128, 0));
-            }
-            const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
-            *reinterpret_cast<V*>(Bm + pl * kRowBytes + q * 16) = blend_pk(g4, cw);
-          }
-        }
-      };
-      patch_offsets(cur);
-      patch_issue(cur, 1);      // CC >= 2
-      produce(0);
-      __syncthreads();  // #2 stage 0 columns in LDS
-      for (int st = 0; st < nstage; st++) {
-        const int sn = st + 1;          // stage produced while stage st is consumed
-        if (sn < nstage) {
-          const int t = sn % 9, cc = sn / 9;
-          // chunk cc+1 -> its buffer (loads issued >= 3 stages ago); in the last chunk that is chunk 0 of the NEXT tile
-          if (t == 4 && (cc + 1 < CC || has_next)) patch_write(cc + 1);
-          produce(sn);
-          if (t == 8) {
-            if (cc + 2 < CC) patch_issue(cur, cc + 2);      // next-next chunk: lands during the next chunk
-            else if (cc + 2 == CC && has_next) {           // chunk 0 of the next tile
-              const Geo nxt = make_geo(lin + gstep);
-              patch_offsets(nxt);
-              patch_issue(nxt, 0);
-            }
-          }
-        }
-        __syncthreads();
-      }
-    }
-
-    // ===================== epilogue: 512-byte rows of the staged tile stored
-    __syncthreads();   // E1
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      int idx = tid + 512 * i, pos = idx >> 5, col = idx & 31;
-      int64_t gp = tile_pos(cur.tile, pos, 8, H, W, HW, cur.Ntot);
-      if (gp >= 0 && col * 8 < Oloc)
-        *reinterpret_cast<V*>(cur.out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
-    }
-    if (!has_next) break;
-    lin += gstep;
-    cur = make_geo(lin);
-    __syncthreads();   // E2: the staged tile has been read -> B tiles reusable
   }
 }
 
@@ -2507,6 +1760,23 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   }
 }
 
+// CU count of the CURRENT device (cached per device index: a process may drive devices of different size)
+inline int device_cu_count(int* out) {
+  static int cached[64] = {};
+  int dev = 0;
+  S2A_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || cached[dev] == 0) {
+    hipDeviceProp_t prop;
+    S2A_HIP(hipGetDeviceProperties(&prop, dev));
+    const int n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (dev >= 0 && dev < 64) __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);   // (racing writers store the same value)
+    *out = n;
+    return S2A_OK;
+  }
+  *out = cached[dev];
+  return S2A_OK;
+}
+
 template <int NPOS>
 constexpr int mfma_lds_bytes() { return NPOS * 9 * 32 + 2 * (kMaxO + NPOS) * kRowBytes; }  // 110592 / 147456
 
@@ -2610,10 +1880,8 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));                \
     /* timing-only experiment (cdna guide, rocprof section): a zero-record descriptor drops every  \
        buffer load through it while the instruction stream stays; outputs are then wrong */       \
-    const char* drop = getenv("S2A_DCN_DROP");                                                    \
     unsigned xb = (unsigned)x_bytes, wb = (unsigned)w_bytes;                                      \
-    if (drop && strchr(drop, 'x')) xb = 0;                                                        \
-    if (drop && strchr(drop, 'w')) wb = 0;                                                        \
+    S2A_DCN_DROP_SWITCH(xb, wb);                                                                  \
     kern<<<grid, 512, lds, st>>>(x_nhwc, src, wp, out, Ntot, C, H, W, O, stride, relu, xb, wb);   \
   } while (0)
   const char* variant = getenv("S2A_DCN_VARIANT");   // A/B switch for measurements: "ws" | "mfma"
@@ -2624,13 +1892,10 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
   const bool ws_use = ws_ok && !(variant && !strcmp(variant, "mfma"));
   // One 153 KB workgroup per CU: a launch whose 8 x 16 tiles fill the last round badly (one P3 level of ONE chip: 128
   // tiles on 256 CUs, BASELINE configs[1]) runs as 4 x 16 half tiles instead when that needs less time (bit-identical)
-  static int n_cu_fast = 0;
-  if (n_cu_fast == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    S2A_HIP(hipGetDevice(&dev));
-    S2A_HIP(hipGetDeviceProperties(&prop, dev));
-    n_cu_fast = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int n_cu_fast = 0;
+  {
+    int rc_ = device_cu_count(&n_cu_fast);
+    if (rc_ != S2A_OK) return rc_;
   }
   // rounds of one workgroup per CU; a half tile takes ~0.62 of a full one (measured: 128 tiles 44.5 -> 34.8 us as 256 half
   // tiles, but 256 tiles -- exactly one full round -- 50 -> 61 us as 512 half tiles)
@@ -2851,6 +2116,18 @@ extern "C" int64_t s2a_dcn_packed_elems(int64_t out_channels, int64_t channels, 
   // order for the patch-staged kernel)
   return out_channels * channels * 9 * (dtype == S2A_DTYPE_F16 ? 2 : 1);
 }
+
+namespace s2a {
+int build_flags_dcn() {
+  int f = S2A_ABL & 0xff;
+  if (!S2A_MPIPE) f |= 1 << 8;
+  if (S2A_STAMP) f |= 1 << 9;
+#ifdef S2A_MEASURE
+  f |= 1 << 10;
+#endif
+  return f;
+}
+}  // namespace s2a
 
 extern "C" int s2a_debug_read_stamps(unsigned long long* host_dst, int64_t count) {
 #if S2A_STAMP
@@ -3171,86 +2448,15 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
   hipStream_t st = as_stream(stream);
   // s2a_dcn_pack_weight (f16) = stage-major layout followed by the MFMA-fragment layout
   const _Float16* wfrag = (const _Float16*)weight_packed + (size_t)out_channels * channels * 9;
-  // persistent form (one workgroup per CU walking tiles, next tile's anchors / patch prefetched): bit-identical, but
-  // measured SLOWER on MI355X this round (245 vs 232 us on the bench's launch): the loop-carried state pushes the
-  // kernel over 256 VGPRs / 104 SGPRs (scratch + lane spills) and the per-tile level lookup sits on the barrier path.
-  // Opt-in (S2A_DCN_PERSIST=1) until that is fixed.
-  bool persist = false;
-  if (const char* f = getenv("S2A_DCN_PERSIST")) persist = atoi(f) != 0;
-  if (persist && channels % 128 == 0) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      S2A_HIP(hipGetDevice(&dev));
-      S2A_HIP(hipGetDeviceProperties(&prop, dev));
-      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    auto pk = k_dcn_patch_persist;
-    dim3 pgrid((unsigned)std::min<int64_t>(tiles, n_cu), (unsigned)((out_channels + kMaxO - 1) / kMaxO));
-    S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
-    pk<<<pgrid, 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, (int)channels, (int)out_channels,
-                                     relu, lt, (int)tiles);
-    S2A_LAUNCH_CHECK();
-    return S2A_OK;
-  }
+  // (Forms of this launch that were built, tested bit-identical, measured on MI355X and removed again -- DESIGN.md 4 has the
+  // numbers: a persistent workgroup per CU with the next tile's anchors / patch prefetched (245 vs 232 us: spills), a
+  // three-slot column ring with loaders two stages ahead (2-8 % slower), two half-tile workgroups per CU (332 vs 282 us:
+  // the filter streamed twice), half tiles for the last round in a second launch (-1.2 %).)
   const unsigned ogroups = (unsigned)((out_channels + kMaxO - 1) / kMaxO);
-  {
-    // ring-3 variant (loaders two stages ahead with LDS-DMA patches, fragment reads across stage boundaries, raw
-    // barriers): bit-identical, measured 2-8 % SLOWER than k_dcn_patch on MI355X (241 vs 235 us on the bench's launch,
-    // 320 vs 291 us on dense random data) -- the stalls it removes are not what bounds a stage.  Opt-in (S2A_DCN_RING3=1).
-    const char* r3 = getenv("S2A_DCN_RING3");
-    if (channels % 128 == 0 && r3 && atoi(r3) != 0) {
-      auto k3 = k_dcn_ring3<true, 1>;
-      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, kRing3Lds));
-      k3<<<dim3((unsigned)tiles, ogroups), 512, kRing3Lds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
-                                                                 lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu, 0u, lt);
-      S2A_LAUNCH_CHECK();
-      return S2A_OK;
-    }
-  }
-  if (const char* d = getenv("S2A_DCN_DUO"); d && atoi(d) != 0) {
-    // two half-tile workgroups per CU (k_dcn_patch<.., 4, DUO>): see the kernel's header
-    constexpr int kDuoLds = 64 * 9 * 16 + 2 * 64 * kRowBytes + (4 + 2 * kHalo) * kPW * 128;   // 64 512 B
-    auto kd = k_dcn_patch<true, 1, 4, true>;
-    S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, kDuoLds));
-    kd<<<dim3((unsigned)(2 * tiles), ogroups), 512, kDuoLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0,
-                                                                   (int)channels, lt.H[0], lt.W[0], (int)out_channels,
-                                                                   lt.stride[0], relu, 0u, lt, 0);
-    S2A_LAUNCH_CHECK();
-    return S2A_OK;
-  }
   auto kern = k_dcn_patch<true, 1>;
-  // One 153 KB workgroup per CU: a launch runs in rounds of n_cu tiles.  When the last round would fill less than
-  // half of the chip (the bench's 1 368 tiles on 256 CUs: 5 rounds + 88 tiles), those tiles can run as twice as many
-  // 4 x 16 half tiles in a second launch -- half a round instead of a whole one.  Bit-identical; measured gain only
-  // 1.2 % (236.9 -> 234.1 us: a half tile costs ~60 % of a full one and the second launch has its own ramp), so it
-  // is opt-in (S2A_DCN_TAIL=1) and the roofline figure stays one kernel = one launch.
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    S2A_HIP(hipGetDevice(&dev));
-    S2A_HIP(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  int64_t full = tiles, rem = 0;
-  const char* tl = getenv("S2A_DCN_TAIL");
-  if (ogroups == 1 && tiles > n_cu && (tiles % n_cu) * 2 <= n_cu && tl && atoi(tl) != 0) {
-    rem = tiles % n_cu;
-    full = tiles - rem;
-  }
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
-  kern<<<dim3((unsigned)full, ogroups), 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
-                                                              lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu, 0u, lt, 0);
-  if (rem > 0) {
-    constexpr int kHalfLds = 64 * 9 * 16 + 2 * 64 * kRowBytes + 2 * (4 + 2 * kHalo) * kPW * 128;
-    auto kh = k_dcn_patch<true, 1, 4>;
-    S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds));
-    kh<<<dim3((unsigned)(2 * rem), ogroups), 512, kHalfLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
-                                                                  lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu, 0u, lt,
-                                                                  (int)full);
-  }
+  kern<<<dim3((unsigned)tiles, ogroups), 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
+                                                               lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu, 0u, lt, 0);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -2123,6 +2123,16 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
 }  // namespace s2a
 
 namespace s2a {
+int build_flags_rotated() {
+  int f = 0;
+#ifdef S2A_MEASURE
+  f |= 1;
+#endif
+#ifdef S2A_ABL_NOFENCE
+  f |= 2;
+#endif
+  return f;
+}
 // the greedy scan is metric-agnostic: poly_ops.hip (chip-merge NMS on polygon IoU) reuses it
 int launch_nms_scan(const unsigned long long* mask, const uint32_t* seg_start, const uint32_t* num_seg,
                     const unsigned long long* mask_off, const uint32_t* nblk, const int32_t* perm_seg,
@@ -2201,8 +2211,10 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     // workgroups and s_sleep 12 it moves ~3.5 TB/s (113 us at 10 k x 10 k), ends before the chain beside it does (pair
     // finding 62 + exact pass 60-65 us, both at their stand-alone speed) and the call takes ~157 us instead of ~195.
     int fill_wgs = 512, pace = 12;
-    if (const char* fw = getenv("S2A_IOU_FILL_WGS")) fill_wgs = atoi(fw);     // measurements; 0 = no fill (wrong results)
+#ifdef S2A_MEASURE
+    if (const char* fw = getenv("S2A_IOU_FILL_WGS")) fill_wgs = atoi(fw);     // measurement builds only; 0 = no fill (WRONG results)
     if (const char* fp = getenv("S2A_IOU_FILL_PACE")) pace = atoi(fp);
+#endif
     const unsigned long long nm = (unsigned long long)n * (unsigned long long)m;
     if (fill_wgs > 0) {
       if (pace >= 12) k_fill_zero<12><<<fill_wgs, 256, 0, side>>>(ious, nm);

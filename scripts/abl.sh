@@ -7,6 +7,7 @@
 # 32 = filter fragments loaded once, 64 = loaded every stage but from a fixed address (plain kernel, S2A_MPIPE form).  S2A_MPIPE=0: matrix waves without the fragment prefetch.
 # (Skipping LOADS is not a valid ablation: the compiler deletes the arithmetic that consumes undefined values.)
 cd $GRAFT_REPO_ROOT
+export S2A_ALLOW_MEASURE_BUILD=1   # the objects built below carry measurement switches (s2anet_amd/_lib.py refuses them otherwise)
 # whatever happens, the box is left with the DEFAULT build (the Makefile does not track EXTRA)
 restore() { rm -f s2anet_amd/csrc/dcn_ops.o; make -C s2anet_amd/csrc -s 2>&1 | grep -E "error" | head -3; }
 trap restore EXIT

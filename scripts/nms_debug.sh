@@ -1,6 +1,7 @@
 #!/bin/bash
 # measurement build (-DS2A_MEASURE) of rotated_ops on the GPU box's copy: device-side totals of one 200 k-row ml-NMS call
 cd $GRAFT_REPO_ROOT
+export S2A_ALLOW_MEASURE_BUILD=1   # the objects built below carry measurement switches (s2anet_amd/_lib.py refuses them otherwise)
 restore() { rm -f s2anet_amd/csrc/rotated_ops.o; make -C s2anet_amd/csrc -s 2>&1 | grep -E "error" | head -3; }
 trap restore EXIT
 rm -f s2anet_amd/csrc/rotated_ops.o
