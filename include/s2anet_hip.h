@@ -326,6 +326,20 @@ int s2a_deformable_col2im(const void* columns, const void* offset, float* grad_i
 int s2a_deformable_col2im_coord(const void* columns, const void* im, const void* offset, void* grad_offset,
                                 const s2a_dcn_params* p, s2a_stream_t stream);
 
+/* deform_conv_backward_input_cuda (models/dcn/src/deform_conv_cuda.cpp:262-374: gradInput and gradOffset) for f16 tensors
+ * with the AlignConv geometry -- 3x3, stride 1, pad 1, dilation 1, one group, one deformable group, channels % 32 == 0,
+ * out_channels % 16 == 0, out_channels <= 256 -- as ONE fused kernel per call: the column gradient W^T . gradOutput is
+ * formed tile by tile on the matrix cores and consumed in LDS (offset gradient = contraction with the sampled corners,
+ * input gradient = bilinear scatter into an LDS window, flushed with one atomic per touched cell); the reference's
+ * `columns` [C*9, N] never exists.  All tensors NCHW f16 as the reference passes them; grad_input_f32 [S,C,H,W] is
+ * ACCUMULATED (the caller zeroes it, deform_conv.py:88), grad_offset [S,18,H,W] f16 is overwritten. */
+size_t s2a_deform_conv_backward_input_workspace_bytes(int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                                      int64_t out_channels);
+int s2a_deform_conv_backward_input_f16(const void* input, const void* offset, const void* grad_output, const void* weight,
+                                       float* grad_input_f32, void* grad_offset, int64_t batch, int64_t channels,
+                                       int64_t height, int64_t width, int64_t out_channels, void* workspace,
+                                       size_t workspace_bytes, s2a_stream_t stream);
+
 /* A bottleneck's conv2 + conv3 in one launch (models/backbone.py:56-83 with the BatchNorms folded):
  *   out = relu(W3 . relu(conv3x3(x; W2) + b2) + b3 + residual)        x [B,H,W,64] -> out [B,H,W,256], f16 NHWC
  * The 64-map intermediate never leaves the workgroup (LDS); results are bit-identical to s2a_conv_nhwc_f16 (3x3,

@@ -226,6 +226,335 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
   }
 }
 
+// ================================================================= fused input + offset gradient (f16, AlignConv geometry)
+// deform_conv_backward_input_cuda (models/dcn/src/deform_conv_cuda.cpp:262-374) WITHOUT `columns` in HBM.  The reference
+// (and the first version here) materialises columns = W^T x gradOutput [C*9, N] per chunk (604 MB at P3, batch 8), then
+// runs col2im_coord and col2im over it: 9-10 ms, all of it memory traffic and global atomics.  Here ONE workgroup owns a
+// 4 x 16 tile of output positions and walks the 32-channel chunks of the input:
+//   * gradOutput of the tile ([64 pos][O] f16, <= 33 KB) stays in LDS for the whole tile;
+//   * per chunk the eight waves form the column-gradient tiles of all nine taps on the MATRIX CORES
+//     (v_mfma_f32_32x32x16_f16: G[32 c, 32 pos] = sum_o W[o, c, tap] * gO[o, pos], K = O; filter pre-packed in fragment
+//     order, one 1 KB load per k-step) and leave them in LDS as f32 (72 KB);
+//   * (position, 8-channel group, tap) items: the four bilinear corners of the sample are read from an LDS patch of the
+//     input (the forward's patch idea), four 8-channel dot products give the OFFSET gradient (deformable_col2im_coord's sum
+//     over channels, reduced over the four lanes of a position and added to an LDS array);
+//   * the INPUT gradient (deformable_col2im's scatter) is a GATHER: the list of (position, tap, corner, weight)
+//     contributions of every pixel of a 12 x 24 window is built once per tile, and per chunk a thread sums its pixel's list
+//     from the column-gradient tiles -- nine taps and all positions of the tile summed first -- and issues one global f32
+//     atomic per touched cell.
+// Samples whose corners leave the window / patch (offsets beyond its 2-3 pixel slack) take global loads and atomics.
+// HBM traffic per tile: gradOutput once, the input patch once per chunk, the gradient window once per chunk.
+constexpr int kBTH = 4, kBTW = 16, kBPos = kBTH * kBTW, kBHalo = 4;
+constexpr int kBPH = kBTH + 2 * kBHalo, kBPW = kBTW + 2 * kBHalo, kBPix = kBPH * kBPW;   // 12 x 24 = 288
+constexpr int kBCh = 32;                       // input channels per chunk
+constexpr int kBWinRow = kBCh + 1;             // window row in floats (+1: the flush reads it pixel-major)
+constexpr int kBGoRow = 528;                   // bytes per position of the gradOutput tile: 256 halfs + 16 B pad
+using f32x16b = __attribute__((ext_vector_type(16))) float;
+using f16x8b = __attribute__((ext_vector_type(8))) _Float16;
+using f32x4b = __attribute__((ext_vector_type(4))) float;
+
+struct alignas(16) BTap {
+  short y, x;        // top-left bilinear corner (h_low, w_low), image coordinates
+  unsigned flags;    // bit 0: sample valid; bit 1: all four corners inside the LDS window; bits 31..2: window pixel index
+  _Float16 w[4];     // hh*hw, hh*lw, lh*hw, lh*lw; 0 where the corner is outside the image
+};
+
+// weight [O][C][9] f16 -> [tap][C/32][O/16][lane 64][8 halfs]: the A operand of G = W^T . gO
+// lane l, element j of fragment (tap, cc, ks) = W[o = ks*16 + 8*(l>>5) + j][c = cc*32 + (l&31)][tap]
+__global__ void k_pack_weight_bwd(const _Float16* __restrict__ w, int O, int C, _Float16* __restrict__ wp) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)O * C * 9;
+  if (e >= total) return;
+  const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+  int64_t r = e >> 9;
+  const int KS = O / 16, CC = C / kBCh;
+  const int ks = (int)(r % KS);
+  r /= KS;
+  const int cc = (int)(r % CC), t = (int)(r / CC);
+  const int o = ks * 16 + 8 * (lane >> 5) + j, c = cc * kBCh + (lane & 31);
+  wp[e] = w[((int64_t)o * C + c) * 9 + t];
+}
+
+// 32 x 32 tile transpose: [S, C, HW] -> [S, HW, C]
+__global__ __launch_bounds__(256) void k_bwd_nchw_to_nhwc(const _Float16* __restrict__ src, int C, int64_t HW,
+                                                          _Float16* __restrict__ dst) {
+  __shared__ _Float16 tile[32][33];
+  const int64_t b = blockIdx.z, p0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const int64_t p = p0 + tx;
+    if (c < C && p < HW) tile[r][tx] = src[(b * C + c) * HW + p];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t p = p0 + r;
+    const int c = c0 + tx;
+    if (c < C && p < HW) dst[(b * HW + p) * C + c] = tile[tx][r];
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __restrict__ x,        // NHWC [S,H,W,C]
+                                                         const _Float16* __restrict__ go,       // NHWC [S,H,W,O]
+                                                         const _Float16* __restrict__ offset,   // NCHW [S,18,H,W]
+                                                         const _Float16* __restrict__ wpk,
+                                                         float* __restrict__ grad_in,           // NCHW [S,C,H,W] f32, accumulated
+                                                         _Float16* __restrict__ grad_off,       // NCHW [S,18,H,W]
+                                                         int S, int C, int H, int W, int O) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_go = smem;                                                       // [64][kBGoRow]
+  float* s_G = reinterpret_cast<float*>(s_go + kBPos * kBGoRow);            // [9][64][32] f32: column gradient of a chunk
+  char* s_patch = reinterpret_cast<char*>(s_G + 9 * kBPos * kBCh);          // [288][32 halfs]
+  BTap* s_tab = reinterpret_cast<BTap*>(s_patch + kBPix * kBCh * 2);        // [64 * 9]
+  _Float16* s_frac = reinterpret_cast<_Float16*>(s_tab + kBPos * 9);        // [64 * 9][2]: lh, lw
+  float* s_goff = reinterpret_cast<float*>(s_frac + kBPos * 9 * 2);         // [64 * 9][2]
+  unsigned* s_list = reinterpret_cast<unsigned*>(s_goff + kBPos * 9 * 2);   // [64 * 9 * 4]: (tap * 64 + pos) << 16 | weight (f16 bits)
+  unsigned* s_start = s_list + kBPos * 9 * 4;                               // [288 + 1] first list entry of a window pixel
+  unsigned* s_cur = s_start + kBPix + 1;                                    // [288] fill cursors
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int txn = (W + kBTW - 1) / kBTW, tyn = (H + kBTH - 1) / kBTH;
+  int t_ = blockIdx.x;
+  const int tx0 = (t_ % txn) * kBTW;
+  t_ /= txn;
+  const int ty0 = (t_ % tyn) * kBTH, b = t_ / tyn;
+  // window / patch origin: the undeformed samples of the tile and their lower-right corners span rows ty0 - 1 .. ty0 + 5 and
+  // columns tx0 - 1 .. tx0 + 17; the 12 x 24 window leaves 2 pixels of slack above / left and 3 below / right of that
+  const int oy = ty0 - 3, ox = tx0 - 3;
+  const int64_t HW = (int64_t)H * W;
+  const int KS = O / 16, CC = C / kBCh;
+
+  // ---- gradOutput tile -> LDS (positions outside the image: zeros), offset-gradient accumulators, sampling table
+  for (int v = tid; v < kBPos * (O / 8); v += 512) {
+    const int pos = v / (O / 8), ch = v % (O / 8);
+    const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
+    f16x8b d = {};
+    if (y < H && xq < W) d = *reinterpret_cast<const f16x8b*>(go + ((int64_t)b * HW + (int64_t)y * W + xq) * O + ch * 8);
+    *reinterpret_cast<f16x8b*>(s_go + pos * kBGoRow + ch * 16) = d;
+  }
+  for (int e = tid; e < kBPos * 9 * 2; e += 512) s_goff[e] = 0.f;
+  for (int e = tid; e <= kBPix; e += 512) s_start[e] = 0u;
+  for (int e = tid; e < kBPos * 9; e += 512) {
+    const int pos = e / 9, t = e % 9;
+    const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
+    BTap tp;
+    tp.y = 0; tp.x = 0; tp.flags = 0u;
+    for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
+    float lh = 0.f, lw = 0.f;
+    if (y < H && xq < W) {
+      const _Float16* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
+      const float off_y = (float)ob[(int64_t)(2 * t) * HW], off_x = (float)ob[(int64_t)(2 * t + 1) * HW];
+      const float h_im = (float)(y - 1 + t / 3) + off_y, w_im = (float)(xq - 1 + t % 3) + off_x;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {      // (kernel.cu:228 / get_gradient_weight / coordinate_weight)
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        lh = h_im - h_low; lw = w_im - w_low;
+        const float hh = 1 - lh, hw = 1 - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+        tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
+        tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
+        tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
+        tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
+        tp.y = (short)h_low;
+        tp.x = (short)w_low;
+        const bool in = h_low >= oy && h_low + 1 <= oy + kBPH - 1 && w_low >= ox && w_low + 1 <= ox + kBPW - 1;
+        const int py = min(max(h_low - oy, 0), kBPH - 2), px = min(max(w_low - ox, 0), kBPW - 2);
+        tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kBPW + px) << 2);
+      }
+    }
+    s_tab[e] = tp;
+    s_frac[2 * e] = (_Float16)lh;
+    s_frac[2 * e + 1] = (_Float16)lw;
+  }
+  __syncthreads();
+  // ---- the scatter of deformable_col2im turned into a GATHER: which (position, tap, corner) lands on which window pixel
+  // is the same for every channel, so it is sorted out ONCE per tile (2 304 integer LDS atomics) -- every pixel gets the list
+  // of its contributions -- and per chunk a thread sums its pixel's list from the column-gradient tiles and issues one
+  // global atomic per cell.  (The first version added w * G into an f32 LDS window with ds_add_f32, 32 per item: LDS
+  // float atomics retire about a lane every 2-3 cycles, 6.7 ms per P3 x 8 call against 2.5 ms with three quarters of them
+  // skipped.)
+  for (int e = tid; e < kBPos * 9; e += 512) {
+    const BTap tp = s_tab[e];
+    if ((tp.flags & 3u) != 3u) continue;
+    const int pix = (int)(tp.flags >> 2);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if ((float)tp.w[k] != 0.f) atomicAdd(&s_start[pix + (k >> 1) * kBPW + (k & 1) + 1], 1u);
+  }
+  __syncthreads();
+  if (wave == 0) {                               // inclusive scan of the 288 counts (shifted by one: s_start[p + 1])
+    unsigned carry = 0;
+    for (int base = 0; base < kBPix; base += 64) {
+      const int p = base + lane;
+      unsigned v = p < kBPix ? s_start[p + 1] : 0u;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)v, o);
+        if (lane >= o) v += u;
+      }
+      if (p < kBPix) s_start[p + 1] = carry + v;
+      carry += (unsigned)__shfl((int)v, 63);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < kBPix; e += 512) s_cur[e] = s_start[e];
+  __syncthreads();
+  for (int e = tid; e < kBPos * 9; e += 512) {
+    const BTap tp = s_tab[e];
+    if ((tp.flags & 3u) != 3u) continue;
+    const int pix = (int)(tp.flags >> 2), pos = e / 9, t = e % 9;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if ((float)tp.w[k] != 0.f) {
+        const unsigned slot = atomicAdd(&s_cur[pix + (k >> 1) * kBPW + (k & 1)], 1u);
+        s_list[slot] = ((unsigned)(t * kBPos + pos) << 16) | (unsigned)__builtin_bit_cast(unsigned short, tp.w[k]);
+      }
+  }
+
+  // patch of chunk cc: 288 pixels x 4 vectors of 8 channels; vector v -> pixel v >> 2, group v & 3
+  f16x8b pv[3];
+  auto patch_issue = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int v = tid + 512 * i, p = v >> 2, q = v & 3;
+      pv[i] = f16x8b{};
+      if (v < kBPix * 4) {
+        const int yy = oy + p / kBPW, xx = ox + p % kBPW;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+          pv[i] = *reinterpret_cast<const f16x8b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * kBCh + q * 8);
+      }
+    }
+  };
+  auto patch_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int v = tid + 512 * i;
+      if (v < kBPix * 4) *reinterpret_cast<f16x8b*>(s_patch + v * 16) = pv[i];
+    }
+  };
+  patch_issue(0);
+  for (int cc = 0; cc < CC; cc++) {
+    __syncthreads();                             // everybody is done with the previous chunk's patch and column gradient
+    patch_write();
+    if (cc + 1 < CC) patch_issue(cc + 1);        // (in flight under this chunk's work)
+    // ---- column-gradient tiles of the nine taps on the matrix cores: job = (tap, 32-position half), 18 jobs over 8 waves
+    for (int job = wave; job < 18; job += 8) {
+      const int t = job >> 1, ph = job & 1;
+      const f16x8b* ap = reinterpret_cast<const f16x8b*>(wpk) + ((int64_t)(t * CC + cc) * KS) * 64 + lane;
+      const char* bp = s_go + (ph * 32 + (lane & 31)) * kBGoRow + (lane >> 5) * 16;
+      f32x16b acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      for (int k0 = 0; k0 < KS; k0 += 4) {
+        f16x8b a[4], bb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k0 + k < KS) { a[k] = ap[(int64_t)(k0 + k) * 64]; bb[k] = *reinterpret_cast<const f16x8b*>(bp + (k0 + k) * 32); }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k0 + k < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k], bb[k], acc, 0, 0, 0);
+      }
+      // D rows = channels (4 consecutive per register quad), columns = positions
+      float* gp = s_G + (t * kBPos + ph * 32 + (lane & 31)) * kBCh + 4 * (lane >> 5);
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        const f32x4b v4 = {acc[rq * 4], acc[rq * 4 + 1], acc[rq * 4 + 2], acc[rq * 4 + 3]};
+        *reinterpret_cast<f32x4b*>(gp + 8 * rq) = v4;
+      }
+    }
+    __syncthreads();
+    // ---- offset gradient: items (tap, position, 8-channel group); the four lanes of a position are neighbours
+    for (int it = tid; it < 9 * kBPos * 4; it += 512) {
+      const int t = it >> 8, r = it & 255, pos = r >> 2, q = r & 3;
+      const BTap tp = s_tab[pos * 9 + t];
+      if (!(tp.flags & 1u)) continue;            // (the four lanes of a position decide alike)
+      const float* gp = s_G + (t * kBPos + pos) * kBCh + q * 8;
+      float G[8];
+      {
+        const f32x4b g0 = *reinterpret_cast<const f32x4b*>(gp), g1 = *reinterpret_cast<const f32x4b*>(gp + 4);
+        G[0] = g0[0]; G[1] = g0[1]; G[2] = g0[2]; G[3] = g0[3]; G[4] = g1[0]; G[5] = g1[1]; G[6] = g1[2]; G[7] = g1[3];
+      }
+      const bool in = (tp.flags & 2u) != 0u;
+      const int pix = (int)(tp.flags >> 2);
+      f16x8b c4[4];
+      if (in) {
+        const char* p0 = s_patch + (pix * 4 + q) * 16;
+        c4[0] = *reinterpret_cast<const f16x8b*>(p0);
+        c4[1] = *reinterpret_cast<const f16x8b*>(p0 + 64);
+        c4[2] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 64);
+        c4[3] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 64 + 64);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int yy = (int)tp.y + (k >> 1), xx = (int)tp.x + (k & 1);
+          c4[k] = f16x8b{};
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            c4[k] = *reinterpret_cast<const f16x8b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * kBCh + q * 8);
+        }
+      }
+      // get_coordinate_weight (kernel.cu:145-187): corners outside the image hold zeros
+      float d[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a = __builtin_fmaf(G[j], (float)c4[k][j], a);
+        d[k] = a;
+      }
+      const float lh = (float)s_frac[2 * (pos * 9 + t)], lw = (float)s_frac[2 * (pos * 9 + t) + 1];
+      float gh = (1.f - lw) * (d[2] - d[0]) + lw * (d[3] - d[1]);
+      float gw = (1.f - lh) * (d[1] - d[0]) + lh * (d[3] - d[2]);
+      gh += __shfl_xor(gh, 1); gw += __shfl_xor(gw, 1);
+      gh += __shfl_xor(gh, 2); gw += __shfl_xor(gw, 2);
+      if (q == 0) {                              // one owner per (position, tap): plain read-modify-write
+        s_goff[2 * (pos * 9 + t)] += gh;
+        s_goff[2 * (pos * 9 + t) + 1] += gw;
+      }
+      if (!in) {                                 // input gradient of a sample that left the window: straight to memory
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float wk = (float)tp.w[k];
+          if (wk == 0.f) continue;
+          const int yy = (int)tp.y + (k >> 1), xx = (int)tp.x + (k & 1);
+          float* gp2 = grad_in + (((int64_t)b * C + cc * kBCh + q * 8) * H + yy) * W + xx;
+#pragma unroll
+          for (int j = 0; j < 8; j++) atomicAdd(gp2 + (int64_t)j * HW, wk * G[j]);
+        }
+      }
+    }
+    // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels
+    for (int wi = tid; wi < 4 * kBPix; wi += 512) {
+      const int q = wi / kBPix, pix = wi % kBPix;
+      const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
+      if (l0 == l1) continue;
+      float a8[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) a8[j] = 0.f;
+      for (unsigned l = l0; l < l1; l++) {
+        const unsigned ent = s_list[l];
+        const float wk = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent & 0xffffu));
+        const float* gp = s_G + (ent >> 16) * kBCh + q * 8;
+        const f32x4b g0 = *reinterpret_cast<const f32x4b*>(gp), g1 = *reinterpret_cast<const f32x4b*>(gp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { a8[j] = __builtin_fmaf(wk, g0[j], a8[j]); a8[4 + j] = __builtin_fmaf(wk, g1[j], a8[4 + j]); }
+      }
+      const int yy = oy + pix / kBPW, xx = ox + pix % kBPW;      // (pixels outside the image have no list: w = 0 there)
+      float* gp2 = grad_in + (((int64_t)b * C + cc * kBCh + q * 8) * H + yy) * W + xx;
+#pragma unroll
+      for (int j = 0; j < 8; j++) atomicAdd(gp2 + (int64_t)j * HW, a8[j]);
+    }
+  }
+  __syncthreads();
+  // ---- offset gradient of the tile: [S, 18, H, W], channel 2 t = dy, 2 t + 1 = dx
+  for (int i = tid; i < 18 * kBPos; i += 512) {
+    const int ch = i / kBPos, pos = i % kBPos;
+    const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
+    if (y < H && xq < W)
+      grad_off[((int64_t)b * 18 + ch) * HW + (int64_t)y * W + xq] = (_Float16)s_goff[2 * (pos * 9 + (ch >> 1)) + (ch & 1)];
+  }
+}
+
+constexpr int kBwdLds = kBPos * kBGoRow + 9 * kBPos * kBCh * 4 + kBPix * kBCh * 2 + kBPos * 9 * 16 + kBPos * 9 * 4 +
+                        kBPos * 9 * 8 + kBPos * 9 * 4 * 4 + (kBPix + 1) * 4 + kBPix * 4 + 64;   // ~152 KB
+
 int make_geom(const s2a_dcn_params* pp, BwdGeom* g, const char* who) {
   S2A_CHECK_ARG(pp != nullptr, "%s: NULL params", who);
   const s2a_dcn_params& p = *pp;
@@ -310,6 +639,51 @@ extern "C" int s2a_deformable_col2im_coord(const void* columns, const void* im, 
   else
     k_def_col2im_coord<_Float16><<<grid_for(n), 256, 0, st>>>(n, (const _Float16*)columns, (const _Float16*)im,
                                                               (const _Float16*)offset, g, (_Float16*)grad_offset);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+// deform_conv_backward_input_cuda for f16 tensors with the AlignConv geometry (3x3, stride 1, pad 1, dilation 1, one group,
+// one deformable group, C % 32 == 0, O % 16 == 0, O <= 256), fused: see k_dcn_bwd_input.  All tensors NCHW as the reference
+// passes them; grad_input_f32 [S,C,H,W] is ACCUMULATED (caller zeroes it), grad_offset [S,18,H,W] f16 is overwritten.
+// workspace: NHWC copies of input and gradOutput + the fragment-order filter.
+extern "C" size_t s2a_deform_conv_backward_input_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
+                                                                 int64_t width, int64_t out_channels) {
+  return align_up((size_t)(batch * height * width * channels) * 2) + align_up((size_t)(batch * height * width * out_channels) * 2) +
+         align_up((size_t)(out_channels * channels * 9) * 2) + 1024;
+}
+
+extern "C" int s2a_deform_conv_backward_input_f16(const void* input, const void* offset, const void* grad_output,
+                                                  const void* weight, float* grad_input_f32, void* grad_offset,
+                                                  int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                                  int64_t out_channels, void* workspace, size_t workspace_bytes,
+                                                  s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && height >= 3 && width >= 3 && out_channels > 0, "deform_conv_backward_input_f16: bad shape");
+  S2A_CHECK_ARG(channels % kBCh == 0 && out_channels % 16 == 0 && out_channels <= 256,
+                "deform_conv_backward_input_f16: needs channels %% 32 == 0, out_channels %% 16 == 0, out_channels <= 256");
+  S2A_CHECK_ARG(height < (1 << 15) && width < (1 << 15), "deform_conv_backward_input_f16: shape too large");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(input && offset && grad_output && weight && grad_input_f32 && grad_offset, "deform_conv_backward_input_f16: NULL tensor");
+  S2A_CHECK_ARG(workspace_bytes >= s2a_deform_conv_backward_input_workspace_bytes(batch, channels, height, width, out_channels),
+                "deform_conv_backward_input_f16: workspace too small");
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace, workspace_bytes);
+  const int64_t HW = height * width;
+  _Float16* xn = cv.take<_Float16>((size_t)(batch * HW * channels));
+  _Float16* gn = cv.take<_Float16>((size_t)(batch * HW * out_channels));
+  _Float16* wp = cv.take<_Float16>((size_t)(out_channels * channels * 9));
+  S2A_CHECK_ARG(xn && gn && wp, "deform_conv_backward_input_f16: workspace too small");
+  k_bwd_nchw_to_nhwc<<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+      (const _Float16*)input, (int)channels, HW, xn);
+  k_bwd_nchw_to_nhwc<<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+      (const _Float16*)grad_output, (int)out_channels, HW, gn);
+  const int64_t wtotal = out_channels * channels * 9;
+  k_pack_weight_bwd<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, wp);
+  const int64_t tiles = batch * ((height + kBTH - 1) / kBTH) * ((width + kBTW - 1) / kBTW);
+  S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_input_f16: too many tiles");
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
+  k_dcn_bwd_input<<<(unsigned)tiles, 512, kBwdLds, st>>>(xn, gn, (const _Float16*)offset, wp, grad_input_f32, (_Float16*)grad_offset,
+                                                        (int)batch, (int)channels, (int)height, (int)width, (int)out_channels);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

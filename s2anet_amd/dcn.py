@@ -8,6 +8,7 @@
         deformable_groups=1, bias=False).forward(x, offset)      parameter name: ``weight``
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -164,6 +165,21 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
     p = params(step)
     gin32 = torch.zeros((B, C, H, W), dtype=torch.float32, device=x.device)
     goff = torch.empty_like(off)
+    # f16 + AlignConv geometry: ONE fused kernel for the whole batch -- column gradient on the matrix cores, consumed in
+    # LDS, no `columns` tensor (s2a_deform_conv_backward_input_f16); the chunking by im2col_step has nothing to chunk then
+    fused = (x.dtype == torch.float16 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)
+             and group == 1 and deformable_group == 1 and C % 32 == 0 and O % 16 == 0 and O <= 256 and H >= 3 and W >= 3
+             and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
+    if fused:
+        nbytes = L.s2a_deform_conv_backward_input_workspace_bytes(B, C, H, W, O)
+        ws = _lib.workspace(nbytes, x.device, "dcn_bwd")
+        with torch.cuda.device(x.device):
+            _lib.check(L.s2a_deform_conv_backward_input_f16(_lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(w), _lib.ptr(gin32),
+                                                            _lib.ptr(goff), B, C, H, W, O, _lib.ptr(ws), ws.numel(),
+                                                            _lib.stream_ptr(x.device)))
+        gradInput.view(B, C, H, W).add_(gin32.to(gradInput.dtype))
+        gradOffset.view_as(goff).copy_(goff)
+        return 1
     wg = w.view(group, O // group, -1)                                  # [g, O/g, C/g*kh*kw]
     with torch.cuda.device(x.device):
         st = _lib.stream_ptr(x.device)

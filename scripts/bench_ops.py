@@ -107,12 +107,24 @@ def poly_ops(n_nms=20000, n_pairs=2000000):
     return res
 
 
-def dcn_backward(batch=8, H=128, W=128, C=256, O=256, dtype=torch.float32):
-    """deform_conv backward (input + offset + weight gradients) at the P3 AlignConv shape"""
+def dcn_backward(batch=8, H=128, W=128, C=256, O=256, dtype=torch.float32, offsets="align"):
+    """deform_conv backward (input + offset + weight gradients) at the P3 AlignConv shape.  offsets = "align": the offsets
+    AlignConv really produces (SURVEY 8(d) config-2 anchors through get_offset); "wild": N(0, 2 px) on every tap"""
     from s2anet_amd.dcn import deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda
     g = torch.Generator().manual_seed(3)
     x = torch.randn(batch, C, H, W, generator=g).to(dev, dtype)
-    off = (torch.randn(batch, 18, H, W, generator=g) * 2).to(dev, dtype)
+    if offsets == "align":
+        from s2anet_amd.alignconv import AlignConv
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        anc = torch.zeros(batch, H, W, 5)
+        anc[..., 0] = xs * 8 + 3.5 + torch.randn(batch, H, W, generator=g) * 4
+        anc[..., 1] = ys * 8 + 3.5 + torch.randn(batch, H, W, generator=g) * 4
+        anc[..., 2:4] = 32 * torch.exp(torch.randn(batch, H, W, 2, generator=g) * 0.5)
+        anc[..., 4] = (torch.rand(batch, H, W, generator=g) - 0.25) * math.pi
+        from s2anet_amd.alignconv import align_offsets
+        off = align_offsets(anc.to(dev).view(batch, -1, 5), (H, W), 8, 3).to(dtype).contiguous()
+    else:
+        off = (torch.randn(batch, 18, H, W, generator=g) * 2).to(dev, dtype)
     w = (torch.randn(O, C, 3, 3, generator=g) * 0.01).to(dev, dtype)
     go = torch.randn(batch, O, H, W, generator=g).to(dev, dtype)
     gi, goff, gw = torch.zeros_like(x), torch.zeros_like(off), torch.zeros_like(w)
@@ -121,9 +133,10 @@ def dcn_backward(batch=8, H=128, W=128, C=256, O=256, dtype=torch.float32):
     t_in = timeit(lambda: deform_conv_backward_input_cuda(x, off, go, gi, goff, w, None, *args, step), iters=5, warm=2)
     t_w = timeit(lambda: deform_conv_backward_parameters_cuda(x, off, go, gw, None, None, *args, 1.0, step), iters=5, warm=2)
     flops = 2.0 * O * C * 9 * batch * H * W
-    return dict(op="deform_conv backward", dtype=str(dtype).split(".")[-1], batch=batch, hw=[H, W],
+    return dict(op="deform_conv backward", dtype=str(dtype).split(".")[-1], batch=batch, hw=[H, W], offsets=offsets,
                 input_offset_ms=round(t_in * 1e3, 3), weight_ms=round(t_w * 1e3, 3),
-                gemm_tflops_each=round(flops / 1e12, 3), note="columns materialised per chunk as the reference does")
+                gemm_tflops_each=round(flops / 1e12, 3),
+                note="input/offset gradient: fused MFMA + LDS kernel for f16 (no columns); weight gradient and f32: columns per chunk + library GEMM")
 
 
 def assign(n_gt=300):
@@ -219,6 +232,9 @@ if __name__ == "__main__":
         res.append(assign(300)); res.append(assign(32))
     if a.which in ("all", "bwd"):
         res.append(dcn_backward(8, dtype=torch.float32)); res.append(dcn_backward(8, dtype=torch.float16))
+        res.append(dcn_backward(8, dtype=torch.float16, offsets="wild"))
+    if a.which == "bwd16":
+        res.append(dcn_backward(8, dtype=torch.float16))
     if a.which in ("all", "poly"):
         res += poly_ops()
     if a.which == "iou10k":

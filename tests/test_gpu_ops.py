@@ -1406,6 +1406,38 @@ def test_dcn_backward_vs_oracle_and_golden(rng):
         assert np.abs(got.float().cpu().numpy() - ref).max() < 3e-2 * max(1.0, np.abs(ref).max())
 
 
+def test_dcn_backward_input_fused_f16_vs_oracle(rng, monkeypatch):
+    """the fused f16 input / offset gradient (s2a_deform_conv_backward_input_f16: column gradient on the matrix cores,
+    consumed in LDS, no `columns`) against the oracle (deform_conv_cuda.cpp:262-374 restated in f32) on the f16-rounded
+    operands, and against the unfused path (library GEMM + col2im kernels) on the same call: tame offsets (everything
+    inside the LDS window), wild ones (global-atomic path), a ragged image (partly filled tiles), two channel chunks"""
+    from s2anet_amd.dcn import deform_conv_backward_input_cuda
+    for (B, C, H, W, O, amp) in ((2, 64, 19, 45, 32, 0.7), (1, 32, 9, 20, 16, 5.0), (2, 64, 8, 16, 48, 2.0)):
+        xn = rng.standard_normal((B, C, H, W)).astype(np.float16)
+        wn = (rng.standard_normal((O, C, 3, 3)) * 0.1).astype(np.float16)
+        on = (rng.standard_normal((B, 18, H, W)) * amp).astype(np.float16)
+        gn = rng.standard_normal((B, O, H, W)).astype(np.float16)
+        gx, goff, _ = oracle.deform_conv_backward(xn.astype(np.float32), on.astype(np.float32), wn.astype(np.float32),
+                                                  gn.astype(np.float32))
+        outs = {}
+        for mode in ("fused", "unfused"):
+            if mode == "unfused":
+                monkeypatch.setenv("S2A_DCN_BWD_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("S2A_DCN_BWD_UNFUSED", raising=False)
+            gi = torch.zeros(B, C, H, W, device=dev(), dtype=torch.float16)
+            go_ = torch.zeros(B, 18, H, W, device=dev(), dtype=torch.float16)
+            assert deform_conv_backward_input_cuda(cu(xn), cu(on), cu(gn), gi, go_, cu(wn), None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, B) == 1
+            outs[mode] = (gi.float().cpu().numpy(), go_.float().cpu().numpy())
+        for mode, (gi, go_) in outs.items():
+            # f16 outputs; the fused path accumulates in f32 and rounds once (the unfused one keeps f16 columns)
+            tol_i = (4e-3 if mode == "fused" else 2e-2) * max(1.0, np.abs(gx).max())
+            tol_o = (4e-3 if mode == "fused" else 3e-2) * max(1.0, np.abs(goff).max())
+            assert np.abs(gi - gx).max() < tol_i, (mode, (B, C, H, W, O), np.abs(gi - gx).max(), np.abs(gx).max())
+            assert np.abs(go_ - goff).max() < tol_o, (mode, (B, C, H, W, O), np.abs(go_ - goff).max(), np.abs(goff).max())
+        assert np.abs(gx).max() > 0.5 and np.abs(goff).max() > 0.5
+
+
 def test_assign_labels_fused(rng):
     """fused label assignment == the reference's assign_labels (golden from its own Python on its CPU IoU op;
     the two sort branches of the IoU agree on these inputs) and == the oracle on fresh inputs"""
