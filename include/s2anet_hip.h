@@ -340,6 +340,18 @@ int s2a_deform_conv_backward_input_f16(const void* input, const void* offset, co
                                        int64_t height, int64_t width, int64_t out_channels, void* workspace,
                                        size_t workspace_bytes, s2a_stream_t stream);
 
+/* deform_conv_backward_parameters_cuda (models/dcn/src/deform_conv_cuda.cpp:376-489: gradWeight) for f16 tensors with the
+ * AlignConv geometry (channels % 64 == 0, out_channels % 32 == 0, out_channels <= 256), fused: the sampled columns are
+ * formed tile by tile in LDS (bilinear corners from an LDS patch, as the forward does) and contracted with gradOutput over
+ * the POSITIONS on the matrix cores, both operands through gfx950's transposing LDS read; split-K over the position tiles,
+ * f32 atomics into grad_weight_f32 [O,C,3,3] (ACCUMULATED, unscaled: the caller zeroes it and applies `scale`). */
+size_t s2a_deform_conv_backward_weight_workspace_bytes(int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                                       int64_t out_channels);
+int s2a_deform_conv_backward_weight_f16(const void* input, const void* offset, const void* grad_output,
+                                        float* grad_weight_f32, int64_t batch, int64_t channels, int64_t height,
+                                        int64_t width, int64_t out_channels, void* workspace, size_t workspace_bytes,
+                                        s2a_stream_t stream);
+
 /* A bottleneck's conv2 + conv3 in one launch (models/backbone.py:56-83 with the BatchNorms folded):
  *   out = relu(W3 . relu(conv3x3(x; W2) + b2) + b3 + residual)        x [B,H,W,64] -> out [B,H,W,256], f16 NHWC
  * The 64-map intermediate never leaves the workgroup (LDS); results are bit-identical to s2a_conv_nhwc_f16 (3x3,

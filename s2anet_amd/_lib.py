@@ -89,6 +89,8 @@ SYMBOLS = {
     "s2a_debug_read_stamps": (c_int, [c_vp, c_i64]),
     "s2a_build_flags": (c_int, []),
     "s2a_deform_conv_backward_input_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "s2a_deform_conv_backward_weight_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "s2a_deform_conv_backward_weight_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
     "s2a_deform_conv_backward_input_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64,
                                            c_vp, c_sz, c_vp]),
     "s2a_deformable_im2col": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(DcnParams), c_vp]),

@@ -555,6 +555,216 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
 constexpr int kBwdLds = kBPos * kBGoRow + 9 * kBPos * kBCh * 4 + kBPix * kBCh * 2 + kBPos * 9 * 16 + kBPos * 9 * 4 +
                         kBPos * 9 * 8 + kBPos * 9 * 4 * 4 + (kBPix + 1) * 4 + kBPix * 4 + 64;   // ~152 KB
 
+// ================================================================= fused weight gradient (f16, AlignConv geometry)
+// deform_conv_backward_parameters_cuda (deform_conv_cuda.cpp:376-489): gradWeight[o, c, tap] = sum over positions of
+// gradOutput[o, p] * columns[c, tap, p].  The reference (and the first version here) writes the sampled columns
+// [C*9, N] to HBM (604 MB at P3, batch 8) and runs a GEMM over them.  Here the contraction index is the POSITION, so both
+// MFMA operands would have to be read "down the rows" of their natural LDS images ([position][channel] columns as the
+// forward's loaders make them, [position][out channel] gradOutput as it sits in NHWC memory): gfx950's transposing LDS
+// read ds_read_b64_tr_b16 delivers exactly that -- four consecutive positions of one channel per lane -- so neither tile is
+// ever transposed in software.
+//   * a workgroup owns ONE 64-channel chunk and ONE row of three taps and a slice of the position tiles (split-K: 21 slices
+//     x 12 owners = 252 workgroups on 256 CUs); its 3 x [O x 64] f32 results stay in registers over all its tiles
+//     (8 waves x 6 accumulator tiles) and go out once, as global f32 atomics;
+//   * per 4 x 16 position tile: gradOutput tile and the input patch of the chunk arrive in LDS (the NEXT tile's are already
+//     in flight in registers), the eight waves blend the three taps' column tiles into LDS (bilinear corners from the patch,
+//     as the forward does), then read both operands with transposing reads: 24 MFMAs per wave and tile.
+constexpr int kWPos = 64;                       // positions per tile (4 x 16)
+constexpr int kWColRow = 192;                   // bytes per position of a column tile: 64 halfs + pad (pitch = 48 dwords: the four
+                                                // rows of a transposing read fall into four different 16-bank groups)
+constexpr int kWPatchPix = kBPix;               // 12 x 24 window, 128 B per pixel (64 channels)
+__device__ __forceinline__ int wgrad_go_pitch(int O) {   // bytes per position of the gradOutput tile: O halfs + pad to 16 (mod 64) dwords
+  const int dw = O / 2;
+  return (dw + ((16 - (dw & 63)) & 63)) * 4;
+}
+using s16x4b = __attribute__((ext_vector_type(4))) short;
+
+__global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __restrict__ x,        // NHWC [S,H,W,C]
+                                                          const _Float16* __restrict__ go,       // NHWC [S,H,W,O]
+                                                          const _Float16* __restrict__ offset,   // NCHW [S,18,H,W]
+                                                          float* __restrict__ grad_w,            // [O][C][9] f32, accumulated
+                                                          int S, int C, int H, int W, int O, int ksplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int gop = wgrad_go_pitch(O);
+  char* s_go = smem;                                          // [64][gop]
+  char* s_patch = s_go + kWPos * gop;                         // [288][128 B]
+  char* s_col = s_patch + kWPatchPix * 128;                   // [3][64][kWColRow]
+  BTap* s_tab = reinterpret_cast<BTap*>(s_col + 3 * kWPos * kWColRow);   // [3 * 64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CC = C / 64;
+  const int owner = blockIdx.x % (3 * CC), slice = blockIdx.x / (3 * CC);
+  const int cc = owner / 3, ky = owner % 3;
+  const int txn = (W + kBTW - 1) / kBTW, tyn = (H + kBTH - 1) / kBTH;
+  const int ntiles = S * tyn * txn;
+  const int64_t HW = (int64_t)H * W;
+  const int OT = O / 32;                                      // out-channel tiles; wave w owns tile w (O <= 256)
+  const bool mwave = wave < OT;
+  f32x16b acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
+
+  // registers that carry the NEXT tile's gradOutput tile and patch (issued a tile ahead)
+  constexpr int kGoVec = 5, kPaVec = 5;                       // 16-byte vectors per thread: 64 * 32 / 512 = 4 (O = 256), 288 * 8 / 512 = 4.5
+  f16x8b gv[kGoVec], pvv[kPaVec];
+  auto tile_geom = [&](int tile, int& b, int& ty0, int& tx0) {
+    tx0 = (tile % txn) * kBTW;
+    const int r = tile / txn;
+    ty0 = (r % tyn) * kBTH;
+    b = r / tyn;
+  };
+  auto issue = [&](int tile) {
+    int b, ty0, tx0;
+    tile_geom(tile, b, ty0, tx0);
+    const int oy = ty0 - 3, ox = tx0 - 3;
+    const int ovec = O / 8;
+#pragma unroll
+    for (int i = 0; i < kGoVec; i++) {
+      const int v = tid + 512 * i;
+      gv[i] = f16x8b{};
+      if (v < kWPos * ovec) {
+        const int pos = v / ovec, ch = v % ovec;
+        const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
+        if (y < H && xq < W) gv[i] = *reinterpret_cast<const f16x8b*>(go + ((int64_t)b * HW + (int64_t)y * W + xq) * O + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kPaVec; i++) {
+      const int v = tid + 512 * i;
+      pvv[i] = f16x8b{};
+      if (v < kWPatchPix * 8) {
+        const int p = v >> 3, q = v & 7;
+        const int yy = oy + p / kBPW, xx = ox + p % kBPW;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+          pvv[i] = *reinterpret_cast<const f16x8b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8);
+      }
+    }
+  };
+  auto land = [&]() {
+    const int ovec = O / 8;
+#pragma unroll
+    for (int i = 0; i < kGoVec; i++) {
+      const int v = tid + 512 * i;
+      if (v < kWPos * ovec) *reinterpret_cast<f16x8b*>(s_go + (v / ovec) * gop + (v % ovec) * 16) = gv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kPaVec; i++) {
+      const int v = tid + 512 * i;
+      if (v < kWPatchPix * 8) *reinterpret_cast<f16x8b*>(s_patch + v * 16) = pvv[i];
+    }
+  };
+
+  int tile = slice;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += ksplit) {
+    int b, ty0, tx0;
+    tile_geom(tile, b, ty0, tx0);
+    const int oy = ty0 - 3, ox = tx0 - 3;
+    __syncthreads();                             // the previous tile's operands have been read
+    land();
+    if (tid < 3 * kWPos) {                       // sampling table of this tile's three taps
+      const int tl = tid / kWPos, pos = tid % kWPos, t = ky * 3 + tl;
+      const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
+      BTap tp;
+      tp.y = 0; tp.x = 0; tp.flags = 0u;
+      for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
+      if (y < H && xq < W) {
+        const _Float16* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
+        const float off_y = (float)ob[(int64_t)(2 * t) * HW], off_x = (float)ob[(int64_t)(2 * t + 1) * HW];
+        const float h_im = (float)(y - 1 + ky) + off_y, w_im = (float)(xq - 1 + tl) + off_x;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+          const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+          tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
+          tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
+          tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
+          tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
+          tp.y = (short)h_low;
+          tp.x = (short)w_low;
+          const bool in = h_low >= oy && h_low + 1 <= oy + kBPH - 1 && w_low >= ox && w_low + 1 <= ox + kBPW - 1;
+          const int py = min(max(h_low - oy, 0), kBPH - 2), px = min(max(w_low - ox, 0), kBPW - 2);
+          tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kBPW + px) << 2);
+        }
+      }
+      s_tab[tid] = tp;
+    }
+    __syncthreads();
+    if (tile + ksplit < ntiles) issue(tile + ksplit);      // next tile's loads: in flight under the blend and the MFMAs
+    // ---- column tiles of the three taps: item = (tap, position, 8-channel group)
+    for (int it = tid; it < 3 * kWPos * 8; it += 512) {
+      const int tl = it >> 9, r = it & 511, pos = r >> 3, q = r & 7;
+      const BTap tp = s_tab[tl * kWPos + pos];
+      f16x8b outv = {};
+      if (tp.flags & 1u) {
+        f16x8b c4[4];
+        if (tp.flags & 2u) {
+          const char* p0 = s_patch + ((int)(tp.flags >> 2) * 8 + q) * 16;
+          c4[0] = *reinterpret_cast<const f16x8b*>(p0);
+          c4[1] = *reinterpret_cast<const f16x8b*>(p0 + 128);
+          c4[2] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 128);
+          c4[3] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 128 + 128);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int yy = min(max((int)tp.y + (k >> 1), 0), H - 1), xx = min(max((int)tp.x + (k & 1), 0), W - 1);
+            c4[k] = *reinterpret_cast<const f16x8b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8);
+          }
+        }
+        const float w0 = (float)tp.w[0], w1 = (float)tp.w[1], w2 = (float)tp.w[2], w3 = (float)tp.w[3];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          outv[j] = (_Float16)(w0 * (float)c4[0][j] + w1 * (float)c4[1][j] + w2 * (float)c4[2][j] + w3 * (float)c4[3][j]);
+      }
+      *reinterpret_cast<f16x8b*>(s_col + (tl * kWPos + pos) * kWColRow + q * 16) = outv;
+    }
+    __syncthreads();
+    // ---- gradW tiles += gradOutput^T . columns over the 64 positions: both operands by transposing reads
+    // (lane 16 g + 4 q + p supplies row q, elements 4 p .. 4 p + 3 of its group's 4 x 16 block and receives column
+    // (lane & 15) of the four rows; group g covers rows 8 (g >> 1) + 4 r .. + 3 of the k-step and columns 16 (g & 1) .. + 15)
+    if (mwave) {
+      const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+      const char* a_base = s_go + (8 * (g >> 1) + qq) * gop + (wave * 32 + 16 * (g & 1) + 4 * pp) * 2;
+      const char* b_base = s_col + (8 * (g >> 1) + qq) * kWColRow + (16 * (g & 1) + 4 * pp) * 2;
+#pragma unroll
+      for (int ks = 0; ks < kWPos / 16; ks++) {
+        auto tr = [&](const char* p) {
+          return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4b*)p);
+        };
+        auto frag = [&](const char* p, int pitch) {
+          const s16x4b lo = tr(p + (ks * 16) * pitch), hi = tr(p + (ks * 16 + 4) * pitch);
+          const __attribute__((ext_vector_type(8))) short v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          return __builtin_bit_cast(f16x8b, v);
+        };
+        const f16x8b A = frag(a_base, gop);
+#pragma unroll
+        for (int tl = 0; tl < 3; tl++)
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++) {
+            const f16x8b Bf = frag(b_base + tl * kWPos * kWColRow + ct * 64, kWColRow);
+            acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bf, acc[tl][ct], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // ---- results: rows = out channels (4 consecutive per register quad), columns = channels of the chunk
+  if (mwave) {
+#pragma unroll
+    for (int tl = 0; tl < 3; tl++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int o = wave * 32 + 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5), c = cc * 64 + ct * 32 + (lane & 31);
+          const float v = acc[tl][ct][r];
+          if (v != 0.f) atomicAdd(grad_w + ((int64_t)o * C + c) * 9 + ky * 3 + tl, v);
+        }
+  }
+}
+
 int make_geom(const s2a_dcn_params* pp, BwdGeom* g, const char* who) {
   S2A_CHECK_ARG(pp != nullptr, "%s: NULL params", who);
   const s2a_dcn_params& p = *pp;
@@ -684,6 +894,58 @@ extern "C" int s2a_deform_conv_backward_input_f16(const void* input, const void*
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
   k_dcn_bwd_input<<<(unsigned)tiles, 512, kBwdLds, st>>>(xn, gn, (const _Float16*)offset, wp, grad_input_f32, (_Float16*)grad_offset,
                                                         (int)batch, (int)channels, (int)height, (int)width, (int)out_channels);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+// deform_conv_backward_parameters_cuda for f16 tensors with the AlignConv geometry (as s2a_deform_conv_backward_input_f16;
+// channels % 64 == 0, out_channels % 32 == 0, out_channels <= 256), fused: see k_dcn_bwd_weight.  grad_weight_f32 [O,C,3,3]
+// is ACCUMULATED (unscaled; the caller zeroes it and applies `scale`).  workspace: NHWC copies of input and gradOutput.
+extern "C" size_t s2a_deform_conv_backward_weight_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
+                                                                  int64_t width, int64_t out_channels) {
+  return align_up((size_t)(batch * height * width * channels) * 2) + align_up((size_t)(batch * height * width * out_channels) * 2) + 1024;
+}
+
+extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void* offset, const void* grad_output,
+                                                   float* grad_weight_f32, int64_t batch, int64_t channels, int64_t height,
+                                                   int64_t width, int64_t out_channels, void* workspace,
+                                                   size_t workspace_bytes, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && height >= 3 && width >= 3 && out_channels > 0, "deform_conv_backward_weight_f16: bad shape");
+  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 32 == 0 && out_channels <= 256,
+                "deform_conv_backward_weight_f16: needs channels %% 64 == 0, out_channels %% 32 == 0, out_channels <= 256");
+  S2A_CHECK_ARG(height < (1 << 15) && width < (1 << 15), "deform_conv_backward_weight_f16: shape too large");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(input && offset && grad_output && grad_weight_f32, "deform_conv_backward_weight_f16: NULL tensor");
+  S2A_CHECK_ARG(workspace_bytes >= s2a_deform_conv_backward_weight_workspace_bytes(batch, channels, height, width, out_channels),
+                "deform_conv_backward_weight_f16: workspace too small");
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace, workspace_bytes);
+  const int64_t HW = height * width;
+  _Float16* xn = cv.take<_Float16>((size_t)(batch * HW * channels));
+  _Float16* gn = cv.take<_Float16>((size_t)(batch * HW * out_channels));
+  S2A_CHECK_ARG(xn && gn, "deform_conv_backward_weight_f16: workspace too small");
+  k_bwd_nchw_to_nhwc<<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+      (const _Float16*)input, (int)channels, HW, xn);
+  k_bwd_nchw_to_nhwc<<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+      (const _Float16*)grad_output, (int)out_channels, HW, gn);
+  const int64_t tiles = batch * ((height + kBTH - 1) / kBTH) * ((width + kBTW - 1) / kBTW);
+  S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_weight_f16: too many tiles");
+  const int owners = 3 * (int)(channels / 64);
+  int n_cu = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    S2A_HIP(hipGetDevice(&dev));
+    S2A_HIP(hipGetDeviceProperties(&prop, dev));
+    if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+  }
+  const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, n_cu / owners));
+  const int dw = (int)out_channels / 2;
+  const int gop = (dw + ((16 - (dw & 63)) & 63)) * 4;
+  const int lds = kWPos * gop + kWPatchPix * 128 + 3 * kWPos * kWColRow + 3 * kWPos * 16;
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  k_dcn_bwd_weight<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, (const _Float16*)offset, grad_weight_f32, (int)batch,
+                                                               (int)channels, (int)height, (int)width, (int)out_channels, ksplit);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -207,6 +207,19 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
     L = _lib.lib()
     step, npos = im2col_step, im2col_step * Ho * Wo
     p = params(step)
+    # f16 + AlignConv geometry: ONE fused kernel for the whole batch (columns formed and contracted in LDS, positions as the
+    # MFMA's K through transposing LDS reads, split-K atomics): s2a_deform_conv_backward_weight_f16
+    fused = (x.dtype == torch.float16 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)
+             and group == 1 and deformable_group == 1 and C % 64 == 0 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3
+             and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
+    if fused:
+        acc = torch.zeros((O, C, 3, 3), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(L.s2a_deform_conv_backward_weight_workspace_bytes(B, C, H, W, O), x.device, "dcn_bwd")
+        with torch.cuda.device(x.device):
+            _lib.check(L.s2a_deform_conv_backward_weight_f16(_lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(acc), B, C, H, W, O,
+                                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
+        gradWeight.add_((float(scale) * acc).view_as(gradWeight).to(gradWeight.dtype))
+        return 1
     cols = torch.empty((C * kH * kW, npos), dtype=x.dtype, device=x.device)
     acc = torch.zeros((group, O // group, (C // group) * kH * kW), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):

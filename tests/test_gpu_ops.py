@@ -1438,6 +1438,33 @@ def test_dcn_backward_input_fused_f16_vs_oracle(rng, monkeypatch):
         assert np.abs(gx).max() > 0.5 and np.abs(goff).max() > 0.5
 
 
+def test_dcn_backward_weight_fused_f16_vs_oracle(rng, monkeypatch):
+    """the fused f16 weight gradient (s2a_deform_conv_backward_weight_f16: columns formed in LDS, contracted over the
+    positions on the matrix cores through transposing LDS reads, split-K atomics) against the oracle
+    (deform_conv_cuda.cpp:376-489 restated) on the f16-rounded operands and against the unfused path (im2col + library
+    GEMM): tame and wild offsets, ragged images, one and two channel chunks, fewer out channels than waves, scale"""
+    from s2anet_amd.dcn import deform_conv_backward_parameters_cuda
+    for (B, C, H, W, O, amp, scale) in ((2, 64, 19, 45, 32, 0.7, 1.0), (1, 128, 9, 20, 64, 5.0, 0.5), (3, 64, 8, 16, 256, 2.0, 1.0)):
+        xn = rng.standard_normal((B, C, H, W)).astype(np.float16)
+        on = (rng.standard_normal((B, 18, H, W)) * amp).astype(np.float16)
+        gn = (rng.standard_normal((B, O, H, W)) * 0.5).astype(np.float16)
+        w0 = np.zeros((O, C, 3, 3), np.float32)
+        _, _, gw = oracle.deform_conv_backward(xn.astype(np.float32), on.astype(np.float32), w0, gn.astype(np.float32))
+        gw = gw * scale
+        for mode in ("fused", "unfused"):
+            if mode == "unfused":
+                monkeypatch.setenv("S2A_DCN_BWD_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("S2A_DCN_BWD_UNFUSED", raising=False)
+            gwt = torch.zeros(O, C, 3, 3, device=dev(), dtype=torch.float32)
+            assert deform_conv_backward_parameters_cuda(cu(xn), cu(on), cu(gn), gwt, None, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1,
+                                                        scale, B) == 1
+            err = np.abs(gwt.cpu().numpy() - gw).max()
+            # columns are rounded to f16 either way; the sums run over B * H * W positions in f32
+            assert err < 6e-3 * max(1.0, np.abs(gw).max()), (mode, (B, C, H, W, O), err, np.abs(gw).max())
+        assert np.abs(gw).max() > 1.0
+
+
 def test_assign_labels_fused(rng):
     """fused label assignment == the reference's assign_labels (golden from its own Python on its CPU IoU op;
     the two sort branches of the IoU agree on these inputs) and == the oracle on fresh inputs"""
