@@ -1924,7 +1924,7 @@ inline int count_rows(int64_t n) { return 256 * (int)((n + 256ll * kSegCountBloc
 // in B.perm_glob / B.keyC_s (joined from its side stream).
 int nms_core(const float* dets, const float* scores, const float* labels, const int32_t* seg_ids,
              const int32_t* group_ids, int64_t n, uint32_t num_segments_hint, uint32_t num_groups,
-             float thr, const NmsPlan& pl, NmsBuffers& B, hipStream_t st) {
+             float thr, const NmsPlan& pl, NmsBuffers& B, hipStream_t st, bool side_streams) {
   size_t sz = (size_t)n;
   const unsigned g = grid_for(n);
   const uint32_t ignore_key = num_segments_hint;           // one past the last real segment
@@ -1954,9 +1954,12 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   //   spatial:      prep, B-keys, sort B, seg_count, sp_meta, filter, cull, exact pass, rounds ... | side 0: sort A, pos_meta
   //                                                                                                 | side 1: sort C
   //   score blocks: prep, sort A, seg_count, pos_meta, filter, cull, ...                            | side 1: sort C
-  // Under stream capture everything stays on the caller's stream (S2A_NMS_FORK=0 forces that form: A/B and tests).
-  bool fork = !stream_capturing(st);
-  if (const char* e = std::getenv("S2A_NMS_FORK")) fork = e[0] == '1';
+  // Under stream capture everything stays on the caller's stream (S2A_NMS_FORK=0 / 1 forces either form: A/B and tests).
+  // side_streams: the drop-in ops (one call, the host waits for its count: latency matters) use them; the detector's
+  // segmented call does not -- with three batches in flight the extra queues cost 1.6 % of the end-to-end rate and on one
+  // stream they gain nothing there (the output order is needed right behind the short cull of a detector batch).
+  bool fork = side_streams && !stream_capturing(st);
+  if (const char* e = std::getenv("S2A_NMS_FORK")) fork = e[0] == '1' && !stream_capturing(st);
   SideSet* ss = nullptr;
   if (fork && (spatial || need_c)) {
     int rc = side_set(st, &ss);
@@ -2100,7 +2103,7 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
     set_error("nms_rotated: workspace too small (%zu < %zu)", ws_bytes, cv.off);
     return S2A_EWORKSPACE;
   }
-  int rc = nms_core(dets, scores, labels, nullptr, nullptr, n, 0, 1, thr, pl, B, st);
+  int rc = nms_core(dets, scores, labels, nullptr, nullptr, n, 0, 1, thr, pl, B, st, true);
   if (rc != S2A_OK) return rc;
   {
     const int rows = count_rows(n);
@@ -2624,7 +2627,7 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
   B.edges = reinterpret_cast<uint2*>(base + tbytes);
   B.gq = reinterpret_cast<uint2*>(base + tbytes + ebytes);
   int rc = nms_core(dets, scores, nullptr, segment_ids, group_ids, n, (uint32_t)num_segments,
-                    (uint32_t)num_groups, iou_threshold, pl, B, st);
+                    (uint32_t)num_groups, iou_threshold, pl, B, st, false);
   if (rc != S2A_OK) return rc;
 #ifdef S2A_MEASURE
   { int rc_ = nms_debug_dump(B, n, st); if (rc_ != S2A_OK) return rc_; }
