@@ -285,6 +285,27 @@ def measure_ops(dev, with_cpu=True):
     ops["ml_nms_rotated_200k_x_15"] = {"ms": round(sec * 1e3, 3), "keep": int(keep.numel()), "same_label_pairs": pairs,
                                        "Tpairs_s": round(pairs / sec / 1e12, 3)}
     del d, sc, lab
+    # SURVEY 8(f) row 1 at the AlignConv shape: deform_conv backward, P3 x batch 8, f16, AlignConv-like offsets
+    try:
+        from s2anet_amd.alignconv import align_offsets
+        from s2anet_amd.dcn import deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda
+        Bb = 8
+        xb = torch.randn(Bb, C, H, W, generator=g).to(dev).half()
+        ancb = anc.expand(Bb, -1, -1, -1).contiguous().view(Bb, -1, 5)
+        offb = align_offsets(ancb, (H, W), 8, 3).half().contiguous()
+        wb = w32.to(dev).half()
+        gob = torch.randn(Bb, O, H, W, generator=g).to(dev).half()
+        gi, goff, gw = torch.zeros_like(xb), torch.zeros_like(offb), torch.zeros_like(wb)
+        args = (3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+        t_in = _time_launches(lambda: deform_conv_backward_input_cuda(xb, offb, gob, gi, goff, wb, None, *args, Bb), iters=5)
+        t_w = _time_launches(lambda: deform_conv_backward_parameters_cuda(xb, offb, gob, gw, None, None, *args, 1.0, Bb), iters=5)
+        ops["deform_conv_backward_8x256x128x128_f16"] = {
+            "input_offset_ms": round(t_in * 1e3, 3), "weight_ms": round(t_w * 1e3, 3),
+            "GFLOP_each": round(2.0 * O * C * 9 * Bb * H * W / 1e9, 1),
+            "note": "fused kernels, no columns tensor (host-side tensor conversions included)"}
+        del xb, offb, gob, gi, goff, gw
+    except Exception as e:          # a report, never a reason to lose the line
+        ops["deform_conv_backward_8x256x128x128_f16"] = {"failed": repr(e)}
     if with_cpu:
         try:
             ops["cpu_reference"] = _ops_cpu_figures()

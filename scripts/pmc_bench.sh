@@ -18,7 +18,7 @@ fi
 i=0
 for set in "${SETS[@]}"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ops > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; exit 1; }
   find $OUT/p$i -name "*kernel_trace.csv" -delete
 done
 python $R/scripts/pmc_summary.py $OUT k_dcn_patch > $OUT/summary_k_dcn_patch.txt

@@ -294,7 +294,7 @@ def test_nms_list_overflow_takes_the_direct_path(rng):
     assert ref.sum() < n // 10 and not ref[seg < 0].any()
 
 
-def test_nms_segmented_big_segments_take_the_spatial_path(rng):
+def test_nms_segmented_big_segments_take_the_spatial_path(rng, monkeypatch):
     """the segmented entry point with few, large segments (> 4096 rows on average: Morton order + bounding-box tile
     filter) and with many small ones (blocks in score order, every tile tested) gives the oracle's keep flags either way"""
     from s2anet_amd import _lib
@@ -303,19 +303,21 @@ def test_nms_segmented_big_segments_take_the_spatial_path(rng):
         d = rand_rboxes(rng, n, span=span)
         s = distinct_scores(rng, n)
         seg = rng.integers(0, nseg, n).astype(np.int32)
-        flags = torch.zeros(n, dtype=torch.uint8, device=dev())
         ws = torch.empty(L.s2a_nms_rotated_workspace_bytes(n, n), dtype=torch.uint8, device=dev())
         D, Sc, Sg = cu(d), cu(s), cu(seg)                     # (held: the raw pointers below do not keep them alive)
-        _lib.check(L.s2a_nms_rotated_segmented(_lib.ptr(D), _lib.ptr(Sc), _lib.ptr(Sg), None, n, nseg, 1, 0.5,
-                                               _lib.ptr(flags), None, None, 0, _lib.ptr(ws), ws.numel(),
-                                               _lib.stream_ptr(dev())))
-        got = flags.cpu().numpy().astype(bool)
         ref = np.zeros(n, bool)
         for c in range(nseg):
             idx = np.nonzero(seg == c)[0]
             ref[idx[oracle.nms_rotated(d[idx], s[idx], 0.5)]] = True
-        assert np.array_equal(got, ref), (n, nseg, int((got != ref).sum()))
         assert n // 4 < ref.sum() < n
+        for fork in ("0", "1"):          # one stream (the segmented call's default) and the side-stream form of the drop-in ops
+            monkeypatch.setenv("S2A_NMS_FORK", fork)
+            flags = torch.zeros(n, dtype=torch.uint8, device=dev())
+            _lib.check(L.s2a_nms_rotated_segmented(_lib.ptr(D), _lib.ptr(Sc), _lib.ptr(Sg), None, n, nseg, 1, 0.5,
+                                                   _lib.ptr(flags), None, None, 0, _lib.ptr(ws), ws.numel(),
+                                                   _lib.stream_ptr(dev())))
+            got = flags.cpu().numpy().astype(bool)
+            assert np.array_equal(got, ref), (n, nseg, fork, int((got != ref).sum()))
 
 
 @pytest.mark.parametrize("thr", [0.1, 0.3, 0.5, 0.75])
