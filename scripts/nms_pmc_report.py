@@ -52,7 +52,8 @@ for k in kernels:
     if c.get("SQ_LDS_IDX_ACTIVE"):
         print(f"  LDS: bank-conflict cycles {c['SQ_LDS_BANK_CONFLICT']:.3g} of {c['SQ_LDS_IDX_ACTIVE']:.3g} LDS-array cycles = {c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'] * 100:4.1f} %; "
               f"LDS array busy {c['SQ_LDS_IDX_ACTIVE'] / (cycles * CUS) * 100:4.1f} % of CU cycles")
-    print(f"  HBM: FETCH_SIZE {c['FETCH_SIZE']:.0f} KiB (x2 on gfx950 for wide reads), WRITE_SIZE {c['WRITE_SIZE']:.0f} KiB per dispatch")
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        print(f"  HBM: FETCH_SIZE {c['FETCH_SIZE']:.0f} KiB (x2 on gfx950 for wide reads), WRITE_SIZE {c['WRITE_SIZE']:.0f} KiB per dispatch")
     summary[k] = {"us": round(us, 1), "waves_per_cu": round(waves_in_flight / CUS, 2), "occupancy_pct": round(waves_in_flight / CUS / MAXW * 100, 1),
                   "valu_util_pct": round(c['SQ_ACTIVE_INST_VALU'] * 4 / simd_cycles * 100, 1), "theoretical_waves_per_cu": limit}
 if json_out:
