@@ -45,6 +45,11 @@ namespace {
 #ifndef S2A_STAMP
 #define S2A_STAMP 0
 #endif
+// S2A_CONV_M16 = 0: every convolution on v_mfma_f32_32x32x16_f16 (rounds 1-2); 2: 16x16x32 for the towers with the filter through
+// LDS only; 1 (shipped): for every full-width (OG 4) 1x1 and stride-1 3x3 launch -- A/B builds only
+#ifndef S2A_CONV_M16
+#define S2A_CONV_M16 1
+#endif
 // measurement builds (-DS2A_MEASURE) only: S2A_DCN_DROP=x|w gives the wave-specialised kernel zero-record descriptors (the
 // loads are dropped, the instruction stream stays; OUTPUTS ARE WRONG) -- never compiled into a shipped library
 #ifdef S2A_MEASURE
@@ -1311,11 +1316,17 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   V wt[2][4];                                        // TAIL: this wave's 64 x 64 block of the 1x1 filter
   if constexpr (TAIL) {
     if (tid < 256) tail_bias_v = ex.tail_b[tid];
-    const V* tp = reinterpret_cast<const V*>(ex.tail_w) + lane + (int64_t)wave4 * 8 * 64;
+    if constexpr (S2A_CONV_M16 == 1) {   // 16x16x32 fragments (f = 16-channel tile * 2 + k-step), as the stand-alone 1x1 takes them
+      const V* tp = reinterpret_cast<const V*>(ex.tail_w) + (int64_t)wave4 * 8 * 64 + ((lane >> 4) & 1) * 128 + (lane >> 5) * 32 + (lane & 15);
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+      for (int f = 0; f < 8; f++) wt[f >> 2][f & 3] = tp[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
+    } else {
+      const V* tp = reinterpret_cast<const V*>(ex.tail_w) + lane + (int64_t)wave4 * 8 * 64;
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) wt[a][kk] = tp[(a * 4 + kk) * 64];
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) wt[a][kk] = tp[(a * 4 + kk) * 64];
+    }
   }
   auto patch_issue = [&](int cc) {
     char* P = smem + (cc & 1) * Cfg::kPatchBytes;
@@ -1333,7 +1344,16 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   const int g = min(o0 / 64 + grp, G - 1);
   const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
   V wA[2][4], wB[2][4];
+  constexpr bool M16 = OG == 4 && !TAIL && (TAPS == 1 || SD == 1) && (S2A_CONV_M16 == 1 || (S2A_CONV_M16 == 2 && Cfg::kWLds));
+  constexpr int NB16 = 2 * NT;        // 16-position tiles per wave (8; 4 on the 64-position tiles)
   auto load_w = [&](int s, V (&wv)[2][4]) {
+    if constexpr (M16) {
+      // 16x16x32 fragments out of the same packed filter (lane maps below): fragment f = (16-channel tile f >> 1, k-step f & 1)
+      const V* p = reinterpret_cast<const V*>(wfrag) + ((int64_t)s * G + g) * 8 * 64 + ((lane >> 4) & 1) * 128 + (lane >> 5) * 32 + (lane & 15);
+#pragma unroll
+      for (int f = 0; f < 8; f++) wv[f >> 2][f & 3] = p[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
+      return;
+    }
     const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -1355,17 +1375,57 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     int pix = TAPS == 9 ? SD * ((pl >> 4) * Cfg::kPW + (pl & 15)) : pl;
     fbase[b] = pix * kRowBytes + (lane >> 5) * 16;
   }
+  // full-width layers (OG 4, 128 positions per wave): v_mfma_f32_16x16x32_f16 -- same flops per cycle and the same LDS reads
+  // per flop as 32x32x16, but the chip holds a higher clock on it under load (MI355X_MICROARCH.md, clocks (7): measured here
+  // 187 -> 173 us on the pyramid towers, same box); the wave's 64 x 128 outputs are 4 x 8 tiles of 16 out channels x 16
+  // positions (3x3: one patch row of 16 pixels)
   f32x16 acc[2][NT];
+  f32x4 acc16[M16 ? 4 : 1][M16 ? NB16 : 1];
+  if constexpr (M16) {
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < NT; b++)
+      for (int b = 0; b < NB16; b++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 4; r++) acc16[a][b][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+  }
+  // 16x16x32 lane maps.  Lane l = (i = l & 15, kg = l >> 4).  Its eight k-values are the channel group c(ks, kg) =
+  // {0, 4, 1, 5}[kg] + 2 ks of the 64-channel chunk (any order works as long as A and B agree): within the lane groups a
+  // ds_read_b128 serves per cycle ({0-3,12-15,20-27}, ...) the two k-groups present then sit 64 B = 4 sixteen-byte slots
+  // apart, and with the pixel map pix16 (i in 4..11 -> pixels = 0,1 mod 4, the others -> 2,3 mod 4; pixel pitch 9 slots)
+  // all sixteen slots of a group differ -- conflict-free B reads.  The A fragment comes out of the SAME packed filter as
+  // the 32x32x16 form: (out channel o, channel group c) is the 16 B at ((o>>5)*4 + (c>>1))*1 KB + ((c&1)*32 + (o&31))*16.
+  const int kg16 = lane >> 4, i16 = lane & 15;
+  const int pix16 = (i16 >= 4 && i16 < 12) ? (((i16 - 4) >> 1) * 4 + (i16 & 1))
+                                           : (((i16 & 3) >> 1) * 4 + 2 + (i16 & 1) + (i16 >= 12 ? 8 : 0));
+  const int fbase16 = (TAPS == 9 ? (8 * blk) * Cfg::kPW + pix16 : 128 * blk + pix16) * kRowBytes + (kg16 & 1) * 64 + (kg16 >> 1) * 16;
+  constexpr int kTile16 = (TAPS == 9 ? Cfg::kPW : 16) * kRowBytes;      // LDS distance between a wave's 16-position tiles
+  const int abase16 = (kg16 & 1) * 2048 + ((kg16 >> 1) * 32 + i16) * 16;
 
   auto compute = [&](const char* P, int t, const V (&wv)[2][4]) {
     if (!wave_active) return;
     const int toff = ((t / 3) * Cfg::kPW + (t % 3)) * kRowBytes;
+    if constexpr (M16) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        V pf[NB16];
+#pragma unroll
+        for (int b = 0; b < NB16; b++) pf[b] = *reinterpret_cast<const V*>(P + fbase16 + b * kTile16 + toff + ks * 32);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < NB16; b++)
+            acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[(a * 2 + ks) >> 2][(a * 2 + ks) & 3], pf[b], acc16[a][b], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       V pf[NT];
@@ -1380,6 +1440,10 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   };
 
   const int nstage = TAPS * CC, last = nstage - 1;
+#if S2A_STAMP
+  unsigned long long t_tic = 0, t_work = 0, t_wait = 0;
+  if (Cfg::kWLds && OG == 4) S2A_STAMP_AT(0);
+#endif
   if constexpr (Cfg::kWLds) {
     // 16 x 16 tile, filter through LDS: every tap's 32 KB (this workgroup's 256 out channels, fragment order =
     // contiguous) is DMA-ed once into one of two LDS buffers while the previous tap computes; all eight waves
@@ -1399,6 +1463,24 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     };
     auto compute_wl = [&](const char* P, int t, const char* Wb) {
       const int toff = ((t / 3) * Cfg::kPW + (t % 3)) * kRowBytes;
+      if constexpr (M16) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          V wv[4], pf[NB16];
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+            wv[a] = *reinterpret_cast<const V*>(Wb + grp * 8192 + abase16 + (a >> 1) * 4096 + ks * 1024 + (a & 1) * 256);
+#pragma unroll
+          for (int b = 0; b < NB16; b++)
+            pf[b] = *reinterpret_cast<const V*>(P + fbase16 + b * kTile16 + toff + ks * 32);
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < NB16; b++)
+              acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[a], pf[b], acc16[a][b], 0, 0, 0);
+        }
+        return;
+      }
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         V pf[NT], wv[2];
@@ -1434,7 +1516,9 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     w_issue(0);
     if (tid < 64 * OG) s_bias[tid] = bias_v;
     if constexpr (TAIL) { if (tid < 256) s_bias[64 + tid] = tail_bias_v; }
+    S2A_STAMP_AT(1);
     __syncthreads();
+    S2A_STAMP_AT(2);
     // (Measured dead end, round 2: fragments one k-step ahead in two register sets across taps, the barrier in front of
     // the tap's last k-step with counted vmcnt, DMAs issued behind it -- bit-identical and within noise of this form,
     // 219-225 vs 222 us: at two waves per SIMD the partner wave already covers these waits.  Timing-only ablations of
@@ -1446,10 +1530,17 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
         const int s = cc * 9 + t;
         if (s + 1 < nstage) w_issue(s + 1);
         if (t == 0 && cc + 1 < CC) patch_issue(cc + 1);
+        S2A_TIC();
         compute_wl(Pc, t, wb + (s & 1) * Cfg::kWBuf);
+        S2A_TOC(t_work);
+        S2A_TIC();
         __syncthreads();     // drains this tap's DMAs (vmcnt(0)) and frees the buffers they will overwrite next
+        S2A_TOC(t_wait);
       }
     }
+    S2A_STAMP_AT(3);
+    S2A_STAMP_VAL(6, t_work);
+    S2A_STAMP_VAL(7, t_wait);
     }
   } else {
   patch_issue(0);
@@ -1505,7 +1596,26 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
 
   // ---- epilogue: bias (+ residual) + ReLU; tile staged through LDS, rows stored 16 B per lane
   char* s_out = smem;
-  if (wave_active) {
+  if constexpr (M16) {
+    using h4 = __attribute__((ext_vector_type(4))) _Float16;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      const int och = grp * 64 + 16 * a + 4 * kg16;       // D: row (out channel) = 4 (lane >> 4) + register, column = pixel
+      const h4 bq = *reinterpret_cast<const h4*>(s_bias + och);
+#pragma unroll
+      for (int b = 0; b < NB16; b++) {
+        h4 v4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float v = acc16[a][b][e] + (float)bq[e];
+          if (relu && !residual) v = fmaxf(v, 0.f);
+          v4[e] = (_Float16)v;
+        }
+        const int pos = 128 * blk + 16 * b + pix16;
+        *reinterpret_cast<h4*>(s_out + pos * Cfg::kOutRowB + och * 2) = v4;
+      }
+    }
+  } else if (wave_active) {
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -1528,10 +1638,37 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       }
   }
   __syncthreads();
+#if S2A_STAMP
+  if (Cfg::kWLds && OG == 4) S2A_STAMP_AT(4);
+#endif
   if constexpr (TAIL) {
     // ---- fused 1x1 (64 -> 256) on the staged tile: wave w = out maps 64w..64w+63 x the 128 positions of its block,
     // B fragments from the staged rows (144-byte stride: conflict-free), accumulation order = the stand-alone 1x1's
+    constexpr bool T16 = S2A_CONV_M16 == 1;      // the second GEMM on 16x16x32 MFMAs, as the stand-alone 64 -> 256 1x1
     f32x16 acc3[2][4];
+    f32x4 acc3s[T16 ? 4 : 1][T16 ? 8 : 1];
+    if constexpr (T16) {
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc3s[a][b][r] = 0.f;
+      const char* brow = s_out + (128 * blk + pix16) * Cfg::kOutRowB + (kg16 & 1) * 64 + (kg16 >> 1) * 16;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int bh = 0; bh < 8; bh += 4) {      // four position tiles at a time: the residual prefetch below needs the registers
+          V pf[4];
+#pragma unroll
+          for (int b = 0; b < 4; b++) pf[b] = *reinterpret_cast<const V*>(brow + (bh + b) * 16 * Cfg::kOutRowB + ks * 32);
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+              acc3s[a][bh + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[(a * 2 + ks) >> 2][(a * 2 + ks) & 3], pf[b], acc3s[a][bh + b], 0, 0, 0);
+        }
+    } else {
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -1550,6 +1687,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
         for (int b = 0; b < 4; b++)
           acc3[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt[a][kk], pf[b], acc3[a][b], 0, 0, 0);
     }
+    }
     // residual vectors of the whole tile in flight before the tile is re-staged (issuing them at kernel start was
     // slower: they queue ahead of the patch and the filters on the in-order memory path)
     constexpr int NI2 = Cfg::kPos * 32 / kThreads_;
@@ -1565,6 +1703,21 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       r2[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(ex.tail_res ? off2[i] : 0x80000000u), 0, 0));
     }
     __syncthreads();                       // every wave has read its B fragments: the tile may be overwritten
+    if constexpr (T16) {
+      using h4 = __attribute__((ext_vector_type(4))) _Float16;
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        const int och = wave4 * 64 + 16 * a + 4 * kg16;
+        const h4 bq = *reinterpret_cast<const h4*>(s_bias + 64 + och);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          h4 v4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v4[e] = (_Float16)(acc3s[a][b][e] + (float)bq[e]);
+          *reinterpret_cast<h4*>(s_out + (128 * blk + 16 * b + pix16) * Cfg::kTailRowB + och * 2) = v4;
+        }
+      }
+    } else
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -1758,6 +1911,9 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       *reinterpret_cast<V*>(pool_out_ + gp * (O / 8) + o0 / 8 + q * 8) = res;
     }
   }
+#if S2A_STAMP
+  if (Cfg::kWLds && OG == 4) S2A_STAMP_AT(5);
+#endif
 }
 
 // CU count of the CURRENT device (cached per device index: a process may drive devices of different size)
@@ -2122,6 +2278,7 @@ int build_flags_dcn() {
   int f = S2A_ABL & 0xff;
   if (!S2A_MPIPE) f |= 1 << 8;
   if (S2A_STAMP) f |= 1 << 9;
+  if (S2A_CONV_M16 != 1) f |= 1 << 11;
 #ifdef S2A_MEASURE
   f |= 1 << 10;
 #endif

@@ -819,7 +819,8 @@ def test_conv1x1_half_tiles_match(monkeypatch):
 
 
 def test_conv3x3_wide_layer_filter_through_lds_matches(monkeypatch):
-    """single-level 256-map 3x3 on 16 x 16 tiles with the filter through LDS (S2A_CONV_PH=2) == 8 x 16 tiles"""
+    """single-level 256-map 3x3 on 16 x 16 tiles with the filter through LDS (S2A_CONV_PH=2) == 8 x 16 tiles (both on
+    16x16x32 MFMAs with the same accumulation order)"""
     from s2anet_amd.fused import conv_f16, conv_pack_weight
     g = torch.Generator().manual_seed(12)
     for (B, C, H, W, O) in ((1, 256, 40, 72, 256), (2, 128, 33, 31, 512)):
