@@ -50,6 +50,10 @@ namespace {
 #ifndef S2A_CONV_M16
 #define S2A_CONV_M16 1
 #endif
+// S2A_DCN_M16 = 1: the matrix waves of the patch-staged AlignConv on v_mfma_f32_16x16x32_f16 as well -- A/B builds only
+#ifndef S2A_DCN_M16
+#define S2A_DCN_M16 1
+#endif
 // measurement builds (-DS2A_MEASURE) only: S2A_DCN_DROP=x|w gives the wave-specialised kernel zero-record descriptors (the
 // loads are dropped, the instruction stream stays; OUTPUTS ARE WRONG) -- never compiled into a shipped library
 #ifdef S2A_MEASURE
@@ -838,7 +842,20 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   const int g = min(o0 / 64 + (wave & 3), G - 1);
   const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
   V wA[2][4], wB[2][4];
+  // D16: 16x16x32 MFMAs (lane maps and the reason: k_conv_f16).  Lane = (i = lane & 15, kg = lane >> 4); fragment
+  // f = (16-channel tile f >> 1, k-step f & 1) comes out of the same packed filter; 16-position tile pt = tile row pt, its
+  // pixel for lane i = pix16 (conflict-free ds_read_b128 on the 144-byte rows of the column tile)
+  constexpr bool D16 = S2A_DCN_M16 != 0;
+  const int kg16 = lane >> 4, i16 = lane & 15;
+  const int pix16 = (i16 >= 4 && i16 < 12) ? (((i16 - 4) >> 1) * 4 + (i16 & 1))
+                                           : (((i16 & 3) >> 1) * 4 + 2 + (i16 & 1) + (i16 >= 12 ? 8 : 0));
   auto load_w = [&](int s, V (&wv)[2][4]) {
+    if constexpr (D16) {
+      const V* p = reinterpret_cast<const V*>(wfrag) + ((int64_t)s * G + g) * 8 * 64 + (kg16 & 1) * 128 + (kg16 >> 1) * 32 + i16;
+#pragma unroll
+      for (int f = 0; f < 8; f++) wv[f >> 2][f & 3] = p[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
+      return;
+    }
     const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -908,15 +925,25 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   S2A_STAMP_AT(2);
 
   f32x16 acc[2][NT];
+  f32x4 acc16[D16 ? 4 : 1][D16 ? 2 * NT : 1];
   const bool wave_active = wave < 4 && wave * 64 < Oloc;
   if (wave < 4) {
     // ===================== MFMA waves =====================
+    if constexpr (D16) {
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2 * NT; b++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc16[a][b][r] = 0.f;
+    } else {
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int b = 0; b < NT; b++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    }
     auto compute = [&](int s, const V (&wv)[2][4]) {
       if (!wave_active || (S2A_ABL & 4)) return;
       const char* prow = s_B + (s & 1) * (NPOS * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
@@ -950,13 +977,30 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     // (no branch on wave_active in here: a wave without out-channels computes on clamped filter fragments and drops the
     // result in the epilogue -- a branch would split the basic block and hipcc's waitcnt pass then waits for ALL LDS
     // reads at every join, the prefetched ones included)
+    // D16: step kk = (k-step kk >> 1 of 32 channels, half kk & 1 of the wave's 16-position tiles): NT reads and 4 NT
+    // MFMAs of 16 cycles per step -- the same reads and MFMA cycles per step as the 32x32x16 form, the same pipeline
     auto bfrag = [&](int st, int kk, V (&pf)[NT]) {
+      if constexpr (D16) {
+        const char* prow = s_B + (st & 1) * (NPOS * kRowBytes) + ((kk & 1) * NT * 16 + pix16) * kRowBytes + (kg16 & 1) * 64 + (kg16 >> 1) * 16 + (kk >> 1) * 32;
+#pragma unroll
+        for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 16 * kRowBytes);
+        return;
+      }
       const char* prow = s_B + (st & 1) * (NPOS * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
 #pragma unroll
       for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
     };
     auto mma = [&](const V (&wv)[2][4], int kk, const V (&pf)[NT]) {
       if (S2A_ABL & 4) return;
+      if constexpr (D16) {
+        const int ks = kk >> 1, bh = (kk & 1) * NT;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < NT; b++)
+            acc16[a][bh + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[(a * 2 + ks) >> 2][(a * 2 + ks) & 3], pf[b], acc16[a][bh + b], 0, 0, 0);
+        return;
+      }
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -1110,7 +1154,22 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     // Stage the 128 x 256 tile through LDS (the patch buffers are free now) and store whole
     // 512-byte position rows, 16 B per lane, instead of 2-byte scattered stores.
     char* s_out = s_patch;
-    if (wave_active) {
+    if (D16 && wave_active) {
+      using h4 = __attribute__((ext_vector_type(4))) _Float16;
+#pragma unroll
+      for (int a = 0; a < (D16 ? 4 : 0); a++)
+#pragma unroll
+        for (int b = 0; b < 2 * NT; b++) {
+          h4 v4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float v = acc16[D16 ? a : 0][D16 ? b : 0][e];
+            if (relu) v = fmaxf(v, 0.f);
+            v4[e] = (_Float16)v;
+          }
+          *reinterpret_cast<h4*>(s_out + (16 * b + pix16) * kOutRow + (wave * 64 + 16 * a + 4 * kg16) * 2) = v4;
+        }
+    } else if (wave_active) {
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -1141,6 +1200,24 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     S2A_STAMP_AT(5);
   } else {
     if (!wave_active) return;
+    if constexpr (D16) {
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2 * NT; b++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float v = acc16[a][b][e];
+            if (relu) v = fmaxf(v, 0.f);
+            const int och = o0 + wave * 64 + 16 * a + 4 * kg16 + e;
+            const int64_t gp = out_pos(16 * b + pix16);
+            if (gp >= 0) {
+              int64_t bi = gp / HW, p = gp % HW;
+              out[(bi * O + och) * HW + p] = (T)v;
+            }
+          }
+      return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -2279,6 +2356,7 @@ int build_flags_dcn() {
   if (!S2A_MPIPE) f |= 1 << 8;
   if (S2A_STAMP) f |= 1 << 9;
   if (S2A_CONV_M16 != 1) f |= 1 << 11;
+  if (S2A_DCN_M16 != 1) f |= 1 << 12;
 #ifdef S2A_MEASURE
   f |= 1 << 10;
 #endif
