@@ -2483,6 +2483,13 @@ extern "C" int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const v
       return launch_conv<1, 4, 1, 2>(X, Wf, Bi, R, Y, batch, (int)channels, (int)height, (int)width, Ho, Wo, stride,
                                      (int)out_channels, relu, st);
   }
+#ifdef S2A_MEASURE
+  if (const char* f = getenv("S2A_CONV1_OG")) {     // measurement builds: narrower out-channel groups for the 1x1 layers
+    const int cap = atoi(f);
+    if (cap == 2 && og == 4) return S2A_CONV(1, 2);
+    if (cap == 1) return S2A_CONV(1, 1);
+  }
+#endif
   return og == 4 ? S2A_CONV(1, 4) : (og == 2 ? S2A_CONV(1, 2) : S2A_CONV(1, 1));
 #undef S2A_CONV
 }

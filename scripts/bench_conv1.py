@@ -28,6 +28,13 @@ for (B, C, H, W, O, st, with_res) in shapes:
     for half in ("0", "1"):
         os.environ["S2A_CONV1_HALF"] = half
         res[half] = round(timeit(lambda: conv_f16(x, wp, b, O, 1, st, True, r, out=out)), 1)
+    os.environ["S2A_CONV1_HALF"] = "0"
+    for og in ("2", "1"):          # measurement builds only (-DS2A_MEASURE): narrower out-channel groups
+        os.environ["S2A_CONV1_OG"] = og
+        res["og" + og] = round(timeit(lambda: conv_f16(x, wp, b, O, 1, st, True, r, out=out)), 1)
+    os.environ.pop("S2A_CONV1_OG")
     flops = 2.0 * B * Ho * Wo * C * O
-    print(json.dumps({"shape": [B, C, H, W, O, st], "res": with_res, "us_128": res["0"], "us_64": res["1"],
+    bytes_ = 2.0 * B * (H * W * C + Ho * Wo * O * (2 if with_res else 1)) + 2.0 * C * O
+    print(json.dumps({"shape": [B, C, H, W, O, st], "res": with_res, "us_128": res["0"], "us_64": res["1"], "us_og2": res["og2"],
+                      "us_og1": res["og1"], "floor_us": round(max(flops / 2.5e9, bytes_ / 8e6), 1),
                       "TF_best": round(flops / min(res.values()) / 1e6, 1)}))
