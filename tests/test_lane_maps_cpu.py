@@ -1,0 +1,57 @@
+"""The 16x16x32 lane maps of the convolution / AlignConv kernels (csrc/dcn_ops.hip: pix16, fbase16, abase16) restated on the host:
+every lane's pixel is distinct, the B-fragment and A-fragment ds_read_b128 are conflict-free on the 144-byte rows, and both operands
+address the same 8-channel group of the 64-channel chunk.  A device read of 16 B per lane is served in four groups of 16 lanes
+({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32); a group is conflict-free when its sixteen 16-byte slots differ mod 16."""
+GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+GROUPS += [[l + 32 for l in g] for g in GROUPS]
+ROW = 144            # kRowBytes: 128 B of channels + 16 B pad
+
+
+def pix16(i):
+    return (((i - 4) >> 1) * 4 + (i & 1)) if 4 <= i < 12 else (((i & 3) >> 1) * 4 + 2 + (i & 1) + (8 if i >= 12 else 0))
+
+
+def b_offset(lane, ks):          # byte offset of the lane's B fragment inside a 16-position tile (tap / tile offsets are uniform)
+    i, kg = lane & 15, lane >> 4
+    return pix16(i) * ROW + (kg & 1) * 64 + (kg >> 1) * 16 + ks * 32
+
+
+def a_offset(lane, ot, ks):      # byte offset inside one out-channel group's 8 KB of the packed (32x32x16-ordered) filter
+    i, kg = lane & 15, lane >> 4
+    return (kg & 1) * 2048 + ((kg >> 1) * 32 + i) * 16 + (ot >> 1) * 4096 + ks * 1024 + (ot & 1) * 256
+
+
+def test_pixel_map_is_a_permutation():
+    assert sorted(pix16(i) for i in range(16)) == list(range(16))
+
+
+def test_b_fragment_reads_are_conflict_free():
+    for ks in range(2):
+        for g in GROUPS:
+            assert len({(b_offset(l, ks) // 16) % 16 for l in g}) == 16
+
+
+def test_a_fragment_reads_are_conflict_free():
+    for ot in range(4):
+        for ks in range(2):
+            for g in GROUPS:
+                assert len({(a_offset(l, ot, ks) // 16) % 16 for l in g}) == 16
+
+
+def test_a_and_b_take_the_same_channel_group_and_cover_the_chunk():
+    """packed filter: fragment (a, kk) of a 64-channel group is 1 KB at (a*4 + kk) KB, lane slot = half*32 + row -> element
+    (out channel 32a + row, channels 16kk + 8half .. +7); the 16x16x32 A operand must hand lane (i, kg) of tile ot the row
+    16*ot + i and the channel group the B operand reads for that lane"""
+    seen = set()
+    for ot in range(4):
+        for ks in range(2):
+            for lane in range(64):
+                off = a_offset(lane, ot, ks)
+                frag, slot = off // 1024, (off % 1024) // 16
+                a, kk, half, row = frag // 4, frag % 4, slot // 32, slot % 32
+                assert 32 * a + row == 16 * ot + (lane & 15)
+                cgroup_a = 2 * kk + half
+                cgroup_b = (b_offset(lane, ks) % ROW) // 16
+                assert cgroup_a == cgroup_b
+                seen.add((32 * a + row, cgroup_a))
+    assert len(seen) == 64 * 8          # every (out channel, channel group) of the chunk exactly once per tap
