@@ -50,6 +50,10 @@ namespace {
 #ifndef S2A_CONV_M16
 #define S2A_CONV_M16 1
 #endif
+// S2A_TAIL_EARLY_RES = 1: the fused bottleneck tail (16 x 16 tiles) requests its residual tile before the 3x3 GEMM -- A/B builds only
+#ifndef S2A_TAIL_EARLY_RES
+#define S2A_TAIL_EARLY_RES 1
+#endif
 // S2A_DCN_M16 = 1: the matrix waves of the patch-staged AlignConv on v_mfma_f32_16x16x32_f16 as well -- A/B builds only
 #ifndef S2A_DCN_M16
 #define S2A_DCN_M16 1
@@ -1516,6 +1520,25 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     }
   };
 
+  // fused tail: residual vectors of the whole 256-map tile.  With the filter through LDS (16 x 16 tiles) they are requested
+  // right after the prologue's barrier: the 3x3 GEMM waits on LDS reads only, so the 128 KB are in flight under it and under
+  // the first epilogue instead of in front of the second one (at kernel start they queue ahead of the patch and the
+  // filter on the in-order memory path: measured slower).  Register-filter form: requested behind the second GEMM, as before.
+  constexpr bool kEarlyRes = TAIL && Cfg::kWLds && S2A_TAIL_EARLY_RES;
+  constexpr int NI2 = TAIL ? Cfg::kPos * 32 / kThreads_ : 1;
+  unsigned off2[NI2];
+  V r2[NI2];
+  auto tail_res_issue = [&]() {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(ex.tail_res ? ex.tail_res : ex.tail_out), 0, (int)((uint64_t)Ntot * 256 * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NI2; i++) {
+      const int idx = tid + kThreads_ * i, pos = idx >> 5, col = idx & 31;
+      const int64_t gp = tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot);
+      off2[i] = gp >= 0 ? (unsigned)((gp * 256 + col * 8) * 2) : 0x80000000u;
+      r2[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(ex.tail_res ? off2[i] : 0x80000000u), 0, 0));
+    }
+  };
   const int nstage = TAPS * CC, last = nstage - 1;
 #if S2A_STAMP
   unsigned long long t_tic = 0, t_work = 0, t_wait = 0;
@@ -1585,6 +1608,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       if (tid < 64) s_bias[tid] = bias_v;
       if constexpr (TAIL) { if (tid < 256) s_bias[64 + tid] = tail_bias_v; }
       __syncthreads();
+      if constexpr (kEarlyRes) tail_res_issue();
 #pragma unroll
       for (int t = 0; t < 9; t++) compute_wl(smem, t, wall + t * 8192);
       __syncthreads();
@@ -1767,17 +1791,16 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     }
     // residual vectors of the whole tile in flight before the tile is re-staged (issuing them at kernel start was
     // slower: they queue ahead of the patch and the filters on the in-order memory path)
-    constexpr int NI2 = Cfg::kPos * 32 / kThreads_;
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(ex.tail_res ? ex.tail_res : ex.tail_out), 0, (int)((uint64_t)Ntot * 256 * 2), 0x00020000);
-    unsigned off2[NI2];
-    V r2[NI2];
+    if constexpr (!kEarlyRes) {
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<T*>(ex.tail_res ? ex.tail_res : ex.tail_out), 0, (int)((uint64_t)Ntot * 256 * 2), 0x00020000);
 #pragma unroll
-    for (int i = 0; i < NI2; i++) {
-      const int idx = tid + kThreads_ * i, pos = idx >> 5, col = idx & 31;
-      const int64_t gp = tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot);
-      off2[i] = gp >= 0 ? (unsigned)((gp * 256 + col * 8) * 2) : 0x80000000u;
-      r2[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(ex.tail_res ? off2[i] : 0x80000000u), 0, 0));
+      for (int i = 0; i < NI2; i++) {
+        const int idx = tid + kThreads_ * i, pos = idx >> 5, col = idx & 31;
+        const int64_t gp = tile_pos(tile, pos, Cfg::kTH, Ho, Wo, HWo, Ntot);
+        off2[i] = gp >= 0 ? (unsigned)((gp * 256 + col * 8) * 2) : 0x80000000u;
+        r2[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(ex.tail_res ? off2[i] : 0x80000000u), 0, 0));
+      }
     }
     __syncthreads();                       // every wave has read its B fragments: the tile may be overwritten
     if constexpr (T16) {
@@ -1811,6 +1834,20 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
         }
       }
     __syncthreads();
+    // chained conv1: its 16 filter fragments are requested here, in front of the residual add / store pass (they were
+    // loaded behind it, one exposed L2 round trip per tile in front of the third GEMM)
+    const int O3 = ex.chain_O, MT = max(O3 / 32, 1);                // 2 | 4 m-tiles
+    const int nper = (Cfg::kPos / 32) * MT / Cfg::kWaves;          // 32-position tiles per wave: 2 | 4
+    const int mt = wave % MT, nt0 = (wave / MT) * nper;
+    const int G3 = O3 / 64;
+    V aw[16];
+    if (S2A_TAIL_EARLY_RES && ex.chain_w) {
+      const V* cwp = reinterpret_cast<const V*>(ex.chain_w) + lane + ((mt >> 1) * 8 + (mt & 1) * 4) * 64;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) aw[c4 * 4 + kk] = cwp[(c4 * G3 * 8 + kk) * 64];
+    }
 #pragma unroll
     for (int i = 0; i < NI2; i++) {
       const int idx = tid + kThreads_ * i, pos = idx >> 5, col = idx & 31;
@@ -1828,16 +1865,13 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       // (first block of the next stage).  wave = (m-tile, a run of 32-position tiles); B fragments from the staged
       // rows (528-byte stride: conflict-free), the 16 filter fragments of the m-tile straight from L2; K order =
       // the stand-alone 1x1 kernel's (chunk, k-step).
-      const int O3 = ex.chain_O, MT = O3 / 32;                       // 2 | 4 m-tiles
-      const int nper = (Cfg::kPos / 32) * MT / Cfg::kWaves;          // 32-position tiles per wave: 2 | 4
-      const int mt = wave % MT, nt0 = (wave / MT) * nper;
-      const int G3 = O3 / 64;
-      V aw[16];
-      const V* cwp = reinterpret_cast<const V*>(ex.chain_w) + lane + ((mt >> 1) * 8 + (mt & 1) * 4) * 64;
+      if (!S2A_TAIL_EARLY_RES) {
+        const V* cwp = reinterpret_cast<const V*>(ex.chain_w) + lane + ((mt >> 1) * 8 + (mt & 1) * 4) * 64;
 #pragma unroll
-      for (int c4 = 0; c4 < 4; c4++)
+        for (int c4 = 0; c4 < 4; c4++)
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) aw[c4 * 4 + kk] = cwp[(c4 * G3 * 8 + kk) * 64];
+          for (int kk = 0; kk < 4; kk++) aw[c4 * 4 + kk] = cwp[(c4 * G3 * 8 + kk) * 64];
+      }
       f32x16 c2[4];
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -2357,6 +2391,7 @@ int build_flags_dcn() {
   if (S2A_STAMP) f |= 1 << 9;
   if (S2A_CONV_M16 != 1) f |= 1 << 11;
   if (S2A_DCN_M16 != 1) f |= 1 << 12;
+  if (S2A_TAIL_EARLY_RES != 1) f |= 1 << 13;
 #ifdef S2A_MEASURE
   f |= 1 << 10;
 #endif
