@@ -70,19 +70,22 @@ namespace {
 #else
 #define S2A_DCN_DROP_SWITCH(xb, wb) do {} while (0)
 #endif
+#ifndef S2A_STAMP_W2
+#define S2A_STAMP_W2 4        // second stamped wave (0 is the first)
+#endif
 #if S2A_STAMP
 // diagnostic build only: per-workgroup phase stamps (s_memtime) into a buffer nothing else reads
 __device__ unsigned long long g_stamps[4096 * 16];
 #define S2A_STAMP_AT(slot)                                                                   \
   do {                                                                                       \
-    if (lane == 0 && (wave == 0 || wave == 4))                                               \
+    if (lane == 0 && (wave == 0 || wave == S2A_STAMP_W2))                                    \
       g_stamps[((blockIdx.x & 4095) * 16) + (wave ? 8 : 0) + (slot)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #define S2A_TIC() (t_tic = __builtin_amdgcn_s_memtime())
 #define S2A_TOC(accv) (accv += __builtin_amdgcn_s_memtime() - t_tic)
 #define S2A_STAMP_VAL(slot, val)                                                             \
   do {                                                                                       \
-    if (lane == 0 && (wave == 0 || wave == 4))                                               \
+    if (lane == 0 && (wave == 0 || wave == S2A_STAMP_W2))                                    \
       g_stamps[((blockIdx.x & 4095) * 16) + (wave ? 8 : 0) + (slot)] = (val);                \
   } while (0)
 #else
@@ -1542,7 +1545,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   const int nstage = TAPS * CC, last = nstage - 1;
 #if S2A_STAMP
   unsigned long long t_tic = 0, t_work = 0, t_wait = 0;
-  if (Cfg::kWLds && OG == 4) S2A_STAMP_AT(0);
+  if ((Cfg::kWLds && OG == 4) || (TAPS == 1 && OG == 4 && SD == 1)) S2A_STAMP_AT(0);
 #endif
   if constexpr (Cfg::kWLds) {
     // 16 x 16 tile, filter through LDS: every tap's 32 KB (this workgroup's 256 out channels, fragment order =
@@ -1648,7 +1651,13 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   load_w(0, wA);
   if (tid < 64 * OG) s_bias[tid] = bias_v;
   if constexpr (TAIL) { if (tid < 256) s_bias[64 + tid] = tail_bias_v; }
+#if S2A_STAMP
+  if (TAPS == 1 && OG == 4 && SD == 1) S2A_STAMP_AT(1);
+#endif
   __syncthreads();   // (the compiler drains the DMA with vmcnt(0) before the barrier)
+#if S2A_STAMP
+  if (TAPS == 1 && OG == 4 && SD == 1) S2A_STAMP_AT(2);
+#endif
   if constexpr (TAPS == 9) {
     for (int cc = 0; cc < CC; cc++) {
       const int s0 = cc * 9;
@@ -1683,8 +1692,11 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
 #define S2A_STAGE(C_, WCUR, WNEXT)                                                   \
     if ((C_) + 1 < CC) patch_issue((C_) + 1);                                           \
     load_w(min((C_) + 1, last), WNEXT);                                                 \
+    S2A_TIC();                                                                          \
     compute(smem + ((C_) & 1) * Cfg::kPatchBytes, 0, WCUR);                             \
-    __syncthreads();
+    S2A_TOC(t_work); S2A_TIC();                                                         \
+    __syncthreads();                                                                    \
+    S2A_TOC(t_wait);
     int cc = 0;
     for (; cc + 1 < CC; cc += 2) {
       S2A_STAGE(cc, wA, wB)
@@ -1692,6 +1704,9 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     }
     if (cc < CC) { S2A_STAGE(cc, wA, wB) }
 #undef S2A_STAGE
+#if S2A_STAMP
+    if (TAPS == 1 && OG == 4 && SD == 1) { S2A_STAMP_AT(3); S2A_STAMP_VAL(6, t_work); S2A_STAMP_VAL(7, t_wait); }
+#endif
   }
   }   // !kWLds
 
@@ -1740,7 +1755,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   }
   __syncthreads();
 #if S2A_STAMP
-  if (Cfg::kWLds && OG == 4) S2A_STAMP_AT(4);
+  if ((Cfg::kWLds && OG == 4) || (TAPS == 1 && OG == 4 && SD == 1)) S2A_STAMP_AT(4);
 #endif
   if constexpr (TAIL) {
     // ---- fused 1x1 (64 -> 256) on the staged tile: wave w = out maps 64w..64w+63 x the 128 positions of its block,
@@ -2023,7 +2038,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     }
   }
 #if S2A_STAMP
-  if (Cfg::kWLds && OG == 4) S2A_STAMP_AT(5);
+  if ((Cfg::kWLds && OG == 4) || (TAPS == 1 && OG == 4 && SD == 1)) S2A_STAMP_AT(5);
 #endif
 }
 
