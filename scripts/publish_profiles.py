@@ -67,6 +67,12 @@ with open(os.path.join(P, RN + "_iou_10k_pmc.txt"), "w") as f:
 # 3c. fused deformable-convolution backward: per-kernel stats of scripts/bwd_trace.sh; kernels of one captured detect() replay
 shutil.copy(os.path.join(F, "bwd_trace.txt"), os.path.join(P, RN + "_dcn_backward_kernel_stats.txt"))
 shutil.copy(os.path.join(F, "graph_replay_kernels.txt"), os.path.join(P, RN + "_graph_replay_kernels.txt"))
+if os.path.exists(os.path.join(F, "conv_stamps.txt")):
+    with open(os.path.join(P, RN + "_conv_phase_stamps.txt"), "w") as f:
+        f.write("# in-kernel phase stamps (s_memtime, diagnostic builds -DS2A_STAMP=1; the shipped library has none) of the pyramid tower\n"
+                "# convolution (scripts/stamp_conv_run.sh) and of two full-width 1x1 layers (scripts/stamp_conv1_run.sh), dense random data:\n"
+                "# cycles per phase of a workgroup (median over workgroups) and the in-kernel clock they imply (DESIGN.md section 4)\n")
+        f.write("".join(l for l in open(os.path.join(F, "conv_stamps.txt")) if "amdgpu.ids" not in l))
 
 # 4. bench: line, steady-state tables, kernel stats
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, RN + "_bench_line.json"))
