@@ -46,7 +46,8 @@ namespace {
 #define S2A_STAMP 0
 #endif
 // S2A_CONV_M16 = 0: every convolution on v_mfma_f32_32x32x16_f16 (rounds 1-2); 2: 16x16x32 for the towers with the filter through
-// LDS only; 1 (shipped): for every full-width (OG 4) 1x1 and stride-1 3x3 launch -- A/B builds only
+// LDS only; 3: for the full-width (OG 4) launches only; 1 (shipped): every stride-1 3x3 launch and the full-width 1x1 launches --
+// A/B builds only
 #ifndef S2A_CONV_M16
 #define S2A_CONV_M16 1
 #endif
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   V wt[2][4];                                        // TAIL: this wave's 64 x 64 block of the 1x1 filter
   if constexpr (TAIL) {
     if (tid < 256) tail_bias_v = ex.tail_b[tid];
-    if constexpr (S2A_CONV_M16 == 1) {   // 16x16x32 fragments (f = 16-channel tile * 2 + k-step), as the stand-alone 1x1 takes them
+    if constexpr (S2A_CONV_M16 == 1 || S2A_CONV_M16 == 3) {   // 16x16x32 fragments (f = 16-channel tile * 2 + k-step), as the stand-alone 1x1 takes them
       const V* tp = reinterpret_cast<const V*>(ex.tail_w) + (int64_t)wave4 * 8 * 64 + ((lane >> 4) & 1) * 128 + (lane >> 5) * 32 + (lane & 15);
 #pragma unroll
       for (int f = 0; f < 8; f++) wt[f >> 2][f & 3] = tp[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
@@ -1428,7 +1429,10 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   const int g = min(o0 / 64 + grp, G - 1);
   const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
   V wA[2][4], wB[2][4];
-  constexpr bool M16 = OG == 4 && !TAIL && (TAPS == 1 || SD == 1) && (S2A_CONV_M16 == 1 || (S2A_CONV_M16 == 2 && Cfg::kWLds));
+  // (every stride-1 3x3 launch and the full-width 1x1 launches; the narrower 1x1 launches stay on 32x32x16, as the chained conv1 of
+  // the fused tail, which must agree with them bit for bit)
+  constexpr bool M16 = ((TAPS == 9 && SD == 1) || (TAPS == 1 && OG == 4)) &&
+                       (S2A_CONV_M16 == 1 || (S2A_CONV_M16 == 3 && OG == 4 && !TAIL) || (S2A_CONV_M16 == 2 && Cfg::kWLds && OG == 4));
   constexpr int NB16 = 2 * NT;        // 16-position tiles per wave (8; 4 on the 64-position tiles)
   auto load_w = [&](int s, V (&wv)[2][4]) {
     if constexpr (M16) {
@@ -1489,7 +1493,8 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   const int kg16 = lane >> 4, i16 = lane & 15;
   const int pix16 = (i16 >= 4 && i16 < 12) ? (((i16 - 4) >> 1) * 4 + (i16 & 1))
                                            : (((i16 & 3) >> 1) * 4 + 2 + (i16 & 1) + (i16 >= 12 ? 8 : 0));
-  const int fbase16 = (TAPS == 9 ? (8 * blk) * Cfg::kPW + pix16 : 128 * blk + pix16) * kRowBytes + (kg16 & 1) * 64 + (kg16 >> 1) * 16;
+  const int t16 = 2 * sub * NT;                   // first 16-position tile of this wave inside its 128-position block
+  const int fbase16 = (TAPS == 9 ? (8 * blk + t16) * Cfg::kPW + pix16 : 128 * blk + 16 * t16 + pix16) * kRowBytes + (kg16 & 1) * 64 + (kg16 >> 1) * 16;
   constexpr int kTile16 = (TAPS == 9 ? Cfg::kPW : 16) * kRowBytes;      // LDS distance between a wave's 16-position tiles
   const int abase16 = (kg16 & 1) * 2048 + ((kg16 >> 1) * 32 + i16) * 16;
 
@@ -1714,6 +1719,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   char* s_out = smem;
   if constexpr (M16) {
     using h4 = __attribute__((ext_vector_type(4))) _Float16;
+    if (wave_active)
 #pragma unroll
     for (int a = 0; a < 4; a++) {
       const int och = grp * 64 + 16 * a + 4 * kg16;       // D: row (out channel) = 4 (lane >> 4) + register, column = pixel
@@ -1727,7 +1733,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
           if (relu && !residual) v = fmaxf(v, 0.f);
           v4[e] = (_Float16)v;
         }
-        const int pos = 128 * blk + 16 * b + pix16;
+        const int pos = 128 * blk + 16 * (t16 + b) + pix16;
         *reinterpret_cast<h4*>(s_out + pos * Cfg::kOutRowB + och * 2) = v4;
       }
     }
@@ -1760,7 +1766,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   if constexpr (TAIL) {
     // ---- fused 1x1 (64 -> 256) on the staged tile: wave w = out maps 64w..64w+63 x the 128 positions of its block,
     // B fragments from the staged rows (144-byte stride: conflict-free), accumulation order = the stand-alone 1x1's
-    constexpr bool T16 = S2A_CONV_M16 == 1;      // the second GEMM on 16x16x32 MFMAs, as the stand-alone 64 -> 256 1x1
+    constexpr bool T16 = S2A_CONV_M16 == 1 || S2A_CONV_M16 == 3;      // the second GEMM on 16x16x32 MFMAs, as the stand-alone 64 -> 256 1x1
     f32x16 acc3[2][4];
     f32x4 acc3s[T16 ? 4 : 1][T16 ? 8 : 1];
     if constexpr (T16) {
