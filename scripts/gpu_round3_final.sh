@@ -33,5 +33,5 @@ python -c "
 import json
 for f in ('bench_s1','bench_s1_graph'):
     d=json.load(open('$O/'+f+'.json')); print(f, d['value'], d['ms_per_step'])"
-echo "== conv phase stamps (diagnostic builds, restored afterwards)"; bash scripts/stamp_conv_run.sh > $O/conv_stamps.txt 2>&1; bash scripts/stamp_conv1_run.sh >> $O/conv_stamps.txt 2>&1; grep -v amdgpu.ids $O/conv_stamps.txt | cut -c1-220
+echo "== conv phase stamps (diagnostic builds, restored afterwards)"; bash scripts/stamp_conv_run.sh > $O/conv_stamps.txt 2>&1; bash scripts/stamp_conv1_run.sh >> $O/conv_stamps.txt 2>&1; bash scripts/stamp_run.sh > $O/alignconv_stamps.txt 2>&1; grep -v amdgpu.ids $O/conv_stamps.txt | cut -c1-220
 echo "== nms device totals (measurement build, restored afterwards)"; bash scripts/nms_debug.sh > $O/nms_debug.txt 2>&1; bash scripts/nms_bench_debug.sh >> $O/nms_debug.txt 2>&1; cat $O/nms_debug.txt | cut -c1-200

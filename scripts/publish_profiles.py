@@ -73,6 +73,9 @@ if os.path.exists(os.path.join(F, "conv_stamps.txt")):
                 "# convolution (scripts/stamp_conv_run.sh) and of two full-width 1x1 layers (scripts/stamp_conv1_run.sh), dense random data:\n"
                 "# cycles per phase of a workgroup (median over workgroups) and the in-kernel clock they imply (DESIGN.md section 4)\n")
         f.write("".join(l for l in open(os.path.join(F, "conv_stamps.txt")) if "amdgpu.ids" not in l))
+        if os.path.exists(os.path.join(F, "alignconv_stamps.txt")):
+            f.write("# AlignConv (k_dcn_patch, P3 level at batch 8, dense random data; scripts/stamp_run.sh): matrix (consumer) and loader waves\n")
+            f.write("".join(l for l in open(os.path.join(F, "alignconv_stamps.txt")) if "amdgpu.ids" not in l))
 
 # 4. bench: line, steady-state tables, kernel stats
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, RN + "_bench_line.json"))

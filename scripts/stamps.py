@@ -13,5 +13,7 @@ c = st[:, :8]; l = st[:, 8:]
 def d(a, i, j): return np.median(a[:, j] - a[:, i])
 print("consumer: start->pre#1 %d | #1 wait %d | #1->#2 %d | main loop %d | epilogue %d | total %d" % (d(c,0,1), d(c,1,2), d(c,2,3), d(c,3,4), d(c,4,5), d(c,0,5)))
 print("loader:   start->pre#1 %d | #1 wait %d | produce0 %d | #2 wait %d | main loop %d" % (d(l,0,1), d(l,1,2), d(l,2,6), d(l,6,3), d(l,3,4)))
-print("consumer loop: work %d wait %d   loader loop: work %d wait %d" % (np.median(c[:,6]), np.median(c[:,7]), np.median(l[:,7]), np.median(l[:,5])))
-print("WG duration cycles (memtime ticks @100MHz?):", np.median(c[:,5]-c[:,0]), " first-start to last-end:", (st[:, [5, 13]].max() - st[:, [0, 8]].min()))
+tot = np.median(c[:, 5] - c[:, 0])
+rounds = -(-8 * 128 * 128 // 128 // 256)      # 8 x 16 tiles of the P3 level at batch 8 on 256 CUs, one workgroup per CU
+print("workgroup lifetime %d cycles (36 stages of %d; 1024 of them MFMA); %d rounds of tiles in %.1f us -> %.2f GHz in-kernel clock"
+      % (tot, d(c, 3, 4) / 36, rounds, r["us"], tot * rounds / r["us"] / 1e3))
