@@ -32,8 +32,7 @@ def head_level(h, x, stride, with_fam_cls=True, timers=None):
     timers: dict; 'oracle_ops_s' accumulates the seconds spent in the oracle's ops (AlignConv, ARF, pooling, decode)"""
     H, W = x.shape[-2:]
     fam_bbox = h.fam_reg_head(h.fam_reg_ls(x))
-    if with_fam_cls:
-        h.fam_cls_head(h.fam_cls_ls(x))                       # evaluated and discarded at inference (head.py:306)
+    fam_cls = h.fam_cls_head(h.fam_cls_ls(x)) if with_fam_cls else None   # evaluated, unused at inference (head.py:306)
     t0 = time.perf_counter()
     anchors = oracle.grid_anchors(H, W, stride)
     refined = oracle.delta2bbox_rotated(anchors, fam_bbox[0].permute(1, 2, 0).reshape(-1, 5).numpy(), 1e-6)
@@ -50,7 +49,7 @@ def head_level(h, x, stride, with_fam_cls=True, timers=None):
     cls = h.odm_cls_head(cls_feat)
     reg = h.odm_reg_head(h.odm_reg_ls(or_feat))
     C = cls.shape[1]
-    return dict(size=(H, W), stride=stride, refined=refined, fam_bbox=fam_bbox, align=al, or_feat=or_feat, pooled=pooled,
+    return dict(size=(H, W), stride=stride, anchors=anchors, refined=refined, fam_bbox=fam_bbox, fam_cls=fam_cls, align=al, or_feat=or_feat, pooled=pooled,
                 cls_feat=cls_feat, cls=cls[0].permute(1, 2, 0).reshape(-1, C).numpy().copy(),
                 reg=reg[0].permute(1, 2, 0).reshape(-1, 5).numpy().copy())
 

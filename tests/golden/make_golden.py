@@ -10,6 +10,7 @@ Run in the build container only (needs /root/reference):  python tests/golden/ma
 The fixtures hold DATA only (inputs + expected outputs).  The reference never travels to the
 GPU box; these arrays do.
 """
+import collections
 import ctypes
 import os
 import sys
@@ -413,6 +414,141 @@ def gen_dcn_backward():
     print("dcn backward golden:", float(x.grad.abs().max()), float(off.grad.abs().max()), float(wgt.grad.abs().max()))
 
 
+def gen_net_forward():
+    """The reference's OWN composed network run here: models.detector.S2ANet (backbone.py:283-354 -> neck.py:64-96 ->
+    head.py:261-348 forward_single per level -> head.py:648-725 get_bboxes) in float32 on the CPU, batch 2 of 384 x 384
+    chips (levels 48 / 24 / 12 / 6 / 3; the 48 x 48 level exceeds max_before_nms_per_level = 2000, so the top-k runs).
+
+    Three things are patched, nothing else:
+      * models.backbone.load_checkpoint (a torchvision download, backbone.py:241-255) returns the state_dict of a
+        fresh ResNet; every parameter is then overwritten by tests/golden/synth_net.py anyway
+      * DeformConv.forward (CUDA only, deform_conv.py:58-59 raises on the CPU) -> oracle.deform_conv_forward, so
+        AlignConv.get_offset / AlignConv.forward and the ReLU stay the reference's Python
+      * orn_cuda.arf_forward: the reference CPU op wraps a uint16 index at the head's [32,256,1,3,3] filter
+        (SURVEY a7), so the plain definition (oracle.arf_forward) is used and checked against the reference CPU op on
+        the 224-channel sub-block that stays below 65 536 elements
+    The fixture holds the ordered state_dict entries (names, shapes, dtypes, checksums), the prediction-head scale
+    factors that make the random network produce rotated anchors and ~1 500 NMS candidates per chip, samples of C3-C5
+    and P3-P7 (every 64th / 4th element + float64 sums), the forward_single outputs of every level and get_bboxes."""
+    import_reference_python()
+    sys.path.insert(0, OUT)
+    import synth_net
+    import models.backbone as ref_backbone
+    import models.dcn  # noqa: F401
+    import models.orn  # noqa: F401
+    ref_dc = sys.modules["models.dcn.deform_conv"]          # (models.dcn re-exports a FUNCTION of that name)
+    ref_orn = ref.orn()
+
+    ref_backbone.load_checkpoint = lambda name: ref_backbone.ResNet(name).state_dict()
+
+    def dcn_forward(self, x, offset):
+        assert self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1
+        y = oracle.deform_conv_forward(x.detach().numpy(), offset.detach().numpy(), self.weight.detach().numpy())
+        return torch.from_numpy(y)
+    ref_dc.DeformConv.forward = dcn_forward
+
+    class OrnShim:
+        @staticmethod
+        def arf_forward(w, idx):
+            full = torch.from_numpy(oracle.arf_forward(w.detach().numpy(), idx.numpy()))
+            sub = w[:, :224].contiguous()
+            assert sub.numel() < 65536
+            assert torch.equal(ref_orn.arf_forward(sub, idx), torch.from_numpy(
+                oracle.arf_forward(sub.detach().numpy(), idx.numpy()))), "plain ARF != reference CPU ARF"
+            return full
+        arf_backward = staticmethod(ref_orn.arf_backward)
+    sys.modules["models.orn.functions.active_rotating_filter"].orn_cuda = OrnShim
+
+    from models.detector import S2ANet
+    torch.manual_seed(0)
+    net = S2ANet("resnet50", 15).eval()
+    sd = net.state_dict()
+    names = list(sd.keys())
+    shapes = [tuple(v.shape) for v in sd.values()]
+    dtypes = [str(v.dtype).replace("torch.", "") for v in sd.values()]
+    fixed = {n: v.numpy() for n, v in sd.items() if not v.dtype.is_floating_point and not n.endswith("num_batches_tracked")}
+    B, S = 2, 384
+    imgs_u8 = synth_net.synth_images(B, S, S)
+    imgs = torch.from_numpy(imgs_u8).float() / 255.0                       # val.py:246-247
+
+    def load(scales):
+        st = synth_net.synth_state(names, shapes, dtypes, fixed, scales)
+        net.load_state_dict(collections.OrderedDict((k, torch.from_numpy(v)) for k, v in st.items()), strict=True)
+        return st
+
+    scales = {}
+    heads = {"fam_cls": ("head.fam_cls_head", 0, 1.5), "fam_reg": ("head.fam_reg_head", 1, 0.3),
+             "odm_cls": ("head.odm_cls_head", 2, 1.5), "odm_reg": ("head.odm_reg_head", 3, 0.3)}
+    for mod, _, _ in heads.values():
+        fixed[mod + ".bias"] = np.zeros(sd[mod + ".bias"].shape, np.float32)
+
+    def centre(p, which):
+        """scale the prediction head so that its outputs spread with the wanted std around zero, per channel: the
+        post-ReLU tower features have a large mean, which a random head turns into one constant per output channel"""
+        mod, ki, std = heads[which]
+        t = torch.cat([x.permute(1, 0, 2, 3).reshape(x.shape[1], -1) for x in p[ki]], 1).double()   # [channels, positions]
+        mu = t.mean(1)
+        s = std / float((t - mu[:, None]).std())
+        scales[mod + ".weight"] = scales.get(mod + ".weight", 1.0) * s
+        fixed[mod + ".bias"] = (-s * mu).float().numpy()
+
+    load(scales)
+    with torch.no_grad():
+        p = net(imgs)["pred"]
+        centre(p, "fam_reg")            # refined anchors really rotate / shift / scale ...
+        centre(p, "fam_cls")
+        load(scales)
+        p = net(imgs)["pred"]           # ... the ODM branches see the aligned features of THOSE anchors
+        centre(p, "odm_reg")
+        centre(p, "odm_cls")
+        load(scales)
+        p = net(imgs)["pred"]
+        # bias: ~1 500 (box, class) candidates per chip above 0.05, threshold placed in the widest logit gap nearby
+        logits = torch.cat([t.reshape(-1) for t in p[2]]).double().numpy()
+        srt = np.sort(logits)[::-1]
+        kk = 1500 * B
+        lo, hi = kk - 150, kk + 150
+        kk = lo + int(np.argmax(srt[lo - 1:hi - 1] - srt[lo:hi]))
+        q = 0.5 * (srt[kk - 1] + srt[kk])
+        fixed["head.odm_cls_head.bias"] = (fixed["head.odm_cls_head.bias"] + np.float32(np.log(0.05 / 0.95) - q)).astype(np.float32)
+    st = load(scales)
+
+    feats = {}
+    hooks = [net.backbone.register_forward_hook(lambda m, i, o: feats.__setitem__("C", o)),
+             net.neck.register_forward_hook(lambda m, i, o: feats.__setitem__("P", o))]
+    with torch.no_grad():
+        pred = net(imgs)["pred"]
+        res = net(imgs, post_process=True)["boxes_ls"]
+    for h in hooks:
+        h.remove()
+
+    out = dict(names=np.array(names), shapes=np.array([",".join(map(str, s)) for s in shapes]), dtypes=np.array(dtypes),
+               checksums=synth_net.checksums(st), seed=np.int64(synth_net.SEED), images_checksum=np.int64(imgs_u8.astype(np.int64).sum()),
+               batch=np.int64(B), size=np.int64(S),
+               scale_names=np.array(list(scales)), scale_values=np.array([scales[k] for k in scales], np.float64),
+               fixed_names=np.array(list(fixed)))
+    for k, v in fixed.items():
+        out["fixed:" + k] = v
+    for tag, step in (("C", 64), ("P", 4)):
+        for i, t in enumerate(feats[tag]):
+            a = t.numpy()
+            out[f"{tag}{i}_shape"] = np.array(a.shape)
+            out[f"{tag}{i}_sample"] = a.reshape(-1)[::step].copy()
+            out[f"{tag}{i}_sums"] = np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+    keys = ("fam_cls", "fam_bbox", "odm_cls", "odm_bbox", "init_anchors", "refine_anchors")
+    for ki, key in enumerate(keys):
+        for l, t in enumerate(pred[ki]):
+            out[f"{key}_{l}"] = t.numpy()
+    for b, (det, lab) in enumerate(res):
+        out[f"det_{b}"], out[f"labels_{b}"] = det.numpy(), lab.numpy()
+        print("net_forward: image", b, "detections", det.shape[0], "labels used", len(np.unique(lab.numpy())))
+    # how far the NMS decisions are from the threshold (a detection flips only if an IoU crosses it)
+    np.savez_compressed(os.path.join(OUT, "net_forward.npz"), **out)
+    print("net_forward: entries", len(names), "params", sum(int(np.prod(s)) for s in shapes),
+          "refine angle std", float(torch.cat([t[..., 4].reshape(-1) for t in pred[5]]).std()),
+          "file MB", os.path.getsize(os.path.join(OUT, "net_forward.npz")) / 1e6)
+
+
 def torch_deform_conv(x, off, wgt, pad=1):
     B, C, H, W = x.shape
     O, _, kH, kW = wgt.shape
@@ -444,6 +580,10 @@ def torch_deform_conv(x, off, wgt, pad=1):
 if __name__ == "__main__":
     assert build_ref.have_reference(), "run in the build container (needs /root/reference)"
     build_ref.build_all()
+    if len(sys.argv) > 1:                      # e.g. `make_golden.py net_forward`: only the generators with an own rng
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     rng = np.random.default_rng(SEED)
     gen_iou(rng)
     gen_nms(rng)
@@ -457,4 +597,5 @@ if __name__ == "__main__":
     gen_voc_eval()
     gen_merge_file()
     gen_rie()
+    gen_net_forward()
     print("done ->", OUT)
