@@ -414,6 +414,23 @@ def gen_dcn_backward():
     print("dcn backward golden:", float(x.grad.abs().max()), float(off.grad.abs().max()), float(wgt.grad.abs().max()))
 
 
+def gen_formats():
+    """scale_coords_rotated from the reference's own utils/general.py:629-648 (imported with the cv2 stub): letterboxed
+    network coordinates -> original-image coordinates, with and without an explicit ratio_pad"""
+    import_reference_python()
+    from utils.general import scale_coords_rotated
+    rng = np.random.default_rng(97531)
+    d = np.concatenate([rand_boxes(rng, 64, span=1024), rng.uniform(0.05, 1, (64, 1)).astype(np.float32)], 1)
+    out = {"dets": d}
+    cases = {"a": ((1024, 1024), (2048, 1000), None), "b": ((1024, 1024), (683, 1024), None),
+             "c": ((640, 1024), (1500, 3000), None), "d": ((1024, 1024), (4000, 4000), ((0.256, 0.256), (11.5, 3.25)))}
+    for tag, (s1, s0, rp) in cases.items():
+        out["out_" + tag] = scale_coords_rotated(s1, torch.from_numpy(d.copy()), s0, rp).numpy()
+        out["args_" + tag] = np.array(list(s1) + list(s0) + ([rp[0][0], rp[0][1], rp[1][0], rp[1][1]] if rp else []), np.float64)
+    np.savez_compressed(os.path.join(OUT, "formats.npz"), **out)
+    print("formats:", {k: v.shape for k, v in out.items()})
+
+
 def gen_net_forward():
     """The reference's OWN composed network run here: models.detector.S2ANet (backbone.py:283-354 -> neck.py:64-96 ->
     head.py:261-348 forward_single per level -> head.py:648-725 get_bboxes) in float32 on the CPU, batch 2 of 384 x 384
@@ -598,4 +615,5 @@ if __name__ == "__main__":
     gen_merge_file()
     gen_rie()
     gen_net_forward()
+    gen_formats()
     print("done ->", OUT)

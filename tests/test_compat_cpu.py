@@ -97,3 +97,20 @@ def test_reference_checkpoint_loads_by_position(tmp_path):
         load_reference_checkpoint(S2ANet(15), {"state_dict": short})
     with pytest.raises(KeyError):
         load_reference_checkpoint(S2ANet(15), {"weights": {}})
+
+
+def test_scale_coords_rotated_matches_reference_function():
+    """utils/general.py:629-648 run in the build container (tests/golden/formats.npz): letterbox gain / padding with
+    and without an explicit ratio_pad, in place, width / height scaled, angle and score untouched"""
+    import numpy as np
+    import torch
+    from conftest import golden
+    from s2anet_amd.formats import scale_coords_rotated
+    g = golden("formats.npz")
+    for tag in "abcd":
+        a = g["args_" + tag]
+        rp = None if len(a) == 4 else ((a[4], a[5]), (a[6], a[7]))
+        t = torch.from_numpy(g["dets"].copy())
+        out = scale_coords_rotated((int(a[0]), int(a[1])), t, (int(a[2]), int(a[3])), rp)
+        assert out is t                                                      # in place, as the reference
+        assert np.array_equal(out.numpy(), g["out_" + tag]), tag
