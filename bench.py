@@ -486,9 +486,14 @@ class StubDetector:
             self.dets[b, self.counts[b]:] = 0
             self.labels[b, self.counts[b]:] = -1
         self.ovf = torch.zeros(2, dtype=torch.int64, device=device)
+        from s2anet_amd.gather import pack_detections
+        self.wire = pack_detections(self.dets, self.labels, self.counts)
 
-    def detect(self, imgs, max_candidates=None, return_overflow=False):
-        return (self.dets, self.labels, self.counts, self.ovf) if return_overflow else (self.dets, self.labels, self.counts)
+    def detect(self, imgs, max_candidates=None, return_overflow=False, dropped_total=None, return_wire=False):
+        out = (self.dets, self.labels, self.counts)
+        if return_overflow:
+            out += (self.ovf,)
+        return out + (self.wire,) if return_wire else out
 
 
 def profiler_preloaded(env=None):
@@ -563,17 +568,23 @@ def main():
         got = calibrate_cls_bias(model, imgs, args.candidates)
     max_cand = int(min(B * 5344 * NUM_CLASSES, max(4 * args.candidates * B, 65536)))
     nslots = max(args.streams, 1)
-    # one gather object (output buffer) and one overflow accumulator per batch in flight
-    gathers = [DetectionGather(world, B, model.head.max_per_img, dev) for _ in range(nslots)] if world > 1 else None
-    dropped = [torch.zeros((), dtype=torch.int64, device=dev) for _ in range(nslots)]
-    slot = [0]
+    # one gather object (output buffers) and one overflow accumulator per batch in flight.  The NMS finish kernel writes
+    # the wire buffer and adds the dropped-candidate count to the accumulator: no stock tensor op behind the detector.
+    # With one batch at a time the all-gather goes to a side stream behind an event, so that batch i's gather overlaps
+    # batch i+1's trunk; with several batches in flight each stream's gather already overlaps the other streams' work.
+    side = world > 1 and not stub and args.streams <= 1 and not args.graph and not os.environ.get("S2A_BENCH_NO_SIDE_GATHER")
+    gathers = [DetectionGather(world, B, model.head.max_per_img, dev, side_stream=side) for _ in range(nslots)] \
+        if world > 1 else None
+    dropped = [torch.zeros((1,), dtype=torch.int64, device=dev) for _ in range(nslots)]
+    slot, do_gather, last_wire = [0], [True], [None]
 
     def step():
         x = imgs if stub else batches[slot[0] % len(batches)]
-        dets, labels, counts, ovf = model.detect(x, max_candidates=max_cand, return_overflow=True)
-        dropped[slot[0] % nslots].add_(ovf[1])     # candidates the static cap cut (must stay 0); same stream, no sync
-        if gathers is not None:
-            return gathers[slot[0] % nslots](dets, labels, counts)
+        k = slot[0] % nslots
+        dets, labels, counts, wire = model.detect(x, max_candidates=max_cand, dropped_total=dropped[k], return_wire=True)
+        last_wire[0] = wire
+        if gathers is not None and do_gather[0]:
+            return gathers[k](wire)
         return dets, labels, counts
 
     for _ in range(max(args.warmup, 1)):
@@ -635,10 +646,41 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        # attribution of a scaling loss, OUTSIDE the timed region: every rank's step time without the collective
+        # (same runner, same streams) and the collective alone on an otherwise idle GPU, gathered to rank 0
+        if gathers is not None:
+            for g_ in gathers:
+                g_.wait()
+            sync()
+            out = gathers[(slot[0]) % nslots].unpack()
+        if not args.graph:
+            def loop_ms(fn, n):
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                sync()
+                return (time.perf_counter() - t1) / n * 1e3
+            do_gather[0] = False
+            compute_ms = loop_ms(runner, args.steps)
+            do_gather[0] = True
+            dist.barrier()
+            w_ = last_wire[0]
+
+            def gather_once():
+                gathers[0](w_)
+                gathers[0].wait()
+            gather_ms = loop_ms(gather_once, 20)
+            mine = {"rank": rank, "step_ms": round(elapsed / args.steps * 1e3, 3), "compute_ms": round(compute_ms, 3),
+                    "gather_ms": round(gather_ms, 3)}
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            per_rank = allr
     # outside the timed region: the static candidate cap must not have cut a single row in any step (the reference
     # never drops a candidate, utils/bbox_nms_rotated.py:29-40) -- one host read
     n_dropped = int(sum(int(d.item()) for d in dropped))
@@ -670,6 +712,11 @@ def main():
             "parallelism": "dp%d (one process per GPU)" % world, "collective_backend": collective,
         },
     }
+    if per_rank is not None:
+        # per rank: the timed step, the same step without the all-gather, and the all-gather alone (ms) -- measured after
+        # the timed region; with world > 1 a loss shows up either as an uneven compute_ms or as a large gather_ms
+        result["per_rank"] = per_rank
+        result["config"]["gather_on_side_stream"] = bool(side)
     if stub:
         # the gathered batch must be the rank-major concatenation of what every rank's stub produced
         exp = [StubDetector(r, B, dev) for r in range(world)]

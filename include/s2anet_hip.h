@@ -142,6 +142,27 @@ int s2a_nms_rotated_segmented(const float* dets, const float* scores, const int3
                               int32_t* keep, int32_t* group_counts, int32_t max_per_group,
                               void* workspace, size_t workspace_bytes, s2a_stream_t stream);
 
+/* s2a_nms_rotated_segmented followed, in the same launch sequence, by the output assembly of
+ * multiclass_nms_rotated (utils/bbox_nms_rotated.py:47-64: dets = cat([bboxes, scores[:, None]]), labels, sorted by
+ * score, cut to max_per_img) for a whole batch — no host synchronisation, no stock tensor ops behind the NMS:
+ *   wire[g][r*7 .. r*7+6] = x, y, w, h, angle, score, label (as float) of the r-th kept row of group g in
+ *   descending-score order; rows behind the last kept one are 0,0,0,0,0,0,-1; wire[g][max_per_group*7] = the number
+ *   of rows written = min(K_g, max_per_group).  wire is float32 [num_groups][max_per_group*7 + 1]: also the
+ *   all-gather wire format of the data-parallel detector (one buffer per rank, s2anet_amd/gather.py).
+ *   labels_out int32 [num_groups][max_per_group] (-1 padded) and counts_out int32 [num_groups]: optional copies.
+ * row_labels[n] int32 = class of every row (out_cls of s2a_multiclass_candidates).
+ * cand_found (device int64, may be NULL) = the untruncated candidate count of s2a_multiclass_candidates whose first
+ * n rows these are: overflow_out (device int64[2], may be NULL) receives [found, found - n clamped at 0] and
+ * *dropped_total (device int64, may be NULL) is incremented by the second number (the reference never drops a
+ * candidate, so a caller with a static row cap must be able to prove that nothing was cut). */
+int s2a_nms_rotated_segmented_dets(const float* dets, const float* scores, const int32_t* segment_ids,
+                                   const int32_t* group_ids, const int32_t* row_labels, int64_t n,
+                                   int32_t num_segments, int32_t num_groups, float iou_threshold,
+                                   int32_t max_per_group, float* wire, int32_t* labels_out,
+                                   int32_t* counts_out, const int64_t* cand_found, int64_t* overflow_out,
+                                   int64_t* dropped_total, void* workspace, size_t workspace_bytes,
+                                   s2a_stream_t stream);
+
 /* Candidate selection of multiclass_nms_rotated (utils/bbox_nms_rotated.py:29-42) for a whole
  * batch: every (box, class) pair with score > score_thr, in row-major (image, box, class) order,
  * compacted into `cap` slots (first `cap` in that order if there are more; *count_dev holds the
@@ -296,6 +317,10 @@ int s2a_fam_refine_anchors(const void* bbox_pred, int64_t batch, int64_t height,
  * models/head.py:163-222 and models/backbone.py:37-83 (same arithmetic, one pass over HBM). */
 int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual, int64_t positions,
                       int64_t channels, int dtype, int relu, s2a_stream_t stream);
+/* the same pass writing out[positions, channels] instead (out may equal y): lets the two library convolutions that
+ * remain (FPN's stride-2 extra levels, models/neck.py:86-94) land in the pyramid-packed head buffer without a copy */
+int s2a_bias_act_nhwc_to(const void* y, const void* bias, const void* residual, void* out, int64_t positions,
+                         int64_t channels, int dtype, int relu, s2a_stream_t stream);
 
 /* Regular convolutions, f16 channels-last, with bias / residual / ReLU fused — the conv towers of
  * S2ANetHead (models/head.py:163-222, nn.Conv2d + nn.ReLU pairs) and the 1x1 layers of the carrier,

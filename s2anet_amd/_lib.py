@@ -63,6 +63,8 @@ SYMBOLS = {
     "s2a_nms_rotated_segmented": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int32,
                                           ctypes.c_int32, c_f32, c_vp, c_vp, c_vp, ctypes.c_int32,
                                           c_vp, c_sz, c_vp]),
+    "s2a_nms_rotated_segmented_dets": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int32, ctypes.c_int32, c_f32,
+                                               ctypes.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "s2a_multiclass_candidates_workspace_bytes": (c_sz, [c_i64]),
     "s2a_multiclass_candidates": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i64, c_vp, c_vp, c_vp,
                                           c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -83,6 +85,7 @@ SYMBOLS = {
     "s2a_dcn_packed_elems": (c_i64, [c_i64, c_i64, c_int]),
     "s2a_dcn_pack_weight": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
     "s2a_bias_act_nhwc": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
+    "s2a_bias_act_nhwc_to": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
     "s2a_conv_pack_weight_f16": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
     "s2a_conv_nhwc_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int,
                                   c_int, c_vp]),

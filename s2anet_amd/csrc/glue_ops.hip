@@ -136,9 +136,9 @@ __global__ void k_align_offsets(const float* __restrict__ anchors, int64_t B, in
 // dimension): one pass instead of the three (bias add, residual add, ReLU) the stock
 // elementwise kernels make after every convolution.  8 halfs / 4 floats per lane (16 B).
 template <typename T, int VEC, bool HOIST>
-__global__ __launch_bounds__(256) void k_bias_act(T* __restrict__ y, const T* __restrict__ bias,
+__global__ __launch_bounds__(256) void k_bias_act(const T* y, T* out, const T* __restrict__ bias,
                                                   const T* __restrict__ res, int64_t nvec, int cvec,
-                                                  int relu) {
+                                                  int relu) {      // out == y: in place (every element is read before it is written)
   using V = T __attribute__((ext_vector_type(VEC)));
   const int64_t T0 = (int64_t)gridDim.x * blockDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -162,18 +162,18 @@ __global__ __launch_bounds__(256) void k_bias_act(T* __restrict__ y, const T* __
     V v[4], r[4], b[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      v[k] = reinterpret_cast<V*>(y)[i + k * T0];
+      v[k] = reinterpret_cast<const V*>(y)[i + k * T0];
       if (res) r[k] = reinterpret_cast<const V*>(res)[i + k * T0];
       b[k] = HOIST ? b0 : reinterpret_cast<const V*>(bias)[(i + k * T0) % cvec];
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) reinterpret_cast<V*>(y)[i + k * T0] = apply(v[k], b[k], r[k]);
+    for (int k = 0; k < 4; k++) reinterpret_cast<V*>(out)[i + k * T0] = apply(v[k], b[k], r[k]);
   }
   for (; i < nvec; i += T0) {
-    V v = reinterpret_cast<V*>(y)[i], r;
+    V v = reinterpret_cast<const V*>(y)[i], r;
     if (res) r = reinterpret_cast<const V*>(res)[i];
     V b = HOIST ? b0 : reinterpret_cast<const V*>(bias)[i % cvec];
-    reinterpret_cast<V*>(y)[i] = apply(v, b, r);
+    reinterpret_cast<V*>(out)[i] = apply(v, b, r);
   }
 }
 
@@ -182,23 +182,23 @@ __global__ __launch_bounds__(256) void k_bias_act(T* __restrict__ y, const T* __
 
 using namespace s2a;
 
-extern "C" int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual, int64_t positions,
-                                 int64_t channels, int dtype, int relu, s2a_stream_t stream) {
+static int bias_act_impl(const void* y, void* out, const void* bias, const void* residual, int64_t positions,
+                         int64_t channels, int dtype, int relu, s2a_stream_t stream) {
   S2A_CHECK_ARG(positions >= 0 && channels > 0, "bias_act: bad shape");
   S2A_CHECK_ARG(dtype == S2A_DTYPE_F32 || dtype == S2A_DTYPE_F16, "bias_act: dtype");
   const int vec = dtype == S2A_DTYPE_F16 ? 8 : 4;
   S2A_CHECK_ARG(channels % vec == 0, "bias_act: channels must be a multiple of %d", vec);
   if (positions == 0) return S2A_OK;
   S2A_CHECK_ARG(y && bias, "bias_act: NULL tensor");
-  S2A_CHECK_ARG(((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0 && ((uintptr_t)residual % 16) == 0,
-                "bias_act: tensors must be 16-byte aligned");
+  S2A_CHECK_ARG(((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
+                ((uintptr_t)out % 16) == 0 && out, "bias_act: tensors must be 16-byte aligned");
   const int64_t nvec = positions * channels / vec;
   const int cvec = (int)(channels / vec);
   unsigned g = (unsigned)std::min<int64_t>((nvec + 1023) / 1024, 256 * 8);
   if (g == 0) g = 1;
   const bool hoist = cvec <= 256 && (256 % cvec) == 0;   // then gridDim*256 is a multiple of cvec
   hipStream_t st = as_stream(stream);
-#define S2A_BA(T, V, H) k_bias_act<T, V, H><<<g, 256, 0, st>>>((T*)y, (const T*)bias, (const T*)residual, nvec, cvec, relu)
+#define S2A_BA(T, V, H) k_bias_act<T, V, H><<<g, 256, 0, st>>>((const T*)y, (T*)out, (const T*)bias, (const T*)residual, nvec, cvec, relu)
   if (dtype == S2A_DTYPE_F16) {
     if (hoist) S2A_BA(_Float16, 8, true); else S2A_BA(_Float16, 8, false);
   } else {
@@ -207,6 +207,16 @@ extern "C" int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual
 #undef S2A_BA
   S2A_LAUNCH_CHECK();
   return S2A_OK;
+}
+
+extern "C" int s2a_bias_act_nhwc(void* y, const void* bias, const void* residual, int64_t positions,
+                                 int64_t channels, int dtype, int relu, s2a_stream_t stream) {
+  return bias_act_impl(y, y, bias, residual, positions, channels, dtype, relu, stream);
+}
+
+extern "C" int s2a_bias_act_nhwc_to(const void* y, const void* bias, const void* residual, void* out, int64_t positions,
+                                    int64_t channels, int dtype, int relu, s2a_stream_t stream) {
+  return bias_act_impl(y, out, bias, residual, positions, channels, dtype, relu, stream);
 }
 
 extern "C" int s2a_delta2bbox_rotated(const float* rois, const float* deltas, int64_t n,

@@ -861,6 +861,90 @@ __global__ __launch_bounds__(1024) void k_nms_group_compact(const unsigned long 
   if (threadIdx.x == 0) group_counts[g] = written;
 }
 
+// per-group compaction + output assembly of multiclass_nms_rotated (utils/bbox_nms_rotated.py:47-64) for the batched
+// detector: the r-th kept row of group g (score descending) goes to wire[g][r*7 .. r*7+6] = x, y, w, h, angle, score,
+// label; rows behind the last kept one are 0,0,0,0,0,0,-1; wire[g][max_per_group*7] = the count.  One workgroup per
+// group; the stock index / cat / where / clamp launches this replaces were ~15 per step.
+__global__ __launch_bounds__(1024) void k_nms_group_emit(const unsigned long long* __restrict__ key1s,
+                                                         const int32_t* __restrict__ perm_glob,
+                                                         const uint8_t* __restrict__ keep_orig,
+                                                         const float* __restrict__ dets5,
+                                                         const float* __restrict__ scores,
+                                                         const int32_t* __restrict__ row_labels, int64_t n,
+                                                         int32_t max_per_group, float* __restrict__ wire,
+                                                         int32_t* __restrict__ labels_out,
+                                                         int32_t* __restrict__ counts_out,
+                                                         const long long* __restrict__ cand_found,
+                                                         long long* __restrict__ overflow_out,
+                                                         long long* __restrict__ dropped_total) {
+  __shared__ int s_wave[16];
+  __shared__ int s_total;
+  const uint32_t g = blockIdx.x;
+  if (g == 0 && threadIdx.x == 0 && cand_found) {     // candidates the static row cap n cut (the reference drops none)
+    const long long found = *cand_found, dropped = found > (long long)n ? found - (long long)n : 0;
+    if (overflow_out) { overflow_out[0] = found; overflow_out[1] = dropped; }
+    if (dropped_total) *dropped_total += dropped;      // stream-ordered: one writer per buffer
+  }
+  auto lower = [&](unsigned long long gv) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if ((key1s[mid] >> 32) < gv) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int64_t lo = lower(g), hi = lower((unsigned long long)g + 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* wg = wire + (int64_t)g * ((int64_t)max_per_group * 7 + 1);
+  int32_t* lg = labels_out ? labels_out + (int64_t)g * max_per_group : nullptr;
+  int written = 0;
+  for (int64_t base = lo; base < hi && written < max_per_group; base += 1024) {
+    int64_t p = base + threadIdx.x;
+    int32_t o = -1;
+    bool f = false;
+    if (p < hi) {
+      o = perm_glob[p];
+      f = keep_orig[o] != 0;
+    }
+    unsigned long long bal = __ballot(f);
+    int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0;
+      for (int w = 0; w < 16; w++) {
+        int c = s_wave[w];
+        s_wave[w] = acc;
+        acc += c;
+      }
+      s_total = acc;
+    }
+    __syncthreads();
+    int pos = written + s_wave[wave] + rank;
+    if (f && pos < max_per_group) {
+      const float* d = dets5 + (int64_t)o * 5;
+      float* w7 = wg + (int64_t)pos * 7;
+      const int lab = row_labels[o];
+      w7[0] = d[0]; w7[1] = d[1]; w7[2] = d[2]; w7[3] = d[3]; w7[4] = d[4];
+      w7[5] = scores[o];
+      w7[6] = (float)lab;
+      if (lg) lg[pos] = lab;
+    }
+    written += s_total;
+    __syncthreads();
+  }
+  if (written > max_per_group) written = max_per_group;
+  for (int r = written + threadIdx.x; r < max_per_group; r += 1024) {
+    float* w7 = wg + (int64_t)r * 7;
+    w7[0] = 0.f; w7[1] = 0.f; w7[2] = 0.f; w7[3] = 0.f; w7[4] = 0.f; w7[5] = 0.f; w7[6] = -1.f;
+    if (lg) lg[r] = -1;
+  }
+  if (threadIdx.x == 0) {
+    wg[(int64_t)max_per_group * 7] = (float)written;
+    if (counts_out) counts_out[g] = written;
+  }
+}
+
 __global__ void k_zero_u8(uint8_t* p, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
@@ -2580,22 +2664,53 @@ extern "C" int s2a_nms_rotated(const float* dets, const float* scores, int64_t n
                     workspace_bytes, as_stream(stream));
 }
 
-extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
-                                         const int32_t* segment_ids, const int32_t* group_ids,
-                                         int64_t n, int32_t num_segments, int32_t num_groups,
-                                         float iou_threshold, uint8_t* keep_flags, int32_t* keep,
-                                         int32_t* group_counts, int32_t max_per_group,
-                                         void* workspace, size_t workspace_bytes,
-                                         s2a_stream_t stream) {
-  hipStream_t st = as_stream(stream);
+namespace {
+// what the batched detector wants written behind the NMS (s2a_nms_rotated_segmented_dets); all NULL for the plain form
+struct NmsEmit {
+  const int32_t* row_labels;
+  float* wire;
+  int32_t* labels_out;
+  int32_t* counts_out;
+  const int64_t* cand_found;
+  int64_t* overflow_out;
+  int64_t* dropped_total;
+};
+
+__global__ __launch_bounds__(256) void k_nms_emit_empty(int32_t num_groups, int32_t max_per_group, float* __restrict__ wire,
+                                                        int32_t* __restrict__ labels_out, int32_t* __restrict__ counts_out,
+                                                        long long* __restrict__ overflow_out) {
+  if (overflow_out && blockIdx.x == 0 && threadIdx.x == 0) overflow_out[0] = overflow_out[1] = 0;
+  const int64_t row = (int64_t)max_per_group * 7 + 1, total = (int64_t)num_groups * row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t c = i % row;
+    wire[i] = (c < (int64_t)max_per_group * 7 && c % 7 == 6) ? -1.f : 0.f;
+  }
+  if (labels_out)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)num_groups * max_per_group; i += (int64_t)gridDim.x * 256)
+      labels_out[i] = -1;
+  if (counts_out && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < num_groups; i += 256) counts_out[i] = 0;
+}
+
+int nms_segmented_impl(const float* dets, const float* scores, const int32_t* segment_ids, const int32_t* group_ids,
+                       int64_t n, int32_t num_segments, int32_t num_groups, float iou_threshold, uint8_t* keep_flags,
+                       int32_t* keep, int32_t* group_counts, int32_t max_per_group, const NmsEmit& em, void* workspace,
+                       size_t workspace_bytes, hipStream_t st) {
   S2A_CHECK_ARG(n >= 0 && n < (1ll << 31), "nms_rotated_segmented: n out of range");
   S2A_CHECK_ARG(num_segments > 0 && num_groups > 0, "nms_rotated_segmented: bad segment/group count");
   S2A_CHECK_ARG(keep == nullptr || (group_counts != nullptr && max_per_group > 0),
                 "nms_rotated_segmented: keep needs group_counts and max_per_group");
+  S2A_CHECK_ARG(em.wire == nullptr || (em.row_labels != nullptr && max_per_group > 0),
+                "nms_rotated_segmented_dets: the detection rows need row_labels and max_per_group");
   if (n == 0) {
     if (keep) {
       fill_u32(keep, 0xffffffffu, (size_t)num_groups * max_per_group, st);
       fill_u32(group_counts, 0u, (size_t)num_groups, st);
+    }
+    if (em.wire) {
+      k_nms_emit_empty<<<64, 256, 0, st>>>(num_groups, max_per_group, em.wire, em.labels_out, em.counts_out,
+                                           reinterpret_cast<long long*>(em.overflow_out));
+      S2A_LAUNCH_CHECK();
     }
     return S2A_OK;
   }
@@ -2638,6 +2753,39 @@ extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
     k_nms_group_compact<<<(unsigned)num_groups, 1024, 0, st>>>(B.keyC_s, B.perm_glob, B.keep_orig, n,
                                                                max_per_group, keep, group_counts);
   }
+  if (em.wire) {
+    k_nms_group_emit<<<(unsigned)num_groups, 1024, 0, st>>>(B.keyC_s, B.perm_glob, B.keep_orig, dets, scores,
+                                                            em.row_labels, n, max_per_group, em.wire, em.labels_out,
+                                                            em.counts_out, reinterpret_cast<const long long*>(em.cand_found),
+                                                            reinterpret_cast<long long*>(em.overflow_out),
+                                                            reinterpret_cast<long long*>(em.dropped_total));
+  }
   S2A_LAUNCH_CHECK();
   return S2A_OK;
+}
+}  // namespace
+
+extern "C" int s2a_nms_rotated_segmented(const float* dets, const float* scores,
+                                         const int32_t* segment_ids, const int32_t* group_ids,
+                                         int64_t n, int32_t num_segments, int32_t num_groups,
+                                         float iou_threshold, uint8_t* keep_flags, int32_t* keep,
+                                         int32_t* group_counts, int32_t max_per_group,
+                                         void* workspace, size_t workspace_bytes,
+                                         s2a_stream_t stream) {
+  return nms_segmented_impl(dets, scores, segment_ids, group_ids, n, num_segments, num_groups, iou_threshold, keep_flags,
+                            keep, group_counts, max_per_group, NmsEmit{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, workspace,
+                            workspace_bytes, as_stream(stream));
+}
+
+extern "C" int s2a_nms_rotated_segmented_dets(const float* dets, const float* scores, const int32_t* segment_ids,
+                                              const int32_t* group_ids, const int32_t* row_labels, int64_t n,
+                                              int32_t num_segments, int32_t num_groups, float iou_threshold,
+                                              int32_t max_per_group, float* wire, int32_t* labels_out,
+                                              int32_t* counts_out, const int64_t* cand_found, int64_t* overflow_out,
+                                              int64_t* dropped_total, void* workspace, size_t workspace_bytes,
+                                              s2a_stream_t stream) {
+  S2A_CHECK_ARG(wire != nullptr, "nms_rotated_segmented_dets: NULL output");
+  return nms_segmented_impl(dets, scores, segment_ids, group_ids, n, num_segments, num_groups, iou_threshold, nullptr,
+                            nullptr, nullptr, max_per_group, NmsEmit{row_labels, wire, labels_out, counts_out, cand_found, overflow_out, dropped_total}, workspace,
+                            workspace_bytes, as_stream(stream));
 }

@@ -186,6 +186,10 @@ class FPN(nn.Module):
             if i < self.num_ins and hasattr(conv, "packed_args"):
                 w, b, o = conv.packed_args()
                 prev = conv_f16(src, w, b, o, 3, 1, False, out=dst)
+            elif isinstance(conv, FusedConv2d) and conv.bias is not None and src.is_contiguous(memory_format=torch.channels_last) \
+                    and not own_conv_ok(src, conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride,
+                                        conv.padding, conv.dilation, conv.groups):
+                prev = conv(src, out=dst)       # library convolution, its bias pass writes the pyramid slice (no copy)
             else:
                 prev = conv(src)
                 dst.copy_(prev)
@@ -232,20 +236,23 @@ class S2ANet(nn.Module):
         return tuple(map(list, zip(*per_level)))
 
     @torch.no_grad()
-    def detect(self, imgs_u8, max_candidates=None, return_overflow=False):
+    def detect(self, imgs_u8, max_candidates=None, return_overflow=False, **nms_kw):
         """device-resident uint8 batch [B,3,H,W] -> (dets[B,2000,6], labels[B,2000], counts[B]).
         /255 normalisation as val.py:246-247; no host synchronisation anywhere.
         max_candidates caps the (box, class) rows the batch's NMS considers (static shapes); the reference never
         drops one, so with return_overflow=True a fourth result int64[2] = [candidates found, candidates dropped]
-        comes back on the device (dropped must be 0 for reference-equal results)."""
+        comes back on the device (dropped must be 0 for reference-equal results).
+        nms_kw: ``dropped_total`` (device int64 accumulator) and ``return_wire`` (append the all-gather wire buffer
+        float32 [B, 2000*7+1] that ``dets`` is a view of) -- see rotated.batched_multiclass_nms_rotated."""
         if self.backbone.stem_fusable(imgs_u8):
             return self.head.get_bboxes_batched(
-                self.features_to_pred(imgs_u8, self.backbone.forward_u8(imgs_u8, 255.0)), max_candidates, return_overflow)
+                self.features_to_pred(imgs_u8, self.backbone.forward_u8(imgs_u8, 255.0)), max_candidates, return_overflow,
+                **nms_kw)
         dt = next(self.parameters()).dtype
         x = imgs_u8.to(dt).div_(255.0)
         if imgs_u8.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        return self.head.get_bboxes_batched(self.features_to_pred(x), max_candidates, return_overflow)
+        return self.head.get_bboxes_batched(self.features_to_pred(x), max_candidates, return_overflow, **nms_kw)
 
 
 def load_reference_checkpoint(model, weights, map_location="cpu"):

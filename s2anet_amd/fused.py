@@ -9,10 +9,13 @@ import torch.nn.functional as F
 from . import _lib
 
 
-def bias_act_(y, bias, residual=None, relu=False):
-    """in place: y = act(y + bias[c] (+ residual)); y must be channels-last contiguous"""
+def bias_act_(y, bias, residual=None, relu=False, out=None):
+    """in place: y = act(y + bias[c] (+ residual)); y must be channels-last contiguous.
+    out: a dense NHWC buffer of y's shape that receives the result instead (e.g. a level slice of a pyramid-packed tensor)"""
     _lib.require_cuda(y, bias, residual)
     B, C, H, W = y.shape
+    if out is not None:
+        assert out.shape == y.shape and out.dtype == y.dtype and out.permute(0, 2, 3, 1).is_contiguous()
     ok = (y.is_contiguous(memory_format=torch.channels_last) and
           C % (8 if y.dtype == torch.float16 else 4) == 0 and y.dtype in (torch.float16, torch.float32) and
           (residual is None or (residual.shape == y.shape and residual.dtype == y.dtype and
@@ -21,12 +24,14 @@ def bias_act_(y, bias, residual=None, relu=False):
         y = y + bias.view(1, -1, 1, 1).to(y.dtype)
         if residual is not None:
             y = y + residual
-        return F.relu(y) if relu else y
-    b = bias.to(y.dtype).contiguous()
+        y = F.relu(y) if relu else y
+        return y if out is None else out.copy_(y)
+    b = bias if bias.dtype == y.dtype and bias.is_contiguous() else bias.to(y.dtype).contiguous()
     with torch.cuda.device(y.device):
-        _lib.check(_lib.lib().s2a_bias_act_nhwc(_lib.ptr(y), _lib.ptr(b), _lib.ptr(residual), B * H * W, C,
-                                                _lib.dtype_code(y), int(bool(relu)), _lib.stream_ptr(y.device)))
-    return y
+        _lib.check(_lib.lib().s2a_bias_act_nhwc_to(_lib.ptr(y), _lib.ptr(b), _lib.ptr(residual),
+                                                   _lib.ptr(y if out is None else out), B * H * W, C,
+                                                   _lib.dtype_code(y), int(bool(relu)), _lib.stream_ptr(y.device)))
+    return y if out is None else out
 
 
 def own_conv_ok(x, in_channels, out_channels, kernel_size, stride, padding, dilation, groups):
@@ -207,7 +212,13 @@ class FusedConv2d(nn.Conv2d):
         width = max(64, self.out_channels)
         return self._packed.get(self.weight), self._packed.get_bias(self.bias, width), width
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, out=None):
+        """out: dense NHWC buffer for the result (library path only; the own kernel is called with out= directly)"""
+        if out is not None:
+            assert x.is_cuda and self.bias is not None and not torch.is_grad_enabled() and not own_conv_ok(
+                x, self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.dilation, self.groups)
+            y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+            return bias_act_(y, self.bias, residual, self.fuse_relu, out=out)
         if not torch.is_grad_enabled() and own_conv_ok(
                 x, self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
                 self.dilation, self.groups) and (residual is None or (

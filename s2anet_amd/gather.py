@@ -22,6 +22,8 @@ def shard_range(global_batch, world, rank):
 
 
 def pack_detections(dets, labels, counts):
+    """three tensors -> the wire buffer (tests and callers that did not come through ``detect(..., return_wire=True)``;
+    the detector itself never packs: its NMS finish kernel writes the wire buffer, s2a_nms_rotated_segmented_dets)"""
     B, K, _ = dets.shape
     buf = torch.empty((B, K * 7 + 1), dtype=torch.float32, device=dets.device)
     body = buf[:, :K * 7].view(B, K, 7)
@@ -39,19 +41,52 @@ def unpack_detections(buf, max_per_img):
 
 
 class DetectionGather:
-    """callable: (dets[B,K,6], labels[B,K], counts[B]) of this rank ->
-    (dets[world*B,K,6], labels[world*B,K], counts[world*B]) on every rank, rank-major order"""
+    """callable: this rank's wire buffer float32 [B, K*7+1] (or the (dets, labels, counts) triple, packed here) ->
+    the gathered wire buffer [world*B, K*7+1] on every rank, rank-major order; ``unpack()`` turns it into
+    (dets[world*B,K,6], labels[world*B,K], counts[world*B]).
 
-    def __init__(self, world, batch_local, max_per_img, device, group=None):
+    With ``side_stream=True`` the collective is issued on an own stream behind an event of the producing stream, so the
+    next batch's trunk (issued on the producing stream right after) overlaps it; ``wait()`` makes the current stream
+    wait for the last gather, and the rotating output slots keep a gather's result alive while the next one runs."""
+
+    def __init__(self, world, batch_local, max_per_img, device, group=None, side_stream=False, slots=2):
         self.world, self.B, self.K = world, batch_local, max_per_img
         self.group = group
-        self.out = torch.empty((world, batch_local, max_per_img * 7 + 1), dtype=torch.float32, device=device)
+        self.outs = [torch.empty((world, batch_local, max_per_img * 7 + 1), dtype=torch.float32, device=device)
+                     for _ in range(max(1, slots if side_stream else 1))]
+        self.turn = 0
+        self.stream = torch.cuda.Stream(device=device) if side_stream and torch.device(device).type == "cuda" else None
+        self.done = None
 
-    def __call__(self, dets, labels, counts):
-        buf = pack_detections(dets, labels, counts)
+    @property
+    def out(self):
+        return self.outs[(self.turn - 1) % len(self.outs)]
+
+    def __call__(self, wire, labels=None, counts=None):
+        if labels is not None:
+            wire = pack_detections(wire, labels, counts)
+        assert tuple(wire.shape) == (self.B, self.K * 7 + 1) and wire.dtype == torch.float32 and wire.is_contiguous()
+        out = self.outs[self.turn % len(self.outs)]
+        self.turn += 1
         if self.world == 1:
-            self.out[0].copy_(buf)
+            out[0].copy_(wire)
+        elif self.stream is None:
+            dist.all_gather_into_tensor(out.view(-1), wire.view(-1), group=self.group)
         else:
-            dist.all_gather_into_tensor(self.out.view(-1), buf.view(-1), group=self.group)
-        d, l, c = unpack_detections(self.out.view(self.world * self.B, -1), self.K)
-        return d, l, c
+            ready = torch.cuda.Event()
+            ready.record()                                  # the NMS finish kernel that wrote `wire`
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                dist.all_gather_into_tensor(out.view(-1), wire.view(-1), group=self.group)
+                wire.record_stream(self.stream)             # the allocator must not hand it out before the gather ran
+                self.done = torch.cuda.Event()
+                self.done.record()
+        return out.view(self.world * self.B, -1)
+
+    def wait(self):
+        """current stream waits for the last side-stream gather (no-op otherwise)"""
+        if self.done is not None:
+            torch.cuda.current_stream().wait_event(self.done)
+
+    def unpack(self, gathered=None):
+        return unpack_detections(self.out.view(self.world * self.B, -1) if gathered is None else gathered, self.K)

@@ -230,9 +230,10 @@ class S2ANetHead(nn.Module):
         bboxes = delta2bbox_rotated(anc.reshape(-1, 5), deltas.reshape(-1, 5)).reshape(B, n, 5)
         return bboxes, scores
 
-    def get_bboxes_batched(self, p, max_candidates=None, return_overflow=False):
+    def get_bboxes_batched(self, p, max_candidates=None, return_overflow=False, **nms_kw):
         """-> dets[B,max_per_img,6], labels[B,max_per_img] (-1 padded), counts[B]; no host sync.
-        return_overflow: fourth result int64[2] = [NMS candidates found, candidates dropped by max_candidates]"""
+        return_overflow: fourth result int64[2] = [NMS candidates found, candidates dropped by max_candidates];
+        nms_kw: dropped_total / return_wire of batched_multiclass_nms_rotated"""
         fused = None
         if isinstance(p, PyramidPred) and not os.environ.get("S2A_NO_FUSED_CANDIDATES"):
             from . import pyramid as P
@@ -240,7 +241,8 @@ class S2ANetHead(nn.Module):
             fused = P.candidates(layout, cls, reg, anc, self.num_classes, self.max_before_nms_per_level)
         bboxes, scores = fused[:2] if fused is not None else self.candidates(p)
         return batched_multiclass_nms_rotated(bboxes, scores, self.score_thres_before_nms,
-                                              self.iou_thres_nms, self.max_per_img, max_candidates, return_overflow)
+                                              self.iou_thres_nms, self.max_per_img, max_candidates, return_overflow,
+                                              **nms_kw)
 
     def get_bboxes(self, p):
         """reference return shape (head.py:648-682): list of (det_bboxes[K,6], det_labels[K]) per image"""

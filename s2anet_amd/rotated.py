@@ -185,8 +185,8 @@ def multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, max_per_
 
 
 def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, max_per_img=2000,
-                                   max_candidates=None, return_overflow=False):
-    """Whole-batch multiclass rotated NMS with NO host synchronisation.
+                                   max_candidates=None, return_overflow=False, dropped_total=None, return_wire=False):
+    """Whole-batch multiclass rotated NMS with NO host synchronisation and no stock tensor op.
 
     bboxes[B,n,5] f32, scores[B,n,C] -> dets[B,max_per_img,6] (x,y,w,h,a,score; zero padded),
     labels[B,max_per_img] int32 (-1 padded), counts[B] int32.  Same result per image as
@@ -194,12 +194,18 @@ def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, 
     (box, class) pairs with score > score_thr, suppressed per (image, class), survivors
     listed by descending score and truncated to max_per_img.
 
+    Two library calls: ``s2a_multiclass_candidates`` (threshold + compaction) and
+    ``s2a_nms_rotated_segmented_dets`` (NMS + the output rows, written once by its last kernel).  ``dets`` is a
+    strided view of the wire buffer ``float32 [B, max_per_img*7 + 1]`` (rows x,y,w,h,a,score,label; last column the
+    count) that the data-parallel detector all-gathers as it is (``return_wire=True`` appends it to the result).
+
     Static shapes: at most ``max_candidates`` (default n*C, i.e. lossless) candidates per
     batch are considered; the candidate list is compacted on the device.  The reference never
     drops a candidate (utils/bbox_nms_rotated.py:29-40), so a cap that is too small must not pass
-    silently: ``return_overflow=True`` adds a fourth result ``overflow`` = int64[2] on the device,
+    silently: ``return_overflow=True`` adds a result ``overflow`` = int64[2] on the device,
     ``[candidates found, candidates dropped]`` (dropped > 0 <=> the cap cut rows; still no host sync —
-    the caller reads it when it synchronises anyway).
+    the caller reads it when it synchronises anyway); ``dropped_total`` (a device int64 tensor of the caller)
+    is incremented by the dropped count of this call, on the stream, by the same kernel.
     """
     _lib.require_cuda(bboxes, scores)
     B, n, C = scores.shape
@@ -209,14 +215,19 @@ def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, 
     total = B * n * C
     cap = total if max_candidates is None else min(int(max_candidates), total)
     L = _lib.lib()
+    K = int(max_per_img)
     cboxes = torch.empty((cap, 5), dtype=torch.float32, device=dev)
     cscores = torch.empty((cap,), dtype=torch.float32, device=dev)
     seg = torch.empty((cap,), dtype=torch.int32, device=dev)
     grp = torch.empty((cap,), dtype=torch.int32, device=dev)
     cls = torch.empty((cap,), dtype=torch.int32, device=dev)
     ncand = torch.empty((1,), dtype=torch.int64, device=dev)
-    keep = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    wire = torch.empty((B, K * 7 + 1), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, K), dtype=torch.int32, device=dev)
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    overflow = torch.empty((2,), dtype=torch.int64, device=dev) if return_overflow else None
+    if dropped_total is not None:
+        assert dropped_total.dtype == torch.int64 and dropped_total.device == dev and dropped_total.numel() == 1
     with torch.cuda.device(dev):
         st = _lib.stream_ptr(dev)
         ws = _lib.workspace(L.s2a_multiclass_candidates_workspace_bytes(total), dev, "cand")
@@ -225,15 +236,14 @@ def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, 
                                                _lib.ptr(cls), _lib.ptr(ncand), _lib.ptr(ws), ws.numel(), st))
         # one (image, class) segment holds at most n rows: tight bound for the mask workspace
         ws2 = _lib.workspace(L.s2a_nms_rotated_workspace_bytes(cap, min(cap, n)), dev, "nms_b")
-        _lib.check(L.s2a_nms_rotated_segmented(
-            _lib.ptr(cboxes), _lib.ptr(cscores), _lib.ptr(seg), _lib.ptr(grp), cap, B * C, B,
-            float(iou_thr), None, _lib.ptr(keep), _lib.ptr(counts), int(max_per_img),
-            _lib.ptr(ws2), ws2.numel(), st))
-    ok = keep >= 0
-    kidx = keep.clamp(min=0).to(torch.int64)
-    dets = torch.cat([cboxes[kidx], cscores[kidx][..., None]], dim=-1)
-    dets = torch.where(ok[..., None], dets, 0.0)        # (scalars: no zeros_like / memset node in a captured graph)
-    labels = torch.where(ok, cls[kidx], -1)
+        _lib.check(L.s2a_nms_rotated_segmented_dets(
+            _lib.ptr(cboxes), _lib.ptr(cscores), _lib.ptr(seg), _lib.ptr(grp), _lib.ptr(cls), cap, B * C, B,
+            float(iou_thr), K, _lib.ptr(wire), _lib.ptr(labels), _lib.ptr(counts), _lib.ptr(ncand),
+            _lib.ptr(overflow), _lib.ptr(dropped_total), _lib.ptr(ws2), ws2.numel(), st))
+    dets = wire[:, :K * 7].view(B, K, 7)[..., :6]
+    out = (dets, labels, counts)
     if return_overflow:
-        return dets, labels, counts, torch.cat([ncand, (ncand - cap).clamp_(min=0)])
-    return dets, labels, counts
+        out += (overflow,)
+    if return_wire:
+        out += (wire,)
+    return out

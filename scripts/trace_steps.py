@@ -1,8 +1,8 @@
-"""per-kernel time inside the last N full steps of a bench.py trace; a step ends at k_nms_group_compact"""
+"""per-kernel time inside the last N full steps of a bench.py trace; a step ends at k_nms_group_emit (k_nms_group_compact before round 4)"""
 import csv, sys, collections
 path, nsteps = sys.argv[1], int(sys.argv[2])
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp']))
-marks = [int(r['End_Timestamp']) for r in rows if 'k_nms_group_compact' in r['Kernel_Name']]
+marks = [int(r['End_Timestamp']) for r in rows if ('k_nms_group_emit' in r['Kernel_Name'] or 'k_nms_group_compact' in r['Kernel_Name'])]
 t0, t1 = marks[-nsteps - 1], marks[-1]
 agg = collections.defaultdict(lambda: [0, 0.0]); busy = 0.0; n = 0
 for r in rows:

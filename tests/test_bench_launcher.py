@@ -29,6 +29,21 @@ def test_self_launch_two_ranks_gloo():
     assert out["config"]["global_batch"] == 16 and out["config"]["nms_candidates_dropped"] == 0
     assert out["gather_equals_concatenation"] is True      # gathered == rank-major concatenation of the rank outputs
     assert "roofline" not in out and "cpu_baseline" not in out
+    # per-rank attribution for a future scaling loss: the timed step, the step without the collective, the collective alone
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1]
+    assert all(r["compute_ms"] >= 0 and r["gather_ms"] >= 0 and r["step_ms"] > 0 for r in out["per_rank"])
+
+
+def test_self_launch_eight_ranks_gloo():
+    """the driver's N = 8 shape (BASELINE configs[3]: batch 64 over 8 ranks), rehearsed on CPU with the stub detector"""
+    r = _run({}, "--gpus", "8", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 64 and out["stub"] is True
+    assert out["gather_equals_concatenation"] is True and len(out["per_rank"]) == 8
+    assert out["config"]["parallelism"].startswith("dp8")
 
 
 def test_failed_rank_fails_the_launch():

@@ -26,7 +26,12 @@ def worker(rank, world, port, B, K, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     gather = DetectionGather(world, B, K, torch.device("cpu"))
-    d, l, c = gather(*make_rank_output(rank, B, K))
+    d0, l0, c0 = make_rank_output(rank, B, K)
+    wire = gather(pack_detections(d0, l0, c0))            # the detector hands over its wire buffer as it is
+    assert tuple(wire.shape) == (world * B, K * 7 + 1)
+    d, l, c = gather.unpack(wire)
+    d2, l2, c2 = gather.unpack(gather(d0, l0, c0))         # the triple form packs first: same result
+    assert torch.equal(d, d2) and torch.equal(l, l2) and torch.equal(c, c2)
     q.put((rank, d.clone(), l.clone(), c.clone()))
     dist.barrier()
     dist.destroy_process_group()

@@ -476,6 +476,42 @@ def test_batched_multiclass_nms_equals_per_image(rng):
             assert (labels[b, kb:] == -1).all()
 
 
+def test_batched_nms_writes_the_wire_buffer_and_counts_dropped_candidates(rng):
+    """the NMS finish kernel writes the detection rows once: dets / labels / counts and the all-gather wire buffer are
+    the same memory or exact copies, padding rows are 0,...,0,-1, the candidate cap is accounted without a host sync"""
+    import s2anet_amd as S
+    from s2anet_amd.gather import unpack_detections
+    B, n, C, K = 3, 500, 15, 120
+    boxes = np.stack([rand_rboxes(rng, n, span=240) for _ in range(B)])
+    scores = (rng.random((B, n, C)) ** 8).astype(np.float32)
+    scores[1] *= 0.01                                             # an image without candidates
+    found = int((scores > 0.05).sum())
+    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    dets, labels, counts, ovf, wire = S.batched_multiclass_nms_rotated(
+        cu(boxes), cu(scores), 0.05, 0.5, K, return_overflow=True, dropped_total=total, return_wire=True)
+    assert tuple(wire.shape) == (B, K * 7 + 1) and dets.data_ptr() == wire.data_ptr()      # dets is a view of the wire buffer
+    d2, l2, c2 = unpack_detections(wire, K)
+    assert torch.equal(d2, dets) and torch.equal(l2, labels) and torch.equal(c2, counts)
+    assert ovf.cpu().tolist() == [found, 0] and int(total) == 0
+    for b in range(B):
+        rd, rl = oracle.multiclass_nms_rotated(boxes[b], scores[b], 0.05, 0.5, K)
+        kb = int(counts[b])
+        assert kb == len(rd) and np.array_equal(dets[b, :kb].cpu().numpy(), rd)
+        assert np.array_equal(labels[b, :kb].cpu().numpy().astype(np.float32), rl)
+        assert (labels[b, kb:] == -1).all() and (dets[b, kb:] == 0).all()
+        assert (wire[b, :K * 7].view(K, 7)[kb:, 6] == -1).all()
+    assert int(counts[1]) == 0
+    # a cap below the candidate count: reported twice (this call, running total), never silent
+    cap = found - 37
+    for rep in (1, 2):
+        _, _, _, ovf2 = S.batched_multiclass_nms_rotated(cu(boxes), cu(scores), 0.05, 0.5, K, max_candidates=cap,
+                                                         return_overflow=True, dropped_total=total)
+        assert ovf2.cpu().tolist() == [found, 37] and int(total) == 37 * rep
+    # no candidate at all in the batch
+    d0, l0, c0, o0 = S.batched_multiclass_nms_rotated(cu(boxes), cu(scores * 0), 0.05, 0.5, K, return_overflow=True)
+    assert (d0 == 0).all() and (l0 == -1).all() and (c0 == 0).all() and o0.cpu().tolist() == [0, 0]
+
+
 # ------------------------------------------------------------------ ORN
 def test_arf_and_pool(rng):
     import s2anet_amd as S
