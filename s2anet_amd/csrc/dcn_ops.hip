@@ -785,6 +785,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   char* s_B = smem + NPOS * 9 * 16;
   char* s_patch = s_B + 2 * NPOS * kRowBytes;
 
+  const bool half_coords = (relu & 2) != 0;          // relu: bit 0 = ReLU epilogue, bit 1 = S2A_DCN_HALF_COORDS
+  auto rh16 = [](float v) { return (float)(_Float16)v; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (waves 0-3 = matrix: the older half wins issue
                                                                    // arbitration; roles swapped measured 4 % slower)
   int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -903,11 +905,19 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
       } else {
         anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
       }
+      // half_coords: the reference's scalar_t = Half instantiation (deform_conv.py:45-46 casts the offsets to half;
+      // deform_conv_cuda_kernel.cu:221-228 h_im / w_im, :97-109 lh / lw / hh / hw and the four weights are Half
+      // results): every one of them rounded to binary16.  Default: f32 coordinates.
+      if (half_coords) { off_y = rh16(off_y); off_x = rh16(off_x); }
       float h_im = (float)(y - 1 + ky) + off_y;
       float w_im = (float)(xq - 1 + kx) + off_x;
+      if (half_coords) { h_im = rh16(h_im); w_im = rh16(w_im); }
       if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
         int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+        float lh = h_im - h_low, lw = w_im - w_low;
+        if (half_coords) { lh = rh16(lh); lw = rh16(lw); }
+        float hh = 1 - lh, hw = 1 - lw;
+        if (half_coords) { hh = rh16(hh); hw = rh16(hw); }
         bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
         tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
         tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
@@ -1172,7 +1182,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             float v = acc16[D16 ? a : 0][D16 ? b : 0][e];
-            if (relu) v = fmaxf(v, 0.f);
+            if (relu & 1) v = fmaxf(v, 0.f);
             v4[e] = (_Float16)v;
           }
           *reinterpret_cast<h4*>(s_out + (16 * b + pix16) * kOutRow + (wave * 64 + 16 * a + 4 * kg16) * 2) = v4;
@@ -1189,7 +1199,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
             for (int e = 0; e < 4; e++) {
               float v = acc[a][b][rq * 4 + e];
-              if (relu) v = fmaxf(v, 0.f);
+              if (relu & 1) v = fmaxf(v, 0.f);
               v4[e] = (_Float16)v;
             }
             int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);   // rows (r&3)+8*(r>>2)+4*(lane>>5)
@@ -1216,7 +1226,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             float v = acc16[a][b][e];
-            if (relu) v = fmaxf(v, 0.f);
+            if (relu & 1) v = fmaxf(v, 0.f);
             const int och = o0 + wave * 64 + 16 * a + 4 * kg16 + e;
             const int64_t gp = out_pos(16 * b + pix16);
             if (gp >= 0) {
@@ -1233,7 +1243,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           float v = acc[a][b][r];
-          if (relu) v = fmaxf(v, 0.f);
+          if (relu & 1) v = fmaxf(v, 0.f);
           int och = o0 + wave * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           int64_t gp = out_pos(32 * b + (lane & 31));
           if (gp >= 0) {
@@ -2140,6 +2150,11 @@ inline bool fast_path_ok(const s2a_dcn_params& p) {
 
 inline size_t esize(int dtype) { return dtype == S2A_DTYPE_F32 ? 4 : 2; }
 
+inline bool half_coords_requested() {
+  const char* f = getenv("S2A_DCN_HALF_COORDS");
+  return f && atoi(f) != 0;
+}
+
 template <typename T>
 int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* wp, const T* wfrag,
                 T* out, bool out_nhwc, int64_t B, int C, int H, int W, int O, float stride, int relu,
@@ -2189,6 +2204,13 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
   // tiles, but 256 tiles -- exactly one full round -- 50 -> 61 us as 512 half tiles)
   const int64_t rounds_full = (ntiles(128) + n_cu_fast - 1) / n_cu_fast, rounds_half = (2 * ntiles(128) + n_cu_fast - 1) / n_cu_fast;
   const bool half_tiles = 62 * rounds_half < 100 * rounds_full && !getenv("S2A_DCN_NO_HALF");
+  // S2A_DCN_HALF_COORDS=1: sampling coordinates and weights rounded as the reference's Half instantiation rounds them
+  // (f16 inputs only -- the f32 instantiation keeps f32 coordinates; built into the patch-staged kernel alone)
+  const int hc_bit = half_coords_requested() && sizeof(T) == 2 ? 2 : 0;
+  if (hc_bit && !patch_ok) {
+    set_error("deform_conv: S2A_DCN_HALF_COORDS=1 needs the patch-staged f16 kernel (>= 128 position tiles, C %% 64 == 0)");
+    return S2A_ENOTIMPL;
+  }
 #define S2A_DCN_LAUNCH_PATCH(NHWC, SRC)                                                           \
   do {                                                                                            \
     if constexpr (sizeof(T) == 2) {                                                               \
@@ -2198,14 +2220,14 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
         dim3 grid((unsigned)(2 * ntiles(128)), (unsigned)((O + kMaxO - 1) / kMaxO));              \
         S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLdsF));      \
-        kern<<<grid, 512, kHalfLdsF, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, relu, \
+        kern<<<grid, 512, kHalfLdsF, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, (relu ? 1 : 0) | hc_bit, \
                                            (unsigned)x_bytes, LevelTab{}, 0);                     \
       } else {                                                                                    \
         auto kern = k_dcn_patch<NHWC, SRC>;                                                       \
         dim3 grid((unsigned)ntiles(128), (unsigned)((O + kMaxO - 1) / kMaxO));                    \
         S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));      \
-        kern<<<grid, 512, kPatchLds, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, relu, \
+        kern<<<grid, 512, kPatchLds, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, (relu ? 1 : 0) | hc_bit, \
                                            (unsigned)x_bytes, LevelTab{}, 0);                     \
       }                                                                                           \
     }                                                                                             \
@@ -2754,7 +2776,8 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
   auto kern = k_dcn_patch<true, 1>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
   kern<<<dim3((unsigned)tiles, ogroups), 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
-                                                               lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu, 0u, lt, 0);
+                                                               lt.H[0], lt.W[0], (int)out_channels, lt.stride[0],
+                                                               (relu ? 1 : 0) | (half_coords_requested() ? 2 : 0), 0u, lt, 0);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
