@@ -29,11 +29,41 @@ RULE_GE = 0    # reference CPU NMS: suppress when iou >= thr
 RULE_GT = 1    # reference GPU NMS: suppress when iou >  thr
 
 
+def _src_sha():
+    import hashlib
+    with open(os.path.join(_HERE, "s2a_oracle.cpp"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def _gpu_or_profiler_live():
+    """a process that has initialised the GPU (or that a GPU profiler is preloaded into) must not start child processes
+    on this pool: then a missing / stale library is an error to report, not something to rebuild"""
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("HSA_TOOLS_LIB") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return True
+    try:
+        import sys
+        torch = sys.modules.get("torch")
+        return bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        return False
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "s2a_oracle.cpp")
-    if force or (not os.path.exists(_LIB_PATH)) or (
-            os.path.exists(src) and os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    """compile libs2a_oracle.so when it is missing or its source changed.  Staleness is decided by the CONTENT of the
+    source (sha256 kept beside the library), not by mtimes: a snapshot copied to the GPU box does not keep them."""
+    stamp = _LIB_PATH + ".src_sha256"
+    want = _src_sha()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if not force and os.path.exists(_LIB_PATH) and have == want:
+        return _LIB_PATH
+    if _gpu_or_profiler_live():
+        if os.path.exists(_LIB_PATH) and have is None and not force:
+            return _LIB_PATH            # a library built before the stamp existed: use it, never shell out from here
+        raise RuntimeError("oracle/libs2a_oracle.so is missing or stale and this process has the GPU initialised: build it "
+                           "first (python -c 'import oracle; oracle.build()' or __graft_entry__.build())")
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
     return _LIB_PATH
 
 
