@@ -258,8 +258,9 @@ def measure_ops(dev, with_cpu=True):
     p1 = rbox_to_poly(b1)[ii].double()
     shift = torch.from_numpy(rng.normal(0, 8, (m, 1, 2))).to(dev)
     p2 = (p1.view(m, 4, 2) + shift).reshape(m, 8).contiguous()
-    overl = float((S.polyiou_pairs(p1, p2) > 0).double().mean())
-    sec = _time_launches(lambda: S.polyiou_pairs(p1, p2), iters=10)
+    from s2anet_amd.rotated import polyiou_pairs
+    overl = float((polyiou_pairs(p1, p2) > 0).double().mean())
+    sec = _time_launches(lambda: polyiou_pairs(p1, p2), iters=10)
     ops["polyiou_1M_pairs"] = {"us": round(sec * 1e6, 1), "Mpairs_s": round(m / sec / 1e6, 1), "dtype": "f64",
                                "overlapping_fraction": round(overl, 3), "bound": "fp64 vector ALU (Sutherland-Hodgman per pair)"}
     del b1, b2, p1, p2, ii, shift
@@ -613,7 +614,11 @@ def main():
     # the wire buffer and adds the dropped-candidate count to the accumulator: no stock tensor op behind the detector.
     # With one batch at a time the all-gather goes to a side stream behind an event, so that batch i's gather overlaps
     # batch i+1's trunk; with several batches in flight each stream's gather already overlaps the other streams' work.
-    side = world > 1 and not stub and args.streams <= 1 and not args.graph and not os.environ.get("S2A_BENCH_NO_SIDE_GATHER")
+    # (RCCL only: ProcessGroupNCCL orders its collective behind the current stream with events and never blocks the host;
+    # gloo's CUDA path blocks the host in wait() -- the rehearsal backend measured 72 vs 14 ms per step with the side
+    # stream -- so the rehearsal keeps the gather on the compute stream)
+    side = (world > 1 and not stub and backend == "nccl" and args.streams <= 1 and not args.graph
+            and not os.environ.get("S2A_BENCH_NO_SIDE_GATHER"))
     gathers = [DetectionGather(world, B, model.head.max_per_img, dev, side_stream=side) for _ in range(nslots)] \
         if world > 1 else None
     dropped = [torch.zeros((1,), dtype=torch.int64, device=dev) for _ in range(nslots)]
