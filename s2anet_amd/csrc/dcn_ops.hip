@@ -288,6 +288,24 @@ __device__ __forceinline__ f16x8 blend_pk(const f16x8 (&v)[4], const float (&w)[
   return r;
 }
 
+// the same blend with the four weights still in binary16 (the sampling table stores them so): no conversions
+__device__ __forceinline__ f16x8 blend_pk_h(const f16x8 (&v)[4], const _Float16 (&w)[4]) {
+  f16x8 r;
+  const f16x2 w0 = {w[0], w[0]}, w1 = {w[1], w[1]}, w2 = {w[2], w[2]}, w3 = {w[3], w[3]};
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const f16x2 a0 = {v[0][2 * e], v[0][2 * e + 1]}, a1 = {v[1][2 * e], v[1][2 * e + 1]};
+    const f16x2 a2 = {v[2][2 * e], v[2][2 * e + 1]}, a3 = {v[3][2 * e], v[3][2 * e + 1]};
+    f16x2 acc = w0 * a0;
+    acc = __builtin_elementwise_fma(w1, a1, acc);
+    acc = __builtin_elementwise_fma(w2, a2, acc);
+    acc = __builtin_elementwise_fma(w3, a3, acc);
+    r[2 * e] = acc[0];
+    r[2 * e + 1] = acc[1];
+  }
+  return r;
+}
+
 // XCD-aware tile order: blockIdx round-robins over the 8 XCDs (private L2 each); give every XCD
 // a contiguous run of position tiles so neighbouring tiles (which sample overlapping input rows)
 // share one L2.  Bijective for any tile count (cdna guide T1).
@@ -1251,6 +1269,379 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
             out[(bi * O + och) * HW + p] = (T)v;
           }
         }
+  }
+}
+
+// ------------------------------------------------------------------ symmetric 16 x 16-tile AlignConv (f16; round 4)
+// k_dcn_patch pairs ONE matrix wave with ONE loader wave per SIMD: each role alone needs ~1.5 k cycles of its own work
+// per 1.0 k cycles of MFMA (stamps) and an in-order wave has nothing to put into its own stalls.  Here every
+// wave does both jobs on a tile of twice the size, the way the conv towers run (two matrix waves per SIMD):
+//   * tile = 16 x 16 positions x 256 out channels, 8 waves: wave = (out-channel group of 64, tile rows 0-7 | 8-15)
+//   * a stage = one tap x 32 input channels = ONE k-step of v_mfma_f32_16x16x32_f16: 32 MFMAs per wave; the 32-channel
+//     patch around the tile (24 x 24 pixels x 64 B = 36 KB) is double-buffered and arrives by LDS-DMA (no registers)
+//   * in every stage interval a wave blends its 2 of the 1024 (position, 8-channel group) items of the NEXT stage's column
+//     tile and contracts the CURRENT one; waves 0-3 blend first, waves 4-7 contract first (SIMD partners are w and w+4),
+//     so that one partner's MFMAs run beside the other's LDS / VALU work instead of both queueing for the matrix pipe
+//   * the filter comes in its own fragment order (k_pack_weight_sym): one contiguous 1 KB load per 16-channel tile, and
+//     the out-channel <-> MFMA-row map is chosen so that a lane ends up with 16 CONSECUTIVE out channels of one pixel:
+//     the epilogue stores straight from the accumulators (two 16-byte stores per pixel and lane, no LDS staging)
+// Summation order: 32-channel chunks outermost, taps inside (k_dcn_patch: 64-channel chunks, taps, two k-steps) -- the two
+// kernels agree within f32 accumulation noise, not bit for bit; both are checked against the oracle with the same bound.
+constexpr int kSymPW = 24;                                  // patch: 16 + 2 * kHalo pixels each way
+constexpr int kSymPatchBytes = kSymPW * kSymPW * 64;        // 36 864 (32 channels)
+constexpr int kSymPieces = kSymPatchBytes / 1024;           // 36 LDS-DMA pieces
+constexpr int kSymBRow = 96;                                // column-tile row: 64 B + 32 B pad (conflict-free B fragments:
+                                                            // slot = 6 * position + k-group mod 16, see the lane groups above)
+constexpr int kSymBBytes = 256 * kSymBRow;                  // 24 576
+constexpr int kSymTabBytes = 256 * 9 * 16;                  // 36 864
+constexpr int kSymLds = kSymTabBytes + 2 * kSymBBytes + 2 * kSymPatchBytes;   // 159 744 B
+
+// weight [O][C][9] f16 -> [stage = c32*9 + t][och group of 64][a 4][lane 64][8 halfs]: lane (i = l & 15, kg = l >> 4),
+// element j of fragment a = W[g*64 + 16*(i >> 2) + 4*a + (i & 3)][32*c32 + 8*kg + j][t]
+__global__ void k_pack_weight_sym(const _Float16* __restrict__ w, int O, int C, _Float16* __restrict__ wp) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)O * C * 9) return;
+  const int G = O / 64;
+  const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), a = (int)((e >> 9) & 3);
+  const int64_t r = e >> 11;
+  const int g = (int)(r % G), st = (int)(r / G), t = st % 9, c32 = st / 9;
+  const int i = lane & 15, kg = lane >> 4;
+  const int och = g * 64 + 16 * (i >> 2) + 4 * a + (i & 3);
+  const int k = c32 * 32 + 8 * kg + j;
+  wp[e] = w[((int64_t)och * C + k) * 9 + t];
+}
+
+__global__ __launch_bounds__(512, 2) void k_dcn_sym(const _Float16* __restrict__ x_, const float* __restrict__ src_,
+                                                    const _Float16* __restrict__ wsym, _Float16* __restrict__ out_,
+                                                    int C, int O, int relu, LevelTab lt) {
+  using T = _Float16;
+  using V = f16x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  PTap* s_tab = reinterpret_cast<PTap*>(smem);
+  char* s_B = smem + kSymTabBytes;
+  char* s_patch = s_B + 2 * kSymBBytes;
+  const bool half_coords = (relu & 2) != 0;          // relu: bit 0 = ReLU epilogue, bit 1 = S2A_DCN_HALF_COORDS
+  auto rh16 = [](float v) { return (float)(_Float16)v; };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave & 3, blk = wave >> 2;
+  int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  int H = 1, W = 1, t0 = 0, p0 = 0;
+  float stride = 1.f;
+#pragma unroll
+  for (int i = 0; i < kMaxLevels; i++)
+    if (i < lt.n && tile >= lt.tile0[i]) {
+      t0 = lt.tile0[i]; p0 = lt.pix0[i]; H = lt.H[i]; W = lt.W[i]; stride = lt.stride[i];
+    }
+  tile -= t0;
+  const int64_t Ntot = (int64_t)lt.batch * H * W;
+  const T* x = x_ + (int64_t)p0 * C;
+  T* out = out_ + (int64_t)p0 * O;
+  const float* src = src_ + (int64_t)p0 * 5;
+  const unsigned x_bytes = (unsigned)(Ntot * C * 2);
+  const int64_t HW = (int64_t)H * W;
+  const int txn = (W + 15) / 16, tyn = (H + 15) / 16;
+  const int64_t bimg = tile / (txn * tyn);
+  const int trem = (int)(tile % (txn * tyn));
+  const int ty0 = (trem / txn) * 16, tx0 = (trem % txn) * 16;
+  const int oy = ty0 - kHalo, ox = tx0 - kHalo;
+  const int o0 = blockIdx.y * kMaxO;
+  const int Oloc = min(kMaxO, O - o0);
+  const int G = O / 64, NC = C / 32, nstage = 9 * NC, last = nstage - 1;
+  const unsigned row_bytes = (unsigned)C * 2;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
+
+  // ---- patch chunk c (32 channels) -> LDS, 1 KB pieces (36 per chunk): slot v = piece * 64 + lane = pixel * 4 + 16-byte
+  // group; pixels outside the image get an out-of-range offset (zeros).  Through a register, not LDS-DMA: behind a DMA the
+  // compiler cannot tell which LDS reads it may alias and puts s_waitcnt vmcnt(0) in front of EVERY ds_read of the loop
+  // (each blend then waited for the filter fragments that had just been requested).  One piece per wave and stage
+  // interval at taps 0-4, written to LDS an interval later; every consumer of a vector-memory result of the loop sits
+  // behind the interval's barrier, so the conservative vmcnt(0) hipcc places behind a branch with a load costs nothing.
+  unsigned pvoff[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const int i = wave + 8 * j, v = i * 64 + lane, p = v >> 2, q = v & 3;
+    const int yy = oy + p / kSymPW, xx = ox + p % kSymPW;
+    const bool in = i < kSymPieces && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    pvoff[j] = in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
+  }
+  auto piece_load = [&](int c, int j) -> V {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)pvoff[j], c * 64, 0));
+  };
+  auto piece_store = [&](int c, int i, const V& v) {
+    if (i < kSymPieces) *reinterpret_cast<V*>(s_patch + (c & 1) * kSymPatchBytes + (i * 64 + lane) * 16) = v;
+  };
+  S2A_STAMP_AT(0);
+  V pv0[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) pv0[j] = piece_load(0, j);
+
+  // ---- filter fragments: global -> registers, one stage ahead
+  const int g = min(o0 / 64 + grp, G - 1);
+  const V* wbase = reinterpret_cast<const V*>(wsym) + (int64_t)g * 256 + lane;
+  auto load_w = [&](int st, V (&wv)[4]) {
+    const V* p = wbase + (int64_t)st * G * 256;
+#pragma unroll
+    for (int a = 0; a < 4; a++) wv[a] = p[a * 64];
+  };
+  V wA[4], wN[4];
+  load_w(0, wA);
+
+  // ---- per-position anchor context, then the sampling table (same arithmetic as k_dcn_patch)
+  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);
+  if (tid < 256) {
+    const int y = ty0 + (tid >> 4), xq = tx0 + (tid & 15);
+    AnchorCtx c = {0, 0, 0, 0, 1, 0};
+    if (y < H && xq < W) c = anchor_ctx(src + (bimg * HW + (int64_t)y * W + xq) * 5, stride);
+    s_ctx[tid] = c;
+  }
+  __syncthreads();
+  for (int e = tid; e < 256 * 9; e += 512) {
+    const int pl = e / 9, t = e % 9;
+    const int y = ty0 + (pl >> 4), xq = tx0 + (pl & 15);
+    PTap tp;
+    tp.y = (short)oy;
+    tp.x = (short)ox;
+    tp.flags = 1u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
+    if (y < H && xq < W) {
+      const int ky = t / 3, kx = t % 3;
+      float off_y, off_x;
+      anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
+      if (half_coords) { off_y = rh16(off_y); off_x = rh16(off_x); }
+      float h_im = (float)(y - 1 + ky) + off_y;
+      float w_im = (float)(xq - 1 + kx) + off_x;
+      if (half_coords) { h_im = rh16(h_im); w_im = rh16(w_im); }
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        float lh = h_im - h_low, lw = w_im - w_low;
+        if (half_coords) { lh = rh16(lh); lw = rh16(lw); }
+        float hh = 1 - lh, hw = 1 - lw;
+        if (half_coords) { hh = rh16(hh); hw = rh16(hw); }
+        const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+        tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
+        tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
+        tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
+        tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
+        tp.y = (short)h_low;
+        tp.x = (short)w_low;
+        const bool in = h_low >= oy && h_low + 1 <= oy + kSymPW - 1 && w_low >= ox && w_low + 1 <= ox + kSymPW - 1;
+        const int py = min(max(h_low - oy, 0), kSymPW - 2), px = min(max(w_low - ox, 0), kSymPW - 2);
+        tp.flags = (in ? 1u : 0u) | ((unsigned)((py * kSymPW + px) * 64) << 1);
+      }
+    }
+    s_tab[e] = tp;
+  }
+#pragma unroll
+  for (int j = 0; j < 5; j++) piece_store(0, wave + 8 * j, pv0[j]);
+  S2A_STAMP_AT(1);
+  __syncthreads();   // table + patch 0 in LDS; s_ctx is dead
+  S2A_STAMP_AT(2);
+
+  // ---- column tile of stage st (tap st % 9 of chunk st / 9): this thread's two (position, 8-channel group) items
+  auto blend = [&](int st, int t, int c) {
+    const char* P = s_patch + (c & 1) * kSymPatchBytes;
+    char* Bm = s_B + (st & 1) * kSymBBytes;
+    PTap tp[2];
+    V cv[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int item = tid + 512 * it, pl = item >> 2, q = item & 3;
+      tp[it] = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + t]));
+      const char* b0 = P + (tp[it].flags >> 1) + q * 16;
+      cv[it][0] = *reinterpret_cast<const V*>(b0);
+      cv[it][1] = *reinterpret_cast<const V*>(b0 + 64);
+      cv[it][2] = *reinterpret_cast<const V*>(b0 + kSymPW * 64);
+      cv[it][3] = *reinterpret_cast<const V*>(b0 + kSymPW * 64 + 64);
+    }
+    bool any_out = false;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int item = tid + 512 * it, pl = item >> 2, q = item & 3;
+      const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
+      *reinterpret_cast<V*>(Bm + pl * kSymBRow + q * 16) = blend_pk(cv[it], cw);
+      any_out |= !(tp[it].flags & 1u);
+    }
+    if (any_out) {     // rare: a corner left the patch -> global gather for that (position, tap)
+      for (int it = 0; it < 2; it++) {
+        if (tp[it].flags & 1u) continue;
+        const int item = tid + 512 * it, pl = item >> 2, q = item & 3;
+        V g4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int yy = min(max((int)tp[it].y + (k >> 1), 0), H - 1), xx = min(max((int)tp[it].x + (k & 1), 0), W - 1);
+          const unsigned vo = (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16);
+          g4[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, c * 64, 0));
+        }
+        const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
+        *reinterpret_cast<V*>(Bm + pl * kSymBRow + q * 16) = blend_pk(g4, cw);
+      }
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[a][b][r] = 0.f;
+  const int i16 = lane & 15, kg16 = lane >> 4;
+  const int boff = (blk * 128 + i16) * kSymBRow + kg16 * 16;      // b-tile b = tile row 8 * blk + b: + b * 16 rows
+  auto mma = [&](int st, const V (&wv)[4]) {
+    const char* Bm = s_B + (st & 1) * kSymBBytes + boff;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {          // four b-tiles at a time: 16 registers of fragments instead of 32
+      V pf[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) pf[b] = *reinterpret_cast<const V*>(Bm + (4 * h + b) * 16 * kSymBRow);
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          acc[a][4 * h + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[a], pf[b], acc[a][4 * h + b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // One stage interval of a wave: contract stage st AND blend this thread's two items of stage st + 1 (tap tn of chunk cn),
+  // as ONE instruction stream in two halves -- LDS requests first (four B fragments, the item's table entry, then its four
+  // corners), sixteen MFMAs with the blend's packed FMAs issued between them (an MFMA occupies the matrix pipe for 16
+  // cycles but the issue port for 8: an in-order wave can put two vector instructions into every gap), the column store
+  // last.  Written as separate blend / contract phases each wave needed ~650 + ~650-1200 cycles per interval for 512
+  // cycles of MFMA (stamps); sched_group_barrier pins the interleaving, hipcc otherwise clusters the MFMAs.
+  // Items whose corners left the patch are redone from global memory afterwards (rare).
+  auto fused = [&](int st, const V (&wv)[4], int tn, int cn) {
+    const char* Bc = s_B + (st & 1) * kSymBBytes + boff;
+    const char* P = s_patch + (cn & 1) * kSymPatchBytes;
+    char* Bn = s_B + ((st + 1) & 1) * kSymBBytes;
+    unsigned all_in = 1u;
+#define S2A_SB() __builtin_amdgcn_sched_barrier(0)
+#define S2A_MMA(AA, BB) acc[AA][4 * h + (BB)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[AA], pf[BB], acc[AA][4 * h + (BB)], 0, 0, 0)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      // blocks pinned in this order by sched_barrier (hipcc otherwise clusters the 16 MFMAs in front of the blend):
+      // LDS requests (4 fragments + table entry) | 4 MFMAs | corner requests | 4 MFMAs | 4 x (2 MFMAs + the four packed
+      // multiply-adds of one pair of the item's 8 channels) | column store
+      const int item = tid + 512 * h, pl = item >> 2, q = item & 3;
+      V pf[4], cv[4];
+#pragma unroll
+      for (int bb = 0; bb < 4; bb++) pf[bb] = *reinterpret_cast<const V*>(Bc + (4 * h + bb) * 16 * kSymBRow);
+      const PTap tp = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + tn]));
+      S2A_SB();
+      S2A_MMA(0, 0); S2A_MMA(0, 1); S2A_MMA(0, 2); S2A_MMA(0, 3);
+      S2A_SB();
+      const char* b0 = P + (tp.flags >> 1) + q * 16;
+      cv[0] = *reinterpret_cast<const V*>(b0);
+      cv[1] = *reinterpret_cast<const V*>(b0 + 64);
+      cv[2] = *reinterpret_cast<const V*>(b0 + kSymPW * 64);
+      cv[3] = *reinterpret_cast<const V*>(b0 + kSymPW * 64 + 64);
+      const f16x2 w0 = {tp.w[0], tp.w[0]}, w1 = {tp.w[1], tp.w[1]}, w2 = {tp.w[2], tp.w[2]}, w3 = {tp.w[3], tp.w[3]};
+      all_in &= tp.flags;
+      S2A_SB();
+      S2A_MMA(1, 0); S2A_MMA(1, 1); S2A_MMA(1, 2); S2A_MMA(1, 3);
+      S2A_SB();
+      V r;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (e == 0) { S2A_MMA(2, 0); S2A_MMA(2, 1); }
+        if (e == 1) { S2A_MMA(2, 2); S2A_MMA(2, 3); }
+        if (e == 2) { S2A_MMA(3, 0); S2A_MMA(3, 1); }
+        if (e == 3) { S2A_MMA(3, 2); S2A_MMA(3, 3); }
+        const f16x2 a0 = {cv[0][2 * e], cv[0][2 * e + 1]}, a1 = {cv[1][2 * e], cv[1][2 * e + 1]};
+        const f16x2 a2 = {cv[2][2 * e], cv[2][2 * e + 1]}, a3 = {cv[3][2 * e], cv[3][2 * e + 1]};
+        f16x2 sacc = w0 * a0;                                // explicit FMAs in the reference's order, as blend_pk
+        sacc = __builtin_elementwise_fma(w1, a1, sacc);
+        sacc = __builtin_elementwise_fma(w2, a2, sacc);
+        sacc = __builtin_elementwise_fma(w3, a3, sacc);
+        r[2 * e] = sacc[0];
+        r[2 * e + 1] = sacc[1];
+        S2A_SB();
+      }
+      *reinterpret_cast<V*>(Bn + pl * kSymBRow + q * 16) = r;
+      S2A_SB();
+    }
+#undef S2A_MMA
+#undef S2A_SB
+    if (__builtin_amdgcn_ballot_w64(!(all_in & 1u)) != 0) {     // rare: a corner left the patch -> global gather
+      for (int h = 0; h < 2; h++) {
+        const int item = tid + 512 * h, pl = item >> 2, q = item & 3;
+        const PTap tp = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + tn]));
+        if (tp.flags & 1u) continue;
+        V g4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int yy = min(max((int)tp.y + (k >> 1), 0), H - 1), xx = min(max((int)tp.x + (k & 1), 0), W - 1);
+          const unsigned vo = (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16);
+          g4[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, cn * 64, 0));
+        }
+        *reinterpret_cast<V*>(Bn + pl * kSymBRow + q * 16) = blend_pk_h(g4, tp.w);
+      }
+    }
+  };
+
+  V pv = pv0[0];
+  blend(0, 0, 0);
+  __syncthreads();
+  S2A_STAMP_AT(3);
+  unsigned long long t_tic = 0, t_blend = 0, t_mma = 0, t_wait = 0;
+  (void)t_tic; (void)t_blend; (void)t_mma; (void)t_wait;
+  // one interval per stage: contract stage s, blend stage s + 1; filter fragments of s + 1 and (at a chunk's first tap) the
+  // patch of the chunk after the next one's predecessor ... i.e. chunk s/9 + 1 into the buffer chunk s/9 - 1 left
+#define S2A_SYM_STEP(S_, WC, WN)                                                       \
+  {                                                                                    \
+    const int s_ = (S_);                                                               \
+    /* next chunk's patch, one piece per wave and interval: requested at taps 0-4, written at taps 1-5 (its buffer   \
+       was last read two intervals before tap 0; the chunk is first read in the interval of tap 8) */                \
+    if (tcur >= 1 && tcur <= 5 && ccur + 1 < NC) piece_store(ccur + 1, wave + 8 * (tcur - 1), pv);                   \
+    if (tcur < 5 && ccur + 1 < NC) {                                                   \
+      const unsigned vo_ = tcur == 0 ? pvoff[0] : tcur == 1 ? pvoff[1] : tcur == 2 ? pvoff[2] : tcur == 3 ? pvoff[3] : pvoff[4]; \
+      pv = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo_, (ccur + 1) * 64, 0));           \
+    }                                                                                  \
+    load_w(min(s_ + 1, last), WN);                                                     \
+    /* stage s + 1 (behind the last stage: the last one again -- its columns go to the buffer nobody reads any more) */ \
+    const int tn_ = s_ == last ? tcur : (tcur == 8 ? 0 : tcur + 1), cn_ = s_ == last ? ccur : (tcur == 8 ? ccur + 1 : ccur); \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    S2A_TIC();                                                                         \
+    fused(s_, WC, tn_, cn_);                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    S2A_TOC(t_mma); S2A_TIC();                                                         \
+    __syncthreads();                                                                   \
+    S2A_TOC(t_wait);                                                                   \
+    tcur = tn_; ccur = cn_;                                                            \
+  }
+  int tcur = 0, ccur = 0;                    // tap and chunk of the stage being contracted
+  for (int s = 0; s < nstage; s += 2) {      // nstage = 9 * C / 32 is even (C % 64 == 0)
+    S2A_SYM_STEP(s, wA, wN)
+    S2A_SYM_STEP(s + 1, wN, wA)
+  }
+#undef S2A_SYM_STEP
+  S2A_STAMP_AT(4);
+  S2A_STAMP_VAL(5, t_mma);
+  S2A_STAMP_VAL(6, t_blend);
+  S2A_STAMP_VAL(7, t_wait);
+
+  // ---- epilogue: ReLU, f16, straight from the accumulators: lane (pixel i16 of tile row 8 * blk + b, kg16) holds
+  // out channels grp*64 + 16*kg16 + 4*a + e -- 16 consecutive ones
+  if (grp * 64 >= Oloc) return;
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const int y = ty0 + 8 * blk + b, xq = tx0 + i16;
+    V lo, hi;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float v = acc[a][b][e];
+        if (relu & 1) v = fmaxf(v, 0.f);
+        if (a < 2) lo[4 * a + e] = (_Float16)v; else hi[4 * (a - 2) + e] = (_Float16)v;
+      }
+    if (y < H && xq < W) {
+      T* o = out + (bimg * HW + (int64_t)y * W + xq) * O + o0 + grp * 64 + 16 * kg16;
+      *reinterpret_cast<V*>(o) = lo;
+      *reinterpret_cast<V*>(o + 8) = hi;
+    }
   }
 }
 
@@ -2416,15 +2807,16 @@ extern "C" int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int
     S2A_CHECK_ARG(out_channels % 64 == 0, "dcn_pack_weight: out_channels must be a multiple of 64");
     k_pack_weight<_Float16><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, kc, (_Float16*)packed);
     k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + wtot);
+    k_pack_weight_sym<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + 2 * wtot);
   }
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
 
 extern "C" int64_t s2a_dcn_packed_elems(int64_t out_channels, int64_t channels, int dtype) {
-  // f16 holds two layouts back to back (stage-major for the LDS-staged kernels, MFMA-fragment
-  // order for the patch-staged kernel)
-  return out_channels * channels * 9 * (dtype == S2A_DTYPE_F16 ? 2 : 1);
+  // f16 holds three layouts back to back (stage-major for the LDS-staged kernels, MFMA-fragment order for the
+  // patch-staged kernel, 16x16x32 fragment order of 32-channel stages for the symmetric 16 x 16-tile kernel)
+  return out_channels * channels * 9 * (dtype == S2A_DTYPE_F16 ? 3 : 1);
 }
 
 namespace s2a {
@@ -2773,11 +3165,29 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
   // three-slot column ring with loaders two stages ahead (2-8 % slower), two half-tile workgroups per CU (332 vs 282 us:
   // the filter streamed twice), half tiles for the last round in a second launch (-1.2 %).)
   const unsigned ogroups = (unsigned)((out_channels + kMaxO - 1) / kMaxO);
+  const int relu_flags = (relu ? 1 : 0) | (half_coords_requested() ? 2 : 0);
+  {
+    // S2A_DCN_SYM=1: 16 x 16 tiles with every wave blending AND contracting (k_dcn_sym).  Opt-in: measured 261 us against
+    // 236 us for k_dcn_patch on this launch (round 4) -- kept as the tested second form of the launch.
+    LevelTab lt16; int64_t pix16 = 0;
+    const int64_t tiles16 = build_levels(pyr, batch, &lt16, &pix16, 16);
+    bool sym = false;
+    if (const char* f = getenv("S2A_DCN_SYM")) sym = atoi(f) != 0;
+    if (sym && channels % 64 == 0 && tiles16 > 0) {
+      if (lt16.n == 1) lt16.n = 2, lt16.tile0[1] = 0x7fffffff;
+      const _Float16* wsym = (const _Float16*)weight_packed + 2 * (size_t)out_channels * channels * 9;
+      auto ks = k_dcn_sym;
+      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, kSymLds));
+      ks<<<dim3((unsigned)tiles16, ogroups), 512, kSymLds, st>>>((const _Float16*)x, anchors, wsym, (_Float16*)out, (int)channels,
+                                                                (int)out_channels, relu_flags, lt16);
+      S2A_LAUNCH_CHECK();
+      return S2A_OK;
+    }
+  }
   auto kern = k_dcn_patch<true, 1>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
   kern<<<dim3((unsigned)tiles, ogroups), 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
-                                                               lt.H[0], lt.W[0], (int)out_channels, lt.stride[0],
-                                                               (relu ? 1 : 0) | (half_coords_requested() ? 2 : 0), 0u, lt, 0);
+                                                               lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu_flags, 0u, lt, 0);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -1228,8 +1228,12 @@ def test_pyramid_tower_with_fused_head():
         assert torch.equal(tw, tower) and torch.equal(got2[:, :nh], got[:, :nh])
 
 
-def test_pyramid_alignconv_and_refine(rng):
-    """pyramid-packed fam_refine + AlignConv against the per-level entry points and the oracle"""
+@pytest.mark.parametrize("sym", ["0", "1"])
+def test_pyramid_alignconv_and_refine(rng, sym, monkeypatch):
+    """pyramid-packed fam_refine + AlignConv against the per-level entry points and the oracle; both forms of the packed
+    launch (S2A_DCN_SYM=0: 8 x 16 tiles, wave-specialised k_dcn_patch; 1: 16 x 16 tiles, every wave blends and contracts,
+    k_dcn_sym) -- the size heuristic would pick only one of them here"""
+    monkeypatch.setenv("S2A_DCN_SYM", sym)
     from s2anet_amd import pyramid as P
     from s2anet_amd.alignconv import align_conv_forward, pack_weight
     from s2anet_amd.head import fam_refine_anchors
@@ -1262,14 +1266,16 @@ def test_pyramid_alignconv_and_refine(rng):
             assert err.max() < 2e-2 and err.mean() < 2e-3, (l, bi, err.max(), err.mean())
 
 
-def test_pyramid_alignconv_wild_anchors_vs_oracle():
-    """the pyramid-packed AlignConv launch with more tiles than CUs, ragged level sizes and WILD anchors (bilinear corners
+@pytest.mark.parametrize("sym", ["0", "1"])
+def test_pyramid_alignconv_wild_anchors_vs_oracle(sym, monkeypatch):
+    """(both forms of the launch, see test_pyramid_alignconv_and_refine) the pyramid-packed AlignConv launch with more tiles than CUs, ragged level sizes and WILD anchors (bilinear corners
     that leave the 16 x 24 LDS patch take the global-gather path; tame anchors stay inside it): every level of every
     image against the f16-column oracle, and two launches of the same inputs bit-identical (round 2 also held four
     alternative forms of this launch to that -- persistent, three-slot ring, two workgroups per CU, half-tile tail --
     all measured slower and removed)"""
     from s2anet_amd import pyramid as P
     from s2anet_amd.alignconv import pack_weight
+    monkeypatch.setenv("S2A_DCN_SYM", sym)
     B, C = 2, 256
     sizes = [(96, 136), (48, 68), (24, 34), (12, 17), (6, 9)]
     strides = (8, 16, 32, 64, 128)
