@@ -128,6 +128,17 @@ int s2a_nms_rotated(const float* dets, const float* scores, int64_t n, float iou
                     int64_t* keep, int64_t* count_dev, int64_t* host_count, void* workspace,
                     size_t workspace_bytes, s2a_stream_t stream);
 
+/* The same two ops on float64 boxes.  The reference dispatches the NMS kernels on the dtype of `dets`
+ * (AT_DISPATCH_FLOATING_TYPES_AND_HALF, utils/nms_rotated/src/nms_rotated_cuda.cu:95-100,
+ * utils/ml_nms_rotated/src/nms_rotated_cuda.cu:100-105; AT_DISPATCH_FLOATING_TYPES in the CPU files): on double boxes it
+ * evaluates single_box_iou_rotated<double>, and keep decisions next to the threshold differ from the float32 evaluation.
+ * dets[n,5], scores[n], labels[n] (NULL: single class) float64; the threshold stays a float as in the reference's
+ * signature.  A plain N x N/64 mask form (API completeness, not a hot path): n < 260 k.  Not HIP-graph capturable. */
+size_t s2a_nms_rotated_f64_workspace_bytes(int64_t n);
+int s2a_nms_rotated_f64(const double* dets, const double* scores, const double* labels, int64_t n,
+                        float iou_threshold, int64_t* keep, int64_t* count_dev, int64_t* host_count,
+                        void* workspace, size_t workspace_bytes, s2a_stream_t stream);
+
 /* Batched form used by the detector (one call for a whole batch of images):
  * segment_ids[n] int32 in [0, num_segments) — NMS runs independently inside each
  * segment (segment = image*num_classes + label); a NEGATIVE segment id marks a padding row

@@ -86,6 +86,10 @@ def lib():
         L.orc_box_iou_rotated.argtypes = [f32p, i64, f32p, i64, f32p, ci, ci]
         L.orc_iou_pairs.restype = None
         L.orc_iou_pairs.argtypes = [f32p, f32p, i64, ci, f32p, ci]
+        L.orc_iou_pairs_f64.restype = None
+        L.orc_iou_pairs_f64.argtypes = [f64p, f64p, i64, ci, f64p, ci]
+        L.orc_nms_rotated_f64.restype = i64
+        L.orc_nms_rotated_f64.argtypes = [f64p, f64p, f64p, i64, ctypes.c_float, ci, ci, i64p]
         L.orc_nms_rotated.restype = i64
         L.orc_nms_rotated.argtypes = [f32p, f32p, f32p, i64, ctypes.c_float, ci, ci, ci, i64p]
         L.orc_nms_margin.restype = ctypes.c_double
@@ -151,6 +155,28 @@ def nms_rotated(dets, scores, iou_thr, labels=None, rule=RULE_GT, sort_mode=SORT
     k = lib().orc_nms_rotated(_p(d), _p(s), None if lab is None else _p(lab), n,
                               float(iou_thr), rule, sort_mode, int(cull),
                               _p(keep, ctypes.c_int64))
+    return keep[:k].copy()
+
+
+def iou_pairs_f64(b1, b2, sort_mode=SORT_GPU):
+    """single_box_iou_rotated<double> element-wise: b1/b2 [n,5] (or [n,6] with the label test) float64 -> float64[n]"""
+    b1 = np.ascontiguousarray(b1, np.float64)
+    b2 = np.ascontiguousarray(b2, np.float64)
+    out = np.empty(b1.shape[0], np.float64)
+    lib().orc_iou_pairs_f64(_p(b1, ctypes.c_double), _p(b2, ctypes.c_double), b1.shape[0], b1.shape[1],
+                            _p(out, ctypes.c_double), sort_mode)
+    return out
+
+
+def nms_rotated_f64(dets, scores, iou_thr, labels=None, rule=RULE_GT, sort_mode=SORT_GPU):
+    """nms_rotated / ml_nms_rotated on float64 boxes (the ops dispatch on dets' dtype): keep indices, descending score"""
+    d = np.ascontiguousarray(dets, np.float64)
+    s = np.ascontiguousarray(scores, np.float64)
+    lab = None if labels is None else np.ascontiguousarray(labels, np.float64)
+    keep = np.empty(d.shape[0], np.int64)
+    k = lib().orc_nms_rotated_f64(_p(d, ctypes.c_double), _p(s, ctypes.c_double),
+                                  None if lab is None else _p(lab, ctypes.c_double), d.shape[0], float(iou_thr), rule,
+                                  sort_mode, keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
     return keep[:k].copy()
 
 

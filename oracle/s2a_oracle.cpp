@@ -300,9 +300,162 @@ inline double quad_iou(const double* p, const double* q) {  // iou_poly :108-128
   return inter / uni;
 }
 
+// ---------------------------------------------------------------------------
+// The same geometry instantiated for T = double (the NMS ops dispatch on the dtype of `dets`:
+// AT_DISPATCH_FLOATING_TYPES, utils/nms_rotated/src/nms_rotated_cpu.cpp:66, utils/ml_nms_rotated/src/nms_rotated_cpu.cpp:67;
+// AT_DISPATCH_FLOATING_TYPES_AND_HALF in the CUDA files :95-100 / :100-105).  With T = double every intermediate of
+// box_iou_rotated_utils.h is a double and the float-only promotions above disappear; the 0.5f / 1e-14 / 1e-6 / 1e-8
+// constants keep their values.  Written out separately so that the float path above stays byte for byte what the
+// fixtures pinned.
+// ---------------------------------------------------------------------------
+namespace d64 {
+struct Q2 {
+  double x, y;
+};
+inline double cr(double ax, double ay, double bx, double by) { return ax * by - bx * ay; }
+inline double dt(double ax, double ay, double bx, double by) { return ax * bx + ay * by; }
+inline void verts(double xc, double yc, double w, double h, double a, double* vx, double* vy) {
+  double c2 = std::cos(a) * 0.5f, s2 = std::sin(a) * 0.5f;     // (:62-64) theta is the double angle itself
+  vx[0] = xc - s2 * h - c2 * w;
+  vy[0] = yc + c2 * h - s2 * w;
+  vx[1] = xc + s2 * h - c2 * w;
+  vy[1] = yc - c2 * h - s2 * w;
+  vx[2] = 2 * xc - vx[0];
+  vy[2] = 2 * yc - vy[0];
+  vx[3] = 2 * xc - vx[1];
+  vy[3] = 2 * yc - vy[1];
+}
+inline int points(const double* ax, const double* ay, const double* bx, const double* by, double* ox, double* oy) {
+  double eax[4], eay[4], ebx[4], eby[4];
+  for (int i = 0; i < 4; i++) {
+    eax[i] = ax[(i + 1) & 3] - ax[i];
+    eay[i] = ay[(i + 1) & 3] - ay[i];
+    ebx[i] = bx[(i + 1) & 3] - bx[i];
+    eby[i] = by[(i + 1) & 3] - by[i];
+  }
+  int n = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double det = cr(ebx[j], eby[j], eax[i], eay[i]);
+      if (std::fabs(det) <= 1e-14) continue;
+      double dx = bx[j] - ax[i], dy = by[j] - ay[i];
+      double t1 = cr(ebx[j], eby[j], dx, dy) / det;
+      double t2 = cr(eax[i], eay[i], dx, dy) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
+        ox[n] = ax[i] + eax[i] * t1;
+        oy[n] = ay[i] + eay[i] * t1;
+        n++;
+      }
+    }
+  for (int side = 0; side < 2; side++) {          // vertices of A inside B, then of B inside A
+    const double* px = side ? bx : ax; const double* py = side ? by : ay;
+    const double* rx = side ? ax : bx; const double* ry = side ? ay : by;
+    const double* ex = side ? eax : ebx; const double* ey = side ? eay : eby;
+    double abx = ex[0], aby = ey[0], dax = ex[3], day = ey[3];
+    double abab = dt(abx, aby, abx, aby), adad = dt(dax, day, dax, day);
+    for (int i = 0; i < 4; i++) {
+      double apx = px[i] - rx[0], apy = py[i] - ry[0];
+      double apab = dt(apx, apy, abx, aby), apad = -dt(apx, apy, dax, day);
+      if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) {
+        ox[n] = px[i];
+        oy[n] = py[i];
+        n++;
+      }
+    }
+  }
+  return n;
+}
+inline double hull(const double* px, const double* py, int n, int sort_mode) {
+  int t = 0;
+  for (int i = 1; i < n; i++)
+    if (py[i] < py[t] || (py[i] == py[t] && px[i] < px[t])) t = i;
+  Q2 q[kMaxPts];
+  double dist[kMaxPts];
+  for (int i = 0; i < n; i++) q[i] = {px[i] - px[t], py[i] - py[t]};
+  std::swap(q[0], q[t]);
+  for (int i = 0; i < n; i++) dist[i] = dt(q[i].x, q[i].y, q[i].x, q[i].y);
+  if (sort_mode == 1) {
+    for (int i = 1; i < n - 1; i++)
+      for (int j = i + 1; j < n; j++) {
+        double cp = cr(q[i].x, q[i].y, q[j].x, q[j].y);
+        if ((cp < -1e-6) || (std::fabs(cp) < 1e-6 && dist[i] > dist[j])) {
+          std::swap(q[i], q[j]);
+          std::swap(dist[i], dist[j]);
+        }
+      }
+  } else {
+    std::sort(q + 1, q + n, [](const Q2& A, const Q2& B) -> bool {
+      double c = cr(A.x, A.y, B.x, B.y);
+      if (std::fabs(c) < 1e-6) return dt(A.x, A.y, A.x, A.y) < dt(B.x, B.y, B.x, B.y);
+      return c > 0;
+    });
+  }
+  int k = 1;
+  for (; k < n; k++)
+    if (dist[k] > 1e-8) break;
+  if (k == n) return 0.0;
+  q[1] = q[k];
+  int m = 2;
+  for (int i = k + 1; i < n; i++) {
+    while (m > 1 && cr(q[i].x - q[m - 2].x, q[i].y - q[m - 2].y, q[m - 1].x - q[m - 2].x, q[m - 1].y - q[m - 2].y) >= 0) m--;
+    q[m++] = q[i];
+  }
+  if (m <= 2) return 0.0;
+  double area = 0;
+  for (int i = 1; i < m - 1; i++)
+    area += std::fabs(cr(q[i].x - q[0].x, q[i].y - q[0].y, q[i + 1].x - q[0].x, q[i + 1].y - q[0].y));
+  return area / 2.0;
+}
+inline double iou(const double* b1, const double* b2, int sort_mode, bool with_label) {
+  if (with_label && b1[5] != b2[5]) return 0.0;
+  double sx = (b1[0] + b2[0]) / 2.0, sy = (b1[1] + b2[1]) / 2.0;
+  double area1 = b1[2] * b1[3], area2 = b2[2] * b2[3];
+  if (area1 < 1e-14 || area2 < 1e-14) return 0.0;
+  double ax[4], ay[4], bx[4], by[4];
+  verts(b1[0] - sx, b1[1] - sy, b1[2], b1[3], b1[4], ax, ay);
+  verts(b2[0] - sx, b2[1] - sy, b2[2], b2[3], b2[4], bx, by);
+  double px[kMaxPts], py[kMaxPts];
+  int n = points(ax, ay, bx, by, px, py);
+  double inter = n > 2 ? hull(px, py, n, sort_mode) : 0.0;
+  return inter / (area1 + area2 - inter);
+}
+}  // namespace d64
+
 }  // namespace
 
 extern "C" {
+
+// ----- rotated IoU / NMS on double boxes (the dtype dispatch of the NMS ops) -------------------
+void orc_iou_pairs_f64(const double* b1, const double* b2, int64_t n, int stride, double* out, int sort_mode) {
+  for (int64_t i = 0; i < n; i++) out[i] = d64::iou(b1 + stride * i, b2 + stride * i, sort_mode, stride == 6);
+}
+// as orc_nms_rotated; the threshold stays a float (`const float iou_threshold` in both reference files) and is promoted
+int64_t orc_nms_rotated_f64(const double* dets5, const double* scores, const double* labels, int64_t n, float thr,
+                            int rule, int sort_mode, int64_t* keep) {
+  if (n == 0) return 0;
+  std::vector<int64_t> order(n);
+  for (int64_t i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return scores[a] > scores[b]; });
+  std::vector<double> box(6 * n);
+  for (int64_t i = 0; i < n; i++) {
+    std::memcpy(&box[6 * i], dets5 + 5 * i, 5 * sizeof(double));
+    box[6 * i + 5] = labels ? labels[i] : 0.0;
+  }
+  std::vector<uint8_t> dead(n, 0);
+  int64_t k = 0;
+  for (int64_t oi = 0; oi < n; oi++) {
+    int64_t i = order[oi];
+    if (dead[i]) continue;
+    keep[k++] = i;
+    for (int64_t oj = oi + 1; oj < n; oj++) {
+      int64_t j = order[oj];
+      if (dead[j]) continue;
+      double v = d64::iou(&box[6 * i], &box[6 * j], sort_mode, true);
+      if (rule == 0 ? (v >= thr) : (v > thr)) dead[j] = 1;
+    }
+  }
+  return k;
+}
 
 // ----- rotated IoU ---------------------------------------------------------
 float orc_iou_single(const float* b1, const float* b2, int sort_mode) {

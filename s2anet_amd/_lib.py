@@ -60,6 +60,8 @@ SYMBOLS = {
                                    ctypes.POINTER(c_i64), c_vp, c_sz, c_vp]),
     "s2a_nms_rotated": (c_int, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp,
                                 c_sz, c_vp]),
+    "s2a_nms_rotated_f64_workspace_bytes": (c_sz, [c_i64]),
+    "s2a_nms_rotated_f64": (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, c_sz, c_vp]),
     "s2a_nms_rotated_segmented": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int32,
                                           ctypes.c_int32, c_f32, c_vp, c_vp, c_vp, ctypes.c_int32,
                                           c_vp, c_sz, c_vp]),

@@ -1505,6 +1505,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_sym(const _Float16* __restrict__
     }
   };
 
+  V pv;                                        // the patch piece in flight (requested in one interval, stored in the next)
   // One stage interval of a wave: contract stage st AND blend this thread's two items of stage st + 1 (tap tn of chunk cn),
   // as ONE instruction stream in two halves -- LDS requests first (four B fragments, the item's table entry, then its four
   // corners), sixteen MFMAs with the blend's packed FMAs issued between them (an MFMA occupies the matrix pipe for 16
@@ -1512,57 +1513,88 @@ __global__ __launch_bounds__(512, 2) void k_dcn_sym(const _Float16* __restrict__
   // last.  Written as separate blend / contract phases each wave needed ~650 + ~650-1200 cycles per interval for 512
   // cycles of MFMA (stamps); sched_group_barrier pins the interleaving, hipcc otherwise clusters the MFMAs.
   // Items whose corners left the patch are redone from global memory afterwards (rare).
-  auto fused = [&](int st, const V (&wv)[4], int tn, int cn) {
+  auto fused = [&](int st, const V (&wv)[4], int tn, int cn, V (&wn)[4], const V* wnp, unsigned pvo, int psoff) {
     const char* Bc = s_B + (st & 1) * kSymBBytes + boff;
     const char* P = s_patch + (cn & 1) * kSymPatchBytes;
     char* Bn = s_B + ((st + 1) & 1) * kSymBBytes;
     unsigned all_in = 1u;
 #define S2A_SB() __builtin_amdgcn_sched_barrier(0)
-#define S2A_MMA(AA, BB) acc[AA][4 * h + (BB)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[AA], pf[BB], acc[AA][4 * h + (BB)], 0, 0, 0)
+#define S2A_BF(B_) pf[B_] = *reinterpret_cast<const V*>(Bc + (B_) * 16 * kSymBRow)
+#define S2A_MMA4(B_)                                                                                             \
+  acc[0][B_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[0], pf[B_], acc[0][B_], 0, 0, 0);                       \
+  acc[1][B_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[1], pf[B_], acc[1][B_], 0, 0, 0);                       \
+  acc[2][B_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[2], pf[B_], acc[2][B_], 0, 0, 0);                       \
+  acc[3][B_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[3], pf[B_], acc[3][B_], 0, 0, 0)
+#define S2A_BLEND2(E0_)                                                                                          \
+  _Pragma("unroll") for (int e = (E0_); e < (E0_) + 2; e++) {                                                    \
+    const f16x2 a0 = {cv[0][2 * e], cv[0][2 * e + 1]}, a1 = {cv[1][2 * e], cv[1][2 * e + 1]};                    \
+    const f16x2 a2 = {cv[2][2 * e], cv[2][2 * e + 1]}, a3 = {cv[3][2 * e], cv[3][2 * e + 1]};                    \
+    f16x2 sacc = w0 * a0;                           /* explicit FMAs in the reference's order, as blend_pk */    \
+    sacc = __builtin_elementwise_fma(w1, a1, sacc);                                                              \
+    sacc = __builtin_elementwise_fma(w2, a2, sacc);                                                              \
+    sacc = __builtin_elementwise_fma(w3, a3, sacc);                                                              \
+    r[2 * e] = sacc[0];                                                                                          \
+    r[2 * e + 1] = sacc[1];                                                                                      \
+  }
+    // Eight groups of four MFMAs (one 16-position tile against the wave's four 16-channel filter fragments = 64 cycles of
+    // the matrix pipe), pinned in order by sched_barrier; around them, two groups ahead of their use, the LDS requests:
+    // the next fragments, the item's table entry, then its four corners; the item's packed FMAs ride in the groups
+    // behind.  Item 0 lives in groups 0-3, item 1 in groups 4-7; three fragments, one item's corners in flight at a time.
+    V pf[8], cv[4], r;
+    PTap tp;
+    f16x2 w0, w1, w2, w3;
+    int pl, q;
+    S2A_BF(0); S2A_BF(1);
+    pl = tid >> 2; q = tid & 3;
+    tp = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + tn]));
+    S2A_SB();
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      // blocks pinned in this order by sched_barrier (hipcc otherwise clusters the 16 MFMAs in front of the blend):
-      // LDS requests (4 fragments + table entry) | 4 MFMAs | corner requests | 4 MFMAs | 4 x (2 MFMAs + the four packed
-      // multiply-adds of one pair of the item's 8 channels) | column store
-      const int item = tid + 512 * h, pl = item >> 2, q = item & 3;
-      V pf[4], cv[4];
-#pragma unroll
-      for (int bb = 0; bb < 4; bb++) pf[bb] = *reinterpret_cast<const V*>(Bc + (4 * h + bb) * 16 * kSymBRow);
-      const PTap tp = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + tn]));
-      S2A_SB();
-      S2A_MMA(0, 0); S2A_MMA(0, 1); S2A_MMA(0, 2); S2A_MMA(0, 3);
-      S2A_SB();
-      const char* b0 = P + (tp.flags >> 1) + q * 16;
-      cv[0] = *reinterpret_cast<const V*>(b0);
-      cv[1] = *reinterpret_cast<const V*>(b0 + 64);
-      cv[2] = *reinterpret_cast<const V*>(b0 + kSymPW * 64);
-      cv[3] = *reinterpret_cast<const V*>(b0 + kSymPW * 64 + 64);
-      const f16x2 w0 = {tp.w[0], tp.w[0]}, w1 = {tp.w[1], tp.w[1]}, w2 = {tp.w[2], tp.w[2]}, w3 = {tp.w[3], tp.w[3]};
-      all_in &= tp.flags;
-      S2A_SB();
-      S2A_MMA(1, 0); S2A_MMA(1, 1); S2A_MMA(1, 2); S2A_MMA(1, 3);
-      S2A_SB();
-      V r;
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (e == 0) { S2A_MMA(2, 0); S2A_MMA(2, 1); }
-        if (e == 1) { S2A_MMA(2, 2); S2A_MMA(2, 3); }
-        if (e == 2) { S2A_MMA(3, 0); S2A_MMA(3, 1); }
-        if (e == 3) { S2A_MMA(3, 2); S2A_MMA(3, 3); }
-        const f16x2 a0 = {cv[0][2 * e], cv[0][2 * e + 1]}, a1 = {cv[1][2 * e], cv[1][2 * e + 1]};
-        const f16x2 a2 = {cv[2][2 * e], cv[2][2 * e + 1]}, a3 = {cv[3][2 * e], cv[3][2 * e + 1]};
-        f16x2 sacc = w0 * a0;                                // explicit FMAs in the reference's order, as blend_pk
-        sacc = __builtin_elementwise_fma(w1, a1, sacc);
-        sacc = __builtin_elementwise_fma(w2, a2, sacc);
-        sacc = __builtin_elementwise_fma(w3, a3, sacc);
-        r[2 * e] = sacc[0];
-        r[2 * e + 1] = sacc[1];
-        S2A_SB();
+      // group 4h: fragments + 2, corners of item h (its table entry was requested two groups ago)
+      // (the interval's five vector-memory requests -- next stage's four filter fragments, one patch piece -- are spread
+      // over groups 0-2, the patch piece first: at the head of the interval they cost every wave 0.5-0.7 k cycles of issue with the matrix pipe
+      // idle, 40 requests of 1 KB per CU against a request path of 64 B per clock)
+      S2A_MMA4(4 * h);
+      S2A_BF(4 * h + 2);
+      if (h == 0) {      // (the patch piece first: the next interval stores it before anything else)
+        pv = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)pvo, psoff, 0));
+        wn[0] = wnp[0];
       }
-      *reinterpret_cast<V*>(Bn + pl * kSymBRow + q * 16) = r;
+      {
+        const char* b0 = P + (tp.flags >> 1) + q * 16;
+        cv[0] = *reinterpret_cast<const V*>(b0);
+        cv[1] = *reinterpret_cast<const V*>(b0 + 64);
+        cv[2] = *reinterpret_cast<const V*>(b0 + kSymPW * 64);
+        cv[3] = *reinterpret_cast<const V*>(b0 + kSymPW * 64 + 64);
+        w0 = f16x2{tp.w[0], tp.w[0]}; w1 = f16x2{tp.w[1], tp.w[1]}; w2 = f16x2{tp.w[2], tp.w[2]}; w3 = f16x2{tp.w[3], tp.w[3]};
+        all_in &= tp.flags;
+      }
+      S2A_SB();
+      // group 4h + 1: fragments + 2; the NEXT item's table entry
+      S2A_MMA4(4 * h + 1);
+      S2A_BF(4 * h + 3);
+      if (h == 0) { wn[1] = wnp[64]; wn[2] = wnp[128]; }
+      const int plw = pl, qw = q;
+      if (h == 0) {
+        pl = (tid + 512) >> 2; q = tid & 3;
+        tp = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + tn]));
+      }
+      S2A_SB();
+      // group 4h + 2: first half of the item's blend
+      S2A_MMA4(4 * h + 2);
+      if (h == 0) { S2A_BF(4); wn[3] = wnp[192]; }
+      S2A_BLEND2(0)
+      S2A_SB();
+      // group 4h + 3: second half, column store
+      S2A_MMA4(4 * h + 3);
+      if (h == 0) S2A_BF(5);
+      S2A_BLEND2(2)
+      *reinterpret_cast<V*>(Bn + plw * kSymBRow + qw * 16) = r;
       S2A_SB();
     }
-#undef S2A_MMA
+#undef S2A_BLEND2
+#undef S2A_MMA4
+#undef S2A_BF
 #undef S2A_SB
     if (__builtin_amdgcn_ballot_w64(!(all_in & 1u)) != 0) {     // rare: a corner left the patch -> global gather
       for (int h = 0; h < 2; h++) {
@@ -1581,7 +1613,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_sym(const _Float16* __restrict__
     }
   };
 
-  V pv = pv0[0];
+  pv = pv0[0];
   blend(0, 0, 0);
   __syncthreads();
   S2A_STAMP_AT(3);
@@ -1595,16 +1627,14 @@ __global__ __launch_bounds__(512, 2) void k_dcn_sym(const _Float16* __restrict__
     /* next chunk's patch, one piece per wave and interval: requested at taps 0-4, written at taps 1-5 (its buffer   \
        was last read two intervals before tap 0; the chunk is first read in the interval of tap 8) */                \
     if (tcur >= 1 && tcur <= 5 && ccur + 1 < NC) piece_store(ccur + 1, wave + 8 * (tcur - 1), pv);                   \
-    if (tcur < 5 && ccur + 1 < NC) {                                                   \
-      const unsigned vo_ = tcur == 0 ? pvoff[0] : tcur == 1 ? pvoff[1] : tcur == 2 ? pvoff[2] : tcur == 3 ? pvoff[3] : pvoff[4]; \
-      pv = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo_, (ccur + 1) * 64, 0));           \
-    }                                                                                  \
-    load_w(min(s_ + 1, last), WN);                                                     \
+    const unsigned vo_ = !(tcur < 5 && ccur + 1 < NC) ? 0x80000000u                                                  \
+                         : tcur == 0 ? pvoff[0] : tcur == 1 ? pvoff[1] : tcur == 2 ? pvoff[2] : tcur == 3 ? pvoff[3] : pvoff[4]; \
+    const V* wnp_ = wbase + (int64_t)min(s_ + 1, last) * G * 256;                      \
     /* stage s + 1 (behind the last stage: the last one again -- its columns go to the buffer nobody reads any more) */ \
     const int tn_ = s_ == last ? tcur : (tcur == 8 ? 0 : tcur + 1), cn_ = s_ == last ? ccur : (tcur == 8 ? ccur + 1 : ccur); \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     S2A_TIC();                                                                         \
-    fused(s_, WC, tn_, cn_);                                                           \
+    fused(s_, WC, tn_, cn_, WN, wnp_, vo_, (ccur + 1) * 64);                           \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     S2A_TOC(t_mma); S2A_TIC();                                                         \
     __syncthreads();                                                                   \
@@ -1612,6 +1642,9 @@ __global__ __launch_bounds__(512, 2) void k_dcn_sym(const _Float16* __restrict__
     tcur = tn_; ccur = cn_;                                                            \
   }
   int tcur = 0, ccur = 0;                    // tap and chunk of the stage being contracted
+  // static priority for the younger half (waves 4-7 lose the issue arbitration to their SIMD partners 0-3: their interval
+  // took 1.58 k cycles against 1.13 k, the partner waiting at the barrier; MI355X_MICROARCH.md, two waves per SIMD (4))
+  if (blk != 0 && !(relu & 4)) __builtin_amdgcn_s_setprio(1);      // (relu bit 2: A/B switch, S2A_DCN_SYM_NOPRIO=1)
   for (int s = 0; s < nstage; s += 2) {      // nstage = 9 * C / 32 is even (C % 64 == 0)
     S2A_SYM_STEP(s, wA, wN)
     S2A_SYM_STEP(s + 1, wN, wA)
@@ -3165,7 +3198,7 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
   // three-slot column ring with loaders two stages ahead (2-8 % slower), two half-tile workgroups per CU (332 vs 282 us:
   // the filter streamed twice), half tiles for the last round in a second launch (-1.2 %).)
   const unsigned ogroups = (unsigned)((out_channels + kMaxO - 1) / kMaxO);
-  const int relu_flags = (relu ? 1 : 0) | (half_coords_requested() ? 2 : 0);
+  const int relu_flags = (relu ? 1 : 0) | (half_coords_requested() ? 2 : 0) | (getenv("S2A_DCN_SYM_NOPRIO") ? 4 : 0);
   {
     // S2A_DCN_SYM=1: 16 x 16 tiles with every wave blending AND contracting (k_dcn_sym).  Opt-in: measured 261 us against
     // 236 us for k_dcn_patch on this launch (round 4) -- kept as the tested second form of the launch.

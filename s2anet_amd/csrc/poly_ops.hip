@@ -403,6 +403,175 @@ __global__ void k_poly_flags(const uint8_t* __restrict__ keep_orig, const int32_
   if (p < n) flags[p] = keep_orig[order[p]];
 }
 
+// ------------------------------------------------------------------ rotated NMS on DOUBLE boxes
+// nms_rotated / ml_nms_rotated dispatch on the dtype of `dets` (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// utils/nms_rotated/src/nms_rotated_cuda.cu:95-100, utils/ml_nms_rotated/src/nms_rotated_cuda.cu:100-105): on float64
+// boxes the reference evaluates single_box_iou_rotated<double>, and keep decisions next to the threshold differ from the
+// float32 evaluation.  This is that instantiation -- box_iou_rotated_utils.h:56-375 with T = double, __CUDACC__ branch
+// (swap sort), the label test of the ml copy (:319-322) -- as a plain per-thread evaluation: the f32 path's cull / list
+// machinery (PreBox, tiles, pair lists) is built around 32-bit boxes, and float64 inputs are an API-completeness case,
+// not a hot one.  Same structure as the reference's kernel (:14-72): 64 x 64 blocks of the upper triangle, one thread
+// per row, suppression bits into an N x N/64 mask, then the greedy scan shared with the polygon NMS.
+struct RBox6 {
+  double x, y, w, h, a, label;
+};
+
+__device__ __forceinline__ double cr2(double ax, double ay, double bx, double by) { return ax * by - bx * ay; }
+__device__ __forceinline__ double dt2(double ax, double ay, double bx, double by) { return ax * bx + ay * by; }
+
+__device__ __forceinline__ void rbox_vertices_f64(double xc, double yc, double w, double h, double a, double* vx, double* vy) {
+  const double c2 = cos(a) * 0.5f, s2 = sin(a) * 0.5f;
+  vx[0] = xc - s2 * h - c2 * w;
+  vy[0] = yc + c2 * h - s2 * w;
+  vx[1] = xc + s2 * h - c2 * w;
+  vy[1] = yc - c2 * h - s2 * w;
+  vx[2] = 2 * xc - vx[0];
+  vy[2] = 2 * yc - vy[0];
+  vx[3] = 2 * xc - vx[1];
+  vy[3] = 2 * yc - vy[1];
+}
+
+__device__ double rot_iou_f64(const RBox6& A, const RBox6& B) {
+  if (A.label != B.label) return 0.0;
+  const double sx = (A.x + B.x) / 2.0, sy = (A.y + B.y) / 2.0;
+  const double area1 = A.w * A.h, area2 = B.w * B.h;
+  if (area1 < 1e-14 || area2 < 1e-14) return 0.0;
+  double ax[4], ay[4], bx[4], by[4];
+  rbox_vertices_f64(A.x - sx, A.y - sy, A.w, A.h, A.a, ax, ay);
+  rbox_vertices_f64(B.x - sx, B.y - sy, B.w, B.h, B.a, bx, by);
+  double eax[4], eay[4], ebx[4], eby[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    eax[i] = ax[(i + 1) & 3] - ax[i];
+    eay[i] = ay[(i + 1) & 3] - ay[i];
+    ebx[i] = bx[(i + 1) & 3] - bx[i];
+    eby[i] = by[(i + 1) & 3] - by[i];
+  }
+  double qx[24], qy[24], dist[24];
+  int n = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      const double det = cr2(ebx[j], eby[j], eax[i], eay[i]);
+      if (fabs(det) <= 1e-14) continue;
+      const double dx = bx[j] - ax[i], dy = by[j] - ay[i];
+      const double t1 = cr2(ebx[j], eby[j], dx, dy) / det;
+      const double t2 = cr2(eax[i], eay[i], dx, dy) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
+        qx[n] = ax[i] + eax[i] * t1;
+        qy[n] = ay[i] + eay[i] * t1;
+        n++;
+      }
+    }
+  {
+    const double abx = ebx[0], aby = eby[0], dax = ebx[3], day = eby[3];
+    const double abab = dt2(abx, aby, abx, aby), adad = dt2(dax, day, dax, day);
+    for (int i = 0; i < 4; i++) {
+      const double apx = ax[i] - bx[0], apy = ay[i] - by[0];
+      const double apab = dt2(apx, apy, abx, aby), apad = -dt2(apx, apy, dax, day);
+      if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) { qx[n] = ax[i]; qy[n] = ay[i]; n++; }
+    }
+  }
+  {
+    const double abx = eax[0], aby = eay[0], dax = eax[3], day = eay[3];
+    const double abab = dt2(abx, aby, abx, aby), adad = dt2(dax, day, dax, day);
+    for (int i = 0; i < 4; i++) {
+      const double apx = bx[i] - ax[0], apy = by[i] - ay[0];
+      const double apab = dt2(apx, apy, abx, aby), apad = -dt2(apx, apy, dax, day);
+      if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) { qx[n] = bx[i]; qy[n] = by[i]; n++; }
+    }
+  }
+  double inter = 0.0;
+  if (n > 2) {
+    int t = 0;
+    for (int i = 1; i < n; i++)
+      if (qy[i] < qy[t] || (qy[i] == qy[t] && qx[i] < qx[t])) t = i;
+    const double ox = qx[t], oy = qy[t];
+    for (int i = 0; i < n; i++) { qx[i] -= ox; qy[i] -= oy; }
+    { const double tx = qx[0], ty = qy[0]; qx[0] = qx[t]; qy[0] = qy[t]; qx[t] = tx; qy[t] = ty; }
+    for (int i = 0; i < n; i++) dist[i] = dt2(qx[i], qy[i], qx[i], qy[i]);
+    for (int i = 1; i < n - 1; i++)
+      for (int j = i + 1; j < n; j++) {
+        const double cp = cr2(qx[i], qy[i], qx[j], qy[j]);
+        if ((cp < -1e-6) || (fabs(cp) < 1e-6 && dist[i] > dist[j])) {
+          double s_;
+          s_ = qx[i]; qx[i] = qx[j]; qx[j] = s_;
+          s_ = qy[i]; qy[i] = qy[j]; qy[j] = s_;
+          s_ = dist[i]; dist[i] = dist[j]; dist[j] = s_;
+        }
+      }
+    int k = 1;
+    for (; k < n; k++)
+      if (dist[k] > 1e-8) break;
+    if (k < n) {
+      qx[1] = qx[k]; qy[1] = qy[k];
+      int m = 2;
+      for (int i = k + 1; i < n; i++) {
+        while (m > 1 && cr2(qx[i] - qx[m - 2], qy[i] - qy[m - 2], qx[m - 1] - qx[m - 2], qy[m - 1] - qy[m - 2]) >= 0) m--;
+        qx[m] = qx[i]; qy[m] = qy[i];
+        m++;
+      }
+      if (m > 2) {
+        double area = 0;
+        for (int i = 1; i < m - 1; i++)
+          area += fabs(cr2(qx[i] - qx[0], qy[i] - qy[0], qx[i + 1] - qx[0], qy[i + 1] - qy[0]));
+        inter = area / 2.0;
+      }
+    }
+  }
+  return inter / (area1 + area2 - inter);
+}
+
+__global__ void k_rot64_keys(const double* __restrict__ scores, int64_t n, unsigned long long* __restrict__ key,
+                             int32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  key[i] = ~dbl_sortable(scores[i]);          // ascending stable radix sort == descending score, ties by ascending index
+  idx[i] = (int32_t)i;
+}
+
+__global__ void k_rot64_prep(const double* __restrict__ dets5, const double* __restrict__ labels,
+                             const int32_t* __restrict__ order, int64_t n, RBox6* __restrict__ sorted,
+                             uint32_t* __restrict__ seg_start, uint32_t* __restrict__ num_seg,
+                             unsigned long long* __restrict__ mask_off, uint32_t* __restrict__ nblk) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) {
+    const unsigned long long nb = (unsigned long long)(n + 63) / 64;
+    seg_start[0] = 0;
+    seg_start[1] = (uint32_t)n;
+    *num_seg = 1;
+    mask_off[0] = 0;
+    mask_off[1] = (unsigned long long)n * nb;
+    nblk[0] = (uint32_t)nb;
+  }
+  if (p >= n) return;
+  const int64_t o = order[p];
+  const double* d = dets5 + 5 * o;
+  double l = labels ? labels[o] : 0.0;
+  if (l == 0.0) l = 0.0;                       // -0 == +0 in the reference's compare
+  sorted[p] = RBox6{d[0], d[1], d[2], d[3], d[4], l};
+}
+
+__global__ __launch_bounds__(64) void k_rot64_mask(const RBox6* __restrict__ sorted, int64_t n, float thr,
+                                                   unsigned long long* __restrict__ mask) {
+  const uint32_t rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  __shared__ RBox6 s_col[64];
+  const uint32_t nb = (uint32_t)((n + 63) / 64);
+  const int64_t j0 = (int64_t)cb * 64;
+  if (j0 + threadIdx.x < n) s_col[threadIdx.x] = sorted[j0 + threadIdx.x];
+  __syncthreads();
+  const int64_t i = (int64_t)rb * 64 + threadIdx.x;
+  if (i >= n) return;
+  const RBox6 A = sorted[i];
+  unsigned long long bits = 0;
+  for (int c = 0; c < 64; c++) {
+    const int64_t j = j0 + c;
+    if (j >= n || j <= i) continue;
+    if (rot_iou_f64(A, s_col[c]) > thr) bits |= 1ull << c;       // (cuda.cu:63-64: double > float)
+  }
+  mask[(unsigned long long)i * nb + cb] = bits;
+}
+
 }  // namespace
 }  // namespace s2a
 
@@ -508,6 +677,76 @@ extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64
   need = 0;
   S2A_HIP(rocprim::select(nullptr, need, order, flags, keep, count_dev, sz, st));
   S2A_CHECK_ARG(need <= rpb, "nms_poly: select scratch too small");
+  S2A_HIP(rocprim::select(rp, need, order, flags, keep, count_dev, sz, st));
+  S2A_LAUNCH_CHECK();
+  if (host_count) {
+    S2A_HIP(hipMemcpyAsync(host_count, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    S2A_HIP(hipStreamSynchronize(st));
+  }
+  return S2A_OK;
+}
+
+extern "C" size_t s2a_nms_rotated_f64_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  size_t sz = (size_t)n, nb = (sz + 63) / 64;
+  return align_up(sz * 8) * 2 + align_up(sz * 4) * 2 + align_up(sz * sizeof(RBox6)) + align_up(sz * nb * 8) +
+         align_up(sz) * 2 + align_up(sz * 40 + (8u << 20)) + 8192;
+}
+
+extern "C" int s2a_nms_rotated_f64(const double* dets5, const double* scores, const double* labels, int64_t n,
+                                   float iou_threshold, int64_t* keep, int64_t* count_dev, int64_t* host_count,
+                                   void* workspace, size_t workspace_bytes, s2a_stream_t stream) {
+  S2A_CHECK_ARG(n >= 0 && n < (1ll << 31), "nms_rotated_f64: n out of range");
+  S2A_CHECK_ARG(count_dev != nullptr, "nms_rotated_f64: count_dev must not be NULL");
+  hipStream_t st = as_stream(stream);
+  S2A_REFUSE_CAPTURE(st, "nms_rotated_f64");
+  if (n == 0) {
+    S2A_HIP(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
+    if (host_count) *host_count = 0;
+    return S2A_OK;
+  }
+  S2A_CHECK_ARG(dets5 && scores && keep, "nms_rotated_f64: NULL tensor");
+  const size_t sz = (size_t)n, nb = (sz + 63) / 64;
+  S2A_CHECK_ARG(nb <= 65535 && sz * nb * 8 < (8ull << 30), "nms_rotated_f64: more than 260 k boxes is not supported (N x N/64 mask)");
+  Carver cv(workspace, workspace_bytes);
+  auto* key_a = cv.take<unsigned long long>(sz);
+  auto* key_b = cv.take<unsigned long long>(sz);
+  auto* idx_a = cv.take<int32_t>(sz);
+  auto* order = cv.take<int32_t>(sz);
+  auto* sorted = cv.take<RBox6>(sz);
+  auto* mask = cv.take<unsigned long long>(sz * nb);
+  auto* keep_orig = cv.take<uint8_t>(sz);
+  auto* flags = cv.take<uint8_t>(sz);
+  auto* small = cv.take<unsigned long long>(64);
+  size_t rpb = sz * 40 + (8u << 20);
+  void* rp = cv.take<char>(rpb);
+  if (!rp || !small || cv.off > workspace_bytes) {
+    set_error("nms_rotated_f64: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+    return S2A_EWORKSPACE;
+  }
+  uint32_t* seg_start = reinterpret_cast<uint32_t*>(small);
+  uint32_t* num_seg = seg_start + 4;
+  uint32_t* nblk = seg_start + 6;
+  uint32_t* status = seg_start + 8;
+  unsigned long long* mask_off = small + 8;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  S2A_HIP(hipMemsetAsync(small, 0, 64 * 8, st));
+  S2A_HIP(hipMemsetAsync(keep_orig, 0, sz, st));
+  k_rot64_keys<<<g, 256, 0, st>>>(scores, n, key_a, idx_a);
+  size_t need = 0;
+  S2A_HIP(rocprim::radix_sort_pairs(nullptr, need, key_a, key_b, idx_a, order, sz, 0, 64, st));
+  S2A_CHECK_ARG(need <= rpb, "nms_rotated_f64: sort scratch too small");
+  S2A_HIP(rocprim::radix_sort_pairs(rp, need, key_a, key_b, idx_a, order, sz, 0, 64, st));
+  k_rot64_prep<<<g, 256, 0, st>>>(dets5, labels, order, n, sorted, seg_start, num_seg, mask_off, nblk);
+  k_rot64_mask<<<dim3((unsigned)nb, (unsigned)nb), 64, 0, st>>>(sorted, n, iou_threshold, mask);
+  S2A_LAUNCH_CHECK();
+  int rc = launch_nms_scan(mask, seg_start, num_seg, mask_off, nblk, order, keep_orig, (uint32_t)nb, mask_off + 1,
+                           (unsigned long long)sz * nb, status, st);
+  if (rc != S2A_OK) return rc;
+  k_poly_flags<<<g, 256, 0, st>>>(keep_orig, order, n, flags);
+  need = 0;
+  S2A_HIP(rocprim::select(nullptr, need, order, flags, keep, count_dev, sz, st));
+  S2A_CHECK_ARG(need <= rpb, "nms_rotated_f64: select scratch too small");
   S2A_HIP(rocprim::select(rp, need, order, flags, keep, count_dev, sz, st));
   S2A_LAUNCH_CHECK();
   if (host_count) {

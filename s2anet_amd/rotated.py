@@ -110,8 +110,36 @@ def nms_poly(dets, thresh=0.5):
     return keep[:host_k.value]
 
 
+def _nms_raw_f64(dets, scores, labels, iou_threshold):
+    """float64 boxes: the reference dispatches its NMS kernels on the dtype of `dets` (nms_rotated_cuda.cu:95-100) and
+    evaluates single_box_iou_rotated<double> -- s2a_nms_rotated_f64 is that instantiation (keep decisions next to the
+    threshold differ from the float32 evaluation; tests/golden/nms_f64.npz)"""
+    d = dets.contiguous()
+    s = scores.to(torch.float64).contiguous()
+    lab = None if labels is None else labels.to(torch.float64).contiguous()
+    n = d.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=d.device)
+    if d.dim() != 2 or d.shape[1] != 5:
+        raise RuntimeError("dets must be [N,5]")
+    if s.numel() != n or (lab is not None and lab.numel() != n):
+        raise RuntimeError("scores / labels must have N elements")
+    L = _lib.lib()
+    with torch.cuda.device(d.device):
+        keep = torch.empty((n,), dtype=torch.int64, device=d.device)
+        cnt = torch.empty((1,), dtype=torch.int64, device=d.device)
+        ws = _lib.workspace(L.s2a_nms_rotated_f64_workspace_bytes(n), d.device, "nms_f64")
+        host_k = ctypes.c_int64(0)
+        _lib.check(L.s2a_nms_rotated_f64(_lib.ptr(d), _lib.ptr(s), _lib.ptr(lab), n, float(iou_threshold), _lib.ptr(keep),
+                                         _lib.ptr(cnt), ctypes.byref(host_k), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr(d.device)))
+    return keep[:host_k.value]
+
+
 def _nms_raw(dets, scores, labels, iou_threshold):
     _lib.require_cuda(dets, scores, labels)
+    if dets.dtype == torch.float64:
+        return _nms_raw_f64(dets, scores, labels, iou_threshold)
     d = _f32c(dets)
     s = _f32c(scores)       # f16 scores are only sorted (SURVEY a13): f16->f32 is order preserving
     lab = None if labels is None else _f32c(labels)

@@ -414,6 +414,47 @@ def gen_dcn_backward():
     print("dcn backward golden:", float(x.grad.abs().max()), float(off.grad.abs().max()), float(wgt.grad.abs().max()))
 
 
+def gen_nms_f64():
+    """nms_rotated / ml_nms_rotated on float64 boxes: the reference's CPU ops dispatch on the dtype of `dets`
+    (AT_DISPATCH_FLOATING_TYPES, nms_rotated_cpu.cpp:66 / :67) and evaluate single_box_iou_rotated<double>.  The data
+    are built so that float32 arithmetic DECIDES DIFFERENTLY: next to 400 random boxes sit 300 partners shifted along x
+    by the amount that puts their double IoU within 2e-8 of the threshold (bisection on the oracle's double IoU), on
+    either side -- a float32 evaluation (relative error ~1e-7) lands on the wrong side for a good part of them."""
+    rng = np.random.default_rng(86420)
+    thr = 0.5
+    base = rand_boxes(rng, 400, span=900).astype(np.float64)
+    base[:, 2:4] = rng.uniform(20, 90, (400, 2))
+    partners = []
+    for i in range(300):
+        a = base[i]
+        lo, hi = 0.0, float(a[2])                 # shift 0 -> IoU 1, shift w -> IoU small
+        target = thr + (2e-8 if i % 2 else -2e-8)
+        for _ in range(80):
+            mid = 0.5 * (lo + hi)
+            b = a.copy(); b[0] += mid * np.cos(a[4]); b[1] += mid * np.sin(a[4])
+            v = oracle.iou_pairs_f64(a[None], b[None], sort_mode=oracle.SORT_CPU)[0]
+            if v > target:
+                lo = mid
+            else:
+                hi = mid
+        b = a.copy(); b[0] += lo * np.cos(a[4]); b[1] += lo * np.sin(a[4])
+        partners.append(b)
+    dets = np.concatenate([base, np.array(partners)])
+    n = len(dets)
+    scores = (rng.permutation(n) + 1.0) / (n + 1.0)
+    scores[400:] = scores[:300] - 1e-9 * (1 + np.arange(300))       # a partner right behind its box
+    labels = np.concatenate([rng.integers(0, 5, 400), np.zeros(300)]).astype(np.float64)
+    labels[400:] = labels[:300]
+    td, ts, tl = torch.from_numpy(dets), torch.from_numpy(scores), torch.from_numpy(labels)
+    out = dict(dets=dets, scores=scores, labels=labels, thr=np.float64(thr))
+    out["ml_keep_f64"] = ref.ml_nms_rotated()(td, ts, tl, thr).numpy()
+    out["sc_keep_f64"] = ref.nms_rotated()(td, ts, thr).numpy()
+    out["ml_keep_f32"] = ref.ml_nms_rotated()(td.float(), ts.float(), tl.float(), thr).numpy()
+    print("nms f64: n", n, "keep f64", len(out["ml_keep_f64"]), "keep f32", len(out["ml_keep_f32"]),
+          "f64 != f32 decisions:", len(set(out["ml_keep_f64"]) ^ set(out["ml_keep_f32"])))
+    np.savez_compressed(os.path.join(OUT, "nms_f64.npz"), **out)
+
+
 def gen_formats():
     """scale_coords_rotated from the reference's own utils/general.py:629-648 (imported with the cv2 stub): letterboxed
     network coordinates -> original-image coordinates, with and without an explicit ratio_pad"""
@@ -616,4 +657,5 @@ if __name__ == "__main__":
     gen_rie()
     gen_net_forward()
     gen_formats()
+    gen_nms_f64()
     print("done ->", OUT)

@@ -512,6 +512,33 @@ def test_batched_nms_writes_the_wire_buffer_and_counts_dropped_candidates(rng):
     assert (d0 == 0).all() and (l0 == -1).all() and (c0 == 0).all() and o0.cpu().tolist() == [0, 0]
 
 
+def test_nms_float64_dispatch_matches_reference_double_arithmetic(rng):
+    """float64 boxes take the double instantiation (the reference dispatches on dets' dtype, nms_rotated_cuda.cu:95-100):
+    on the fixture built so that 136 keep decisions differ between float32 and float64 arithmetic, the GPU keep lists
+    equal the reference's CPU op run on the double tensors; fresh inputs against the (pinned) double oracle with the GPU
+    rule; float32 inputs still take the float32 path."""
+    import s2anet_amd as S
+    g = golden("nms_f64.npz")
+    d, s, l, thr = g["dets"], g["scores"], g["labels"], float(g["thr"])
+    td, ts, tl = torch.from_numpy(d).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(l).cuda()
+    k_ml = S.ml_nms_rotated(td, ts, tl, thr).cpu().numpy()
+    from s2anet_amd.rotated import nms_rotated_raw
+    k_sc = nms_rotated_raw(td, ts, thr).cpu().numpy()
+    # (no pair of the fixture sits EXACTLY on the threshold, so the CPU op's >= and the GPU op's > agree)
+    assert np.array_equal(k_ml, g["ml_keep_f64"]) and np.array_equal(k_sc, g["sc_keep_f64"])
+    k32 = S.ml_nms_rotated(td.float(), ts.float(), tl.float(), thr).cpu().numpy()
+    assert not np.array_equal(k32, g["ml_keep_f64"])                  # float32 inputs: the float32 evaluation, as the reference
+    for n, thr2 in ((1, 0.5), (65, 0.3), (3000, 0.5)):
+        dd = rand_rboxes(rng, n, span=400).astype(np.float64)
+        ss = distinct_scores(rng, n).astype(np.float64)
+        ll = rng.integers(0, 6, n).astype(np.float64)
+        got = S.ml_nms_rotated(torch.from_numpy(dd).cuda(), torch.from_numpy(ss).cuda(), torch.from_numpy(ll).cuda(), thr2)
+        assert np.array_equal(got.cpu().numpy(), oracle.nms_rotated_f64(dd, ss, thr2, labels=ll))
+    empty = S.ml_nms_rotated(torch.zeros((0, 5), dtype=torch.float64).cuda(), torch.zeros(0, dtype=torch.float64).cuda(),
+                             torch.zeros(0, dtype=torch.float64).cuda(), 0.5)
+    assert empty.numel() == 0 and empty.dtype == torch.int64
+
+
 # ------------------------------------------------------------------ ORN
 def test_arf_and_pool(rng):
     import s2anet_amd as S

@@ -229,3 +229,28 @@ def test_live_reference_ops_agree_on_fresh_inputs(rng):
     lab = rng.integers(0, 15, n).astype(np.float32)
     rk = ref.ml_nms_rotated()(torch.from_numpy(d), torch.from_numpy(s), torch.from_numpy(lab), 0.3).numpy()
     assert np.array_equal(rk, oracle.ml_nms_rotated(d, s, lab, 0.3, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU))
+
+
+def test_nms_f64_matches_reference_cpu_double_dispatch():
+    """the NMS ops dispatch on the dtype of `dets` (AT_DISPATCH_FLOATING_TYPES, nms_rotated_cpu.cpp:66): on float64 boxes
+    the reference evaluates single_box_iou_rotated<double>.  Fixture from the reference's CPU ops on data where 136
+    keep decisions differ between float32 and float64 arithmetic (tests/golden/make_golden.py:gen_nms_f64)."""
+    g = golden("nms_f64.npz")
+    d, s, l, thr = g["dets"], g["scores"], g["labels"], float(g["thr"])
+    assert d.dtype == np.float64
+    k_ml = oracle.nms_rotated_f64(d, s, thr, labels=l, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU)
+    k_sc = oracle.nms_rotated_f64(d, s, thr, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU)
+    assert np.array_equal(k_ml, g["ml_keep_f64"]) and np.array_equal(k_sc, g["sc_keep_f64"])
+    assert len(set(g["ml_keep_f64"].tolist()) ^ set(g["ml_keep_f32"].tolist())) > 50      # the fixture has teeth
+    k32 = oracle.ml_nms_rotated(d.astype(np.float32), s.astype(np.float32), l.astype(np.float32), thr, rule=oracle.RULE_GE,
+                                sort_mode=oracle.SORT_CPU)
+    assert not np.array_equal(k32, g["ml_keep_f64"])                                        # ... float32 arithmetic fails it
+    ref_ml = ref.ml_nms_rotated()
+    if ref_ml is not None:                      # live: fresh double inputs through the reference's own CPU op
+        import torch
+        rng = np.random.default_rng(5)
+        dd = rand_rboxes(rng, 500, span=260).astype(np.float64)
+        ss = distinct_scores(rng, 500).astype(np.float64)
+        ll = rng.integers(0, 4, 500).astype(np.float64)
+        want = ref_ml(torch.from_numpy(dd), torch.from_numpy(ss), torch.from_numpy(ll), 0.3).numpy()
+        assert np.array_equal(oracle.nms_rotated_f64(dd, ss, 0.3, labels=ll, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU), want)
