@@ -39,6 +39,7 @@ extern "C" {
 
 #define S2A_DTYPE_F32 0
 #define S2A_DTYPE_F16 1
+#define S2A_DTYPE_F64 2 /* ARF forward / backward only (AT_DISPATCH_FLOATING_TYPES, ActiveRotatingFilter_cuda.cu:104,149) */
 
 #define S2A_LAYOUT_NCHW 0 /* reference layout (contiguous NCHW) */
 #define S2A_LAYOUT_NHWC 1 /* channels-last storage of the same logical tensor */

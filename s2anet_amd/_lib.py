@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S2A_LIB_PATH") or os.path.join(_HERE, "libs2anet_hip.so")   # override: A/B builds
 
 OK, EINVAL, EWORKSPACE, EHIP, ENOTIMPL = 0, -1, -2, -3, -4
-DTYPE_F32, DTYPE_F16 = 0, 1
+DTYPE_F32, DTYPE_F16, DTYPE_F64 = 0, 1, 2
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 
 c_i64, c_int, c_f32, c_sz, c_vp = (ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,

@@ -134,7 +134,7 @@ extern "C" int s2a_arf_forward(const void* weight, const uint8_t* indices, int64
   const int n_entry = n_orientation * kh * kw;
   S2A_CHECK_ARG(n_entry <= 255, "arf_forward: nOrientation*kH*kW must be <= 255 (uint8 1-based index)");
   S2A_CHECK_ARG(n_rotation <= 8, "arf_forward: nRotation must be <= 8");
-  S2A_CHECK_ARG(dtype == S2A_DTYPE_F32 || dtype == S2A_DTYPE_F16, "arf_forward: dtype");
+  S2A_CHECK_ARG(dtype == S2A_DTYPE_F32 || dtype == S2A_DTYPE_F16 || dtype == S2A_DTYPE_F64, "arf_forward: dtype");
   const int64_t total = n_out * n_rotation * n_in * n_entry;
   if (total == 0) return S2A_OK;  // reference returns the empty tensor (cuda.cu:100-103)
   S2A_CHECK_ARG(weight && indices && output, "arf_forward: NULL tensor");
@@ -143,6 +143,9 @@ extern "C" int s2a_arf_forward(const void* weight, const uint8_t* indices, int64
   if (dtype == S2A_DTYPE_F32)
     k_arf_forward<float><<<g, 256, 0, st>>>((const float*)weight, indices, n_out, n_in, n_entry,
                                             n_rotation, (float*)output);
+  else if (dtype == S2A_DTYPE_F64)
+    k_arf_forward<double><<<g, 256, 0, st>>>((const double*)weight, indices, n_out, n_in, n_entry,
+                                             n_rotation, (double*)output);
   else
     k_arf_forward<uint16_t><<<g, 256, 0, st>>>((const uint16_t*)weight, indices, n_out, n_in,
                                                n_entry, n_rotation, (uint16_t*)output);
@@ -157,12 +160,16 @@ extern "C" int s2a_arf_backward(const uint8_t* indices, const void* grad_output,
                 "arf_backward: bad shape");
   const int n_entry = n_orientation * kh * kw;
   S2A_CHECK_ARG(n_entry <= 255 && n_rotation <= 8, "arf_backward: index table too large");
-  S2A_CHECK_ARG(dtype == S2A_DTYPE_F32, "arf_backward: float32 only (the reference dispatches float/double, cuda.cu:149)");
+  S2A_CHECK_ARG(dtype == S2A_DTYPE_F32 || dtype == S2A_DTYPE_F64, "arf_backward: float32 / float64 (the reference's dispatch, cuda.cu:149)");
   const int64_t total = n_out * n_in * n_entry;
   if (total == 0) return S2A_OK;
   S2A_CHECK_ARG(indices && grad_output && grad_input, "arf_backward: NULL tensor");
-  k_arf_backward<float><<<grid_cap(total), 256, 0, as_stream(stream)>>>((const float*)grad_output, indices, n_out, n_in,
-                                                                       n_entry, n_rotation, (float*)grad_input);
+  if (dtype == S2A_DTYPE_F64)
+    k_arf_backward<double><<<grid_cap(total), 256, 0, as_stream(stream)>>>((const double*)grad_output, indices, n_out, n_in,
+                                                                          n_entry, n_rotation, (double*)grad_input);
+  else
+    k_arf_backward<float><<<grid_cap(total), 256, 0, as_stream(stream)>>>((const float*)grad_output, indices, n_out, n_in,
+                                                                         n_entry, n_rotation, (float*)grad_input);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

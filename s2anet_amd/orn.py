@@ -39,27 +39,28 @@ def arf_forward(weight, indices):
     out = torch.empty((O * nRot, I * nOri, kH, kW), dtype=w.dtype, device=w.device)
     with torch.cuda.device(w.device):
         _lib.check(_lib.lib().s2a_arf_forward(_lib.ptr(w), _lib.ptr(idx), O, I, nOri, kH, kW, nRot,
-                                              _lib.dtype_code(w), _lib.ptr(out),
+                                              _lib.DTYPE_F64 if w.dtype == torch.float64 else _lib.dtype_code(w), _lib.ptr(out),
                                               _lib.stream_ptr(w.device)))
     return out
 
 
 def arf_backward(indices, grad_output):
     """orn_cuda.arf_backward: indices uint8[nOri,kH,kW,nRot], gradOutput[O*nRot, I*nOri, kH, kW]
-    -> gradInput[O, I, nOri, kH, kW] (new tensor; float32)"""
+    -> gradInput[O, I, nOri, kH, kW] (new tensor; float32 or float64)"""
     _lib.require_cuda(indices, grad_output)
     idx = indices.contiguous()
     if idx.dtype != torch.uint8:
         idx = idx.byte()
     g = grad_output.contiguous()
-    if g.dtype != torch.float32:
-        raise RuntimeError("arf_backward: float32 gradients only")
+    if g.dtype not in (torch.float32, torch.float64):     # the reference's dispatch (ActiveRotatingFilter_cuda.cu:149)
+        raise RuntimeError("arf_backward: float32 / float64 gradients only")
     nOri, kH, kW, nRot = idx.shape
     O, I = g.shape[0] // nRot, g.shape[1] // nOri
     out = torch.empty((O, I, nOri, kH, kW), dtype=g.dtype, device=g.device)
     with torch.cuda.device(g.device):
         _lib.check(_lib.lib().s2a_arf_backward(_lib.ptr(idx), _lib.ptr(g), O, I, nOri, kH, kW, nRot,
-                                               _lib.dtype_code(g), _lib.ptr(out), _lib.stream_ptr(g.device)))
+                                               _lib.DTYPE_F64 if g.dtype == torch.float64 else _lib.dtype_code(g),
+                                               _lib.ptr(out), _lib.stream_ptr(g.device)))
     return out
 
 

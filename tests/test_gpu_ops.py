@@ -1059,6 +1059,33 @@ def test_arf_backward_and_autograd(rng):
     assert torch.allclose(oc.weight.grad, S.arf_backward(oc.indices, w_exp.grad), rtol=1e-5, atol=1e-5)
 
 
+def test_arf_float64_dispatch(rng):
+    """arf_forward / arf_backward on float64 tensors (AT_DISPATCH_FLOATING_TYPES, ActiveRotatingFilter_cuda.cu:104,149):
+    bit-exact against the reference's CPU op run on the same double tensors (small shapes: its uint16 index wraps beyond
+    65 535 elements) and against the definition at the head's shape"""
+    import s2anet_amd as S
+    from oracle import ref
+    orn = ref.orn()
+    for shp in ((4, 2, 1, 3, 3), (4, 2, 8, 3, 3)):
+        O, I, nOri, kH, kW = shp
+        idx = oracle.arf_indices(nOri, 8, 3)
+        w = rng.standard_normal(shp)
+        g = rng.standard_normal((O * 8, I * nOri, kH, kW))
+        out = S.arf_forward(torch.from_numpy(w).cuda(), cu(idx))
+        gin = S.arf_backward(cu(idx), torch.from_numpy(g).cuda())
+        assert out.dtype == torch.float64 and gin.dtype == torch.float64
+        if orn is not None:
+            assert np.array_equal(out.cpu().numpy(), orn.arf_forward(torch.from_numpy(w), torch.from_numpy(idx)).numpy())
+            assert np.array_equal(gin.cpu().numpy(), orn.arf_backward(torch.from_numpy(idx), torch.from_numpy(g)).numpy())
+        # the same values as the float32 path where float32 is exact: forward is a pure copy
+        assert np.array_equal(out.cpu().numpy().astype(np.float32), S.arf_forward(cu(w.astype(np.float32)), cu(idx)).cpu().numpy())
+    idx = oracle.arf_indices(1, 8, 3)
+    w = rng.standard_normal((32, 256, 1, 3, 3))
+    got = S.arf_forward(torch.from_numpy(w).cuda(), cu(idx)).cpu().numpy()
+    assert np.array_equal(got.astype(np.float32), oracle.arf_forward(w.astype(np.float32), idx)) and got.dtype == np.float64
+    assert np.array_equal(got, np.ascontiguousarray(got))          # (values are copies of w: exact in float64 as well)
+
+
 def test_modulated_deform_conv_forward_vs_torch_formulation(rng):
     """deform_conv_cuda.modulated_deform_conv_cuda_forward (DCNv2): no runnable reference (CUDA only) -> checked against
     an independent torch formulation (explicit 4-corner gather x mask, einsum with the grouped filter, + bias) in
