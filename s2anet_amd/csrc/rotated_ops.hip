@@ -503,6 +503,87 @@ __device__ __forceinline__ void block_sum2(unsigned& a, unsigned& b) {
   b = s_b[0] + s_b[1] + s_b[2] + s_b[3];
 }
 
+// ---- own order-B sort (round 4).  The spatial order only has to GROUP the rows by segment and keep them spatially coherent
+// inside a segment: a counting sort into (segment, Morton cell) buckets does that in three launches where rocPRIM's pair
+// sort takes nine (73 us of host-paced launches at 200 k rows).  The segment key is 32 arbitrary bits (float_sortable(label)
+// for the drop-in op), so the distinct keys are first hashed into a small table and numbered in order of arrival -- the B
+// order may list the segments in any order: everything behind the cull works on B positions, and the direct fallback,
+// which works in score order, gets segment starts of its own (seg_start_a).  More than ~8 k distinct keys, or 65 536
+// (segment, cell) buckets exceeded: status bit 1 -> that fallback settles the call (slow, exact).
+constexpr uint32_t kSpbSlots = 16384, kSpbHist = 65536, kSpbGroups = kSpbHist / 64, kSpbPending = 0x7fffffffu;
+constexpr unsigned long long kSpbEmpty = ~0ull;
+__device__ __forceinline__ uint32_t spb_hash(uint32_t k) {
+  k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16;
+  return k & (kSpbSlots - 1);
+}
+// insert key (first thread to claim an empty slot numbers it); safe against stale reads: a slot only ever goes
+// EMPTY -> (key | pending) -> (key | id), and the claim itself is a device-scope compare-and-swap
+__device__ __forceinline__ void spb_insert(unsigned long long* __restrict__ htab, uint32_t* __restrict__ ctr, uint32_t key) {
+  uint32_t h = spb_hash(key);
+  for (uint32_t probe = 0; probe < kSpbSlots; probe++) {
+    unsigned long long cur = __hip_atomic_load(&htab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kSpbEmpty) {
+      const unsigned long long want = ((unsigned long long)key << 32) | kSpbPending;
+      cur = atomicCAS(&htab[h], kSpbEmpty, want);
+      if (cur == kSpbEmpty) {
+        const uint32_t id = atomicAdd(&ctr[0], 1u);
+        atomicExch(&htab[h], ((unsigned long long)key << 32) | id);
+        return;
+      }
+    }
+    if ((uint32_t)(cur >> 32) == key) return;
+    h = (h + 1) & (kSpbSlots - 1);
+  }
+  atomicOr(&ctr[1], 1u);                         // table full
+}
+// the distinct keys of a 256-thread workgroup, each inserted ONCE: 200 k rows with 15 labels are 200 k reads of 15 hot
+// slots otherwise, and at the start of the launch every one of them still sees "empty" and goes for the compare-and-swap
+// (same-address atomics serialise at ~11 ns: the insert took 100 us).  A 64-slot LDS set per workgroup; a key that does
+// not fit goes to the global table directly.
+__device__ __forceinline__ void spb_insert_block(unsigned long long* __restrict__ htab, uint32_t* __restrict__ ctr,
+                                                 uint32_t key, bool valid) {
+  __shared__ unsigned long long s_set[64];
+  if (threadIdx.x < 64) s_set[threadIdx.x] = kSpbEmpty;
+  __syncthreads();
+  bool mine = false, direct = false;
+  if (valid) {
+    uint32_t h = (key * 0x9e3779b1u) >> 26;      // 6 bits
+    direct = true;
+    for (int probe = 0; probe < 8; probe++) {
+      const unsigned long long prev = atomicCAS(&s_set[h], kSpbEmpty, (unsigned long long)key);
+      if (prev == kSpbEmpty) { mine = true; direct = false; break; }
+      if ((uint32_t)prev == key) { direct = false; break; }
+      h = (h + 1) & 63;
+    }
+  }
+  if (mine || direct) spb_insert(htab, ctr, key);
+}
+__device__ __forceinline__ uint32_t spb_lookup(const unsigned long long* __restrict__ htab, uint32_t key) {
+  uint32_t h = spb_hash(key);
+  for (uint32_t probe = 0; probe < kSpbSlots; probe++) {
+    const unsigned long long cur = htab[h];
+    if (cur == kSpbEmpty) break;
+    if ((uint32_t)(cur >> 32) == key) return (uint32_t)cur;
+    h = (h + 1) & (kSpbSlots - 1);
+  }
+  return 0xffffffffu;
+}
+// bits of the Morton code that go into the bucket index: ~4 rows per bucket, at most kSpbHist buckets for the m distinct
+// segments.  (16 rows per bucket made the scan one short workgroup but cost the cull 15-25 us: rows arrive in a bucket in
+// any order, and the cull's 64-row blocks are as compact as the buckets are fine.)
+__device__ __forceinline__ uint32_t spb_buckets(int64_t n) {
+  uint32_t b = 1024;
+  while (b < kSpbHist && (int64_t)b * 4 < n) b <<= 1;
+  return b;
+}
+__device__ __forceinline__ int spb_cell_bits(uint32_t m, int64_t n) {
+  int sb = 0, tb = 0;
+  while ((1u << sb) < m) sb++;                   // ceil(log2(m))
+  while ((1u << tb) < spb_buckets(n)) tb++;
+  const int cb = tb - sb;
+  return cb < 0 ? 0 : (cb > 12 ? 12 : cb);
+}
+
 // keys of all three orders + the workspace initialisation (counters, round flags, block bounding boxes: by kernels, never
 // hipMemsetAsync -- DESIGN 5) + per-block partial bounding box of the finite centres (no atomics, so no init hazard)
 __global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ dets5, const float* __restrict__ scores,
@@ -513,8 +594,15 @@ __global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ dets
                                                   uint4* __restrict__ bbox_part, NmsCounters* __restrict__ C,
                                                   uint32_t* __restrict__ blocked32, size_t nblocked32,
                                                   uint32_t* __restrict__ seg_cnt, size_t nseg_cnt,
-                                                  uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots) {
+                                                  uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots,
+                                                  unsigned long long* __restrict__ htab, uint32_t* __restrict__ hist,
+                                                  uint32_t* __restrict__ spb_ctr) {
   const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (htab) {                                    // own order-B sort: table, histogram and counters (filled by k_spb_insert)
+    for (size_t i = i0; i < kSpbSlots; i += stride) htab[i] = kSpbEmpty;
+    for (size_t i = i0; i < kSpbHist + 64; i += stride) hist[i] = 0u;
+    if (i0 < 4) spb_ctr[i0] = 0u;
+  }
   for (size_t i = i0; i < sizeof(NmsCounters) / 4; i += stride) reinterpret_cast<uint32_t*>(C)[i] = 0u;
   for (size_t i = i0; i < nblocked32; i += stride) blocked32[i] = 0u;
   for (size_t i = i0; i < nseg_cnt; i += stride) seg_cnt[i] = 0u;
@@ -563,7 +651,8 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every
 __global__ __launch_bounds__(256) void k_nms_spkeys(const float* __restrict__ dets5,
                                                     const unsigned long long* __restrict__ keyA,
                                                     const uint4* __restrict__ bbox_part, int nparts, int64_t n,
-                                                    unsigned long long* __restrict__ keyB) {
+                                                    unsigned long long* __restrict__ keyB,
+                                                    unsigned long long* __restrict__ htab, uint32_t* __restrict__ spb_ctr) {
   __shared__ uint4 s_bb[4];
   uint4 r = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
   for (int k = threadIdx.x; k < nparts; k += 256) {
@@ -582,6 +671,7 @@ __global__ __launch_bounds__(256) void k_nms_spkeys(const float* __restrict__ de
     r.x = min(r.x, s_bb[w].x); r.y = min(r.y, s_bb[w].y); r.z = max(r.z, s_bb[w].z); r.w = max(r.w, s_bb[w].w);
   }
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (htab) spb_insert_block(htab, spb_ctr, p < n ? (uint32_t)(keyA[p] >> 32) : 0u, p < n);   // own order-B sort, pass 1 (k_spb_*)
   if (p >= n) return;
   const float x0 = sortable_float(r.x), y0 = sortable_float(r.y), x1 = sortable_float(r.z), y1 = sortable_float(r.w);
   const float sx = x1 > x0 ? 1023.f / (x1 - x0) : 0.f, sy = y1 > y0 ? 1023.f / (y1 - y0) : 0.f;
@@ -590,6 +680,75 @@ __global__ __launch_bounds__(256) void k_nms_spkeys(const float* __restrict__ de
   qy = qy >= 0.f ? fminf(qy, 1023.f) : 0.f;
   const uint32_t m = spread10((uint32_t)qx) | (spread10((uint32_t)qy) << 1);
   keyB[p] = ((keyA[p] >> 32) << 20) | m;
+}
+
+// own order-B sort (pass 1, the hash insert, rides in k_nms_spkeys)
+// pass 2: bucket = (segment number, top bits of the Morton code) of every row, its rank inside the bucket
+__global__ __launch_bounds__(256) void k_spb_hist(const unsigned long long* __restrict__ keyB, int64_t n,
+                                                  const unsigned long long* __restrict__ htab,
+                                                  uint32_t* __restrict__ ctr, uint32_t* __restrict__ hist,
+                                                  uint32_t* __restrict__ bucket, uint32_t* __restrict__ rank,
+                                                  NmsCounters* __restrict__ C) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t m = ctr[0];
+  const int cb = spb_cell_bits(m, n);
+  const unsigned long long k = keyB[p];
+  uint32_t id = spb_lookup(htab, (uint32_t)(k >> 20));
+  const uint32_t cell = ((uint32_t)k & 0xfffffu) >> (20 - cb);
+  if (id == 0xffffffffu || id >= kSpbPending || ctr[1] != 0u || ((unsigned long long)id << cb) + cell >= spb_buckets(n)) {
+    id = 0;                                      // cannot be bucketed: the direct fallback settles the call
+    if ((C->status & 2u) == 0u) atomicOr(&C->status, 2u);
+  }
+  const uint32_t b = (id << cb) | cell;
+  bucket[p] = b;
+  rank[p] = atomicAdd(&hist[b], 1u);
+}
+// pass 3: exclusive scan of the histogram in two levels -- a wave per group of 64 buckets (in place, group total aside),
+// then one workgroup over the <= 1 024 group totals.  (One workgroup over 61 k buckets took 75 us, uncoalesced; the scan as
+// the last act of the LAST workgroup of pass 2 -- fence, ticket, scan -- 97 us: a device-scope release per workgroup writes
+// the XCD's dirty L2 lines back 782 times.)
+__global__ __launch_bounds__(256) void k_spb_scan1(uint32_t* __restrict__ hist, uint32_t* __restrict__ group_sum, int64_t n) {
+  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g * 64 >= spb_buckets(n)) return;
+  const unsigned v = hist[g * 64 + lane];
+  unsigned incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o);
+    if (lane >= (unsigned)o) incl += t;
+  }
+  hist[g * 64 + lane] = incl - v;
+  if (lane == 63) group_sum[g] = incl;
+}
+__global__ __launch_bounds__(1024) void k_spb_scan2(uint32_t* __restrict__ group_sum, int64_t n) {
+  __shared__ unsigned s_w[16];
+  const uint32_t groups = spb_buckets(n) / 64;                 // 16 .. 1024
+  const unsigned v = threadIdx.x < groups ? group_sum[threadIdx.x] : 0u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  unsigned base = incl - v;
+  for (int w = 0; w < wave; w++) base += s_w[w];
+  if (threadIdx.x < groups) group_sum[threadIdx.x] = base;
+}
+// pass 4: rows into their places
+__global__ __launch_bounds__(256) void k_spb_scatter(const unsigned long long* __restrict__ keyB, int64_t n,
+                                                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ group_base,
+                                                     const uint32_t* __restrict__ bucket, const uint32_t* __restrict__ rank,
+                                                     unsigned long long* __restrict__ keyB_s, int32_t* __restrict__ perm_sp) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t b = bucket[p];
+  const uint32_t pos = group_base[b >> 6] + hist[b] + rank[p];
+  keyB_s[pos] = keyB[p];
+  perm_sp[pos] = (int32_t)p;
 }
 
 // number of segment heads (rows whose segment key -- key >> shift -- differs from the row before) per block of `rows`
@@ -961,10 +1120,13 @@ __global__ __launch_bounds__(256) void k_nms_pos_meta(const float* __restrict__ 
                                                       uint32_t ignore_key, int use_ignore,
                                                       uint32_t* __restrict__ segidx1, uint32_t* __restrict__ seg_start,
                                                       uint32_t* __restrict__ num_seg, PreBox* __restrict__ sorted,
-                                                      uint8_t* __restrict__ state, uint8_t* __restrict__ state_fb) {
+                                                      uint8_t* __restrict__ state, uint8_t* __restrict__ state_fb,
+                                                      uint32_t* __restrict__ seg_start_a, uint32_t* __restrict__ num_seg_a) {
   unsigned before, total;
   count_prefix(cnt, nb, blockIdx.x, before, total);
   if (seg_start && blockIdx.x == 0 && threadIdx.x == 0) { *num_seg = total; seg_start[total] = (uint32_t)n; }
+  // (spatial path: the B order numbers the segments in its own way; the direct fallback works in THIS order)
+  if (seg_start_a && blockIdx.x == 0 && threadIdx.x == 0) { *num_seg_a = total; seg_start_a[total] = (uint32_t)n; }
   const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
   unsigned running = before;
   for (int64_t base = r0; base < r1; base += 256) {
@@ -983,6 +1145,7 @@ __global__ __launch_bounds__(256) void k_nms_pos_meta(const float* __restrict__ 
         segidx1[p] = s + 1;
         if (head) seg_start[s] = (uint32_t)p;
       }
+      if (seg_start_a && head) seg_start_a[s] = (uint32_t)p;
       const int32_t o = perm_seg[p];
       const float* b = dets5 + 5 * (int64_t)o;
       PreBox pb = make_prebox(b[0], b[1], b[2], b[3], b[4], __uint_as_float(s));
@@ -1805,7 +1968,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_greedy_direct(const PreBox* __
                                                                 unsigned long long ecap, unsigned long long tile_cap,
                                                                 uint8_t* __restrict__ state /* score order: state_fb */,
                                                                 float thr) {
-  if (!(C->pairs > cap || C->edges > ecap || C->tiles > tile_cap)) return;
+  if (!(C->pairs > cap || C->edges > ecap || C->tiles > tile_cap || (C->status & 2u))) return;
   __shared__ float2 s_pts[24 * kThreads];
   __shared__ unsigned s_next;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&C->status, 1u);
@@ -1927,6 +2090,10 @@ struct NmsBuffers {
   uint2 *gq, *edges;
   uint8_t *keep_orig, *state, *state_fb, *blocked;
   uint32_t *seg_cnt, *seg_cur;
+  // own order-B sort (k_spb_*): hash table of the distinct segment keys, (segment, cell) histogram, per-row bucket / rank,
+  // [0] distinct keys, [1] table-full flag; and the A-order segment starts of the direct fallback
+  unsigned long long* htab;
+  uint32_t *hist, *spb_ctr, *rank, *bucket, *seg_start_a, *num_seg_a;
   void* rp_temp[3];
 };
 
@@ -1989,6 +2156,13 @@ void nms_carve_fixed(Carver& cv, int64_t n, const NmsPlan& pl, NmsBuffers* B) {
   B->blocked = cv.take<uint8_t>(2 * sz + 4);
   B->seg_cnt = cv.take<uint32_t>(sz + 2);
   B->seg_cur = cv.take<uint32_t>(sz + 2);
+  B->htab = cv.take<unsigned long long>(kSpbSlots);
+  B->hist = cv.take<uint32_t>(kSpbHist + 64 + kSpbGroups);        // histogram | group totals
+  B->spb_ctr = cv.take<uint32_t>(4);
+  B->rank = cv.take<uint32_t>(sz);
+  B->bucket = cv.take<uint32_t>(sz);
+  B->seg_start_a = cv.take<uint32_t>(sz + 1);
+  B->num_seg_a = cv.take<uint32_t>(4);
   for (int k = 0; k < 3; k++) B->rp_temp[k] = cv.take<char>(pl.rocprim_bytes);
 }
 
@@ -2022,6 +2196,10 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   const int force_global = e_lds && e_lds[0] == '1';
   // one segment and no groups (plain nms_rotated): order A is the output order
   const bool need_c = labels != nullptr || seg_ids != nullptr || group_ids != nullptr;
+  // order B by the own counting sort (four short launches behind the key kernel) instead of rocPRIM's pair sort (nine);
+  // S2A_NMS_SORTB=0: A/B, tests
+  bool own_sort = spatial;
+  if (const char* e = std::getenv("S2A_NMS_SORTB")) own_sort = spatial && e[0] != '0';
   uint2* lo = spatial ? B.lo : nullptr;
   const size_t slots = block_slots_for(sz);
   const unsigned gp = (unsigned)std::min<size_t>(kPrepBlocks, std::max<size_t>(grid_for(n), 1));
@@ -2029,7 +2207,8 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   const int nb = (int)((n + rows - 1) / rows);
   k_nms_prep<<<gp, 256, 0, st>>>(dets, scores, labels, seg_ids, group_ids, num_groups, ignore_key, n, B.keyA,
                                  need_c ? B.keyC : nullptr, B.idx, B.bbox_part, B.C,
-                                 reinterpret_cast<uint32_t*>(B.blocked), (2 * sz + 3) / 4, B.seg_cnt, sz + 2, lo, B.hi, slots);
+                                 reinterpret_cast<uint32_t*>(B.blocked), (2 * sz + 3) / 4, B.seg_cnt, sz + 2, lo, B.hi, slots,
+                                 own_sort ? B.htab : nullptr, B.hist, B.spb_ctr);
   // A call is as long as its chain of LAUNCHES while the kernels are short (the host needs ~5 us per launch, a rocPRIM
   // sort is nine of them).  For big segments only the spatial order B is enqueued in front of the cull, and everything
   // behind the cull works on SPATIAL positions (greedy direction from the rank keys): the score order A is needed by the
@@ -2056,7 +2235,8 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     k_nms_seg_count<<<nb, 256, 0, q>>>(B.keyA_s, 32, n, rows, B.cnt, nullptr);
     k_nms_pos_meta<<<nb, 256, 0, q>>>(dets, B.keyA_s, B.perm_seg, B.cnt, nb, rows, n, ignore_key, use_ignore, B.segidx1,
                                       main_order ? B.seg_start : nullptr, B.num_seg, B.sorted,
-                                      main_order ? B.state : nullptr, B.state_fb);
+                                      main_order ? B.state : nullptr, B.state_fb,
+                                      main_order ? nullptr : B.seg_start_a, B.num_seg_a);
     return S2A_OK;
   };
   auto sort_c = [&](hipStream_t q) -> int {
@@ -2068,9 +2248,16 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   const unsigned long long* rankkey = nullptr;   // ... and a lower position IS the higher score
   const int32_t* perm = B.perm_seg;              // original row of a position
   if (spatial) {
-    k_nms_spkeys<<<g, 256, 0, st>>>(dets, B.keyA, B.bbox_part, (int)gp, n, B.keyB);
-    size_t rpb = pl.rocprim_bytes;
-    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[1], rpb, B.keyB, B.keyB_s, B.idx, B.perm_sp, sz, 0, 52, st));
+    k_nms_spkeys<<<g, 256, 0, st>>>(dets, B.keyA, B.bbox_part, (int)gp, n, B.keyB, own_sort ? B.htab : nullptr, B.spb_ctr);
+    if (own_sort) {
+      k_spb_hist<<<g, 256, 0, st>>>(B.keyB, n, B.htab, B.spb_ctr, B.hist, B.bucket, B.rank, B.C);
+      k_spb_scan1<<<kSpbGroups / 4, 256, 0, st>>>(B.hist, B.hist + kSpbHist + 64, n);
+      k_spb_scan2<<<1, 1024, 0, st>>>(B.hist + kSpbHist + 64, n);
+      k_spb_scatter<<<g, 256, 0, st>>>(B.keyB, n, B.hist, B.hist + kSpbHist + 64, B.bucket, B.rank, B.keyB_s, B.perm_sp);
+    } else {
+      size_t rpb = pl.rocprim_bytes;
+      S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[1], rpb, B.keyB, B.keyB_s, B.idx, B.perm_sp, sz, 0, 52, st));
+    }
     k_nms_seg_count<<<nb, 256, 0, st>>>(B.keyB_s, 20, n, rows, B.cnt2, B.lasthead);
     k_nms_sp_meta<<<nb, 256, 0, st>>>(dets, B.keyB_s, B.perm_sp, B.cnt2, B.lasthead, nb, rows, n, scores, ignore_key,
                                       use_ignore, B.segidx1, B.seg_start, B.num_seg, B.sp_box, B.rankkey, B.state, B.lo, B.hi);
@@ -2130,7 +2317,8 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   k_nms_finish_segments<<<512, kThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.seg_cnt, B.edges, B.state, B.blocked, n,
                                                   force_global);
   if (ss && spatial) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
-  k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, B.seg_start, B.num_seg, B.keyA_s, ignore_key, use_ignore, B.C,
+  k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, spatial ? B.seg_start_a : B.seg_start, spatial ? B.num_seg_a : B.num_seg,
+                                                B.keyA_s, ignore_key, use_ignore, B.C,
                                                 pair_cap, pl.edge_cap, pl.tile_cap, B.state_fb, thr);
   k_nms_finish<<<g, 256, 0, st>>>(B.state, B.blocked, B.C, perm, B.state_fb, B.perm_seg, n, B.keep_orig);
   if (ss && need_c) S2A_HIP(hipStreamWaitEvent(st, ss->join[1], 0));

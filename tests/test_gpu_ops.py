@@ -512,6 +512,39 @@ def test_batched_nms_writes_the_wire_buffer_and_counts_dropped_candidates(rng):
     assert (d0 == 0).all() and (l0 == -1).all() and (c0 == 0).all() and o0.cpu().tolist() == [0, 0]
 
 
+def test_nms_order_b_counting_sort_labels_of_any_kind(rng, monkeypatch):
+    """the spatial order of big inputs is built by an own counting sort into (segment, Morton cell) buckets (k_spb_*): the
+    distinct segment keys are hashed and numbered in order of arrival.  Labels that are not small integers (negative,
+    fractional, huge, -0.0 next to +0.0), the rocPRIM form of the same order (S2A_NMS_SORTB=0) and -- more distinct labels
+    than the table holds -- the direct fallback must all give the oracle's keep list."""
+    import s2anet_amd as S
+    n = 9000
+    d = rand_rboxes(rng, n, span=700)
+    s = distinct_scores(rng, n)
+    weird = np.array([-3.5, -0.0, 0.0, 0.25, 1.0, 7.0, 1e9, -1e-30, 65504.0, 3.0000002], np.float32)
+    lab = weird[rng.integers(0, len(weird), n)]
+    want = oracle.ml_nms_rotated(d, s, lab, 0.5)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("S2A_NMS_SORTB", mode)
+        got = S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.5).cpu().numpy()
+        assert np.array_equal(got, want), mode
+    monkeypatch.delenv("S2A_NMS_SORTB")
+    # 12 000 distinct labels on 24 000 rows: the 16 384-slot table takes them (load 0.73) or reports itself full; either
+    # way the keep list is the oracle's
+    n = 24000
+    d = rand_rboxes(rng, n, span=300)
+    s = distinct_scores(rng, n)
+    lab = (rng.integers(0, 12000, n)).astype(np.float32) * 0.5
+    got = S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.3).cpu().numpy()
+    assert np.array_equal(got, oracle.ml_nms_rotated(d, s, lab, 0.3))
+    # and one label for everything (plain nms_rotated): a single segment of 30 000 rows
+    n = 30000
+    d = rand_rboxes(rng, n, span=2000)
+    s = distinct_scores(rng, n)
+    from s2anet_amd.rotated import nms_rotated_raw
+    assert np.array_equal(nms_rotated_raw(cu(d), cu(s), 0.5).cpu().numpy(), oracle.nms_rotated(d, s, 0.5, cull=True))
+
+
 def test_nms_float64_dispatch_matches_reference_double_arithmetic(rng):
     """float64 boxes take the double instantiation (the reference dispatches on dets' dtype, nms_rotated_cuda.cu:95-100):
     on the fixture built so that 136 keep decisions differ between float32 and float64 arithmetic, the GPU keep lists
