@@ -21,4 +21,5 @@ for f in ('bench_s1','bench_s1_graph'):
 echo "== clock probe + AlignConv forms"; timeout -k 10 300 python scripts/pyr_power_probe.py > $O/pyr_power_probe.jsonl 2>/dev/null; cat $O/pyr_power_probe.jsonl
 echo "== half-coordinate mode, end to end"; timeout -k 10 300 python scripts/half_mode_effect.py > $O/half_mode_effect.log 2>&1; tail -1 $O/half_mode_effect.log | cut -c1-300
 echo "== two ranks on one card (gloo rehearsal)"; S2A_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-ops --streams 1 2>/dev/null | grep '^{' > $O/bench_2rank_gloo.json; head -c 300 $O/bench_2rank_gloo.json; echo
+echo "== nms timeline"; bash scripts/nms_timeline.sh > $O/nms_timeline.txt 2>&1; grep -v rocprim $O/nms_timeline.txt | head -12 | cut -c1-110
 echo "== phase stamps (diagnostic builds, restored afterwards)"; bash scripts/stamp_conv_run.sh > $O/conv_stamps.txt 2>&1; bash scripts/stamp_run.sh > $O/alignconv_stamps.txt 2>&1; bash scripts/stamp_sym_run.sh > $O/alignconv_sym_stamps.txt 2>&1; grep -v amdgpu.ids $O/alignconv_sym_stamps.txt | cut -c1-260

@@ -69,4 +69,6 @@ for src, dst in (("half_mode_effect.json", "_half_mode_effect.json"), ("half_coo
                  ("half_path_deviation.json", "_half_path_deviation.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, RN + dst))
+if os.path.exists(os.path.join(F, "nms_timeline.txt")):
+    shutil.copy(os.path.join(F, "nms_timeline.txt"), os.path.join(P, RN + "_nms_200k_timeline.txt"))
 print("published for", head)

@@ -254,3 +254,35 @@ def test_nms_f64_matches_reference_cpu_double_dispatch():
         ll = rng.integers(0, 4, 500).astype(np.float64)
         want = ref_ml(torch.from_numpy(dd), torch.from_numpy(ss), torch.from_numpy(ll), 0.3).numpy()
         assert np.array_equal(oracle.nms_rotated_f64(dd, ss, 0.3, labels=ll, rule=oracle.RULE_GE, sort_mode=oracle.SORT_CPU), want)
+
+
+def test_deform_conv_restatement_vs_torch_grid_sample(rng):
+    """a SECOND independent formulation of the deformable convolution: torch's own bilinear sampler,
+    F.grid_sample(align_corners=True, padding_mode='zeros'), fed with the sampling positions p + tap + offset, then an
+    einsum with the filter.  Zero padding of grid_sample == the reference's dropped corners, and its (-1, H) validity band
+    == deform_conv_cuda_kernel.cu:228 (a corner at -1 or H contributes zero either way).  Neither this nor the 4-corner
+    gather of tests/golden/make_golden.py is the reference -- the op stays "parity unpinned" -- but the oracle now agrees
+    with two formulations that share no code, on offsets that leave the image, sit on the border band and are wild."""
+    import torch
+    import torch.nn.functional as F
+    B, C, H, W, O = 2, 6, 11, 13, 5
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((O, C, 3, 3)) * 0.2).astype(np.float32)
+    off = (rng.standard_normal((B, 18, H, W)) * 2.5).astype(np.float32)
+    off[0, :, 0, :] = -1.4                                   # leaves the image at the top
+    off[1, :, :, -1] = 0.9999                                # the (W-1, W) band on the right
+    off[0, :, 5, 5] = 40.0
+    xt, offt = torch.from_numpy(x).double(), torch.from_numpy(off).double()
+    ys = torch.arange(H, dtype=torch.float64).view(1, H, 1)
+    xs = torch.arange(W, dtype=torch.float64).view(1, 1, W)
+    cols = []
+    for t in range(9):
+        ky, kx = t // 3, t % 3
+        py = ys - 1 + ky + offt[:, 2 * t]                    # [B,H,W] sampling rows / columns in pixels
+        px = xs - 1 + kx + offt[:, 2 * t + 1]
+        grid = torch.stack([2 * px / (W - 1) - 1, 2 * py / (H - 1) - 1], -1)      # align_corners=True normalisation
+        cols.append(F.grid_sample(xt, grid, mode="bilinear", padding_mode="zeros", align_corners=True))
+    col = torch.stack(cols, 2)                               # [B,C,9,H,W]
+    want = torch.einsum("ock,bckhw->bohw", torch.from_numpy(w).double().view(O, C, 9), col).float().numpy()
+    got = oracle.deform_conv_forward(x, off, w)
+    assert np.abs(got - want).max() < 2e-5, float(np.abs(got - want).max())
