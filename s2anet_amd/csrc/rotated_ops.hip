@@ -688,21 +688,42 @@ __global__ __launch_bounds__(256) void k_spb_hist(const unsigned long long* __re
                                                   const unsigned long long* __restrict__ htab,
                                                   uint32_t* __restrict__ ctr, uint32_t* __restrict__ hist,
                                                   uint32_t* __restrict__ bucket, uint32_t* __restrict__ rank,
-                                                  NmsCounters* __restrict__ C) {
+                                                  NmsCounters* __restrict__ C, uint32_t ignore_key, int use_ignore) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  const uint32_t m = ctr[0];
-  const int cb = spb_cell_bits(m, n);
-  const unsigned long long k = keyB[p];
-  uint32_t id = spb_lookup(htab, (uint32_t)(k >> 20));
-  const uint32_t cell = ((uint32_t)k & 0xfffffu) >> (20 - cb);
-  if (id == 0xffffffffu || id >= kSpbPending || ctr[1] != 0u || ((unsigned long long)id << cb) + cell >= spb_buckets(n)) {
-    id = 0;                                      // cannot be bucketed: the direct fallback settles the call
-    if ((C->status & 2u) == 0u) atomicOr(&C->status, 2u);
+  const bool valid = p < n;
+  uint32_t b = 0xffffffffu;
+  if (valid) {
+    const uint32_t m = ctr[0];
+    const int cb = spb_cell_bits(m, n);
+    const unsigned long long k = keyB[p];
+    const uint32_t sk = (uint32_t)(k >> 20);
+    uint32_t id = spb_lookup(htab, sk);
+    uint32_t cell = ((uint32_t)k & 0xfffffu) >> (20 - cb);
+    // padding rows of the batched detector (segment -1): never compared, never kept -- their place inside their segment is
+    // irrelevant, and their coordinates are whatever the caller left there (typically all equal): spread them over the
+    // segment's cells by row number, or 600 k of them queue for ONE counter (6.7 ms of same-address atomics, measured)
+    if (use_ignore && sk == ignore_key) cell = (((uint32_t)p * 0x9e3779b1u) >> 12) & ((1u << cb) - 1u);
+    if (id == 0xffffffffu || id >= kSpbPending || ctr[1] != 0u || ((unsigned long long)id << cb) + cell >= spb_buckets(n)) {
+      id = 0;                                    // cannot be bucketed: the direct fallback settles the call
+      if ((C->status & 2u) == 0u) atomicOr(&C->status, 2u);
+    }
+    b = (id << cb) | cell;
+    bucket[p] = b;
   }
-  const uint32_t b = (id << cb) | cell;
-  bucket[p] = b;
-  rank[p] = atomicAdd(&hist[b], 1u);
+  // rank inside the bucket by the returning atomic; the lanes that share the FIRST lane's bucket go together (one atomic for
+  // the group: rows with identical centres -- a degenerate input -- would otherwise serialise on one counter)
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+  const unsigned long long same = __ballot(valid && b == b0);
+  const int lane = threadIdx.x & 63;
+  if (valid && b == b0) {
+    const int leader = __ffsll((long long)same) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&hist[b], (uint32_t)__popcll(same));
+    base = (uint32_t)__shfl((int)base, leader);
+    rank[p] = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+  } else if (valid) {
+    rank[p] = atomicAdd(&hist[b], 1u);
+  }
 }
 // pass 3: exclusive scan of the histogram in two levels -- a wave per group of 64 buckets (in place, group total aside),
 // then one workgroup over the <= 1 024 group totals.  (One workgroup over 61 k buckets took 75 us, uncoalesced; the scan as
@@ -2250,7 +2271,7 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   if (spatial) {
     k_nms_spkeys<<<g, 256, 0, st>>>(dets, B.keyA, B.bbox_part, (int)gp, n, B.keyB, own_sort ? B.htab : nullptr, B.spb_ctr);
     if (own_sort) {
-      k_spb_hist<<<g, 256, 0, st>>>(B.keyB, n, B.htab, B.spb_ctr, B.hist, B.bucket, B.rank, B.C);
+      k_spb_hist<<<g, 256, 0, st>>>(B.keyB, n, B.htab, B.spb_ctr, B.hist, B.bucket, B.rank, B.C, ignore_key, use_ignore);
       k_spb_scan1<<<kSpbGroups / 4, 256, 0, st>>>(B.hist, B.hist + kSpbHist + 64, n);
       k_spb_scan2<<<1, 1024, 0, st>>>(B.hist + kSpbHist + 64, n);
       k_spb_scatter<<<g, 256, 0, st>>>(B.keyB, n, B.hist, B.hist + kSpbHist + 64, B.bucket, B.rank, B.keyB_s, B.perm_sp);

@@ -476,6 +476,48 @@ def test_batched_multiclass_nms_equals_per_image(rng):
             assert (labels[b, kb:] == -1).all()
 
 
+def test_batched_nms_uncapped_call_at_benchmark_shape_takes_the_cell_ordered_path(rng):
+    """max_candidates=None at 8 x 5344 x 15 sizes the candidate buffer at 641 280 rows, ~500 k of them padding (segment
+    -1): the call goes down the cell-ordered path. Results equal the oracle per image, and the padding rows do not queue
+    for one histogram counter (that cost 6.7 ms once; the bound here is generous, a regression is 10x over it)"""
+    import s2anet_amd as S, time
+    B, n, C = 8, 5344, 15
+    boxes = np.stack([np.concatenate([rng.uniform(0, 1024, (n, 2)), rng.uniform(8, 80, (n, 2)),
+                                      rng.uniform(-0.7, 2.3, (n, 1))], 1) for _ in range(B)]).astype(np.float32)
+    scores = (rng.random((B, n, C)) ** 12).astype(np.float32)
+    bb, sc = cu(boxes), cu(scores)
+    for _ in range(3):
+        out = S.batched_multiclass_nms_rotated(bb, sc, 0.05, 0.5, 2000)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        out = S.batched_multiclass_nms_rotated(bb, sc, 0.05, 0.5, 2000)
+    torch.cuda.synchronize()
+    assert (time.perf_counter() - t) / 5 < 3e-3
+    dets, labels, counts = out
+    for b in (0, 3, 7):
+        rd, rl = oracle.multiclass_nms_rotated(boxes[b], scores[b], 0.05, 0.5, 2000)
+        kb = int(counts[b])
+        assert kb == len(rd) and np.array_equal(dets[b, :kb].cpu().numpy(), rd)
+        assert np.array_equal(labels[b, :kb].cpu().numpy().astype(np.float32), rl)
+
+
+def test_nms_many_rows_at_one_centre_share_a_histogram_counter(rng):
+    """degenerate input for the counting sort: 40 000 boxes of one label at the same centre (one cell). The rows of a
+    wave that share a cell take their ranks from one atomic; the result is the oracle's"""
+    import s2anet_amd as S
+    n = 40000
+    d = np.zeros((n, 5), np.float32)
+    d[:, 0:2] = 300.0
+    d[:, 2] = rng.uniform(10, 40, n); d[:, 3] = rng.uniform(10, 40, n); d[:, 4] = rng.uniform(-0.7, 0.7, n)
+    d[: n // 2, 0] += rng.uniform(0, 2000, n // 2).astype(np.float32)    # half of them spread out
+    s = distinct_scores(rng, n)
+    lab = np.zeros(n, np.float32)
+    keep = S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.5).cpu().numpy()
+    ref = oracle.ml_nms_rotated(d, s, lab, 0.5)
+    assert np.array_equal(keep, ref)
+
+
 def test_batched_nms_writes_the_wire_buffer_and_counts_dropped_candidates(rng):
     """the NMS finish kernel writes the detection rows once: dets / labels / counts and the all-gather wire buffer are
     the same memory or exact copies, padding rows are 0,...,0,-1, the candidate cap is accounted without a host sync"""
