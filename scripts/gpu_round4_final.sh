@@ -8,6 +8,7 @@ timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; 
 if [ $rc -ne 0 ]; then exit 1; fi
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log | cut -c1-200
 echo "== bench pmc"; bash scripts/pmc_bench.sh > $O/pmc_bench.log 2>&1; echo "pmc bench rc=$?"; cat gpurun_out/pmc_bench/traffic.json | head -c 900; echo
+python -c "import json; json.dump(json.load(open('gpurun_out/pmc_bench/traffic.json')), open('profiles/r04_traffic.json', 'w'), indent=1)"   # the bench below reads this copy (publish_profiles.py writes the same file at home)
 echo "== steady state"; bash scripts/prof_bench.sh r4final --no-ops > $O/prof_bench3.log 2>&1; head -3 $O/prof_bench3.log | cut -c1-160
 bash scripts/prof_bench.sh r4final_s1 --streams 1 --no-ops > $O/prof_bench1.log 2>&1; head -3 $O/prof_bench1.log | cut -c1-160
 echo "== graph replay kernels"; bash scripts/graph_trace.sh > $O/graph_replay_kernels.txt 2>&1; echo "graph trace rc=$?"; tail -1 $O/graph_replay_kernels.txt
