@@ -59,6 +59,11 @@ namespace {
 #ifndef S2A_DCN_M16
 #define S2A_DCN_M16 1
 #endif
+// S2A_DCN_DIRECT_ST = 1: k_dcn_patch stores its output tile straight from the accumulators (filter rows permuted by
+// k_pack_weight_frag16) instead of staging it through LDS (-1 % same-box, bit-identical) -- A/B builds only
+#ifndef S2A_DCN_DIRECT_ST
+#define S2A_DCN_DIRECT_ST 1
+#endif
 // measurement builds (-DS2A_MEASURE) only: S2A_DCN_DROP=x|w gives the wave-specialised kernel zero-record descriptors (the
 // loads are dropped, the instruction stream stays; OUTPUTS ARE WRONG) -- never compiled into a shipped library
 #ifdef S2A_MEASURE
@@ -779,6 +784,29 @@ __global__ void k_pack_weight_frag(const _Float16* __restrict__ w, int O, int C,
   wp[e] = w[((int64_t)och * C + k) * taps + t];
 }
 
+// the same filter for the 16x16x32 matrix waves of k_dcn_patch: [stage][och group of 64][fragment f = 2a + ks (8)][lane 64][8 halfs],
+// lane = (i = lane & 15, kg = lane >> 4): element j = W[g*64 + och_l(a, i)][cc*64 + 32 (kg & 1) + 16 ks + 8 (kg >> 1) + j][t] with
+// och_l(a, i) = 32 (a >> 1) + 8 (i >> 2) + 4 (a & 1) + (i & 3).  One contiguous 1 KB load per fragment, and the D rows of a lane
+// (4 kg + e of fragments a = 0..3) are out channels 8 kg .. 8 kg + 7 and 32 + 8 kg .. 32 + 8 kg + 7 of its pixel: the epilogue
+// stores two 16-byte vectors per pixel straight from the accumulators (no LDS staging, no barrier)
+__device__ __forceinline__ int frag16_och(int a, int i) { return 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3); }
+__global__ void k_pack_weight_frag16(const _Float16* __restrict__ w, int O, int C, _Float16* __restrict__ wp) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)O * C * 9;
+  if (e >= total) return;
+  const int G = O / 64;
+  int j = (int)(e & 7);
+  int lane = (int)((e >> 3) & 63);
+  int f = (int)((e >> 9) & 7);
+  int64_t r = e >> 12;
+  int g = (int)(r % G);
+  int st = (int)(r / G);
+  int t = st % 9, cc = st / 9;
+  int och = g * 64 + frag16_och(f >> 1, lane & 15);
+  int k = cc * 64 + 32 * ((lane >> 4) & 1) + 16 * (f & 1) + 8 * (lane >> 5) + j;   // the k slots of the column fragments (bfrag)
+  wp[e] = w[((int64_t)och * C + k) * 9 + t];
+}
+
 constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs + 16 B pad
 
 // TH = rows of the position tile: 8 (128 positions), or 4 (64 positions: half tiles for launches that fill the chip badly,
@@ -874,14 +902,21 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   // f = (16-channel tile f >> 1, k-step f & 1) comes out of the same packed filter; 16-position tile pt = tile row pt, its
   // pixel for lane i = pix16 (conflict-free ds_read_b128 on the 144-byte rows of the column tile)
   constexpr bool D16 = S2A_DCN_M16 != 0;
+  constexpr bool DST = D16 && S2A_DCN_DIRECT_ST != 0;      // direct-store epilogue + k_pack_weight_frag16 filter
   const int kg16 = lane >> 4, i16 = lane & 15;
   const int pix16 = (i16 >= 4 && i16 < 12) ? (((i16 - 4) >> 1) * 4 + (i16 & 1))
                                            : (((i16 & 3) >> 1) * 4 + 2 + (i16 & 1) + (i16 >= 12 ? 8 : 0));
   auto load_w = [&](int s, V (&wv)[2][4]) {
     if constexpr (D16) {
-      const V* p = reinterpret_cast<const V*>(wfrag) + ((int64_t)s * G + g) * 8 * 64 + (kg16 & 1) * 128 + (kg16 >> 1) * 32 + i16;
+      if constexpr (DST) {
+        const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;      // k_pack_weight_frag16 order: 1 KB per fragment
 #pragma unroll
-      for (int f = 0; f < 8; f++) wv[f >> 2][f & 3] = p[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
+        for (int f = 0; f < 8; f++) wv[f >> 2][f & 3] = p[f * 64];
+      } else {
+        const V* p = reinterpret_cast<const V*>(wfrag) + ((int64_t)s * G + g) * 8 * 64 + (kg16 & 1) * 128 + (kg16 >> 1) * 32 + i16;
+#pragma unroll
+        for (int f = 0; f < 8; f++) wv[f >> 2][f & 3] = p[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
+      }
       return;
     }
     const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
@@ -892,19 +927,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   };
   if (wave < 4) load_w(0, wA);
 
-  // ---- per-position anchor context (cos/sin once per position, not once per tap)
-  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);   // B tiles are not in use yet
-  if (SRC == 1 && tid < NPOS) {
-    int y = ty0 + (tid >> 4), xq = tx0 + (tid & 15);
-    AnchorCtx c = {0, 0, 0, 0, 1, 0};
-    if (y < H && xq < W) c = anchor_ctx(src + (bimg * HW + (int64_t)y * W + xq) * 5, stride);
-    s_ctx[tid] = c;
-  }
-  if (SRC == 1) __syncthreads();
-
-  // ---- sampling table
-  for (int e = tid; e < NPOS * 9; e += 512) {
-    int pl = e / 9, t = e % 9;
+  // ---- one table entry: tap t of tile position pl, anchor context c (SRC 1) or the offset maps (SRC 0)
+  auto table_entry = [&](int pl, int t, const AnchorCtx& c) {
     int y = ty0 + (pl >> 4), xq = tx0 + (pl & 15);
     PTap tp;
     tp.y = (short)oy;
@@ -921,7 +945,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         off_y = ob[(int64_t)(2 * t) * HW];
         off_x = ob[(int64_t)(2 * t + 1) * HW];
       } else {
-        anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
+        anchor_offset(c, ky, kx, (float)y, (float)xq, off_y, off_x);
       }
       // half_coords: the reference's scalar_t = Half instantiation (deform_conv.py:45-46 casts the offsets to half;
       // deform_conv_cuda_kernel.cu:221-228 h_im / w_im, :97-109 lh / lw / hh / hw and the four weights are Half
@@ -950,8 +974,26 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         tp.flags = (in ? 1u : 0u) | ((unsigned)((py * kPW + px) * 128) << 1);
       }
     }
-    s_tab[e] = tp;
+    s_tab[pl * 9 + t] = tp;
+  };
+  // ---- per-position anchor context (cos/sin once per position, not once per tap)
+  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);   // B tiles are not in use yet
+  if (SRC == 1 && tid < NPOS) {
+    int y = ty0 + (tid >> 4), xq = tx0 + (tid & 15);
+    AnchorCtx c = {0, 0, 0, 0, 1, 0};
+    if (y < H && xq < W) c = anchor_ctx(src + (bimg * HW + (int64_t)y * W + xq) * 5, stride);
+    s_ctx[tid] = c;
   }
+  if (SRC == 1) __syncthreads();
+  S2A_STAMP_AT(6);   // (matrix wave: anchor contexts ready; the loader wave overwrites its slots 6 / 7 later)
+
+  // ---- sampling table
+  for (int e = tid; e < NPOS * 9; e += 512) {
+    AnchorCtx c = {0, 0, 0, 0, 1, 0};
+    if (SRC == 1) c = s_ctx[e / 9];
+    table_entry(e / 9, e % 9, c);
+  }
+  S2A_STAMP_AT(7);   // (matrix wave: table written)
   if (wave >= 4) {  // first patch -> LDS
 #pragma unroll
     for (int i = 0; i < NPV; i++) *reinterpret_cast<V*>(s_patch + (L + 256 * i) * 16) = pv[i];
@@ -1190,6 +1232,29 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     // Stage the 128 x 256 tile through LDS (the patch buffers are free now) and store whole
     // 512-byte position rows, 16 B per lane, instead of 2-byte scattered stores.
     char* s_out = s_patch;
+    if constexpr (DST) {
+      // straight from the accumulators (filter rows permuted by k_pack_weight_frag16): lane (pixel pix16 of 16-position tile b,
+      // kg16) holds out channels 8 kg16 .. +7 (fragments 0, 1) and 32 + 8 kg16 .. +7 (fragments 2, 3) of its wave's 64
+      if (wave_active) {
+#pragma unroll
+        for (int b = 0; b < 2 * NT; b++) {
+          const int64_t gp = out_pos(16 * b + pix16);
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++) {
+            V v8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              float v = acc16[D16 ? 2 * hf + (e >> 2) : 0][D16 ? b : 0][e & 3];
+              if (relu & 1) v = fmaxf(v, 0.f);
+              v8[e] = (_Float16)v;
+            }
+            if (gp >= 0) *reinterpret_cast<V*>(out + gp * O + o0 + wave * 64 + 32 * hf + 8 * kg16) = v8;
+          }
+        }
+      }
+      S2A_STAMP_AT(5);
+      return;
+    }
     if (D16 && wave_active) {
       using h4 = __attribute__((ext_vector_type(4))) _Float16;
 #pragma unroll
@@ -1245,7 +1310,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
           for (int e = 0; e < 4; e++) {
             float v = acc16[a][b][e];
             if (relu & 1) v = fmaxf(v, 0.f);
-            const int och = o0 + wave * 64 + 16 * a + 4 * kg16 + e;
+            const int och = o0 + wave * 64 + (DST ? 32 * (a >> 1) + 8 * kg16 + 4 * (a & 1) : 16 * a + 4 * kg16) + e;
             const int64_t gp = out_pos(16 * b + pix16);
             if (gp >= 0) {
               int64_t bi = gp / HW, p = gp % HW;
@@ -2690,8 +2755,10 @@ int run_fast(const void* input, const float* src, bool from_anchors, const void*
   const int64_t wtot = (int64_t)O * C * 9;
   if (!weight_packed) {
     k_pack_weight<T><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const T*)weight, O, C, KC, wp);
-    if constexpr (sizeof(T) == 2)
-      k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, O, C, wp + wel);
+    if constexpr (sizeof(T) == 2) {
+      if (S2A_DCN_M16 != 0 && S2A_DCN_DIRECT_ST != 0) k_pack_weight_frag16<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, O, C, wp + wel);
+      else k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, O, C, wp + wel);
+    }
   }
   const T* wfrag = has_frag ? wp + wel : nullptr;
   const T* x_nhwc = (const T*)input;
@@ -2839,7 +2906,8 @@ extern "C" int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int
   } else {
     S2A_CHECK_ARG(out_channels % 64 == 0, "dcn_pack_weight: out_channels must be a multiple of 64");
     k_pack_weight<_Float16><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, kc, (_Float16*)packed);
-    k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + wtot);
+    if (S2A_DCN_M16 != 0 && S2A_DCN_DIRECT_ST != 0) k_pack_weight_frag16<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + wtot);
+    else k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + wtot);
     k_pack_weight_sym<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + 2 * wtot);
   }
   S2A_LAUNCH_CHECK();

@@ -1898,82 +1898,196 @@ __global__ __launch_bounds__(kThreads) void k_nms_alive_scatter(const NmsCounter
 }
 
 constexpr int kSegRows = 8192, kSegEdges = 4096;     // 8 + 16 KB of states / flags, 2 x 32 KB of edges
+#ifdef S2A_MEASURE
+__device__ unsigned long long g_fin_dbg[16];   // clean-up kernel: max iterations, max edges, sum iterations, segments with work, max rows
+#endif
 
-__global__ __launch_bounds__(kThreads) void k_nms_finish_segments(const NmsCounters* __restrict__ C,
-                                                                  const uint32_t* __restrict__ seg_start,
-                                                                  const uint32_t* __restrict__ num_seg,
-                                                                  const uint32_t* __restrict__ seg_off,
-                                                                  uint2* __restrict__ bucketed,
-                                                                  uint8_t* __restrict__ state,
-                                                                  uint8_t* __restrict__ blocked, int64_t n,
-                                                                  int force_global) {
+// the rounds of one segment.  LDS: states / flags / both edge lists are the workgroup's shared arrays (the pointers arrive
+// here as plain pointers, but after inlining their origin is unambiguous and they compile to ds_* instructions -- picked by a
+// run-time `lds ? shared : global` they were FLAT accesses, three dependent ones per edge at ~3x the latency: 1.4 us a round);
+// global: the same loop on the call's arrays, one edge list (every round reads all edges again).
+#ifndef S2A_FIN_THREADS
+#define S2A_FIN_THREADS 1024
+#endif
+constexpr int kFinThreads = S2A_FIN_THREADS;
+template <bool LDS>
+__device__ __forceinline__ unsigned finish_rounds(uint8_t* __restrict__ St, uint8_t* __restrict__ Fl, int64_t fstride,
+                                                  uint2* __restrict__ Ed, int estride, uint32_t cnt0,
+                                                  unsigned* __restrict__ s_n) {
+  uint32_t cnt = cnt0;
+  int cur = 0, f = 0;
+  unsigned iters = 0;
+  bool done = false;
+#ifdef S2A_MEASURE
+  unsigned long long t0 = 0, tp1 = 0, tb1 = 0, tp2 = 0, tb2 = 0;
+#define FIN_TIC() t0 = __builtin_amdgcn_s_memtime()
+#define FIN_TOC(acc) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } while (0)
+#else
+#define FIN_TIC() do {} while (0)
+#define FIN_TOC(acc) do {} while (0)
+#endif
+  // ---- (A) list rounds: two lists in turn, the surviving edges compacted every round (that is what retires waves early)
+  for (;;) {
+    iters++;
+    FIN_TIC();
+    const uint2* Ein = Ed + (LDS ? cur * estride : 0);
+    uint8_t* Ff = Fl + f * fstride;
+    uint8_t* Fo = Fl + (f ^ 1) * fstride;
+    for (uint32_t e = threadIdx.x; e < cnt; e += kFinThreads) {        // pass 1
+      const uint2 ij = Ein[e];
+      const uint32_t sj = St[ij.y], si = St[ij.x];             // (both requested at once: one LDS round trip, not two)
+      if (sj == kOpen) {
+        if (si == kKept) St[ij.y] = (uint8_t)kRemoved;
+        else if (si == kOpen) Ff[ij.y] = 1;
+      }
+    }
+    if (threadIdx.x == 0) s_n[(iters + 1) % 3] = 0;             // the counter of the NEXT round: last read at the end of round
+                                                                // iters - 2, two barriers ago (three counters in rotation)
+    FIN_TOC(tp1);
+    __threadfence_block();
+    __syncthreads();
+    FIN_TOC(tb1);
+    uint2* Eout = LDS ? Ed + (cur ^ 1) * estride : nullptr;
+    unsigned* ctr = s_n + iters % 3;
+    for (uint32_t e = threadIdx.x; e < cnt; e += kFinThreads) {        // pass 2
+      const uint2 ij = Ein[e];
+      const uint32_t sj = St[ij.y], fj = Ff[ij.y];
+      if (sj == kOpen) {
+        if (fj == 0) {
+          St[ij.y] = (uint8_t)kKept;
+        } else {
+          Fo[ij.y] = 0;
+          // (one LDS atomic per surviving edge: a ballot + one atomic per wave measured SLOWER, 57 against 46 us in the detector)
+          const unsigned pos = atomicAdd(ctr, 1u);
+          if (LDS) Eout[pos] = ij;
+        }
+      }
+    }
+    FIN_TOC(tp2);
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t live = *ctr;
+    FIN_TOC(tb2);
+    if (live == 0) { done = true; break; }
+    if (LDS) { cnt = live; cur ^= 1; }                        // (global path: no second list, all edges again)
+    f ^= 1;
+#ifdef S2A_MEASURE
+    if (threadIdx.x == 0 && cnt0 > 1500) atomicAdd(&g_fin_dbg[11], 1ull);
+#endif
+    if (LDS && cnt <= (uint32_t)kFinThreads) break;           // (uniform) one edge per thread from here on
+  }
+  // ---- (B) the list fits one edge per thread (the list shrinks ~15 % a round): every thread keeps ITS edge in registers until
+  // the edge's target is decided -- no list, no compaction, one LDS round trip per pass; waves whose edges are all dead only
+  // take the barriers.  (The same form with four edges per thread from the start measured SLOWER than the lists: 88 us --
+  // sixteen waves issuing the full pass every round.)
+  if (LDS && !done) {
+    bool lv = threadIdx.x < cnt;
+    uint2 ij = make_uint2(0, 0);
+    if (lv) ij = Ed[cur * estride + threadIdx.x];
+    for (;;) {
+      iters++;
+      FIN_TIC();
+      uint8_t* Ff = Fl + f * fstride;
+      uint8_t* Fo = Fl + (f ^ 1) * fstride;
+      if (lv) {                                                         // pass 1
+        const uint32_t sj = St[ij.y], si = St[ij.x];
+        if (sj == kOpen) {
+          if (si == kKept) St[ij.y] = (uint8_t)kRemoved;
+          else if (si == kOpen) Ff[ij.y] = 1;
+        } else {
+          lv = false;
+        }
+      }
+      if (threadIdx.x == 0) s_n[(iters + 1) % 3] = 0;
+      FIN_TOC(tp1);
+      __threadfence_block();
+      __syncthreads();
+      FIN_TOC(tb1);
+      bool stays = false;
+      if (lv) {                                                         // pass 2
+        const uint32_t sj = St[ij.y], fj = Ff[ij.y];
+        if (sj == kOpen && fj != 0) {
+          Fo[ij.y] = 0;
+          stays = true;
+        } else {
+          if (sj == kOpen) St[ij.y] = (uint8_t)kKept;
+          lv = false;
+        }
+      }
+      if (stays) atomicAdd(&s_n[iters % 3], 1u);
+      FIN_TOC(tp2);
+      __threadfence_block();
+      __syncthreads();
+      const uint32_t live = s_n[iters % 3];
+      FIN_TOC(tb2);
+#ifdef S2A_MEASURE
+      if (threadIdx.x == 0 && cnt0 > 1500) atomicAdd(&g_fin_dbg[live > 256 ? 12 : live > 64 ? 13 : live > 16 ? 14 : 15], 1ull);
+#endif
+      if (live == 0) break;
+      f ^= 1;
+    }
+  }
+  // (a third phase -- the last <= 64 / 256 / 512 edges handed to wave 0 alone, in registers, without workgroup barriers --
+  // measured SLOWER: 44 / 68 / 147 us against 41: a lone wave pays every instruction's latency itself, and the branchy
+  // predicated passes are a few hundred instructions)
+#ifdef S2A_MEASURE
+  if (threadIdx.x == 0 && LDS && cnt0 > 1500) {           // the big segments: cycles of wave 0 per phase, summed (phases A, B)
+    atomicAdd(&g_fin_dbg[6], (unsigned long long)iters);
+    atomicAdd(&g_fin_dbg[7], tp1); atomicAdd(&g_fin_dbg[8], tb1); atomicAdd(&g_fin_dbg[9], tp2); atomicAdd(&g_fin_dbg[10], tb2);
+  }
+#endif
+  return iters;
+}
+
+__global__ __launch_bounds__(kFinThreads) void k_nms_finish_segments(const NmsCounters* __restrict__ C,
+                                                                     const uint32_t* __restrict__ seg_start,
+                                                                     const uint32_t* __restrict__ num_seg,
+                                                                     const uint32_t* __restrict__ seg_off,
+                                                                     uint2* __restrict__ bucketed,
+                                                                     uint8_t* __restrict__ state,
+                                                                     uint8_t* __restrict__ blocked, int64_t n,
+                                                                     int force_global) {
   if (C->alive[kNmsRounds] == 0) return;
   __shared__ uint8_t s_state[kSegRows];
-  __shared__ uint8_t s_flag[2][kSegRows];
-  __shared__ uint2 s_edges[2][kSegEdges];
-  __shared__ unsigned s_n;
+  __shared__ uint8_t s_flag[2 * kSegRows];
+  __shared__ uint2 s_edges[2 * kSegEdges];
+  __shared__ unsigned s_n[3];
   const uint32_t S = *num_seg;
   for (uint32_t s = blockIdx.x; s < S; s += gridDim.x) {
     const uint32_t e0 = seg_off[s], cnt0 = seg_off[s + 1] - e0;
     if (cnt0 == 0) continue;                                  // (uniform)
     const uint32_t st = seg_start[s], ns = seg_start[s + 1] - st;
     const bool lds = !force_global && ns <= (uint32_t)kSegRows && cnt0 <= (uint32_t)kSegEdges;
-    uint8_t* St = lds ? s_state : state + st;                 // generic pointers: LDS or global
-    uint8_t* F[2] = {lds ? s_flag[0] : blocked + st, lds ? s_flag[1] : blocked + n + st};
-    uint2* E[2] = {lds ? s_edges[0] : bucketed + e0, lds ? s_edges[1] : nullptr};
     __syncthreads();
+    if (threadIdx.x == 0) s_n[1] = 0;                         // round r counts in s_n[r % 3]
+    unsigned iters;
     if (lds) {
-      for (uint32_t i = threadIdx.x; i < ns; i += kThreads) { s_state[i] = state[st + i]; s_flag[0][i] = 0; s_flag[1][i] = 0; }
-      for (uint32_t e = threadIdx.x; e < cnt0; e += kThreads) {
+      for (uint32_t i = threadIdx.x; i < ns; i += kFinThreads) { s_state[i] = state[st + i]; s_flag[i] = 0; s_flag[kSegRows + i] = 0; }
+      for (uint32_t e = threadIdx.x; e < cnt0; e += kFinThreads) {
         const uint2 ij = bucketed[e0 + e];
-        s_edges[0][e] = make_uint2(ij.x - st, ij.y - st);
+        s_edges[e] = make_uint2(ij.x - st, ij.y - st);
       }
+      __threadfence_block();
+      __syncthreads();
+      iters = finish_rounds<true>(s_state, s_flag, kSegRows, s_edges, kSegEdges, cnt0, s_n);
+      for (uint32_t i = threadIdx.x; i < ns; i += kFinThreads) state[st + i] = s_state[i];
     } else {
-      for (uint32_t e = threadIdx.x; e < cnt0; e += kThreads) {      // local indices in place
+      for (uint32_t e = threadIdx.x; e < cnt0; e += kFinThreads) {      // local indices in place
         const uint2 ij = bucketed[e0 + e];
         bucketed[e0 + e] = make_uint2(ij.x - st, ij.y - st);
       }
-    }
-    __threadfence_block();
-    __syncthreads();
-    uint32_t cnt = cnt0;
-    int cur = 0, f = 0;
-    for (;;) {
-      const uint2* Ein = E[cur];
-      for (uint32_t e = threadIdx.x; e < cnt; e += kThreads) {        // pass 1
-        const uint2 ij = Ein[e];
-        if (St[ij.y] == kOpen) {
-          const uint32_t si = St[ij.x];
-          if (si == kKept) St[ij.y] = (uint8_t)kRemoved;
-          else if (si == kOpen) F[f][ij.y] = 1;
-        }
-      }
-      if (threadIdx.x == 0) s_n = 0;
       __threadfence_block();
       __syncthreads();
-      uint2* Eout = E[cur ^ 1];
-      for (uint32_t e = threadIdx.x; e < cnt; e += kThreads) {        // pass 2
-        const uint2 ij = Ein[e];
-        if (St[ij.y] == kOpen) {
-          if (F[f][ij.y] == 0) {
-            St[ij.y] = (uint8_t)kKept;
-          } else {
-            F[f ^ 1][ij.y] = 0;
-            const unsigned pos = atomicAdd(&s_n, 1u);
-            if (Eout) Eout[pos] = ij;
-          }
-        }
-      }
-      __threadfence_block();
-      __syncthreads();
-      const uint32_t live = s_n;
-      __syncthreads();
-      if (live == 0) break;
-      if (Eout) { cnt = live; cur ^= 1; }                     // (global path: no second list, all edges again)
-      f ^= 1;
+      iters = finish_rounds<false>(state + st, blocked + st, n, bucketed + e0, 0, cnt0, s_n);
     }
-    if (lds)
-      for (uint32_t i = threadIdx.x; i < ns; i += kThreads) state[st + i] = s_state[i];
+    (void)iters;
+#ifdef S2A_MEASURE
+    if (threadIdx.x == 0) {
+      atomicMax(&g_fin_dbg[0], (unsigned long long)iters); atomicMax(&g_fin_dbg[1], (unsigned long long)cnt0);
+      atomicAdd(&g_fin_dbg[2], (unsigned long long)iters); atomicAdd(&g_fin_dbg[3], 1ull);
+      atomicMax(&g_fin_dbg[4], (unsigned long long)ns); atomicAdd(&g_fin_dbg[5], (unsigned long long)cnt0);
+    }
+#endif
   }
 }
 
@@ -2335,7 +2449,7 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   k_nms_alive_count<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cnt);
   k_nms_alive_scan<<<1, 1024, 0, st>>>(B.C, B.num_seg, B.seg_cnt, B.seg_cur);
   k_nms_alive_scatter<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cur, B.edges);
-  k_nms_finish_segments<<<512, kThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.seg_cnt, B.edges, B.state, B.blocked, n,
+  k_nms_finish_segments<<<512, kFinThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.seg_cnt, B.edges, B.state, B.blocked, n,
                                                   force_global);
   if (ss && spatial) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
   k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, spatial ? B.seg_start_a : B.seg_start, spatial ? B.num_seg_a : B.num_seg,
@@ -2371,6 +2485,17 @@ static int nms_debug_dump(const NmsBuffers& B, int64_t n, hipStream_t st) {
     fprintf(stderr, "[cull] waves %llu tiles %llu  cycles per wave: total %.0f  wait(claim+loads) %.0f  stage1 %.0f  list %.0f  stage2 %.0f\n",
             dbg[6], dbg[5], (double)dbg[0] / dbg[6], (double)dbg[1] / dbg[6], (double)dbg[2] / dbg[6], (double)dbg[3] / dbg[6],
             (double)dbg[4] / dbg[6]);
+  unsigned long long fd[16] = {}, zero16[16] = {};
+  S2A_HIP(hipMemcpyFromSymbol(fd, HIP_SYMBOL(g_fin_dbg), sizeof(fd)));
+  S2A_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fin_dbg), zero16, sizeof(zero16)));
+  if (fd[6])
+    fprintf(stderr, "[finish] segments > 1500 edges: %llu rounds; cycles per round (wave 0): pass 1 %.0f  barrier %.0f  pass 2 %.0f  barrier + counter %.0f\n",
+            fd[6], (double)fd[7] / fd[6], (double)fd[8] / fd[6], (double)fd[9] / fd[6], (double)fd[10] / fd[6]);
+  if (fd[6])
+    fprintf(stderr, "[finish] of those rounds: %llu with lists (> %d edges), then edges left after the round: > 256: %llu, 65..256: %llu, 17..64: %llu, <= 16: %llu\n",
+            fd[11], kFinThreads, fd[12], fd[13], fd[14], fd[15]);
+  fprintf(stderr, "[finish] segments with work %llu: iterations max %llu sum %llu, edges max %llu sum %llu, rows max %llu\n", fd[3], fd[0], fd[2],
+          fd[1], fd[5], fd[4]);
   fprintf(stderr, "[nms] n %lld tiles %llu pairs %llu edges %llu alive_list %llu status %u alive %u %u %u %u\n", (long long)n,
           h.tiles, h.pairs, h.edges, h.alive_list, h.status, h.alive[1], h.alive[2], h.alive[3], h.alive[4]);
   return S2A_OK;

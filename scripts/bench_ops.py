@@ -221,6 +221,8 @@ if __name__ == "__main__":
                                (512, 128, 128, 1), (256, 512, 256, 2), (512, 256, 128, 1), (256, 1024, 64, 1), (1024, 256, 64, 1),
                                (1024, 512, 64, 1), (512, 2048, 32, 1), (2048, 512, 32, 1), (1024, 2048, 64, 2), (2048, 256, 32, 1)):
             res.append(conv3(8, hw, c, o, 1, st))
+    if a.which == "alignconv1":
+        res.append(alignconv(1, torch.float16))
     if a.which == "align8":
         res.append(alignconv(8, torch.float16))
     if a.which == "align8s":

@@ -2,5 +2,5 @@
 cd $GRAFT_REPO_ROOT
 export S2A_ALLOW_MEASURE_BUILD=1   # the objects built below carry measurement switches (s2anet_amd/_lib.py refuses them otherwise)
 rm -f s2anet_amd/csrc/dcn_ops.o; make -C s2anet_amd/csrc -s EXTRA=-DS2A_STAMP=1 2>&1 | grep error
-timeout -k 10 200 python scripts/stamps.py 2>&1 | tail -5
+for a in "8 128" "1 128" "1 64" "1 32"; do timeout -k 10 200 python scripts/stamps.py $a 2>&1 | tail -5; done
 rm -f s2anet_amd/csrc/dcn_ops.o; make -C s2anet_amd/csrc -s
