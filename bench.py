@@ -123,10 +123,21 @@ def calibrate_cls_bias(model, imgs, target_per_chip, logit_std=1.5):
     return got
 
 
+WARM_SECONDS = 0.25
+
+
 def _time_launches(fn, iters=100):
-    """HIP events on the launching stream (torch's current stream) around `iters` launches"""
-    for _ in range(3):
+    """HIP events on the launching stream (torch's current stream) around `iters` launches, after WARM_SECONDS of the same
+    launches back to back: the operands of these measurements are built on the host, the GPU idles meanwhile and comes back
+    at a low clock -- three warm-up launches measured the ramp (P3 x 8 AlignConv: 200-217 us cold, 167-177 us after 0.3 s;
+    in-kernel stamps 1.69 GHz against 2.1-2.3 GHz, scripts/p3_probe.py)"""
+    t_w = time.perf_counter()
+    n_w = 0
+    while n_w < 3 or time.perf_counter() - t_w < WARM_SECONDS:
         fn()
+        n_w += 1
+        if n_w % 8 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -64,6 +64,10 @@ namespace {
 #ifndef S2A_DCN_DIRECT_ST
 #define S2A_DCN_DIRECT_ST 1
 #endif
+// S2A_DCN_MIXED = 1: the pyramid launch may end in half tiles (k_dcn_patch) -- A/B builds only
+#ifndef S2A_DCN_MIXED
+#define S2A_DCN_MIXED 1
+#endif
 // measurement builds (-DS2A_MEASURE) only: S2A_DCN_DROP=x|w gives the wave-specialised kernel zero-record descriptors (the
 // loads are dropped, the instruction stream stays; OUTPUTS ARE WRONG) -- never compiled into a shipped library
 #ifdef S2A_MEASURE
@@ -811,13 +815,16 @@ constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs +
 
 // TH = rows of the position tile: 8 (128 positions), or 4 (64 positions: half tiles for launches that fill the chip badly,
 // e.g. one P3 level of one chip = 128 full tiles on 256 CUs; tile index = tile_base + block / 2, half = block & 1)
+// (MW = 4 matrix waves, one per SIMD, 64 out channels x all positions each.  The form with EIGHT -- two per SIMD, 32 out channels
+// each, twelve waves of <= 168 registers, the later patch chunks in two halves -- passed the same tests and measured 10 % slower,
+// 241.7 against 219.8 us: DESIGN 4)
 template <bool OUT_NHWC, int SRC, int TH = 8>
-__global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict__ x_,
-                                                      const float* __restrict__ src_,
-                                                      const _Float16* __restrict__ wfrag,
-                                                      _Float16* __restrict__ out_, int64_t Ntot_, int C,
-                                                      int H_, int W_, int O, float stride_, int relu,
-                                                      unsigned x_bytes_, LevelTab lt, int tile_base = 0) {
+__device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
+                                               const float* __restrict__ src_,
+                                               const _Float16* __restrict__ wfrag,
+                                               _Float16* __restrict__ out_, int64_t Ntot_, int C,
+                                               int H_, int W_, int O, float stride_, int relu,
+                                               unsigned x_bytes_, const LevelTab& lt, int tile_base, unsigned vb, unsigned nvb, const int tid) {
   using T = _Float16;
   using V = f16x8;
   constexpr int NPOS = TH * 16, NT = NPOS / 32, ITEMS = NPOS / 32;
@@ -825,6 +832,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   constexpr int kPatchBytesT = kPHt * kPW * 128;
   constexpr int NPV = kPHt * kPW * 8 / 256;            // 16-byte patch vectors per loader thread (12 | 9)
   static_assert(TH == 8 || TH == 4, "tile height");
+  constexpr int MW = 4, NTHR = 64 * (MW + 4);          // matrix waves (0 .. MW-1; the loaders are waves MW .. MW+3), threads
+  constexpr int AH = 16 / MW;                          // 16-channel accumulator tiles per matrix wave
   static_assert(kPHt * kPW * 8 % 256 == 0, "patch vectors must divide among the loader threads");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PTap* s_tab = reinterpret_cast<PTap*>(smem);
@@ -833,9 +842,9 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 
   const bool half_coords = (relu & 2) != 0;          // relu: bit 0 = ReLU epilogue, bit 1 = S2A_DCN_HALF_COORDS
   auto rh16 = [](float v) { return (float)(_Float16)v; };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (waves 0-3 = matrix: the older half wins issue
+  const int lane = tid & 63, wave = tid >> 6;                      // (waves 0-3 = matrix: the older half wins issue
                                                                    // arbitration; roles swapped measured 4 % slower)
-  int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  int64_t tile = xcd_remap(vb, nvb);
   const int half = TH == 4 ? (int)(tile & 1) : 0;
   if (TH == 4) tile >>= 1;
   tile += tile_base;
@@ -875,20 +884,25 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
 
   S2A_STAMP_AT(0);
+  S2A_STAMP_VAL(6, __builtin_amdgcn_s_memrealtime());   // (matrix wave; 100 MHz: the in-kernel clock is d memtime / d memrealtime)
   // ---- loader waves: put the first patch in flight before anything else (its latency hides
   // under the table build).  patch element v = L + 256*i: pixel v>>3, 16-byte channel group v&7;
   // out-of-image pixels get an out-of-range offset -> the bounds-checked load returns zeros.
-  const int L = tid - 256;
+  const int L = tid - 64 * MW;
+  auto patch_off = [&](int i) -> unsigned {
+    int v = L + 256 * i, p = v >> 3, q = v & 7;
+    int yy = oy + p / kPW, xx = ox + p % kPW;
+    bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    return in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
+  };
   unsigned pvoff[NPV];
   V pv[NPV];
-  if (wave >= 4) {
+  if (wave >= MW) {
 #pragma unroll
     for (int i = 0; i < NPV; i++) {
-      int v = L + 256 * i, p = v >> 3, q = v & 7;
-      int yy = oy + p / kPW, xx = ox + p % kPW;
-      bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      pvoff[i] = in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
-      u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)pvoff[i], 0, 0);
+      const unsigned o = patch_off(i);
+      pvoff[i] = o;
+      u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
       pv[i] = __builtin_bit_cast(V, d);
     }
   }
@@ -897,7 +911,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   // whole prologue instead of three in a row)
   const int g = min(o0 / 64 + (wave & 3), G - 1);
   const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
-  V wA[2][4], wB[2][4];
+  constexpr int WR = 2;                                // filter fragments per matrix wave and stage: 4 WR
+  V wA[WR][4], wB[WR][4];
   // D16: 16x16x32 MFMAs (lane maps and the reason: k_conv_f16).  Lane = (i = lane & 15, kg = lane >> 4); fragment
   // f = (16-channel tile f >> 1, k-step f & 1) comes out of the same packed filter; 16-position tile pt = tile row pt, its
   // pixel for lane i = pix16 (conflict-free ds_read_b128 on the 144-byte rows of the column tile)
@@ -906,12 +921,12 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   const int kg16 = lane >> 4, i16 = lane & 15;
   const int pix16 = (i16 >= 4 && i16 < 12) ? (((i16 - 4) >> 1) * 4 + (i16 & 1))
                                            : (((i16 & 3) >> 1) * 4 + 2 + (i16 & 1) + (i16 >= 12 ? 8 : 0));
-  auto load_w = [&](int s, V (&wv)[2][4]) {
+  auto load_w = [&](int s, V (&wv)[WR][4]) {
     if constexpr (D16) {
       if constexpr (DST) {
-        const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;      // k_pack_weight_frag16 order: 1 KB per fragment
+        const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;        // k_pack_weight_frag16 order: 1 KB per fragment
 #pragma unroll
-        for (int f = 0; f < 8; f++) wv[f >> 2][f & 3] = p[f * 64];
+        for (int f = 0; f < 4 * WR; f++) wv[f >> 2][f & 3] = p[f * 64];
       } else {
         const V* p = reinterpret_cast<const V*>(wfrag) + ((int64_t)s * G + g) * 8 * 64 + (kg16 & 1) * 128 + (kg16 >> 1) * 32 + i16;
 #pragma unroll
@@ -925,7 +940,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
   };
-  if (wave < 4) load_w(0, wA);
+  if (wave < MW) load_w(0, wA);
 
   // ---- one table entry: tap t of tile position pl, anchor context c (SRC 1) or the offset maps (SRC 0)
   auto table_entry = [&](int pl, int t, const AnchorCtx& c) {
@@ -985,16 +1000,14 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     s_ctx[tid] = c;
   }
   if (SRC == 1) __syncthreads();
-  S2A_STAMP_AT(6);   // (matrix wave: anchor contexts ready; the loader wave overwrites its slots 6 / 7 later)
 
   // ---- sampling table
-  for (int e = tid; e < NPOS * 9; e += 512) {
+  for (int e = tid; e < NPOS * 9; e += NTHR) {
     AnchorCtx c = {0, 0, 0, 0, 1, 0};
     if (SRC == 1) c = s_ctx[e / 9];
     table_entry(e / 9, e % 9, c);
   }
-  S2A_STAMP_AT(7);   // (matrix wave: table written)
-  if (wave >= 4) {  // first patch -> LDS
+  if (wave >= MW) {  // first patch -> LDS
 #pragma unroll
     for (int i = 0; i < NPV; i++) *reinterpret_cast<V*>(s_patch + (L + 256 * i) * 16) = pv[i];
   }
@@ -1003,13 +1016,13 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
   S2A_STAMP_AT(2);
 
   f32x16 acc[2][NT];
-  f32x4 acc16[D16 ? 4 : 1][D16 ? 2 * NT : 1];
-  const bool wave_active = wave < 4 && wave * 64 < Oloc;
-  if (wave < 4) {
+  f32x4 acc16[D16 ? AH : 1][D16 ? 2 * NT : 1];
+  const bool wave_active = wave < MW && (wave & 3) * 64 < Oloc;
+  if (wave < MW) {
     // ===================== MFMA waves =====================
     if constexpr (D16) {
 #pragma unroll
-      for (int a = 0; a < 4; a++)
+      for (int a = 0; a < AH; a++)
 #pragma unroll
         for (int b = 0; b < 2 * NT; b++)
 #pragma unroll
@@ -1022,7 +1035,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
     }
-    auto compute = [&](int s, const V (&wv)[2][4]) {
+    auto compute = [&](int s, const V (&wv)[WR][4]) {
       if (!wave_active || (S2A_ABL & 4)) return;
       const char* prow = s_B + (s & 1) * (NPOS * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
 #pragma unroll
@@ -1058,6 +1071,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
     // D16: step kk = (k-step kk >> 1 of 32 channels, half kk & 1 of the wave's 16-position tiles): NT reads and 4 NT
     // MFMAs of 16 cycles per step -- the same reads and MFMA cycles per step as the 32x32x16 form, the same pipeline
     auto bfrag = [&](int st, int kk, V (&pf)[NT]) {
+      if ((S2A_ABL & 128) && st > 0) return;           // timing only: the fragments of stage 0 serve every stage
       if constexpr (D16) {
         const char* prow = s_B + (st & 1) * (NPOS * kRowBytes) + ((kk & 1) * NT * 16 + pix16) * kRowBytes + (kg16 & 1) * 64 + (kg16 >> 1) * 16 + (kk >> 1) * 32;
 #pragma unroll
@@ -1068,12 +1082,12 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
 #pragma unroll
       for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
     };
-    auto mma = [&](const V (&wv)[2][4], int kk, const V (&pf)[NT]) {
+    auto mma = [&](const V (&wv)[WR][4], int kk, const V (&pf)[NT]) {
       if (S2A_ABL & 4) return;
       if constexpr (D16) {
         const int ks = kk >> 1, bh = (kk & 1) * NT;
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < AH; a++)
 #pragma unroll
           for (int b = 0; b < NT; b++)
             acc16[a][bh + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[(a * 2 + ks) >> 2][(a * 2 + ks) & 3], pf[b], acc16[a][bh + b], 0, 0, 0);
@@ -1085,14 +1099,14 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         for (int b = 0; b < NT; b++)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], pf[b], acc[a][b], 0, 0, 0);
     };
-    auto stage = [&](int st, const V (&wv)[2][4]) {
+    auto stage = [&](int st, const V (&wv)[WR][4]) {
       bfrag(st, 1, p1); __builtin_amdgcn_sched_barrier(0);
       mma(wv, 0, p0);   __builtin_amdgcn_sched_barrier(0);
       bfrag(st, 2, p0); __builtin_amdgcn_sched_barrier(0);
       mma(wv, 1, p1);   __builtin_amdgcn_sched_barrier(0);
       bfrag(st, 3, p1); __builtin_amdgcn_sched_barrier(0);
       mma(wv, 2, p0);   __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // tile st+1 sealed; this tile's buffer is free for the loaders (all its reads have landed)
+      if (!(S2A_ABL & 256)) __syncthreads();  // tile st+1 sealed; this tile's buffer is free for the loaders (all its reads have landed)
       bfrag(min(st + 1, last), 0, p0); __builtin_amdgcn_sched_barrier(0);   // (last stage: a dead re-read)
       mma(wv, 3, p1);   __builtin_amdgcn_sched_barrier(0);
     };
@@ -1213,7 +1227,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         if (sn + 1 < nstage) fetch(sn + 1);               // (chunk of stage sn+1: written >= 4 stages ago)
       }
       S2A_TOC(t_work); S2A_TIC();
-      __syncthreads();
+      if (!(S2A_ABL & 256)) __syncthreads();
       S2A_TOC(t_wait);
     }
     S2A_STAMP_VAL(7, t_work);
@@ -1240,7 +1254,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
         for (int b = 0; b < 2 * NT; b++) {
           const int64_t gp = out_pos(16 * b + pix16);
 #pragma unroll
-          for (int hf = 0; hf < 2; hf++) {
+          for (int hf = 0; hf < AH / 2; hf++) {
             V v8;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
@@ -1248,11 +1262,12 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
               if (relu & 1) v = fmaxf(v, 0.f);
               v8[e] = (_Float16)v;
             }
-            if (gp >= 0) *reinterpret_cast<V*>(out + gp * O + o0 + wave * 64 + 32 * hf + 8 * kg16) = v8;
+            if (gp >= 0) *reinterpret_cast<V*>(out + gp * O + o0 + (wave & 3) * 64 + 32 * hf + 8 * kg16) = v8;
           }
         }
       }
       S2A_STAMP_AT(5);
+      if (wave == 0) S2A_STAMP_VAL(7, __builtin_amdgcn_s_memrealtime());
       return;
     }
     if (D16 && wave_active) {
@@ -1335,6 +1350,40 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(const _Float16* __restrict
           }
         }
   }
+}
+
+// the launch.  n_full = 0: one TH-row tile per workgroup.  n_full > 0 (TH 8 only): workgroups [0, n_full) take full 8 x 16
+// tiles, the workgroups behind them take the remaining tiles as 4 x 16 HALF tiles (two per tile) -- the hardware hands out
+// workgroups in index order, so the halves are what runs last.  Why: the launch is rounds of one workgroup per CU, every round
+// as long as a tile (36.7 us), and the last round of the detector's pyramid holds 84 tiles for 256 CUs: as 168 half tiles
+// (0.62 of a tile each) it costs 0.62 rounds instead of one.  (A fixed grid of workgroups walking the tiles in a loop -- with
+// the arguments re-read and the thread index laundered per tile so that nothing is hoisted across the body -- was bit-identical
+// and 3 % SLOWER, 227 against 220 us: it keeps the same 6-tile critical path and adds a barrier per tile.)
+struct PatchArgs {
+  const _Float16* x;
+  const float* src;
+  const _Float16* wfrag;
+  _Float16* out;
+  int64_t Ntot;
+  int C, H, W, O;
+  float stride;
+  int relu;
+  unsigned x_bytes;
+  int tile_base;
+  unsigned n_full;
+  LevelTab lt;
+};
+template <bool OUT_NHWC, int SRC, int TH = 8>
+__global__ __launch_bounds__(512, 2) void k_dcn_patch(PatchArgs a) {
+  if constexpr (TH == 8 && OUT_NHWC && SRC == 1 && S2A_DCN_MIXED != 0) {
+    if (a.n_full != 0 && blockIdx.x >= a.n_full) {      // (uniform)
+      dcn_patch_tile<OUT_NHWC, SRC, 4>(a.x, a.src, a.wfrag, a.out, a.Ntot, a.C, a.H, a.W, a.O, a.stride, a.relu, a.x_bytes, a.lt,
+                                           (int)a.n_full, blockIdx.x - a.n_full, gridDim.x - a.n_full, threadIdx.x);
+      return;
+    }
+  }
+  dcn_patch_tile<OUT_NHWC, SRC, TH>(a.x, a.src, a.wfrag, a.out, a.Ntot, a.C, a.H, a.W, a.O, a.stride, a.relu, a.x_bytes, a.lt,
+                                        a.tile_base, blockIdx.x, a.n_full ? a.n_full : gridDim.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ symmetric 16 x 16-tile AlignConv (f16; round 4)
@@ -2709,15 +2758,15 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
         dim3 grid((unsigned)(2 * ntiles(128)), (unsigned)((O + kMaxO - 1) / kMaxO));              \
         S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLdsF));      \
-        kern<<<grid, 512, kHalfLdsF, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, (relu ? 1 : 0) | hc_bit, \
-                                           (unsigned)x_bytes, LevelTab{}, 0);                     \
+        kern<<<grid, 512, kHalfLdsF, st>>>(PatchArgs{x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, (relu ? 1 : 0) | hc_bit, \
+                                                     (unsigned)x_bytes, 0, 0u, LevelTab{}});           \
       } else {                                                                                    \
         auto kern = k_dcn_patch<NHWC, SRC>;                                                       \
         dim3 grid((unsigned)ntiles(128), (unsigned)((O + kMaxO - 1) / kMaxO));                    \
         S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));      \
-        kern<<<grid, 512, kPatchLds, st>>>(x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, (relu ? 1 : 0) | hc_bit, \
-                                           (unsigned)x_bytes, LevelTab{}, 0);                     \
+        kern<<<grid, 512, kPatchLds, st>>>(PatchArgs{x_nhwc, src, wfrag, out, Ntot, C, H, W, O, stride, (relu ? 1 : 0) | hc_bit, \
+                                                     (unsigned)x_bytes, 0, 0u, LevelTab{}});           \
       }                                                                                           \
     }                                                                                             \
   } while (0)
@@ -3287,8 +3336,19 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
   }
   auto kern = k_dcn_patch<true, 1>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
-  kern<<<dim3((unsigned)tiles, ogroups), 512, kPatchLds, st>>>((const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
-                                                               lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu_flags, 0u, lt, 0);
+  // the last round as half tiles when it would leave more than half of the CUs idle (see k_dcn_patch); S2A_DCN_HALF_TAIL=0|1 forces
+  int ncu = 0;
+  {
+    int rc_ = device_cu_count(&ncu);
+    if (rc_ != S2A_OK) return rc_;
+  }
+  const int64_t rem = tiles % ncu;
+  bool half_tail = S2A_DCN_MIXED != 0 && tiles > ncu && rem != 0 && 2 * rem <= ncu;
+  if (const char* f = getenv("S2A_DCN_HALF_TAIL")) half_tail = S2A_DCN_MIXED != 0 && atoi(f) != 0 && tiles > rem && rem != 0;
+  const unsigned n_full = half_tail ? (unsigned)(tiles - rem) : 0u;
+  const unsigned grid_x = half_tail ? (unsigned)(tiles - rem + 2 * rem) : (unsigned)tiles;
+  kern<<<dim3(grid_x, ogroups), 512, kPatchLds, st>>>(PatchArgs{(const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,
+                                                      lt.H[0], lt.W[0], (int)out_channels, lt.stride[0], relu_flags, 0u, 0, n_full, lt});
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

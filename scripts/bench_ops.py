@@ -9,8 +9,12 @@ from s2anet_amd.alignconv import align_conv_forward, pack_weight
 
 dev = torch.device("cuda:0")
 
-def timeit(fn, iters=20, warm=3):
-    for _ in range(warm): fn()
+def timeit(fn, iters=20, warm=3, warm_s=0.25):
+    # warm_s seconds of the same launches first: after host-side set-up the GPU comes back at a low clock
+    t_w, n_w = time.time(), 0
+    while n_w < warm or time.time() - t_w < warm_s:
+        fn(); n_w += 1
+        if n_w % 8 == 0: torch.cuda.synchronize()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -14,7 +14,8 @@ st = st[st[:, 0] > 0][:1024]
 c = st[:, :8]; l = st[:, 8:]
 def d(a, i, j): return np.median(a[:, j] - a[:, i])
 print("consumer: start->pre#1 %d | #1 wait %d | #1->#2 %d | main loop %d | epilogue %d | total %d" % (d(c,0,1), d(c,1,2), d(c,2,3), d(c,3,4), d(c,4,5), d(c,0,5)))
-print("consumer prologue: start->contexts %d | table %d | ->pre#1 %d" % (d(c,0,6), d(c,6,7), d(c,7,1)))
+rt = np.median(c[:, 7] - c[:, 6])
+print("in-kernel clock of a tile: %.2f GHz" % (np.median(c[:, 5] - c[:, 0]) / rt / 10.0))
 print("loader:   start->pre#1 %d | #1 wait %d | produce0 %d | #2 wait %d | main loop %d" % (d(l,0,1), d(l,1,2), d(l,2,6), d(l,6,3), d(l,3,4)))
 tot = np.median(c[:, 5] - c[:, 0])
 rounds = -(-BATCH * 128 * 128 // 128 // 256) if BATCH > 1 else 1      # 8 x 16 tiles of the P3 level at batch 8 on 256 CUs, one workgroup per CU
