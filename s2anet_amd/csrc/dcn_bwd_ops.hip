@@ -244,9 +244,17 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
 //     atomic per touched cell.
 // Samples whose corners leave the window / patch (offsets beyond its 2-3 pixel slack) take global loads and atomics.
 // HBM traffic per tile: gradOutput once, the input patch once per chunk, the gradient window once per chunk.
+// S2A_BWD_ABL: timing-only ablations of k_dcn_bwd_input (never set in a shipped build): 1 = no global atomics of the gathered
+// input gradient, 2 = no gather pass at all, 4 = no offset-gradient pass, 8 = no MFMA jobs, 16 = no list building
+#ifndef S2A_BWD_ABL
+#define S2A_BWD_ABL 0
+#endif
 constexpr int kBTH = 4, kBTW = 16, kBPos = kBTH * kBTW, kBHalo = 4;
 constexpr int kBPH = kBTH + 2 * kBHalo, kBPW = kBTW + 2 * kBHalo, kBPix = kBPH * kBPW;   // 12 x 24 = 288
 constexpr int kBCh = 32;                       // input channels per chunk
+constexpr int kBGRow = kBCh + 4;               // floats per (tap, position) row of the column-gradient tiles: 144 B -- with 128-B rows every
+                                               // lane of the gather pass read the SAME 8 banks (its channel group of a different row):
+                                               // the pass took 19 k cycles per chunk for ~2 k cycles of instructions
 constexpr int kBWinRow = kBCh + 1;             // window row in floats (+1: the flush reads it pixel-major)
 constexpr int kBGoRow = 528;                   // bytes per position of the gradOutput tile: 256 halfs + 16 B pad
 using f32x16b = __attribute__((ext_vector_type(16))) float;
@@ -303,8 +311,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
                                                          int S, int C, int H, int W, int O) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_go = smem;                                                       // [64][kBGoRow]
-  float* s_G = reinterpret_cast<float*>(s_go + kBPos * kBGoRow);            // [9][64][32] f32: column gradient of a chunk
-  char* s_patch = reinterpret_cast<char*>(s_G + 9 * kBPos * kBCh);          // [288][32 halfs]
+  float* s_G = reinterpret_cast<float*>(s_go + kBPos * kBGoRow);            // [9][64][kBGRow] f32: column gradient of a chunk
+  char* s_patch = reinterpret_cast<char*>(s_G + 9 * kBPos * kBGRow);        // [288][32 halfs]
   BTap* s_tab = reinterpret_cast<BTap*>(s_patch + kBPix * kBCh * 2);        // [64 * 9]
   _Float16* s_frac = reinterpret_cast<_Float16*>(s_tab + kBPos * 9);        // [64 * 9][2]: lh, lw
   float* s_goff = reinterpret_cast<float*>(s_frac + kBPos * 9 * 2);         // [64 * 9][2]
@@ -436,24 +444,39 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
     patch_write();
     if (cc + 1 < CC) patch_issue(cc + 1);        // (in flight under this chunk's work)
     // ---- column-gradient tiles of the nine taps on the matrix cores: job = (tap, 32-position half), 18 jobs over 8 waves
-    for (int job = wave; job < 18; job += 8) {
+    for (int job = wave; job < ((S2A_BWD_ABL & 8) ? 0 : 18); job += 8) {
       const int t = job >> 1, ph = job & 1;
       const f16x8b* ap = reinterpret_cast<const f16x8b*>(wpk) + ((int64_t)(t * CC + cc) * KS) * 64 + lane;
       const char* bp = s_go + (ph * 32 + (lane & 31)) * kBGoRow + (lane >> 5) * 16;
       f32x16b acc;
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[r] = 0.f;
-      for (int k0 = 0; k0 < KS; k0 += 4) {
-        f16x8b a[4], bb[4];
+      // the filter fragments come from L2: requested in batches of four right in front of their MFMAs they exposed that
+      // latency four times per job (11.5 k cycles per chunk for 2.3 k of MFMA) -- a batch of eight is in flight one batch ahead
+      f16x8b a0[8], a1[8];
+      auto load_a = [&](int k0, f16x8b (&a)[8]) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (k0 + k < KS) { a[k] = ap[(int64_t)(k0 + k) * 64]; bb[k] = *reinterpret_cast<const f16x8b*>(bp + (k0 + k) * 32); }
+        for (int k = 0; k < 8; k++)
+          if (k0 + k < KS) a[k] = ap[(int64_t)(k0 + k) * 64];
+      };
+      auto run = [&](int k0, const f16x8b (&a)[8]) {
+        f16x8b bb[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 8; k++)
+          if (k0 + k < KS) bb[k] = *reinterpret_cast<const f16x8b*>(bp + (k0 + k) * 32);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
           if (k0 + k < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k], bb[k], acc, 0, 0, 0);
+      };
+      load_a(0, a0);
+      for (int k0 = 0; k0 < KS; k0 += 16) {
+        if (k0 + 8 < KS) load_a(k0 + 8, a1);
+        run(k0, a0);
+        if (k0 + 16 < KS) load_a(k0 + 16, a0);
+        if (k0 + 8 < KS) run(k0 + 8, a1);
       }
       // D rows = channels (4 consecutive per register quad), columns = positions
-      float* gp = s_G + (t * kBPos + ph * 32 + (lane & 31)) * kBCh + 4 * (lane >> 5);
+      float* gp = s_G + (t * kBPos + ph * 32 + (lane & 31)) * kBGRow + 4 * (lane >> 5);
 #pragma unroll
       for (int rq = 0; rq < 4; rq++) {
         const f32x4b v4 = {acc[rq * 4], acc[rq * 4 + 1], acc[rq * 4 + 2], acc[rq * 4 + 3]};
@@ -462,11 +485,11 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
     }
     __syncthreads();
     // ---- offset gradient: items (tap, position, 8-channel group); the four lanes of a position are neighbours
-    for (int it = tid; it < 9 * kBPos * 4; it += 512) {
+    for (int it = tid; it < ((S2A_BWD_ABL & 4) ? 0 : 9 * kBPos * 4); it += 512) {
       const int t = it >> 8, r = it & 255, pos = r >> 2, q = r & 3;
       const BTap tp = s_tab[pos * 9 + t];
       if (!(tp.flags & 1u)) continue;            // (the four lanes of a position decide alike)
-      const float* gp = s_G + (t * kBPos + pos) * kBCh + q * 8;
+      const float* gp = s_G + (t * kBPos + pos) * kBGRow + q * 8;
       float G[8];
       {
         const f32x4b g0 = *reinterpret_cast<const f32x4b*>(gp), g1 = *reinterpret_cast<const f32x4b*>(gp + 4);
@@ -521,23 +544,37 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
       }
     }
     // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels
-    for (int wi = tid; wi < 4 * kBPix; wi += 512) {
+    for (int wi = tid; wi < ((S2A_BWD_ABL & 2) ? 0 : 4 * kBPix); wi += 512) {
       const int q = wi / kBPix, pix = wi % kBPix;
       const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
       if (l0 == l1) continue;
       float a8[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) a8[j] = 0.f;
-      for (unsigned l = l0; l < l1; l++) {
-        const unsigned ent = s_list[l];
-        const float wk = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent & 0xffffu));
-        const float* gp = s_G + (ent >> 16) * kBCh + q * 8;
-        const f32x4b g0 = *reinterpret_cast<const f32x4b*>(gp), g1 = *reinterpret_cast<const f32x4b*>(gp + 4);
+      // four list entries per trip: the entry -> row address -> two row reads chain is three dependent LDS round trips, and a
+      // pixel in the middle of the tile has 20-40 entries (one entry per trip: 19 k cycles per chunk, all of it latency).
+      // Entries past the end repeat the last one with weight 0; the sums run in list order as before.
+      for (unsigned l = l0; l < l1; l += 4) {
+        unsigned ent[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { a8[j] = __builtin_fmaf(wk, g0[j], a8[j]); a8[4 + j] = __builtin_fmaf(wk, g1[j], a8[4 + j]); }
+        for (int k = 0; k < 4; k++) ent[k] = s_list[min(l + k, l1 - 1)];
+        f32x4b g0[4], g1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float* gp = s_G + (ent[k] >> 16) * kBGRow + q * 8;
+          g0[k] = *reinterpret_cast<const f32x4b*>(gp);
+          g1[k] = *reinterpret_cast<const f32x4b*>(gp + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float wk = l + k < l1 ? (float)__builtin_bit_cast(_Float16, (unsigned short)(ent[k] & 0xffffu)) : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; j++) { a8[j] = __builtin_fmaf(wk, g0[k][j], a8[j]); a8[4 + j] = __builtin_fmaf(wk, g1[k][j], a8[4 + j]); }
+        }
       }
       const int yy = oy + pix / kBPW, xx = ox + pix % kBPW;      // (pixels outside the image have no list: w = 0 there)
       float* gp2 = grad_in + (((int64_t)b * C + cc * kBCh + q * 8) * H + yy) * W + xx;
+      if (S2A_BWD_ABL & 1) { if (a8[0] == 12345.f) gp2[0] = a8[1] + a8[2] + a8[3] + a8[4] + a8[5] + a8[6] + a8[7]; continue; }
 #pragma unroll
       for (int j = 0; j < 8; j++) atomicAdd(gp2 + (int64_t)j * HW, a8[j]);
     }
@@ -552,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
   }
 }
 
-constexpr int kBwdLds = kBPos * kBGoRow + 9 * kBPos * kBCh * 4 + kBPix * kBCh * 2 + kBPos * 9 * 16 + kBPos * 9 * 4 +
+constexpr int kBwdLds = kBPos * kBGoRow + 9 * kBPos * kBGRow * 4 + kBPix * kBCh * 2 + kBPos * 9 * 16 + kBPos * 9 * 4 +
                         kBPos * 9 * 8 + kBPos * 9 * 4 * 4 + (kBPix + 1) * 4 + kBPix * 4 + 64;   // ~152 KB
 
 // ================================================================= fused weight gradient (f16, AlignConv geometry)
