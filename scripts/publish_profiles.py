@@ -41,7 +41,7 @@ with open(os.path.join(P, RN + "_alignconv_forms.txt"), "w") as f:
             "#     instruction streams, so a time that moves with the data is the clock the chip holds, a time that does not is issue / latency\n" % head)
     f.write(cat(os.path.join(F, "pyr_power_probe.jsonl")))
     f.write("# (b) in-kernel phase stamps (s_memtime, -DS2A_STAMP=1 diagnostic builds; the shipped library has none), dense random data\n")
-    f.write("# k_dcn_patch, P3 level at batch 8 (scripts/stamp_run.sh):\n")
+    f.write("# k_dcn_patch: P3 level at batch 8, configs[1] as stated, then the pyramid launch on dense and zero data with the in-kernel clock of a tile (scripts/stamp_run.sh):\n")
     f.write("".join(l for l in open(os.path.join(F, "alignconv_stamps.txt")) if "amdgpu.ids" not in l))
     f.write("# k_dcn_sym, the whole pyramid (scripts/stamp_sym_run.sh; cycles per stage interval = 1 024 cycles of MFMA per SIMD):\n")
     f.write("".join(l for l in open(os.path.join(F, "alignconv_sym_stamps.txt")) if "amdgpu.ids" not in l))
