@@ -1427,6 +1427,14 @@ def test_pyramid_alignconv_wild_anchors_vs_oracle(sym, monkeypatch):
         anchors = torch.cat(anchors).to(dev()).contiguous()
         out = P.align_conv(lay, x, anchors, wp, 256).clone()
         assert torch.equal(out, P.align_conv(lay, x, anchors, wp, 256))
+        if sym == "0":
+            # 304 tiles on 256 CUs: the 48 tiles behind the full round run as 96 half tiles inside the same launch
+            # (PatchArgs::n_full); S2A_DCN_HALF_TAIL=0 launches 304 full tiles instead -- the same bits either way
+            monkeypatch.setenv("S2A_DCN_HALF_TAIL", "0")
+            assert torch.equal(out, P.align_conv(lay, x, anchors, wp, 256))
+            monkeypatch.setenv("S2A_DCN_HALF_TAIL", "1")
+            assert torch.equal(out, P.align_conv(lay, x, anchors, wp, 256))
+            monkeypatch.delenv("S2A_DCN_HALF_TAIL")
         for l in (1, 2, 4):                                   # (level 0 at this size: 20 s of oracle per image)
             H, W = sizes[l]
             a = lay.rows(anchors, l).view(B, H * W, 5).cpu().numpy()
