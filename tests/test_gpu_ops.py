@@ -1780,7 +1780,9 @@ def test_full_size_ml_nms_200k(rng):
 
 def test_full_size_alignconv_zero_offset_identity():
     """config 2 at batch 8: anchors that sit on the sampling grid (centre = index * stride, side 3 * stride, angle 0)
-    give zero offsets, so AlignConv == 3x3 convolution + ReLU (SURVEY 8(c) ii) at the full P3 size, f16"""
+    give zero offsets, so AlignConv == 3x3 convolution + ReLU (SURVEY 8(c) ii) at the full P3 size, f16.
+    A size-independent PROPERTY (two kernels of this library against each other), not a parity test: configs[1] / [2]
+    parity against the oracle is test_config1_* / test_config2_* in test_gpu_e2e.py"""
     from s2anet_amd.alignconv import align_conv_forward
     from s2anet_amd.fused import conv_f16, conv_pack_weight
     B, C, H, W, O, st = 8, 256, 128, 128, 256, 8
