@@ -964,17 +964,33 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
       }
       // half_coords: the reference's scalar_t = Half instantiation (deform_conv.py:45-46 casts the offsets to half;
       // deform_conv_cuda_kernel.cu:221-228 h_im / w_im, :97-109 lh / lw / hh / hw and the four weights are Half
-      // results): every one of them rounded to binary16.  Default: f32 coordinates.
-      if (half_coords) { off_y = rh16(off_y); off_x = rh16(off_x); }
-      float h_im = (float)(y - 1 + ky) + off_y;
-      float w_im = (float)(xq - 1 + kx) + off_x;
-      if (half_coords) { h_im = rh16(h_im); w_im = rh16(w_im); }
-      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
-        int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        float lh = h_im - h_low, lw = w_im - w_low;
-        if (half_coords) { lh = rh16(lh); lw = rh16(lw); }
-        float hh = 1 - lh, hw = 1 - lw;
-        if (half_coords) { hh = rh16(hh); hw = rh16(hw); }
+      // results): every one of them rounded to binary16.  Default: f32 coordinates.  ONE uniform branch per
+      // entry: written as a rounding after each step the compiler computed both forms and selected per value
+      // (30 of the entry's 150 instructions for a mode that is off)
+      float h_im, w_im, lh = 0.f, lw = 0.f, hh = 0.f, hw = 0.f;
+      int h_low = 0, w_low = 0;
+      bool inside;
+      if (!half_coords) {
+        h_im = (float)(y - 1 + ky) + off_y;
+        w_im = (float)(xq - 1 + kx) + off_x;
+        inside = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+        if (inside) {
+          h_low = (int)floorf(h_im); w_low = (int)floorf(w_im);
+          lh = h_im - h_low; lw = w_im - w_low;
+          hh = 1 - lh; hw = 1 - lw;
+        }
+      } else {
+        off_y = rh16(off_y); off_x = rh16(off_x);
+        h_im = rh16((float)(y - 1 + ky) + off_y);
+        w_im = rh16((float)(xq - 1 + kx) + off_x);
+        inside = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+        if (inside) {
+          h_low = (int)floorf(h_im); w_low = (int)floorf(w_im);
+          lh = rh16(h_im - h_low); lw = rh16(w_im - w_low);
+          hh = rh16(1 - lh); hw = rh16(1 - lw);
+        }
+      }
+      if (inside) {
         bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
         tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
         tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
@@ -1249,22 +1265,37 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
     if constexpr (DST) {
       // straight from the accumulators (filter rows permuted by k_pack_weight_frag16): lane (pixel pix16 of 16-position tile b,
       // kg16) holds out channels 8 kg16 .. +7 (fragments 0, 1) and 32 + 8 kg16 .. +7 (fragments 2, 3) of its wave's 64
-      if (wave_active) {
+      // ReLU on the rounded halves, two per instruction (rounding is monotonic and keeps zero and sign: max(round(v), 0) ==
+      // round(max(v, 0)); a NaN becomes 0 either way), and the ReLU switch as ONE uniform branch around the tile: with
+      // fmaxf + a per-value select on the f32 accumulators the epilogue was 800 instructions, 5.3 k of a tile's 87 k cycles
+      auto store_tile = [&](auto relu_c) {
+        constexpr bool kRelu = decltype(relu_c)::value;
+        using h2 = __attribute__((ext_vector_type(2))) _Float16;
+        // tile position 16 b + pix16 = (row ty0 + b, column tx0 + pix16): one address, then a row pitch per b
+        const int xq = tx0 + pix16;
+        int64_t gp = bimg * HW + (int64_t)ty0 * W + xq;
+        _Float16* orow = out + o0 + (wave & 3) * 64 + 8 * kg16 + gp * O;
+        const int64_t pitch = (int64_t)W * O;
 #pragma unroll
-        for (int b = 0; b < 2 * NT; b++) {
-          const int64_t gp = out_pos(16 * b + pix16);
+        for (int b = 0; b < 2 * NT; b++, gp += W, orow += pitch) {
+          const bool ok = xq < W && ty0 + b < H && gp < Ntot;
 #pragma unroll
           for (int hf = 0; hf < AH / 2; hf++) {
             V v8;
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-              float v = acc16[D16 ? 2 * hf + (e >> 2) : 0][D16 ? b : 0][e & 3];
-              if (relu & 1) v = fmaxf(v, 0.f);
-              v8[e] = (_Float16)v;
+            for (int i = 0; i < 4; i++) {
+              const f32x4& a4 = acc16[D16 ? 2 * hf + (i >> 1) : 0][D16 ? b : 0];
+              h2 v = {(_Float16)a4[2 * (i & 1)], (_Float16)a4[2 * (i & 1) + 1]};
+              if constexpr (kRelu) v = __builtin_elementwise_max(v, h2{(_Float16)0.f, (_Float16)0.f});
+              v8[2 * i] = v[0];
+              v8[2 * i + 1] = v[1];
             }
-            if (gp >= 0) *reinterpret_cast<V*>(out + gp * O + o0 + (wave & 3) * 64 + 32 * hf + 8 * kg16) = v8;
+            if (ok) *reinterpret_cast<V*>(orow + 32 * hf) = v8;
           }
         }
+      };
+      if (wave_active) {
+        if (relu & 1) store_tile(std::true_type{}); else store_tile(std::false_type{});
       }
       S2A_STAMP_AT(5);
       if (wave == 0) S2A_STAMP_VAL(7, __builtin_amdgcn_s_memrealtime());

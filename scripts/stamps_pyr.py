@@ -6,7 +6,14 @@ from s2anet_amd import _lib, pyramid as P
 from s2anet_amd.pyramid import PyramidLayout
 from s2anet_amd.alignconv import pack_weight
 dev = torch.device("cuda:0")
-layout = PyramidLayout(8, [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], (8, 16, 32, 64, 128))
+# S2A_STAMP_LAYOUT="B:HxW,HxW,..." picks another pyramid (e.g. "2:64x64": 64 tiles on a quarter of the CUs)
+_lay = os.environ.get("S2A_STAMP_LAYOUT")
+if _lay:
+    _b, _lv = _lay.split(":")
+    _sizes = [tuple(int(v) for v in t.split("x")) for t in _lv.split(",")]
+    layout = PyramidLayout(int(_b), _sizes, tuple(8 << i for i in range(len(_sizes))))
+else:
+    layout = PyramidLayout(8, [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], (8, 16, 32, 64, 128))
 g = torch.Generator().manual_seed(0)
 x = torch.randn(layout.pixels, 256, generator=g).to(dev).half()
 w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev).half()
@@ -32,7 +39,7 @@ st = buf.reshape(4096, 16).astype(np.int64)
 st = st[st[:, 0] > 0][:1024]
 c = st[:, :8]; l = st[:, 8:]
 def d(a, i, j): return np.median(a[:, j] - a[:, i])
-print("data: %s, %.2f s of launches before the timed ones  " % ("zeros" if "zeros" in sys.argv else "dense", WARM_S), end=""); print("form: %s   us per launch (stamped build) %.1f" % ("MW 8" if os.environ.get("S2A_DCN_MW8") == "1" else "MW 4", us))
+print("layout %s  " % (_lay or "bench pyramid"), end=""); print("data: %s, %.2f s of launches before the timed ones  " % ("zeros" if "zeros" in sys.argv else "dense", WARM_S), end=""); print("form: %s   us per launch (stamped build) %.1f" % ("MW 8" if os.environ.get("S2A_DCN_MW8") == "1" else "MW 4", us))
 print("matrix wave 0: start->pre#1 %d | #1 wait %d | #1->#2 %d | main loop %d (per stage %d) | epilogue %d | total %d" % (d(c,0,1), d(c,1,2), d(c,2,3), d(c,3,4), d(c,3,4) / 36, d(c,4,5), d(c,0,5)))
 print("loader:        start->pre#1 %d | #1 wait %d | columns 0 %d | #2 wait %d | main loop %d: own work per stage %d, barrier wait per stage %d" % (d(l,0,1), d(l,1,2), d(l,2,6), d(l,6,3), d(l,3,4), np.median(l[:, 7]) / 36, np.median(l[:, 5]) / 36))
 rt = np.median(c[:, 7] - c[:, 6])                      # 100 MHz ticks between the start and end stamps of matrix wave 0
