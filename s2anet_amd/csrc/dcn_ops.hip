@@ -1007,8 +1007,10 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
     }
     s_tab[pl * 9 + t] = tp;
   };
-  // ---- per-position anchor context (cos/sin once per position, not once per tap)
-  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);   // B tiles are not in use yet
+  // ---- per-position anchor context (cos/sin once per position, not once per tap).  It lives in the SECOND column buffer:
+  // the first one is written (first column tile) while the matrix waves still read contexts for the rest of the table
+  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B + NPOS * kRowBytes);
+  static_assert(NPOS * sizeof(AnchorCtx) <= NPOS * kRowBytes, "contexts fit a column buffer");
   if (SRC == 1 && tid < NPOS) {
     int y = ty0 + (tid >> 4), xq = tx0 + (tid & 15);
     AnchorCtx c = {0, 0, 0, 0, 1, 0};
@@ -1017,19 +1019,29 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
   }
   if (SRC == 1) __syncthreads();
 
-  // ---- sampling table
-  for (int e = tid; e < NPOS * 9; e += NTHR) {
-    AnchorCtx c = {0, 0, 0, 0, 1, 0};
-    if (SRC == 1) c = s_ctx[e / 9];
-    table_entry(e / 9, e % 9, c);
-  }
+  // ---- sampling table, TAP-major (entry e = tap e / NPOS of position e % NPOS): everyone builds the first NTHR entries
+  // (taps 0 .. 3 of a full tile), which is all the loaders need for their first column tiles; the matrix waves, idle until
+  // the first columns exist, build the rest under the loaders' first tile (the whole table in front of barrier #1 was
+  // 2.85 k cycles with the matrix pipes and then the loaders waiting on each other: 9.9 k cycles before the first MFMA)
+  auto table_entries = [&](int e0, int e1, int t0, int nthr) {
+    for (int e = e0 + t0; e < e1; e += nthr) {
+      const int pl = e % NPOS, t = e / NPOS;
+      AnchorCtx c = {0, 0, 0, 0, 1, 0};
+      if (SRC == 1) c = s_ctx[pl];
+      table_entry(pl, t, c);
+    }
+  };
+  constexpr int kTabFirst = NTHR < NPOS * 9 ? NTHR : NPOS * 9;        // 512 entries = taps 0 .. 3 (TH 8), 0 .. 7 (TH 4)
+  static_assert(kTabFirst % NPOS == 0 && kTabFirst / NPOS >= 2, "the first round of entries covers whole taps, at least taps 0 and 1");
+  table_entries(0, kTabFirst, tid, NTHR);
   if (wave >= MW) {  // first patch -> LDS
 #pragma unroll
     for (int i = 0; i < NPV; i++) *reinterpret_cast<V*>(s_patch + (L + 256 * i) * 16) = pv[i];
   }
   S2A_STAMP_AT(1);
-  __syncthreads();  // #1 table + patch 0 ready (s_ctx is dead from here on)
+  __syncthreads();  // #1 table rows of the first taps + patch 0 ready
   S2A_STAMP_AT(2);
+  if (wave < MW) table_entries(kTabFirst, NPOS * 9, tid, 64 * MW);   // (s_ctx is dead behind barrier #2)
 
   f32x16 acc[2][NT];
   f32x4 acc16[D16 ? AH : 1][D16 ? 2 * NT : 1];
@@ -1272,6 +1284,18 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
         constexpr bool kRelu = decltype(relu_c)::value;
         using h2 = __attribute__((ext_vector_type(2))) _Float16;
         // tile position 16 b + pix16 = (row ty0 + b, column tx0 + pix16): one address, then a row pitch per b
+        auto pack8 = [&](int b, int hf) {
+          V v8;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const f32x4& a4 = acc16[D16 ? 2 * hf + (i >> 1) : 0][D16 ? b : 0];
+            h2 v = {(_Float16)a4[2 * (i & 1)], (_Float16)a4[2 * (i & 1) + 1]};
+            if constexpr (kRelu) v = __builtin_elementwise_max(v, h2{(_Float16)0.f, (_Float16)0.f});
+            v8[2 * i] = v[0];
+            v8[2 * i + 1] = v[1];
+          }
+          return v8;
+        };
         const int xq = tx0 + pix16;
         int64_t gp = bimg * HW + (int64_t)ty0 * W + xq;
         _Float16* orow = out + o0 + (wave & 3) * 64 + 8 * kg16 + gp * O;
@@ -1280,18 +1304,8 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
         for (int b = 0; b < 2 * NT; b++, gp += W, orow += pitch) {
           const bool ok = xq < W && ty0 + b < H && gp < Ntot;
 #pragma unroll
-          for (int hf = 0; hf < AH / 2; hf++) {
-            V v8;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const f32x4& a4 = acc16[D16 ? 2 * hf + (i >> 1) : 0][D16 ? b : 0];
-              h2 v = {(_Float16)a4[2 * (i & 1)], (_Float16)a4[2 * (i & 1) + 1]};
-              if constexpr (kRelu) v = __builtin_elementwise_max(v, h2{(_Float16)0.f, (_Float16)0.f});
-              v8[2 * i] = v[0];
-              v8[2 * i + 1] = v[1];
-            }
-            if (ok) *reinterpret_cast<V*>(orow + 32 * hf) = v8;
-          }
+          for (int hf = 0; hf < AH / 2; hf++)
+            if (ok) *reinterpret_cast<V*>(orow + 32 * hf) = pack8(b, hf);
         }
       };
       if (wave_active) {
@@ -1301,19 +1315,21 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
       if (wave == 0) S2A_STAMP_VAL(7, __builtin_amdgcn_s_memrealtime());
       return;
     }
+    const bool relu_u = __builtin_amdgcn_readfirstlane(relu & 1) != 0;
     if (D16 && wave_active) {
       using h4 = __attribute__((ext_vector_type(4))) _Float16;
 #pragma unroll
       for (int a = 0; a < (D16 ? 4 : 0); a++)
 #pragma unroll
         for (int b = 0; b < 2 * NT; b++) {
-          h4 v4;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            float v = acc16[D16 ? a : 0][D16 ? b : 0][e];
-            if (relu & 1) v = fmaxf(v, 0.f);
-            v4[e] = (_Float16)v;
+          using h2s = __attribute__((ext_vector_type(2))) _Float16;
+          const f32x4& a4 = acc16[D16 ? a : 0][D16 ? b : 0];
+          h2s v01 = {(_Float16)a4[0], (_Float16)a4[1]}, v23 = {(_Float16)a4[2], (_Float16)a4[3]};
+          if (relu_u) {
+            v01 = __builtin_elementwise_max(v01, h2s{(_Float16)0.f, (_Float16)0.f});
+            v23 = __builtin_elementwise_max(v23, h2s{(_Float16)0.f, (_Float16)0.f});
           }
+          const h4 v4 = {v01[0], v01[1], v23[0], v23[1]};
           *reinterpret_cast<h4*>(s_out + (16 * b + pix16) * kOutRow + (wave * 64 + 16 * a + 4 * kg16) * 2) = v4;
         }
     } else if (wave_active) {
