@@ -259,7 +259,14 @@ def measure_ops(dev, with_cpu=True):
     sec = _time_launches(lambda: S.box_iou_rotated(b1, b2), iters=20)
     byts = n * n * 4 + 2 * n * 20
     ops["box_iou_rotated_10k_x_10k"] = {
-        "us": round(sec * 1e6, 1), "Gpairs_s": round(n * n / sec / 1e9, 1), "bound": "hbm (N*M*4 B of output)",
+        "us": round(sec * 1e6, 1), "Gpairs_s": round(n * n / sec / 1e9, 1),
+        # what binds the call is max(HBM write of N*M*4 B, the vector-ALU chain on the caller's stream): the zero-fill
+        # (96 us = 4.2 TB/s) runs on a side stream BESIDE pair finder (60 us) -> exact pass (60 us), the scatter (21 us)
+        # behind both (kernel timeline: scripts/iou_timeline.sh; utilisation of the two VALU-bound kernels 76 % / 81 %,
+        # profiles/r03_iou_10k_pmc.txt) -- the chain, not the write, is the longer leg
+        "bound": "max(hbm write of N*M*4 B, VALU chain finder -> exact pass -> scatter); the chain binds",
+        "hbm_write_floor_us": round(byts / (PEAK_HBM_GBS * 1e9) * 1e6, 1),
+        "valu_chain_us_recorded": {"pair_finder": 60, "exact_pass": 60, "scatter": 21, "zero_fill_beside": 96},
         "alg_bytes": byts, "achieved_GBs": round(byts / sec / 1e9, 1), "hbm_write_frac": round(byts / sec / 1e9 / PEAK_HBM_GBS, 4)}
     # configs[0], second half: polyiou (DOTA_devkit/polyiou/csrc/polyiou.cpp:108-128) on the 10 k boxes as polygons,
     # 1 M (i, j) pairs of nearby boxes so that most of them overlap (f64 on the vector units, bit-exact by test)
