@@ -239,6 +239,8 @@ if __name__ == "__main__":
     if a.which in ("all", "bwd"):
         res.append(dcn_backward(8, dtype=torch.float32)); res.append(dcn_backward(8, dtype=torch.float16))
         res.append(dcn_backward(8, dtype=torch.float16, offsets="wild"))
+    if a.which == "bwd32":
+        res.append(dcn_backward(8, dtype=torch.float32))
     if a.which == "bwd16":
         res.append(dcn_backward(8, dtype=torch.float16))
     if a.which in ("all", "poly"):
