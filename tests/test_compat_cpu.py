@@ -114,3 +114,16 @@ def test_scale_coords_rotated_matches_reference_function():
         out = scale_coords_rotated((int(a[0]), int(a[1])), t, (int(a[2]), int(a[3])), rp)
         assert out is t                                                      # in place, as the reference
         assert np.array_equal(out.numpy(), g["out_" + tag]), tag
+
+
+def test_unfused_backward_column_chunks_fit_the_last_level_cache(monkeypatch):
+    """deform_conv_backward_parameters_cuda cuts the reference's im2col_step chunk to the largest divisor whose `columns`
+    stay under the cache budget (host logic only; the reference's own chunking with S2A_DCN_COLUMNS_MB=0)"""
+    from s2anet_amd.dcn import _cache_step
+    per_image = 2304 * 128 * 128 * 4                      # P3, 256 x 3 x 3 rows, f32: 151 MB
+    assert _cache_step(8, per_image) == 1
+    assert _cache_step(8, per_image // 4) == 4            # 38 MB per image: four of them fit 192 MB
+    assert _cache_step(6, per_image // 4) == 3            # divisors only
+    assert _cache_step(8, 4 * per_image) == 1             # never below one image
+    monkeypatch.setenv("S2A_DCN_COLUMNS_MB", "0")
+    assert _cache_step(8, per_image) == 8
