@@ -1831,24 +1831,14 @@ __global__ __launch_bounds__(kThreads) void k_nms_round(const uint2* __restrict_
   }
 }
 
-// writes the implicit "open and not blocked == kept" view after the last launched round out as explicit states (only
-// when edges are still alive); the two `blocked` arrays become plain "blocked this round" flags
-__global__ void k_nms_materialize(const NmsCounters* __restrict__ C, uint8_t* __restrict__ state,
-                                  uint8_t* __restrict__ blocked, int64_t n) {
-  if (C->alive[kNmsRounds] == 0) return;
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const uint32_t v = nms_view(state, blocked, n, kNmsRounds, (uint32_t)p);
-  blocked[p] = 0;            // (kNmsRounds is even: the view reads array 0 at this very index, before the write)
-  blocked[n + p] = 0;        // both arrays become plain "blocked this round" flags
-  if (v == kKept) state[p] = (uint8_t)kKept;
-}
-static_assert(kNmsRounds % 2 == 0 && kNmsRounds < 15, "k_nms_materialize / NmsCounters::alive assume this");
+// (the implicit "open and not blocked == kept" view after the last launched round is written out as explicit states by
+// k_nms_alive_count, only when edges are still alive; the two `blocked` arrays become plain "blocked this round" flags)
+static_assert(kNmsRounds % 2 == 0 && kNmsRounds < 15, "the materialising pass of k_nms_alive_count / NmsCounters::alive assume this");
 
 // ---- FINISH per segment: chains longer than the launched rounds (dense detector outputs: tens of dependent rounds).
 // The edges that are still alive are bucketed by segment (count, scan, scatter) and every segment that has some is
 // finished by ONE workgroup with the rows' states, the round flags and the edge list in LDS, so that a round costs two
-// short passes and two barriers instead of a kernel launch.  Explicit states (k_nms_materialize ran): a round is
+// short passes and two barriers instead of a kernel launch.  Explicit states (the materialising pass of k_nms_alive_count ran): a round is
 //   pass 1: kept source -> target removed; open source and open target -> target flagged;
 //   pass 2: open and not flagged -> kept; edges whose target is still open stay (also when their source was removed
 //           in pass 1: the target is then decided next round), the others are dropped; the flags of the other array are
@@ -1875,11 +1865,20 @@ __device__ __forceinline__ unsigned seg_aggregate(bool valid, uint32_t seg, uint
   return slot;
 }
 
+// (also the body of k_nms_materialize, whose rows and this kernel's edges are independent work: one launch less in the
+// launch-paced tail of the call -- `mat_n` rows by grid-stride, then the edges)
 __global__ __launch_bounds__(kThreads) void k_nms_alive_count(const NmsCounters* __restrict__ C,
                                                               const uint2* __restrict__ alive, unsigned long long alive_cap,
                                                               const PreBox* __restrict__ sorted,
-                                                              uint32_t* __restrict__ seg_cnt) {
+                                                              uint32_t* __restrict__ seg_cnt, uint8_t* __restrict__ state,
+                                                              uint8_t* __restrict__ blocked, int64_t mat_n) {
   if (C->alive[kNmsRounds] == 0) return;
+  for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < mat_n; p += (int64_t)gridDim.x * kThreads) {
+    const uint32_t v = nms_view(state, blocked, mat_n, kNmsRounds, (uint32_t)p);
+    blocked[p] = 0;            // (kNmsRounds is even: the view reads array 0 at this very index, before the write)
+    blocked[mat_n + p] = 0;    // both arrays become plain "blocked this round" flags
+    if (v == kKept) state[p] = (uint8_t)kKept;
+  }
   const unsigned long long A = min(C->alive_list, alive_cap);
   const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
   for (unsigned long long e0 = (unsigned long long)blockIdx.x * kThreads; e0 < A; e0 += stride) {
@@ -2488,8 +2487,7 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
                                           r == kNmsRounds ? B.gq : nullptr, pl.queue_cap);
   // still-alive edges (listed by the last launched round in the dead pair list): by segment into the edge buffer (the full
   // edge list is dead now), then one workgroup per segment; all five kernels return at once when nothing is alive
-  k_nms_materialize<<<g, 256, 0, st>>>(B.C, B.state, B.blocked, n);
-  k_nms_alive_count<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cnt);
+  k_nms_alive_count<<<std::max(256u, std::min(g, 2048u)), kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cnt, B.state, B.blocked, n);
   k_nms_alive_scan<<<1, 1024, 0, st>>>(B.C, B.num_seg, B.seg_cnt, B.seg_cur);
   k_nms_alive_scatter<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cur, B.edges);
   k_nms_finish_segments<<<512, kFinThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.seg_cnt, B.edges, B.state, B.blocked, n,
