@@ -93,6 +93,10 @@ def parse():
     ap.add_argument("--no-fam-cls", action="store_true",
                     help="skip the FAM classification branch (unused at inference; the reference evaluates it)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) also for ONE rank and send the detections through "
+                         "all_gather_into_tensor instead of the world-of-one copy: executes the real collective path "
+                         "(backend, side stream, events) on a one-GPU box.  S2A_BENCH_FORCE_DIST=1 does the same")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight: step i runs on HIP stream i %% S (independent batches; S > 1 lets the "
                          "latency-bound NMS tail of one batch overlap the convolutions of the next)")
@@ -371,7 +375,13 @@ def _ops_cpu_figures():
             ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(nt))
         except OSError:
             pass
-    nth = torch.get_num_threads()
+
+    def get_omp():
+        try:
+            return int(ctypes.CDLL("libgomp.so.1").omp_get_max_threads())
+        except OSError:
+            return None
+    nth, omp_before = torch.get_num_threads(), get_omp()
     torch.set_num_threads(1)
     set_omp(1)
     try:
@@ -412,7 +422,11 @@ def _ops_cpu_figures():
     x = rng.standard_normal((1, 256, 32, 32)).astype(np.float32)
     w = (rng.standard_normal((256, 256, 3, 3)) * 0.01).astype(np.float32)
     off = rng.standard_normal((1, 18, 32, 32)).astype(np.float32)
-    dt = best_of_3(lambda: oracle.deform_conv_forward(x, off, w))
+    try:
+        dt = best_of_3(lambda: oracle.deform_conv_forward(x, off, w))
+    finally:
+        if omp_before is not None:
+            set_omp(omp_before)         # leave the OpenMP pool as it was found
     out["deform_conv_forward"] = {"kind": "port", "sample": "[1,256,32,32] f32 (the reference has no CPU path: oracle port, OpenMP)",
                                   "cores": ncores, "s": round(dt, 4), "GFLOPs": round(2 * 256 * 2304 * 1024 / dt / 1e9, 2),
                                   "timing": "warm-up + best of 3, OMP_NUM_THREADS pinned to `cores`"}
@@ -440,7 +454,10 @@ def cpu_baseline(seed, candidates, chips=3):
     except OSError:
         pass
     ref_nms = ref.ml_nms_rotated()
-    kind = "reference" if ref_nms is not None else "port"
+    # per leg: the carrier convolutions are torch's CPU kernels, AlignConv / ARF / pooling / decode the oracle port (the
+    # reference has no CPU path for them), the NMS the reference's own CPU op when oracle/_ref holds it
+    legs = {"conv": "torch-cpu", "ops": "port", "nms": "reference" if ref_nms is not None else "port"}
+    kind = "mixed" if ref_nms is not None else "port"
     timers = {"oracle_ops_s": 0.0}
     t0 = time.perf_counter()
     t_nms, n_cand, n_keep = 0.0, 0, 0
@@ -469,11 +486,11 @@ def cpu_baseline(seed, candidates, chips=3):
         n_cand += int(cb.shape[0]); n_keep += len(keep)
     sec = time.perf_counter() - t0
     return {
-        "value": round(chips / sec, 4), "unit": "chips/s", "cores": ncores, "kind": kind,
+        "value": round(chips / sec, 4), "unit": "chips/s", "cores": ncores, "kind": kind, "legs": legs,
         "sample": "%d chips 1024x1024 one after the other, fp32, %d NMS candidates per chip, kept %d per chip: torch-CPU "
                   "convolutions (%d threads) + oracle AlignConv/ARF/pooling/decode (OpenMP, %d threads) + %s ml_nms_rotated "
                   "(1 thread: the reference's CPU op is serial)"
-                  % (chips, n_cand // chips, n_keep // chips, ncores, ncores, "reference CPU" if kind == "reference" else "oracle"),
+                  % (chips, n_cand // chips, n_keep // chips, ncores, ncores, "reference CPU" if ref_nms is not None else "oracle"),
         "chips": chips, "total_s": round(sec, 3),
         "conv_s": round(sec - timers["oracle_ops_s"] - t_nms, 3), "conv_threads": ncores,
         "oracle_ops_s": round(timers["oracle_ops_s"], 3), "oracle_ops_threads": ncores,
@@ -597,7 +614,13 @@ def main():
         if not stub:
             torch.cuda.synchronize()
     backend = None
-    if world > 1:
+    force_dist = (args.force_dist or bool(os.environ.get("S2A_BENCH_FORCE_DIST"))) and world == 1
+    dist_on = world > 1 or force_dist
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # nccl == RCCL on ROCm.  S2A_BENCH_BACKEND=gloo is only for rehearsing the multi-rank code
         # path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device).
@@ -635,10 +658,10 @@ def main():
     # (RCCL only: ProcessGroupNCCL orders its collective behind the current stream with events and never blocks the host;
     # gloo's CUDA path blocks the host in wait() -- the rehearsal backend measured 72 vs 14 ms per step with the side
     # stream -- so the rehearsal keeps the gather on the compute stream)
-    side = (world > 1 and not stub and backend == "nccl" and args.streams <= 1 and not args.graph
+    side = (dist_on and not stub and backend == "nccl" and args.streams <= 1 and not args.graph
             and not os.environ.get("S2A_BENCH_NO_SIDE_GATHER"))
-    gathers = [DetectionGather(world, B, model.head.max_per_img, dev, side_stream=side) for _ in range(nslots)] \
-        if world > 1 else None
+    gathers = [DetectionGather(world, B, model.head.max_per_img, dev, side_stream=side, force_collective=force_dist)
+               for _ in range(nslots)] if dist_on else None
     dropped = [torch.zeros((1,), dtype=torch.int64, device=dev) for _ in range(nslots)]
     slot, do_gather, last_wire = [0], [True], [None]
 
@@ -699,29 +722,28 @@ def main():
             runner()
         sync()
 
-    if world > 1:
+    if dist_on:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner()
     sync()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
     per_rank = None
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
         # attribution of a scaling loss, OUTSIDE the timed region: every rank's step time without the collective
         # (same runner, same streams) and the collective alone on an otherwise idle GPU, gathered to rank 0
         if gathers is not None:
-            for g_ in gathers:
-                g_.wait()
             sync()
-            out = gathers[(slot[0]) % nslots].unpack()
+            # clones: the attribution loop below gathers into its own object, but the timed slots stay untouched anyway
+            out = tuple(t_.clone() for t_ in gathers[(slot[0]) % nslots].unpack())
         if not args.graph:
             def loop_ms(fn, n):
                 sync()
@@ -735,16 +757,33 @@ def main():
             do_gather[0] = True
             dist.barrier()
             w_ = last_wire[0]
+            g_alone = DetectionGather(world, B, model.head.max_per_img, dev, side_stream=side, force_collective=force_dist)
 
             def gather_once():
-                gathers[0](w_)
-                gathers[0].wait()
+                g_alone(w_)
+                g_alone.wait()
+            gather_once()
             gather_ms = loop_ms(gather_once, 20)
             mine = {"rank": rank, "step_ms": round(elapsed / args.steps * 1e3, 3), "compute_ms": round(compute_ms, 3),
                     "gather_ms": round(gather_ms, 3)}
             allr = [None] * world
             dist.all_gather_object(allr, mine)
             per_rank = allr
+    # the latency-optimal setting beside the throughput one, measured after the timed region: one batch at a time on the
+    # default stream (what a scaling run with the side-stream gather uses); eager launches, same step
+    single_stream = None
+    if streams and not stub and world == 1:
+        slot[0] = 0
+        for _ in range(3):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        ms1 = (time.perf_counter() - t1) / args.steps * 1e3
+        single_stream = {"ms_per_step": round(ms1, 3), "chips_s": round(B / ms1 * 1e3, 1), "steps": args.steps,
+                         "note": "one batch at a time on one HIP stream (--streams 1), measured after the timed region"}
     # outside the timed region: the static candidate cap must not have cut a single row in any step (the reference
     # never drops a candidate, utils/bbox_nms_rotated.py:29-40) -- one host read
     n_dropped = int(sum(int(d.item()) for d in dropped))
@@ -752,7 +791,7 @@ def main():
 
     counts = out[2].reshape(-1)
     # the label names the backend that was really initialised (never assumed)
-    collective = None if world == 1 else {"nccl": "RCCL (torch.distributed nccl backend)"}.get(
+    collective = None if not dist_on else {"nccl": "RCCL (torch.distributed nccl backend)"}.get(
         dist.get_backend(), "%s (rehearsal backend, not RCCL)" % dist.get_backend())
     result = {
         "metric": "1024x1024 DOTA chips/sec (R-50-FPN S2ANet inference)",
@@ -764,7 +803,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[2]: full R-50-FPN S2ANet inference, batch %d of 1024x1024 synthetic "
-                        "uint8 chips per GPU%s%s" % (B, "" if world == 1 else ", detections all-gathered over %s" % collective,
+                        "uint8 chips per GPU%s%s" % (B, "" if not dist_on else ", detections all-gathered over %s%s" % (
+                            collective, " (world of ONE: the collective path executed, not a scaling run)" if force_dist else ""),
                                                      "" if args.streams == 1 else "; %d independent batches in flight on %d HIP streams"
                                                      % (args.streams, args.streams)),
             "chips_per_gpu_per_step": B, "global_batch": world * B, "num_classes": NUM_CLASSES,
@@ -776,6 +816,8 @@ def main():
             "parallelism": "dp%d (one process per GPU)" % world, "collective_backend": collective,
         },
     }
+    if single_stream is not None:
+        result["single_stream"] = single_stream
     if per_rank is not None:
         # per rank: the timed step, the same step without the all-gather, and the all-gather alone (ms) -- measured after
         # the timed region; with world > 1 a loss shows up either as an uneven compute_ms or as a large gather_ms
@@ -804,7 +846,7 @@ def main():
                 result["cpu_baseline"] = {"value": None, "unit": "chips/s", "cores": os.cpu_count(), "kind": "port",
                                           "sample": "failed: %r" % (e,)}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -36,37 +36,11 @@ namespace s2a {
 namespace {
 
 // S2A_ABL: compile-time ablation switches for timing experiments only (never set in a shipped build)
-#ifndef S2A_MPIPE
-#define S2A_MPIPE 1
-#endif
 #ifndef S2A_ABL
 #define S2A_ABL 0
 #endif
 #ifndef S2A_STAMP
 #define S2A_STAMP 0
-#endif
-// S2A_CONV_M16 = 0: every convolution on v_mfma_f32_32x32x16_f16 (rounds 1-2); 2: 16x16x32 for the towers with the filter through
-// LDS only; 3: for the full-width (OG 4) launches only; 1 (shipped): every stride-1 3x3 launch and the full-width 1x1 launches --
-// A/B builds only
-#ifndef S2A_CONV_M16
-#define S2A_CONV_M16 1
-#endif
-// S2A_TAIL_EARLY_RES = 1: the fused bottleneck tail (16 x 16 tiles) requests its residual tile before the 3x3 GEMM -- A/B builds only
-#ifndef S2A_TAIL_EARLY_RES
-#define S2A_TAIL_EARLY_RES 1
-#endif
-// S2A_DCN_M16 = 1: the matrix waves of the patch-staged AlignConv on v_mfma_f32_16x16x32_f16 as well -- A/B builds only
-#ifndef S2A_DCN_M16
-#define S2A_DCN_M16 1
-#endif
-// S2A_DCN_DIRECT_ST = 1: k_dcn_patch stores its output tile straight from the accumulators (filter rows permuted by
-// k_pack_weight_frag16) instead of staging it through LDS (-1 % same-box, bit-identical) -- A/B builds only
-#ifndef S2A_DCN_DIRECT_ST
-#define S2A_DCN_DIRECT_ST 1
-#endif
-// S2A_DCN_MIXED = 1: the pyramid launch may end in half tiles (k_dcn_patch) -- A/B builds only
-#ifndef S2A_DCN_MIXED
-#define S2A_DCN_MIXED 1
 #endif
 // measurement builds (-DS2A_MEASURE) only: S2A_DCN_DROP=x|w gives the wave-specialised kernel zero-record descriptors (the
 // loads are dropped, the instruction stream stays; OUTPUTS ARE WRONG) -- never compiled into a shipped library
@@ -811,8 +785,6 @@ __global__ void k_pack_weight_frag16(const _Float16* __restrict__ w, int O, int 
   wp[e] = w[((int64_t)och * C + k) * 9 + t];
 }
 
-constexpr int kOutRow = 528;   // LDS row of the staged output tile: 256 halfs + 16 B pad
-
 // TH = rows of the position tile: 8 (128 positions), or 4 (64 positions: half tiles for launches that fill the chip badly,
 // e.g. one P3 level of one chip = 128 full tiles on 256 CUs; tile index = tile_base + block / 2, half = block & 1)
 // (MW = 4 matrix waves, one per SIMD, 64 out channels x all positions each.  The form with EIGHT -- two per SIMD, 32 out channels
@@ -913,32 +885,17 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
   const V* wf_base = reinterpret_cast<const V*>(wfrag) + lane;
   constexpr int WR = 2;                                // filter fragments per matrix wave and stage: 4 WR
   V wA[WR][4], wB[WR][4];
-  // D16: 16x16x32 MFMAs (lane maps and the reason: k_conv_f16).  Lane = (i = lane & 15, kg = lane >> 4); fragment
-  // f = (16-channel tile f >> 1, k-step f & 1) comes out of the same packed filter; 16-position tile pt = tile row pt, its
-  // pixel for lane i = pix16 (conflict-free ds_read_b128 on the 144-byte rows of the column tile)
-  constexpr bool D16 = S2A_DCN_M16 != 0;
-  constexpr bool DST = D16 && S2A_DCN_DIRECT_ST != 0;      // direct-store epilogue + k_pack_weight_frag16 filter
+  // 16x16x32 MFMAs (lane maps and the reason: k_conv_f16; the 32x32x16 form of rounds 1-2 measured +1.7 %).
+  // Lane = (i = lane & 15, kg = lane >> 4); fragment f = (16-channel tile f >> 1, k-step f & 1) in k_pack_weight_frag16
+  // order; 16-position tile pt = tile row pt, its pixel for lane i = pix16 (conflict-free ds_read_b128 on the 144-byte
+  // rows of the column tile)
   const int kg16 = lane >> 4, i16 = lane & 15;
   const int pix16 = (i16 >= 4 && i16 < 12) ? (((i16 - 4) >> 1) * 4 + (i16 & 1))
                                            : (((i16 & 3) >> 1) * 4 + 2 + (i16 & 1) + (i16 >= 12 ? 8 : 0));
   auto load_w = [&](int s, V (&wv)[WR][4]) {
-    if constexpr (D16) {
-      if constexpr (DST) {
-        const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;        // k_pack_weight_frag16 order: 1 KB per fragment
+    const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;        // k_pack_weight_frag16 order: 1 KB per fragment
 #pragma unroll
-        for (int f = 0; f < 4 * WR; f++) wv[f >> 2][f & 3] = p[f * 64];
-      } else {
-        const V* p = reinterpret_cast<const V*>(wfrag) + ((int64_t)s * G + g) * 8 * 64 + (kg16 & 1) * 128 + (kg16 >> 1) * 32 + i16;
-#pragma unroll
-        for (int f = 0; f < 8; f++) wv[f >> 2][f & 3] = p[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
-      }
-      return;
-    }
-    const V* p = wf_base + ((int64_t)s * G + g) * 8 * 64;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) wv[a][kk] = p[(a * 4 + kk) * 64];
+    for (int f = 0; f < 4 * WR; f++) wv[f >> 2][f & 3] = p[f * 64];
   };
   if (wave < MW) load_w(0, wA);
 
@@ -1043,50 +1000,22 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
   S2A_STAMP_AT(2);
   if (wave < MW) table_entries(kTabFirst, NPOS * 9, tid, 64 * MW);   // (s_ctx is dead behind barrier #2)
 
-  f32x16 acc[2][NT];
-  f32x4 acc16[D16 ? AH : 1][D16 ? 2 * NT : 1];
+  f32x4 acc16[AH][2 * NT];
   const bool wave_active = wave < MW && (wave & 3) * 64 < Oloc;
   if (wave < MW) {
     // ===================== MFMA waves =====================
-    if constexpr (D16) {
 #pragma unroll
-      for (int a = 0; a < AH; a++)
+    for (int a = 0; a < AH; a++)
 #pragma unroll
-        for (int b = 0; b < 2 * NT; b++)
+      for (int b = 0; b < 2 * NT; b++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) acc16[a][b][r] = 0.f;
-    } else {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < NT; b++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-    }
-    auto compute = [&](int s, const V (&wv)[WR][4]) {
-      if (!wave_active || (S2A_ABL & 4)) return;
-      const char* prow = s_B + (s & 1) * (NPOS * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        V pf[NT];
-#pragma unroll
-        for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
-        // weights are the A operand: D rows = out channels (4 consecutive per register quad),
-        // D columns = positions (lane & 31)
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-          for (int b = 0; b < NT; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], pf[b], acc[a][b], 0, 0, 0);
-      }
-    };
+        for (int r = 0; r < 4; r++) acc16[a][b][r] = 0.f;
     const int last = nstage - 1;
     __syncthreads();  // #2 stage 0 columns in LDS
     S2A_STAMP_AT(3);
     int s = 0;
     unsigned long long t_tic = 0, t_work = 0, t_wait = 0;
     (void)t_tic; (void)t_work; (void)t_wait;
-#if S2A_MPIPE
     // B fragments one k-step AHEAD of the MFMAs that use them (two register sets), also across the stage boundary: the
     // stage's barrier sits in front of the LAST k-step, after all four reads of the current tile have been issued and
     // have landed -- behind it the next tile is sealed and its first fragments are requested under the last 2*NT MFMAs.
@@ -1096,36 +1025,22 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
     // (no branch on wave_active in here: a wave without out-channels computes on clamped filter fragments and drops the
     // result in the epilogue -- a branch would split the basic block and hipcc's waitcnt pass then waits for ALL LDS
     // reads at every join, the prefetched ones included)
-    // D16: step kk = (k-step kk >> 1 of 32 channels, half kk & 1 of the wave's 16-position tiles): NT reads and 4 NT
-    // MFMAs of 16 cycles per step -- the same reads and MFMA cycles per step as the 32x32x16 form, the same pipeline
+    // step kk = (k-step kk >> 1 of 32 channels, half kk & 1 of the wave's 16-position tiles): NT reads and 4 NT MFMAs of
+    // 16 cycles per step
     auto bfrag = [&](int st, int kk, V (&pf)[NT]) {
       if ((S2A_ABL & 128) && st > 0) return;           // timing only: the fragments of stage 0 serve every stage
-      if constexpr (D16) {
-        const char* prow = s_B + (st & 1) * (NPOS * kRowBytes) + ((kk & 1) * NT * 16 + pix16) * kRowBytes + (kg16 & 1) * 64 + (kg16 >> 1) * 16 + (kk >> 1) * 32;
+      const char* prow = s_B + (st & 1) * (NPOS * kRowBytes) + ((kk & 1) * NT * 16 + pix16) * kRowBytes + (kg16 & 1) * 64 + (kg16 >> 1) * 16 + (kk >> 1) * 32;
 #pragma unroll
-        for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 16 * kRowBytes);
-        return;
-      }
-      const char* prow = s_B + (st & 1) * (NPOS * kRowBytes) + (lane & 31) * kRowBytes + (lane >> 5) * 16;
-#pragma unroll
-      for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 32 * kRowBytes + kk * 32);
+      for (int h = 0; h < NT; h++) pf[h] = *reinterpret_cast<const V*>(prow + h * 16 * kRowBytes);
     };
     auto mma = [&](const V (&wv)[WR][4], int kk, const V (&pf)[NT]) {
       if (S2A_ABL & 4) return;
-      if constexpr (D16) {
-        const int ks = kk >> 1, bh = (kk & 1) * NT;
+      const int ks = kk >> 1, bh = (kk & 1) * NT;
 #pragma unroll
-        for (int a = 0; a < AH; a++)
-#pragma unroll
-          for (int b = 0; b < NT; b++)
-            acc16[a][bh + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[(a * 2 + ks) >> 2][(a * 2 + ks) & 3], pf[b], acc16[a][bh + b], 0, 0, 0);
-        return;
-      }
-#pragma unroll
-      for (int a = 0; a < 2; a++)
+      for (int a = 0; a < AH; a++)
 #pragma unroll
         for (int b = 0; b < NT; b++)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[a][kk], pf[b], acc[a][b], 0, 0, 0);
+          acc16[a][bh + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[(a * 2 + ks) >> 2][(a * 2 + ks) & 3], pf[b], acc16[a][bh + b], 0, 0, 0);
     };
     auto stage = [&](int st, const V (&wv)[WR][4]) {
       bfrag(st, 1, p1); __builtin_amdgcn_sched_barrier(0);
@@ -1148,27 +1063,6 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
       stage(s + 1, wB);
     }
     if (s < nstage) stage(s, wA);
-#else
-    for (; s + 1 < nstage; s += 2) {
-      S2A_TIC();
-      load_w(s + 1, wB);
-      compute(s, wA);
-      S2A_TOC(t_work); S2A_TIC();
-      __syncthreads();
-      S2A_TOC(t_wait); S2A_TIC();
-      load_w(min(s + 2, last), wA);
-      compute(s + 1, wB);
-      S2A_TOC(t_work); S2A_TIC();
-      __syncthreads();
-      S2A_TOC(t_wait);
-    }
-    if (s < nstage) {
-      compute(s, wA);
-      __syncthreads();
-    }
-    S2A_STAMP_VAL(6, t_work);
-    S2A_STAMP_VAL(7, t_wait);
-#endif
   } else {
     // ===================== loader waves =====================
     auto patch_issue = [&](int cc) {
@@ -1271,126 +1165,57 @@ __device__ __forceinline__ void dcn_patch_tile(const _Float16* __restrict__ x_,
   };
   if ((S2A_ABL & 1) && relu != 12345) return;
   if constexpr (OUT_NHWC) {
-    // Stage the 128 x 256 tile through LDS (the patch buffers are free now) and store whole
-    // 512-byte position rows, 16 B per lane, instead of 2-byte scattered stores.
-    char* s_out = s_patch;
-    if constexpr (DST) {
-      // straight from the accumulators (filter rows permuted by k_pack_weight_frag16): lane (pixel pix16 of 16-position tile b,
-      // kg16) holds out channels 8 kg16 .. +7 (fragments 0, 1) and 32 + 8 kg16 .. +7 (fragments 2, 3) of its wave's 64
-      // ReLU on the rounded halves, two per instruction (rounding is monotonic and keeps zero and sign: max(round(v), 0) ==
-      // round(max(v, 0)); a NaN becomes 0 either way), and the ReLU switch as ONE uniform branch around the tile: with
-      // fmaxf + a per-value select on the f32 accumulators the epilogue was 800 instructions, 5.3 k of a tile's 87 k cycles
-      auto store_tile = [&](auto relu_c) {
-        constexpr bool kRelu = decltype(relu_c)::value;
-        using h2 = __attribute__((ext_vector_type(2))) _Float16;
-        // tile position 16 b + pix16 = (row ty0 + b, column tx0 + pix16): one address, then a row pitch per b
-        auto pack8 = [&](int b, int hf) {
-          V v8;
+    // straight from the accumulators (filter rows permuted by k_pack_weight_frag16): lane (pixel pix16 of 16-position tile b,
+    // kg16) holds out channels 8 kg16 .. +7 (fragments 0, 1) and 32 + 8 kg16 .. +7 (fragments 2, 3) of its wave's 64 -- two
+    // 16-byte stores per pixel, no LDS staging, no barrier (the LDS-staged whole-row form measured +1 %).
+    // ReLU on the rounded halves, two per instruction (rounding is monotonic and keeps zero and sign: max(round(v), 0) ==
+    // round(max(v, 0)); a NaN becomes 0 either way), and the ReLU switch as ONE uniform branch around the tile: with
+    // fmaxf + a per-value select on the f32 accumulators the epilogue was 800 instructions, 5.3 k of a tile's 87 k cycles
+    auto store_tile = [&](auto relu_c) {
+      constexpr bool kRelu = decltype(relu_c)::value;
+      using h2 = __attribute__((ext_vector_type(2))) _Float16;
+      // tile position 16 b + pix16 = (row ty0 + b, column tx0 + pix16): one address, then a row pitch per b
+      auto pack8 = [&](int b, int hf) {
+        V v8;
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const f32x4& a4 = acc16[D16 ? 2 * hf + (i >> 1) : 0][D16 ? b : 0];
-            h2 v = {(_Float16)a4[2 * (i & 1)], (_Float16)a4[2 * (i & 1) + 1]};
-            if constexpr (kRelu) v = __builtin_elementwise_max(v, h2{(_Float16)0.f, (_Float16)0.f});
-            v8[2 * i] = v[0];
-            v8[2 * i + 1] = v[1];
-          }
-          return v8;
-        };
-        const int xq = tx0 + pix16;
-        int64_t gp = bimg * HW + (int64_t)ty0 * W + xq;
-        _Float16* orow = out + o0 + (wave & 3) * 64 + 8 * kg16 + gp * O;
-        const int64_t pitch = (int64_t)W * O;
-#pragma unroll
-        for (int b = 0; b < 2 * NT; b++, gp += W, orow += pitch) {
-          const bool ok = xq < W && ty0 + b < H && gp < Ntot;
-#pragma unroll
-          for (int hf = 0; hf < AH / 2; hf++)
-            if (ok) *reinterpret_cast<V*>(orow + 32 * hf) = pack8(b, hf);
+        for (int i = 0; i < 4; i++) {
+          const f32x4& a4 = acc16[2 * hf + (i >> 1)][b];
+          h2 v = {(_Float16)a4[2 * (i & 1)], (_Float16)a4[2 * (i & 1) + 1]};
+          if constexpr (kRelu) v = __builtin_elementwise_max(v, h2{(_Float16)0.f, (_Float16)0.f});
+          v8[2 * i] = v[0];
+          v8[2 * i + 1] = v[1];
         }
+        return v8;
       };
-      if (wave_active) {
-        if (relu & 1) store_tile(std::true_type{}); else store_tile(std::false_type{});
+      const int xq = tx0 + pix16;
+      int64_t gp = bimg * HW + (int64_t)ty0 * W + xq;
+      _Float16* orow = out + o0 + (wave & 3) * 64 + 8 * kg16 + gp * O;
+      const int64_t pitch = (int64_t)W * O;
+#pragma unroll
+      for (int b = 0; b < 2 * NT; b++, gp += W, orow += pitch) {
+        const bool ok = xq < W && ty0 + b < H && gp < Ntot;
+#pragma unroll
+        for (int hf = 0; hf < AH / 2; hf++)
+          if (ok) *reinterpret_cast<V*>(orow + 32 * hf) = pack8(b, hf);
       }
-      S2A_STAMP_AT(5);
-      if (wave == 0) S2A_STAMP_VAL(7, __builtin_amdgcn_s_memrealtime());
-      return;
-    }
-    const bool relu_u = __builtin_amdgcn_readfirstlane(relu & 1) != 0;
-    if (D16 && wave_active) {
-      using h4 = __attribute__((ext_vector_type(4))) _Float16;
-#pragma unroll
-      for (int a = 0; a < (D16 ? 4 : 0); a++)
-#pragma unroll
-        for (int b = 0; b < 2 * NT; b++) {
-          using h2s = __attribute__((ext_vector_type(2))) _Float16;
-          const f32x4& a4 = acc16[D16 ? a : 0][D16 ? b : 0];
-          h2s v01 = {(_Float16)a4[0], (_Float16)a4[1]}, v23 = {(_Float16)a4[2], (_Float16)a4[3]};
-          if (relu_u) {
-            v01 = __builtin_elementwise_max(v01, h2s{(_Float16)0.f, (_Float16)0.f});
-            v23 = __builtin_elementwise_max(v23, h2s{(_Float16)0.f, (_Float16)0.f});
-          }
-          const h4 v4 = {v01[0], v01[1], v23[0], v23[1]};
-          *reinterpret_cast<h4*>(s_out + (16 * b + pix16) * kOutRow + (wave * 64 + 16 * a + 4 * kg16) * 2) = v4;
-        }
-    } else if (wave_active) {
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < NT; b++)
-#pragma unroll
-          for (int rq = 0; rq < 4; rq++) {
-            using h4 = __attribute__((ext_vector_type(4))) _Float16;
-            h4 v4;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              float v = acc[a][b][rq * 4 + e];
-              if (relu & 1) v = fmaxf(v, 0.f);
-              v4[e] = (_Float16)v;
-            }
-            int och = wave * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);   // rows (r&3)+8*(r>>2)+4*(lane>>5)
-            int pos = 32 * b + (lane & 31);
-            *reinterpret_cast<h4*>(s_out + pos * kOutRow + och * 2) = v4;
-          }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NPOS / 16; i++) {
-      int idx = tid + 512 * i, pos = idx >> 5, col = idx & 31;
-      int64_t gp = out_pos(pos);
-      if (gp >= 0 && col * 8 < Oloc)
-        *reinterpret_cast<V*>(out + gp * O + o0 + col * 8) = *reinterpret_cast<const V*>(s_out + pos * kOutRow + col * 16);
+    };
+    if (wave_active) {
+      if (relu & 1) store_tile(std::true_type{}); else store_tile(std::false_type{});
     }
     S2A_STAMP_AT(5);
+    if (wave == 0) S2A_STAMP_VAL(7, __builtin_amdgcn_s_memrealtime());
   } else {
     if (!wave_active) return;
-    if constexpr (D16) {
 #pragma unroll
-      for (int a = 0; a < 4; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 2 * NT; b++)
+      for (int b = 0; b < 2 * NT; b++)
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            float v = acc16[a][b][e];
-            if (relu & 1) v = fmaxf(v, 0.f);
-            const int och = o0 + wave * 64 + (DST ? 32 * (a >> 1) + 8 * kg16 + 4 * (a & 1) : 16 * a + 4 * kg16) + e;
-            const int64_t gp = out_pos(16 * b + pix16);
-            if (gp >= 0) {
-              int64_t bi = gp / HW, p = gp % HW;
-              out[(bi * O + och) * HW + p] = (T)v;
-            }
-          }
-      return;
-    }
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < NT; b++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          float v = acc[a][b][r];
+        for (int e = 0; e < 4; e++) {
+          float v = acc16[a][b][e];
           if (relu & 1) v = fmaxf(v, 0.f);
-          int och = o0 + wave * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          int64_t gp = out_pos(32 * b + (lane & 31));
+          const int och = o0 + wave * 64 + 32 * (a >> 1) + 8 * kg16 + 4 * (a & 1) + e;
+          const int64_t gp = out_pos(16 * b + pix16);
           if (gp >= 0) {
             int64_t bi = gp / HW, p = gp % HW;
             out[(bi * O + och) * HW + p] = (T)v;
@@ -1422,7 +1247,7 @@ struct PatchArgs {
 };
 template <bool OUT_NHWC, int SRC, int TH = 8>
 __global__ __launch_bounds__(512, 2) void k_dcn_patch(PatchArgs a) {
-  if constexpr (TH == 8 && OUT_NHWC && SRC == 1 && S2A_DCN_MIXED != 0) {
+  if constexpr (TH == 8 && OUT_NHWC && SRC == 1) {
     if (a.n_full != 0 && blockIdx.x >= a.n_full) {      // (uniform)
       dcn_patch_tile<OUT_NHWC, SRC, 4>(a.x, a.src, a.wfrag, a.out, a.Ntot, a.C, a.H, a.W, a.O, a.stride, a.relu, a.x_bytes, a.lt,
                                            (int)a.n_full, blockIdx.x - a.n_full, gridDim.x - a.n_full, threadIdx.x);
@@ -1431,412 +1256,6 @@ __global__ __launch_bounds__(512, 2) void k_dcn_patch(PatchArgs a) {
   }
   dcn_patch_tile<OUT_NHWC, SRC, TH>(a.x, a.src, a.wfrag, a.out, a.Ntot, a.C, a.H, a.W, a.O, a.stride, a.relu, a.x_bytes, a.lt,
                                         a.tile_base, blockIdx.x, a.n_full ? a.n_full : gridDim.x, threadIdx.x);
-}
-
-// ------------------------------------------------------------------ symmetric 16 x 16-tile AlignConv (f16; round 4)
-// k_dcn_patch pairs ONE matrix wave with ONE loader wave per SIMD: each role alone needs ~1.5 k cycles of its own work
-// per 1.0 k cycles of MFMA (stamps) and an in-order wave has nothing to put into its own stalls.  Here every
-// wave does both jobs on a tile of twice the size, the way the conv towers run (two matrix waves per SIMD):
-//   * tile = 16 x 16 positions x 256 out channels, 8 waves: wave = (out-channel group of 64, tile rows 0-7 | 8-15)
-//   * a stage = one tap x 32 input channels = ONE k-step of v_mfma_f32_16x16x32_f16: 32 MFMAs per wave; the 32-channel
-//     patch around the tile (24 x 24 pixels x 64 B = 36 KB) is double-buffered and arrives by LDS-DMA (no registers)
-//   * in every stage interval a wave blends its 2 of the 1024 (position, 8-channel group) items of the NEXT stage's column
-//     tile and contracts the CURRENT one; waves 0-3 blend first, waves 4-7 contract first (SIMD partners are w and w+4),
-//     so that one partner's MFMAs run beside the other's LDS / VALU work instead of both queueing for the matrix pipe
-//   * the filter comes in its own fragment order (k_pack_weight_sym): one contiguous 1 KB load per 16-channel tile, and
-//     the out-channel <-> MFMA-row map is chosen so that a lane ends up with 16 CONSECUTIVE out channels of one pixel:
-//     the epilogue stores straight from the accumulators (two 16-byte stores per pixel and lane, no LDS staging)
-// Summation order: 32-channel chunks outermost, taps inside (k_dcn_patch: 64-channel chunks, taps, two k-steps) -- the two
-// kernels agree within f32 accumulation noise, not bit for bit; both are checked against the oracle with the same bound.
-constexpr int kSymPW = 24;                                  // patch: 16 + 2 * kHalo pixels each way
-constexpr int kSymPatchBytes = kSymPW * kSymPW * 64;        // 36 864 (32 channels)
-constexpr int kSymPieces = kSymPatchBytes / 1024;           // 36 LDS-DMA pieces
-constexpr int kSymBRow = 96;                                // column-tile row: 64 B + 32 B pad (conflict-free B fragments:
-                                                            // slot = 6 * position + k-group mod 16, see the lane groups above)
-constexpr int kSymBBytes = 256 * kSymBRow;                  // 24 576
-constexpr int kSymTabBytes = 256 * 9 * 16;                  // 36 864
-constexpr int kSymLds = kSymTabBytes + 2 * kSymBBytes + 2 * kSymPatchBytes;   // 159 744 B
-
-// weight [O][C][9] f16 -> [stage = c32*9 + t][och group of 64][a 4][lane 64][8 halfs]: lane (i = l & 15, kg = l >> 4),
-// element j of fragment a = W[g*64 + 16*(i >> 2) + 4*a + (i & 3)][32*c32 + 8*kg + j][t]
-__global__ void k_pack_weight_sym(const _Float16* __restrict__ w, int O, int C, _Float16* __restrict__ wp) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)O * C * 9) return;
-  const int G = O / 64;
-  const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), a = (int)((e >> 9) & 3);
-  const int64_t r = e >> 11;
-  const int g = (int)(r % G), st = (int)(r / G), t = st % 9, c32 = st / 9;
-  const int i = lane & 15, kg = lane >> 4;
-  const int och = g * 64 + 16 * (i >> 2) + 4 * a + (i & 3);
-  const int k = c32 * 32 + 8 * kg + j;
-  wp[e] = w[((int64_t)och * C + k) * 9 + t];
-}
-
-__global__ __launch_bounds__(512, 2) void k_dcn_sym(const _Float16* __restrict__ x_, const float* __restrict__ src_,
-                                                    const _Float16* __restrict__ wsym, _Float16* __restrict__ out_,
-                                                    int C, int O, int relu, LevelTab lt) {
-  using T = _Float16;
-  using V = f16x8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  PTap* s_tab = reinterpret_cast<PTap*>(smem);
-  char* s_B = smem + kSymTabBytes;
-  char* s_patch = s_B + 2 * kSymBBytes;
-  const bool half_coords = (relu & 2) != 0;          // relu: bit 0 = ReLU epilogue, bit 1 = S2A_DCN_HALF_COORDS
-  auto rh16 = [](float v) { return (float)(_Float16)v; };
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave & 3, blk = wave >> 2;
-  int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
-  int H = 1, W = 1, t0 = 0, p0 = 0;
-  float stride = 1.f;
-#pragma unroll
-  for (int i = 0; i < kMaxLevels; i++)
-    if (i < lt.n && tile >= lt.tile0[i]) {
-      t0 = lt.tile0[i]; p0 = lt.pix0[i]; H = lt.H[i]; W = lt.W[i]; stride = lt.stride[i];
-    }
-  tile -= t0;
-  const int64_t Ntot = (int64_t)lt.batch * H * W;
-  const T* x = x_ + (int64_t)p0 * C;
-  T* out = out_ + (int64_t)p0 * O;
-  const float* src = src_ + (int64_t)p0 * 5;
-  const unsigned x_bytes = (unsigned)(Ntot * C * 2);
-  const int64_t HW = (int64_t)H * W;
-  const int txn = (W + 15) / 16, tyn = (H + 15) / 16;
-  const int64_t bimg = tile / (txn * tyn);
-  const int trem = (int)(tile % (txn * tyn));
-  const int ty0 = (trem / txn) * 16, tx0 = (trem % txn) * 16;
-  const int oy = ty0 - kHalo, ox = tx0 - kHalo;
-  const int o0 = blockIdx.y * kMaxO;
-  const int Oloc = min(kMaxO, O - o0);
-  const int G = O / 64, NC = C / 32, nstage = 9 * NC, last = nstage - 1;
-  const unsigned row_bytes = (unsigned)C * 2;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
-
-  // ---- patch chunk c (32 channels) -> LDS, 1 KB pieces (36 per chunk): slot v = piece * 64 + lane = pixel * 4 + 16-byte
-  // group; pixels outside the image get an out-of-range offset (zeros).  Through a register, not LDS-DMA: behind a DMA the
-  // compiler cannot tell which LDS reads it may alias and puts s_waitcnt vmcnt(0) in front of EVERY ds_read of the loop
-  // (each blend then waited for the filter fragments that had just been requested).  One piece per wave and stage
-  // interval at taps 0-4, written to LDS an interval later; every consumer of a vector-memory result of the loop sits
-  // behind the interval's barrier, so the conservative vmcnt(0) hipcc places behind a branch with a load costs nothing.
-  unsigned pvoff[5];
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    const int i = wave + 8 * j, v = i * 64 + lane, p = v >> 2, q = v & 3;
-    const int yy = oy + p / kSymPW, xx = ox + p % kSymPW;
-    const bool in = i < kSymPieces && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    pvoff[j] = in ? (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16) : 0x80000000u;
-  }
-  auto piece_load = [&](int c, int j) -> V {
-    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)pvoff[j], c * 64, 0));
-  };
-  auto piece_store = [&](int c, int i, const V& v) {
-    if (i < kSymPieces) *reinterpret_cast<V*>(s_patch + (c & 1) * kSymPatchBytes + (i * 64 + lane) * 16) = v;
-  };
-  S2A_STAMP_AT(0);
-  V pv0[5];
-#pragma unroll
-  for (int j = 0; j < 5; j++) pv0[j] = piece_load(0, j);
-
-  // ---- filter fragments: global -> registers, one stage ahead
-  const int g = min(o0 / 64 + grp, G - 1);
-  const V* wbase = reinterpret_cast<const V*>(wsym) + (int64_t)g * 256 + lane;
-  auto load_w = [&](int st, V (&wv)[4]) {
-    const V* p = wbase + (int64_t)st * G * 256;
-#pragma unroll
-    for (int a = 0; a < 4; a++) wv[a] = p[a * 64];
-  };
-  V wA[4], wN[4];
-  load_w(0, wA);
-
-  // ---- per-position anchor context, then the sampling table (same arithmetic as k_dcn_patch)
-  AnchorCtx* s_ctx = reinterpret_cast<AnchorCtx*>(s_B);
-  if (tid < 256) {
-    const int y = ty0 + (tid >> 4), xq = tx0 + (tid & 15);
-    AnchorCtx c = {0, 0, 0, 0, 1, 0};
-    if (y < H && xq < W) c = anchor_ctx(src + (bimg * HW + (int64_t)y * W + xq) * 5, stride);
-    s_ctx[tid] = c;
-  }
-  __syncthreads();
-  for (int e = tid; e < 256 * 9; e += 512) {
-    const int pl = e / 9, t = e % 9;
-    const int y = ty0 + (pl >> 4), xq = tx0 + (pl & 15);
-    PTap tp;
-    tp.y = (short)oy;
-    tp.x = (short)ox;
-    tp.flags = 1u;
-#pragma unroll
-    for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
-    if (y < H && xq < W) {
-      const int ky = t / 3, kx = t % 3;
-      float off_y, off_x;
-      anchor_offset(s_ctx[pl], ky, kx, (float)y, (float)xq, off_y, off_x);
-      if (half_coords) { off_y = rh16(off_y); off_x = rh16(off_x); }
-      float h_im = (float)(y - 1 + ky) + off_y;
-      float w_im = (float)(xq - 1 + kx) + off_x;
-      if (half_coords) { h_im = rh16(h_im); w_im = rh16(w_im); }
-      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
-        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        float lh = h_im - h_low, lw = w_im - w_low;
-        if (half_coords) { lh = rh16(lh); lw = rh16(lw); }
-        float hh = 1 - lh, hw = 1 - lw;
-        if (half_coords) { hh = rh16(hh); hw = rh16(hw); }
-        const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
-        tp.w[0] = (_Float16)((t_ok && l_ok) ? hh * hw : 0.f);
-        tp.w[1] = (_Float16)((t_ok && r_ok) ? hh * lw : 0.f);
-        tp.w[2] = (_Float16)((b_ok && l_ok) ? lh * hw : 0.f);
-        tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
-        tp.y = (short)h_low;
-        tp.x = (short)w_low;
-        const bool in = h_low >= oy && h_low + 1 <= oy + kSymPW - 1 && w_low >= ox && w_low + 1 <= ox + kSymPW - 1;
-        const int py = min(max(h_low - oy, 0), kSymPW - 2), px = min(max(w_low - ox, 0), kSymPW - 2);
-        tp.flags = (in ? 1u : 0u) | ((unsigned)((py * kSymPW + px) * 64) << 1);
-      }
-    }
-    s_tab[e] = tp;
-  }
-#pragma unroll
-  for (int j = 0; j < 5; j++) piece_store(0, wave + 8 * j, pv0[j]);
-  S2A_STAMP_AT(1);
-  __syncthreads();   // table + patch 0 in LDS; s_ctx is dead
-  S2A_STAMP_AT(2);
-
-  // ---- column tile of stage st (tap st % 9 of chunk st / 9): this thread's two (position, 8-channel group) items
-  auto blend = [&](int st, int t, int c) {
-    const char* P = s_patch + (c & 1) * kSymPatchBytes;
-    char* Bm = s_B + (st & 1) * kSymBBytes;
-    PTap tp[2];
-    V cv[2][4];
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const int item = tid + 512 * it, pl = item >> 2, q = item & 3;
-      tp[it] = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + t]));
-      const char* b0 = P + (tp[it].flags >> 1) + q * 16;
-      cv[it][0] = *reinterpret_cast<const V*>(b0);
-      cv[it][1] = *reinterpret_cast<const V*>(b0 + 64);
-      cv[it][2] = *reinterpret_cast<const V*>(b0 + kSymPW * 64);
-      cv[it][3] = *reinterpret_cast<const V*>(b0 + kSymPW * 64 + 64);
-    }
-    bool any_out = false;
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const int item = tid + 512 * it, pl = item >> 2, q = item & 3;
-      const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
-      *reinterpret_cast<V*>(Bm + pl * kSymBRow + q * 16) = blend_pk(cv[it], cw);
-      any_out |= !(tp[it].flags & 1u);
-    }
-    if (any_out) {     // rare: a corner left the patch -> global gather for that (position, tap)
-      for (int it = 0; it < 2; it++) {
-        if (tp[it].flags & 1u) continue;
-        const int item = tid + 512 * it, pl = item >> 2, q = item & 3;
-        V g4[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int yy = min(max((int)tp[it].y + (k >> 1), 0), H - 1), xx = min(max((int)tp[it].x + (k & 1), 0), W - 1);
-          const unsigned vo = (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16);
-          g4[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, c * 64, 0));
-        }
-        const float cw[4] = {(float)tp[it].w[0], (float)tp[it].w[1], (float)tp[it].w[2], (float)tp[it].w[3]};
-        *reinterpret_cast<V*>(Bm + pl * kSymBRow + q * 16) = blend_pk(g4, cw);
-      }
-    }
-  };
-
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 8; b++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) acc[a][b][r] = 0.f;
-  const int i16 = lane & 15, kg16 = lane >> 4;
-  const int boff = (blk * 128 + i16) * kSymBRow + kg16 * 16;      // b-tile b = tile row 8 * blk + b: + b * 16 rows
-  auto mma = [&](int st, const V (&wv)[4]) {
-    const char* Bm = s_B + (st & 1) * kSymBBytes + boff;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {          // four b-tiles at a time: 16 registers of fragments instead of 32
-      V pf[4];
-#pragma unroll
-      for (int b = 0; b < 4; b++) pf[b] = *reinterpret_cast<const V*>(Bm + (4 * h + b) * 16 * kSymBRow);
-#pragma unroll
-      for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-          acc[a][4 * h + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[a], pf[b], acc[a][4 * h + b], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  V pv;                                        // the patch piece in flight (requested in one interval, stored in the next)
-  // One stage interval of a wave: contract stage st AND blend this thread's two items of stage st + 1 (tap tn of chunk cn),
-  // as ONE instruction stream in two halves -- LDS requests first (four B fragments, the item's table entry, then its four
-  // corners), sixteen MFMAs with the blend's packed FMAs issued between them (an MFMA occupies the matrix pipe for 16
-  // cycles but the issue port for 8: an in-order wave can put two vector instructions into every gap), the column store
-  // last.  Written as separate blend / contract phases each wave needed ~650 + ~650-1200 cycles per interval for 512
-  // cycles of MFMA (stamps); sched_group_barrier pins the interleaving, hipcc otherwise clusters the MFMAs.
-  // Items whose corners left the patch are redone from global memory afterwards (rare).
-  auto fused = [&](int st, const V (&wv)[4], int tn, int cn, V (&wn)[4], const V* wnp, unsigned pvo, int psoff) {
-    const char* Bc = s_B + (st & 1) * kSymBBytes + boff;
-    const char* P = s_patch + (cn & 1) * kSymPatchBytes;
-    char* Bn = s_B + ((st + 1) & 1) * kSymBBytes;
-    unsigned all_in = 1u;
-#define S2A_SB() __builtin_amdgcn_sched_barrier(0)
-#define S2A_BF(B_) pf[B_] = *reinterpret_cast<const V*>(Bc + (B_) * 16 * kSymBRow)
-#define S2A_MMA4(B_)                                                                                             \
-  acc[0][B_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[0], pf[B_], acc[0][B_], 0, 0, 0);                       \
-  acc[1][B_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[1], pf[B_], acc[1][B_], 0, 0, 0);                       \
-  acc[2][B_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[2], pf[B_], acc[2][B_], 0, 0, 0);                       \
-  acc[3][B_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[3], pf[B_], acc[3][B_], 0, 0, 0)
-#define S2A_BLEND2(E0_)                                                                                          \
-  _Pragma("unroll") for (int e = (E0_); e < (E0_) + 2; e++) {                                                    \
-    const f16x2 a0 = {cv[0][2 * e], cv[0][2 * e + 1]}, a1 = {cv[1][2 * e], cv[1][2 * e + 1]};                    \
-    const f16x2 a2 = {cv[2][2 * e], cv[2][2 * e + 1]}, a3 = {cv[3][2 * e], cv[3][2 * e + 1]};                    \
-    f16x2 sacc = w0 * a0;                           /* explicit FMAs in the reference's order, as blend_pk */    \
-    sacc = __builtin_elementwise_fma(w1, a1, sacc);                                                              \
-    sacc = __builtin_elementwise_fma(w2, a2, sacc);                                                              \
-    sacc = __builtin_elementwise_fma(w3, a3, sacc);                                                              \
-    r[2 * e] = sacc[0];                                                                                          \
-    r[2 * e + 1] = sacc[1];                                                                                      \
-  }
-    // Eight groups of four MFMAs (one 16-position tile against the wave's four 16-channel filter fragments = 64 cycles of
-    // the matrix pipe), pinned in order by sched_barrier; around them, two groups ahead of their use, the LDS requests:
-    // the next fragments, the item's table entry, then its four corners; the item's packed FMAs ride in the groups
-    // behind.  Item 0 lives in groups 0-3, item 1 in groups 4-7; three fragments, one item's corners in flight at a time.
-    V pf[8], cv[4], r;
-    PTap tp;
-    f16x2 w0, w1, w2, w3;
-    int pl, q;
-    S2A_BF(0); S2A_BF(1);
-    pl = tid >> 2; q = tid & 3;
-    tp = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + tn]));
-    S2A_SB();
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      // group 4h: fragments + 2, corners of item h (its table entry was requested two groups ago)
-      // (the interval's five vector-memory requests -- next stage's four filter fragments, one patch piece -- are spread
-      // over groups 0-2, the patch piece first: at the head of the interval they cost every wave 0.5-0.7 k cycles of issue with the matrix pipe
-      // idle, 40 requests of 1 KB per CU against a request path of 64 B per clock)
-      S2A_MMA4(4 * h);
-      S2A_BF(4 * h + 2);
-      if (h == 0) {      // (the patch piece first: the next interval stores it before anything else)
-        pv = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)pvo, psoff, 0));
-        wn[0] = wnp[0];
-      }
-      {
-        const char* b0 = P + (tp.flags >> 1) + q * 16;
-        cv[0] = *reinterpret_cast<const V*>(b0);
-        cv[1] = *reinterpret_cast<const V*>(b0 + 64);
-        cv[2] = *reinterpret_cast<const V*>(b0 + kSymPW * 64);
-        cv[3] = *reinterpret_cast<const V*>(b0 + kSymPW * 64 + 64);
-        w0 = f16x2{tp.w[0], tp.w[0]}; w1 = f16x2{tp.w[1], tp.w[1]}; w2 = f16x2{tp.w[2], tp.w[2]}; w3 = f16x2{tp.w[3], tp.w[3]};
-        all_in &= tp.flags;
-      }
-      S2A_SB();
-      // group 4h + 1: fragments + 2; the NEXT item's table entry
-      S2A_MMA4(4 * h + 1);
-      S2A_BF(4 * h + 3);
-      if (h == 0) { wn[1] = wnp[64]; wn[2] = wnp[128]; }
-      const int plw = pl, qw = q;
-      if (h == 0) {
-        pl = (tid + 512) >> 2; q = tid & 3;
-        tp = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + tn]));
-      }
-      S2A_SB();
-      // group 4h + 2: first half of the item's blend
-      S2A_MMA4(4 * h + 2);
-      if (h == 0) { S2A_BF(4); wn[3] = wnp[192]; }
-      S2A_BLEND2(0)
-      S2A_SB();
-      // group 4h + 3: second half, column store
-      S2A_MMA4(4 * h + 3);
-      if (h == 0) S2A_BF(5);
-      S2A_BLEND2(2)
-      *reinterpret_cast<V*>(Bn + plw * kSymBRow + qw * 16) = r;
-      S2A_SB();
-    }
-#undef S2A_BLEND2
-#undef S2A_MMA4
-#undef S2A_BF
-#undef S2A_SB
-    if (__builtin_amdgcn_ballot_w64(!(all_in & 1u)) != 0) {     // rare: a corner left the patch -> global gather
-      for (int h = 0; h < 2; h++) {
-        const int item = tid + 512 * h, pl = item >> 2, q = item & 3;
-        const PTap tp = __builtin_bit_cast(PTap, *reinterpret_cast<const u32x4*>(&s_tab[pl * 9 + tn]));
-        if (tp.flags & 1u) continue;
-        V g4[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int yy = min(max((int)tp.y + (k >> 1), 0), H - 1), xx = min(max((int)tp.x + (k & 1), 0), W - 1);
-          const unsigned vo = (unsigned)((bimg * HW + (int64_t)yy * W + xx) * row_bytes + q * 16);
-          g4[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, cn * 64, 0));
-        }
-        *reinterpret_cast<V*>(Bn + pl * kSymBRow + q * 16) = blend_pk_h(g4, tp.w);
-      }
-    }
-  };
-
-  pv = pv0[0];
-  blend(0, 0, 0);
-  __syncthreads();
-  S2A_STAMP_AT(3);
-  unsigned long long t_tic = 0, t_blend = 0, t_mma = 0, t_wait = 0;
-  (void)t_tic; (void)t_blend; (void)t_mma; (void)t_wait;
-  // one interval per stage: contract stage s, blend stage s + 1; filter fragments of s + 1 and (at a chunk's first tap) the
-  // patch of the chunk after the next one's predecessor ... i.e. chunk s/9 + 1 into the buffer chunk s/9 - 1 left
-#define S2A_SYM_STEP(S_, WC, WN)                                                       \
-  {                                                                                    \
-    const int s_ = (S_);                                                               \
-    /* next chunk's patch, one piece per wave and interval: requested at taps 0-4, written at taps 1-5 (its buffer   \
-       was last read two intervals before tap 0; the chunk is first read in the interval of tap 8) */                \
-    if (tcur >= 1 && tcur <= 5 && ccur + 1 < NC) piece_store(ccur + 1, wave + 8 * (tcur - 1), pv);                   \
-    const unsigned vo_ = !(tcur < 5 && ccur + 1 < NC) ? 0x80000000u                                                  \
-                         : tcur == 0 ? pvoff[0] : tcur == 1 ? pvoff[1] : tcur == 2 ? pvoff[2] : tcur == 3 ? pvoff[3] : pvoff[4]; \
-    const V* wnp_ = wbase + (int64_t)min(s_ + 1, last) * G * 256;                      \
-    /* stage s + 1 (behind the last stage: the last one again -- its columns go to the buffer nobody reads any more) */ \
-    const int tn_ = s_ == last ? tcur : (tcur == 8 ? 0 : tcur + 1), cn_ = s_ == last ? ccur : (tcur == 8 ? ccur + 1 : ccur); \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    S2A_TIC();                                                                         \
-    fused(s_, WC, tn_, cn_, WN, wnp_, vo_, (ccur + 1) * 64);                           \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    S2A_TOC(t_mma); S2A_TIC();                                                         \
-    __syncthreads();                                                                   \
-    S2A_TOC(t_wait);                                                                   \
-    tcur = tn_; ccur = cn_;                                                            \
-  }
-  int tcur = 0, ccur = 0;                    // tap and chunk of the stage being contracted
-  // static priority for the younger half (waves 4-7 lose the issue arbitration to their SIMD partners 0-3: their interval
-  // took 1.58 k cycles against 1.13 k, the partner waiting at the barrier; MI355X_MICROARCH.md, two waves per SIMD (4))
-  if (blk != 0 && !(relu & 4)) __builtin_amdgcn_s_setprio(1);      // (relu bit 2: A/B switch, S2A_DCN_SYM_NOPRIO=1)
-  for (int s = 0; s < nstage; s += 2) {      // nstage = 9 * C / 32 is even (C % 64 == 0)
-    S2A_SYM_STEP(s, wA, wN)
-    S2A_SYM_STEP(s + 1, wN, wA)
-  }
-#undef S2A_SYM_STEP
-  S2A_STAMP_AT(4);
-  S2A_STAMP_VAL(5, t_mma);
-  S2A_STAMP_VAL(6, t_blend);
-  S2A_STAMP_VAL(7, t_wait);
-
-  // ---- epilogue: ReLU, f16, straight from the accumulators: lane (pixel i16 of tile row 8 * blk + b, kg16) holds
-  // out channels grp*64 + 16*kg16 + 4*a + e -- 16 consecutive ones
-  if (grp * 64 >= Oloc) return;
-#pragma unroll
-  for (int b = 0; b < 8; b++) {
-    const int y = ty0 + 8 * blk + b, xq = tx0 + i16;
-    V lo, hi;
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        float v = acc[a][b][e];
-        if (relu & 1) v = fmaxf(v, 0.f);
-        if (a < 2) lo[4 * a + e] = (_Float16)v; else hi[4 * (a - 2) + e] = (_Float16)v;
-      }
-    if (y < H && xq < W) {
-      T* o = out + (bimg * HW + (int64_t)y * W + xq) * O + o0 + grp * 64 + 16 * kg16;
-      *reinterpret_cast<V*>(o) = lo;
-      *reinterpret_cast<V*>(o + 8) = hi;
-    }
-  }
 }
 
 // ------------------------------------------------------------------ regular convolutions (f16)
@@ -1996,17 +1415,10 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   V wt[2][4];                                        // TAIL: this wave's 64 x 64 block of the 1x1 filter
   if constexpr (TAIL) {
     if (tid < 256) tail_bias_v = ex.tail_b[tid];
-    if constexpr (S2A_CONV_M16 == 1 || S2A_CONV_M16 == 3) {   // 16x16x32 fragments (f = 16-channel tile * 2 + k-step), as the stand-alone 1x1 takes them
-      const V* tp = reinterpret_cast<const V*>(ex.tail_w) + (int64_t)wave4 * 8 * 64 + ((lane >> 4) & 1) * 128 + (lane >> 5) * 32 + (lane & 15);
+    // 16x16x32 fragments (f = 16-channel tile * 2 + k-step), as the stand-alone 1x1 takes them
+    const V* tp = reinterpret_cast<const V*>(ex.tail_w) + (int64_t)wave4 * 8 * 64 + ((lane >> 4) & 1) * 128 + (lane >> 5) * 32 + (lane & 15);
 #pragma unroll
-      for (int f = 0; f < 8; f++) wt[f >> 2][f & 3] = tp[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
-    } else {
-      const V* tp = reinterpret_cast<const V*>(ex.tail_w) + lane + (int64_t)wave4 * 8 * 64;
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) wt[a][kk] = tp[(a * 4 + kk) * 64];
-    }
+    for (int f = 0; f < 8; f++) wt[f >> 2][f & 3] = tp[((f >> 2) * 4 + (f & 1)) * 64 + ((f >> 1) & 1) * 16];
   }
   auto patch_issue = [&](int cc) {
     char* P = smem + (cc & 1) * Cfg::kPatchBytes;
@@ -2026,8 +1438,8 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   V wA[2][4], wB[2][4];
   // (every stride-1 3x3 launch and the full-width 1x1 launches; the narrower 1x1 launches stay on 32x32x16, as the chained conv1 of
   // the fused tail, which must agree with them bit for bit)
-  constexpr bool M16 = ((TAPS == 9 && SD == 1) || (TAPS == 1 && OG == 4)) &&
-                       (S2A_CONV_M16 == 1 || (S2A_CONV_M16 == 3 && OG == 4 && !TAIL) || (S2A_CONV_M16 == 2 && Cfg::kWLds && OG == 4));
+  // v_mfma_f32_16x16x32_f16 there (same-box: towers -5 ... -7 %, every full-width layer +3 % end to end)
+  constexpr bool M16 = (TAPS == 9 && SD == 1) || (TAPS == 1 && OG == 4);
   constexpr int NB16 = 2 * NT;        // 16-position tiles per wave (8; 4 on the 64-position tiles)
   auto load_w = [&](int s, V (&wv)[2][4]) {
     if constexpr (M16) {
@@ -2127,7 +1539,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   // right after the prologue's barrier: the 3x3 GEMM waits on LDS reads only, so the 128 KB are in flight under it and under
   // the first epilogue instead of in front of the second one (at kernel start they queue ahead of the patch and the
   // filter on the in-order memory path: measured slower).  Register-filter form: requested behind the second GEMM, as before.
-  constexpr bool kEarlyRes = TAIL && Cfg::kWLds && S2A_TAIL_EARLY_RES;
+  constexpr bool kEarlyRes = TAIL && Cfg::kWLds;
   constexpr int NI2 = TAIL ? Cfg::kPos * 32 / kThreads_ : 1;
   unsigned off2[NI2];
   V r2[NI2];
@@ -2367,10 +1779,9 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
   if constexpr (TAIL) {
     // ---- fused 1x1 (64 -> 256) on the staged tile: wave w = out maps 64w..64w+63 x the 128 positions of its block,
     // B fragments from the staged rows (144-byte stride: conflict-free), accumulation order = the stand-alone 1x1's
-    constexpr bool T16 = S2A_CONV_M16 == 1 || S2A_CONV_M16 == 3;      // the second GEMM on 16x16x32 MFMAs, as the stand-alone 64 -> 256 1x1
-    f32x16 acc3[2][4];
-    f32x4 acc3s[T16 ? 4 : 1][T16 ? 8 : 1];
-    if constexpr (T16) {
+    // (the second GEMM on 16x16x32 MFMAs, as the stand-alone 64 -> 256 1x1)
+    f32x4 acc3s[4][8];
+    {
 #pragma unroll
       for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -2391,25 +1802,6 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
             for (int b = 0; b < 4; b++)
               acc3s[a][bh + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[(a * 2 + ks) >> 2][(a * 2 + ks) & 3], pf[b], acc3s[a][bh + b], 0, 0, 0);
         }
-    } else {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 4; b++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc3[a][b][r] = 0.f;
-    const char* brow = s_out + (128 * blk + (lane & 31)) * Cfg::kOutRowB + (lane >> 5) * 16;
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      V pf[4];
-#pragma unroll
-      for (int b = 0; b < 4; b++) pf[b] = *reinterpret_cast<const V*>(brow + b * 32 * Cfg::kOutRowB + kk * 32);
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-          acc3[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt[a][kk], pf[b], acc3[a][b], 0, 0, 0);
-    }
     }
     // residual vectors of the whole tile in flight before the tile is re-staged (issuing them at kernel start was
     // slower: they queue ahead of the patch and the filters on the in-order memory path)
@@ -2425,7 +1817,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       }
     }
     __syncthreads();                       // every wave has read its B fragments: the tile may be overwritten
-    if constexpr (T16) {
+    {
       using h4 = __attribute__((ext_vector_type(4))) _Float16;
 #pragma unroll
       for (int a = 0; a < 4; a++) {
@@ -2439,22 +1831,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
           *reinterpret_cast<h4*>(s_out + (128 * blk + 16 * b + pix16) * Cfg::kTailRowB + och * 2) = v4;
         }
       }
-    } else
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int rq = 0; rq < 4; rq++) {
-        using h4 = __attribute__((ext_vector_type(4))) _Float16;
-        const int och = wave4 * 64 + 32 * a + 8 * rq + 4 * (lane >> 5);
-        const h4 bq = *reinterpret_cast<const h4*>(s_bias + 64 + och);
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          h4 v4;
-#pragma unroll
-          for (int e = 0; e < 4; e++) v4[e] = (_Float16)(acc3[a][b][rq * 4 + e] + (float)bq[e]);
-          *reinterpret_cast<h4*>(s_out + (128 * blk + 32 * b + (lane & 31)) * Cfg::kTailRowB + och * 2) = v4;
-        }
-      }
+    }
     __syncthreads();
     // chained conv1: its 16 filter fragments are requested here, in front of the residual add / store pass (they were
     // loaded behind it, one exposed L2 round trip per tile in front of the third GEMM)
@@ -2463,7 +1840,7 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
     const int mt = wave % MT, nt0 = (wave / MT) * nper;
     const int G3 = O3 / 64;
     V aw[16];
-    if (S2A_TAIL_EARLY_RES && ex.chain_w) {
+    if (ex.chain_w) {
       const V* cwp = reinterpret_cast<const V*>(ex.chain_w) + lane + ((mt >> 1) * 8 + (mt & 1) * 4) * 64;
 #pragma unroll
       for (int c4 = 0; c4 < 4; c4++)
@@ -2489,13 +1866,6 @@ __global__ __launch_bounds__(256 * PH, PH == 1 ? 2 : 1) void k_conv_f16(const _F
       // (first block of the next stage).  wave = (m-tile, a run of 32-position tiles); B fragments from the staged
       // rows (528-byte stride: conflict-free), the 16 filter fragments of the m-tile straight from L2; K order =
       // the stand-alone 1x1 kernel's (chunk, k-step).
-      if (!S2A_TAIL_EARLY_RES) {
-        const V* cwp = reinterpret_cast<const V*>(ex.chain_w) + lane + ((mt >> 1) * 8 + (mt & 1) * 4) * 64;
-#pragma unroll
-        for (int c4 = 0; c4 < 4; c4++)
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) aw[c4 * 4 + kk] = cwp[(c4 * G3 * 8 + kk) * 64];
-      }
       f32x16 c2[4];
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -2864,8 +2234,7 @@ int run_fast(const void* input, const float* src, bool from_anchors, const void*
   if (!weight_packed) {
     k_pack_weight<T><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const T*)weight, O, C, KC, wp);
     if constexpr (sizeof(T) == 2) {
-      if (S2A_DCN_M16 != 0 && S2A_DCN_DIRECT_ST != 0) k_pack_weight_frag16<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, O, C, wp + wel);
-      else k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, O, C, wp + wel);
+      k_pack_weight_frag16<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, O, C, wp + wel);
     }
   }
   const T* wfrag = has_frag ? wp + wel : nullptr;
@@ -3014,28 +2383,21 @@ extern "C" int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int
   } else {
     S2A_CHECK_ARG(out_channels % 64 == 0, "dcn_pack_weight: out_channels must be a multiple of 64");
     k_pack_weight<_Float16><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, kc, (_Float16*)packed);
-    if (S2A_DCN_M16 != 0 && S2A_DCN_DIRECT_ST != 0) k_pack_weight_frag16<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + wtot);
-    else k_pack_weight_frag<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + wtot);
-    k_pack_weight_sym<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + 2 * wtot);
+    k_pack_weight_frag16<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, (_Float16*)packed + wtot);
   }
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
 
 extern "C" int64_t s2a_dcn_packed_elems(int64_t out_channels, int64_t channels, int dtype) {
-  // f16 holds three layouts back to back (stage-major for the LDS-staged kernels, MFMA-fragment order for the
-  // patch-staged kernel, 16x16x32 fragment order of 32-channel stages for the symmetric 16 x 16-tile kernel)
-  return out_channels * channels * 9 * (dtype == S2A_DTYPE_F16 ? 3 : 1);
+  // f16 holds two layouts back to back (stage-major for the LDS-staged kernels, MFMA-fragment order for the patch-staged kernel)
+  return out_channels * channels * 9 * (dtype == S2A_DTYPE_F16 ? 2 : 1);
 }
 
 namespace s2a {
 int build_flags_dcn() {
   int f = S2A_ABL & 0xff;
-  if (!S2A_MPIPE) f |= 1 << 8;
   if (S2A_STAMP) f |= 1 << 9;
-  if (S2A_CONV_M16 != 1) f |= 1 << 11;
-  if (S2A_DCN_M16 != 1) f |= 1 << 12;
-  if (S2A_TAIL_EARLY_RES != 1) f |= 1 << 13;
 #ifdef S2A_MEASURE
   f |= 1 << 10;
 #endif
@@ -3374,25 +2736,7 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
   // three-slot column ring with loaders two stages ahead (2-8 % slower), two half-tile workgroups per CU (332 vs 282 us:
   // the filter streamed twice), half tiles for the last round in a second launch (-1.2 %).)
   const unsigned ogroups = (unsigned)((out_channels + kMaxO - 1) / kMaxO);
-  const int relu_flags = (relu ? 1 : 0) | (half_coords_requested() ? 2 : 0) | (getenv("S2A_DCN_SYM_NOPRIO") ? 4 : 0);
-  {
-    // S2A_DCN_SYM=1: 16 x 16 tiles with every wave blending AND contracting (k_dcn_sym).  Opt-in: measured 261 us against
-    // 236 us for k_dcn_patch on this launch (round 4) -- kept as the tested second form of the launch.
-    LevelTab lt16; int64_t pix16 = 0;
-    const int64_t tiles16 = build_levels(pyr, batch, &lt16, &pix16, 16);
-    bool sym = false;
-    if (const char* f = getenv("S2A_DCN_SYM")) sym = atoi(f) != 0;
-    if (sym && channels % 64 == 0 && tiles16 > 0) {
-      if (lt16.n == 1) lt16.n = 2, lt16.tile0[1] = 0x7fffffff;
-      const _Float16* wsym = (const _Float16*)weight_packed + 2 * (size_t)out_channels * channels * 9;
-      auto ks = k_dcn_sym;
-      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, kSymLds));
-      ks<<<dim3((unsigned)tiles16, ogroups), 512, kSymLds, st>>>((const _Float16*)x, anchors, wsym, (_Float16*)out, (int)channels,
-                                                                (int)out_channels, relu_flags, lt16);
-      S2A_LAUNCH_CHECK();
-      return S2A_OK;
-    }
-  }
+  const int relu_flags = (relu ? 1 : 0) | (half_coords_requested() ? 2 : 0);
   auto kern = k_dcn_patch<true, 1>;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
   // the last round as half tiles when it would leave more than half of the CUs idle (see k_dcn_patch); S2A_DCN_HALF_TAIL=0|1 forces
@@ -3402,8 +2746,8 @@ extern "C" int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, c
     if (rc_ != S2A_OK) return rc_;
   }
   const int64_t rem = tiles % ncu;
-  bool half_tail = S2A_DCN_MIXED != 0 && tiles > ncu && rem != 0 && 2 * rem <= ncu;
-  if (const char* f = getenv("S2A_DCN_HALF_TAIL")) half_tail = S2A_DCN_MIXED != 0 && atoi(f) != 0 && tiles > rem && rem != 0;
+  bool half_tail = tiles > ncu && rem != 0 && 2 * rem <= ncu;
+  if (const char* f = getenv("S2A_DCN_HALF_TAIL")) half_tail = atoi(f) != 0 && tiles > rem && rem != 0;
   const unsigned n_full = half_tail ? (unsigned)(tiles - rem) : 0u;
   const unsigned grid_x = half_tail ? (unsigned)(tiles - rem + 2 * rem) : (unsigned)tiles;
   kern<<<dim3(grid_x, ogroups), 512, kPatchLds, st>>>(PatchArgs{(const _Float16*)x, anchors, wfrag, (_Float16*)out, 0, (int)channels,

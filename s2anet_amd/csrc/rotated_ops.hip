@@ -222,9 +222,6 @@ __global__ __launch_bounds__(kThreads) void k_iou_cull(const PreBox* __restrict_
 // records as LDS broadcast reads with per-wave survivor lists (59 us alone became 79), the same on half the LDS, a dense
 // second stage fed from a list, a grid-binned finder, and one launch per 256 x 256 tile that also fills and evaluates.)
 constexpr int kCrStage = 256;                 // per-wave staged pairs
-#ifndef S2A_IOU_PK_CIRCLE
-#define S2A_IOU_PK_CIRCLE 1
-#endif
 __device__ __forceinline__ float lane_bcast(float v, int j) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
 }
@@ -241,7 +238,6 @@ __device__ __forceinline__ void wave_lds_handoff() {
 }
 template <int J0, int J1>
 __device__ __forceinline__ void circle_bits(float ax, float ay, float ar, float cx, float cy, float cr, unsigned& bits) {
-#if S2A_IOU_PK_CIRCLE
   // two columns per packed-f32 instruction (v_pk_add / v_pk_mul / v_pk_fma_f32; the broadcast column pair is one scalar-pair
   // operand): 8.5 instead of 12.5 instructions per column.  The test only has to be conservative (a pair with IoU > 0 has
   // circles that overlap by the 0.2 % margin), so the fused multiply-add is fine here.
@@ -256,13 +252,6 @@ __device__ __forceinline__ void circle_bits(float ax, float ay, float ar, float 
     bits |= (d2[0] > R2[0] ? 0u : 1u) << (j - J0);
     bits |= (d2[1] > R2[1] ? 0u : 1u) << (j + 1 - J0);
   }
-#else
-#pragma unroll
-  for (int j = J0; j < J1; j++) {
-    const float dx = ax - lane_bcast(cx, j), dy = ay - lane_bcast(cy, j), R = ar + lane_bcast(cr, j);
-    bits |= (dx * dx + dy * dy > R * R ? 0u : 1u) << (j - J0);
-  }
-#endif
 }
 // NMS first stage: circle test AND area-ratio test (|la - lc| <= lmax; NaN log-areas never drop a pair), see
 // k_nms_cull_lanes.  The column data ROTATES through the lanes (v_mov_b32_dpp wave_ror:1, one lane per step) instead of

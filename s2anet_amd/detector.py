@@ -218,7 +218,8 @@ class S2ANet(nn.Module):
     def forward(self, imgs, post_process=False):
         return self.head(self.neck(self.backbone(imgs)), post_process=post_process)
 
-    def features_to_pred(self, imgs, backbone_out=None):
+    def features_to_pred(self, imgs, backbone_out=None, **pyramid_kw):
+        """pyramid_kw: ``anchors`` / ``trace`` of S2ANetHead.forward_pyramid (pyramid-packed path only)"""
         c = self.backbone(imgs) if backbone_out is None else backbone_out
         sizes = [tuple(c[0].shape[2:])]
         while len(sizes) < len(self.stride):                    # stride-2 3x3/pad-1 convs: ceil(n/2)
@@ -230,7 +231,10 @@ class S2ANet(nn.Module):
             key = (B, tuple(sizes))
             if getattr(self, "_layout_key", None) != key:
                 self._layout_key, self._layout = key, PyramidLayout(B, sizes, self.stride)
-            return self.head.forward_pyramid(self._layout, self.neck.forward_packed(c, self._layout))
+            if pyramid_kw.get("trace") is not None:
+                pyramid_kw["trace"].update(C=c, layout=self._layout)
+            return self.head.forward_pyramid(self._layout, self.neck.forward_packed(c, self._layout), **pyramid_kw)
+        assert not pyramid_kw, "anchors= / trace= need the pyramid-packed path"
         feats = self.neck(c)
         per_level = [self.head.forward_single(f, s) for f, s in zip(feats, self.stride)]
         return tuple(map(list, zip(*per_level)))

@@ -48,12 +48,16 @@ def own_conv_ok(x, in_channels, out_channels, kernel_size, stride, padding, dila
         return False
     k, st, pd = tuple(kernel_size), tuple(stride), tuple(padding)
     B, _, H, W = x.shape
-    narrow = out_channels < 64     # prediction heads (5 / 15 maps): the library's kernels for these cost 13-56 us flat
+    # S2A_OWN_CONV_ALWAYS=1: every shape the kernel handles, also the small grids the library wins on (the size
+    # thresholds below are speed heuristics, not limits) -- a network evaluated this way runs no library convolution
+    # in the trunk and is therefore bit-reproducible run to run and box to box (tests/test_net_forward.py)
+    narrow = out_channels < 64 or bool(os.environ.get("S2A_OWN_CONV_ALWAYS"))
+    #         ^ prediction heads (5 / 15 maps): the library's kernels for these cost 13-56 us flat
     if k == (3, 3) and st == (1, 1) and pd == (1, 1):
         return narrow or B * ((H + 7) // 8) * ((W + 15) // 16) >= 64
     if k == (3, 3) and st == (2, 2) and pd == (1, 1) and not os.environ.get("S2A_NO_OWN_CONV_S2"):
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1            # the down-sampling conv2 of a stage's first bottleneck
-        return out_channels % 128 == 0 and in_channels % 64 == 0 and B * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= 128
+        return out_channels % 128 == 0 and in_channels % 64 == 0 and (narrow or B * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= 128)
     if k == (1, 1) and pd == (0, 0) and st in ((1, 1), (2, 2)) and not os.environ.get("S2A_NO_OWN_CONV1"):
         Ho, Wo = (H - 1) // st[0] + 1, (W - 1) // st[1] + 1
         return narrow or B * Ho * Wo >= 64 * 128

@@ -46,12 +46,18 @@ class DetectionGather:
     (dets[world*B,K,6], labels[world*B,K], counts[world*B]).
 
     With ``side_stream=True`` the collective is issued on an own stream behind an event of the producing stream, so the
-    next batch's trunk (issued on the producing stream right after) overlaps it; ``wait()`` makes the current stream
-    wait for the last gather, and the rotating output slots keep a gather's result alive while the next one runs."""
+    next batch's trunk (issued on the producing stream right after) overlaps it; the rotating output slots keep a gather's
+    result alive while the next one runs.  The tensor ``__call__`` returns is then still being written: ``unpack()`` and
+    ``.out`` make the CURRENT stream wait for the last gather before they hand out views (``wait()`` does only that).
 
-    def __init__(self, world, batch_local, max_per_img, device, group=None, side_stream=False, slots=2):
+    ``force_collective=True`` sends a world of ONE through ``all_gather_into_tensor`` as well (instead of the copy): the
+    only way to execute the RCCL branch, its side stream, events and ``record_stream`` on a one-GPU box."""
+
+    def __init__(self, world, batch_local, max_per_img, device, group=None, side_stream=False, slots=2,
+                 force_collective=False):
         self.world, self.B, self.K = world, batch_local, max_per_img
         self.group = group
+        self.collective = world > 1 or bool(force_collective)
         self.outs = [torch.empty((world, batch_local, max_per_img * 7 + 1), dtype=torch.float32, device=device)
                      for _ in range(max(1, slots if side_stream else 1))]
         self.turn = 0
@@ -60,6 +66,8 @@ class DetectionGather:
 
     @property
     def out(self):
+        """the last gather's buffer, safe to read on the current stream"""
+        self.wait()
         return self.outs[(self.turn - 1) % len(self.outs)]
 
     def __call__(self, wire, labels=None, counts=None):
@@ -68,7 +76,7 @@ class DetectionGather:
         assert tuple(wire.shape) == (self.B, self.K * 7 + 1) and wire.dtype == torch.float32 and wire.is_contiguous()
         out = self.outs[self.turn % len(self.outs)]
         self.turn += 1
-        if self.world == 1:
+        if not self.collective:
             out[0].copy_(wire)
         elif self.stream is None:
             dist.all_gather_into_tensor(out.view(-1), wire.view(-1), group=self.group)
@@ -89,4 +97,6 @@ class DetectionGather:
             torch.cuda.current_stream().wait_event(self.done)
 
     def unpack(self, gathered=None):
+        """views of the last gather (or of ``gathered``, a tensor ``__call__`` returned); waits for the side stream"""
+        self.wait()
         return unpack_detections(self.out.view(self.world * self.B, -1) if gathered is None else gathered, self.K)

@@ -140,9 +140,12 @@ class S2ANetHead(nn.Module):
                 isinstance(self.fam_reg_head, FusedConv2d) and self.in_channels % 64 == 0 and
                 self.feat_channels % 64 == 0 and self.align_conv.kernel_size == (3, 3))
 
-    def forward_pyramid(self, layout, x):
+    def forward_pyramid(self, layout, x, anchors=None, trace=None):
         """forward_single for ALL FPN levels at once on a pyramid-packed feature buffer x[P,256]
-        (s2anet_amd/pyramid.py).  Returns per-level lists of views with the forward_single shapes."""
+        (s2anet_amd/pyramid.py).  Returns per-level lists of views with the forward_single shapes.
+        anchors: refined anchors [P,5] f32 to sample with instead of the ones decoded from this call's own FAM
+        regression (tests: separates the sampling from the regression that feeds it); trace: dict that receives
+        the packed intermediate buffers by name (tests / scripts/f16_fixture_diag.py)"""
         from . import pyramid as P
 
         def tower(seq, t):
@@ -167,7 +170,11 @@ class S2ANetHead(nn.Module):
         fam_cls = None
         if self.compute_fam_cls:
             fam_cls = tower_with_head(self.fam_cls_ls, self.fam_cls_head, x)
-        anchors = P.fam_refine_anchors(layout, fam_bbox, self.anchor_scale)                 # [P,5] f32
+        own_anchors = P.fam_refine_anchors(layout, fam_bbox, self.anchor_scale)             # [P,5] f32
+        if anchors is None:
+            anchors = own_anchors
+        else:
+            assert anchors.shape == own_anchors.shape and anchors.dtype == torch.float32 and anchors.is_contiguous()
         if getattr(self, "capture", None) is not None:      # bench.py: the operands of this step's launches
             self.capture.update(layout=layout, x=x, anchors=anchors)
         al = P.align_conv(layout, x, anchors, self.align_conv.packed_weight(torch.float16), self.feat_channels)
@@ -187,6 +194,9 @@ class S2ANetHead(nn.Module):
         w, b, o = self.odm_reg_head.packed_args()
         odm_bbox = P.conv3x3(layout, tower(self.odm_reg_ls, or_feat), w, b, o, relu=False)  # [P,64], 5 used
         n = len(layout.sizes)
+        if trace is not None:
+            trace.update(x=x, fam_bbox=fam_bbox, fam_cls=fam_cls, own_anchors=own_anchors, anchors=anchors, align=al,
+                         or_feat=or_feat, pooled=pooled, odm_cls=odm_cls, odm_bbox=odm_bbox)
         return PyramidPred(layout, odm_cls, odm_bbox, anchors,
                            [layout.level(fam_cls, l, self.num_classes) for l in range(n)] if fam_cls is not None else [None] * n,
                 [layout.level(fam_bbox, l, 5) for l in range(n)],

@@ -22,10 +22,8 @@ def timeit(f, n=200):
     for _ in range(n): f()
     t1.record(); torch.cuda.synchronize()
     return t0.elapsed_time(t1) / n * 1e3
-for sym in (("0",) if "--patch-only" in sys.argv else ("0", "1")):
-    os.environ["S2A_DCN_SYM"] = sym
-    for name, x, ww in (("zeros", torch.zeros_like(xr), torch.zeros_like(w)), ("relu-sparse", torch.relu(xr), w), ("dense", xr, w)):
-        wa = pack_weight(ww, torch.float16)
-        us = timeit(lambda: P.align_conv(layout, x, anc, wa, 256))
-        print(json.dumps({"kernel": "k_dcn_sym" if sym == "1" else "k_dcn_patch", "data": name, "us": round(us, 1),
-                          "mfma_frac": round(2.0 * layout.pixels * 256 * 2304 / us / 1e6 / 2500, 4)}))
+for name, x, ww in (("zeros", torch.zeros_like(xr), torch.zeros_like(w)), ("relu-sparse", torch.relu(xr), w), ("dense", xr, w)):
+    wa = pack_weight(ww, torch.float16)
+    us = timeit(lambda: P.align_conv(layout, x, anc, wa, 256))
+    print(json.dumps({"kernel": "k_dcn_patch", "data": name, "us": round(us, 1),
+                      "mfma_frac": round(2.0 * layout.pixels * 256 * 2304 / us / 1e6 / 2500, 4)}))

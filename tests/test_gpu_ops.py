@@ -1357,12 +1357,8 @@ def test_pyramid_tower_with_fused_head():
         assert torch.equal(tw, tower) and torch.equal(got2[:, :nh], got[:, :nh])
 
 
-@pytest.mark.parametrize("sym", ["0", "1"])
-def test_pyramid_alignconv_and_refine(rng, sym, monkeypatch):
-    """pyramid-packed fam_refine + AlignConv against the per-level entry points and the oracle; both forms of the packed
-    launch (S2A_DCN_SYM=0: 8 x 16 tiles, wave-specialised k_dcn_patch; 1: 16 x 16 tiles, every wave blends and contracts,
-    k_dcn_sym) -- the size heuristic would pick only one of them here"""
-    monkeypatch.setenv("S2A_DCN_SYM", sym)
+def test_pyramid_alignconv_and_refine(rng):
+    """pyramid-packed fam_refine + AlignConv (k_dcn_patch) against the per-level entry points and the oracle"""
     from s2anet_amd import pyramid as P
     from s2anet_amd.alignconv import align_conv_forward, pack_weight
     from s2anet_amd.head import fam_refine_anchors
@@ -1395,16 +1391,14 @@ def test_pyramid_alignconv_and_refine(rng, sym, monkeypatch):
             assert err.max() < 2e-2 and err.mean() < 2e-3, (l, bi, err.max(), err.mean())
 
 
-@pytest.mark.parametrize("sym", ["0", "1"])
-def test_pyramid_alignconv_wild_anchors_vs_oracle(sym, monkeypatch):
-    """(both forms of the launch, see test_pyramid_alignconv_and_refine) the pyramid-packed AlignConv launch with more tiles than CUs, ragged level sizes and WILD anchors (bilinear corners
+def test_pyramid_alignconv_wild_anchors_vs_oracle(monkeypatch):
+    """the pyramid-packed AlignConv launch with more tiles than CUs, ragged level sizes and WILD anchors (bilinear corners
     that leave the 16 x 24 LDS patch take the global-gather path; tame anchors stay inside it): every level of every
     image against the f16-column oracle, and two launches of the same inputs bit-identical (round 2 also held four
     alternative forms of this launch to that -- persistent, three-slot ring, two workgroups per CU, half-tile tail --
-    all measured slower and removed)"""
+    all measured slower and removed, as was round 4's symmetric 16 x 16-tile form k_dcn_sym)"""
     from s2anet_amd import pyramid as P
     from s2anet_amd.alignconv import pack_weight
-    monkeypatch.setenv("S2A_DCN_SYM", sym)
     B, C = 2, 256
     sizes = [(96, 136), (48, 68), (24, 34), (12, 17), (6, 9)]
     strides = (8, 16, 32, 64, 128)
@@ -1427,14 +1421,13 @@ def test_pyramid_alignconv_wild_anchors_vs_oracle(sym, monkeypatch):
         anchors = torch.cat(anchors).to(dev()).contiguous()
         out = P.align_conv(lay, x, anchors, wp, 256).clone()
         assert torch.equal(out, P.align_conv(lay, x, anchors, wp, 256))
-        if sym == "0":
-            # 304 tiles on 256 CUs: the 48 tiles behind the full round run as 96 half tiles inside the same launch
-            # (PatchArgs::n_full); S2A_DCN_HALF_TAIL=0 launches 304 full tiles instead -- the same bits either way
-            monkeypatch.setenv("S2A_DCN_HALF_TAIL", "0")
-            assert torch.equal(out, P.align_conv(lay, x, anchors, wp, 256))
-            monkeypatch.setenv("S2A_DCN_HALF_TAIL", "1")
-            assert torch.equal(out, P.align_conv(lay, x, anchors, wp, 256))
-            monkeypatch.delenv("S2A_DCN_HALF_TAIL")
+        # 304 tiles on 256 CUs: the 48 tiles behind the full round run as 96 half tiles inside the same launch
+        # (PatchArgs::n_full); S2A_DCN_HALF_TAIL=0 launches 304 full tiles instead -- the same bits either way
+        monkeypatch.setenv("S2A_DCN_HALF_TAIL", "0")
+        assert torch.equal(out, P.align_conv(lay, x, anchors, wp, 256))
+        monkeypatch.setenv("S2A_DCN_HALF_TAIL", "1")
+        assert torch.equal(out, P.align_conv(lay, x, anchors, wp, 256))
+        monkeypatch.delenv("S2A_DCN_HALF_TAIL")
         for l in (1, 2, 4):                                   # (level 0 at this size: 20 s of oracle per image)
             H, W = sizes[l]
             a = lay.rows(anchors, l).view(B, H * W, 5).cpu().numpy()
