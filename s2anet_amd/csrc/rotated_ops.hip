@@ -625,12 +625,14 @@ __global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ dets
                                                   uint32_t* __restrict__ seg_cnt, size_t nseg_cnt,
                                                   uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots,
                                                   unsigned long long* __restrict__ htab, uint32_t* __restrict__ hist,
-                                                  uint32_t* __restrict__ spb_ctr) {
+                                                  uint32_t* __restrict__ spb_ctr, uint32_t hist_zero) {
   const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (htab) {                                    // own order-B sort: table, histogram and counters (filled by k_spb_insert)
     for (size_t i = i0; i < kSpbSlots; i += stride) htab[i] = kSpbEmpty;
     for (size_t i = i0; i < kSpbHist + 64; i += stride) hist[i] = 0u;
     if (i0 < 4) spb_ctr[i0] = 0u;
+  } else {
+    for (size_t i = i0; i < hist_zero; i += stride) hist[i] = 0u;     // own segment sort: the per-segment row counts
   }
   for (size_t i = i0; i < sizeof(NmsCounters) / 4; i += stride) reinterpret_cast<uint32_t*>(C)[i] = 0u;
   for (size_t i = i0; i < nblocked32; i += stride) blocked32[i] = 0u;
@@ -1154,6 +1156,147 @@ __global__ __launch_bounds__(1024) void k_nms_group_emit(const unsigned long lon
   }
 }
 
+// rows at or behind *row_limit (when given: the candidate count of the producer, s2a_multiclass_candidates) are padding by
+// contract and are never read: a detector batch fills a quarter of its static buffer
+__device__ __forceinline__ int64_t seg_row_limit(const long long* __restrict__ row_limit, int64_t n) {
+  if (!row_limit) return n;
+  const long long v = *row_limit;
+  return v < 0 ? 0 : (v < (long long)n ? (int64_t)v : n);
+}
+// bitonic sort of P (power of two, >= 128) 64-bit keys in LDS, ascending; NT threads; ends with a barrier.  Compare-exchange
+// distances up to 64 stay inside an aligned block of 128 keys: those stages run per wave on its own blocks with no workgroup
+// barrier (7 of the 12 stages of a 4096-key merge; 21 barriers instead of 78 for 4096 keys, 6 instead of 45 for 512)
+template <int NT>
+__device__ __forceinline__ void lds_bitonic_sort(unsigned long long* __restrict__ s, unsigned P) {
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto cmpx = [&](unsigned t, unsigned j, unsigned k) {
+    const unsigned i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
+    const unsigned long long a = s[i], b = s[l];
+    if ((a > b) == ((i & k) == 0u)) { s[i] = b; s[l] = a; }
+  };
+  for (unsigned k = 2; k <= P; k <<= 1) {
+    unsigned j = k >> 1;
+    for (; j >= 128; j >>= 1) {
+      for (unsigned t = threadIdx.x; t < P / 2; t += NT) cmpx(t, j, k);
+      __syncthreads();
+    }
+    for (unsigned blk = wave; blk < P / 128; blk += NT / 64)        // (always the same wave for a block)
+      for (unsigned jj = j; jj > 0; jj >>= 1) {
+        cmpx(blk * 64 + lane, jj, k);
+        wave_lds_handoff();
+      }
+    if (k >= 128) __syncthreads();
+  }
+}
+
+// The same output assembly WITHOUT the (group, score) sort of all rows: one workgroup per group collects the KEPT rows of
+// its group by scanning group ids and keep flags (L2-resident), sorts their (~score | row) keys in LDS and writes the first
+// max_per_group.  Only the best max_per_group <= kEmitCap / 2 rows can be emitted, so more kept rows than the LDS holds are
+// folded in by rounds: the best kEmitCap / 2 so far stay in the lower half, the next kEmitCap / 2 candidates fill the upper
+// half, sort, repeat.  Replaces ~10 library launches over the padded candidate buffer (order C) by nothing.
+constexpr int kEmitCap = 8192;
+__global__ __launch_bounds__(1024) void k_nms_group_emit_scan(const int32_t* __restrict__ group_ids,
+                                                              const uint8_t* __restrict__ keep_orig,
+                                                              const float* __restrict__ dets5,
+                                                              const float* __restrict__ scores,
+                                                              const int32_t* __restrict__ row_labels, int64_t n,
+                                                              int32_t max_per_group, float* __restrict__ wire,
+                                                              int32_t* __restrict__ labels_out,
+                                                              int32_t* __restrict__ counts_out,
+                                                              const long long* __restrict__ cand_found,
+                                                              long long* __restrict__ overflow_out,
+                                                              long long* __restrict__ dropped_total) {
+  // (cand_found = the producer's candidate count: rows behind it are padding, never kept, and are not read)
+  const int64_t nl = seg_row_limit(cand_found, n);
+  __shared__ unsigned long long s_key[kEmitCap];
+  __shared__ unsigned s_cnt;
+  const int32_t g = (int32_t)blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  if (g == 0 && threadIdx.x == 0 && cand_found) {     // candidates the static row cap n cut (the reference drops none)
+    const long long found = *cand_found, dropped = found > (long long)n ? found - (long long)n : 0;
+    if (overflow_out) { overflow_out[0] = found; overflow_out[1] = dropped; }
+    if (dropped_total) *dropped_total += dropped;      // stream-ordered: one writer per buffer
+  }
+  constexpr unsigned kHalf = kEmitCap / 2;
+  unsigned have = 0;                                   // sorted keys held in s_key[0, have)
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  auto fold = [&]() {                                  // sort what was collected behind `have`, keep the best kHalf
+    const unsigned cnt = min(s_cnt, (unsigned)kEmitCap);
+    for (unsigned r = have + threadIdx.x; r < cnt; r += 1024) {       // row indices -> (~score | row) keys
+      const uint32_t i = (uint32_t)s_key[r];
+      s_key[r] = ((unsigned long long)(~float_sortable(scores[i])) << 32) | i;
+    }
+    unsigned P = 128;
+    while (P < cnt) P <<= 1;
+    for (unsigned i = cnt + threadIdx.x; i < P; i += 1024) s_key[i] = ~0ull;
+    __syncthreads();
+    lds_bitonic_sort<1024>(s_key, P);
+    have = min(cnt, kHalf);
+    if (threadIdx.x == 0) s_cnt = have;
+    __syncthreads();
+  };
+  // a sweep = 4096 rows, four per thread; the eight loads of the NEXT sweep are requested before this one is processed (one
+  // sweep per L2 round trip otherwise: 40 round trips of ~2 us for a 160 k-row buffer)
+  uint8_t kf[4], kfn[4];
+  int32_t gid[4], gidn[4];
+  auto request = [&](int64_t base) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t i = base + k * 1024 + threadIdx.x;
+      kfn[k] = i < nl ? keep_orig[i] : (uint8_t)0;
+      gidn[k] = i < nl ? group_ids[i] : -1;
+    }
+  };
+  request(0);
+  for (int64_t base = 0; base < nl; base += 4096) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { kf[k] = kfn[k]; gid[k] = gidn[k]; }
+    request(base + 4096);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t i = base + k * 1024 + threadIdx.x;
+      const bool mine = kf[k] != 0 && gid[k] == g;
+      const unsigned long long bal = __ballot(mine);
+      if (bal) {
+        unsigned slot = 0;
+        if (lane == 0) slot = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+        slot = (unsigned)__shfl((int)slot, 0) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (mine) s_key[slot] = (unsigned long long)i;      // (row index; the key is made in fold(): see k_seg_sort)
+      }
+    }
+    // fold() leaves <= kHalf keys and a sweep adds <= 4096 = kEmitCap - kHalf: a slot never passes kEmitCap.  The count is
+    // read between two barriers: a wave that is already in the next sweep must not move it under a slower wave's decision
+    __syncthreads();
+    const unsigned c = s_cnt;
+    __syncthreads();
+    if (c > kHalf) fold();                               // (uniform)
+  }
+  fold();
+  const int written = (int)min(have, (unsigned)max_per_group);
+  float* wg = wire + (int64_t)g * ((int64_t)max_per_group * 7 + 1);
+  int32_t* lg = labels_out ? labels_out + (int64_t)g * max_per_group : nullptr;
+  for (int r = threadIdx.x; r < max_per_group; r += 1024) {
+    float* w7 = wg + (int64_t)r * 7;
+    if (r < written) {
+      const uint32_t o = (uint32_t)s_key[r];
+      const float* d = dets5 + (int64_t)o * 5;
+      const int lab = row_labels[o];
+      w7[0] = d[0]; w7[1] = d[1]; w7[2] = d[2]; w7[3] = d[3]; w7[4] = d[4];
+      w7[5] = scores[o];
+      w7[6] = (float)lab;
+      if (lg) lg[r] = lab;
+    } else {
+      w7[0] = 0.f; w7[1] = 0.f; w7[2] = 0.f; w7[3] = 0.f; w7[4] = 0.f; w7[5] = 0.f; w7[6] = -1.f;
+      if (lg) lg[r] = -1;
+    }
+  }
+  if (threadIdx.x == 0) {
+    wg[(int64_t)max_per_group * 7] = (float)written;
+    if (counts_out) counts_out[g] = written;
+  }
+}
+
 __global__ void k_zero_u8(uint8_t* p, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
@@ -1205,6 +1348,217 @@ __global__ __launch_bounds__(256) void k_nms_pos_meta(const float* __restrict__ 
       state_fb[p] = st0;
     }
     running += tot;
+  }
+}
+
+// ---- OWN SEGMENT SORT (round 5): the (segment, score) order of a detector batch without a library sort.
+// A detector batch is ~120 (image, class) segments of a few hundred rows inside a static-size candidate buffer that is
+// mostly padding (160 000 rows for ~40 000 candidates): rocPRIM's 64-bit pair sort over the whole buffer took ~10 launches
+// of 5-17 us for order A and as many again for the output order C (0.16 ms per step).  Here:
+//   k_seg_hist  rows per segment (LDS histogram per 4096-row chunk, one global atomic per chunk and non-empty segment) and
+//               the ignored rows of every chunk;
+//   k_seg_sort  ONE workgroup per segment: start = prefix of the counts, collects its rows by scanning the segment ids
+//               (a 160 k-row id array is 640 KB from L2: ~2 us per workgroup, all segments side by side), sorts
+//               (~score | original row) keys in LDS (bitonic, <= 8192 rows; a larger segment ranks its rows by counting over
+//               a global list: slow, exact) and writes everything k_nms_pos_meta wrote: sorted keys, permutation, segment
+//               index, pre-processed boxes, states, seg_start.  Extra workgroups place the ignored rows (in row order)
+//               behind the last real segment: every row keeps a position of its own (k_nms_finish writes keep_orig through
+//               the permutation).
+// Segment index = segment id (empty segments exist as empty ranges), the ignored rows form segment S.
+constexpr int kSegSortMaxSeg = 2048;      // segments the LDS histogram holds
+constexpr int kSegChunk = 4096;           // rows per histogram block / per ignored-row placer
+constexpr int kSegCap = 8192;             // rows a segment may have for the LDS sort (64 KB of keys)
+
+__global__ __launch_bounds__(256) void k_seg_hist(const int32_t* __restrict__ seg_ids, int64_t n,
+                                                  const long long* __restrict__ row_limit, uint32_t S,
+                                                  uint32_t* __restrict__ seg_n, uint32_t* __restrict__ ign_cnt) {
+  __shared__ uint32_t s_h[kSegSortMaxSeg + 1];
+  for (uint32_t i = threadIdx.x; i <= S; i += 256) s_h[i] = 0u;
+  __syncthreads();
+  const int64_t nl = seg_row_limit(row_limit, n);
+  const int64_t r0 = (int64_t)blockIdx.x * kSegChunk, r1 = min(n, r0 + kSegChunk), rl = min(r1, max(nl, r0));
+  for (int64_t p = r0 + threadIdx.x; p < rl; p += 256) {
+    const int32_t sid = seg_ids[p];
+    atomicAdd(&s_h[(sid < 0 || (uint32_t)sid >= S) ? S : (uint32_t)sid], 1u);     // (ids outside [0, S) are padding by contract)
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < S; i += 256)
+    if (s_h[i]) atomicAdd(&seg_n[i], s_h[i]);
+  if (threadIdx.x == 0) ign_cnt[blockIdx.x] = s_h[S] + (uint32_t)(r1 - rl);
+}
+
+// block-wide sums of two values (1024 threads); every thread gets both totals
+__device__ __forceinline__ void block_sum2_1024(unsigned& a, unsigned& b) {
+  __shared__ unsigned s_a[16], s_b[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  a = 0; b = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { a += s_a[w]; b += s_b[w]; }
+}
+
+__global__ __launch_bounds__(1024) void k_seg_sort(const float* __restrict__ dets5, const float* __restrict__ scores,
+                                                   const int32_t* __restrict__ seg_ids, int64_t n,
+                                                   const long long* __restrict__ row_limit, uint32_t S,
+                                                   const uint32_t* __restrict__ seg_n, const uint32_t* __restrict__ ign_cnt,
+                                                   int nchunks, uint32_t ignore_key,
+                                                   unsigned long long* __restrict__ scratch /* keyA: unsorted lists of big segments */,
+                                                   unsigned long long* __restrict__ keyA_s, int32_t* __restrict__ perm_seg,
+                                                   uint32_t* __restrict__ segidx1, uint32_t* __restrict__ seg_start,
+                                                   uint32_t* __restrict__ num_seg, PreBox* __restrict__ sorted,
+                                                   uint8_t* __restrict__ state, uint8_t* __restrict__ state_fb) {
+  __shared__ unsigned long long s_key[kSegCap];
+  __shared__ unsigned s_cnt;
+  const int lane = threadIdx.x & 63;
+  const int64_t nl = seg_row_limit(row_limit, n);
+  // prefix of the segment counts in front of this workgroup's segment (ignore placers: the total)
+  const uint32_t w = blockIdx.x;
+  unsigned before = 0, total = 0;
+  for (uint32_t j = threadIdx.x; j < S; j += 1024) {
+    const unsigned c = seg_n[j];
+    total += c;
+    if (j < w) before += c;
+  }
+  block_sum2_1024(before, total);
+  if (w == 0 && threadIdx.x == 0) { *num_seg = S + 1u; seg_start[S] = total; seg_start[S + 1u] = (uint32_t)n; }
+  auto emit_row = [&](uint32_t p, uint32_t o, uint32_t sidx, unsigned long long key, uint8_t st0) {
+    keyA_s[p] = key;
+    perm_seg[p] = (int32_t)o;
+    segidx1[p] = sidx + 1u;
+    const float* b = dets5 + 5 * (int64_t)o;
+    sorted[p] = make_prebox(b[0], b[1], b[2], b[3], b[4], __uint_as_float(sidx));
+    state[p] = st0;
+    state_fb[p] = st0;
+  };
+  if (w >= S) {
+    // ---- ignored rows of chunk (w - S), in row order, behind the real segments
+    const int cb = (int)(w - S);
+    unsigned ib = 0, dummy = 0;
+    for (int j = threadIdx.x; j < cb; j += 1024) ib += ign_cnt[j];
+    block_sum2_1024(ib, dummy);
+    if (ign_cnt[cb] == 0u) return;                         // (uniform)
+    __shared__ unsigned s_wsum[16];
+    unsigned running = total + ib;
+    const int64_t r0 = (int64_t)cb * kSegChunk, r1 = min(n, r0 + kSegChunk);
+    for (int64_t base = r0; base < r1; base += 1024) {
+      const int64_t i = base + threadIdx.x;
+      bool ign = false;
+      if (i < r1) {
+        ign = i >= nl;
+        if (!ign) { const int32_t sid = seg_ids[i]; ign = sid < 0 || (uint32_t)sid >= S; }
+      }
+      const unsigned long long bal = __ballot(ign);
+      __syncthreads();
+      if (lane == 0) s_wsum[threadIdx.x >> 6] = (unsigned)__popcll(bal);
+      __syncthreads();
+      unsigned wbase = 0, all = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) { if (k < (int)(threadIdx.x >> 6)) wbase += s_wsum[k]; all += s_wsum[k]; }
+      if (ign) {       // never compared, never kept: a position of its own and the removed state is all an ignored row needs
+        const uint32_t p = running + wbase + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        keyA_s[p] = ((unsigned long long)ignore_key << 32) | 0xffffffffull;
+        perm_seg[p] = (int32_t)i;
+        segidx1[p] = S + 1u;
+        PreBox z = {};
+        z.label = __uint_as_float(S);
+        sorted[p] = z;
+        state[p] = 2;
+        state_fb[p] = 2;
+      }
+      running += all;
+    }
+    return;
+  }
+  // ---- segment w
+  const uint32_t ns = seg_n[w], start = before;
+  if (threadIdx.x == 0) { seg_start[w] = start; s_cnt = 0; }
+  if (ns == 0u) return;                                    // (uniform)
+  const bool in_lds = ns <= (uint32_t)kSegCap;
+  __syncthreads();
+  // collect: the rows of this segment, any order.  Eight ids per thread are requested before the first is looked at: one id per
+  // trip made the loop a chain of 157 dependent L2 round trips (160 k rows), ~150 us per workgroup
+  // (and the next eight are requested before these are processed: the loop then runs at the rate of its ballots)
+  constexpr int kU = 8;
+  int32_t sid[kU], nxt[kU];
+  auto request = [&](int64_t base, int32_t (&v)[kU]) {
+#pragma unroll
+    for (int k = 0; k < kU; k++) {
+      const int64_t i = base + k * 1024 + threadIdx.x;
+      v[k] = i < nl ? seg_ids[i] : -1;
+    }
+  };
+  request(0, nxt);
+  for (int64_t base = 0; base < nl; base += kU * 1024) {
+#pragma unroll
+    for (int k = 0; k < kU; k++) sid[k] = nxt[k];
+    request(base + kU * 1024, nxt);
+#pragma unroll
+    for (int k = 0; k < kU; k++) {
+      const int64_t i = base + k * 1024 + threadIdx.x;
+      const bool mine = sid[k] == (int32_t)w;
+      const unsigned long long bal = __ballot(mine);
+      if (bal) {                                           // (wave-uniform)
+        unsigned slot = 0;
+        if (lane == 0) slot = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+        slot = (unsigned)__shfl((int)slot, 0) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        // (only the row index here: the score load behind a match would wait for the prefetched ids as well -- the keys are
+        // made after the scan, all loads of a workgroup in flight at once)
+        if (mine) { if (in_lds) s_key[slot] = (unsigned long long)i; else scratch[start + slot] = (unsigned long long)i; }
+      }
+    }
+  }
+  __syncthreads();
+  // ascending key = descending score, ties by ascending original row (the order of the stable pair sort it replaces)
+  for (uint32_t r = threadIdx.x; r < ns; r += 1024) {
+    const uint32_t i = (uint32_t)(in_lds ? s_key[r] : scratch[start + r]);
+    const unsigned long long key = ((unsigned long long)(~float_sortable(scores[i])) << 32) | i;
+    if (in_lds) s_key[r] = key; else scratch[start + r] = key;
+  }
+  __syncthreads();
+  if (in_lds) {
+    unsigned P = 128;
+    while (P < ns) P <<= 1;
+    for (unsigned i = ns + threadIdx.x; i < P; i += 1024) s_key[i] = ~0ull;
+    __syncthreads();
+    lds_bitonic_sort<1024>(s_key, P);
+    for (uint32_t r = threadIdx.x; r < ns; r += 1024) {
+      const unsigned long long key = s_key[r];
+      emit_row(start + r, (uint32_t)key, w, ((unsigned long long)w << 32) | (key >> 32), 0);
+    }
+    return;
+  }
+  // ---- a segment beyond the LDS capacity: rank of every row = number of smaller keys in the segment's (global) list;
+  // tiles of the list go through LDS, every thread carries its rows' ranks.  O(ns^2 / 1024) per thread: slow, exact.
+  __threadfence();                                          // the list was written by this workgroup: make it visible to all its waves
+  __syncthreads();
+  const unsigned long long* L = scratch + start;
+  for (uint32_t r0 = 0; r0 < ns; r0 += 4 * 1024) {
+    unsigned long long mykey[4];
+    unsigned rank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t r = r0 + k * 1024 + threadIdx.x;
+      mykey[k] = r < ns ? L[r] : ~0ull;
+    }
+    for (uint32_t t0 = 0; t0 < ns; t0 += kSegCap) {
+      const uint32_t tn = min((uint32_t)kSegCap, ns - t0);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < tn; i += 1024) s_key[i] = L[t0 + i];
+      __syncthreads();
+      for (uint32_t i = 0; i < tn; i++) {
+        const unsigned long long v = s_key[i];               // (broadcast read)
+#pragma unroll
+        for (int k = 0; k < 4; k++) rank[k] += v < mykey[k] ? 1u : 0u;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t r = r0 + k * 1024 + threadIdx.x;
+      if (r < ns) emit_row(start + rank[k], (uint32_t)mykey[k], w, ((unsigned long long)w << 32) | (mykey[k] >> 32), 0);
+    }
   }
 }
 
@@ -2141,6 +2495,7 @@ __global__ __launch_bounds__(kThreads) void k_nms_greedy_direct(const PreBox* __
   const uint32_t S = *num_seg;
   for (uint32_t s = blockIdx.x; s < S; s += gridDim.x) {
     const uint32_t st = seg_start[s], ns = seg_start[s + 1] - st;
+    if (ns == 0u) continue;                                                   // (the own segment sort lists empty segments)
     if (use_ignore && (uint32_t)(keyA_s[st] >> 32) == ignore_key) continue;   // ignored rows: stay removed
     for (uint32_t i = threadIdx.x; i < ns; i += kThreads) state[st + i] = (uint8_t)kOpen;
     __syncthreads();
@@ -2348,7 +2703,8 @@ inline int count_rows(int64_t n) { return 256 * (int)((n + 256ll * kSegCountBloc
 // in B.perm_glob / B.keyC_s (joined from its side stream).
 int nms_core(const float* dets, const float* scores, const float* labels, const int32_t* seg_ids,
              const int32_t* group_ids, int64_t n, uint32_t num_segments_hint, uint32_t num_groups,
-             float thr, const NmsPlan& pl, NmsBuffers& B, hipStream_t st, bool side_streams) {
+             float thr, const NmsPlan& pl, NmsBuffers& B, hipStream_t st, bool side_streams, bool want_order_c = true,
+             const long long* row_limit = nullptr) {
   size_t sz = (size_t)n;
   const unsigned g = grid_for(n);
   const uint32_t ignore_key = num_segments_hint;           // one past the last real segment
@@ -2361,7 +2717,7 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   const char* e_lds = std::getenv("S2A_NMS_FINISH_GLOBAL");                          // test switch: finish on the global arrays
   const int force_global = e_lds && e_lds[0] == '1';
   // one segment and no groups (plain nms_rotated): order A is the output order
-  const bool need_c = labels != nullptr || seg_ids != nullptr || group_ids != nullptr;
+  const bool need_c = want_order_c && (labels != nullptr || seg_ids != nullptr || group_ids != nullptr);
   // order B by the own counting sort (four short launches behind the key kernel) instead of rocPRIM's pair sort (nine);
   // S2A_NMS_SORTB=0: A/B, tests
   bool own_sort = spatial;
@@ -2371,10 +2727,17 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   const unsigned gp = (unsigned)std::min<size_t>(kPrepBlocks, std::max<size_t>(grid_for(n), 1));
   const int rows = count_rows(n);
   const int nb = (int)((n + rows - 1) / rows);
+  // order A of a segmented call with small segments by the own segment sort (k_seg_hist + k_seg_sort) instead of the library's
+  // pair sort over the whole (mostly padding) buffer; S2A_NMS_SEGSORT=0: A/B, tests
+  const int64_t nchunks = (n + kSegChunk - 1) / kSegChunk;
+  bool seg_sort = !spatial && seg_ids != nullptr && num_segments_hint <= (uint32_t)kSegSortMaxSeg &&
+                  n >= (int64_t)num_segments_hint + 2 && nchunks <= (int64_t)kSpbHist - kSegSortMaxSeg - 8 &&
+                  (int64_t)num_segments_hint * n <= (1ll << 28);
+  if (const char* e = std::getenv("S2A_NMS_SEGSORT")) seg_sort = seg_sort && e[0] != '0';
   k_nms_prep<<<gp, 256, 0, st>>>(dets, scores, labels, seg_ids, group_ids, num_groups, ignore_key, n, B.keyA,
                                  need_c ? B.keyC : nullptr, B.idx, B.bbox_part, B.C,
                                  reinterpret_cast<uint32_t*>(B.blocked), (2 * sz + 3) / 4, B.seg_cnt, sz + 2, lo, B.hi, slots,
-                                 own_sort ? B.htab : nullptr, B.hist, B.spb_ctr);
+                                 own_sort ? B.htab : nullptr, B.hist, B.spb_ctr, seg_sort ? (uint32_t)kSegSortMaxSeg + 8u : 0u);
   // A call is as long as its chain of LAUNCHES while the kernels are short (the host needs ~5 us per launch, a rocPRIM
   // sort is nine of them).  For big segments only the spatial order B is enqueued in front of the cull, and everything
   // behind the cull works on SPATIAL positions (greedy direction from the rank keys): the score order A is needed by the
@@ -2433,8 +2796,17 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     rankkey = B.rankkey;
     perm = B.perm_sp;
   } else {
-    int rc = chain_a(st, true);
-    if (rc != S2A_OK) return rc;
+    if (seg_sort) {
+      uint32_t* seg_n = B.hist;
+      uint32_t* ign_cnt = B.hist + kSegSortMaxSeg + 8;
+      k_seg_hist<<<(unsigned)nchunks, 256, 0, st>>>(seg_ids, n, row_limit, num_segments_hint, seg_n, ign_cnt);
+      k_seg_sort<<<(unsigned)(num_segments_hint + nchunks), 1024, 0, st>>>(
+          dets, scores, seg_ids, n, row_limit, num_segments_hint, seg_n, ign_cnt, (int)nchunks, ignore_key, B.keyA, B.keyA_s, B.perm_seg,
+          B.segidx1, B.seg_start, B.num_seg, B.sorted, B.state, B.state_fb);
+    } else {
+      int rc = chain_a(st, true);
+      if (rc != S2A_OK) return rc;
+    }
     k_nms_tile_filter<<<g, kThreads, 0, st>>>(B.segidx1, B.seg_start, B.keyA_s, 32, ignore_key, use_ignore, n, nullptr, B.hi,
                                               B.tiles, B.C, pl.tile_cap);
   }
@@ -2498,7 +2870,8 @@ size_t nms_workspace_bytes(int64_t n, int64_t max_seg_rows) {
   Carver cv(nullptr, 0);
   NmsBuffers B;
   nms_carve(cv, n, pl, &B);
-  return cv.off + 256;
+  // (+ 64 KB: the segmented entry points want 48 KB of lists behind the fixed part, which the plan of a tiny n does not reach)
+  return cv.off + 256 + (64u << 10);
 }
 
 #ifdef S2A_MEASURE
@@ -3042,8 +3415,15 @@ struct NmsEmit {
 
 __global__ __launch_bounds__(256) void k_nms_emit_empty(int32_t num_groups, int32_t max_per_group, float* __restrict__ wire,
                                                         int32_t* __restrict__ labels_out, int32_t* __restrict__ counts_out,
-                                                        long long* __restrict__ overflow_out) {
-  if (overflow_out && blockIdx.x == 0 && threadIdx.x == 0) overflow_out[0] = overflow_out[1] = 0;
+                                                        const long long* __restrict__ cand_found,
+                                                        long long* __restrict__ overflow_out,
+                                                        long long* __restrict__ dropped_total) {
+  // a row cap of ZERO drops every candidate that was found: the same accounting as k_nms_group_emit with n = 0
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long found = cand_found ? *cand_found : 0;
+    if (overflow_out) { overflow_out[0] = found; overflow_out[1] = found; }
+    if (dropped_total && cand_found) *dropped_total += found;
+  }
   const int64_t row = (int64_t)max_per_group * 7 + 1, total = (int64_t)num_groups * row;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t c = i % row;
@@ -3064,21 +3444,23 @@ int nms_segmented_impl(const float* dets, const float* scores, const int32_t* se
   S2A_CHECK_ARG(num_segments > 0 && num_groups > 0, "nms_rotated_segmented: bad segment/group count");
   S2A_CHECK_ARG(keep == nullptr || (group_counts != nullptr && max_per_group > 0),
                 "nms_rotated_segmented: keep needs group_counts and max_per_group");
-  S2A_CHECK_ARG(em.wire == nullptr || (em.row_labels != nullptr && max_per_group > 0),
-                "nms_rotated_segmented_dets: the detection rows need row_labels and max_per_group");
-  if (n == 0) {
+  S2A_CHECK_ARG(em.wire == nullptr || max_per_group > 0, "nms_rotated_segmented_dets: the detection rows need max_per_group");
+  if (n == 0) {      // (in front of the NULL checks: the tensors of an empty candidate set have no storage)
     if (keep) {
       fill_u32(keep, 0xffffffffu, (size_t)num_groups * max_per_group, st);
       fill_u32(group_counts, 0u, (size_t)num_groups, st);
     }
     if (em.wire) {
       k_nms_emit_empty<<<64, 256, 0, st>>>(num_groups, max_per_group, em.wire, em.labels_out, em.counts_out,
-                                           reinterpret_cast<long long*>(em.overflow_out));
+                                           reinterpret_cast<const long long*>(em.cand_found),
+                                           reinterpret_cast<long long*>(em.overflow_out),
+                                           reinterpret_cast<long long*>(em.dropped_total));
       S2A_LAUNCH_CHECK();
     }
     return S2A_OK;
   }
   S2A_CHECK_ARG(dets && scores && segment_ids, "nms_rotated_segmented: NULL tensor");
+  S2A_CHECK_ARG(em.wire == nullptr || em.row_labels != nullptr, "nms_rotated_segmented_dets: the detection rows need row_labels");
   NmsPlan pl;
   S2A_CHECK_ARG(nms_plan(n, n, &pl) == 0, "nms_rotated_segmented: rocprim size query failed");
   // the caller may have sized the workspace with a tighter per-segment bound (s2a_nms_rotated_workspace_bytes(n,
@@ -3105,8 +3487,13 @@ int nms_segmented_impl(const float* dets, const float* scores, const int32_t* se
   B.tiles = reinterpret_cast<TileRef*>(base);
   B.edges = reinterpret_cast<uint2*>(base + tbytes);
   B.gq = reinterpret_cast<uint2*>(base + tbytes + ebytes);
+  // the detection rows without the (group, score) sort of the whole buffer: k_nms_group_emit_scan.  S2A_NMS_SEGSORT=0 keeps
+  // the library sorts (A/B, tests)
+  bool scan_emit = em.wire != nullptr && keep == nullptr && group_ids != nullptr && max_per_group <= kEmitCap / 2;
+  if (const char* e = std::getenv("S2A_NMS_SEGSORT")) scan_emit = scan_emit && e[0] != '0';
   int rc = nms_core(dets, scores, nullptr, segment_ids, group_ids, n, (uint32_t)num_segments,
-                    (uint32_t)num_groups, iou_threshold, pl, B, st, false);
+                    (uint32_t)num_groups, iou_threshold, pl, B, st, false, !scan_emit,
+                    reinterpret_cast<const long long*>(em.cand_found));
   if (rc != S2A_OK) return rc;
 #ifdef S2A_MEASURE
   { int rc_ = nms_debug_dump(B, n, st); if (rc_ != S2A_OK) return rc_; }
@@ -3117,7 +3504,13 @@ int nms_segmented_impl(const float* dets, const float* scores, const int32_t* se
     k_nms_group_compact<<<(unsigned)num_groups, 1024, 0, st>>>(B.keyC_s, B.perm_glob, B.keep_orig, n,
                                                                max_per_group, keep, group_counts);
   }
-  if (em.wire) {
+  if (em.wire && scan_emit) {
+    k_nms_group_emit_scan<<<(unsigned)num_groups, 1024, 0, st>>>(group_ids, B.keep_orig, dets, scores, em.row_labels, n,
+                                                                 max_per_group, em.wire, em.labels_out, em.counts_out,
+                                                                 reinterpret_cast<const long long*>(em.cand_found),
+                                                                 reinterpret_cast<long long*>(em.overflow_out),
+                                                                 reinterpret_cast<long long*>(em.dropped_total));
+  } else if (em.wire) {
     k_nms_group_emit<<<(unsigned)num_groups, 1024, 0, st>>>(B.keyC_s, B.perm_glob, B.keep_orig, dets, scores,
                                                             em.row_labels, n, max_per_group, em.wire, em.labels_out,
                                                             em.counts_out, reinterpret_cast<const long long*>(em.cand_found),

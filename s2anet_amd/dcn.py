@@ -159,7 +159,13 @@ _COLUMNS_CACHE_MB = 192
 
 
 def _cache_step(step, bytes_per_image):
-    mb = int(os.environ.get("S2A_DCN_COLUMNS_MB", _COLUMNS_CACHE_MB))
+    """images per chunk of the unfused weight gradient: the largest divisor of im2col_step whose `columns` chunk stays
+    inside the last-level cache (S2A_DCN_COLUMNS_MB, 0 = the reference's chunking by im2col_step itself).  A known
+    deviation from the reference's partial-sum ORDER for the same im2col_step; same sums."""
+    try:
+        mb = int(os.environ.get("S2A_DCN_COLUMNS_MB", _COLUMNS_CACHE_MB))
+    except ValueError:
+        mb = _COLUMNS_CACHE_MB
     if mb <= 0:
         return step
     best = 1
@@ -227,8 +233,7 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
         input, offset, gradOutput, gradWeight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
         deformable_group, im2col_step)
     L = _lib.lib()
-    step, npos = im2col_step, im2col_step * Ho * Wo
-    p = params(step)
+    step = im2col_step
     # f16 + AlignConv geometry: ONE fused kernel for the whole batch (columns formed and contracted in LDS, positions as the
     # MFMA's K through transposing LDS reads, split-K atomics): s2a_deform_conv_backward_weight_f16
     fused = (x.dtype == torch.float16 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)

@@ -241,9 +241,29 @@ def batched_multiclass_nms_rotated(bboxes, scores, score_thr=0.05, iou_thr=0.5, 
     bb = _f32c(bboxes).reshape(-1, 5)
     sc = _f32c(scores).reshape(-1)
     total = B * n * C
+    if max_candidates is not None and int(max_candidates) < 1:
+        raise ValueError("max_candidates must be >= 1 (a cap of zero would drop every candidate)")
     cap = total if max_candidates is None else min(int(max_candidates), total)
     L = _lib.lib()
     K = int(max_per_img)
+    if total == 0:      # no box or no class: padded empty results through the same entry point (n = 0: no tensor is read)
+        wire = torch.empty((B, K * 7 + 1), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, K), dtype=torch.int32, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        ncand = torch.zeros((1,), dtype=torch.int64, device=dev)
+        overflow = torch.empty((2,), dtype=torch.int64, device=dev) if return_overflow else None
+        if B > 0:
+            with torch.cuda.device(dev):
+                _lib.check(L.s2a_nms_rotated_segmented_dets(
+                    None, None, None, None, None, 0, max(B * C, 1), B, float(iou_thr), K, _lib.ptr(wire), _lib.ptr(labels),
+                    _lib.ptr(counts), _lib.ptr(ncand), _lib.ptr(overflow), _lib.ptr(dropped_total), None, 0,
+                    _lib.stream_ptr(dev)))
+        elif overflow is not None:
+            overflow.zero_()
+        out = (wire[:, :K * 7].view(B, K, 7)[..., :6], labels, counts)
+        if return_overflow:
+            out += (overflow,)
+        return out + (wire,) if return_wire else out
     cboxes = torch.empty((cap, 5), dtype=torch.float32, device=dev)
     cscores = torch.empty((cap,), dtype=torch.float32, device=dev)
     seg = torch.empty((cap,), dtype=torch.int32, device=dev)

@@ -294,6 +294,80 @@ def test_nms_list_overflow_takes_the_direct_path(rng):
     assert ref.sum() < n // 10 and not ref[seg < 0].any()
 
 
+def _segmented_dets(L, _lib, D, Sc, Sg, Gr, Cl, n, nseg, ngrp, thr, K):
+    wire = torch.empty((ngrp, K * 7 + 1), dtype=torch.float32, device=dev())
+    labels = torch.empty((ngrp, K), dtype=torch.int32, device=dev())
+    counts = torch.empty((ngrp,), dtype=torch.int32, device=dev())
+    ws = torch.empty(L.s2a_nms_rotated_workspace_bytes(n, n), dtype=torch.uint8, device=dev())
+    _lib.check(L.s2a_nms_rotated_segmented_dets(_lib.ptr(D), _lib.ptr(Sc), _lib.ptr(Sg), _lib.ptr(Gr), _lib.ptr(Cl), n, nseg, ngrp,
+                                                thr, K, _lib.ptr(wire), _lib.ptr(labels), _lib.ptr(counts), None, None, None,
+                                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev())))
+    torch.cuda.synchronize()
+    return wire.cpu().numpy(), labels.cpu().numpy(), counts.cpu().numpy()
+
+
+@pytest.mark.parametrize("case", ["detector_like", "huge_segment", "many_kept", "tiny"])
+def test_nms_own_segment_sort_and_scanning_emit(rng, monkeypatch, case):
+    """round 5: the (segment, score) order by k_seg_hist / k_seg_sort (one workgroup per segment, LDS bitonic sort; a segment
+    beyond the LDS capacity ranks its rows by counting) and the detection rows by k_nms_group_emit_scan (kept rows of a group
+    collected and sorted in LDS, folded in rounds when more are kept than the LDS holds) -- against the library-sort form
+    (S2A_NMS_SEGSORT=0) BIT FOR BIT and against the oracle per segment.  Padding rows anywhere, empty segments, segments of
+    one row, a segment of 9 000 rows, 11 000 kept rows in one group."""
+    from s2anet_amd import _lib
+    L = _lib.lib()
+    if case == "detector_like":        # 3 images x 15 classes inside a mostly empty static buffer, padding at the end
+        n_real, n, nseg, ngrp, K, span = 9000, 40000, 45, 3, 700, 400.0
+    elif case == "huge_segment":       # one segment beyond kSegCap = 8192 rows (rank-by-counting path), the rest small
+        n_real, n, nseg, ngrp, K, span = 12000, 12500, 6, 2, 2000, 900.0
+    elif case == "many_kept":          # nothing overlaps: > 8192 kept rows in one group -> the emit folds in rounds
+        n_real, n, nseg, ngrp, K, span = 11000, 11100, 4, 1, 300, 20000.0
+    else:
+        n_real, n, nseg, ngrp, K, span = 37, 64, 9, 2, 5, 80.0
+    d = np.zeros((n, 5), np.float32)
+    d[:n_real] = rand_rboxes(rng, n_real, span=span, lo=4, hi=(12 if case == "many_kept" else 80))
+    s = np.full(n, -1.0, np.float32)
+    s[:n_real] = distinct_scores(rng, n_real)
+    if case == "tiny":
+        s[3] = s[4] = s[5]                                                  # score ties: broken by the original row
+    seg = np.full(n, -1, np.int32)
+    if case == "huge_segment":
+        seg[:n_real] = np.where(np.arange(n_real) < 9000, 2, rng.integers(0, nseg, n_real))
+    else:
+        seg[:n_real] = rng.integers(0, nseg, n_real)
+        seg[:n_real][seg[:n_real] == 1] = 0                                 # segment 1 stays EMPTY
+    per = (nseg + ngrp - 1) // ngrp
+    grp = np.where(seg >= 0, seg // per, -1).astype(np.int32)
+    cls = np.where(seg >= 0, seg % per, -1).astype(np.int32)
+    hole = rng.integers(0, n_real, max(n_real // 50, 2))                    # padding rows in the middle of the buffer as well
+    seg[hole] = grp[hole] = cls[hole] = -1
+    order = rng.permutation(n) if case != "detector_like" else np.arange(n)
+    d, s, seg, grp, cls = d[order], s[order], seg[order], grp[order], cls[order]
+    D, Sc, Sg, Gr, Cl = cu(d), cu(s), cu(seg), cu(grp), cu(cls)
+    thr = 0.3
+    monkeypatch.setenv("S2A_NMS_SEGSORT", "0")
+    w0, l0, c0 = _segmented_dets(L, _lib, D, Sc, Sg, Gr, Cl, n, nseg, ngrp, thr, K)
+    monkeypatch.delenv("S2A_NMS_SEGSORT")
+    w1, l1, c1 = _segmented_dets(L, _lib, D, Sc, Sg, Gr, Cl, n, nseg, ngrp, thr, K)
+    assert np.array_equal(c0, c1) and np.array_equal(l0, l1) and np.array_equal(w0.view(np.uint32), w1.view(np.uint32))
+    # and the oracle: per segment NMS, per group the kept rows by descending score (ties: original row), cut to K
+    keep = np.zeros(n, bool)
+    for c in range(nseg):
+        idx = np.nonzero(seg == c)[0]
+        if len(idx):
+            keep[idx[oracle.nms_rotated(d[idx], s[idx], thr)]] = True
+    for g in range(ngrp):
+        idx = np.nonzero(keep & (grp == g))[0]
+        idx = idx[np.lexsort((idx, -s[idx].astype(np.float64)))][:K]
+        assert c1[g] == len(idx)
+        rows = w1[g, :K * 7].reshape(K, 7)
+        assert np.array_equal(rows[:len(idx), :5], d[idx]) and np.array_equal(rows[:len(idx), 5], s[idx])
+        assert np.array_equal(rows[:len(idx), 6], cls[idx].astype(np.float32)) and (rows[len(idx):, 6] == -1).all()
+    if case == "many_kept":
+        assert keep.sum() > 8192
+    if case == "huge_segment":
+        assert (seg == 2).sum() > 8192
+
+
 def test_nms_segmented_big_segments_take_the_spatial_path(rng, monkeypatch):
     """the segmented entry point with few, large segments (> 4096 rows on average: Morton order + bounding-box tile
     filter) and with many small ones (blocks in score order, every tile tested) gives the oracle's keep flags either way"""
@@ -552,6 +626,26 @@ def test_batched_nms_writes_the_wire_buffer_and_counts_dropped_candidates(rng):
     # no candidate at all in the batch
     d0, l0, c0, o0 = S.batched_multiclass_nms_rotated(cu(boxes), cu(scores * 0), 0.05, 0.5, K, return_overflow=True)
     assert (d0 == 0).all() and (l0 == -1).all() and (c0 == 0).all() and o0.cpu().tolist() == [0, 0]
+    # an EMPTY candidate set (no box at all: the tensors have no storage): padded empty results, zero accounting
+    e_boxes = torch.empty((B, 0, 5), dtype=torch.float32, device="cuda")
+    e_scores = torch.empty((B, 0, C), dtype=torch.float32, device="cuda")
+    d1, l1, c1, o1, w1 = S.batched_multiclass_nms_rotated(e_boxes, e_scores, 0.05, 0.5, K, return_overflow=True,
+                                                          dropped_total=total, return_wire=True)
+    assert tuple(d1.shape) == (B, K, 6) and (d1 == 0).all() and (l1 == -1).all() and (c1 == 0).all()
+    assert o1.cpu().tolist() == [0, 0] and int(total) == 74 and (w1[:, K * 7] == 0).all()
+    assert (w1[:, :K * 7].view(B, K, 7)[..., 6] == -1).all()
+    with pytest.raises(ValueError):
+        S.batched_multiclass_nms_rotated(cu(boxes), cu(scores), 0.05, 0.5, K, max_candidates=0)
+    # the C entry point with n = 0 and candidates that WERE found upstream (a cap of zero rows): all of them count as dropped
+    from s2anet_amd import _lib
+    L = _lib.lib()
+    wire0 = torch.empty((B, K * 7 + 1), dtype=torch.float32, device="cuda")
+    found_dev = torch.tensor([41], dtype=torch.int64, device="cuda")
+    ovf_dev = torch.empty((2,), dtype=torch.int64, device="cuda")
+    _lib.check(L.s2a_nms_rotated_segmented_dets(None, None, None, None, None, 0, B * C, B, 0.5, K, _lib.ptr(wire0), None, None,
+                                                _lib.ptr(found_dev), _lib.ptr(ovf_dev), _lib.ptr(total), None, 0,
+                                                _lib.stream_ptr(wire0.device)))
+    assert ovf_dev.cpu().tolist() == [41, 41] and int(total) == 74 + 41 and (wire0[:, K * 7] == 0).all()
 
 
 def test_nms_order_b_counting_sort_labels_of_any_kind(rng, monkeypatch):
