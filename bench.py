@@ -79,6 +79,26 @@ def recorded_traffic(key, batch, pixels):
         return None, True
 
 
+def recorded_occupancy(group):
+    """occupancy / VALU-utilisation record of the rotated-NMS and rotated-IoU kernels from the rocprofv3 PMC passes of the
+    round's evidence run (scripts/gpu_round5_final.sh -> scripts/nms_pmc_report.py --json -> profiles/rNN_ops_occupancy.json;
+    `group` = "ml_nms_200k" | "box_iou_10k").  Valid only for the kernel sources it was taken on: otherwise
+    {"stale": True} -- never a number measured on other code."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_ops_occupancy.json")))
+    try:
+        with open(found[-1]) as f:
+            rec = json.load(f)
+        if rec.get("source_sha16") != _sha16(rec["sources"]):
+            return {"stale": True, "record": os.path.basename(found[-1])}
+        out = dict(rec[group])
+        out["record"] = os.path.basename(found[-1])
+        out["unit"] = "achieved waves per CU (of 32), from SQ_WAVE_CYCLES / kernel cycles; valu_util_pct = share of SIMD issue cycles"
+        return out
+    except (OSError, KeyError, ValueError, TypeError, IndexError):
+        return {"stale": True, "record": None}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,7 +291,8 @@ def measure_ops(dev, with_cpu=True):
         "bound": "max(hbm write of N*M*4 B, VALU chain finder -> exact pass -> scatter); the chain binds",
         "hbm_write_floor_us": round(byts / (PEAK_HBM_GBS * 1e9) * 1e6, 1),
         "valu_chain_us_recorded": {"pair_finder": 60, "exact_pass": 60, "scatter": 21, "zero_fill_beside": 96},
-        "alg_bytes": byts, "achieved_GBs": round(byts / sec / 1e9, 1), "hbm_write_frac": round(byts / sec / 1e9 / PEAK_HBM_GBS, 4)}
+        "alg_bytes": byts, "achieved_GBs": round(byts / sec / 1e9, 1), "hbm_write_frac": round(byts / sec / 1e9 / PEAK_HBM_GBS, 4),
+        "occupancy": recorded_occupancy("box_iou_10k")}
     # configs[0], second half: polyiou (DOTA_devkit/polyiou/csrc/polyiou.cpp:108-128) on the 10 k boxes as polygons,
     # 1 M (i, j) pairs of nearby boxes so that most of them overlap (f64 on the vector units, bit-exact by test)
     from s2anet_amd.formats import rbox_to_poly
@@ -318,8 +339,16 @@ def measure_ops(dev, with_cpu=True):
     cnt = np.bincount(lab_h).astype(np.float64)
     pairs = float((cnt * (cnt - 1) / 2).sum())
     ops["ml_nms_rotated_200k_x_15"] = {"ms": round(sec * 1e3, 3), "keep": int(keep.numel()), "same_label_pairs": pairs,
-                                       "Tpairs_s": round(pairs / sec / 1e12, 3)}
-    del d, sc, lab
+                                       "Tpairs_s": round(pairs / sec / 1e12, 3), "occupancy": recorded_occupancy("ml_nms_200k")}
+    # the size ONE image's post-processing hands the drop-in op (utils/bbox_nms_rotated.py:47): 5 000 rows x 15 labels --
+    # a synchronous call (the host reads the count); settled by one launch (k_nms_small) since round 5
+    n5 = 5000
+    keep5 = S.ml_nms_rotated(d[:n5].contiguous(), sc[:n5].contiguous(), lab[:n5].contiguous(), 0.5)
+    d5, s5, l5 = d[:n5].contiguous(), sc[:n5].contiguous(), lab[:n5].contiguous()
+    sec5 = _time_launches(lambda: S.ml_nms_rotated(d5, s5, l5, 0.5), iters=20)
+    ops["ml_nms_rotated_5k_x_15"] = {"us": round(sec5 * 1e6, 1), "keep": int(keep5.numel()),
+                                     "note": "synchronous drop-in call incl. the host's wait for the count; one kernel launch"}
+    del d, sc, lab, d5, s5, l5
     # SURVEY 8(f) row 1 at the AlignConv shape: deform_conv backward, P3 x batch 8, f16, AlignConv-like offsets
     try:
         from s2anet_amd.alignconv import align_offsets

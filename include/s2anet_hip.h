@@ -134,6 +134,12 @@ int s2a_nms_rotated(const float* dets, const float* scores, int64_t n, float iou
                     int64_t* keep, int64_t* count_dev, int64_t* host_count, void* workspace,
                     size_t workspace_bytes, s2a_stream_t stream);
 
+/* Synchronous calls (host_count != NULL) of the two ops above on at most 16 384 rows are settled by ONE kernel launch when the
+ * labels split the rows into at most 64 segments of at most 640 rows and at most 4 096 pairs survive the cull of a segment;
+ * otherwise -- and always for host_count == NULL -- by the general multi-launch path (same keep list either way, tested).
+ * Counters of the two outcomes since the library was loaded (diagnostic; tests assert that the small path really ran). */
+int s2a_nms_small_stats(int64_t* taken, int64_t* fell_back);
+
 /* The same two ops on float64 boxes.  The reference dispatches the NMS kernels on the dtype of `dets`
  * (AT_DISPATCH_FLOATING_TYPES_AND_HALF, utils/nms_rotated/src/nms_rotated_cuda.cu:95-100,
  * utils/ml_nms_rotated/src/nms_rotated_cuda.cu:100-105; AT_DISPATCH_FLOATING_TYPES in the CPU files): on double boxes it

@@ -85,6 +85,7 @@ SYMBOLS = {
     "s2a_align_conv_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AlignParams), c_vp,
                                        c_sz, c_vp]),
     "s2a_dcn_packed_elems": (c_i64, [c_i64, c_i64, c_int]),
+    "s2a_nms_small_stats": (c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "s2a_dcn_pack_weight": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
     "s2a_bias_act_nhwc": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
     "s2a_bias_act_nhwc_to": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),

@@ -1164,28 +1164,66 @@ __device__ __forceinline__ int64_t seg_row_limit(const long long* __restrict__ r
   return v < 0 ? 0 : (v < (long long)n ? (int64_t)v : n);
 }
 // bitonic sort of P (power of two, >= 128) 64-bit keys in LDS, ascending; NT threads; ends with a barrier.  Compare-exchange
-// distances up to 64 stay inside an aligned block of 128 keys: those stages run per wave on its own blocks with no workgroup
-// barrier (7 of the 12 stages of a 4096-key merge; 21 barriers instead of 78 for 4096 keys, 6 instead of 45 for 512)
+// distances up to 64 stay inside an aligned block of 128 keys: those stages run per wave on its own blocks with the two keys
+// of a lane in REGISTERS (distance 64 = the lane's own pair, shorter distances by cross-lane exchange) -- no workgroup barrier
+// and no LDS round trip per stage (a stage through LDS cost ~300 cycles of latency, 91 of them for 8 192 keys).  Longer
+// distances go through LDS with a barrier per stage.  first_k: the length the data is ALREADY sorted to in alternating
+// directions (runs of first_k / 2 keys, even runs ascending, odd runs descending), 2 = nothing: merging pre-sorted runs
+// skips the levels below it.
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m);
+  return ((unsigned long long)hi << 32) | lo;
+}
 template <int NT>
-__device__ __forceinline__ void lds_bitonic_sort(unsigned long long* __restrict__ s, unsigned P) {
+__device__ __forceinline__ void lds_bitonic_sort(unsigned long long* __restrict__ s, unsigned P, unsigned first_k = 2) {
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   auto cmpx = [&](unsigned t, unsigned j, unsigned k) {
     const unsigned i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
     const unsigned long long a = s[i], b = s[l];
     if ((a > b) == ((i & k) == 0u)) { s[i] = b; s[l] = a; }
   };
-  for (unsigned k = 2; k <= P; k <<= 1) {
-    unsigned j = k >> 1;
-    for (; j >= 128; j >>= 1) {
+  // the stages of level k with distance <= 64 (all of them when k <= 128) on the wave's own 128-key blocks; levels k0 .. k1
+  // one level in registers; KC = min(k, 128) at compile time so that the distances >= k vanish (27 exchange stages for a
+  // 128-key sort, not 42)
+  auto level = [&](auto kc, unsigned k, unsigned base, unsigned long long& lo, unsigned long long& hi) {
+    constexpr unsigned KC = decltype(kc)::value;
+    const bool asc_lo = ((base + lane) & k) == 0u, asc_hi = ((base + 64 + lane) & k) == 0u;
+    if constexpr (KC >= 128) {                                            // distance 64: the lane's own two keys
+      if ((lo > hi) == asc_lo) { const unsigned long long t = lo; lo = hi; hi = t; }
+    }
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) {
+      if ((unsigned)j >= KC) continue;                                    // (level k starts at distance k / 2)
+      const unsigned long long olo = shfl_xor_u64(lo, j), ohi = shfl_xor_u64(hi, j);
+      const bool low = (lane & (unsigned)j) == 0u;                        // this lane holds the lower index of its pair
+      lo = ((lo > olo) == (low == asc_lo)) ? olo : lo;
+      hi = ((hi > ohi) == (low == asc_hi)) ? ohi : hi;
+    }
+  };
+  auto local = [&](unsigned k0, unsigned k1) {
+    for (unsigned blk = wave; blk < P / 128; blk += NT / 64) {            // (always the same wave for a block)
+      const unsigned base = blk * 128;
+      unsigned long long lo = s[base + lane], hi = s[base + 64 + lane];
+      if (k0 <= 2u && 2u <= k1) level(std::integral_constant<unsigned, 2>{}, 2u, base, lo, hi);
+      if (k0 <= 4u && 4u <= k1) level(std::integral_constant<unsigned, 4>{}, 4u, base, lo, hi);
+      if (k0 <= 8u && 8u <= k1) level(std::integral_constant<unsigned, 8>{}, 8u, base, lo, hi);
+      if (k0 <= 16u && 16u <= k1) level(std::integral_constant<unsigned, 16>{}, 16u, base, lo, hi);
+      if (k0 <= 32u && 32u <= k1) level(std::integral_constant<unsigned, 32>{}, 32u, base, lo, hi);
+      if (k0 <= 64u && 64u <= k1) level(std::integral_constant<unsigned, 64>{}, 64u, base, lo, hi);
+      for (unsigned k = k0 > 128u ? k0 : 128u; k <= k1; k <<= 1) level(std::integral_constant<unsigned, 128>{}, k, base, lo, hi);
+      s[base + lane] = lo;
+      s[base + 64 + lane] = hi;
+    }
+  };
+  if (first_k <= 128) local(first_k, 128);
+  __syncthreads();
+  for (unsigned k = first_k > 256 ? first_k : 256; k <= P; k <<= 1) {
+    for (unsigned j = k >> 1; j >= 128; j >>= 1) {
       for (unsigned t = threadIdx.x; t < P / 2; t += NT) cmpx(t, j, k);
       __syncthreads();
     }
-    for (unsigned blk = wave; blk < P / 128; blk += NT / 64)        // (always the same wave for a block)
-      for (unsigned jj = j; jj > 0; jj >>= 1) {
-        cmpx(blk * 64 + lane, jj, k);
-        wave_lds_handoff();
-      }
-    if (k >= 128) __syncthreads();
+    local(k, k);
+    __syncthreads();
   }
 }
 
@@ -2550,6 +2588,416 @@ __global__ void k_nms_finish(const uint8_t* __restrict__ state, const uint8_t* _
   keep_orig[perm[p]] = v == kKept ? 1 : 0;
 }
 
+// ---------------------------------------------------------------- SMALL inputs in ONE launch (round 5)
+// The drop-in ops are synchronous (the host reads the count), so a call costs its chain of launches: ~40 of them at
+// ~5 us each whatever the size -- 0.20 ms for 5 000 rows, the size one image's post-processing really has
+// (utils/bbox_nms_rotated.py:47).  For n <= kSmallN rows whose labels split them into segments of <= kSmallSeg rows:
+//   one workgroup per distinct label (every workgroup finds the distinct labels itself: <= 16 label loads per thread, an
+//   LDS hash set, a rank sort of <= 64 entries) -- collects its rows, sorts (~score | row) keys in LDS, pre-processes the
+//   boxes, culls all pairs (circle, separating axes, IoU upper bound: the big path's tests) into an LDS candidate list,
+//   evaluates the candidates exactly (8-slot lanes, the rare 24-slot redo) into a suppression BIT MASK in LDS, resolves the
+//   greedy order with one wave walking the mask rows, and appends its kept keys to a global list; the LAST workgroup to
+//   finish (ticket) sorts the kept keys of all labels and writes keep[] in descending score order.
+// Anything outside the limits (more labels, a bigger segment, more candidates than the list holds) raises a status bit and
+// the host runs the general path: never a wrong or partial answer.
+constexpr int kSmallN = 16384, kSmallSeg = 640, kSmallLabels = 64, kSmallCand = 4096, kSmallGrid = kSmallLabels;
+constexpr int kSmallW = kSmallSeg / 64;                   // mask words per row
+constexpr int kSmOffBox = kSmallSeg * kSmallW * 8;        // 51 200
+constexpr int kSmOffCand = kSmOffBox + kSmallSeg * 32;    // 71 680
+constexpr int kSmOffPts = kSmOffCand + kSmallCand * 4;    // 88 064
+constexpr int kSmallExact = 768;                          // threads of the exact pass (8 candidate-point slots each)
+constexpr int kSmOffKey = kSmOffPts + 8 * kSmallExact * 8;
+constexpr int kSmOffIdx = kSmOffKey + 1024 * 8;
+constexpr int kSmOffMisc = kSmOffIdx + kSmallSeg * 4;     // 147 968
+constexpr int kSmallLds = kSmOffMisc + 1024;              // 148 992 (the merge holds <= 16 384 kept keys in [0, 131 072))
+static_assert(kSmallN * 8 <= kSmOffMisc, "the merge buffer must not reach the counters");
+struct SmallCtl {                 // one slot per call in flight (zero between calls: the last workgroup resets the first four)
+  uint32_t kept, ticket, status, done;
+  uint32_t result_count, result_status, pad2[2];
+};
+__device__ SmallCtl g_small_ctl[16];
+#ifdef S2A_MEASURE
+__device__ unsigned long long g_small_stamps[64 * 16];     // measurement builds: phase stamps of k_nms_small per workgroup
+#define SMALL_STAMP(k) do { if (threadIdx.x == 0) g_small_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SMALL_STAMP(k) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(1024) void k_nms_small(const float* __restrict__ dets5, const float* __restrict__ scores,
+                                                    const float* __restrict__ labels, int n, float thr,
+                                                    unsigned long long* __restrict__ kept_keys, SmallCtl* __restrict__ ctl,
+                                                    uint32_t* __restrict__ host_result /* pinned, mapped: count, status */,
+                                                    int64_t* __restrict__ keep, int64_t* __restrict__ count_dev) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem);
+  PreBox* s_box = reinterpret_cast<PreBox*>(smem + kSmOffBox);
+  uint32_t* s_cand = reinterpret_cast<uint32_t*>(smem + kSmOffCand);
+  float2* s_pts = reinterpret_cast<float2*>(smem + kSmOffPts);
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem + kSmOffKey);
+  uint32_t* s_idx = reinterpret_cast<uint32_t*>(smem + kSmOffIdx);
+  uint32_t* s_hash = reinterpret_cast<uint32_t*>(smem + kSmOffMisc);          // [128]
+  uint32_t* s_list = s_hash + 128;                                             // [64] distinct label keys, then sorted
+  uint32_t* s_ctr = s_list + 64;                                               // [8]: 0 distinct, 1 rows, 2 candidates, 3 redo, 4 last flag, 5 kept
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr uint32_t kEmptyKey = 0xffffffffu;       // (float_sortable never yields all ones for a label that is not a -NaN)
+  if (tid < 128) s_hash[tid] = kEmptyKey;
+  if (tid < 8) s_ctr[tid] = 0u;
+  SMALL_STAMP(0);
+  __syncthreads();
+  // ---- distinct labels (every workgroup, the same set)
+  uint32_t lab[kSmallN / 1024], sck[kSmallN / 1024];    // label keys and (~score) keys of this thread's rows: one round trip
+#pragma unroll
+  for (int k = 0; k < kSmallN / 1024; k++) {
+    const int i = tid + 1024 * k;
+    lab[k] = i < n ? nms_segkey(labels, nullptr, 0u, i) : kEmptyKey;
+    sck[k] = i < n ? ~float_sortable(scores[i]) : 0u;
+  }
+  bool too_many = false;
+#pragma unroll
+  for (int k = 0; k < kSmallN / 1024; k++) {
+    const uint32_t key = lab[k];
+    if (tid + 1024 * k >= n) continue;
+    uint32_t h = (key * 0x9e3779b1u) >> 25;          // 7 bits
+    bool placed = false;
+    for (int probe = 0; probe < 128; probe++) {
+      // (look first: 5 000 rows are 5 000 reads of 15 hot slots, and same-address LDS atomics serialise lane by lane)
+      uint32_t prev = __hip_atomic_load(&s_hash[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (prev == kEmptyKey) prev = atomicCAS(&s_hash[h], kEmptyKey, key);
+      if (prev == kEmptyKey || prev == key) { placed = true; break; }
+      h = (h + 1) & 127;
+    }
+    too_many |= !placed;
+  }
+  if (__syncthreads_or(too_many)) {                // > 128 distinct labels: every workgroup decides the same
+    if (blockIdx.x == 0 && tid == 0) atomicOr(&ctl->status, 1u);
+    if (tid == 0) s_ctr[6] = 1u;
+    goto finish;
+  }
+  if (tid < 128 && s_hash[tid] != kEmptyKey) {
+    const unsigned pos = atomicAdd(&s_ctr[0], 1u);
+    if (pos < (unsigned)kSmallLabels) s_list[pos] = s_hash[tid];
+  }
+  __syncthreads();
+  {
+    const unsigned nd = s_ctr[0];
+    if (nd > (unsigned)kSmallLabels) {                // (uniform, and the same in every workgroup)
+      if (blockIdx.x == 0 && tid == 0) atomicOr(&ctl->status, 1u);
+      if (tid == 0) s_ctr[6] = 1u;
+      goto finish;
+    }
+    uint32_t mine = 0, rank = 0;
+    if (tid < (int)nd) {
+      mine = s_list[tid];
+      for (unsigned j = 0; j < nd; j++) rank += s_list[j] < mine ? 1u : 0u;
+    }
+    __syncthreads();
+    if (tid < (int)nd) s_list[rank] = mine;         // ascending label order (any fixed order would do)
+    __syncthreads();
+  }
+  {
+  const unsigned nd = s_ctr[0];
+  if (blockIdx.x >= nd) return;                      // (no label for this workgroup: it takes no ticket)
+  const uint32_t my_label = s_list[blockIdx.x];
+  SMALL_STAMP(1);
+  // ---- rows of this label
+#pragma unroll
+  for (int k = 0; k < kSmallN / 1024; k++) {
+    const bool mine = tid + 1024 * k < n && lab[k] == my_label;
+    const unsigned long long bal = __ballot(mine);
+    if (bal) {
+      unsigned slot = 0;
+      if (lane == 0) slot = atomicAdd(&s_ctr[1], (unsigned)__popcll(bal));
+      slot = (unsigned)__shfl((int)slot, 0) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+      // (the key goes straight into the sort buffer: ascending key = descending score, ties by ascending row)
+      if (mine && slot < (unsigned)kSmallSeg) s_key[slot] = ((unsigned long long)sck[k] << 32) | (uint32_t)(tid + 1024 * k);
+    }
+  }
+  __syncthreads();
+  const unsigned ns = s_ctr[1];
+  if (ns > (unsigned)kSmallSeg) {                    // (uniform) a segment beyond the LDS mask: general path
+    if (tid == 0) atomicOr(&ctl->status, 2u);
+  }
+  const unsigned nsc = min(ns, (unsigned)kSmallSeg);
+  const unsigned W = (nsc + 63) >> 6;
+  unsigned P = 128;
+  while (P < nsc) P <<= 1;
+  for (unsigned r = nsc + tid; r < P; r += 1024) s_key[r] = ~0ull;
+  for (unsigned i = tid; i < nsc * (unsigned)kSmallW; i += 1024) s_mask[i] = 0ull;
+  __syncthreads();
+  SMALL_STAMP(2);
+  lds_bitonic_sort<1024>(s_key, P);
+  SMALL_STAMP(3);
+  for (unsigned r = tid; r < nsc; r += 1024) {
+    const uint32_t o = (uint32_t)s_key[r];
+    const float* d = dets5 + 5 * (int64_t)o;
+    s_box[r] = make_prebox(d[0], d[1], d[2], d[3], d[4], 0.f);
+  }
+  __syncthreads();
+  SMALL_STAMP(4);
+  // ---- cull: 64 x 64 tiles of the upper triangle, a wave per tile, lane = row j, the 64 rows i of the other block broadcast
+  // Stage 1, by tiles (half tiles: 32 rows of block ib against the 64 of block jb, a wave per item, lane = row j, the rows i a
+  // broadcast read each): the circle test; survivors go to an LDS list (the exact pass's point slots are free until then).
+  // Stage 2, dense: every thread takes ONE survivor through the separating-axis / IoU-bound test (in place in the tile loop
+  // it ran for whole waves with a handful of live lanes: 25 k of the cull's 33-43 k cycles).
+  uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_pts);          // <= kSmallPairs circle survivors, (i << 16) | j
+  constexpr unsigned kSmallPairs = 8u * kSmallExact * 8u / 4u;     // 12 288
+  const unsigned nb = W;
+  for (unsigned t2 = wave; t2 < nb * (nb + 1); t2 += 16) {
+    const unsigned t = t2 >> 1, half = t2 & 1u;
+    unsigned ib = 0, rem = t;
+    while (rem >= nb - ib) { rem -= nb - ib; ib++; }              // tile t = (ib, jb = ib + rem)
+    const unsigned jb = ib + rem, j = jb * 64 + lane;
+    const bool jv = j < nsc;
+    PreBox Bj = {};
+    if (jv) Bj = s_box[j];
+    const unsigned ibeg = half * 32u, iend = min(ibeg + 32u, nsc - ib * 64 > ibeg ? nsc - ib * 64 : ibeg);
+    unsigned pass = 0u;                                            // verdicts of this lane's row against the 32 rows i
+    if (ibeg < iend) {                                             // (uniform)
+      // a fixed 32 trips, eight rows requested before the first is used (a row per LDS round trip otherwise); rows behind
+      // the segment's end are inside the array and masked out by i < j, j < nsc
+#pragma unroll 8
+      for (unsigned ii = 0; ii < 32u; ii++) {
+        const unsigned i = ib * 64 + ibeg + ii;
+        const float2 c = *reinterpret_cast<const float2*>(&s_box[i]);        // x, y  (same address in every lane)
+        const float ar = s_box[i].r;
+        const bool ok = jv && i < j && !surely_disjoint(c.x, c.y, ar, Bj.x, Bj.y, Bj.r);
+        pass |= ok ? 1u << ii : 0u;
+      }
+    }
+    // one reservation per wave and item (a prefix sum over the lanes), not one per row i: appends inside the loop put an
+    // LDS atomic's round trip on every second trip
+    unsigned cnt = (unsigned)__popc(pass), incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = (unsigned)__shfl_up((int)incl, o);
+      if (lane >= o) incl += up;
+    }
+    const unsigned all = (unsigned)__shfl((int)incl, 63);
+    if (all) {                                                     // (wave-uniform)
+      unsigned slot = 0;
+      if (lane == 0) slot = atomicAdd(&s_ctr[3], all);
+      slot = (unsigned)__shfl((int)slot, 0) + incl - cnt;
+      while (pass) {
+        const unsigned ii = (unsigned)__builtin_ctz(pass);
+        pass &= pass - 1u;
+        if (slot < kSmallPairs) s_pairs[slot] = ((ib * 64 + ibeg + ii) << 16) | j;
+        slot++;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const unsigned npairs = s_ctr[3];
+    if (npairs > kSmallPairs && tid == 0) atomicOr(&ctl->status, 4u);
+    const unsigned np = min(npairs, kSmallPairs);
+    for (unsigned e = tid; e < np; e += 1024) {
+      const uint32_t ij = s_pairs[e];
+      const bool cand = !nms_pair_skippable(s_box[ij >> 16], s_box[ij & 0xffffu], thr);
+      const unsigned long long bal = __ballot(cand);
+      if (bal) {
+        unsigned slot = 0;
+        if (lane == 0) slot = atomicAdd(&s_ctr[2], (unsigned)__popcll(bal));
+        slot = (unsigned)__shfl((int)slot, 0) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (cand && slot < (unsigned)kSmallCand) s_cand[slot] = ij;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_ctr[3] = 0u;                                  // (the redo counter of the exact pass)
+  }
+  __syncthreads();
+  SMALL_STAMP(5);
+  const unsigned ncand = s_ctr[2];
+  if (ncand > (unsigned)kSmallCand) {
+    if (tid == 0) atomicOr(&ctl->status, 4u);
+  }
+  const unsigned nc = min(ncand, (unsigned)kSmallCand);
+  // ---- exact IoU of the candidates (higher-scored box first, as the general path); pairs with more than 8 candidate points
+  // are marked (top bit) and redone with the reference's 24 slots by the first 128 threads
+  if (tid < kSmallExact) {
+    for (unsigned c = tid; c < nc; c += kSmallExact) {
+      const uint32_t ij = s_cand[c];
+      const unsigned i = ij >> 16, j = ij & 0xffffu;
+      bool redo = false;
+      const float v = rbox_iou<kSmallExact, kIouCap>(s_box[i], s_box[j], s_pts + tid, &redo);
+      if (redo) { const unsigned q = atomicAdd(&s_ctr[3], 1u); s_idx[q % kSmallSeg] = c; if (q >= (unsigned)kSmallSeg) atomicOr(&ctl->status, 4u); }
+      else if (v > thr) atomicOr(&s_mask[i * kSmallW + (j >> 6)], 1ull << (j & 63));
+    }
+  }
+  __syncthreads();
+  {
+    const unsigned nredo = min(s_ctr[3], (unsigned)kSmallSeg);
+    if (tid < 128) {
+      for (unsigned q = tid; q < nredo; q += 128) {
+        const uint32_t ij = s_cand[s_idx[q]];
+        const unsigned i = ij >> 16, j = ij & 0xffffu;
+        const float v = rbox_iou<128>(s_box[i], s_box[j], s_pts + tid);
+        if (v > thr) atomicOr(&s_mask[i * kSmallW + (j >> 6)], 1ull << (j & 63));
+      }
+    }
+  }
+  __syncthreads();
+  SMALL_STAMP(6);
+  // ---- greedy order, one wave, 64 rows at a time: the block's own 64 x 64 corner of the mask sits in registers (lane r = row r)
+  // and only the rows that HAVE an edge inside the block are walked (scalar work: a bit test, two v_readlane per such row; a
+  // row without one cannot remove anybody here); then the kept rows of the block are OR-ed into the removed words of the
+  // later blocks, lane = (later word, a sixth of the rows).  (One row per trip with the removed set spread over the lanes
+  // cost ~300 cycles a row: a cross-lane read and an LDS round trip on the dependency chain.)
+  if (wave == 0) {
+    unsigned long long* s_removed = reinterpret_cast<unsigned long long*>(s_idx);   // [W] (s_idx is dead: the keys are made)
+    if (lane < (int)kSmallW) s_removed[lane] = 0ull;
+    wave_lds_handoff();
+    unsigned long long keptw = 0ull;                  // lane w: kept bits of block w
+    unsigned nkept = 0;
+    const unsigned parts = 64u / W;                   // row slices of the transposed OR (W <= 10: >= 6)
+    for (unsigned blk = 0; blk < W; blk++) {
+      const unsigned row = blk * 64 + lane;
+      const bool rv = row < nsc;
+      const unsigned long long diag = rv ? s_mask[row * kSmallW + blk] : 0ull;
+      unsigned long long rem = s_removed[blk];                              // (same address in every lane)
+      rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem);
+      unsigned long long src = __ballot(diag != 0ull);                      // rows with an edge into this block
+      while (src) {
+        const int r = __builtin_ctzll(src);
+        src &= src - 1ull;
+        if (!((rem >> r) & 1ull)) {
+          const unsigned dlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)diag, r);
+          const unsigned dhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), r);
+          rem |= ((unsigned long long)dhi << 32) | dlo;
+        }
+      }
+      const unsigned rows_here = min(64u, nsc - blk * 64);
+      const unsigned long long valid = rows_here == 64u ? ~0ull : ((1ull << rows_here) - 1ull);
+      const unsigned long long kept = ~rem & valid;
+      nkept += (unsigned)__popcll(kept);
+      if (lane == (int)blk) keptw = kept;
+      // this block's kept rows -> the removed words of the later blocks
+      if (blk + 1 < W) {
+        const unsigned w = blk + 1 + (unsigned)lane % (W - blk - 1 ? W - blk - 1 : 1), part = (unsigned)lane / (W - blk - 1);
+        unsigned long long v = 0ull;
+        if (part < parts) {
+          unsigned long long m = kept;
+          for (unsigned r = part; r < 64u; r += parts)
+            if ((m >> r) & 1ull) v |= s_mask[(blk * 64 + r) * kSmallW + w];
+        }
+        if (v) atomicOr(&s_removed[w], v);
+        wave_lds_handoff();
+      }
+    }
+    // kept keys -> the global list (one reservation per workgroup): a run in ascending key order, its place and length
+    // published for the merge
+    unsigned base = 0;
+    if (lane == 0) {
+      base = atomicAdd(&ctl->kept, nkept);
+      uint32_t* run_info = reinterpret_cast<uint32_t*>(kept_keys + n);
+      run_info[2 * blockIdx.x] = base;
+      run_info[2 * blockIdx.x + 1] = nkept;
+      s_ctr[5] = base;
+      s_ctr[7] = nkept;
+    }
+    base = (unsigned)__shfl((int)base, 0);
+    unsigned before = 0;                              // kept rows in the words in front of this lane's word
+    for (int w = 0; w < (int)W; w++) {
+      const unsigned c = (unsigned)__popcll(__shfl(keptw, w));
+      if (w < lane) before += c;
+    }
+    if (lane < (int)W) {
+      unsigned long long m = keptw;
+      unsigned k = 0;
+      while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1ull;
+        kept_keys[base + before + k++] = s_key[lane * 64 + b];
+      }
+    }
+  }
+  }
+finish:
+  SMALL_STAMP(7);
+  // ---- merge, by ALL labelled workgroups: once every run is published (ticket), each workgroup loads all kept keys into LDS
+  // and ranks ITS keys among the other runs by binary search (all runs are sorted): keep[rank] = row.  The wait on the
+  // ticket is safe -- at most 64 workgroups of one CU each, all resident -- and bounded anyway: a timeout raises a status bit
+  // and the host takes the general path.  (One workgroup sorting all kept keys took 60 us for 5 000 rows.)
+  __threadfence();                                   // this workgroup's kept keys are visible device-wide before its ticket
+  __syncthreads();
+  {
+    uint32_t* s_ctr2 = reinterpret_cast<uint32_t*>(smem + kSmOffMisc) + 128 + 64;
+    uint32_t* s_run = reinterpret_cast<uint32_t*>(smem + kSmOffMisc);               // [64][2] start, length (the label set is dead)
+    const unsigned nd = min(s_ctr2[0], (unsigned)kSmallLabels);
+    // too many labels: decided identically by every workgroup from its own LDS set (s_ctr[6]), before any ticket -- then
+    // workgroup 0 alone reports (count 0, the status for the host) and nobody takes a ticket
+    if (s_ctr2[6] != 0u) {
+      if (blockIdx.x == 0 && tid == 0) {
+        *count_dev = 0;
+        __hip_atomic_store(&host_result[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_result[1], __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | 1u,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        ctl->kept = 0; ctl->ticket = 0; ctl->status = 0; ctl->done = 0;
+      }
+      return;
+    }
+    if (tid == 0) {
+      atomicAdd(&ctl->ticket, 1u);
+      unsigned polls = 0;
+      while (__hip_atomic_load(&ctl->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nd) {
+        if (++polls > (1u << 16)) { atomicOr(&ctl->status, 8u); break; }       // ~10 ms: never a hang
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    __threadfence();
+    const unsigned status = __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned total = __hip_atomic_load(&ctl->kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (status) total = 0;
+    unsigned long long* s_all = reinterpret_cast<unsigned long long*>(smem);
+    const uint32_t* run_info = reinterpret_cast<const uint32_t*>(kept_keys + n);
+    const unsigned my_start = s_ctr2[5], my_len = status ? 0u : s_ctr2[7];
+    __syncthreads();                                 // (s_ctr2 / the label set are read: the run table may overwrite it)
+    for (unsigned r = tid; r < total; r += 1024) s_all[r] = __builtin_nontemporal_load(&kept_keys[r]);
+    if (tid < (int)nd * 2) s_run[tid] = __builtin_nontemporal_load(&run_info[tid]);
+    __syncthreads();
+    SMALL_STAMP(8);
+    for (unsigned q = tid; q < my_len; q += 1024) {
+      const unsigned long long key = s_all[my_start + q];
+      unsigned rank = q;
+      for (unsigned b0 = 0; b0 < nd; b0 += 8) {        // eight runs searched in lockstep: their probes are independent reads
+        unsigned st8[8], len8[8], pos[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const unsigned b = b0 + k;
+          const bool use = b < nd && b != blockIdx.x;
+          st8[k] = use ? s_run[2 * b] : 0u;
+          len8[k] = use ? s_run[2 * b + 1] : 0u;
+          pos[k] = 0u;
+        }
+        for (unsigned step = 512; step; step >>= 1) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const unsigned p = pos[k] + step;
+            if (p <= len8[k] && s_all[st8[k] + p - 1u] < key) pos[k] = p;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) rank += pos[k];
+      }
+      keep[rank] = (int64_t)(uint32_t)key;
+    }
+    SMALL_STAMP(9);
+    __syncthreads();
+    if (tid == 0) {                                  // the workgroup that finishes last reports and clears the slot
+      if (atomicAdd(&ctl->done, 1u) == nd - 1u) {
+        *count_dev = (int64_t)total;
+        // (the host reads these two words after it has synchronised the stream: no copy launch behind the kernel)
+        __hip_atomic_store(&host_result[0], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_result[1], status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        ctl->kept = 0; ctl->ticket = 0; ctl->status = 0; ctl->done = 0;     // ready for the next call on this slot
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- side streams
 // Two side streams + fork / join events per (device, caller stream), created on first use.  box_iou_rotated runs the
 // zero-fill of a large output beside its pair finding; the NMS prelude runs its three independent sorts side by side.
@@ -2904,6 +3352,38 @@ static int nms_debug_dump(const NmsBuffers& B, int64_t n, hipStream_t st) {
   return S2A_OK;
 }
 #endif
+// control slots of k_nms_small: one per call in flight (the kernel leaves its slot zeroed; a slot is handed out again only
+// after the call that used it has been synchronised)
+constexpr int kSmallDevices = 16;
+std::mutex g_small_mutex;
+uint32_t g_small_busy[kSmallDevices] = {};          // per device, bit s: slot s is in use
+SmallCtl* g_small_dev[kSmallDevices] = {};
+uint32_t* g_small_host[kSmallDevices] = {};          // pinned + mapped: 16 slots x {count, status, pad, pad}
+uint32_t* g_small_host_dev[kSmallDevices] = {};      // the same memory as the device sees it
+long long g_small_taken = 0, g_small_fallback = 0;   // calls settled by k_nms_small / handed on to the general path
+
+int small_slot_acquire(int* slot, int* device, SmallCtl** dev) {
+  int d = 0;
+  S2A_HIP(hipGetDevice(&d));
+  *slot = -1;
+  *device = d;
+  if (d < 0 || d >= kSmallDevices) return S2A_OK;
+  std::lock_guard<std::mutex> lock(g_small_mutex);
+  if (!g_small_dev[d]) {
+    S2A_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&g_small_dev[d]), HIP_SYMBOL(g_small_ctl)));
+    S2A_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_small_host[d]), 16 * 4 * sizeof(uint32_t), hipHostMallocMapped));
+    S2A_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_small_host_dev[d]), g_small_host[d], 0));
+  }
+  for (int s = 0; s < 16; s++)
+    if (!(g_small_busy[d] & (1u << s))) { g_small_busy[d] |= 1u << s; *slot = s; *dev = g_small_dev[d] + s; return S2A_OK; }
+  return S2A_OK;                     // (all sixteen in flight: the caller takes the general path)
+}
+void small_slot_release(int device, int slot, bool taken) {
+  std::lock_guard<std::mutex> lock(g_small_mutex);
+  g_small_busy[device] &= ~(1u << slot);
+  (taken ? g_small_taken : g_small_fallback)++;
+}
+
 int nms_dropin(const float* dets, const float* scores, const float* labels, int64_t n, float thr,
                int64_t* keep, int64_t* count_dev, int64_t* host_count, void* ws, size_t ws_bytes,
                hipStream_t st) {
@@ -2915,6 +3395,52 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
     return S2A_OK;
   }
   S2A_CHECK_ARG(dets && scores && keep, "nms_rotated: NULL tensor");
+  // small synchronous calls: ONE launch (k_nms_small); anything outside its limits reports a status and falls through to
+  // the general path below.  S2A_NMS_SMALL=0: A/B, tests
+  {
+    const char* e = std::getenv("S2A_NMS_SMALL");
+    const bool small = host_count != nullptr && n <= kSmallN && !(e && e[0] == '0') && !stream_capturing(st) &&
+                       ws != nullptr && ws_bytes >= (size_t)n * 8 + 1024;
+    if (small) {
+      int slot = -1, device = 0;
+      SmallCtl* ctl = nullptr;
+      int rc = small_slot_acquire(&slot, &device, &ctl);
+      if (rc != S2A_OK) return rc;
+      if (slot >= 0) {
+        auto kern = k_nms_small;
+        static bool attr_set[kSmallDevices] = {};
+        hipError_t he = hipSuccess;
+        if (!attr_set[device]) {         // (once per device: the call is not free)
+          he = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds);
+          attr_set[device] = he == hipSuccess;
+        }
+        uint32_t res[2] = {0u, 0xffffffffu};
+        volatile uint32_t* hres = g_small_host[device] + 4 * slot;
+        hres[0] = 0u;
+        hres[1] = 0xffffffffu;
+        if (he == hipSuccess) {
+          kern<<<kSmallGrid, 1024, kSmallLds, st>>>(dets, scores, labels, (int)n, thr, static_cast<unsigned long long*>(ws), ctl,
+                                                    g_small_host_dev[device] + 4 * slot, keep, count_dev);
+          he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        res[0] = hres[0];
+        res[1] = hres[1];
+        if (he != hipSuccess) {
+          // the slot may be dirty: clear it before anyone else gets it
+          (void)hipMemset(ctl, 0, sizeof(SmallCtl));
+          small_slot_release(device, slot, false);
+          set_error("nms_rotated (small path) failed: %s", hipGetErrorString(he));
+          return S2A_EHIP;
+        }
+        small_slot_release(device, slot, res[1] == 0u);
+        if (res[1] == 0u) {
+          *host_count = (int64_t)res[0];
+          return S2A_OK;
+        }
+      }
+    }
+  }
   NmsPlan pl;
   S2A_CHECK_ARG(nms_plan(n, n, &pl) == 0, "nms_rotated: rocprim size query failed");
   Carver cv(ws, ws_bytes);
@@ -3379,6 +3905,20 @@ extern "C" int s2a_multiclass_candidates(const float* boxes, const float* scores
       boxes, scores, sel, reinterpret_cast<const unsigned long long*>(count_dev), cap, (int)n,
       (int)num_classes, out_boxes, out_scores, out_seg, out_grp, out_cls);
   S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+#ifdef S2A_MEASURE
+extern "C" int s2a_debug_small_stamps(unsigned long long* host_dst) {
+  S2A_HIP(hipDeviceSynchronize());
+  S2A_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_small_stamps), 64 * 16 * 8));
+  return S2A_OK;
+}
+#endif
+extern "C" int s2a_nms_small_stats(int64_t* taken, int64_t* fell_back) {
+  std::lock_guard<std::mutex> lock(g_small_mutex);
+  if (taken) *taken = g_small_taken;
+  if (fell_back) *fell_back = g_small_fallback;
   return S2A_OK;
 }
 

@@ -294,6 +294,78 @@ def test_nms_list_overflow_takes_the_direct_path(rng):
     assert ref.sum() < n // 10 and not ref[seg < 0].any()
 
 
+def _small_stats():
+    import ctypes
+    from s2anet_amd import _lib
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().s2a_nms_small_stats(ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+
+def test_nms_small_inputs_one_launch(rng, monkeypatch):
+    """round 5: synchronous nms_rotated / ml_nms_rotated calls on <= 16 384 rows are settled by ONE kernel (k_nms_small: a
+    workgroup per label -- LDS sort, cull, exact IoU into an LDS bit mask, greedy walk, last-workgroup merge) when they fit
+    its limits, and by the general path otherwise.  Keep lists == oracle == general path (S2A_NMS_SMALL=0) for: typical
+    detector-sized inputs, one row, ties, duplicates / shared edges (> 8 candidate points: the 24-slot redo), piles (candidate
+    list overflow -> fallback), a label with > 640 rows (fallback), 65 and 200 distinct labels (fallback), weird labels."""
+    import s2anet_amd as S
+    from s2anet_amd.rotated import nms_rotated_raw
+
+    def both(d, s, lab, thr):
+        t0, f0 = _small_stats()
+        got = (S.ml_nms_rotated(cu(d), cu(s), cu(lab), thr) if lab is not None else nms_rotated_raw(cu(d), cu(s), thr)).cpu().numpy()
+        t1, f1 = _small_stats()
+        monkeypatch.setenv("S2A_NMS_SMALL", "0")
+        ref = (S.ml_nms_rotated(cu(d), cu(s), cu(lab), thr) if lab is not None else nms_rotated_raw(cu(d), cu(s), thr)).cpu().numpy()
+        monkeypatch.delenv("S2A_NMS_SMALL")
+        t2, f2 = _small_stats()
+        assert (t2, f2) == (t1, f1)                                  # the switch really bypasses the small path
+        want = oracle.ml_nms_rotated(d, s, lab, thr) if lab is not None else oracle.nms_rotated(d, s, thr)
+        assert np.array_equal(got, want) and np.array_equal(ref, want)
+        return t1 - t0, f1 - f0
+
+    # the size one image's post-processing has: 5 000 rows, 15 labels -> one launch
+    n = 5000
+    d, s = rand_rboxes(rng, n), distinct_scores(rng, n)
+    lab = rng.integers(0, 15, n).astype(np.float32)
+    assert both(d, s, lab, 0.5) == (1, 0)
+    assert both(d, s, lab, 0.1) == (1, 0)
+    # 16 000 rows over 40 labels (400 each), negative / fractional / huge labels, -0.0 and +0.0 one label
+    n = 16000
+    d, s = rand_rboxes(rng, n, span=2000), distinct_scores(rng, n)
+    vals = np.concatenate([np.arange(36, dtype=np.float32) * 0.5 - 3.0, np.array([1e9, -1e-30, 65504.0, 3.0000002], np.float32)])
+    lab = vals[rng.integers(0, 40, n)]
+    lab[lab == 0.0] = np.where(rng.random((lab == 0.0).sum()) < 0.5, np.float32(-0.0), np.float32(0.0))
+    assert both(d, s, lab, 0.3) == (1, 0)
+    # single class, no labels: one segment of <= 640 rows; one row; score ties (broken by the original row)
+    for m in (1, 2, 63, 64, 65, 640):
+        d, s = rand_rboxes(rng, m, span=120 * max(1.0, (m / 16) ** 0.5)), distinct_scores(rng, m)
+        if m >= 63:
+            s[5] = s[17] = s[40]
+        assert both(d, s, None, 0.3) == (1, 0)
+    # duplicates, quarter-turn copies, boxes sharing an edge: more than 8 candidate points -> the 24-slot redo inside the kernel
+    base = rand_rboxes(rng, 150, span=300, lo=20, hi=60)
+    dup = base.copy()
+    turn = base.copy(); turn[:, 4] += np.float32(np.pi / 2)
+    edge = base.copy(); edge[:, 0] += base[:, 2] * np.cos(base[:, 4]); edge[:, 1] += base[:, 2] * np.sin(base[:, 4])
+    d = np.concatenate([base, dup, turn, edge]).astype(np.float32)
+    s = distinct_scores(rng, len(d))
+    assert both(d, s, (np.arange(len(d)) % 2).astype(np.float32), 0.5) == (1, 0)
+    # everything piles up: more than 4 096 surviving pairs in a segment -> status -> general path, same answer
+    d, s = rand_rboxes(rng, 600, span=50, lo=30, hi=80), distinct_scores(rng, 600)
+    assert both(d, s, np.zeros(600, np.float32), 0.3) == (0, 1)
+    # a label with more than 640 rows; 65 labels; 200 labels
+    n = 3000
+    d, s = rand_rboxes(rng, n), distinct_scores(rng, n)
+    assert both(d, s, (np.arange(n) < 700).astype(np.float32), 0.5) == (0, 1)
+    assert both(d, s, (np.arange(n) % 65).astype(np.float32), 0.5) == (0, 1)
+    assert both(d, s, (np.arange(n) % 200).astype(np.float32), 0.5) == (0, 1)
+    # beyond 16 384 rows the general path is taken without trying
+    n = 17000
+    d, s = rand_rboxes(rng, n, span=2000), distinct_scores(rng, n)
+    assert both(d, s, rng.integers(0, 40, n).astype(np.float32), 0.5) == (0, 0)
+
+
 def _segmented_dets(L, _lib, D, Sc, Sg, Gr, Cl, n, nseg, ngrp, thr, K):
     wire = torch.empty((ngrp, K * 7 + 1), dtype=torch.float32, device=dev())
     labels = torch.empty((ngrp, K), dtype=torch.int32, device=dev())
