@@ -491,6 +491,7 @@ struct NmsCounters {
   unsigned long long edges;      // pairs with IoU > thr (true total)
   unsigned long long tiles;      // tiles that passed the filter (true total)
   unsigned long long alive_list; // edges handed to the clean-up kernel
+  unsigned long long bucket_cursor;  // clean-up kernel: edges of segments beyond the LDS capacity, reserved in the dead edge buffer
   uint32_t status;               // bit 0: a list overflowed -> direct greedy fallback ran
   uint32_t alive[16];            // edges still between two unsettled rows after round r
 };
@@ -999,10 +1000,15 @@ __global__ __launch_bounds__(256) void k_nms_keep_count(const uint8_t* __restric
 __global__ __launch_bounds__(256) void k_nms_keep_write(const uint8_t* __restrict__ keep_orig,
                                                         const int32_t* __restrict__ perm_glob, int64_t n, int rows,
                                                         const uint32_t* __restrict__ cnt, int nb,
-                                                        int64_t* __restrict__ keep, int64_t* __restrict__ count_dev) {
+                                                        int64_t* __restrict__ keep, int64_t* __restrict__ count_dev,
+                                                        uint32_t* __restrict__ host_count /* pinned, mapped; may be NULL */) {
   unsigned before, total;
   count_prefix(cnt, nb, blockIdx.x, before, total);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *count_dev = (int64_t)total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *count_dev = (int64_t)total;
+    // (a synchronous caller reads the count from host-mapped memory after its stream synchronise: no copy launch)
+    if (host_count) __hip_atomic_store(host_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
   unsigned running = before;
   for (int64_t base = r0; base < r1; base += 256) {
@@ -2226,100 +2232,10 @@ static_assert(kNmsRounds % 2 == 0 && kNmsRounds < 15, "the materialising pass of
 //           cleared for the rows that stay open.
 // Every open row always has an edge in its segment's list, so it is reached; the loop ends when the list is empty.
 // Segments too large for LDS (> kSegRows rows or > kSegEdges alive edges) run the same loop on the global arrays.
-// (wave-aggregated: the alive list comes in segment-coherent runs, and the counters of a detector batch -- ~120
-// segments -- share a handful of cache lines: one atomic per edge serialised at the L2 channel, 143 us)
-__device__ __forceinline__ unsigned seg_aggregate(bool valid, uint32_t seg, uint32_t* __restrict__ counters) {
-  // returns this lane's slot: old counter value + rank among the lanes of the same segment; one atomic per distinct segment
-  const int lane = threadIdx.x & 63;
-  unsigned slot = 0;
-  unsigned long long todo = __ballot(valid);
-  while (todo) {
-    const int leader = __builtin_ctzll(todo);
-    const uint32_t s0 = (uint32_t)__shfl((int)seg, leader);
-    const unsigned long long same = __ballot(valid && seg == s0) & todo;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&counters[s0], (unsigned)__popcll(same));
-    base = (unsigned)__shfl((int)base, leader);
-    if (valid && seg == s0) slot = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
-  }
-  return slot;
-}
-
-// (also the body of k_nms_materialize, whose rows and this kernel's edges are independent work: one launch less in the
-// launch-paced tail of the call -- `mat_n` rows by grid-stride, then the edges)
-__global__ __launch_bounds__(kThreads) void k_nms_alive_count(const NmsCounters* __restrict__ C,
-                                                              const uint2* __restrict__ alive, unsigned long long alive_cap,
-                                                              const PreBox* __restrict__ sorted,
-                                                              uint32_t* __restrict__ seg_cnt, uint8_t* __restrict__ state,
-                                                              uint8_t* __restrict__ blocked, int64_t mat_n) {
-  if (C->alive[kNmsRounds] == 0) return;
-  for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < mat_n; p += (int64_t)gridDim.x * kThreads) {
-    const uint32_t v = nms_view(state, blocked, mat_n, kNmsRounds, (uint32_t)p);
-    blocked[p] = 0;            // (kNmsRounds is even: the view reads array 0 at this very index, before the write)
-    blocked[mat_n + p] = 0;    // both arrays become plain "blocked this round" flags
-    if (v == kKept) state[p] = (uint8_t)kKept;
-  }
-  const unsigned long long A = min(C->alive_list, alive_cap);
-  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
-  for (unsigned long long e0 = (unsigned long long)blockIdx.x * kThreads; e0 < A; e0 += stride) {
-    const unsigned long long e = e0 + threadIdx.x;
-    const bool valid = e < A;
-    const uint32_t seg = valid ? __float_as_uint(sorted[alive[e].x].label) : 0u;
-    (void)seg_aggregate(valid, seg, seg_cnt);
-  }
-}
-
-// exclusive scan of the per-segment counts in place (one workgroup); seg_cur = a second copy for the scatter cursors
-__global__ __launch_bounds__(1024) void k_nms_alive_scan(const NmsCounters* __restrict__ C,
-                                                         const uint32_t* __restrict__ num_seg,
-                                                         uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_cur) {
-  if (C->alive[kNmsRounds] == 0) return;
-  __shared__ unsigned s_w[16];
-  __shared__ unsigned s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t S = *num_seg;
-  for (uint32_t b0 = 0; b0 <= S; b0 += 1024) {           // S + 1 entries: entry S ends up holding the total
-    const uint32_t b = b0 + threadIdx.x;
-    const unsigned v = b < S ? seg_cnt[b] : 0u;
-    unsigned incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    unsigned wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += s_w[w];
-    const unsigned carry = s_carry;
-    if (b <= S) { seg_cnt[b] = carry + wbase + incl - v; seg_cur[b] = carry + wbase + incl - v; }
-    __syncthreads();
-    if (threadIdx.x == 1023) s_carry = carry + wbase + incl;
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void k_nms_alive_scatter(const NmsCounters* __restrict__ C,
-                                                                const uint2* __restrict__ alive, unsigned long long alive_cap,
-                                                                const PreBox* __restrict__ sorted,
-                                                                uint32_t* __restrict__ seg_cur, uint2* __restrict__ bucketed) {
-  if (C->alive[kNmsRounds] == 0) return;
-  const unsigned long long A = min(C->alive_list, alive_cap);
-  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
-  for (unsigned long long e0 = (unsigned long long)blockIdx.x * kThreads; e0 < A; e0 += stride) {
-    const unsigned long long e = e0 + threadIdx.x;
-    const bool valid = e < A;
-    uint2 ij = make_uint2(0, 0);
-    if (valid) ij = alive[e];
-    const uint32_t seg = valid ? __float_as_uint(sorted[ij.x].label) : 0u;
-    const unsigned slot = seg_aggregate(valid, seg, seg_cur);
-    if (valid) bucketed[slot] = ij;
-  }
-}
-
+// (Round 5: the bucketing of the alive edges by segment -- count, scan, scatter: three launches, 25 us of a detector step
+// and of the drop-in op's launch-paced tail -- is gone: positions of a segment are contiguous, so the segment's workgroup picks
+// its edges out of the alive list by a range test on the source position while it scans the list once, and writes out the
+// implicit "open and not blocked == kept" view of its own rows first.)
 constexpr int kSegRows = 8192, kSegEdges = 4096;     // 8 + 16 KB of states / flags, 2 x 32 KB of edges
 #ifdef S2A_MEASURE
 __device__ unsigned long long g_fin_dbg[16];   // clean-up kernel: max iterations, max edges, sum iterations, segments with work, max rows
@@ -2462,46 +2378,102 @@ __device__ __forceinline__ unsigned finish_rounds(uint8_t* __restrict__ St, uint
   return iters;
 }
 
-__global__ __launch_bounds__(kFinThreads) void k_nms_finish_segments(const NmsCounters* __restrict__ C,
+__global__ __launch_bounds__(kFinThreads) void k_nms_finish_segments(NmsCounters* __restrict__ C,
                                                                      const uint32_t* __restrict__ seg_start,
                                                                      const uint32_t* __restrict__ num_seg,
-                                                                     const uint32_t* __restrict__ seg_off,
-                                                                     uint2* __restrict__ bucketed,
+                                                                     const uint2* __restrict__ alive, unsigned long long alive_cap,
+                                                                     uint2* __restrict__ bucketed, unsigned long long bucket_cap,
                                                                      uint8_t* __restrict__ state,
                                                                      uint8_t* __restrict__ blocked, int64_t n,
-                                                                     int force_global) {
+                                                                     const unsigned long long* __restrict__ keys, int shift,
+                                                                     uint32_t ignore_key, int use_ignore, int force_global) {
   if (C->alive[kNmsRounds] == 0) return;
   __shared__ uint8_t s_state[kSegRows];
   __shared__ uint8_t s_flag[2 * kSegRows];
   __shared__ uint2 s_edges[2 * kSegEdges];
   __shared__ unsigned s_n[3];
+  __shared__ unsigned s_ecnt;
+  __shared__ unsigned long long s_gbase;
   const uint32_t S = *num_seg;
+  const unsigned long long A = min(C->alive_list, alive_cap);
+  const int lane = threadIdx.x & 63;
   for (uint32_t s = blockIdx.x; s < S; s += gridDim.x) {
-    const uint32_t e0 = seg_off[s], cnt0 = seg_off[s + 1] - e0;
-    if (cnt0 == 0) continue;                                  // (uniform)
     const uint32_t st = seg_start[s], ns = seg_start[s + 1] - st;
-    const bool lds = !force_global && ns <= (uint32_t)kSegRows && cnt0 <= (uint32_t)kSegEdges;
+    if (ns == 0u) continue;                                   // (uniform)
+    // the ignored rows (the padding of a detector batch: three quarters of the buffer) are removed from the start, have no
+    // edges and nothing to write out
+    if (use_ignore && (uint32_t)(keys[st] >> shift) == ignore_key) continue;
     __syncthreads();
-    if (threadIdx.x == 0) s_n[1] = 0;                         // round r counts in s_n[r % 3]
+    if (threadIdx.x == 0) { s_ecnt = 0; s_n[1] = 0; }         // round r counts in s_n[r % 3]
+    // the implicit view after the last launched round, written out for this segment's rows (k_nms_finish reads explicit
+    // states once edges are alive); the two `blocked` arrays become plain "blocked this round" flags (kNmsRounds is even:
+    // the view reads array 0 at this very index, before the write)
+    for (uint32_t i = threadIdx.x; i < ns; i += kFinThreads) {
+      const uint32_t p = st + i;
+      const uint32_t v = nms_view(state, blocked, n, kNmsRounds, p);
+      blocked[p] = 0;
+      blocked[n + p] = 0;
+      if (v == kKept) state[p] = (uint8_t)kKept;
+    }
+    __syncthreads();
+    // this segment's edges: one scan of the alive list, four entries per thread in flight; the first kSegEdges go to LDS
+    for (unsigned long long e0 = 0; e0 < A; e0 += 4ull * kFinThreads) {
+      uint2 ij[4];
+      bool mine[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned long long e = e0 + (unsigned long long)k * kFinThreads + threadIdx.x;
+        ij[k] = e < A ? alive[e] : make_uint2(0xffffffffu, 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        mine[k] = ij[k].x - st < ns;                          // (unsigned: also false for the 0xffffffff filler)
+        const unsigned long long bal = __ballot(mine[k]);
+        if (bal) {
+          unsigned slot = 0;
+          if (lane == 0) slot = atomicAdd(&s_ecnt, (unsigned)__popcll(bal));
+          slot = (unsigned)__shfl((int)slot, 0) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+          if (mine[k] && slot < (unsigned)kSegEdges) s_edges[slot] = make_uint2(ij[k].x - st, ij[k].y - st);
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t cnt0 = s_ecnt;
+    if (cnt0 == 0) continue;                                  // (uniform)
+    const bool lds = !force_global && ns <= (uint32_t)kSegRows && cnt0 <= (uint32_t)kSegEdges;
     unsigned iters;
     if (lds) {
       for (uint32_t i = threadIdx.x; i < ns; i += kFinThreads) { s_state[i] = state[st + i]; s_flag[i] = 0; s_flag[kSegRows + i] = 0; }
-      for (uint32_t e = threadIdx.x; e < cnt0; e += kFinThreads) {
-        const uint2 ij = bucketed[e0 + e];
-        s_edges[e] = make_uint2(ij.x - st, ij.y - st);
-      }
       __threadfence_block();
       __syncthreads();
       iters = finish_rounds<true>(s_state, s_flag, kSegRows, s_edges, kSegEdges, cnt0, s_n);
       for (uint32_t i = threadIdx.x; i < ns; i += kFinThreads) state[st + i] = s_state[i];
     } else {
-      for (uint32_t e = threadIdx.x; e < cnt0; e += kFinThreads) {      // local indices in place
-        const uint2 ij = bucketed[e0 + e];
-        bucketed[e0 + e] = make_uint2(ij.x - st, ij.y - st);
+      // a segment beyond the LDS arrays: its edges (local indices) into a region of the dead edge buffer, reserved with one
+      // atomic; a second scan of the alive list fills it.  (No room left there -- cannot happen while the alive list fits
+      // the pair buffer it lives in -- would leave the rows to the direct kernel: status bit 2.)
+      if (threadIdx.x == 0) { s_gbase = atomicAdd(&C->bucket_cursor, (unsigned long long)cnt0); s_ecnt = 0; }
+      __syncthreads();
+      const unsigned long long gb = s_gbase;
+      if (gb + cnt0 > bucket_cap) {                           // (uniform)
+        if (threadIdx.x == 0) atomicOr(&C->status, 2u);
+        continue;
+      }
+      for (unsigned long long e0 = 0; e0 < A; e0 += kFinThreads) {
+        const unsigned long long e = e0 + threadIdx.x;
+        uint2 ij = e < A ? alive[e] : make_uint2(0xffffffffu, 0u);
+        const bool mine = ij.x - st < ns;
+        const unsigned long long bal = __ballot(mine);
+        if (bal) {
+          unsigned slot = 0;
+          if (lane == 0) slot = atomicAdd(&s_ecnt, (unsigned)__popcll(bal));
+          slot = (unsigned)__shfl((int)slot, 0) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+          if (mine) bucketed[gb + slot] = make_uint2(ij.x - st, ij.y - st);
+        }
       }
       __threadfence_block();
       __syncthreads();
-      iters = finish_rounds<false>(state + st, blocked + st, n, bucketed + e0, 0, cnt0, s_n);
+      iters = finish_rounds<false>(state + st, blocked + st, n, bucketed + gb, 0, cnt0, s_n);
     }
     (void)iters;
 #ifdef S2A_MEASURE
@@ -3296,11 +3268,9 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
                                           r == kNmsRounds ? B.gq : nullptr, pl.queue_cap);
   // still-alive edges (listed by the last launched round in the dead pair list): by segment into the edge buffer (the full
   // edge list is dead now), then one workgroup per segment; all five kernels return at once when nothing is alive
-  k_nms_alive_count<<<std::max(256u, std::min(g, 2048u)), kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cnt, B.state, B.blocked, n);
-  k_nms_alive_scan<<<1, 1024, 0, st>>>(B.C, B.num_seg, B.seg_cnt, B.seg_cur);
-  k_nms_alive_scatter<<<256, kThreads, 0, st>>>(B.C, B.gq, pl.queue_cap, boxes, B.seg_cur, B.edges);
-  k_nms_finish_segments<<<512, kFinThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.seg_cnt, B.edges, B.state, B.blocked, n,
-                                                  force_global);
+  k_nms_finish_segments<<<512, kFinThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.gq, pl.queue_cap, B.edges, pl.edge_cap,
+                                                     B.state, B.blocked, n, spatial ? B.keyB_s : B.keyA_s, spatial ? 20 : 32,
+                                                     ignore_key, use_ignore, force_global);
   if (ss && spatial) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
   k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, spatial ? B.seg_start_a : B.seg_start, spatial ? B.num_seg_a : B.num_seg,
                                                 B.keyA_s, ignore_key, use_ignore, B.C,
@@ -3378,10 +3348,10 @@ int small_slot_acquire(int* slot, int* device, SmallCtl** dev) {
     if (!(g_small_busy[d] & (1u << s))) { g_small_busy[d] |= 1u << s; *slot = s; *dev = g_small_dev[d] + s; return S2A_OK; }
   return S2A_OK;                     // (all sixteen in flight: the caller takes the general path)
 }
-void small_slot_release(int device, int slot, bool taken) {
+void small_slot_release(int device, int slot, bool taken, bool count = true) {
   std::lock_guard<std::mutex> lock(g_small_mutex);
   g_small_busy[device] &= ~(1u << slot);
-  (taken ? g_small_taken : g_small_fallback)++;
+  if (count) (taken ? g_small_taken : g_small_fallback)++;
 }
 
 int nms_dropin(const float* dets, const float* scores, const float* labels, int64_t n, float thr,
@@ -3456,15 +3426,32 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
     const int rows = count_rows(n);
     const int nb = (int)((n + rows - 1) / rows);
     k_nms_keep_count<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3);
-    k_nms_keep_write<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3, nb, keep, count_dev);
-  }
-  S2A_LAUNCH_CHECK();
+    // the count for a synchronous caller through a host-mapped word (a control slot of the small path's pool) when one is
+    // free: the D2H copy behind the last kernel was one more launch (4 us) in the launch-paced tail
+    int slot = -1, device = 0;
+    SmallCtl* ctl = nullptr;
+    if (host_count && !stream_capturing(st)) {
+      int rc2 = small_slot_acquire(&slot, &device, &ctl);
+      if (rc2 != S2A_OK) return rc2;
+    }
+    volatile uint32_t* hres = slot >= 0 ? g_small_host[device] + 4 * slot : nullptr;
+    if (hres) hres[0] = 0xffffffffu;
+    k_nms_keep_write<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3, nb, keep, count_dev,
+                                         slot >= 0 ? g_small_host_dev[device] + 4 * slot : nullptr);
+    hipError_t he = hipGetLastError();
 #ifdef S2A_MEASURE
-  { int rc_ = nms_debug_dump(B, n, st); if (rc_ != S2A_OK) return rc_; }
+    if (he == hipSuccess) { int rc_ = nms_debug_dump(B, n, st); if (rc_ != S2A_OK) { if (slot >= 0) small_slot_release(device, slot, false, false); return rc_; } }
 #endif
-  if (host_count) {
-    S2A_HIP(hipMemcpyAsync(host_count, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    S2A_HIP(hipStreamSynchronize(st));
+    if (he == hipSuccess && host_count) {
+      if (slot < 0) he = hipMemcpyAsync(host_count, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+      if (he == hipSuccess) he = hipStreamSynchronize(st);
+      if (he == hipSuccess && slot >= 0) *host_count = (int64_t)hres[0];
+    }
+    if (slot >= 0) small_slot_release(device, slot, false, false);
+    if (he != hipSuccess) {
+      set_error("nms_rotated failed: %s", hipGetErrorString(he));
+      return S2A_EHIP;
+    }
   }
   return S2A_OK;
 }
