@@ -172,11 +172,13 @@ def _time_launches(fn, iters=100):
     return e0.elapsed_time(e1) / 1e3 / iters
 
 
-def capture_head_operands(model, imgs):
+def capture_head_operands(model, imgs, max_candidates=None):
     """one step with S2ANetHead.capture armed: the pyramid-packed FPN features, the refined anchors and
-    the level table that the step's AlignConv / conv-tower launches really see (None: per-level path)"""
+    the level table that the step's AlignConv / conv-tower launches really see (None: per-level path).
+    max_candidates as the timed step passes it: the same launch sequence (an uncapped call has 5 344 rows per segment
+    and takes the spatial NMS path with its library sorts)"""
     model.head.capture = {}
-    model.detect(imgs)
+    model.detect(imgs, max_candidates=max_candidates)
     torch.cuda.synchronize()
     cap, model.head.capture = model.head.capture, None
     return cap if cap else None
@@ -862,7 +864,7 @@ def main():
         result["data"] = "stub detector (launcher / gather rehearsal, not a measurement)"
     if rank == 0:
         if not stub:
-            cap = capture_head_operands(model, imgs)
+            cap = capture_head_operands(model, imgs, max_cand)
             result["roofline"] = measure_alignconv(model, B, dtype, cap)
             if cap is not None:
                 result["roofline_conv_tower"] = measure_conv_tower(model, cap)

@@ -41,3 +41,7 @@ d=json.load(open('$O/bench_s1_graph.json')); print('graph replay, 1 stream', d['
 echo "== half decode / NMS effect"; timeout -k 10 300 python scripts/half_nms_effect.py > $O/half_nms_effect.log 2>&1; tail -1 $O/half_nms_effect.log | cut -c1-400
 echo "== clock probe"; timeout -k 10 300 python scripts/pyr_power_probe.py > $O/pyr_power_probe.jsonl 2>/dev/null; cat $O/pyr_power_probe.jsonl
 cp gpurun_out/f16_fixture_hashes.json $O/ 2>/dev/null
+# keep what comes home under 64 MiB: the raw per-dispatch counter / trace tables are summarised above
+find $R/gpurun_out -type f \( -name "*_counter_collection.csv" -o -name "*kernel_trace.csv" -o -name "*.db" -o -name "*.rocpd" -o -name "*_agent_info.csv" \) -delete
+find $R/gpurun_out -type f -size +4M -delete
+du -sh $R/gpurun_out | cut -f1

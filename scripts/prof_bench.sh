@@ -12,7 +12,10 @@ cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1 || { echo "rocprof run failed"; tail -5 $OUT/bench.log; exit 1; }
 T=$(ls $OUT/*kernel_trace.csv $OUT/*/*kernel_trace.csv 2>/dev/null | head -1)
 S=$(ls $OUT/*kernel_stats.csv $OUT/*/*kernel_stats.csv 2>/dev/null | head -1)
-python $R/scripts/trace_steps.py $T 5 60 > $OUT/steady.txt
+# the window of five steps ends inside the timed region: behind it come the single-stream loop of a multi-stream run (3 + 10 steps)
+# and the operand-capture step
+SKIP=14; case " $* " in *" --streams 1 "*) SKIP=1;; esac
+python $R/scripts/trace_steps.py $T 5 60 $SKIP > $OUT/steady.txt
 cp $S $OUT/kernel_stats.csv
 grep '^{' $OUT/bench.log > $OUT/line.json
 rm -f $T   # the raw trace is large; the summaries are what gets kept

@@ -1,9 +1,12 @@
-"""per-kernel time inside the last N full steps of a bench.py trace; a step ends at k_nms_group_emit (k_nms_group_compact before round 4)"""
+"""per-kernel time inside N full steps of a bench.py trace; a step ends at k_nms_group_emit* (k_nms_group_compact before round 4).
+python trace_steps.py trace.csv <steps> [<top rows> [<steps to skip at the end of the trace>]] -- the skip keeps the window inside
+the timed region: behind it bench.py runs its single-stream loop, the operand-capture step and the roofline launches"""
 import csv, sys, collections
 path, nsteps = sys.argv[1], int(sys.argv[2])
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp']))
 marks = [int(r['End_Timestamp']) for r in rows if ('k_nms_group_emit' in r['Kernel_Name'] or 'k_nms_group_compact' in r['Kernel_Name'])]
-t0, t1 = marks[-nsteps - 1], marks[-1]
+skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+t0, t1 = marks[-nsteps - 1 - skip], marks[-1 - skip]
 agg = collections.defaultdict(lambda: [0, 0.0]); busy = 0.0; n = 0
 for r in rows:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
