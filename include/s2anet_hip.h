@@ -467,7 +467,7 @@ int s2a_stem_u8_f16(const void* image_u8, const void* weight_packed, const void*
                     int64_t batch, int64_t height, int64_t width, float divisor, s2a_stream_t stream);
 
 /* 0 for a normal build; non-zero when an object was compiled with a measurement / ablation switch (-DS2A_MEASURE,
- * -DS2A_ABL=..., -DS2A_STAMP=1, -DS2A_MPIPE=0: such a build may skip work or print diagnostics). */
+ * -DS2A_ABL=..., -DS2A_STAMP=1: such a build may skip work or print diagnostics). */
 int s2a_build_flags(void);
 
 /* Diagnostic builds only (-DS2A_STAMP=1): per-workgroup s_memtime phase stamps of the AlignConv

@@ -2219,13 +2219,13 @@ __global__ __launch_bounds__(kThreads) void k_nms_round(const uint2* __restrict_
 }
 
 // (the implicit "open and not blocked == kept" view after the last launched round is written out as explicit states by
-// k_nms_alive_count, only when edges are still alive; the two `blocked` arrays become plain "blocked this round" flags)
-static_assert(kNmsRounds % 2 == 0 && kNmsRounds < 15, "the materialising pass of k_nms_alive_count / NmsCounters::alive assume this");
+// k_nms_finish_segments, only when edges are still alive; the two `blocked` arrays become plain "blocked this round" flags)
+static_assert(kNmsRounds % 2 == 0 && kNmsRounds < 15, "the materialising pass of k_nms_finish_segments / NmsCounters::alive assume this");
 
 // ---- FINISH per segment: chains longer than the launched rounds (dense detector outputs: tens of dependent rounds).
-// The edges that are still alive are bucketed by segment (count, scan, scatter) and every segment that has some is
+// Every segment that still has alive edges (picked out of the alive list by its workgroup, see below) is
 // finished by ONE workgroup with the rows' states, the round flags and the edge list in LDS, so that a round costs two
-// short passes and two barriers instead of a kernel launch.  Explicit states (the materialising pass of k_nms_alive_count ran): a round is
+// short passes and two barriers instead of a kernel launch.  Explicit states (the segment's workgroup wrote them out first): a round is
 //   pass 1: kept source -> target removed; open source and open target -> target flagged;
 //   pass 2: open and not flagged -> kept; edges whose target is still open stay (also when their source was removed
 //           in pass 1: the target is then decided next round), the others are dropped; the flags of the other array are
