@@ -388,6 +388,16 @@ int s2a_deform_conv_backward_input_f16(const void* input, const void* offset, co
                                        int64_t height, int64_t width, int64_t out_channels, void* workspace,
                                        size_t workspace_bytes, s2a_stream_t stream);
 
+/* The same entry for f32 tensors (same geometry limits), on the f32 matrix instruction: 4 x 8 position tiles, gradOutput
+ * tile and column gradient in LDS, no `columns`.  grad_input [S,C,H,W] f32 is the caller's gradInput, ACCUMULATED in place
+ * (deform_conv_cuda.cpp:334-340 adds into it through col2im's atomics); grad_offset [S,18,H,W] f32 is overwritten. */
+size_t s2a_deform_conv_backward_input_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                                          int64_t out_channels);
+int s2a_deform_conv_backward_input_f32(const float* input, const float* offset, const float* grad_output, const float* weight,
+                                       float* grad_input, float* grad_offset, int64_t batch, int64_t channels,
+                                       int64_t height, int64_t width, int64_t out_channels, void* workspace,
+                                       size_t workspace_bytes, s2a_stream_t stream);
+
 /* deform_conv_backward_parameters_cuda (models/dcn/src/deform_conv_cuda.cpp:376-489: gradWeight) for f16 tensors with the
  * AlignConv geometry (channels % 64 == 0, out_channels % 32 == 0, out_channels <= 256), fused: the sampled columns are
  * formed tile by tile in LDS (bilinear corners from an LDS patch, as the forward does) and contracted with gradOutput over

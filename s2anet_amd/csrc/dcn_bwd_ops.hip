@@ -284,9 +284,10 @@ __global__ void k_pack_weight_bwd(const _Float16* __restrict__ w, int O, int C, 
 }
 
 // 32 x 32 tile transpose: [S, C, HW] -> [S, HW, C]
-__global__ __launch_bounds__(256) void k_bwd_nchw_to_nhwc(const _Float16* __restrict__ src, int C, int64_t HW,
-                                                          _Float16* __restrict__ dst) {
-  __shared__ _Float16 tile[32][33];
+template <typename T>
+__global__ __launch_bounds__(256) void k_bwd_nchw_to_nhwc(const T* __restrict__ src, int C, int64_t HW,
+                                                          T* __restrict__ dst) {
+  __shared__ T tile[32][33];
   const int64_t b = blockIdx.z, p0 = (int64_t)blockIdx.x * 32;
   const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int r = ty; r < 32; r += 8) {
@@ -591,6 +592,341 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
 
 constexpr int kBwdLds = kBPos * kBGoRow + 9 * kBPos * kBGRow * 4 + kBPix * kBCh * 2 + kBPos * 9 * 16 + kBPos * 9 * 4 +
                         kBPos * 9 * 8 + kBPos * 9 * 4 * 4 + (kBPix + 1) * 4 + kBPix * 4 + 64;   // ~152 KB
+
+// ================================================================= fused input + offset gradient (f32, AlignConv geometry)
+// The same dataflow as k_dcn_bwd_input for float32 tensors (the reference trains in f32 unless amp is on: train.py), on the
+// f32 matrix instruction v_mfma_f32_16x16x4_f32 (64 FLOP / clk / SIMD: 157 TFLOP/s on the chip, 1/16 of the f16 rate --
+// the column gradient of one P3 x 8 call is 155 GFLOP = 1.0 ms at that peak, so here the MFMA jobs are the long phase).
+// Operands are twice as wide, so a workgroup owns a 4 x 8 tile (32 positions) with a 12 x 16 window:
+//   * gradOutput tile [32 pos][O] f32 in LDS (33 KB), rows padded by 4 floats (a quarter wave's sixteen 16-byte reads of
+//     sixteen rows fall into sixteen different 4-bank groups);
+//   * jobs = (tap, 16-position half, 16-channel half): 36 per chunk over 8 waves, 9 per SIMD; K = O is walked 16 out
+//     channels at a time: lane (n or m = l & 15, kq = l >> 4) holds o = 16 g + 4 kq + j for the j-th MFMA of group g, so that
+//     the gradOutput operand is ONE ds_read_b128 and the filter operand ONE 16-byte global load (filter pre-packed in that
+//     order) per four MFMAs;
+//   * offset-gradient pass and gather pass as in the f16 kernel (items of 8 channels; corner weights, fractions and the
+//     list weights in f32).
+// grad_in is the caller's gradInput itself (f32, accumulated in place as the reference's atomics do).
+constexpr int kFTH = 4, kFTW = 8, kFPos = kFTH * kFTW, kFHalo = 4;
+constexpr int kFPH = kFTH + 2 * kFHalo, kFPW = kFTW + 2 * kFHalo, kFPix = kFPH * kFPW;   // 12 x 16 = 192
+constexpr int kFCh = 32;                       // input channels per chunk
+constexpr int kFGRow = kFCh + 4;               // floats per (tap, position) row of the column-gradient tiles
+constexpr int kFPatRow = kFCh + 4;             // floats per window pixel of the input patch
+
+struct FTap {
+  short y, x;        // top-left bilinear corner, image coordinates
+  unsigned flags;    // bit 0: sample valid; bit 1: all four corners inside the LDS window; bits 31..2: window pixel index
+};
+
+// weight [O][C][9] f32 -> [tap][C/32][c half][O/16][lane 64][4]: lane l, element j of group g = W[o = 16 g + 4 (l >> 4) + j][c][tap],
+// c = cc * 32 + half * 16 + (l & 15)
+__global__ void k_pack_weight_bwd_f32(const float* __restrict__ w, int O, int C, float* __restrict__ wp) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)O * C * 9;
+  if (e >= total) return;
+  const int j = (int)(e & 3), lane = (int)((e >> 2) & 63);
+  int64_t r = e >> 8;
+  const int G16 = O / 16, CC = C / kFCh;
+  const int g = (int)(r % G16);
+  r /= G16;
+  const int half = (int)(r & 1);
+  r >>= 1;
+  const int cc = (int)(r % CC), t = (int)(r / CC);
+  const int o = 16 * g + 4 * (lane >> 4) + j, c = cc * kFCh + half * 16 + (lane & 15);
+  wp[e] = w[((int64_t)o * C + c) * 9 + t];
+}
+
+__host__ __device__ constexpr int bwd_f32_lds_bytes(int O) {
+  return kFPos * (O + 4) * 4 + 9 * kFPos * kFGRow * 4 + kFPix * kFPatRow * 4 + kFPos * 9 * 16 + kFPos * 9 * 8 +
+         kFPos * 9 * 8 + kFPos * 9 * 8 + kFPos * 9 * 4 * 4 + kFPos * 9 * 4 * 4 + (kFPix + 1) * 4 + kFPix * 4 + 64;
+}
+
+__global__ __launch_bounds__(512) void k_dcn_bwd_input_f32(const float* __restrict__ x,        // NHWC [S,H,W,C]
+                                                          const float* __restrict__ go,       // NHWC [S,H,W,O]
+                                                          const float* __restrict__ offset,   // NCHW [S,18,H,W]
+                                                          const float* __restrict__ wpk,
+                                                          float* __restrict__ grad_in,        // NCHW [S,C,H,W], accumulated
+                                                          float* __restrict__ grad_off,       // NCHW [S,18,H,W]
+                                                          int S, int C, int H, int W, int O) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int gop = O + 4;                                                    // floats per position of the gradOutput tile
+  float* s_go = reinterpret_cast<float*>(smem);                             // [32][gop]
+  float* s_G = s_go + kFPos * gop;                                          // [9][32][kFGRow]: column gradient of a chunk
+  float* s_patch = s_G + 9 * kFPos * kFGRow;                                // [192][kFPatRow]
+  f32x4b* s_w = reinterpret_cast<f32x4b*>(s_patch + kFPix * kFPatRow);      // [32 * 9] corner weights hh*hw, hh*lw, lh*hw, lh*lw
+  FTap* s_tab = reinterpret_cast<FTap*>(s_w + kFPos * 9);                   // [32 * 9]
+  float* s_frac = reinterpret_cast<float*>(s_tab + kFPos * 9);              // [32 * 9][2]: lh, lw
+  float* s_goff = s_frac + kFPos * 9 * 2;                                   // [32 * 9][2]
+  unsigned* s_list = reinterpret_cast<unsigned*>(s_goff + kFPos * 9 * 2);   // [32 * 9 * 4]: tap * 32 + pos
+  float* s_lw = reinterpret_cast<float*>(s_list + kFPos * 9 * 4);           // [32 * 9 * 4]: weight of the entry
+  unsigned* s_start = reinterpret_cast<unsigned*>(s_lw + kFPos * 9 * 4);    // [192 + 1]
+  unsigned* s_cur = s_start + kFPix + 1;                                    // [192]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int txn = (W + kFTW - 1) / kFTW, tyn = (H + kFTH - 1) / kFTH;
+  int t_ = blockIdx.x;
+  const int tx0 = (t_ % txn) * kFTW;
+  t_ /= txn;
+  const int ty0 = (t_ % tyn) * kFTH, b = t_ / tyn;
+  const int oy = ty0 - 3, ox = tx0 - 3;          // 2 pixels of slack above / left of the undeformed samples, 3 below / right
+  const int64_t HW = (int64_t)H * W;
+  const int G16 = O / 16, CC = C / kFCh;
+
+  // ---- gradOutput tile -> LDS (positions outside the image: zeros), accumulators, sampling table
+  for (int v = tid; v < kFPos * (O / 4); v += 512) {
+    const int pos = v / (O / 4), ch = v % (O / 4);
+    const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
+    f32x4b d = {0.f, 0.f, 0.f, 0.f};
+    if (y < H && xq < W) d = *reinterpret_cast<const f32x4b*>(go + ((int64_t)b * HW + (int64_t)y * W + xq) * O + ch * 4);
+    *reinterpret_cast<f32x4b*>(s_go + pos * gop + ch * 4) = d;
+  }
+  for (int e = tid; e < kFPos * 9 * 2; e += 512) s_goff[e] = 0.f;
+  for (int e = tid; e <= kFPix; e += 512) s_start[e] = 0u;
+  for (int e = tid; e < kFPos * 9; e += 512) {
+    const int pos = e / 9, t = e % 9;
+    const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
+    FTap tp;
+    tp.y = 0; tp.x = 0; tp.flags = 0u;
+    f32x4b w4 = {0.f, 0.f, 0.f, 0.f};
+    float lh = 0.f, lw = 0.f;
+    if (y < H && xq < W) {
+      const float* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
+      const float off_y = ob[(int64_t)(2 * t) * HW], off_x = ob[(int64_t)(2 * t + 1) * HW];
+      const float h_im = (float)(y - 1 + t / 3) + off_y, w_im = (float)(xq - 1 + t % 3) + off_x;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {      // (kernel.cu:228 / get_gradient_weight / coordinate_weight)
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        lh = h_im - h_low; lw = w_im - w_low;
+        const float hh = 1 - lh, hw = 1 - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+        w4[0] = (t_ok && l_ok) ? hh * hw : 0.f;
+        w4[1] = (t_ok && r_ok) ? hh * lw : 0.f;
+        w4[2] = (b_ok && l_ok) ? lh * hw : 0.f;
+        w4[3] = (b_ok && r_ok) ? lh * lw : 0.f;
+        tp.y = (short)h_low;
+        tp.x = (short)w_low;
+        const bool in = h_low >= oy && h_low + 1 <= oy + kFPH - 1 && w_low >= ox && w_low + 1 <= ox + kFPW - 1;
+        const int py = min(max(h_low - oy, 0), kFPH - 2), px = min(max(w_low - ox, 0), kFPW - 2);
+        tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kFPW + px) << 2);
+      }
+    }
+    s_tab[e] = tp;
+    s_w[e] = w4;
+    s_frac[2 * e] = lh;
+    s_frac[2 * e + 1] = lw;
+  }
+  __syncthreads();
+  // ---- contribution lists of the window pixels (see k_dcn_bwd_input)
+  for (int e = tid; e < kFPos * 9; e += 512) {
+    const FTap tp = s_tab[e];
+    if ((tp.flags & 3u) != 3u) continue;
+    const f32x4b w4 = s_w[e];
+    const int pix = (int)(tp.flags >> 2);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (w4[k] != 0.f) atomicAdd(&s_start[pix + (k >> 1) * kFPW + (k & 1) + 1], 1u);
+  }
+  __syncthreads();
+  if (wave == 0) {                               // inclusive scan of the 192 counts (shifted by one: s_start[p + 1])
+    unsigned carry = 0;
+    for (int base = 0; base < kFPix; base += 64) {
+      const int p = base + lane;
+      unsigned v = s_start[p + 1];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)v, o);
+        if (lane >= o) v += u;
+      }
+      s_start[p + 1] = carry + v;
+      carry += (unsigned)__shfl((int)v, 63);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < kFPix; e += 512) s_cur[e] = s_start[e];
+  __syncthreads();
+  for (int e = tid; e < kFPos * 9; e += 512) {
+    const FTap tp = s_tab[e];
+    if ((tp.flags & 3u) != 3u) continue;
+    const f32x4b w4 = s_w[e];
+    const int pix = (int)(tp.flags >> 2), pos = e / 9, t = e % 9;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (w4[k] != 0.f) {
+        const unsigned slot = atomicAdd(&s_cur[pix + (k >> 1) * kFPW + (k & 1)], 1u);
+        s_list[slot] = (unsigned)(t * kFPos + pos);
+        s_lw[slot] = w4[k];
+      }
+  }
+
+  // patch of chunk cc: 192 pixels x 8 vectors of 4 channels; vector v -> pixel v >> 3, group v & 7
+  f32x4b pv[3];
+  auto patch_issue = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int v = tid + 512 * i, p = v >> 3, q = v & 7;
+      pv[i] = f32x4b{0.f, 0.f, 0.f, 0.f};
+      const int yy = oy + p / kFPW, xx = ox + p % kFPW;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        pv[i] = *reinterpret_cast<const f32x4b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * kFCh + q * 4);
+    }
+  };
+  auto patch_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int v = tid + 512 * i;
+      *reinterpret_cast<f32x4b*>(s_patch + (v >> 3) * kFPatRow + (v & 7) * 4) = pv[i];
+    }
+  };
+  patch_issue(0);
+  for (int cc = 0; cc < CC; cc++) {
+    __syncthreads();                             // everybody is done with the previous chunk's patch and column gradient
+    patch_write();
+    if (cc + 1 < CC) patch_issue(cc + 1);        // (in flight under this chunk's work)
+    // ---- column-gradient tiles: job = (tap, 16-position half, 16-channel half); waves 0-3 take five jobs, 4-7 four: nine per SIMD
+    for (int job = wave; job < 36; job += 8) {
+      const int t = job >> 2, ph = (job >> 1) & 1, chh = job & 1;
+      const f32x4b* ap = reinterpret_cast<const f32x4b*>(wpk) + ((int64_t)((t * CC + cc) * 2 + chh) * G16) * 64 + lane;
+      const float* bp = s_go + (ph * 16 + (lane & 15)) * gop + 4 * (lane >> 4);
+      f32x4b acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4b a0[8], a1[8];                       // a batch of eight filter groups in flight one batch ahead (L2 latency)
+      auto load_a = [&](int k0, f32x4b (&a)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (k0 + k < G16) a[k] = ap[(int64_t)(k0 + k) * 64];
+      };
+      auto run = [&](int k0, const f32x4b (&a)[8]) {
+        f32x4b bb[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (k0 + k < G16) bb[k] = *reinterpret_cast<const f32x4b*>(bp + (k0 + k) * 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (k0 + k < G16) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][j], bb[k][j], acc, 0, 0, 0);
+          }
+      };
+      load_a(0, a0);
+      for (int k0 = 0; k0 < G16; k0 += 16) {
+        if (k0 + 8 < G16) load_a(k0 + 8, a1);
+        run(k0, a0);
+        if (k0 + 16 < G16) load_a(k0 + 16, a0);
+        if (k0 + 8 < G16) run(k0 + 8, a1);
+      }
+      // D: register r = channel 4 (lane >> 4) + r of the half, column = position lane & 15
+      *reinterpret_cast<f32x4b*>(s_G + (t * kFPos + ph * 16 + (lane & 15)) * kFGRow + chh * 16 + 4 * (lane >> 4)) = acc;
+    }
+    __syncthreads();
+    // ---- offset gradient: items (tap, position, 8-channel group); the four lanes of a position are neighbours
+    for (int it = tid; it < 9 * kFPos * 4; it += 512) {
+      const int t = it >> 7, r = it & 127, pos = r >> 2, q = r & 3;
+      const FTap tp = s_tab[pos * 9 + t];
+      if (!(tp.flags & 1u)) continue;            // (the four lanes of a position decide alike)
+      const float* gp = s_G + (t * kFPos + pos) * kFGRow + q * 8;
+      const f32x4b g0 = *reinterpret_cast<const f32x4b*>(gp), g1 = *reinterpret_cast<const f32x4b*>(gp + 4);
+      const bool in = (tp.flags & 2u) != 0u;
+      const int pix = (int)(tp.flags >> 2);
+      f32x4b c0[4], c1[4];
+      if (in) {
+        const float* p0 = s_patch + pix * kFPatRow + q * 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float* pk = p0 + ((k >> 1) * kFPW + (k & 1)) * kFPatRow;
+          c0[k] = *reinterpret_cast<const f32x4b*>(pk);
+          c1[k] = *reinterpret_cast<const f32x4b*>(pk + 4);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int yy = (int)tp.y + (k >> 1), xx = (int)tp.x + (k & 1);
+          c0[k] = f32x4b{0.f, 0.f, 0.f, 0.f};
+          c1[k] = c0[k];
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const float* pk = x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * kFCh + q * 8;
+            c0[k] = *reinterpret_cast<const f32x4b*>(pk);
+            c1[k] = *reinterpret_cast<const f32x4b*>(pk + 4);
+          }
+        }
+      }
+      // get_coordinate_weight (kernel.cu:145-187): corners outside the image hold zeros
+      float d[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) a = __builtin_fmaf(g0[j], c0[k][j], a);
+#pragma unroll
+        for (int j = 0; j < 4; j++) a = __builtin_fmaf(g1[j], c1[k][j], a);
+        d[k] = a;
+      }
+      const float lh = s_frac[2 * (pos * 9 + t)], lw = s_frac[2 * (pos * 9 + t) + 1];
+      float gh = (1.f - lw) * (d[2] - d[0]) + lw * (d[3] - d[1]);
+      float gw = (1.f - lh) * (d[1] - d[0]) + lh * (d[3] - d[2]);
+      gh += __shfl_xor(gh, 1); gw += __shfl_xor(gw, 1);
+      gh += __shfl_xor(gh, 2); gw += __shfl_xor(gw, 2);
+      if (q == 0) {                              // one owner per (position, tap): plain read-modify-write
+        s_goff[2 * (pos * 9 + t)] += gh;
+        s_goff[2 * (pos * 9 + t) + 1] += gw;
+      }
+      if (!in) {                                 // input gradient of a sample that left the window: straight to memory
+        const f32x4b w4 = s_w[pos * 9 + t];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float wk = w4[k];
+          if (wk == 0.f) continue;
+          const int yy = (int)tp.y + (k >> 1), xx = (int)tp.x + (k & 1);
+          float* gp2 = grad_in + (((int64_t)b * C + cc * kFCh + q * 8) * H + yy) * W + xx;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            atomicAdd(gp2 + (int64_t)j * HW, wk * g0[j]);
+            atomicAdd(gp2 + (int64_t)(4 + j) * HW, wk * g1[j]);
+          }
+        }
+      }
+    }
+    // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels
+    for (int wi = tid; wi < 4 * kFPix; wi += 512) {
+      const int q = wi / kFPix, pix = wi % kFPix;
+      const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
+      if (l0 == l1) continue;
+      f32x4b s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      for (unsigned l = l0; l < l1; l += 4) {    // four entries per trip (entry -> row -> two row reads are dependent LDS round trips)
+        unsigned ent[4];
+        float wk[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned li = min(l + k, l1 - 1);
+          ent[k] = s_list[li];
+          wk[k] = l + k < l1 ? s_lw[li] : 0.f;
+        }
+        f32x4b g0[4], g1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float* gp = s_G + ent[k] * kFGRow + q * 8;
+          g0[k] = *reinterpret_cast<const f32x4b*>(gp);
+          g1[k] = *reinterpret_cast<const f32x4b*>(gp + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) { s0[j] = __builtin_fmaf(wk[k], g0[k][j], s0[j]); s1[j] = __builtin_fmaf(wk[k], g1[k][j], s1[j]); }
+      }
+      const int yy = oy + pix / kFPW, xx = ox + pix % kFPW;      // (pixels outside the image have no list: w = 0 there)
+      float* gp2 = grad_in + (((int64_t)b * C + cc * kFCh + q * 8) * H + yy) * W + xx;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        atomicAdd(gp2 + (int64_t)j * HW, s0[j]);
+        atomicAdd(gp2 + (int64_t)(4 + j) * HW, s1[j]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- offset gradient of the tile: [S, 18, H, W], channel 2 t = dy, 2 t + 1 = dx
+  for (int i = tid; i < 18 * kFPos; i += 512) {
+    const int ch = i / kFPos, pos = i % kFPos;
+    const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
+    if (y < H && xq < W)
+      grad_off[((int64_t)b * 18 + ch) * HW + (int64_t)y * W + xq] = s_goff[2 * (pos * 9 + (ch >> 1)) + (ch & 1)];
+  }
+}
 
 // ================================================================= fused weight gradient (f16, AlignConv geometry)
 // deform_conv_backward_parameters_cuda (deform_conv_cuda.cpp:376-489): gradWeight[o, c, tap] = sum over positions of
@@ -920,9 +1256,9 @@ extern "C" int s2a_deform_conv_backward_input_f16(const void* input, const void*
   _Float16* gn = cv.take<_Float16>((size_t)(batch * HW * out_channels));
   _Float16* wp = cv.take<_Float16>((size_t)(out_channels * channels * 9));
   S2A_CHECK_ARG(xn && gn && wp, "deform_conv_backward_input_f16: workspace too small");
-  k_bwd_nchw_to_nhwc<<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+  k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
       (const _Float16*)input, (int)channels, HW, xn);
-  k_bwd_nchw_to_nhwc<<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+  k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
       (const _Float16*)grad_output, (int)out_channels, HW, gn);
   const int64_t wtotal = out_channels * channels * 9;
   k_pack_weight_bwd<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, wp);
@@ -931,6 +1267,50 @@ extern "C" int s2a_deform_conv_backward_input_f16(const void* input, const void*
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
   k_dcn_bwd_input<<<(unsigned)tiles, 512, kBwdLds, st>>>(xn, gn, (const _Float16*)offset, wp, grad_input_f32, (_Float16*)grad_offset,
                                                         (int)batch, (int)channels, (int)height, (int)width, (int)out_channels);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+// The same for f32 tensors (k_dcn_bwd_input_f32): grad_input [S,C,H,W] f32 is the caller's gradInput, ACCUMULATED in place;
+// grad_offset [S,18,H,W] f32 is overwritten.  workspace: NHWC copies of input and gradOutput + the packed filter.
+extern "C" size_t s2a_deform_conv_backward_input_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
+                                                                     int64_t width, int64_t out_channels) {
+  return align_up((size_t)(batch * height * width * channels) * 4) + align_up((size_t)(batch * height * width * out_channels) * 4) +
+         align_up((size_t)(out_channels * channels * 9) * 4) + 1024;
+}
+
+extern "C" int s2a_deform_conv_backward_input_f32(const float* input, const float* offset, const float* grad_output,
+                                                  const float* weight, float* grad_input, float* grad_offset,
+                                                  int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                                  int64_t out_channels, void* workspace, size_t workspace_bytes,
+                                                  s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && height >= 3 && width >= 3 && out_channels > 0, "deform_conv_backward_input_f32: bad shape");
+  S2A_CHECK_ARG(channels % kFCh == 0 && out_channels % 16 == 0 && out_channels <= 256,
+                "deform_conv_backward_input_f32: needs channels %% 32 == 0, out_channels %% 16 == 0, out_channels <= 256");
+  S2A_CHECK_ARG(height < (1 << 15) && width < (1 << 15), "deform_conv_backward_input_f32: shape too large");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(input && offset && grad_output && weight && grad_input && grad_offset, "deform_conv_backward_input_f32: NULL tensor");
+  S2A_CHECK_ARG(workspace_bytes >= s2a_deform_conv_backward_input_f32_workspace_bytes(batch, channels, height, width, out_channels),
+                "deform_conv_backward_input_f32: workspace too small");
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace, workspace_bytes);
+  const int64_t HW = height * width;
+  float* xn = cv.take<float>((size_t)(batch * HW * channels));
+  float* gn = cv.take<float>((size_t)(batch * HW * out_channels));
+  float* wp = cv.take<float>((size_t)(out_channels * channels * 9));
+  S2A_CHECK_ARG(xn && gn && wp, "deform_conv_backward_input_f32: workspace too small");
+  k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+      input, (int)channels, HW, xn);
+  k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+      grad_output, (int)out_channels, HW, gn);
+  const int64_t wtotal = out_channels * channels * 9;
+  k_pack_weight_bwd_f32<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>(weight, (int)out_channels, (int)channels, wp);
+  const int64_t tiles = batch * ((height + kFTH - 1) / kFTH) * ((width + kFTW - 1) / kFTW);
+  S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_input_f32: too many tiles");
+  const int lds = bwd_f32_lds_bytes((int)out_channels);
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  k_dcn_bwd_input_f32<<<(unsigned)tiles, 512, lds, st>>>(xn, gn, offset, wp, grad_input, grad_offset, (int)batch, (int)channels,
+                                                        (int)height, (int)width, (int)out_channels);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -961,9 +1341,9 @@ extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void
   _Float16* xn = cv.take<_Float16>((size_t)(batch * HW * channels));
   _Float16* gn = cv.take<_Float16>((size_t)(batch * HW * out_channels));
   S2A_CHECK_ARG(xn && gn, "deform_conv_backward_weight_f16: workspace too small");
-  k_bwd_nchw_to_nhwc<<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+  k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
       (const _Float16*)input, (int)channels, HW, xn);
-  k_bwd_nchw_to_nhwc<<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+  k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
       (const _Float16*)grad_output, (int)out_channels, HW, gn);
   const int64_t tiles = batch * ((height + kBTH - 1) / kBTH) * ((width + kBTW - 1) / kBTW);
   S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_weight_f16: too many tiles");

@@ -179,8 +179,9 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
                                     dW, dH, padW, padH, dilationW, dilationH, group, deformable_group,
                                     im2col_step):
     """models/dcn/src/deform_conv_cuda.cpp:262-374, same positional signature.  gradInput (caller-zeroed,
-    deform_conv.py:88) and gradOffset are filled in place.  Per chunk of im2col_step images:
-    columns = weight^T x gradOutput (library GEMM, the reference's addmm_ :323), then
+    deform_conv.py:88) and gradOffset are filled in place.  AlignConv geometry (3x3, stride 1, pad 1, one group, C % 32 == 0,
+    O % 16 == 0, O <= 256): one fused kernel per call, f32 or f16, no `columns`.  Any other geometry, per chunk of
+    im2col_step images: columns = weight^T x gradOutput (library GEMM, the reference's addmm_ :323), then
     s2a_deformable_col2im_coord -> gradOffset and s2a_deformable_col2im -> gradInput.  Returns 1."""
     x, off, go, (B, C, H, W, O, Ho, Wo), params = _bwd_common(
         input, offset, gradOutput, weight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
@@ -189,14 +190,34 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
     L = _lib.lib()
     step, npos = im2col_step, im2col_step * Ho * Wo
     p = params(step)
-    gin32 = torch.zeros((B, C, H, W), dtype=torch.float32, device=x.device)
     goff = torch.empty_like(off)
+    align_geom = ((kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1) and group == 1
+                  and deformable_group == 1 and C % 32 == 0 and O % 16 == 0 and O <= 256 and H >= 3 and W >= 3
+                  and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
+    # f32 + AlignConv geometry: the fused dataflow on the f32 matrix instruction (s2a_deform_conv_backward_input_f32),
+    # accumulating straight into the caller's gradInput when it is the f32 NCHW tensor deform_conv.py:88 allocates
+    if align_geom and x.dtype == torch.float32:
+        direct = (gradInput.dtype == torch.float32 and gradInput.is_contiguous() and gradInput.numel() == B * C * H * W
+                  and gradInput.device == x.device)
+        gin = gradInput if direct else torch.zeros((B, C, H, W), dtype=torch.float32, device=x.device)
+        direct_off = (gradOffset.dtype == torch.float32 and gradOffset.is_contiguous() and gradOffset.numel() == goff.numel()
+                      and gradOffset.device == x.device)
+        if direct_off:
+            goff = gradOffset
+        ws = _lib.workspace(L.s2a_deform_conv_backward_input_f32_workspace_bytes(B, C, H, W, O), x.device, "dcn_bwd")
+        with torch.cuda.device(x.device):
+            _lib.check(L.s2a_deform_conv_backward_input_f32(_lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(w), _lib.ptr(gin),
+                                                            _lib.ptr(goff), B, C, H, W, O, _lib.ptr(ws), ws.numel(),
+                                                            _lib.stream_ptr(x.device)))
+        if not direct:
+            gradInput.view(B, C, H, W).add_(gin.to(gradInput.dtype))
+        if not direct_off:
+            gradOffset.view_as(goff).copy_(goff)
+        return 1
+    gin32 = torch.zeros((B, C, H, W), dtype=torch.float32, device=x.device)
     # f16 + AlignConv geometry: ONE fused kernel for the whole batch -- column gradient on the matrix cores, consumed in
     # LDS, no `columns` tensor (s2a_deform_conv_backward_input_f16); the chunking by im2col_step has nothing to chunk then
-    fused = (x.dtype == torch.float16 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)
-             and group == 1 and deformable_group == 1 and C % 32 == 0 and O % 16 == 0 and O <= 256 and H >= 3 and W >= 3
-             and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
-    if fused:
+    if align_geom and x.dtype == torch.float16:
         nbytes = L.s2a_deform_conv_backward_input_workspace_bytes(B, C, H, W, O)
         ws = _lib.workspace(nbytes, x.device, "dcn_bwd")
         with torch.cuda.device(x.device):

@@ -1779,6 +1779,40 @@ def test_dcn_backward_input_fused_f16_vs_oracle(rng, monkeypatch):
         assert np.abs(gx).max() > 0.5 and np.abs(goff).max() > 0.5
 
 
+def test_dcn_backward_input_fused_f32_vs_oracle(rng, monkeypatch):
+    """the fused f32 input / offset gradient (s2a_deform_conv_backward_input_f32: column gradient on the f32 matrix
+    instruction, 4 x 8 tiles, accumulated straight into the caller's gradInput) against the oracle
+    (deform_conv_cuda.cpp:262-374 restated) within the north_star's 1e-4, and against the unfused path on the same call:
+    tame offsets, wild ones (global-atomic path), ragged images, one / two / three channel chunks, O = 16 ... 256,
+    a non-zero gradInput (accumulation), a non-contiguous gradInput (staged)"""
+    from s2anet_amd.dcn import deform_conv_backward_input_cuda
+    cases = ((2, 64, 19, 45, 32, 0.7), (1, 32, 9, 20, 16, 5.0), (2, 96, 8, 16, 48, 2.0), (1, 32, 13, 11, 256, 1.0))
+    for (B, C, H, W, O, amp) in cases:
+        xn = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        wn = (rng.standard_normal((O, C, 3, 3)) * 0.1).astype(np.float32)
+        on = (rng.standard_normal((B, 18, H, W)) * amp).astype(np.float32)
+        gn = rng.standard_normal((B, O, H, W)).astype(np.float32)
+        base = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        gx, goff, _ = oracle.deform_conv_backward(xn, on, wn, gn)
+        for mode in ("fused", "unfused", "fused-staged"):
+            if mode == "unfused":
+                monkeypatch.setenv("S2A_DCN_BWD_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("S2A_DCN_BWD_UNFUSED", raising=False)
+            gi = cu(base).clone()
+            if mode == "fused-staged":
+                gi = torch.empty(B, C, W, H, device=dev()).transpose(2, 3)
+                gi.copy_(cu(base))
+                assert not gi.is_contiguous()
+            go_ = torch.full((B, 18, H, W), 7.0, device=dev())
+            assert deform_conv_backward_input_cuda(cu(xn), cu(on), cu(gn), gi, go_, cu(wn), None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, B) == 1
+            ei = np.abs(gi.cpu().numpy() - base - gx).max()
+            eo = np.abs(go_.cpu().numpy() - goff).max()
+            assert ei < 1e-4 * max(1.0, np.abs(gx).max()), (mode, (B, C, H, W, O), ei, np.abs(gx).max())
+            assert eo < 1e-4 * max(1.0, np.abs(goff).max()), (mode, (B, C, H, W, O), eo, np.abs(goff).max())
+        assert np.abs(gx).max() > 0.5 and np.abs(goff).max() > 0.5
+
+
 def test_dcn_backward_weight_fused_f16_vs_oracle(rng, monkeypatch):
     """the fused f16 weight gradient (s2a_deform_conv_backward_weight_f16: columns formed in LDS, contracted over the
     positions on the matrix cores through transposing LDS reads, split-K atomics) against the oracle
