@@ -410,6 +410,15 @@ int s2a_deform_conv_backward_weight_f16(const void* input, const void* offset, c
                                         int64_t width, int64_t out_channels, void* workspace, size_t workspace_bytes,
                                         s2a_stream_t stream);
 
+/* The same entry for f32 tensors (same geometry limits; v_mfma_f32_32x32x2_f32, 4 x 8 position tiles): grad_weight
+ * [O,C,3,3] f32 is the caller's gradWeight, ACCUMULATED in place with `scale` applied (deform_conv_cuda.cpp:455-459). */
+size_t s2a_deform_conv_backward_weight_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                                           int64_t out_channels);
+int s2a_deform_conv_backward_weight_f32(const float* input, const float* offset, const float* grad_output,
+                                        float* grad_weight, float scale, int64_t batch, int64_t channels, int64_t height,
+                                        int64_t width, int64_t out_channels, void* workspace, size_t workspace_bytes,
+                                        s2a_stream_t stream);
+
 /* A bottleneck's conv2 + conv3 in one launch (models/backbone.py:56-83 with the BatchNorms folded):
  *   out = relu(W3 . relu(conv3x3(x; W2) + b2) + b3 + residual)        x [B,H,W,64] -> out [B,H,W,256], f16 NHWC
  * The 64-map intermediate never leaves the workgroup (LDS); results are bit-identical to s2a_conv_nhwc_f16 (3x3,

@@ -22,5 +22,8 @@ extern "C" const char* s2a_version(void) { return "s2anet_hip 0.1 (gfx950)"; }
 namespace s2a {
 int build_flags_dcn();
 int build_flags_rotated();
+int build_flags_dcn_bwd();
 }  // namespace s2a
-extern "C" int s2a_build_flags(void) { return s2a::build_flags_dcn() | (s2a::build_flags_rotated() << 16); }
+extern "C" int s2a_build_flags(void) {
+  return s2a::build_flags_dcn() | (s2a::build_flags_rotated() << 16) | (s2a::build_flags_dcn_bwd() << 24);
+}

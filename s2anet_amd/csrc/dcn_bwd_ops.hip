@@ -246,6 +246,7 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
 // HBM traffic per tile: gradOutput once, the input patch once per chunk, the gradient window once per chunk.
 // S2A_BWD_ABL: timing-only ablations of k_dcn_bwd_input (never set in a shipped build): 1 = no global atomics of the gathered
 // input gradient, 2 = no gather pass at all, 4 = no offset-gradient pass, 8 = no MFMA jobs, 16 = no list building
+// (bits 1 / 2 / 4 / 8 act on k_dcn_bwd_input_f32 too; k_dcn_bwd_weight_f32: 32 = no MFMAs, 64 = no blend, 128 = no tile loads)
 #ifndef S2A_BWD_ABL
 #define S2A_BWD_ABL 0
 #endif
@@ -641,6 +642,7 @@ __host__ __device__ constexpr int bwd_f32_lds_bytes(int O) {
          kFPos * 9 * 8 + kFPos * 9 * 8 + kFPos * 9 * 4 * 4 + kFPos * 9 * 4 * 4 + (kFPix + 1) * 4 + kFPix * 4 + 64;
 }
 
+template <bool EXACT>                          // EXACT: O % 128 == 0, every batch of eight filter groups is full (no branches in a job)
 __global__ __launch_bounds__(512) void k_dcn_bwd_input_f32(const float* __restrict__ x,        // NHWC [S,H,W,C]
                                                           const float* __restrict__ go,       // NHWC [S,H,W,O]
                                                           const float* __restrict__ offset,   // NCHW [S,18,H,W]
@@ -781,42 +783,51 @@ __global__ __launch_bounds__(512) void k_dcn_bwd_input_f32(const float* __restri
     patch_write();
     if (cc + 1 < CC) patch_issue(cc + 1);        // (in flight under this chunk's work)
     // ---- column-gradient tiles: job = (tap, 16-position half, 16-channel half); waves 0-3 take five jobs, 4-7 four: nine per SIMD
-    for (int job = wave; job < 36; job += 8) {
+    for (int job = wave; job < ((S2A_BWD_ABL & 8) ? 0 : 36); job += 8) {
       const int t = job >> 2, ph = (job >> 1) & 1, chh = job & 1;
       const f32x4b* ap = reinterpret_cast<const f32x4b*>(wpk) + ((int64_t)((t * CC + cc) * 2 + chh) * G16) * 64 + lane;
       const float* bp = s_go + (ph * 16 + (lane & 15)) * gop + 4 * (lane >> 4);
-      f32x4b acc = {0.f, 0.f, 0.f, 0.f};
-      f32x4b a0[8], a1[8];                       // a batch of eight filter groups in flight one batch ahead (L2 latency)
-      auto load_a = [&](int k0, f32x4b (&a)[8]) {
+      // two accumulators (back-to-back MFMAs on ONE accumulator wait for each other's eight passes), and both operands of a
+      // batch of eight groups requested one batch ahead: the filter comes from L2, the gradOutput rows from LDS, and hipcc
+      // places a read right in front of its MFMA unless the order is pinned
+      f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      f32x4b a0[8], a1[8], b0[8], b1[8];
+      auto load_ab = [&](int k0, f32x4b (&a)[8], f32x4b (&bb)[8]) {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-          if (k0 + k < G16) a[k] = ap[(int64_t)(k0 + k) * 64];
-      };
-      auto run = [&](int k0, const f32x4b (&a)[8]) {
-        f32x4b bb[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-          if (k0 + k < G16) bb[k] = *reinterpret_cast<const f32x4b*>(bp + (k0 + k) * 16);
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-          if (k0 + k < G16) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][j], bb[k][j], acc, 0, 0, 0);
+          if (EXACT || k0 + k < G16) {
+            a[k] = ap[(int64_t)(k0 + k) * 64];
+            bb[k] = *reinterpret_cast<const f32x4b*>(bp + (k0 + k) * 16);
           }
       };
-      load_a(0, a0);
+      auto run = [&](int k0, const f32x4b (&a)[8], const f32x4b (&bb)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (EXACT || k0 + k < G16) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][0], bb[k][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][1], bb[k][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][2], bb[k][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][3], bb[k][3], acc1, 0, 0, 0);
+          }
+      };
+      load_ab(0, a0, b0);
       for (int k0 = 0; k0 < G16; k0 += 16) {
-        if (k0 + 8 < G16) load_a(k0 + 8, a1);
-        run(k0, a0);
-        if (k0 + 16 < G16) load_a(k0 + 16, a0);
-        if (k0 + 8 < G16) run(k0 + 8, a1);
+        if (k0 + 8 < G16) load_ab(k0 + 8, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        run(k0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 16 < G16) load_ab(k0 + 16, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 8 < G16) run(k0 + 8, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      const f32x4b acc = acc0 + acc1;
       // D: register r = channel 4 (lane >> 4) + r of the half, column = position lane & 15
       *reinterpret_cast<f32x4b*>(s_G + (t * kFPos + ph * 16 + (lane & 15)) * kFGRow + chh * 16 + 4 * (lane >> 4)) = acc;
     }
     __syncthreads();
     // ---- offset gradient: items (tap, position, 8-channel group); the four lanes of a position are neighbours
-    for (int it = tid; it < 9 * kFPos * 4; it += 512) {
+    for (int it = tid; it < ((S2A_BWD_ABL & 4) ? 0 : 9 * kFPos * 4); it += 512) {
       const int t = it >> 7, r = it & 127, pos = r >> 2, q = r & 3;
       const FTap tp = s_tab[pos * 9 + t];
       if (!(tp.flags & 1u)) continue;            // (the four lanes of a position decide alike)
@@ -883,7 +894,7 @@ __global__ __launch_bounds__(512) void k_dcn_bwd_input_f32(const float* __restri
       }
     }
     // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels
-    for (int wi = tid; wi < 4 * kFPix; wi += 512) {
+    for (int wi = tid; wi < ((S2A_BWD_ABL & 2) ? 0 : 4 * kFPix); wi += 512) {
       const int q = wi / kFPix, pix = wi % kFPix;
       const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
       if (l0 == l1) continue;
@@ -911,6 +922,7 @@ __global__ __launch_bounds__(512) void k_dcn_bwd_input_f32(const float* __restri
       }
       const int yy = oy + pix / kFPW, xx = ox + pix % kFPW;      // (pixels outside the image have no list: w = 0 there)
       float* gp2 = grad_in + (((int64_t)b * C + cc * kFCh + q * 8) * H + yy) * W + xx;
+      if (S2A_BWD_ABL & 1) { if (s0[0] == 12345.f) gp2[0] = s0[1] + s0[2] + s0[3] + s1[0] + s1[1] + s1[2] + s1[3]; continue; }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         atomicAdd(gp2 + (int64_t)j * HW, s0[j]);
@@ -1138,6 +1150,259 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
   }
 }
 
+// ================================================================= fused weight gradient (f32, AlignConv geometry)
+// k_dcn_bwd_weight's dataflow for float32 tensors on v_mfma_f32_32x32x2_f32.  With f32 operands nothing has to be transposed:
+// the contraction index (the position) is the ROW of both LDS images, and an f32 MFMA operand is one value per lane -- lane
+// (l & 31, l >> 5) reads element l & 31 of row 2 ks + (l >> 5): 32 consecutive floats per half wave, the two rows a pitch
+// apart that is 32 (mod 64) floats, so the 64 lanes cover the 64 banks.  A workgroup owns ONE 64-channel chunk and ONE row of
+// three taps and a slice of the 4 x 8 position tiles (12 owners x 21 slices = 252 workgroups); wave w owns out channels
+// 32 w .. 32 w + 31, 3 x 2 accumulator tiles of 32 x 32 in registers over all its tiles, written once by f32 atomics
+// (scaled: gradWeight += scale * ..., deform_conv_cuda.cpp:455-459).  Per tile 16 k-steps x 6 MFMAs of 64 cycles per wave.
+#ifdef S2A_MEASURE
+__device__ unsigned long long g_bwd_dbg[8];    // [0..3] cycles of land+table / blend / MFMA / loop-top barrier, [4] tiles, [5] workgroups, [6] whole kernel
+#define BWD_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define BWD_T(v)
+#endif
+constexpr int kFWColRow = 96;                  // floats per position of a column tile: 64 channels + 32
+constexpr int kFWPatRow = 68;                  // floats per window pixel: 64 channels + 4
+__host__ __device__ constexpr int wgrad_f32_go_pitch(int O) { return O + ((32 - (O & 63)) & 63); }
+__host__ __device__ constexpr int wgrad_f32_lds_bytes(int O) {
+  return kFPos * wgrad_f32_go_pitch(O) * 4 + kFPix * kFWPatRow * 4 + 3 * kFPos * kFWColRow * 4 + 3 * kFPos * 16 + 3 * kFPos * 8 + 64;
+}
+
+__global__ __launch_bounds__(512) void k_dcn_bwd_weight_f32(const float* __restrict__ x,        // NHWC [S,H,W,C]
+                                                           const float* __restrict__ go,       // NHWC [S,H,W,O]
+                                                           const float* __restrict__ offset,   // NCHW [S,18,H,W]
+                                                           float* __restrict__ grad_w,         // [O][C][9], accumulated
+                                                           float scale, int S, int C, int H, int W, int O, int ksplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int gop = wgrad_f32_go_pitch(O);
+  float* s_go = reinterpret_cast<float*>(smem);                              // [32][gop]
+  float* s_patch = s_go + kFPos * gop;                                       // [192][kFWPatRow]
+  float* s_col = s_patch + kFPix * kFWPatRow;                                // [3][32][kFWColRow]
+  f32x4b* s_w = reinterpret_cast<f32x4b*>(s_col + 3 * kFPos * kFWColRow);    // [3 * 32] corner weights
+  FTap* s_tab = reinterpret_cast<FTap*>(s_w + 3 * kFPos);                    // [3 * 32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CC = C / 64;
+  const int owner = blockIdx.x % (3 * CC), slice = blockIdx.x / (3 * CC);
+  const int cc = owner / 3, ky = owner % 3;
+  const int txn = (W + kFTW - 1) / kFTW, tyn = (H + kFTH - 1) / kFTH;
+  const int ntiles = S * tyn * txn;
+  const int64_t HW = (int64_t)H * W;
+  const bool mwave = wave < O / 32;                                          // wave w owns out-channel tile w (O <= 256)
+  f32x16b acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
+
+  // registers that carry the NEXT tile's gradOutput tile and patch (issued a tile ahead)
+  constexpr int kGoVec = 4, kPaVec = 6;                       // 16-byte vectors per thread: 32 * 64 / 512 (O = 256), 192 * 16 / 512
+  f32x4b gv[kGoVec], pvv[kPaVec];
+  auto tile_geom = [&](int tile, int& b, int& ty0, int& tx0) {
+    tx0 = (tile % txn) * kFTW;
+    const int r = tile / txn;
+    ty0 = (r % tyn) * kFTH;
+    b = r / tyn;
+  };
+  // The next tile's operands are requested in eleven PIECES that ride between the MFMA groups of this tile (a 1 KB request
+  // occupies its wave's instruction stream for ~63 cycles -- the length of one f32 MFMA, which keeps the pipe busy meanwhile;
+  // all ten at the head of the blend cost every wave 0.6 k cycles and the CU's 64 B/clk address path 1.3 k).  Branch-free:
+  // an element outside the image (or past the tile list: the last tile is requested again) loads from a clamped address and
+  // is zeroed when it lands (`okm`), so the MFMA loop has no CFG edge.  Piece 10: the 96 table threads' two offsets.
+  unsigned okm = 0u;
+  float off_yx[2] = {0.f, 0.f};
+  auto issue_piece = [&](int tile, int i) {
+    int b, ty0, tx0;
+    tile_geom(min(tile, ntiles - 1), b, ty0, tx0);
+    const int oy = ty0 - 3, ox = tx0 - 3;
+    if (i < kGoVec) {
+      const int ovec = O / 4;
+      const int v = min(tid + 512 * i, kFPos * ovec - 1);
+      const int pos = v / ovec, ch = v % ovec;
+      const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
+      const bool ok = y < H && xq < W;
+      gv[i] = *reinterpret_cast<const f32x4b*>(go + ((int64_t)b * HW + (int64_t)min(y, H - 1) * W + min(xq, W - 1)) * O + ch * 4);
+      okm = (okm & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+    } else if (i < kGoVec + kPaVec) {
+      const int j = i - kGoVec;
+      const int v = tid + 512 * j, p = v >> 4, q = v & 15;
+      const int yy = oy + p / kFPW, xx = ox + p % kFPW;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      pvv[j] = *reinterpret_cast<const f32x4b*>(x + ((int64_t)b * HW + (int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * C + cc * 64 + q * 4);
+      okm = (okm & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+    } else {
+      const int e = min(tid, 3 * kFPos - 1), tl = e / kFPos, pos = e % kFPos, t = ky * 3 + tl;
+      const int y = min(ty0 + (pos >> 3), H - 1), xq = min(tx0 + (pos & 7), W - 1);
+      const float* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
+      off_yx[0] = ob[(int64_t)(2 * t) * HW];
+      off_yx[1] = ob[(int64_t)(2 * t + 1) * HW];
+    }
+  };
+  constexpr int kPieces = kGoVec + kPaVec + 1;
+  auto land = [&]() {
+    const int ovec = O / 4;
+    const f32x4b zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kGoVec; i++) {
+      const int v = tid + 512 * i;
+      if (v < kFPos * ovec) *reinterpret_cast<f32x4b*>(s_go + (v / ovec) * gop + (v % ovec) * 4) = ((okm >> i) & 1u) ? gv[i] : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < kPaVec; i++) {
+      const int v = tid + 512 * i;
+      *reinterpret_cast<f32x4b*>(s_patch + (v >> 4) * kFWPatRow + (v & 15) * 4) = ((okm >> (kGoVec + i)) & 1u) ? pvv[i] : zero;
+    }
+  };
+
+#ifdef S2A_MEASURE
+  unsigned long long c_land = 0, c_blend = 0, c_mma = 0, c_bar = 0, c_tiles = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+  int tile = slice;
+  if (tile < ntiles) {
+#pragma unroll
+    for (int i = 0; i < kPieces; i++) issue_piece(tile, i);
+  }
+  for (; tile < ntiles; tile += ksplit) {
+    int b, ty0, tx0;
+    tile_geom(tile, b, ty0, tx0);
+    const int oy = ty0 - 3, ox = tx0 - 3;
+    BWD_T(t0);
+    __syncthreads();                             // the previous tile's operands have been read
+    BWD_T(t1);
+    land();
+    if (tid < 3 * kFPos) {                       // sampling table of this tile's three taps
+      const int tl = tid / kFPos, pos = tid % kFPos, t = ky * 3 + tl;
+      const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
+      FTap tp;
+      tp.y = 0; tp.x = 0; tp.flags = 0u;
+      f32x4b w4 = {0.f, 0.f, 0.f, 0.f};
+      if (y < H && xq < W) {
+        const float off_y = off_yx[0], off_x = off_yx[1];      // (requested a tile ahead, piece 10)
+        const float h_im = (float)(y - 1 + ky) + off_y, w_im = (float)(xq - 1 + tl) + off_x;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+          const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+          w4[0] = (t_ok && l_ok) ? hh * hw : 0.f;
+          w4[1] = (t_ok && r_ok) ? hh * lw : 0.f;
+          w4[2] = (b_ok && l_ok) ? lh * hw : 0.f;
+          w4[3] = (b_ok && r_ok) ? lh * lw : 0.f;
+          tp.y = (short)h_low;
+          tp.x = (short)w_low;
+          const bool in = h_low >= oy && h_low + 1 <= oy + kFPH - 1 && w_low >= ox && w_low + 1 <= ox + kFPW - 1;
+          const int py = min(max(h_low - oy, 0), kFPH - 2), px = min(max(w_low - ox, 0), kFPW - 2);
+          tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kFPW + px) << 2);
+        }
+      }
+      s_tab[tid] = tp;
+      s_w[tid] = w4;
+    }
+    __syncthreads();
+    BWD_T(t2);
+    // ---- column tiles of the three taps: item = (tap, position, 8-channel group)
+    for (int it = tid; it < ((S2A_BWD_ABL & 64) ? 0 : 3 * kFPos * 8); it += 512) {
+      const int tl = it >> 8, r = it & 255, pos = r >> 3, q = r & 7;
+      const FTap tp = s_tab[tl * kFPos + pos];
+      f32x4b o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+      if (tp.flags & 1u) {
+        const f32x4b w4 = s_w[tl * kFPos + pos];
+        f32x4b c0[4], c1[4];
+        if (tp.flags & 2u) {
+          const float* p0 = s_patch + (int)(tp.flags >> 2) * kFWPatRow + q * 8;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float* pk = p0 + ((k >> 1) * kFPW + (k & 1)) * kFWPatRow;
+            c0[k] = *reinterpret_cast<const f32x4b*>(pk);
+            c1[k] = *reinterpret_cast<const f32x4b*>(pk + 4);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int yy = (int)tp.y + (k >> 1), xx = (int)tp.x + (k & 1);
+            c0[k] = f32x4b{0.f, 0.f, 0.f, 0.f};
+            c1[k] = c0[k];
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+              const float* pk = x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8;
+              c0[k] = *reinterpret_cast<const f32x4b*>(pk);
+              c1[k] = *reinterpret_cast<const f32x4b*>(pk + 4);
+            }
+          }
+        }
+        // deformable_im2col_bilinear (:110-112): w1 v1 + w2 v2 + w3 v3 + w4 v4, in that order
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          o0[j] = w4[0] * c0[0][j] + w4[1] * c0[1][j] + w4[2] * c0[2][j] + w4[3] * c0[3][j];
+          o1[j] = w4[0] * c1[0][j] + w4[1] * c1[1][j] + w4[2] * c1[2][j] + w4[3] * c1[3][j];
+        }
+      }
+      float* cp = s_col + (tl * kFPos + pos) * kFWColRow + q * 8;
+      *reinterpret_cast<f32x4b*>(cp) = o0;
+      *reinterpret_cast<f32x4b*>(cp + 4) = o1;
+    }
+    __syncthreads();
+    BWD_T(t3);
+    // ---- gradW tiles += gradOutput^T . columns over the 32 positions, two positions per MFMA
+    if (mwave) {
+      const float* a_base = s_go + (lane >> 5) * gop + wave * 32 + (lane & 31);
+      const float* b_base = s_col + (lane >> 5) * kFWColRow + (lane & 31);
+      // the seven operand values of k-step ks + 1 are requested before the six MFMAs of k-step ks (order pinned: left alone,
+      // hipcc reads each pair right in front of its MFMAs and waits out the LDS round trip three times per k-step)
+      float A[2], Bv[2][6];
+      auto fetch = [&](int ks, float& a, float (&bv)[6]) {
+        a = a_base[2 * ks * gop];
+#pragma unroll
+        for (int tl = 0; tl < 3; tl++)
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++) bv[tl * 2 + ct] = b_base[(tl * kFPos + 2 * ks) * kFWColRow + ct * 32];
+      };
+      fetch(0, A[0], Bv[0]);
+#pragma unroll
+      for (int ks = 0; ks < kFPos / 2; ks++) {
+        if (ks + 1 < kFPos / 2) fetch(ks + 1, A[(ks + 1) & 1], Bv[(ks + 1) & 1]);
+        if (ks < kPieces && !(S2A_BWD_ABL & 128)) issue_piece(tile + ksplit, ks);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tl = 0; tl < 3; tl++)
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++)
+            if (!(S2A_BWD_ABL & 32)) acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[ks & 1], Bv[ks & 1][tl * 2 + ct], acc[tl][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (!(S2A_BWD_ABL & 128)) {            // (fewer out-channel tiles than waves: the idle waves still carry their share)
+#pragma unroll
+      for (int i = 0; i < kPieces; i++) issue_piece(tile + ksplit, i);
+    }
+#ifdef S2A_MEASURE
+    const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+    c_bar += t1 - t0; c_land += t2 - t1; c_blend += t3 - t2; c_mma += t4 - t3; c_tiles++;
+#endif
+  }
+#ifdef S2A_MEASURE
+  if (tid == 0) {
+    atomicAdd(&g_bwd_dbg[0], c_land); atomicAdd(&g_bwd_dbg[1], c_blend); atomicAdd(&g_bwd_dbg[2], c_mma); atomicAdd(&g_bwd_dbg[3], c_bar);
+    atomicAdd(&g_bwd_dbg[4], c_tiles); atomicAdd(&g_bwd_dbg[5], 1ull); atomicAdd(&g_bwd_dbg[6], __builtin_amdgcn_s_memtime() - t_begin);
+  }
+#endif
+  // ---- results: rows = out channels (4 consecutive per register quad), columns = channels of the chunk
+  if (mwave) {
+#pragma unroll
+    for (int tl = 0; tl < 3; tl++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int o = wave * 32 + 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5), c = cc * 64 + ct * 32 + (lane & 31);
+          const float v = acc[tl][ct][r];
+          if (v != 0.f) atomicAdd(grad_w + ((int64_t)o * C + c) * 9 + ky * 3 + tl, scale * v);
+        }
+  }
+}
+
 int make_geom(const s2a_dcn_params* pp, BwdGeom* g, const char* who) {
   S2A_CHECK_ARG(pp != nullptr, "%s: NULL params", who);
   const s2a_dcn_params& p = *pp;
@@ -1160,7 +1425,26 @@ int make_geom(const s2a_dcn_params* pp, BwdGeom* g, const char* who) {
 inline unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 1 << 20); }
 
 }  // namespace
+
+int build_flags_dcn_bwd() {
+  int f = S2A_BWD_ABL ? 1 : 0;
+#ifdef S2A_MEASURE
+  f |= 2;
+#endif
+  return f;
+}
 }  // namespace s2a
+
+#ifdef S2A_MEASURE
+// measurement builds: the phase cycles of k_dcn_bwd_weight_f32 (wave 0 of every workgroup, summed) since the last call
+extern "C" int s2a_debug_bwd_stamps(unsigned long long* host_dst) {
+  S2A_HIP(hipDeviceSynchronize());
+  S2A_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(s2a::g_bwd_dbg), sizeof(unsigned long long) * 8));
+  unsigned long long z[8] = {};
+  S2A_HIP(hipMemcpyToSymbol(HIP_SYMBOL(s2a::g_bwd_dbg), z, sizeof(z)));
+  return S2A_OK;
+}
+#endif
 
 using namespace s2a;
 
@@ -1308,9 +1592,14 @@ extern "C" int s2a_deform_conv_backward_input_f32(const float* input, const floa
   const int64_t tiles = batch * ((height + kFTH - 1) / kFTH) * ((width + kFTW - 1) / kFTW);
   S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_input_f32: too many tiles");
   const int lds = bwd_f32_lds_bytes((int)out_channels);
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  k_dcn_bwd_input_f32<<<(unsigned)tiles, 512, lds, st>>>(xn, gn, offset, wp, grad_input, grad_offset, (int)batch, (int)channels,
-                                                        (int)height, (int)width, (int)out_channels);
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  if (out_channels % 128 == 0)
+    k_dcn_bwd_input_f32<true><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, offset, wp, grad_input, grad_offset, (int)batch, (int)channels,
+                                                                (int)height, (int)width, (int)out_channels);
+  else
+    k_dcn_bwd_input_f32<false><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, offset, wp, grad_input, grad_offset, (int)batch, (int)channels,
+                                                                 (int)height, (int)width, (int)out_channels);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -1363,6 +1652,55 @@ extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   k_dcn_bwd_weight<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, (const _Float16*)offset, grad_weight_f32, (int)batch,
                                                                (int)channels, (int)height, (int)width, (int)out_channels, ksplit);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+// The same for f32 tensors (k_dcn_bwd_weight_f32): grad_weight [O,C,3,3] f32 is the caller's gradWeight, ACCUMULATED in place
+// with `scale` applied (gradWeight += scale * gradOutput x columns^T).  workspace: NHWC copies of input and gradOutput.
+extern "C" size_t s2a_deform_conv_backward_weight_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
+                                                                      int64_t width, int64_t out_channels) {
+  return align_up((size_t)(batch * height * width * channels) * 4) + align_up((size_t)(batch * height * width * out_channels) * 4) + 1024;
+}
+
+extern "C" int s2a_deform_conv_backward_weight_f32(const float* input, const float* offset, const float* grad_output,
+                                                   float* grad_weight, float scale, int64_t batch, int64_t channels,
+                                                   int64_t height, int64_t width, int64_t out_channels, void* workspace,
+                                                   size_t workspace_bytes, s2a_stream_t stream) {
+  S2A_CHECK_ARG(batch >= 0 && channels > 0 && height >= 3 && width >= 3 && out_channels > 0, "deform_conv_backward_weight_f32: bad shape");
+  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 32 == 0 && out_channels <= 256,
+                "deform_conv_backward_weight_f32: needs channels %% 64 == 0, out_channels %% 32 == 0, out_channels <= 256");
+  S2A_CHECK_ARG(height < (1 << 15) && width < (1 << 15), "deform_conv_backward_weight_f32: shape too large");
+  if (batch == 0) return S2A_OK;
+  S2A_CHECK_ARG(input && offset && grad_output && grad_weight, "deform_conv_backward_weight_f32: NULL tensor");
+  S2A_CHECK_ARG(workspace_bytes >= s2a_deform_conv_backward_weight_f32_workspace_bytes(batch, channels, height, width, out_channels),
+                "deform_conv_backward_weight_f32: workspace too small");
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace, workspace_bytes);
+  const int64_t HW = height * width;
+  float* xn = cv.take<float>((size_t)(batch * HW * channels));
+  float* gn = cv.take<float>((size_t)(batch * HW * out_channels));
+  S2A_CHECK_ARG(xn && gn, "deform_conv_backward_weight_f32: workspace too small");
+  k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+      input, (int)channels, HW, xn);
+  k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
+      grad_output, (int)out_channels, HW, gn);
+  const int64_t tiles = batch * ((height + kFTH - 1) / kFTH) * ((width + kFTW - 1) / kFTW);
+  S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_weight_f32: too many tiles");
+  const int owners = 3 * (int)(channels / 64);
+  int n_cu = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    S2A_HIP(hipGetDevice(&dev));
+    S2A_HIP(hipGetDeviceProperties(&prop, dev));
+    if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+  }
+  const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, n_cu / owners));
+  const int lds = wgrad_f32_lds_bytes((int)out_channels);
+  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  k_dcn_bwd_weight_f32<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, offset, grad_weight, scale, (int)batch, (int)channels,
+                                                                   (int)height, (int)width, (int)out_channels, ksplit);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

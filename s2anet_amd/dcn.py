@@ -247,7 +247,8 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
 def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH,
                                          padW, padH, dilationW, dilationH, group, deformable_group, scale,
                                          im2col_step):
-    """models/dcn/src/deform_conv_cuda.cpp:376-489, same positional signature.  Per chunk:
+    """models/dcn/src/deform_conv_cuda.cpp:376-489, same positional signature.  AlignConv geometry (3x3, stride 1, pad 1,
+    one group, C % 64 == 0, O % 32 == 0, O <= 256): one fused kernel per call, f32 or f16, no `columns`.  Otherwise, per chunk:
     columns = s2a_deformable_im2col(input, offset), gradWeight += scale * gradOutput x columns^T (library
     GEMM, the reference's addmm_ :455-459).  gradWeight is accumulated in place.  Returns 1."""
     x, off, go, (B, C, H, W, O, Ho, Wo), params = _bwd_common(
@@ -267,6 +268,22 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
             _lib.check(L.s2a_deform_conv_backward_weight_f16(_lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(acc), B, C, H, W, O,
                                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
         gradWeight.add_((float(scale) * acc).view_as(gradWeight).to(gradWeight.dtype))
+        return 1
+    # f32 + AlignConv geometry: the same dataflow on v_mfma_f32_32x32x2_f32 (s2a_deform_conv_backward_weight_f32), scaled and
+    # accumulated straight into the caller's gradWeight when it is an f32 contiguous tensor
+    fused32 = (x.dtype == torch.float32 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)
+               and group == 1 and deformable_group == 1 and C % 64 == 0 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3
+               and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
+    if fused32:
+        direct = (gradWeight.dtype == torch.float32 and gradWeight.is_contiguous() and gradWeight.numel() == O * C * 9
+                  and gradWeight.device == x.device)
+        acc = gradWeight if direct else torch.zeros((O, C, 3, 3), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(L.s2a_deform_conv_backward_weight_f32_workspace_bytes(B, C, H, W, O), x.device, "dcn_bwd")
+        with torch.cuda.device(x.device):
+            _lib.check(L.s2a_deform_conv_backward_weight_f32(_lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(acc), float(scale),
+                                                             B, C, H, W, O, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
+        if not direct:
+            gradWeight.add_(acc.view_as(gradWeight).to(gradWeight.dtype))
         return 1
     step = _cache_step(step, C * kH * kW * Ho * Wo * x.element_size())
     npos, p = step * Ho * Wo, params(step)

@@ -1,0 +1,7 @@
+#!/bin/bash
+# phase stamps of the fused f32 weight-gradient kernel: measurement build, restored on exit
+cd $GRAFT_REPO_ROOT
+export S2A_ALLOW_MEASURE_BUILD=1
+trap 'rm -f s2anet_amd/csrc/dcn_bwd_ops.o; make -C s2anet_amd/csrc -s' EXIT
+rm -f s2anet_amd/csrc/dcn_bwd_ops.o; make -C s2anet_amd/csrc -s EXTRA="-DS2A_MEASURE $1" 2>&1 | grep error
+timeout -k 10 200 python scripts/bwd32_stamps.py

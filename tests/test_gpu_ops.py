@@ -1840,6 +1840,32 @@ def test_dcn_backward_weight_fused_f16_vs_oracle(rng, monkeypatch):
         assert np.abs(gw).max() > 1.0
 
 
+def test_dcn_backward_weight_fused_f32_vs_oracle(rng, monkeypatch):
+    """the fused f32 weight gradient (s2a_deform_conv_backward_weight_f32: columns formed in LDS, contracted over the
+    positions on v_mfma_f32_32x32x2_f32, split-K atomics straight into the caller's gradWeight, scaled) against the oracle
+    (deform_conv_cuda.cpp:376-489 restated) within the north_star's 1e-4 and against the unfused path: tame and wild
+    offsets, ragged images, one and two channel chunks, fewer out channels than waves, scale, a non-zero gradWeight"""
+    from s2anet_amd.dcn import deform_conv_backward_parameters_cuda
+    for (B, C, H, W, O, amp, scale) in ((2, 64, 19, 45, 32, 0.7, 1.0), (1, 128, 9, 20, 64, 5.0, 0.5), (3, 64, 8, 16, 256, 2.0, 1.0)):
+        xn = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        on = (rng.standard_normal((B, 18, H, W)) * amp).astype(np.float32)
+        gn = (rng.standard_normal((B, O, H, W)) * 0.5).astype(np.float32)
+        base = rng.standard_normal((O, C, 3, 3)).astype(np.float32)
+        _, _, gw = oracle.deform_conv_backward(xn, on, np.zeros((O, C, 3, 3), np.float32), gn)
+        gw = gw * scale
+        for mode in ("fused", "unfused"):
+            if mode == "unfused":
+                monkeypatch.setenv("S2A_DCN_BWD_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("S2A_DCN_BWD_UNFUSED", raising=False)
+            gwt = cu(base).clone()
+            assert deform_conv_backward_parameters_cuda(cu(xn), cu(on), cu(gn), gwt, None, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1,
+                                                        scale, B) == 1
+            err = np.abs(gwt.cpu().numpy() - base - gw).max()
+            assert err < 1e-4 * max(1.0, np.abs(gw).max()), (mode, (B, C, H, W, O), err, np.abs(gw).max())
+        assert np.abs(gw).max() > 1.0
+
+
 def test_assign_labels_fused(rng):
     """fused label assignment == the reference's assign_labels (golden from its own Python on its CPU IoU op;
     the two sort branches of the IoU agree on these inputs) and == the oracle on fresh inputs"""
