@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -247,6 +248,9 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
 // S2A_BWD_ABL: timing-only ablations of k_dcn_bwd_input (never set in a shipped build): 1 = no global atomics of the gathered
 // input gradient, 2 = no gather pass at all, 4 = no offset-gradient pass, 8 = no MFMA jobs, 16 = no list building
 // (bits 1 / 2 / 4 / 8 act on k_dcn_bwd_input_f32 too; k_dcn_bwd_weight_f32: 32 = no MFMAs, 64 = no blend, 128 = no tile loads)
+#ifndef S2A_BWD_PRIO1
+#define S2A_BWD_PRIO1 0
+#endif
 #ifndef S2A_BWD_ABL
 #define S2A_BWD_ABL 0
 #endif
@@ -1151,46 +1155,272 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
 }
 
 // ================================================================= fused weight gradient (f32, AlignConv geometry)
-// k_dcn_bwd_weight's dataflow for float32 tensors on v_mfma_f32_32x32x2_f32.  With f32 operands nothing has to be transposed:
-// the contraction index (the position) is the ROW of both LDS images, and an f32 MFMA operand is one value per lane -- lane
-// (l & 31, l >> 5) reads element l & 31 of row 2 ks + (l >> 5): 32 consecutive floats per half wave, the two rows a pitch
-// apart that is 32 (mod 64) floats, so the 64 lanes cover the 64 banks.  A workgroup owns ONE 64-channel chunk and ONE row of
-// three taps and a slice of the 4 x 8 position tiles (12 owners x 21 slices = 252 workgroups); wave w owns out channels
-// 32 w .. 32 w + 31, 3 x 2 accumulator tiles of 32 x 32 in registers over all its tiles, written once by f32 atomics
-// (scaled: gradWeight += scale * ..., deform_conv_cuda.cpp:455-459).  Per tile 16 k-steps x 6 MFMAs of 64 cycles per wave.
+// k_dcn_bwd_weight's dataflow for float32 tensors on v_mfma_f32_32x32x2_f32 (64 FLOP / clk / SIMD; the 155 GFLOP of a P3 x 8
+// call are 0.99 ms at the 2.4 GHz peak, 1.2 ms at the ~1.95 GHz the chip holds under this kernel).  With f32 operands nothing
+// has to be transposed: the contraction index (the position) is the ROW of the column tiles in LDS, and an f32 MFMA operand
+// is one value per lane -- lane (l & 31, l >> 5) reads element l & 31 of row 2 ks + (l >> 5): 32 consecutive floats per half
+// wave, the two rows a pitch apart that is 32 (mod 64) floats, so the 64 lanes cover the 64 banks.
+// A workgroup owns ONE 64-channel chunk and ONE row of three taps and a slice of the 4 x 8 position tiles (12 owners x 21
+// slices = 252 workgroups); its 3 x [O x 64] f32 results stay in registers over all its tiles and go out once, as scaled
+// f32 atomics (gradWeight += scale * ..., deform_conv_cuda.cpp:455-459).  Twelve waves in two roles:
+//   * waves 0-7 (two per SIMD) own out channels 32 w .. 32 w + 31 and only run MFMAs: 16 k-steps x 6 MFMAs per tile, the
+//     column operand from LDS (requested one k-step ahead), the gradOutput operand straight from memory -- in NHWC a half
+//     wave's 32 out channels of one position are 128 contiguous bytes, and a wave needs just 16 values per lane and tile,
+//     so the whole next tile's operand is requested between this tile's MFMAs and waits in registers (no LDS copy of
+//     gradOutput at all; every element is loaded once per workgroup);
+//   * waves 8-11 (one per SIMD) prepare the NEXT tile under them: input patch -> LDS (requested a tile ahead into registers),
+//     sampling table, the three taps' column tiles blended into the other half of a double buffer.
+// The first form of this kernel did everything with eight waves in sequence (load, blend, MFMA): 19.6 k cycles per tile for
+// 12.3 k of MFMA -- the 80 KB a tile needs pass the CU's load path at ~32 B/clk (2.5 k cycles) whether they are requested in
+// one burst or between the MFMAs of the same waves (a wave whose load waits for a queue slot issues no MFMA either).
+// Two workgroup barriers per tile: B1 (buffers swap) and B2 in the middle of the MFMA phase, which separates the loaders'
+// patch / table writes from their blend; the MFMA waves always arrive last, so only loaders wait.
+constexpr int kFWColRow = 96;                  // floats per position of a column tile: 64 channels + 32
+constexpr int kFWPatRow = 68;                  // floats per window pixel: 64 channels + 4
+constexpr int kFWThreads = 768, kFWLoaders = 256;
+constexpr int kFWColBuf = 3 * kFPos * kFWColRow;              // floats per column buffer
+__host__ __device__ constexpr int wgrad_f32_lds_bytes() {
+  return kFPix * kFWPatRow * 4 + 2 * kFWColBuf * 4 + 3 * kFPos * 16 + 3 * kFPos * 8 + 64;
+}
 #ifdef S2A_MEASURE
-__device__ unsigned long long g_bwd_dbg[8];    // [0..3] cycles of land+table / blend / MFMA / loop-top barrier, [4] tiles, [5] workgroups, [6] whole kernel
+__device__ unsigned long long g_bwd_dbg[16];    // cycles: [0] MFMA halves, [1] B1 wait, [2] B2 wait (wave 0); [3] land + table, [7] blend + requests (wave 8); [4] tiles, [5] workgroups, [6] kernel
 #define BWD_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #else
 #define BWD_T(v)
 #endif
-constexpr int kFWColRow = 96;                  // floats per position of a column tile: 64 channels + 32
-constexpr int kFWPatRow = 68;                  // floats per window pixel: 64 channels + 4
-__host__ __device__ constexpr int wgrad_f32_go_pitch(int O) { return O + ((32 - (O & 63)) & 63); }
-__host__ __device__ constexpr int wgrad_f32_lds_bytes(int O) {
-  return kFPos * wgrad_f32_go_pitch(O) * 4 + kFPix * kFWPatRow * 4 + 3 * kFPos * kFWColRow * 4 + 3 * kFPos * 16 + 3 * kFPos * 8 + 64;
-}
 
-__global__ __launch_bounds__(512) void k_dcn_bwd_weight_f32(const float* __restrict__ x,        // NHWC [S,H,W,C]
-                                                           const float* __restrict__ go,       // NHWC [S,H,W,O]
-                                                           const float* __restrict__ offset,   // NCHW [S,18,H,W]
-                                                           float* __restrict__ grad_w,         // [O][C][9], accumulated
-                                                           float scale, int S, int C, int H, int W, int O, int ksplit) {
+__global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* __restrict__ x,        // NHWC [S,H,W,C]
+                                                                  const float* __restrict__ go,       // NHWC [S,H,W,O]
+                                                                  const float* __restrict__ offset,   // NCHW [S,18,H,W]
+                                                                  float* __restrict__ grad_w,         // [O][C][9], accumulated
+                                                                  float scale, int S, int C, int H, int W, int O, int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int gop = wgrad_f32_go_pitch(O);
-  float* s_go = reinterpret_cast<float*>(smem);                              // [32][gop]
-  float* s_patch = s_go + kFPos * gop;                                       // [192][kFWPatRow]
-  float* s_col = s_patch + kFPix * kFWPatRow;                                // [3][32][kFWColRow]
-  f32x4b* s_w = reinterpret_cast<f32x4b*>(s_col + 3 * kFPos * kFWColRow);    // [3 * 32] corner weights
+  float* s_patch = reinterpret_cast<float*>(smem);                           // [192][kFWPatRow]
+  float* s_col = s_patch + kFPix * kFWPatRow;                                // [2][3][32][kFWColRow]
+  f32x4b* s_w = reinterpret_cast<f32x4b*>(s_col + 2 * kFWColBuf);            // [3 * 32] corner weights
   FTap* s_tab = reinterpret_cast<FTap*>(s_w + 3 * kFPos);                    // [3 * 32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= 8;
+  const int ltid = tid - 512;                                                // loaders: 0 .. 255
   const int CC = C / 64;
-  const int owner = blockIdx.x % (3 * CC), slice = blockIdx.x / (3 * CC);
+  // workgroups are dealt to the eight XCDs round-robin (blockIdx % 8), each with its own L2: the twelve owners of a slice walk the
+  // same tiles at the same pace (one gradOutput tile, four input patches between them), so they are numbered to sit on ONE XCD
+  // -- logical index = XCD * (grid / 8) + blockIdx / 8 (the grid is a multiple of 8; indices past the last workgroup leave)
+  const int logical = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  if (logical >= 3 * CC * ksplit) return;
+  const int owner = logical % (3 * CC), slice = logical / (3 * CC);
   const int cc = owner / 3, ky = owner % 3;
   const int txn = (W + kFTW - 1) / kFTW, tyn = (H + kFTH - 1) / kFTH;
   const int ntiles = S * tyn * txn;
+  const int nt = slice < ntiles ? (ntiles - slice + ksplit - 1) / ksplit : 0;     // tiles of this workgroup: slice + j * ksplit
   const int64_t HW = (int64_t)H * W;
-  const bool mwave = wave < O / 32;                                          // wave w owns out-channel tile w (O <= 256)
+  const bool mwave = wave < O / 32;                                          // MFMA wave w owns out-channel tile w (O <= 256)
+  auto tile_geom = [&](int j, int& b, int& ty0, int& tx0) {                  // (past the end: the last tile again -- harmless reads)
+    const int tile = slice + min(j, nt - 1) * ksplit;
+    tx0 = (tile % txn) * kFTW;
+    const int r = tile / txn;
+    ty0 = (r % tyn) * kFTH;
+    b = r / tyn;
+  };
+#ifdef S2A_MEASURE
+  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c7 = 0, c8 = 0, c9 = 0, c10 = 0, c11 = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+  if (nt == 0) return;
+
+  if (loader) {
+    // =========================================================== loader waves
+    // VALU issue on a SIMD goes by priority, then age: as the youngest of three waves, beside two that always have an MFMA
+    // pending, a loader got ONE vector instruction per MFMA slot (64 cycles: 5.4 k cycles for the twelve stores of a patch)
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int kPaVec = 12;                   // 16-byte vectors per thread: 192 pixels x 16 / 256
+    f32x4b pvv[kPaVec];
+    unsigned okm = 0u;
+    float off_yx[2] = {0.f, 0.f};
+    // branch-free requests: an element outside the image loads from a clamped address and is zeroed when it lands
+    // vector i of a thread = window row i, pixel ltid >> 4 of that row, channels 4 (ltid & 15) ..: the column part of the address is
+    // per tile, the row part one multiply-add per request (issue slots are what a loader is short of beside two MFMA streams)
+    static_assert(kFPW == 16 && kFPH == kPaVec && kFWLoaders == 256, "loader geometry");
+    const int lpx = ltid >> 4, lq = ltid & 15;
+    auto request = [&](int j) {
+      int b, ty0, tx0;
+      tile_geom(j, b, ty0, tx0);
+      const int oy = ty0 - 3, xx = tx0 - 3 + lpx;
+      const bool okx = xx >= 0 && xx < W;
+      const float* colp = x + ((int64_t)b * HW + min(max(xx, 0), W - 1)) * C + cc * 64 + lq * 4;
+      const int64_t rowpitch = (int64_t)W * C;
+      okm = 0u;
+#pragma unroll
+      for (int i = 0; i < kPaVec; i++) {
+        const int yy = oy + i;
+        pvv[i] = *reinterpret_cast<const f32x4b*>(colp + min(max(yy, 0), H - 1) * rowpitch);
+        okm |= ((okx && yy >= 0 && yy < H) ? 1u : 0u) << i;
+      }
+      const int e = min(ltid, 3 * kFPos - 1), tl = e / kFPos, pos = e % kFPos, t = ky * 3 + tl;
+      const int y = min(ty0 + (pos >> 3), H - 1), xq = min(tx0 + (pos & 7), W - 1);
+      const float* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
+      off_yx[0] = ob[(int64_t)(2 * t) * HW];
+      off_yx[1] = ob[(int64_t)(2 * t + 1) * HW];
+    };
+    request(0);
+    for (int j = 0; j <= nt; j++) {
+      int b, ty0, tx0;
+      tile_geom(j, b, ty0, tx0);
+      const int oy = ty0 - 3, ox = tx0 - 3;
+      __syncthreads();                           // B1: the blend of tile j - 1 has read the patch and the table
+      BWD_T(t1);
+#ifdef S2A_MEASURE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t1a = __builtin_amdgcn_s_memtime();
+      unsigned long long t1b = t1a;
+#endif
+      if (j < nt) {
+        float* pw = s_patch + lpx * kFWPatRow + lq * 4;            // row i: + i * 16 pixels
+        if (okm == (1u << kPaVec) - 1u) {
+#pragma unroll
+          for (int i = 0; i < kPaVec; i++) *reinterpret_cast<f32x4b*>(pw + i * kFPW * kFWPatRow) = pvv[i];
+        } else {
+          const f32x4b zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < kPaVec; i++) *reinterpret_cast<f32x4b*>(pw + i * kFPW * kFWPatRow) = ((okm >> i) & 1u) ? pvv[i] : zero;
+        }
+#ifdef S2A_MEASURE
+        t1b = __builtin_amdgcn_s_memtime();
+#endif
+        if (ltid < 3 * kFPos) {                  // sampling table of this tile's three taps
+          const int tl = ltid / kFPos, pos = ltid % kFPos;
+          const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
+          FTap tp;
+          tp.y = 0; tp.x = 0; tp.flags = 0u;
+          f32x4b w4 = {0.f, 0.f, 0.f, 0.f};
+          if (y < H && xq < W) {
+            const float h_im = (float)(y - 1 + ky) + off_yx[0], w_im = (float)(xq - 1 + tl) + off_yx[1];
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+              const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+              const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+              const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+              w4[0] = (t_ok && l_ok) ? hh * hw : 0.f;
+              w4[1] = (t_ok && r_ok) ? hh * lw : 0.f;
+              w4[2] = (b_ok && l_ok) ? lh * hw : 0.f;
+              w4[3] = (b_ok && r_ok) ? lh * lw : 0.f;
+              tp.y = (short)h_low;
+              tp.x = (short)w_low;
+              const bool in = h_low >= oy && h_low + 1 <= oy + kFPH - 1 && w_low >= ox && w_low + 1 <= ox + kFPW - 1;
+              const int py = min(max(h_low - oy, 0), kFPH - 2), px = min(max(w_low - ox, 0), kFPW - 2);
+              tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kFPW + px) << 2);
+            }
+          }
+          s_tab[ltid] = tp;
+          s_w[ltid] = w4;
+        }
+      }
+      BWD_T(t2);
+      __syncthreads();                           // B2: patch and table of tile j are in LDS
+      BWD_T(t3);
+      if (j < nt) {
+        if (j + 1 < nt && !(S2A_BWD_ABL & 128)) request(j + 1);        // in flight under the blend and the next tile's first half
+#ifdef S2A_MEASURE
+        c10 += __builtin_amdgcn_s_memtime() - t3;
+#endif
+        // ---- column tiles of the three taps into buffer j & 1: item = (tap, position, 8-channel group)
+        float* colb = s_col + (j & 1) * kFWColBuf;
+        const int pos = ltid >> 3, q = ltid & 7;       // item (tap tl, position, 8-channel group): a thread's three items differ in the tap
+        FTap tp[3];
+        f32x4b w4[3];
+        bool far = false;                              // a valid sample whose corners left the window (wild offsets): global reads
+#pragma unroll
+        for (int tl = 0; tl < 3; tl++) {
+          tp[tl] = s_tab[tl * kFPos + pos];
+          w4[tl] = s_w[tl * kFPos + pos];              // (all zero for an invalid sample)
+          far |= (tp[tl].flags & 3u) == 1u;
+        }
+        if (S2A_BWD_ABL & 64) {
+        } else if (!__any(far)) {
+          // the usual case, branch-free: twenty-four corner reads in flight, then the arithmetic (an invalid sample reads pixel 0
+          // with zero weights)
+          // (taps 0 and 1 together, then tap 2: all three at once spill beside the twelve patch vectors already requested)
+          auto fast = [&](auto T0, auto T1) {
+            constexpr int t0 = decltype(T0)::value, t1 = decltype(T1)::value;
+            f32x4b c0[t1 - t0][4], c1[t1 - t0][4];
+#pragma unroll
+            for (int tl = t0; tl < t1; tl++) {
+              const float* p0 = s_patch + (int)(tp[tl].flags >> 2) * kFWPatRow + q * 8;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const float* pk = p0 + ((k >> 1) * kFPW + (k & 1)) * kFWPatRow;
+                c0[tl - t0][k] = *reinterpret_cast<const f32x4b*>(pk);
+                c1[tl - t0][k] = *reinterpret_cast<const f32x4b*>(pk + 4);
+              }
+            }
+#pragma unroll
+            for (int tl = t0; tl < t1; tl++) {
+              f32x4b o0, o1;
+              // deformable_im2col_bilinear (:110-112): w1 v1 + w2 v2 + w3 v3 + w4 v4, in that order
+#pragma unroll
+              for (int jj = 0; jj < 4; jj++) {
+                o0[jj] = w4[tl][0] * c0[tl - t0][0][jj] + w4[tl][1] * c0[tl - t0][1][jj] + w4[tl][2] * c0[tl - t0][2][jj] + w4[tl][3] * c0[tl - t0][3][jj];
+                o1[jj] = w4[tl][0] * c1[tl - t0][0][jj] + w4[tl][1] * c1[tl - t0][1][jj] + w4[tl][2] * c1[tl - t0][2][jj] + w4[tl][3] * c1[tl - t0][3][jj];
+              }
+              float* cp = colb + (tl * kFPos + pos) * kFWColRow + q * 8;
+              *reinterpret_cast<f32x4b*>(cp) = o0;
+              *reinterpret_cast<f32x4b*>(cp + 4) = o1;
+            }
+          };
+          fast(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+          fast(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+        } else {
+          for (int tl = 0; tl < 3; tl++) {
+            f32x4b o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+            if (tp[tl].flags & 1u) {
+              f32x4b c0[4], c1[4];
+              if (tp[tl].flags & 2u) {
+                const float* p0 = s_patch + (int)(tp[tl].flags >> 2) * kFWPatRow + q * 8;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  const float* pk = p0 + ((k >> 1) * kFPW + (k & 1)) * kFWPatRow;
+                  c0[k] = *reinterpret_cast<const f32x4b*>(pk);
+                  c1[k] = *reinterpret_cast<const f32x4b*>(pk + 4);
+                }
+              } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  const int yy = (int)tp[tl].y + (k >> 1), xx = (int)tp[tl].x + (k & 1);
+                  c0[k] = f32x4b{0.f, 0.f, 0.f, 0.f};
+                  c1[k] = c0[k];
+                  if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float* pk = x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8;
+                    c0[k] = *reinterpret_cast<const f32x4b*>(pk);
+                    c1[k] = *reinterpret_cast<const f32x4b*>(pk + 4);
+                  }
+                }
+              }
+#pragma unroll
+              for (int jj = 0; jj < 4; jj++) {
+                o0[jj] = w4[tl][0] * c0[0][jj] + w4[tl][1] * c0[1][jj] + w4[tl][2] * c0[2][jj] + w4[tl][3] * c0[3][jj];
+                o1[jj] = w4[tl][0] * c1[0][jj] + w4[tl][1] * c1[1][jj] + w4[tl][2] * c1[2][jj] + w4[tl][3] * c1[3][jj];
+              }
+            }
+            float* cp = colb + (tl * kFPos + pos) * kFWColRow + q * 8;
+            *reinterpret_cast<f32x4b*>(cp) = o0;
+            *reinterpret_cast<f32x4b*>(cp + 4) = o1;
+          }
+        }
+      }
+#ifdef S2A_MEASURE
+      const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+      c3 += t2 - t1; c7 += t4 - t3; c8 += t1a - t1; c9 += t1b - t1a;
+#endif
+    }
+#ifdef S2A_MEASURE
+    if (ltid == 0) {
+      atomicAdd(&g_bwd_dbg[3], c3); atomicAdd(&g_bwd_dbg[7], c7); atomicAdd(&g_bwd_dbg[8], c8); atomicAdd(&g_bwd_dbg[9], c9);
+      atomicAdd(&g_bwd_dbg[10], c10);
+    }
+#endif
+    return;
+  }
+
+  // =========================================================== MFMA waves
   f32x16b acc[3][2];
 #pragma unroll
   for (int a = 0; a < 3; a++)
@@ -1198,196 +1428,92 @@ __global__ __launch_bounds__(512) void k_dcn_bwd_weight_f32(const float* __restr
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
-
-  // registers that carry the NEXT tile's gradOutput tile and patch (issued a tile ahead)
-  constexpr int kGoVec = 4, kPaVec = 6;                       // 16-byte vectors per thread: 32 * 64 / 512 (O = 256), 192 * 16 / 512
-  f32x4b gv[kGoVec], pvv[kPaVec];
-  auto tile_geom = [&](int tile, int& b, int& ty0, int& tx0) {
-    tx0 = (tile % txn) * kFTW;
-    const int r = tile / txn;
-    ty0 = (r % tyn) * kFTH;
-    b = r / tyn;
-  };
-  // The next tile's operands are requested in eleven PIECES that ride between the MFMA groups of this tile (a 1 KB request
-  // occupies its wave's instruction stream for ~63 cycles -- the length of one f32 MFMA, which keeps the pipe busy meanwhile;
-  // all ten at the head of the blend cost every wave 0.6 k cycles and the CU's 64 B/clk address path 1.3 k).  Branch-free:
-  // an element outside the image (or past the tile list: the last tile is requested again) loads from a clamped address and
-  // is zeroed when it lands (`okm`), so the MFMA loop has no CFG edge.  Piece 10: the 96 table threads' two offsets.
-  unsigned okm = 0u;
-  float off_yx[2] = {0.f, 0.f};
-  auto issue_piece = [&](int tile, int i) {
+  // gradOutput operand of a whole tile: k-step ks = positions 2 ks, 2 ks + 1; lane (l & 31, l >> 5) holds out channel
+  // 32 w + (l & 31) of position 2 ks + (l >> 5); positions outside the image load from a clamped address and count as zero
+  // Address arithmetic per tile, not per request (these waves' non-MFMA instructions are what opens gaps in the matrix pipe):
+  // position 2 ks + h sits in tile row ks >> 2, tile column 2 (ks & 3) + h -- four row pointers (uniform) and four lane offsets
+  float a_cur[kFPos / 2], a_nxt[kFPos / 2];
+  unsigned ok_cur = 0u, ok_nxt = 0u;
+  const float* a_row[4];
+  int a_col[4];
+  const int a_lane = min(wave, O / 32 - 1) * 32 + (lane & 31), a_h = lane >> 5;
+  auto setup_a = [&](int j, unsigned& okbits) {
     int b, ty0, tx0;
-    tile_geom(min(tile, ntiles - 1), b, ty0, tx0);
-    const int oy = ty0 - 3, ox = tx0 - 3;
-    if (i < kGoVec) {
-      const int ovec = O / 4;
-      const int v = min(tid + 512 * i, kFPos * ovec - 1);
-      const int pos = v / ovec, ch = v % ovec;
-      const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
-      const bool ok = y < H && xq < W;
-      gv[i] = *reinterpret_cast<const f32x4b*>(go + ((int64_t)b * HW + (int64_t)min(y, H - 1) * W + min(xq, W - 1)) * O + ch * 4);
-      okm = (okm & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-    } else if (i < kGoVec + kPaVec) {
-      const int j = i - kGoVec;
-      const int v = tid + 512 * j, p = v >> 4, q = v & 15;
-      const int yy = oy + p / kFPW, xx = ox + p % kFPW;
-      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      pvv[j] = *reinterpret_cast<const f32x4b*>(x + ((int64_t)b * HW + (int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * C + cc * 64 + q * 4);
-      okm = (okm & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-    } else {
-      const int e = min(tid, 3 * kFPos - 1), tl = e / kFPos, pos = e % kFPos, t = ky * 3 + tl;
-      const int y = min(ty0 + (pos >> 3), H - 1), xq = min(tx0 + (pos & 7), W - 1);
-      const float* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
-      off_yx[0] = ob[(int64_t)(2 * t) * HW];
-      off_yx[1] = ob[(int64_t)(2 * t + 1) * HW];
-    }
-  };
-  constexpr int kPieces = kGoVec + kPaVec + 1;
-  auto land = [&]() {
-    const int ovec = O / 4;
-    const f32x4b zero = {0.f, 0.f, 0.f, 0.f};
+    tile_geom(j, b, ty0, tx0);
+    unsigned oky = 0u, okx = 0u;
 #pragma unroll
-    for (int i = 0; i < kGoVec; i++) {
-      const int v = tid + 512 * i;
-      if (v < kFPos * ovec) *reinterpret_cast<f32x4b*>(s_go + (v / ovec) * gop + (v % ovec) * 4) = ((okm >> i) & 1u) ? gv[i] : zero;
+    for (int r = 0; r < 4; r++) {
+      a_row[r] = go + ((int64_t)b * HW + (int64_t)min(ty0 + r, H - 1) * W) * O;
+      oky |= (ty0 + r < H ? 1u : 0u) << r;
+      const int xq = tx0 + 2 * r + a_h;
+      a_col[r] = min(xq, W - 1) * O + a_lane;
+      okx |= (xq < W ? 1u : 0u) << r;
     }
+    okbits = 0u;
 #pragma unroll
-    for (int i = 0; i < kPaVec; i++) {
-      const int v = tid + 512 * i;
-      *reinterpret_cast<f32x4b*>(s_patch + (v >> 4) * kFWPatRow + (v & 15) * 4) = ((okm >> (kGoVec + i)) & 1u) ? pvv[i] : zero;
-    }
+    for (int ks = 0; ks < kFPos / 2; ks++) okbits |= (((oky >> (ks >> 2)) & (okx >> (ks & 3))) & 1u) << ks;
   };
-
-#ifdef S2A_MEASURE
-  unsigned long long c_land = 0, c_blend = 0, c_mma = 0, c_bar = 0, c_tiles = 0;
-  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  setup_a(0, ok_cur);
+#pragma unroll
+  for (int ks = 0; ks < kFPos / 2; ks++) a_cur[ks] = a_row[ks >> 2][a_col[ks & 3]];
+#if S2A_BWD_PRIO1
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the younger MFMA wave of each SIMD loses every arbitration against the older one
 #endif
-  int tile = slice;
-  if (tile < ntiles) {
-#pragma unroll
-    for (int i = 0; i < kPieces; i++) issue_piece(tile, i);
-  }
-  for (; tile < ntiles; tile += ksplit) {
-    int b, ty0, tx0;
-    tile_geom(tile, b, ty0, tx0);
-    const int oy = ty0 - 3, ox = tx0 - 3;
+  const float* b_lane = s_col + (lane >> 5) * kFWColRow + (lane & 31);
+  for (int j = 0; j <= nt; j++) {
     BWD_T(t0);
-    __syncthreads();                             // the previous tile's operands have been read
+    __syncthreads();                             // B1: column buffer (j - 1) & 1 holds tile j - 1
     BWD_T(t1);
-    land();
-    if (tid < 3 * kFPos) {                       // sampling table of this tile's three taps
-      const int tl = tid / kFPos, pos = tid % kFPos, t = ky * 3 + tl;
-      const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
-      FTap tp;
-      tp.y = 0; tp.x = 0; tp.flags = 0u;
-      f32x4b w4 = {0.f, 0.f, 0.f, 0.f};
-      if (y < H && xq < W) {
-        const float off_y = off_yx[0], off_x = off_yx[1];      // (requested a tile ahead, piece 10)
-        const float h_im = (float)(y - 1 + ky) + off_y, w_im = (float)(xq - 1 + tl) + off_x;
-        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
-          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-          const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
-          const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
-          w4[0] = (t_ok && l_ok) ? hh * hw : 0.f;
-          w4[1] = (t_ok && r_ok) ? hh * lw : 0.f;
-          w4[2] = (b_ok && l_ok) ? lh * hw : 0.f;
-          w4[3] = (b_ok && r_ok) ? lh * lw : 0.f;
-          tp.y = (short)h_low;
-          tp.x = (short)w_low;
-          const bool in = h_low >= oy && h_low + 1 <= oy + kFPH - 1 && w_low >= ox && w_low + 1 <= ox + kFPW - 1;
-          const int py = min(max(h_low - oy, 0), kFPH - 2), px = min(max(w_low - ox, 0), kFPW - 2);
-          tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kFPW + px) << 2);
+    const float* b_base = b_lane + ((j - 1) & 1) * kFWColBuf;
+    // the seven operand values of k-step ks + 1 are requested before the six MFMAs of k-step ks (order pinned: left alone,
+    // hipcc reads each pair right in front of its MFMAs and waits out the LDS round trip three times per k-step)
+    float Bv[2][6];
+    auto fetch = [&](int ks, float (&bv)[6]) {
+#pragma unroll
+      for (int tl = 0; tl < 3; tl++)
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) bv[tl * 2 + ct] = b_base[(tl * kFPos + 2 * ks) * kFWColRow + ct * 32];
+    };
+    auto half = [&](int h) {
+#pragma unroll
+      for (int ks = 8 * h; ks < 8 * h + 8; ks++) {
+        if (ks + 1 < kFPos / 2) fetch(ks + 1, Bv[(ks + 1) & 1]);
+        // the next tile's operand: two values per k-step of the FIRST half -- the registers are handed over at the end of the tile,
+        // and a request made in the last k-steps would have its whole memory latency waited out there (vmcnt counts in order)
+        if (!(S2A_BWD_ABL & 128) && ks < kFPos / 4) {
+          a_nxt[2 * ks] = a_row[(2 * ks) >> 2][a_col[(2 * ks) & 3]];
+          a_nxt[2 * ks + 1] = a_row[(2 * ks + 1) >> 2][a_col[(2 * ks + 1) & 3]];
         }
-      }
-      s_tab[tid] = tp;
-      s_w[tid] = w4;
-    }
-    __syncthreads();
-    BWD_T(t2);
-    // ---- column tiles of the three taps: item = (tap, position, 8-channel group)
-    for (int it = tid; it < ((S2A_BWD_ABL & 64) ? 0 : 3 * kFPos * 8); it += 512) {
-      const int tl = it >> 8, r = it & 255, pos = r >> 3, q = r & 7;
-      const FTap tp = s_tab[tl * kFPos + pos];
-      f32x4b o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
-      if (tp.flags & 1u) {
-        const f32x4b w4 = s_w[tl * kFPos + pos];
-        f32x4b c0[4], c1[4];
-        if (tp.flags & 2u) {
-          const float* p0 = s_patch + (int)(tp.flags >> 2) * kFWPatRow + q * 8;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float* pk = p0 + ((k >> 1) * kFPW + (k & 1)) * kFWPatRow;
-            c0[k] = *reinterpret_cast<const f32x4b*>(pk);
-            c1[k] = *reinterpret_cast<const f32x4b*>(pk + 4);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const int yy = (int)tp.y + (k >> 1), xx = (int)tp.x + (k & 1);
-            c0[k] = f32x4b{0.f, 0.f, 0.f, 0.f};
-            c1[k] = c0[k];
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-              const float* pk = x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8;
-              c0[k] = *reinterpret_cast<const f32x4b*>(pk);
-              c1[k] = *reinterpret_cast<const f32x4b*>(pk + 4);
-            }
-          }
-        }
-        // deformable_im2col_bilinear (:110-112): w1 v1 + w2 v2 + w3 v3 + w4 v4, in that order
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          o0[j] = w4[0] * c0[0][j] + w4[1] * c0[1][j] + w4[2] * c0[2][j] + w4[3] * c0[3][j];
-          o1[j] = w4[0] * c1[0][j] + w4[1] * c1[1][j] + w4[2] * c1[2][j] + w4[3] * c1[3][j];
-        }
-      }
-      float* cp = s_col + (tl * kFPos + pos) * kFWColRow + q * 8;
-      *reinterpret_cast<f32x4b*>(cp) = o0;
-      *reinterpret_cast<f32x4b*>(cp + 4) = o1;
-    }
-    __syncthreads();
-    BWD_T(t3);
-    // ---- gradW tiles += gradOutput^T . columns over the 32 positions, two positions per MFMA
-    if (mwave) {
-      const float* a_base = s_go + (lane >> 5) * gop + wave * 32 + (lane & 31);
-      const float* b_base = s_col + (lane >> 5) * kFWColRow + (lane & 31);
-      // the seven operand values of k-step ks + 1 are requested before the six MFMAs of k-step ks (order pinned: left alone,
-      // hipcc reads each pair right in front of its MFMAs and waits out the LDS round trip three times per k-step)
-      float A[2], Bv[2][6];
-      auto fetch = [&](int ks, float& a, float (&bv)[6]) {
-        a = a_base[2 * ks * gop];
-#pragma unroll
-        for (int tl = 0; tl < 3; tl++)
-#pragma unroll
-          for (int ct = 0; ct < 2; ct++) bv[tl * 2 + ct] = b_base[(tl * kFPos + 2 * ks) * kFWColRow + ct * 32];
-      };
-      fetch(0, A[0], Bv[0]);
-#pragma unroll
-      for (int ks = 0; ks < kFPos / 2; ks++) {
-        if (ks + 1 < kFPos / 2) fetch(ks + 1, A[(ks + 1) & 1], Bv[(ks + 1) & 1]);
-        if (ks < kPieces && !(S2A_BWD_ABL & 128)) issue_piece(tile + ksplit, ks);
         __builtin_amdgcn_sched_barrier(0);
+        const float A = ((ok_cur >> ks) & 1u) ? a_cur[ks] : 0.f;
 #pragma unroll
         for (int tl = 0; tl < 3; tl++)
 #pragma unroll
           for (int ct = 0; ct < 2; ct++)
-            if (!(S2A_BWD_ABL & 32)) acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[ks & 1], Bv[ks & 1][tl * 2 + ct], acc[tl][ct], 0, 0, 0);
+            if (!(S2A_BWD_ABL & 32)) acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, Bv[ks & 1][tl * 2 + ct], acc[tl][ct], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else if (!(S2A_BWD_ABL & 128)) {            // (fewer out-channel tiles than waves: the idle waves still carry their share)
+    };
+    const bool work = j >= 1 && mwave;
+    if (work) {
+      fetch(0, Bv[0]);
+      setup_a(j, ok_nxt);
+      half(0);
+    }
+    BWD_T(t2);
+    __syncthreads();                             // B2 (the loaders' patch / table hand-over; nothing of this role depends on it)
+    BWD_T(t3);
+    if (work) {
+      half(1);
 #pragma unroll
-      for (int i = 0; i < kPieces; i++) issue_piece(tile + ksplit, i);
+      for (int ks = 0; ks < kFPos / 2; ks++) a_cur[ks] = a_nxt[ks];
+      ok_cur = ok_nxt;
     }
 #ifdef S2A_MEASURE
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-    c_bar += t1 - t0; c_land += t2 - t1; c_blend += t3 - t2; c_mma += t4 - t3; c_tiles++;
+    c1 += t1 - t0; c0 += (t2 - t1) + (t4 - t3); c2 += t3 - t2;
 #endif
   }
-#ifdef S2A_MEASURE
-  if (tid == 0) {
-    atomicAdd(&g_bwd_dbg[0], c_land); atomicAdd(&g_bwd_dbg[1], c_blend); atomicAdd(&g_bwd_dbg[2], c_mma); atomicAdd(&g_bwd_dbg[3], c_bar);
-    atomicAdd(&g_bwd_dbg[4], c_tiles); atomicAdd(&g_bwd_dbg[5], 1ull); atomicAdd(&g_bwd_dbg[6], __builtin_amdgcn_s_memtime() - t_begin);
-  }
-#endif
   // ---- results: rows = out channels (4 consecutive per register quad), columns = channels of the chunk
   if (mwave) {
 #pragma unroll
@@ -1401,6 +1527,12 @@ __global__ __launch_bounds__(512) void k_dcn_bwd_weight_f32(const float* __restr
           if (v != 0.f) atomicAdd(grad_w + ((int64_t)o * C + c) * 9 + ky * 3 + tl, scale * v);
         }
   }
+#ifdef S2A_MEASURE
+  if (tid == 0) {
+    atomicAdd(&g_bwd_dbg[0], c0); atomicAdd(&g_bwd_dbg[1], c1); atomicAdd(&g_bwd_dbg[2], c2);
+    atomicAdd(&g_bwd_dbg[4], (unsigned long long)nt); atomicAdd(&g_bwd_dbg[5], 1ull); atomicAdd(&g_bwd_dbg[6], __builtin_amdgcn_s_memtime() - t_begin);
+  }
+#endif
 }
 
 int make_geom(const s2a_dcn_params* pp, BwdGeom* g, const char* who) {
@@ -1439,8 +1571,8 @@ int build_flags_dcn_bwd() {
 // measurement builds: the phase cycles of k_dcn_bwd_weight_f32 (wave 0 of every workgroup, summed) since the last call
 extern "C" int s2a_debug_bwd_stamps(unsigned long long* host_dst) {
   S2A_HIP(hipDeviceSynchronize());
-  S2A_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(s2a::g_bwd_dbg), sizeof(unsigned long long) * 8));
-  unsigned long long z[8] = {};
+  S2A_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(s2a::g_bwd_dbg), sizeof(unsigned long long) * 16));
+  unsigned long long z[16] = {};
   S2A_HIP(hipMemcpyToSymbol(HIP_SYMBOL(s2a::g_bwd_dbg), z, sizeof(z)));
   return S2A_OK;
 }
@@ -1697,9 +1829,9 @@ extern "C" int s2a_deform_conv_backward_weight_f32(const float* input, const flo
     if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
   }
   const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, n_cu / owners));
-  const int lds = wgrad_f32_lds_bytes((int)out_channels);
+  const int lds = wgrad_f32_lds_bytes();
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  k_dcn_bwd_weight_f32<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, offset, grad_weight, scale, (int)batch, (int)channels,
+  k_dcn_bwd_weight_f32<<<(unsigned)((owners * ksplit + 7) / 8 * 8), kFWThreads, lds, st>>>(xn, gn, offset, grad_weight, scale, (int)batch, (int)channels,
                                                                    (int)height, (int)width, (int)out_channels, ksplit);
   S2A_LAUNCH_CHECK();
   return S2A_OK;

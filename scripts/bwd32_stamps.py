@@ -15,7 +15,7 @@ go = torch.randn(B, O, H, W, generator=g).to(dev)
 gw = torch.zeros(O, C, 3, 3, device=dev)
 args = (3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
 L = ctypes.CDLL(_lib.LIB_PATH)
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 for _ in range(3):
     deform_conv_backward_parameters_cuda(x, off, go, gw, None, None, *args, 1.0, B)
 torch.cuda.synchronize()
@@ -30,6 +30,9 @@ L.s2a_debug_bwd_stamps(buf)
 v = list(buf)
 tiles, wgs = v[4] / n, v[5] / n
 print("call %.3f ms; %d workgroups, %.1f tiles each" % (ms, wgs, tiles / wgs))
-for name, c in zip(("land+table", "blend", "mfma", "loop-top barrier"), v[:4]):
-    print("  %-18s %8.0f cycles per tile" % (name, c / n / tiles))
-print("  whole kernel %.0f cycles per workgroup -> %.2f GHz if the kernel is %.3f ms" % (v[6] / n / wgs, v[6] / n / wgs / (ms * 1e-3) / 1e9, ms))
+for name, c in (("MFMA halves (wave 0)", v[0]), ("B1 wait (wave 0)", v[1]), ("B2 wait (wave 0)", v[2]),
+                ("land + table (wave 8)", v[3]), ("  of it: wait for the loads", v[8]), ("  of it: land", v[9]),
+                ("blend + requests (wave 8)", v[7]), ("  of it: requests", v[10])):
+    print("  %-26s %8.0f cycles per tile" % (name, c / n / tiles))
+print("  whole kernel %.0f cycles per workgroup = %.0f per tile -> %.2f GHz if the kernel is %.3f ms" % (
+    v[6] / n / wgs, v[6] / n / tiles, v[6] / n / wgs / (ms * 1e-3) / 1e9, ms))
