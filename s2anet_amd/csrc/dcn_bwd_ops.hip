@@ -248,9 +248,6 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
 // S2A_BWD_ABL: timing-only ablations of k_dcn_bwd_input (never set in a shipped build): 1 = no global atomics of the gathered
 // input gradient, 2 = no gather pass at all, 4 = no offset-gradient pass, 8 = no MFMA jobs, 16 = no list building
 // (bits 1 / 2 / 4 / 8 act on k_dcn_bwd_input_f32 too; k_dcn_bwd_weight_f32: 32 = no MFMAs, 64 = no blend, 128 = no tile loads)
-#ifndef S2A_BWD_PRIO1
-#define S2A_BWD_PRIO1 0
-#endif
 #ifndef S2A_BWD_ABL
 #define S2A_BWD_ABL 0
 #endif
@@ -959,6 +956,7 @@ __global__ __launch_bounds__(512) void k_dcn_bwd_input_f32(const float* __restri
 //     in flight in registers), the eight waves blend the three taps' column tiles into LDS (bilinear corners from the patch,
 //     as the forward does), then read both operands with transposing reads: 24 MFMAs per wave and tile.
 constexpr int kWPos = 64;                       // positions per tile (4 x 16)
+constexpr int kWgradMaxBlocks = 320;            // workgroups of a weight-gradient launch (<= CUs of the device): partial-result blocks
 constexpr int kWColRow = 192;                   // bytes per position of a column tile: 64 halfs + pad (pitch = 48 dwords: the four
                                                 // rows of a transposing read fall into four different 16-bank groups)
 constexpr int kWPatchPix = kBPix;               // 12 x 24 window, 128 B per pixel (64 channels)
@@ -971,7 +969,7 @@ using s16x4b = __attribute__((ext_vector_type(4))) short;
 __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __restrict__ x,        // NHWC [S,H,W,C]
                                                           const _Float16* __restrict__ go,       // NHWC [S,H,W,O]
                                                           const _Float16* __restrict__ offset,   // NCHW [S,18,H,W]
-                                                          float* __restrict__ grad_w,            // [O][C][9] f32, accumulated
+                                                          float* __restrict__ partial,           // [slice][owner][O][3 taps][64] f32
                                                           int S, int C, int H, int W, int O, int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int gop = wgrad_go_pitch(O);
@@ -1139,19 +1137,40 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
       }
     }
   }
-  // ---- results: rows = out channels (4 consecutive per register quad), columns = channels of the chunk
+  // ---- results: rows = out channels (4 consecutive per register quad), columns = channels of the chunk; one block per workgroup
   if (mwave) {
+    float* part = partial + (int64_t)blockIdx.x * O * 192;      // (blockIdx = slice * owners + owner)
 #pragma unroll
     for (int tl = 0; tl < 3; tl++)
 #pragma unroll
       for (int ct = 0; ct < 2; ct++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int o = wave * 32 + 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5), c = cc * 64 + ct * 32 + (lane & 31);
-          const float v = acc[tl][ct][r];
-          if (v != 0.f) atomicAdd(grad_w + ((int64_t)o * C + c) * 9 + ky * 3 + tl, v);
+          const int o = wave * 32 + 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5);
+          part[(o * 3 + tl) * 64 + ct * 32 + (lane & 31)] = acc[tl][ct][r];
         }
   }
+}
+
+// gradWeight += scale * (sum over the position slices of the workgroups' partial results).  The fused weight-gradient kernels
+// used to add their 3 x [O x 64] register tiles into gradWeight with f32 atomics: 12.4 M lane atomics per call, 36 bytes apart
+// (nine taps between two channels), 21 slices contending for every address -- 2.3 k cycles per tile of the f32 kernel, ~0.2 ms
+// per call.  Now every workgroup stores its block once, coalesced, and ONE thread per element sums the slices in a fixed order:
+// no atomics, and the gradient is bit-identical from run to run.
+__global__ __launch_bounds__(256) void k_dcn_bwd_weight_reduce(const float* __restrict__ partial, float* __restrict__ grad_w,
+                                                              float scale, int O, int C, int ksplit) {
+  const int64_t block = (int64_t)O * 192;
+  const int owners = 3 * (C / 64);
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= block * owners) return;
+  const int owner = (int)(e / block);
+  const int rem = (int)(e % block);
+  const int o = rem / 192, tl = (rem / 64) % 3, c = rem & 63;
+  const int cc = owner / 3, ky = owner % 3;
+  float sum = 0.f;
+  for (int sl = 0; sl < ksplit; sl++) sum += partial[((int64_t)sl * owners + owner) * block + rem];
+  float* dst = grad_w + ((int64_t)o * C + cc * 64 + c) * 9 + ky * 3 + tl;
+  *dst += scale * sum;
 }
 
 // ================================================================= fused weight gradient (f32, AlignConv geometry)
@@ -1175,7 +1194,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
 // one burst or between the MFMAs of the same waves (a wave whose load waits for a queue slot issues no MFMA either).
 // Two workgroup barriers per tile: B1 (buffers swap) and B2 in the middle of the MFMA phase, which separates the loaders'
 // patch / table writes from their blend; the MFMA waves always arrive last, so only loaders wait.
-constexpr int kFWColRow = 96;                  // floats per position of a column tile: 64 channels + 32
+constexpr int kFWColRow = 80;                  // floats per position of a column tile: 64 channels + 16 (the four k rows of an
+                                               // operand read -- 16 consecutive floats each -- fall into four different 16-bank groups)
 constexpr int kFWPatRow = 68;                  // floats per window pixel: 64 channels + 4
 constexpr int kFWThreads = 768, kFWLoaders = 256;
 constexpr int kFWColBuf = 3 * kFPos * kFWColRow;              // floats per column buffer
@@ -1192,8 +1212,8 @@ __device__ unsigned long long g_bwd_dbg[16];    // cycles: [0] MFMA halves, [1] 
 __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* __restrict__ x,        // NHWC [S,H,W,C]
                                                                   const float* __restrict__ go,       // NHWC [S,H,W,O]
                                                                   const float* __restrict__ offset,   // NCHW [S,18,H,W]
-                                                                  float* __restrict__ grad_w,         // [O][C][9], accumulated
-                                                                  float scale, int S, int C, int H, int W, int O, int ksplit) {
+                                                                  float* __restrict__ partial,        // [slice][owner][O][3 taps][64]
+                                                                  int S, int C, int H, int W, int O, int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_patch = reinterpret_cast<float*>(smem);                           // [192][kFWPatRow]
   float* s_col = s_patch + kFPix * kFWPatRow;                                // [2][3][32][kFWColRow]
@@ -1215,15 +1235,23 @@ __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* 
   const int nt = slice < ntiles ? (ntiles - slice + ksplit - 1) / ksplit : 0;     // tiles of this workgroup: slice + j * ksplit
   const int64_t HW = (int64_t)H * W;
   const bool mwave = wave < O / 32;                                          // MFMA wave w owns out-channel tile w (O <= 256)
-  auto tile_geom = [&](int j, int& b, int& ty0, int& tx0) {                  // (past the end: the last tile again -- harmless reads)
-    const int tile = slice + min(j, nt - 1) * ksplit;
-    tx0 = (tile % txn) * kFTW;
-    const int r = tile / txn;
-    ty0 = (r % tyn) * kFTH;
-    b = r / tyn;
+  // tile coordinates are carried and advanced by ksplit tiles (a walk of a few steps): the integer divisions of tile -> (image,
+  // row, column) cost ~100 instructions, per tile and wave, in streams that have no issue slots to spare beside the MFMAs
+  struct TilePos { int b, ty, tx; };             // image, tile row, tile column
+  TilePos first;
+  {
+    const int tile = min(slice, ntiles - 1), r = tile / txn;
+    first.tx = tile % txn; first.ty = r % tyn; first.b = r / tyn;
+  }
+  auto advance = [&](TilePos& p) {
+    p.tx += ksplit;
+    while (p.tx >= txn) {
+      p.tx -= txn;
+      if (++p.ty == tyn) { p.ty = 0; ++p.b; }
+    }
   };
 #ifdef S2A_MEASURE
-  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c7 = 0, c8 = 0, c9 = 0, c10 = 0, c11 = 0;
+  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c7 = 0, c8 = 0, c9 = 0, c10 = 0;
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
   if (nt == 0) return;
@@ -1242,9 +1270,8 @@ __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* 
     // per tile, the row part one multiply-add per request (issue slots are what a loader is short of beside two MFMA streams)
     static_assert(kFPW == 16 && kFPH == kPaVec && kFWLoaders == 256, "loader geometry");
     const int lpx = ltid >> 4, lq = ltid & 15;
-    auto request = [&](int j) {
-      int b, ty0, tx0;
-      tile_geom(j, b, ty0, tx0);
+    auto request = [&](const TilePos& tp_) {
+      const int b = tp_.b, ty0 = tp_.ty * kFTH, tx0 = tp_.tx * kFTW;
       const int oy = ty0 - 3, xx = tx0 - 3 + lpx;
       const bool okx = xx >= 0 && xx < W;
       const float* colp = x + ((int64_t)b * HW + min(max(xx, 0), W - 1)) * C + cc * 64 + lq * 4;
@@ -1262,10 +1289,10 @@ __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* 
       off_yx[0] = ob[(int64_t)(2 * t) * HW];
       off_yx[1] = ob[(int64_t)(2 * t + 1) * HW];
     };
-    request(0);
+    TilePos cur = first;
+    request(cur);
     for (int j = 0; j <= nt; j++) {
-      int b, ty0, tx0;
-      tile_geom(j, b, ty0, tx0);
+      const int b = cur.b, ty0 = cur.ty * kFTH, tx0 = cur.tx * kFTW;
       const int oy = ty0 - 3, ox = tx0 - 3;
       __syncthreads();                           // B1: the blend of tile j - 1 has read the patch and the table
       BWD_T(t1);
@@ -1318,7 +1345,10 @@ __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* 
       __syncthreads();                           // B2: patch and table of tile j are in LDS
       BWD_T(t3);
       if (j < nt) {
-        if (j + 1 < nt && !(S2A_BWD_ABL & 128)) request(j + 1);        // in flight under the blend and the next tile's first half
+        if (j + 1 < nt) {                          // in flight under the blend and the next tile's first half
+          advance(cur);
+          if (!(S2A_BWD_ABL & 128)) request(cur);
+        }
 #ifdef S2A_MEASURE
         c10 += __builtin_amdgcn_s_memtime() - t3;
 #endif
@@ -1421,83 +1451,94 @@ __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* 
   }
 
   // =========================================================== MFMA waves
-  f32x16b acc[3][2];
+  // v_mfma_f32_16x16x4_f32, not 32x32x2: the same 64 FLOP / clk, but an accumulator tile is read and written once per FOUR
+  // positions instead of once per two.  Back-to-back 32x32x2 MFMAs keep the SIMD's register-file write port busy with their
+  // own 16-register results (16 x 4 of every 64 cycles), and everything else on that SIMD that returns a value to a register
+  // -- the partner's operand reads, the loader's patch requests -- queues behind them (stamps: the loaders' twelve requests took
+  // 7.0 k cycles per tile beside the MFMAs and 1.4 k with the MFMAs compiled out).
+  // Wave w owns out channels 32 w .. 32 w + 31 as two 16-row tiles of interleaved channels (tile h, row i = channel 2 i + h:
+  // one 8-byte request fetches both), and 3 taps x four 16-channel column tiles: 24 accumulators of 4 registers.
+  f32x4b acc[2][12];
 #pragma unroll
-  for (int a = 0; a < 3; a++)
+  for (int h = 0; h < 2; h++)
 #pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
-  // gradOutput operand of a whole tile: k-step ks = positions 2 ks, 2 ks + 1; lane (l & 31, l >> 5) holds out channel
-  // 32 w + (l & 31) of position 2 ks + (l >> 5); positions outside the image load from a clamped address and count as zero
-  // Address arithmetic per tile, not per request (these waves' non-MFMA instructions are what opens gaps in the matrix pipe):
-  // position 2 ks + h sits in tile row ks >> 2, tile column 2 (ks & 3) + h -- four row pointers (uniform) and four lane offsets
-  float a_cur[kFPos / 2], a_nxt[kFPos / 2];
+    for (int n = 0; n < 12; n++) acc[h][n] = f32x4b{0.f, 0.f, 0.f, 0.f};
+  // gradOutput operand of a whole tile: k-step ks = positions 4 ks .. 4 ks + 3, lane (l & 15, l >> 4) holds the channel pair
+  // 2 (l & 15), + 1 of position 4 ks + (l >> 4) = tile row ks >> 1, tile column 4 (ks & 1) + (l >> 4).  Address arithmetic
+  // per tile, not per request: two row pointers... four (uniform) and two lane offsets; positions outside the image load from a
+  // clamped address and count as zero.
+  using f32x2b = __attribute__((ext_vector_type(2))) float;
+  constexpr int kSteps = kFPos / 4;              // 8
+  f32x2b a_cur[kSteps], a_nxt[kSteps];
   unsigned ok_cur = 0u, ok_nxt = 0u;
   const float* a_row[4];
-  int a_col[4];
-  const int a_lane = min(wave, O / 32 - 1) * 32 + (lane & 31), a_h = lane >> 5;
-  auto setup_a = [&](int j, unsigned& okbits) {
-    int b, ty0, tx0;
-    tile_geom(j, b, ty0, tx0);
+  int a_col[2];
+  const int a_lane = min(wave, O / 32 - 1) * 32 + 2 * (lane & 15), a_h = lane >> 4;
+  auto setup_a = [&](const TilePos& tp_, unsigned& okbits) {
+    const int b = tp_.b, ty0 = tp_.ty * kFTH, tx0 = tp_.tx * kFTW;
     unsigned oky = 0u, okx = 0u;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       a_row[r] = go + ((int64_t)b * HW + (int64_t)min(ty0 + r, H - 1) * W) * O;
       oky |= (ty0 + r < H ? 1u : 0u) << r;
-      const int xq = tx0 + 2 * r + a_h;
-      a_col[r] = min(xq, W - 1) * O + a_lane;
-      okx |= (xq < W ? 1u : 0u) << r;
+    }
+#pragma unroll
+    for (int p2 = 0; p2 < 2; p2++) {
+      const int xq = tx0 + 4 * p2 + a_h;
+      a_col[p2] = min(xq, W - 1) * O + a_lane;
+      okx |= (xq < W ? 1u : 0u) << p2;
     }
     okbits = 0u;
 #pragma unroll
-    for (int ks = 0; ks < kFPos / 2; ks++) okbits |= (((oky >> (ks >> 2)) & (okx >> (ks & 3))) & 1u) << ks;
+    for (int ks = 0; ks < kSteps; ks++) okbits |= (((oky >> (ks >> 1)) & (okx >> (ks & 1))) & 1u) << ks;
   };
-  setup_a(0, ok_cur);
+  auto request_a = [&](int ks) { return *reinterpret_cast<const f32x2b*>(a_row[ks >> 1] + a_col[ks & 1]); };
+  TilePos apos = first;
+  setup_a(apos, ok_cur);
 #pragma unroll
-  for (int ks = 0; ks < kFPos / 2; ks++) a_cur[ks] = a_row[ks >> 2][a_col[ks & 3]];
-#if S2A_BWD_PRIO1
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the younger MFMA wave of each SIMD loses every arbitration against the older one
-#endif
-  const float* b_lane = s_col + (lane >> 5) * kFWColRow + (lane & 31);
+  for (int ks = 0; ks < kSteps; ks++) a_cur[ks] = request_a(ks);
+  const float* b_lane = s_col + (lane >> 4) * kFWColRow + (lane & 15);
   for (int j = 0; j <= nt; j++) {
     BWD_T(t0);
     __syncthreads();                             // B1: column buffer (j - 1) & 1 holds tile j - 1
     BWD_T(t1);
     const float* b_base = b_lane + ((j - 1) & 1) * kFWColBuf;
-    // the seven operand values of k-step ks + 1 are requested before the six MFMAs of k-step ks (order pinned: left alone,
-    // hipcc reads each pair right in front of its MFMAs and waits out the LDS round trip three times per k-step)
-    float Bv[2][6];
-    auto fetch = [&](int ks, float (&bv)[6]) {
+    // the twelve column values of k-step ks + 1 are requested before the 24 MFMAs of k-step ks (order pinned: left alone,
+    // hipcc reads each operand right in front of its MFMAs and waits out the LDS round trip every time)
+    float Bv[2][12];
+    auto fetch = [&](int ks, float (&bv)[12]) {
 #pragma unroll
       for (int tl = 0; tl < 3; tl++)
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) bv[tl * 2 + ct] = b_base[(tl * kFPos + 2 * ks) * kFWColRow + ct * 32];
+        for (int ct = 0; ct < 4; ct++) bv[tl * 4 + ct] = b_base[(tl * kFPos + 4 * ks) * kFWColRow + ct * 16];
     };
-    auto half = [&](int h) {
+    auto half = [&](int hh) {
 #pragma unroll
-      for (int ks = 8 * h; ks < 8 * h + 8; ks++) {
-        if (ks + 1 < kFPos / 2) fetch(ks + 1, Bv[(ks + 1) & 1]);
-        // the next tile's operand: two values per k-step of the FIRST half -- the registers are handed over at the end of the tile,
-        // and a request made in the last k-steps would have its whole memory latency waited out there (vmcnt counts in order)
-        if (!(S2A_BWD_ABL & 128) && ks < kFPos / 4) {
-          a_nxt[2 * ks] = a_row[(2 * ks) >> 2][a_col[(2 * ks) & 3]];
-          a_nxt[2 * ks + 1] = a_row[(2 * ks + 1) >> 2][a_col[(2 * ks + 1) & 3]];
+      for (int ks = 4 * hh; ks < 4 * hh + 4; ks++) {
+        if (ks + 1 < kSteps) fetch(ks + 1, Bv[(ks + 1) & 1]);
+        // the next tile's operand: two requests per k-step of the FIRST half -- the registers are handed over at the end of the
+        // tile, and a request made in the last k-steps would have its whole memory latency waited out there
+        if (!(S2A_BWD_ABL & 128) && hh == 0) {
+          a_nxt[2 * ks] = request_a(2 * ks);
+          a_nxt[2 * ks + 1] = request_a(2 * ks + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float A = ((ok_cur >> ks) & 1u) ? a_cur[ks] : 0.f;
+        const bool ok = (ok_cur >> ks) & 1u;
+        const float A0 = ok ? a_cur[ks][0] : 0.f, A1 = ok ? a_cur[ks][1] : 0.f;
 #pragma unroll
-        for (int tl = 0; tl < 3; tl++)
-#pragma unroll
-          for (int ct = 0; ct < 2; ct++)
-            if (!(S2A_BWD_ABL & 32)) acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, Bv[ks & 1][tl * 2 + ct], acc[tl][ct], 0, 0, 0);
+        for (int n = 0; n < 12; n++)
+          if (!(S2A_BWD_ABL & 32)) {
+            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, Bv[ks & 1][n], acc[0][n], 0, 0, 0);
+            acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, Bv[ks & 1][n], acc[1][n], 0, 0, 0);
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     const bool work = j >= 1 && mwave;
     if (work) {
       fetch(0, Bv[0]);
-      setup_a(j, ok_nxt);
+      if (j < nt) advance(apos);                 // (after the last tile: that tile again -- harmless reads)
+      setup_a(apos, ok_nxt);
       half(0);
     }
     BWD_T(t2);
@@ -1506,7 +1547,7 @@ __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* 
     if (work) {
       half(1);
 #pragma unroll
-      for (int ks = 0; ks < kFPos / 2; ks++) a_cur[ks] = a_nxt[ks];
+      for (int ks = 0; ks < kSteps; ks++) a_cur[ks] = a_nxt[ks];
       ok_cur = ok_nxt;
     }
 #ifdef S2A_MEASURE
@@ -1514,20 +1555,22 @@ __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* 
     c1 += t1 - t0; c0 += (t2 - t1) + (t4 - t3); c2 += t3 - t2;
 #endif
   }
-  // ---- results: rows = out channels (4 consecutive per register quad), columns = channels of the chunk
+  // ---- results: accumulator (h, tl * 4 + ct), register r, lane l = out channel 32 w + 2 (4 (l >> 4) + r) + h, channel 16 ct + (l & 15)
+  // one block per workgroup, summed over the slices by k_dcn_bwd_weight_reduce
   if (mwave) {
+    float* part = partial + (int64_t)logical * O * 192;         // (logical = slice * owners + owner)
 #pragma unroll
-    for (int tl = 0; tl < 3; tl++)
+    for (int h = 0; h < 2; h++)
 #pragma unroll
-      for (int ct = 0; ct < 2; ct++)
+      for (int n = 0; n < 12; n++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int o = wave * 32 + 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5), c = cc * 64 + ct * 32 + (lane & 31);
-          const float v = acc[tl][ct][r];
-          if (v != 0.f) atomicAdd(grad_w + ((int64_t)o * C + c) * 9 + ky * 3 + tl, scale * v);
+        for (int r = 0; r < 4; r++) {
+          const int o = wave * 32 + 2 * (4 * (lane >> 4) + r) + h;
+          part[(o * 3 + (n >> 2)) * 64 + (n & 3) * 16 + (lane & 15)] = acc[h][n][r];
         }
   }
 #ifdef S2A_MEASURE
+  if (tid == 256) { atomicAdd(&g_bwd_dbg[11], c0); atomicAdd(&g_bwd_dbg[12], c1); atomicAdd(&g_bwd_dbg[13], c2); }
   if (tid == 0) {
     atomicAdd(&g_bwd_dbg[0], c0); atomicAdd(&g_bwd_dbg[1], c1); atomicAdd(&g_bwd_dbg[2], c2);
     atomicAdd(&g_bwd_dbg[4], (unsigned long long)nt); atomicAdd(&g_bwd_dbg[5], 1ull); atomicAdd(&g_bwd_dbg[6], __builtin_amdgcn_s_memtime() - t_begin);
@@ -1741,7 +1784,8 @@ extern "C" int s2a_deform_conv_backward_input_f32(const float* input, const floa
 // is ACCUMULATED (unscaled; the caller zeroes it and applies `scale`).  workspace: NHWC copies of input and gradOutput.
 extern "C" size_t s2a_deform_conv_backward_weight_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
                                                                   int64_t width, int64_t out_channels) {
-  return align_up((size_t)(batch * height * width * channels) * 2) + align_up((size_t)(batch * height * width * out_channels) * 2) + 1024;
+  return align_up((size_t)(batch * height * width * channels) * 2) + align_up((size_t)(batch * height * width * out_channels) * 2) +
+         align_up((size_t)kWgradMaxBlocks * out_channels * 192 * 4) + 1024;
 }
 
 extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void* offset, const void* grad_output,
@@ -1761,7 +1805,8 @@ extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void
   const int64_t HW = height * width;
   _Float16* xn = cv.take<_Float16>((size_t)(batch * HW * channels));
   _Float16* gn = cv.take<_Float16>((size_t)(batch * HW * out_channels));
-  S2A_CHECK_ARG(xn && gn, "deform_conv_backward_weight_f16: workspace too small");
+  float* partial = cv.take<float>((size_t)kWgradMaxBlocks * out_channels * 192);
+  S2A_CHECK_ARG(xn && gn && partial, "deform_conv_backward_weight_f16: workspace too small");
   k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
       (const _Float16*)input, (int)channels, HW, xn);
   k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
@@ -1777,13 +1822,16 @@ extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void
     S2A_HIP(hipGetDeviceProperties(&prop, dev));
     if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
   }
-  const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, n_cu / owners));
+  const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::min(n_cu, kWgradMaxBlocks) / owners));
   const int dw = (int)out_channels / 2;
   const int gop = (dw + ((16 - (dw & 63)) & 63)) * 4;
   const int lds = kWPos * gop + kWPatchPix * 128 + 3 * kWPos * kWColRow + 3 * kWPos * 16;
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  k_dcn_bwd_weight<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, (const _Float16*)offset, grad_weight_f32, (int)batch,
+  k_dcn_bwd_weight<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, (const _Float16*)offset, partial, (int)batch,
                                                                (int)channels, (int)height, (int)width, (int)out_channels, ksplit);
+  const int64_t nout = out_channels * channels * 9;
+  k_dcn_bwd_weight_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, st>>>(partial, grad_weight_f32, 1.f, (int)out_channels,
+                                                                         (int)channels, ksplit);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
@@ -1792,7 +1840,8 @@ extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void
 // with `scale` applied (gradWeight += scale * gradOutput x columns^T).  workspace: NHWC copies of input and gradOutput.
 extern "C" size_t s2a_deform_conv_backward_weight_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
                                                                       int64_t width, int64_t out_channels) {
-  return align_up((size_t)(batch * height * width * channels) * 4) + align_up((size_t)(batch * height * width * out_channels) * 4) + 1024;
+  return align_up((size_t)(batch * height * width * channels) * 4) + align_up((size_t)(batch * height * width * out_channels) * 4) +
+         align_up((size_t)kWgradMaxBlocks * out_channels * 192 * 4) + 1024;
 }
 
 extern "C" int s2a_deform_conv_backward_weight_f32(const float* input, const float* offset, const float* grad_output,
@@ -1812,7 +1861,8 @@ extern "C" int s2a_deform_conv_backward_weight_f32(const float* input, const flo
   const int64_t HW = height * width;
   float* xn = cv.take<float>((size_t)(batch * HW * channels));
   float* gn = cv.take<float>((size_t)(batch * HW * out_channels));
-  S2A_CHECK_ARG(xn && gn, "deform_conv_backward_weight_f32: workspace too small");
+  float* partial = cv.take<float>((size_t)kWgradMaxBlocks * out_channels * 192);
+  S2A_CHECK_ARG(xn && gn && partial, "deform_conv_backward_weight_f32: workspace too small");
   k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
       input, (int)channels, HW, xn);
   k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
@@ -1828,11 +1878,14 @@ extern "C" int s2a_deform_conv_backward_weight_f32(const float* input, const flo
     S2A_HIP(hipGetDeviceProperties(&prop, dev));
     if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
   }
-  const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, n_cu / owners));
+  const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::min(n_cu, kWgradMaxBlocks) / owners));
   const int lds = wgrad_f32_lds_bytes();
   S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  k_dcn_bwd_weight_f32<<<(unsigned)((owners * ksplit + 7) / 8 * 8), kFWThreads, lds, st>>>(xn, gn, offset, grad_weight, scale, (int)batch, (int)channels,
-                                                                   (int)height, (int)width, (int)out_channels, ksplit);
+  k_dcn_bwd_weight_f32<<<(unsigned)((owners * ksplit + 7) / 8 * 8), kFWThreads, lds, st>>>(xn, gn, offset, partial, (int)batch, (int)channels,
+                                                                                         (int)height, (int)width, (int)out_channels, ksplit);
+  const int64_t nout = out_channels * channels * 9;
+  k_dcn_bwd_weight_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, st>>>(partial, grad_weight, scale, (int)out_channels, (int)channels,
+                                                                         ksplit);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }

@@ -31,6 +31,7 @@ v = list(buf)
 tiles, wgs = v[4] / n, v[5] / n
 print("call %.3f ms; %d workgroups, %.1f tiles each" % (ms, wgs, tiles / wgs))
 for name, c in (("MFMA halves (wave 0)", v[0]), ("B1 wait (wave 0)", v[1]), ("B2 wait (wave 0)", v[2]),
+                ("MFMA halves (wave 4)", v[11]), ("B1 wait (wave 4)", v[12]), ("B2 wait (wave 4)", v[13]),
                 ("land + table (wave 8)", v[3]), ("  of it: wait for the loads", v[8]), ("  of it: land", v[9]),
                 ("blend + requests (wave 8)", v[7]), ("  of it: requests", v[10])):
     print("  %-26s %8.0f cycles per tile" % (name, c / n / tiles))
