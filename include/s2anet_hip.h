@@ -401,8 +401,9 @@ int s2a_deform_conv_backward_input_f32(const float* input, const float* offset, 
 /* deform_conv_backward_parameters_cuda (models/dcn/src/deform_conv_cuda.cpp:376-489: gradWeight) for f16 tensors with the
  * AlignConv geometry (channels % 64 == 0, out_channels % 32 == 0, out_channels <= 256), fused: the sampled columns are
  * formed tile by tile in LDS (bilinear corners from an LDS patch, as the forward does) and contracted with gradOutput over
- * the POSITIONS on the matrix cores, both operands through gfx950's transposing LDS read; split-K over the position tiles,
- * f32 atomics into grad_weight_f32 [O,C,3,3] (ACCUMULATED, unscaled: the caller zeroes it and applies `scale`). */
+ * the POSITIONS on the matrix cores, both operands through gfx950's transposing LDS read; split-K over the position tiles:
+ * every workgroup stores its partial block and one reduce kernel sums the slices in a fixed order into grad_weight_f32
+ * [O,C,3,3] (ACCUMULATED, unscaled: the caller zeroes it and applies `scale`) -- no atomics, bit-identical from run to run. */
 size_t s2a_deform_conv_backward_weight_workspace_bytes(int64_t batch, int64_t channels, int64_t height, int64_t width,
                                                        int64_t out_channels);
 int s2a_deform_conv_backward_weight_f16(const void* input, const void* offset, const void* grad_output,
@@ -410,14 +411,28 @@ int s2a_deform_conv_backward_weight_f16(const void* input, const void* offset, c
                                         int64_t width, int64_t out_channels, void* workspace, size_t workspace_bytes,
                                         s2a_stream_t stream);
 
-/* The same entry for f32 tensors (same geometry limits; v_mfma_f32_32x32x2_f32, 4 x 8 position tiles): grad_weight
- * [O,C,3,3] f32 is the caller's gradWeight, ACCUMULATED in place with `scale` applied (deform_conv_cuda.cpp:455-459). */
+/* The same entry for f32 tensors (same geometry limits; v_mfma_f32_16x16x4_f32, 4 x 8 position tiles, loader waves beside the
+ * MFMA waves): grad_weight [O,C,3,3] f32 is the caller's gradWeight, += scale * gradOutput x columns^T in place
+ * (deform_conv_cuda.cpp:455-459); deterministic as above. */
 size_t s2a_deform_conv_backward_weight_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height, int64_t width,
                                                            int64_t out_channels);
 int s2a_deform_conv_backward_weight_f32(const float* input, const float* offset, const float* grad_output,
                                         float* grad_weight, float scale, int64_t batch, int64_t channels, int64_t height,
                                         int64_t width, int64_t out_channels, void* workspace, size_t workspace_bytes,
                                         s2a_stream_t stream);
+
+/* Both gradients of the AlignConv-geometry deformable convolution in ONE call -- what DeformConvFunction.backward needs
+ * (models/dcn/deform_conv.py:73-118 calls deform_conv_backward_input_cuda and deform_conv_backward_parameters_cuda on the same
+ * tensors): the NHWC copies of input and gradOutput the fused kernels read are made once instead of twice.
+ * dtype = S2A_DTYPE_F16 / S2A_DTYPE_F32: the type of input, offset, grad_output, weight [O,C,3,3] and grad_offset [S,18,H,W];
+ * grad_input_f32 [S,C,H,W] (ACCUMULATED) and grad_weight_f32 [O,C,3,3] (+= scale * ...) are always f32.  Either may be NULL
+ * to skip that gradient (grad_offset goes with grad_input).  Limits: channels % 64 == 0, out_channels % 32 == 0, <= 256. */
+size_t s2a_deform_conv_backward_workspace_bytes(int dtype, int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                                int64_t out_channels);
+int s2a_deform_conv_backward(int dtype, const void* input, const void* offset, const void* grad_output, const void* weight,
+                             float* grad_input_f32, void* grad_offset, float* grad_weight_f32, float scale, int64_t batch,
+                             int64_t channels, int64_t height, int64_t width, int64_t out_channels, void* workspace,
+                             size_t workspace_bytes, s2a_stream_t stream);
 
 /* A bottleneck's conv2 + conv3 in one launch (models/backbone.py:56-83 with the BatchNorms folded):
  *   out = relu(W3 . relu(conv3x3(x; W2) + b2) + b3 + residual)        x [B,H,W,64] -> out [B,H,W,256], f16 NHWC

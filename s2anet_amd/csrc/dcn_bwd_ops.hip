@@ -1685,207 +1685,200 @@ extern "C" int s2a_deformable_col2im_coord(const void* columns, const void* im, 
   return S2A_OK;
 }
 
-// deform_conv_backward_input_cuda for f16 tensors with the AlignConv geometry (3x3, stride 1, pad 1, dilation 1, one group,
-// one deformable group, C % 32 == 0, O % 16 == 0, O <= 256), fused: see k_dcn_bwd_input.  All tensors NCHW as the reference
-// passes them; grad_input_f32 [S,C,H,W] is ACCUMULATED (caller zeroes it), grad_offset [S,18,H,W] f16 is overwritten.
-// workspace: NHWC copies of input and gradOutput + the fragment-order filter.
-extern "C" size_t s2a_deform_conv_backward_input_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
-                                                                 int64_t width, int64_t out_channels) {
-  return align_up((size_t)(batch * height * width * channels) * 2) + align_up((size_t)(batch * height * width * out_channels) * 2) +
-         align_up((size_t)(out_channels * channels * 9) * 2) + 1024;
+// ================================================================= host side of the fused backward (AlignConv geometry)
+// deform_conv_backward_input_cuda / deform_conv_backward_parameters_cuda (models/dcn/src/deform_conv_cuda.cpp:262-489) for the
+// AlignConv geometry -- 3x3, stride 1, pad 1, dilation 1, one group, one deformable group -- as fused kernels, f16 or f32.
+// All tensors NCHW as the reference passes them.  One implementation behind five entry points: the two gradients separately
+// (the reference's two functions) or both in one call, which shares the NHWC copies of input and gradOutput between them
+// (the autograd backward wants both: two transposes instead of four).
+namespace s2a {
+namespace {
+struct FusedBwdArgs {
+  int dtype;                                     // S2A_DTYPE_F16 / S2A_DTYPE_F32
+  const void *input, *offset, *grad_output, *weight;
+  float* grad_input;                             // f32 [S,C,H,W], accumulated; NULL: no input / offset gradient
+  void* grad_offset;                             // dtype [S,18,H,W], overwritten
+  float* grad_weight;                            // f32 [O,C,3,3], += scale * ...; NULL: no weight gradient
+  float scale;
+  int64_t B, C, H, W, O;
+};
+
+size_t fused_bwd_workspace(int dtype, bool want_input, bool want_weight, int64_t B, int64_t C, int64_t H, int64_t W, int64_t O) {
+  const size_t el = dtype == S2A_DTYPE_F16 ? 2 : 4;
+  size_t n = align_up((size_t)(B * H * W * C) * el) + align_up((size_t)(B * H * W * O) * el) + 1024;
+  if (want_input) n += align_up((size_t)(O * C * 9) * el);
+  if (want_weight) n += align_up((size_t)kWgradMaxBlocks * O * 192 * 4);
+  return n;
 }
 
+template <typename T>
+int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+  constexpr bool kHalf = sizeof(T) == 2;
+  const bool want_input = a.grad_input != nullptr, want_weight = a.grad_weight != nullptr;
+  const int64_t B = a.B, C = a.C, H = a.H, W = a.W, O = a.O;
+  S2A_CHECK_ARG(B >= 0 && C > 0 && H >= 3 && W >= 3 && O > 0, "%s: bad shape", who);
+  S2A_CHECK_ARG(H < (1 << 15) && W < (1 << 15), "%s: shape too large", who);
+  S2A_CHECK_ARG(O <= 256, "%s: needs out_channels <= 256", who);
+  if (want_input) S2A_CHECK_ARG(C % 32 == 0 && O % 16 == 0, "%s: the input gradient needs channels %% 32 == 0, out_channels %% 16 == 0", who);
+  if (want_weight) S2A_CHECK_ARG(C % 64 == 0 && O % 32 == 0, "%s: the weight gradient needs channels %% 64 == 0, out_channels %% 32 == 0", who);
+  if (B == 0 || (!want_input && !want_weight)) return S2A_OK;
+  S2A_CHECK_ARG(a.input && a.offset && a.grad_output, "%s: NULL tensor", who);
+  S2A_CHECK_ARG(!want_input || (a.weight && a.grad_offset), "%s: NULL tensor", who);
+  S2A_CHECK_ARG(workspace_bytes >= fused_bwd_workspace(a.dtype, want_input, want_weight, B, C, H, W, O), "%s: workspace too small", who);
+  Carver cv(workspace, workspace_bytes);
+  const int64_t HW = H * W;
+  T* xn = cv.take<T>((size_t)(B * HW * C));
+  T* gn = cv.take<T>((size_t)(B * HW * O));
+  T* wp = want_input ? cv.take<T>((size_t)(O * C * 9)) : nullptr;
+  float* partial = want_weight ? cv.take<float>((size_t)kWgradMaxBlocks * O * 192) : nullptr;
+  S2A_CHECK_ARG(xn && gn && (!want_input || wp) && (!want_weight || partial), "%s: workspace too small", who);
+  k_bwd_nchw_to_nhwc<T><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B), 256, 0, st>>>((const T*)a.input, (int)C, HW, xn);
+  k_bwd_nchw_to_nhwc<T><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((O + 31) / 32), (unsigned)B), 256, 0, st>>>((const T*)a.grad_output, (int)O, HW, gn);
+  if (want_input) {
+    const int64_t wtotal = O * C * 9;
+    if constexpr (kHalf) {
+      k_pack_weight_bwd<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>((const _Float16*)a.weight, (int)O, (int)C, wp);
+      const int64_t tiles = B * ((H + kBTH - 1) / kBTH) * ((W + kBTW - 1) / kBTW);
+      S2A_CHECK_ARG(tiles < (1ll << 31), "%s: too many tiles", who);
+      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
+      k_dcn_bwd_input<<<(unsigned)tiles, 512, kBwdLds, st>>>(xn, gn, (const _Float16*)a.offset, wp, a.grad_input, (_Float16*)a.grad_offset,
+                                                            (int)B, (int)C, (int)H, (int)W, (int)O);
+    } else {
+      k_pack_weight_bwd_f32<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>((const float*)a.weight, (int)O, (int)C, wp);
+      const int64_t tiles = B * ((H + kFTH - 1) / kFTH) * ((W + kFTW - 1) / kFTW);
+      S2A_CHECK_ARG(tiles < (1ll << 31), "%s: too many tiles", who);
+      const int lds = bwd_f32_lds_bytes((int)O);
+      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      if (O % 128 == 0)
+        k_dcn_bwd_input_f32<true><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, (const float*)a.offset, wp, a.grad_input, (float*)a.grad_offset,
+                                                                    (int)B, (int)C, (int)H, (int)W, (int)O);
+      else
+        k_dcn_bwd_input_f32<false><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, (const float*)a.offset, wp, a.grad_input, (float*)a.grad_offset,
+                                                                     (int)B, (int)C, (int)H, (int)W, (int)O);
+    }
+    S2A_LAUNCH_CHECK();
+  }
+  if (want_weight) {
+    const int owners = 3 * (int)(C / 64);
+    int n_cu = 256;
+    {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      S2A_HIP(hipGetDevice(&dev));
+      S2A_HIP(hipGetDeviceProperties(&prop, dev));
+      if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    }
+    int ksplit;
+    if constexpr (kHalf) {
+      const int64_t tiles = B * ((H + kBTH - 1) / kBTH) * ((W + kBTW - 1) / kBTW);
+      S2A_CHECK_ARG(tiles < (1ll << 31), "%s: too many tiles", who);
+      ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::min(n_cu, kWgradMaxBlocks) / owners));
+      const int dw = (int)O / 2;
+      const int gop = (dw + ((16 - (dw & 63)) & 63)) * 4;
+      const int lds = kWPos * gop + kWPatchPix * 128 + 3 * kWPos * kWColRow + 3 * kWPos * 16;
+      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      k_dcn_bwd_weight<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, (const _Float16*)a.offset, partial, (int)B, (int)C, (int)H,
+                                                                   (int)W, (int)O, ksplit);
+    } else {
+      const int64_t tiles = B * ((H + kFTH - 1) / kFTH) * ((W + kFTW - 1) / kFTW);
+      S2A_CHECK_ARG(tiles < (1ll << 31), "%s: too many tiles", who);
+      ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::min(n_cu, kWgradMaxBlocks) / owners));
+      const int lds = wgrad_f32_lds_bytes();
+      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      k_dcn_bwd_weight_f32<<<(unsigned)((owners * ksplit + 7) / 8 * 8), kFWThreads, lds, st>>>(xn, gn, (const float*)a.offset, partial, (int)B,
+                                                                                             (int)C, (int)H, (int)W, (int)O, ksplit);
+    }
+    const int64_t nout = O * C * 9;
+    k_dcn_bwd_weight_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, st>>>(partial, a.grad_weight, a.scale, (int)O, (int)C, ksplit);
+    S2A_LAUNCH_CHECK();
+  }
+  return S2A_OK;
+}
+
+int fused_bwd(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes, s2a_stream_t stream, const char* who) {
+  S2A_CHECK_ARG(a.dtype == S2A_DTYPE_F16 || a.dtype == S2A_DTYPE_F32, "%s: float16 / float32", who);
+  return a.dtype == S2A_DTYPE_F16 ? fused_bwd_run<_Float16>(a, workspace, workspace_bytes, as_stream(stream), who)
+                                  : fused_bwd_run<float>(a, workspace, workspace_bytes, as_stream(stream), who);
+}
+}  // namespace
+}  // namespace s2a
+
+// f16: grad_input_f32 [S,C,H,W] is ACCUMULATED (the caller zeroes it), grad_offset [S,18,H,W] f16 is overwritten
+extern "C" size_t s2a_deform_conv_backward_input_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
+                                                                 int64_t width, int64_t out_channels) {
+  return fused_bwd_workspace(S2A_DTYPE_F16, true, false, batch, channels, height, width, out_channels);
+}
 extern "C" int s2a_deform_conv_backward_input_f16(const void* input, const void* offset, const void* grad_output,
                                                   const void* weight, float* grad_input_f32, void* grad_offset,
                                                   int64_t batch, int64_t channels, int64_t height, int64_t width,
                                                   int64_t out_channels, void* workspace, size_t workspace_bytes,
                                                   s2a_stream_t stream) {
-  S2A_CHECK_ARG(batch >= 0 && channels > 0 && height >= 3 && width >= 3 && out_channels > 0, "deform_conv_backward_input_f16: bad shape");
-  S2A_CHECK_ARG(channels % kBCh == 0 && out_channels % 16 == 0 && out_channels <= 256,
-                "deform_conv_backward_input_f16: needs channels %% 32 == 0, out_channels %% 16 == 0, out_channels <= 256");
-  S2A_CHECK_ARG(height < (1 << 15) && width < (1 << 15), "deform_conv_backward_input_f16: shape too large");
-  if (batch == 0) return S2A_OK;
-  S2A_CHECK_ARG(input && offset && grad_output && weight && grad_input_f32 && grad_offset, "deform_conv_backward_input_f16: NULL tensor");
-  S2A_CHECK_ARG(workspace_bytes >= s2a_deform_conv_backward_input_workspace_bytes(batch, channels, height, width, out_channels),
-                "deform_conv_backward_input_f16: workspace too small");
-  hipStream_t st = as_stream(stream);
-  Carver cv(workspace, workspace_bytes);
-  const int64_t HW = height * width;
-  _Float16* xn = cv.take<_Float16>((size_t)(batch * HW * channels));
-  _Float16* gn = cv.take<_Float16>((size_t)(batch * HW * out_channels));
-  _Float16* wp = cv.take<_Float16>((size_t)(out_channels * channels * 9));
-  S2A_CHECK_ARG(xn && gn && wp, "deform_conv_backward_input_f16: workspace too small");
-  k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
-      (const _Float16*)input, (int)channels, HW, xn);
-  k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
-      (const _Float16*)grad_output, (int)out_channels, HW, gn);
-  const int64_t wtotal = out_channels * channels * 9;
-  k_pack_weight_bwd<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, wp);
-  const int64_t tiles = batch * ((height + kBTH - 1) / kBTH) * ((width + kBTW - 1) / kBTW);
-  S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_input_f16: too many tiles");
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
-  k_dcn_bwd_input<<<(unsigned)tiles, 512, kBwdLds, st>>>(xn, gn, (const _Float16*)offset, wp, grad_input_f32, (_Float16*)grad_offset,
-                                                        (int)batch, (int)channels, (int)height, (int)width, (int)out_channels);
-  S2A_LAUNCH_CHECK();
-  return S2A_OK;
+  S2A_CHECK_ARG(batch == 0 || grad_input_f32, "deform_conv_backward_input_f16: NULL tensor");
+  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F16, input, offset, grad_output, weight, grad_input_f32, grad_offset, nullptr, 1.f, batch,
+                                channels, height, width, out_channels},
+                   workspace, workspace_bytes, stream, "deform_conv_backward_input_f16");
 }
 
-// The same for f32 tensors (k_dcn_bwd_input_f32): grad_input [S,C,H,W] f32 is the caller's gradInput, ACCUMULATED in place;
-// grad_offset [S,18,H,W] f32 is overwritten.  workspace: NHWC copies of input and gradOutput + the packed filter.
+// f32: grad_input [S,C,H,W] is the caller's gradInput, ACCUMULATED in place; grad_offset [S,18,H,W] f32 is overwritten
 extern "C" size_t s2a_deform_conv_backward_input_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
                                                                      int64_t width, int64_t out_channels) {
-  return align_up((size_t)(batch * height * width * channels) * 4) + align_up((size_t)(batch * height * width * out_channels) * 4) +
-         align_up((size_t)(out_channels * channels * 9) * 4) + 1024;
+  return fused_bwd_workspace(S2A_DTYPE_F32, true, false, batch, channels, height, width, out_channels);
 }
-
 extern "C" int s2a_deform_conv_backward_input_f32(const float* input, const float* offset, const float* grad_output,
                                                   const float* weight, float* grad_input, float* grad_offset,
                                                   int64_t batch, int64_t channels, int64_t height, int64_t width,
                                                   int64_t out_channels, void* workspace, size_t workspace_bytes,
                                                   s2a_stream_t stream) {
-  S2A_CHECK_ARG(batch >= 0 && channels > 0 && height >= 3 && width >= 3 && out_channels > 0, "deform_conv_backward_input_f32: bad shape");
-  S2A_CHECK_ARG(channels % kFCh == 0 && out_channels % 16 == 0 && out_channels <= 256,
-                "deform_conv_backward_input_f32: needs channels %% 32 == 0, out_channels %% 16 == 0, out_channels <= 256");
-  S2A_CHECK_ARG(height < (1 << 15) && width < (1 << 15), "deform_conv_backward_input_f32: shape too large");
-  if (batch == 0) return S2A_OK;
-  S2A_CHECK_ARG(input && offset && grad_output && weight && grad_input && grad_offset, "deform_conv_backward_input_f32: NULL tensor");
-  S2A_CHECK_ARG(workspace_bytes >= s2a_deform_conv_backward_input_f32_workspace_bytes(batch, channels, height, width, out_channels),
-                "deform_conv_backward_input_f32: workspace too small");
-  hipStream_t st = as_stream(stream);
-  Carver cv(workspace, workspace_bytes);
-  const int64_t HW = height * width;
-  float* xn = cv.take<float>((size_t)(batch * HW * channels));
-  float* gn = cv.take<float>((size_t)(batch * HW * out_channels));
-  float* wp = cv.take<float>((size_t)(out_channels * channels * 9));
-  S2A_CHECK_ARG(xn && gn && wp, "deform_conv_backward_input_f32: workspace too small");
-  k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
-      input, (int)channels, HW, xn);
-  k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
-      grad_output, (int)out_channels, HW, gn);
-  const int64_t wtotal = out_channels * channels * 9;
-  k_pack_weight_bwd_f32<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>(weight, (int)out_channels, (int)channels, wp);
-  const int64_t tiles = batch * ((height + kFTH - 1) / kFTH) * ((width + kFTW - 1) / kFTW);
-  S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_input_f32: too many tiles");
-  const int lds = bwd_f32_lds_bytes((int)out_channels);
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  if (out_channels % 128 == 0)
-    k_dcn_bwd_input_f32<true><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, offset, wp, grad_input, grad_offset, (int)batch, (int)channels,
-                                                                (int)height, (int)width, (int)out_channels);
-  else
-    k_dcn_bwd_input_f32<false><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, offset, wp, grad_input, grad_offset, (int)batch, (int)channels,
-                                                                 (int)height, (int)width, (int)out_channels);
-  S2A_LAUNCH_CHECK();
-  return S2A_OK;
+  S2A_CHECK_ARG(batch == 0 || grad_input, "deform_conv_backward_input_f32: NULL tensor");
+  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F32, input, offset, grad_output, weight, grad_input, grad_offset, nullptr, 1.f, batch, channels,
+                                height, width, out_channels},
+                   workspace, workspace_bytes, stream, "deform_conv_backward_input_f32");
 }
 
-// deform_conv_backward_parameters_cuda for f16 tensors with the AlignConv geometry (as s2a_deform_conv_backward_input_f16;
-// channels % 64 == 0, out_channels % 32 == 0, out_channels <= 256), fused: see k_dcn_bwd_weight.  grad_weight_f32 [O,C,3,3]
-// is ACCUMULATED (unscaled; the caller zeroes it and applies `scale`).  workspace: NHWC copies of input and gradOutput.
+// f16: grad_weight_f32 [O,C,3,3] is ACCUMULATED, unscaled (the caller zeroes it and applies `scale`)
 extern "C" size_t s2a_deform_conv_backward_weight_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
                                                                   int64_t width, int64_t out_channels) {
-  return align_up((size_t)(batch * height * width * channels) * 2) + align_up((size_t)(batch * height * width * out_channels) * 2) +
-         align_up((size_t)kWgradMaxBlocks * out_channels * 192 * 4) + 1024;
+  return fused_bwd_workspace(S2A_DTYPE_F16, false, true, batch, channels, height, width, out_channels);
 }
-
 extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void* offset, const void* grad_output,
                                                    float* grad_weight_f32, int64_t batch, int64_t channels, int64_t height,
                                                    int64_t width, int64_t out_channels, void* workspace,
                                                    size_t workspace_bytes, s2a_stream_t stream) {
-  S2A_CHECK_ARG(batch >= 0 && channels > 0 && height >= 3 && width >= 3 && out_channels > 0, "deform_conv_backward_weight_f16: bad shape");
-  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 32 == 0 && out_channels <= 256,
-                "deform_conv_backward_weight_f16: needs channels %% 64 == 0, out_channels %% 32 == 0, out_channels <= 256");
-  S2A_CHECK_ARG(height < (1 << 15) && width < (1 << 15), "deform_conv_backward_weight_f16: shape too large");
-  if (batch == 0) return S2A_OK;
-  S2A_CHECK_ARG(input && offset && grad_output && grad_weight_f32, "deform_conv_backward_weight_f16: NULL tensor");
-  S2A_CHECK_ARG(workspace_bytes >= s2a_deform_conv_backward_weight_workspace_bytes(batch, channels, height, width, out_channels),
-                "deform_conv_backward_weight_f16: workspace too small");
-  hipStream_t st = as_stream(stream);
-  Carver cv(workspace, workspace_bytes);
-  const int64_t HW = height * width;
-  _Float16* xn = cv.take<_Float16>((size_t)(batch * HW * channels));
-  _Float16* gn = cv.take<_Float16>((size_t)(batch * HW * out_channels));
-  float* partial = cv.take<float>((size_t)kWgradMaxBlocks * out_channels * 192);
-  S2A_CHECK_ARG(xn && gn && partial, "deform_conv_backward_weight_f16: workspace too small");
-  k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
-      (const _Float16*)input, (int)channels, HW, xn);
-  k_bwd_nchw_to_nhwc<_Float16><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
-      (const _Float16*)grad_output, (int)out_channels, HW, gn);
-  const int64_t tiles = batch * ((height + kBTH - 1) / kBTH) * ((width + kBTW - 1) / kBTW);
-  S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_weight_f16: too many tiles");
-  const int owners = 3 * (int)(channels / 64);
-  int n_cu = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    S2A_HIP(hipGetDevice(&dev));
-    S2A_HIP(hipGetDeviceProperties(&prop, dev));
-    if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-  }
-  const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::min(n_cu, kWgradMaxBlocks) / owners));
-  const int dw = (int)out_channels / 2;
-  const int gop = (dw + ((16 - (dw & 63)) & 63)) * 4;
-  const int lds = kWPos * gop + kWPatchPix * 128 + 3 * kWPos * kWColRow + 3 * kWPos * 16;
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  k_dcn_bwd_weight<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, (const _Float16*)offset, partial, (int)batch,
-                                                               (int)channels, (int)height, (int)width, (int)out_channels, ksplit);
-  const int64_t nout = out_channels * channels * 9;
-  k_dcn_bwd_weight_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, st>>>(partial, grad_weight_f32, 1.f, (int)out_channels,
-                                                                         (int)channels, ksplit);
-  S2A_LAUNCH_CHECK();
-  return S2A_OK;
+  S2A_CHECK_ARG(batch == 0 || grad_weight_f32, "deform_conv_backward_weight_f16: NULL tensor");
+  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F16, input, offset, grad_output, nullptr, nullptr, nullptr, grad_weight_f32, 1.f, batch,
+                                channels, height, width, out_channels},
+                   workspace, workspace_bytes, stream, "deform_conv_backward_weight_f16");
 }
 
-// The same for f32 tensors (k_dcn_bwd_weight_f32): grad_weight [O,C,3,3] f32 is the caller's gradWeight, ACCUMULATED in place
-// with `scale` applied (gradWeight += scale * gradOutput x columns^T).  workspace: NHWC copies of input and gradOutput.
+// f32: grad_weight [O,C,3,3] is the caller's gradWeight, += scale * gradOutput x columns^T in place
 extern "C" size_t s2a_deform_conv_backward_weight_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height,
                                                                       int64_t width, int64_t out_channels) {
-  return align_up((size_t)(batch * height * width * channels) * 4) + align_up((size_t)(batch * height * width * out_channels) * 4) +
-         align_up((size_t)kWgradMaxBlocks * out_channels * 192 * 4) + 1024;
+  return fused_bwd_workspace(S2A_DTYPE_F32, false, true, batch, channels, height, width, out_channels);
 }
-
 extern "C" int s2a_deform_conv_backward_weight_f32(const float* input, const float* offset, const float* grad_output,
                                                    float* grad_weight, float scale, int64_t batch, int64_t channels,
                                                    int64_t height, int64_t width, int64_t out_channels, void* workspace,
                                                    size_t workspace_bytes, s2a_stream_t stream) {
-  S2A_CHECK_ARG(batch >= 0 && channels > 0 && height >= 3 && width >= 3 && out_channels > 0, "deform_conv_backward_weight_f32: bad shape");
-  S2A_CHECK_ARG(channels % 64 == 0 && out_channels % 32 == 0 && out_channels <= 256,
-                "deform_conv_backward_weight_f32: needs channels %% 64 == 0, out_channels %% 32 == 0, out_channels <= 256");
-  S2A_CHECK_ARG(height < (1 << 15) && width < (1 << 15), "deform_conv_backward_weight_f32: shape too large");
-  if (batch == 0) return S2A_OK;
-  S2A_CHECK_ARG(input && offset && grad_output && grad_weight, "deform_conv_backward_weight_f32: NULL tensor");
-  S2A_CHECK_ARG(workspace_bytes >= s2a_deform_conv_backward_weight_f32_workspace_bytes(batch, channels, height, width, out_channels),
-                "deform_conv_backward_weight_f32: workspace too small");
-  hipStream_t st = as_stream(stream);
-  Carver cv(workspace, workspace_bytes);
-  const int64_t HW = height * width;
-  float* xn = cv.take<float>((size_t)(batch * HW * channels));
-  float* gn = cv.take<float>((size_t)(batch * HW * out_channels));
-  float* partial = cv.take<float>((size_t)kWgradMaxBlocks * out_channels * 192);
-  S2A_CHECK_ARG(xn && gn && partial, "deform_conv_backward_weight_f32: workspace too small");
-  k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
-      input, (int)channels, HW, xn);
-  k_bwd_nchw_to_nhwc<float><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((out_channels + 31) / 32), (unsigned)batch), 256, 0, st>>>(
-      grad_output, (int)out_channels, HW, gn);
-  const int64_t tiles = batch * ((height + kFTH - 1) / kFTH) * ((width + kFTW - 1) / kFTW);
-  S2A_CHECK_ARG(tiles < (1ll << 31), "deform_conv_backward_weight_f32: too many tiles");
-  const int owners = 3 * (int)(channels / 64);
-  int n_cu = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    S2A_HIP(hipGetDevice(&dev));
-    S2A_HIP(hipGetDeviceProperties(&prop, dev));
-    if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-  }
-  const int ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::min(n_cu, kWgradMaxBlocks) / owners));
-  const int lds = wgrad_f32_lds_bytes();
-  S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  k_dcn_bwd_weight_f32<<<(unsigned)((owners * ksplit + 7) / 8 * 8), kFWThreads, lds, st>>>(xn, gn, offset, partial, (int)batch, (int)channels,
-                                                                                         (int)height, (int)width, (int)out_channels, ksplit);
-  const int64_t nout = out_channels * channels * 9;
-  k_dcn_bwd_weight_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, st>>>(partial, grad_weight, scale, (int)out_channels, (int)channels,
-                                                                         ksplit);
-  S2A_LAUNCH_CHECK();
-  return S2A_OK;
+  S2A_CHECK_ARG(batch == 0 || grad_weight, "deform_conv_backward_weight_f32: NULL tensor");
+  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F32, input, offset, grad_output, nullptr, nullptr, nullptr, grad_weight, scale, batch, channels,
+                                height, width, out_channels},
+                   workspace, workspace_bytes, stream, "deform_conv_backward_weight_f32");
+}
+
+// Both gradients in one call (what DeformConvFunction.backward needs, deform_conv.py:73-118): the NHWC copies of input and
+// gradOutput are made once.  dtype = S2A_DTYPE_F16 / S2A_DTYPE_F32 is the type of input, offset, grad_output, weight and
+// grad_offset; grad_input (f32 [S,C,H,W], accumulated) and grad_weight (f32 [O,C,3,3], += scale * ...) are always f32;
+// either of the two may be NULL to skip that gradient (grad_offset goes with grad_input).
+extern "C" size_t s2a_deform_conv_backward_workspace_bytes(int dtype, int64_t batch, int64_t channels, int64_t height,
+                                                           int64_t width, int64_t out_channels) {
+  return fused_bwd_workspace(dtype, true, true, batch, channels, height, width, out_channels);
+}
+extern "C" int s2a_deform_conv_backward(int dtype, const void* input, const void* offset, const void* grad_output,
+                                        const void* weight, float* grad_input_f32, void* grad_offset, float* grad_weight_f32,
+                                        float scale, int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                        int64_t out_channels, void* workspace, size_t workspace_bytes, s2a_stream_t stream) {
+  return fused_bwd(FusedBwdArgs{dtype, input, offset, grad_output, weight, grad_input_f32, grad_offset, grad_weight_f32, scale, batch,
+                                channels, height, width, out_channels},
+                   workspace, workspace_bytes, stream, "deform_conv_backward");
 }

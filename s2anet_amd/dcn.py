@@ -300,6 +300,38 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
     return 1
 
 
+def _fused_backward_ok(input, offset, weight, grad_output, stride, padding, dilation, groups, deformable_groups):
+    """both gradients in one library call (s2a_deform_conv_backward): AlignConv geometry, f16 / f32, C % 64, O % 32, O <= 256"""
+    B, C, H, W = input.shape
+    O = weight.shape[0]
+    return (input.dtype in (torch.float16, torch.float32) and tuple(weight.shape[2:]) == (3, 3)
+            and stride == (1, 1) and padding == (1, 1) and dilation == (1, 1) and groups == 1 and deformable_groups == 1
+            and C % 64 == 0 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3 and B > 0
+            and offset.shape == (B, 18, H, W) and grad_output.shape == (B, O, H, W)
+            and not os.environ.get("S2A_DCN_BWD_UNFUSED") and not os.environ.get("S2A_DCN_BWD_SEPARATE"))
+
+
+def _fused_backward(input, offset, weight, grad_output):
+    """-> (grad_input, grad_offset, grad_weight) as DeformConvFunction.backward returns them (deform_conv.py:73-118: zeroed
+    gradInput / gradOffset / gradWeight filled by the two backward entry points, scale 1)"""
+    _lib.require_cuda(input, offset, weight, grad_output)
+    B, C, H, W = input.shape
+    O = weight.shape[0]
+    x = input.contiguous()
+    dt = x.dtype
+    off, go, w = offset.to(dt).contiguous(), grad_output.to(dt).contiguous(), weight.to(dt).contiguous()
+    gin = torch.zeros((B, C, H, W), dtype=torch.float32, device=x.device)
+    goff = torch.empty((B, 18, H, W), dtype=dt, device=x.device)
+    gw = torch.zeros((O, C, 3, 3), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    code = _lib.dtype_code(x)
+    ws = _lib.workspace(L.s2a_deform_conv_backward_workspace_bytes(code, B, C, H, W, O), x.device, "dcn_bwd")
+    with torch.cuda.device(x.device):
+        _lib.check(L.s2a_deform_conv_backward(code, _lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(w), _lib.ptr(gin), _lib.ptr(goff),
+                                              _lib.ptr(gw), 1.0, B, C, H, W, O, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
+    return gin.to(input.dtype), goff.to(offset.dtype), gw.to(weight.dtype)
+
+
 class DeformConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1,
@@ -341,6 +373,10 @@ class DeformConvFunction(torch.autograd.Function):
         kH, kW = weight.shape[2], weight.shape[3]
         args = (kW, kH, stride[1], stride[0], padding[1], padding[0], dilation[1], dilation[0], groups,
                 deformable_groups)
+        want_in, want_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if want_in and want_w and _fused_backward_ok(input, offset, weight, grad_output, stride, padding, dilation, groups,
+                                                     deformable_groups):
+            return (*_fused_backward(input, offset, weight, grad_output), None, None, None, None, None, None)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             grad_input = torch.zeros_like(input, memory_format=torch.contiguous_format)
             grad_offset = torch.zeros_like(offset, memory_format=torch.contiguous_format)

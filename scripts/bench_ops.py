@@ -136,9 +136,11 @@ def dcn_backward(batch=8, H=128, W=128, C=256, O=256, dtype=torch.float32, offse
     step = min(64, batch)
     t_in = timeit(lambda: deform_conv_backward_input_cuda(x, off, go, gi, goff, w, None, *args, step), iters=5, warm=2)
     t_w = timeit(lambda: deform_conv_backward_parameters_cuda(x, off, go, gw, None, None, *args, 1.0, step), iters=5, warm=2)
+    from s2anet_amd.dcn import _fused_backward
+    t_both = timeit(lambda: _fused_backward(x, off, w, go), iters=5, warm=2)     # what DeformConvFunction.backward runs
     flops = 2.0 * O * C * 9 * batch * H * W
     return dict(op="deform_conv backward", dtype=str(dtype).split(".")[-1], batch=batch, hw=[H, W], offsets=offsets,
-                input_offset_ms=round(t_in * 1e3, 3), weight_ms=round(t_w * 1e3, 3),
+                input_offset_ms=round(t_in * 1e3, 3), weight_ms=round(t_w * 1e3, 3), both_one_call_ms=round(t_both * 1e3, 3),
                 gemm_tflops_each=round(flops / 1e12, 3),
                 note="two fused kernels per call, no columns tensor: MFMA column gradient consumed in LDS; weight gradient contracted over the positions (f16: transposing LDS reads; f32: v_mfma_f32_16x16x4 / 32x32x2, 155 GFLOP each = 0.99 ms at the f32 MFMA peak)")
 

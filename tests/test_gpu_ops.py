@@ -1866,6 +1866,39 @@ def test_dcn_backward_weight_fused_f32_vs_oracle(rng, monkeypatch):
         assert np.abs(gw).max() > 1.0
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_dcn_backward_autograd_one_call(rng, monkeypatch, dtype):
+    """DeformConvFunction.backward through s2a_deform_conv_backward (both gradients in one library call, the NHWC copies of
+    input and gradOutput shared) == the two entry points called one after the other (deform_conv.py:73-118), and == the
+    oracle; the weight gradient is reduced in a fixed order, so it is bit-identical between the two and from run to run"""
+    from s2anet_amd.dcn import deform_conv
+    td = getattr(torch, dtype)
+    B, C, H, W, O = 2, 64, 13, 21, 32
+    xn = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    wn = (rng.standard_normal((O, C, 3, 3)) * 0.1).astype(np.float32)
+    on = (rng.standard_normal((B, 18, H, W)) * 1.5).astype(np.float32)
+    gn = rng.standard_normal((B, O, H, W)).astype(np.float32)
+    if dtype == "float16":
+        xn, wn, on, gn = (a.astype(np.float16).astype(np.float32) for a in (xn, wn, on, gn))
+    gx, goff, gw = oracle.deform_conv_backward(xn, on, wn, gn)
+    res = {}
+    for mode in ("one-call", "one-call-again", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("S2A_DCN_BWD_SEPARATE", "1")
+        else:
+            monkeypatch.delenv("S2A_DCN_BWD_SEPARATE", raising=False)
+        x, off, w = (cu(a).to(td).requires_grad_(True) for a in (xn, on, wn))
+        deform_conv(x, off, w, 1, 1, 1, 1, 1).backward(cu(gn).to(td))
+        res[mode] = tuple(t.grad.float().cpu().numpy() for t in (x, off, w))
+        assert x.grad.dtype == td and off.grad.dtype == td and w.grad.dtype == td
+    tol = 1e-4 if dtype == "float32" else 6e-3
+    for mode, (a, b, c) in res.items():
+        for got, ref in ((a, gx), (b, goff), (c, gw)):
+            assert np.abs(got - ref).max() < tol * max(1.0, np.abs(ref).max()), (mode, np.abs(got - ref).max(), np.abs(ref).max())
+    assert np.array_equal(res["one-call"][2], res["one-call-again"][2]) and np.array_equal(res["one-call"][2], res["separate"][2])
+    assert np.array_equal(res["one-call"][1], res["separate"][1])
+
+
 def test_assign_labels_fused(rng):
     """fused label assignment == the reference's assign_labels (golden from its own Python on its CPU IoU op;
     the two sort branches of the IoU agree on these inputs) and == the oracle on fresh inputs"""
