@@ -997,58 +997,77 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
   // registers that carry the NEXT tile's gradOutput tile and patch (issued a tile ahead)
   constexpr int kGoVec = 5, kPaVec = 5;                       // 16-byte vectors per thread: 64 * 32 / 512 = 4 (O = 256), 288 * 8 / 512 = 4.5
   f16x8b gv[kGoVec], pvv[kPaVec];
-  auto tile_geom = [&](int tile, int& b, int& ty0, int& tx0) {
-    tx0 = (tile % txn) * kBTW;
-    const int r = tile / txn;
-    ty0 = (r % tyn) * kBTH;
-    b = r / tyn;
+  // Everything about a thread's vectors that does not depend on the tile is worked out once (position / channel group of
+  // its gradOutput vectors, window row / column of its patch vectors, their LDS addresses), and the tile coordinates are
+  // carried and advanced by ksplit tiles: the per-tile divisions (v / ovec with a run-time ovec, tile -> image / row / column)
+  // were several hundred instructions per thread and tile in a kernel whose tile has 0.26 k cycles of MFMA.
+  struct TilePos { int b, ty, tx; };             // image, tile row, tile column
+  TilePos cur;
+  {
+    const int tile = min(slice, ntiles - 1), r = tile / txn;
+    cur.tx = tile % txn; cur.ty = r % tyn; cur.b = r / tyn;
+  }
+  auto advance = [&](TilePos& p) {
+    p.tx += ksplit;
+    while (p.tx >= txn) {
+      p.tx -= txn;
+      if (++p.ty == tyn) { p.ty = 0; ++p.b; }
+    }
   };
-  auto issue = [&](int tile) {
-    int b, ty0, tx0;
-    tile_geom(tile, b, ty0, tx0);
+  const int ovec = O / 8;
+  int g_yx[kGoVec], g_ch[kGoVec], g_lds[kGoVec], p_yx[kPaVec];     // y << 8 | x inside the tile / the window; -1: no such vector
+#pragma unroll
+  for (int i = 0; i < kGoVec; i++) {
+    const int v = tid + 512 * i;
+    const int pos = v / ovec, ch = v % ovec;
+    g_yx[i] = v < kWPos * ovec ? ((pos >> 4) << 8 | (pos & 15)) : -1;
+    g_ch[i] = ch * 8;
+    g_lds[i] = pos * gop + ch * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < kPaVec; i++) {
+    const int v = tid + 512 * i, pp = v >> 3;
+    p_yx[i] = v < kWPatchPix * 8 ? ((pp / kBPW) << 8 | (pp % kBPW)) : -1;
+  }
+  float off_yx[2] = {0.f, 0.f};                  // the table threads' two offsets, requested a tile ahead
+  auto issue = [&](const TilePos& tp_) {
+    const int b = tp_.b, ty0 = tp_.ty * kBTH, tx0 = tp_.tx * kBTW;
     const int oy = ty0 - 3, ox = tx0 - 3;
-    const int ovec = O / 8;
+    const _Float16* gb = go + (int64_t)b * HW * O;
+    const _Float16* xb = x + (int64_t)b * HW * C + cc * 64 + (tid & 7) * 8;
 #pragma unroll
     for (int i = 0; i < kGoVec; i++) {
-      const int v = tid + 512 * i;
       gv[i] = f16x8b{};
-      if (v < kWPos * ovec) {
-        const int pos = v / ovec, ch = v % ovec;
-        const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
-        if (y < H && xq < W) gv[i] = *reinterpret_cast<const f16x8b*>(go + ((int64_t)b * HW + (int64_t)y * W + xq) * O + ch * 8);
-      }
+      const int y = ty0 + (g_yx[i] >> 8), xq = tx0 + (g_yx[i] & 255);
+      if (g_yx[i] >= 0 && y < H && xq < W) gv[i] = *reinterpret_cast<const f16x8b*>(gb + ((int64_t)y * W + xq) * O + g_ch[i]);
     }
 #pragma unroll
     for (int i = 0; i < kPaVec; i++) {
-      const int v = tid + 512 * i;
       pvv[i] = f16x8b{};
-      if (v < kWPatchPix * 8) {
-        const int p = v >> 3, q = v & 7;
-        const int yy = oy + p / kBPW, xx = ox + p % kBPW;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-          pvv[i] = *reinterpret_cast<const f16x8b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8);
-      }
+      const int yy = oy + (p_yx[i] >> 8), xx = ox + (p_yx[i] & 255);
+      if (p_yx[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) pvv[i] = *reinterpret_cast<const f16x8b*>(xb + ((int64_t)yy * W + xx) * C);
+    }
+    if (tid < 3 * kWPos) {
+      const int tl = tid / kWPos, pos = tid % kWPos, t = ky * 3 + tl;
+      const int y = min(ty0 + (pos >> 4), H - 1), xq = min(tx0 + (pos & 15), W - 1);
+      const _Float16* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
+      off_yx[0] = (float)ob[(int64_t)(2 * t) * HW];
+      off_yx[1] = (float)ob[(int64_t)(2 * t + 1) * HW];
     }
   };
   auto land = [&]() {
-    const int ovec = O / 8;
 #pragma unroll
-    for (int i = 0; i < kGoVec; i++) {
-      const int v = tid + 512 * i;
-      if (v < kWPos * ovec) *reinterpret_cast<f16x8b*>(s_go + (v / ovec) * gop + (v % ovec) * 16) = gv[i];
-    }
+    for (int i = 0; i < kGoVec; i++)
+      if (g_yx[i] >= 0) *reinterpret_cast<f16x8b*>(s_go + g_lds[i]) = gv[i];
 #pragma unroll
-    for (int i = 0; i < kPaVec; i++) {
-      const int v = tid + 512 * i;
-      if (v < kWPatchPix * 8) *reinterpret_cast<f16x8b*>(s_patch + v * 16) = pvv[i];
-    }
+    for (int i = 0; i < kPaVec; i++)
+      if (p_yx[i] >= 0) *reinterpret_cast<f16x8b*>(s_patch + (tid + 512 * i) * 16) = pvv[i];
   };
 
   int tile = slice;
-  if (tile < ntiles) issue(tile);
+  if (tile < ntiles) issue(cur);
   for (; tile < ntiles; tile += ksplit) {
-    int b, ty0, tx0;
-    tile_geom(tile, b, ty0, tx0);
+    const int b = cur.b, ty0 = cur.ty * kBTH, tx0 = cur.tx * kBTW;
     const int oy = ty0 - 3, ox = tx0 - 3;
     __syncthreads();                             // the previous tile's operands have been read
     land();
@@ -1059,8 +1078,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
       tp.y = 0; tp.x = 0; tp.flags = 0u;
       for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
       if (y < H && xq < W) {
-        const _Float16* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
-        const float off_y = (float)ob[(int64_t)(2 * t) * HW], off_x = (float)ob[(int64_t)(2 * t + 1) * HW];
+        const float off_y = off_yx[0], off_x = off_yx[1];
         const float h_im = (float)(y - 1 + ky) + off_y, w_im = (float)(xq - 1 + tl) + off_x;
         if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
           const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
@@ -1080,7 +1098,10 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
       s_tab[tid] = tp;
     }
     __syncthreads();
-    if (tile + ksplit < ntiles) issue(tile + ksplit);      // next tile's loads: in flight under the blend and the MFMAs
+    if (tile + ksplit < ntiles) {                // next tile's loads: in flight under the blend and the MFMAs
+      advance(cur);
+      issue(cur);
+    }
     // ---- column tiles of the three taps: item = (tap, position, 8-channel group)
     for (int it = tid; it < 3 * kWPos * 8; it += 512) {
       const int tl = it >> 9, r = it & 511, pos = r >> 3, q = r & 7;
