@@ -351,27 +351,33 @@ def measure_ops(dev, with_cpu=True):
     ops["ml_nms_rotated_5k_x_15"] = {"us": round(sec5 * 1e6, 1), "keep": int(keep5.numel()),
                                      "note": "synchronous drop-in call incl. the host's wait for the count; one kernel launch"}
     del d, sc, lab, d5, s5, l5
-    # SURVEY 8(f) row 1 at the AlignConv shape: deform_conv backward, P3 x batch 8, f16, AlignConv-like offsets
-    try:
-        from s2anet_amd.alignconv import align_offsets
-        from s2anet_amd.dcn import deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda
-        Bb = 8
-        xb = torch.randn(Bb, C, H, W, generator=g).to(dev).half()
-        ancb = anc.expand(Bb, -1, -1, -1).contiguous().view(Bb, -1, 5)
-        offb = align_offsets(ancb, (H, W), 8, 3).half().contiguous()
-        wb = w32.to(dev).half()
-        gob = torch.randn(Bb, O, H, W, generator=g).to(dev).half()
-        gi, goff, gw = torch.zeros_like(xb), torch.zeros_like(offb), torch.zeros_like(wb)
-        args = (3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
-        t_in = _time_launches(lambda: deform_conv_backward_input_cuda(xb, offb, gob, gi, goff, wb, None, *args, Bb), iters=5)
-        t_w = _time_launches(lambda: deform_conv_backward_parameters_cuda(xb, offb, gob, gw, None, None, *args, 1.0, Bb), iters=5)
-        ops["deform_conv_backward_8x256x128x128_f16"] = {
-            "input_offset_ms": round(t_in * 1e3, 3), "weight_ms": round(t_w * 1e3, 3),
-            "GFLOP_each": round(2.0 * O * C * 9 * Bb * H * W / 1e9, 1),
-            "note": "fused kernels, no columns tensor (host-side tensor conversions included)"}
-        del xb, offb, gob, gi, goff, gw
-    except Exception as e:          # a report, never a reason to lose the line
-        ops["deform_conv_backward_8x256x128x128_f16"] = {"failed": repr(e)}
+    # SURVEY 8(f) row 1 at the AlignConv shape: deform_conv backward, P3 x batch 8, f16 and f32, AlignConv-like offsets
+    for dt, tag in ((torch.float16, "f16"), (torch.float32, "f32")):
+        key = "deform_conv_backward_8x256x128x128_" + tag
+        try:
+            from s2anet_amd.alignconv import align_offsets
+            from s2anet_amd.dcn import deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda, _fused_backward
+            Bb = 8
+            xb = torch.randn(Bb, C, H, W, generator=g).to(dev, dt)
+            ancb = anc.expand(Bb, -1, -1, -1).contiguous().view(Bb, -1, 5)
+            offb = align_offsets(ancb, (H, W), 8, 3).to(dt).contiguous()
+            wb = w32.to(dev, dt)
+            gob = torch.randn(Bb, O, H, W, generator=g).to(dev, dt)
+            gi, goff, gw = torch.zeros_like(xb), torch.zeros_like(offb), torch.zeros_like(wb)
+            args = (3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+            t_in = _time_launches(lambda: deform_conv_backward_input_cuda(xb, offb, gob, gi, goff, wb, None, *args, Bb), iters=5)
+            t_w = _time_launches(lambda: deform_conv_backward_parameters_cuda(xb, offb, gob, gw, None, None, *args, 1.0, Bb), iters=5)
+            t_both = _time_launches(lambda: _fused_backward(xb, offb, wb, gob), iters=5)
+            flop = 2.0 * O * C * 9 * Bb * H * W
+            ops[key] = {
+                "input_offset_ms": round(t_in * 1e3, 3), "weight_ms": round(t_w * 1e3, 3), "both_one_call_ms": round(t_both * 1e3, 3),
+                "GFLOP_each": round(flop / 1e9, 1),
+                "mfma_frac_one_call": round(2 * flop / t_both / 1e12 / (PEAK_F16_TFLOPS if dt == torch.float16 else PEAK_F32_TFLOPS), 4),
+                "note": "fused kernels, no columns tensor, weight gradient without atomics (host-side tensor conversions included); "
+                        "one call = what DeformConvFunction.backward runs"}
+            del xb, offb, gob, gi, goff, gw
+        except Exception as e:          # a report, never a reason to lose the line
+            ops[key] = {"failed": repr(e)}
     if with_cpu:
         try:
             ops["cpu_reference"] = _ops_cpu_figures()

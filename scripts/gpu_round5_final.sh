@@ -40,6 +40,9 @@ import json
 d=json.load(open('$O/bench_s1_graph.json')); print('graph replay, 1 stream', d['value'], d['ms_per_step'])"
 echo "== half decode / NMS effect"; timeout -k 10 300 python scripts/half_nms_effect.py > $O/half_nms_effect.log 2>&1; tail -1 $O/half_nms_effect.log | cut -c1-400
 echo "== clock probe"; timeout -k 10 300 python scripts/pyr_power_probe.py > $O/pyr_power_probe.jsonl 2>/dev/null; cat $O/pyr_power_probe.jsonl
+echo "== deform-conv backward: kernel trace + stamps of the f32 weight kernel"
+bash scripts/prof_cmd.sh bwd scripts/bench_ops.py --which bwd > $O/dcn_backward_kernel_stats.txt 2>&1; grep '"op"' gpurun_out/prof_bwd/run.log | cut -c1-260 >> $O/dcn_backward_kernel_stats.txt; tail -3 $O/dcn_backward_kernel_stats.txt | cut -c1-200
+bash scripts/bwd32_stamps.sh 2>&1 | grep -v amdgpu.ids > $O/dcn_backward_f32_weight_stamps.txt; cat $O/dcn_backward_f32_weight_stamps.txt
 cp gpurun_out/f16_fixture_hashes.json $O/ 2>/dev/null
 # keep what comes home under 64 MiB: the raw per-dispatch counter / trace tables are summarised above
 find $R/gpurun_out -type f \( -name "*_counter_collection.csv" -o -name "*kernel_trace.csv" -o -name "*.db" -o -name "*.rocpd" -o -name "*_agent_info.csv" \) -delete

@@ -73,4 +73,11 @@ with open(os.path.join(P, RN + "_ops_report.jsonl"), "w") as f:
 copy(os.path.join(G, "half_nms_effect.json"), "_half_nms_effect.json")
 copy(os.path.join(F, "pyr_power_probe.jsonl"), "_alignconv_clock_probe.jsonl")
 copy(os.path.join(F, "f16_fixture_hashes.json"), "_f16_fixture_hashes.json")
+with open(os.path.join(P, RN + "_dcn_backward_kernel_stats.txt"), "w") as f:
+    f.write("# deform_conv backward at P3 x 8 (tree %s): `rocprofv3 --kernel-trace --stats` over `python scripts/bench_ops.py --which bwd`\n"
+            "# (f32, f16, f16 with wild offsets: the average of k_dcn_bwd_input covers the last two), the op lines of that run, and the\n"
+            "# in-kernel phase stamps of k_dcn_bwd_weight_f32 (scripts/bwd32_stamps.sh, -DS2A_MEASURE build)\n" % head)
+    f.write(cat(os.path.join(F, "dcn_backward_kernel_stats.txt")))
+    f.write("\n# k_dcn_bwd_weight_f32, cycles per 32-position tile (12.3 k of them MFMA):\n")
+    f.write(cat(os.path.join(F, "dcn_backward_f32_weight_stamps.txt")))
 print("published for", head)
