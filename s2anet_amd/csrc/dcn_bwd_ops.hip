@@ -548,7 +548,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
     }
     // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels
     for (int wi = tid; wi < ((S2A_BWD_ABL & 2) ? 0 : 4 * kBPix); wi += 512) {
-      const int q = wi / kBPix, pix = wi % kBPix;
+      const int q = wi / kBPix, pix = wi % kBPix;      // (lanes = pixels of ONE channel group: with the four groups of a pixel in
+                                                       // neighbouring lanes the atomics scatter over four planes: 1.36 -> 1.53 ms)
       const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
       if (l0 == l1) continue;
       float a8[8];
