@@ -1783,6 +1783,7 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
   }
   if (want_weight) {
     const int owners = 3 * (int)(C / 64);
+    S2A_CHECK_ARG(owners <= kWgradMaxBlocks, "%s: the fused weight gradient takes channels <= %d", who, kWgradMaxBlocks / 3 * 64);
     int n_cu = 256;
     {
       int dev = 0;

@@ -259,7 +259,7 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
     # f16 + AlignConv geometry: ONE fused kernel for the whole batch (columns formed and contracted in LDS, positions as the
     # MFMA's K through transposing LDS reads, split-K atomics): s2a_deform_conv_backward_weight_f16
     fused = (x.dtype == torch.float16 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)
-             and group == 1 and deformable_group == 1 and C % 64 == 0 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3
+             and group == 1 and deformable_group == 1 and C % 64 == 0 and C <= 4096 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3
              and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
     if fused:
         acc = torch.zeros((O, C, 3, 3), dtype=torch.float32, device=x.device)
@@ -272,7 +272,7 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
     # f32 + AlignConv geometry: the same dataflow on v_mfma_f32_32x32x2_f32 (s2a_deform_conv_backward_weight_f32), scaled and
     # accumulated straight into the caller's gradWeight when it is an f32 contiguous tensor
     fused32 = (x.dtype == torch.float32 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)
-               and group == 1 and deformable_group == 1 and C % 64 == 0 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3
+               and group == 1 and deformable_group == 1 and C % 64 == 0 and C <= 4096 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3
                and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
     if fused32:
         direct = (gradWeight.dtype == torch.float32 and gradWeight.is_contiguous() and gradWeight.numel() == O * C * 9
@@ -306,7 +306,7 @@ def _fused_backward_ok(input, offset, weight, grad_output, stride, padding, dila
     O = weight.shape[0]
     return (input.dtype in (torch.float16, torch.float32) and tuple(weight.shape[2:]) == (3, 3)
             and stride == (1, 1) and padding == (1, 1) and dilation == (1, 1) and groups == 1 and deformable_groups == 1
-            and C % 64 == 0 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3 and B > 0
+            and C % 64 == 0 and C <= 4096 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3 and B > 0
             and offset.shape == (B, 18, H, W) and grad_output.shape == (B, O, H, W)
             and not os.environ.get("S2A_DCN_BWD_UNFUSED") and not os.environ.get("S2A_DCN_BWD_SEPARATE"))
 
