@@ -254,6 +254,10 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
 constexpr int kBTH = 4, kBTW = 16, kBPos = kBTH * kBTW, kBHalo = 4;
 constexpr int kBPH = kBTH + 2 * kBHalo, kBPW = kBTW + 2 * kBHalo, kBPix = kBPH * kBPW;   // 12 x 24 = 288
 constexpr int kBCh = 32;                       // input channels per chunk
+#ifndef S2A_BWD_THREADS
+#define S2A_BWD_THREADS 1024
+#endif
+constexpr int kBThreads = S2A_BWD_THREADS;     // k_dcn_bwd_input: 512 or 1024 (the passes between the MFMA jobs are latency-bound loops)
 constexpr int kBGRow = kBCh + 4;               // floats per (tap, position) row of the column-gradient tiles: 144 B -- with 128-B rows every
                                                // lane of the gather pass read the SAME 8 banks (its channel group of a different row):
                                                // the pass took 19 k cycles per chunk for ~2 k cycles of instructions
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256) void k_bwd_nchw_to_nhwc(const T* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __restrict__ x,        // NHWC [S,H,W,C]
+__global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __restrict__ x,        // NHWC [S,H,W,C]
                                                          const _Float16* __restrict__ go,       // NHWC [S,H,W,O]
                                                          const _Float16* __restrict__ offset,   // NCHW [S,18,H,W]
                                                          const _Float16* __restrict__ wpk,
@@ -335,16 +339,16 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
   const int KS = O / 16, CC = C / kBCh;
 
   // ---- gradOutput tile -> LDS (positions outside the image: zeros), offset-gradient accumulators, sampling table
-  for (int v = tid; v < kBPos * (O / 8); v += 512) {
+  for (int v = tid; v < kBPos * (O / 8); v += kBThreads) {
     const int pos = v / (O / 8), ch = v % (O / 8);
     const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
     f16x8b d = {};
     if (y < H && xq < W) d = *reinterpret_cast<const f16x8b*>(go + ((int64_t)b * HW + (int64_t)y * W + xq) * O + ch * 8);
     *reinterpret_cast<f16x8b*>(s_go + pos * kBGoRow + ch * 16) = d;
   }
-  for (int e = tid; e < kBPos * 9 * 2; e += 512) s_goff[e] = 0.f;
-  for (int e = tid; e <= kBPix; e += 512) s_start[e] = 0u;
-  for (int e = tid; e < kBPos * 9; e += 512) {
+  for (int e = tid; e < kBPos * 9 * 2; e += kBThreads) s_goff[e] = 0.f;
+  for (int e = tid; e <= kBPix; e += kBThreads) s_start[e] = 0u;
+  for (int e = tid; e < kBPos * 9; e += kBThreads) {
     const int pos = e / 9, t = e % 9;
     const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
     BTap tp;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
   // global atomic per cell.  (The first version added w * G into an f32 LDS window with ds_add_f32, 32 per item: LDS
   // float atomics retire about a lane every 2-3 cycles, 6.7 ms per P3 x 8 call against 2.5 ms with three quarters of them
   // skipped.)
-  for (int e = tid; e < kBPos * 9; e += 512) {
+  for (int e = tid; e < kBPos * 9; e += kBThreads) {
     const BTap tp = s_tab[e];
     if ((tp.flags & 3u) != 3u) continue;
     const int pix = (int)(tp.flags >> 2);
@@ -406,9 +410,9 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
     }
   }
   __syncthreads();
-  for (int e = tid; e < kBPix; e += 512) s_cur[e] = s_start[e];
+  for (int e = tid; e < kBPix; e += kBThreads) s_cur[e] = s_start[e];
   __syncthreads();
-  for (int e = tid; e < kBPos * 9; e += 512) {
+  for (int e = tid; e < kBPos * 9; e += kBThreads) {
     const BTap tp = s_tab[e];
     if ((tp.flags & 3u) != 3u) continue;
     const int pix = (int)(tp.flags >> 2), pos = e / 9, t = e % 9;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
   auto patch_issue = [&](int cc) {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const int v = tid + 512 * i, p = v >> 2, q = v & 3;
+      const int v = tid + kBThreads * i, p = v >> 2, q = v & 3;
       pv[i] = f16x8b{};
       if (v < kBPix * 4) {
         const int yy = oy + p / kBPW, xx = ox + p % kBPW;
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
   auto patch_write = [&]() {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const int v = tid + 512 * i;
+      const int v = tid + kBThreads * i;
       if (v < kBPix * 4) *reinterpret_cast<f16x8b*>(s_patch + v * 16) = pv[i];
     }
   };
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
     patch_write();
     if (cc + 1 < CC) patch_issue(cc + 1);        // (in flight under this chunk's work)
     // ---- column-gradient tiles of the nine taps on the matrix cores: job = (tap, 32-position half), 18 jobs over 8 waves
-    for (int job = wave; job < ((S2A_BWD_ABL & 8) ? 0 : 18); job += 8) {
+    for (int job = wave; job < ((S2A_BWD_ABL & 8) ? 0 : 18); job += kBThreads / 64) {
       const int t = job >> 1, ph = job & 1;
       const f16x8b* ap = reinterpret_cast<const f16x8b*>(wpk) + ((int64_t)(t * CC + cc) * KS) * 64 + lane;
       const char* bp = s_go + (ph * 32 + (lane & 31)) * kBGoRow + (lane >> 5) * 16;
@@ -456,27 +460,28 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
       for (int r = 0; r < 16; r++) acc[r] = 0.f;
       // the filter fragments come from L2: requested in batches of four right in front of their MFMAs they exposed that
       // latency four times per job (11.5 k cycles per chunk for 2.3 k of MFMA) -- a batch of eight is in flight one batch ahead
-      f16x8b a0[8], a1[8];
-      auto load_a = [&](int k0, f16x8b (&a)[8]) {
+      constexpr int kAB = kBThreads >= 1024 ? 4 : 8;       // (a 1024-thread workgroup has 128 registers per lane)
+      f16x8b a0[kAB], a1[kAB];
+      auto load_a = [&](int k0, f16x8b (&a)[kAB]) {
 #pragma unroll
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < kAB; k++)
           if (k0 + k < KS) a[k] = ap[(int64_t)(k0 + k) * 64];
       };
-      auto run = [&](int k0, const f16x8b (&a)[8]) {
-        f16x8b bb[8];
+      auto run = [&](int k0, const f16x8b (&a)[kAB]) {
+        f16x8b bb[kAB];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < kAB; k++)
           if (k0 + k < KS) bb[k] = *reinterpret_cast<const f16x8b*>(bp + (k0 + k) * 32);
 #pragma unroll
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < kAB; k++)
           if (k0 + k < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k], bb[k], acc, 0, 0, 0);
       };
       load_a(0, a0);
-      for (int k0 = 0; k0 < KS; k0 += 16) {
-        if (k0 + 8 < KS) load_a(k0 + 8, a1);
+      for (int k0 = 0; k0 < KS; k0 += 2 * kAB) {
+        if (k0 + kAB < KS) load_a(k0 + kAB, a1);
         run(k0, a0);
-        if (k0 + 16 < KS) load_a(k0 + 16, a0);
-        if (k0 + 8 < KS) run(k0 + 8, a1);
+        if (k0 + 2 * kAB < KS) load_a(k0 + 2 * kAB, a0);
+        if (k0 + kAB < KS) run(k0 + kAB, a1);
       }
       // D rows = channels (4 consecutive per register quad), columns = positions
       float* gp = s_G + (t * kBPos + ph * 32 + (lane & 31)) * kBGRow + 4 * (lane >> 5);
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
     }
     __syncthreads();
     // ---- offset gradient: items (tap, position, 8-channel group); the four lanes of a position are neighbours
-    for (int it = tid; it < ((S2A_BWD_ABL & 4) ? 0 : 9 * kBPos * 4); it += 512) {
+    for (int it = tid; it < ((S2A_BWD_ABL & 4) ? 0 : 9 * kBPos * 4); it += kBThreads) {
       const int t = it >> 8, r = it & 255, pos = r >> 2, q = r & 3;
       const BTap tp = s_tab[pos * 9 + t];
       if (!(tp.flags & 1u)) continue;            // (the four lanes of a position decide alike)
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
       }
     }
     // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels
-    for (int wi = tid; wi < ((S2A_BWD_ABL & 2) ? 0 : 4 * kBPix); wi += 512) {
+    for (int wi = tid; wi < ((S2A_BWD_ABL & 2) ? 0 : 4 * kBPix); wi += kBThreads) {
       const int q = wi / kBPix, pix = wi % kBPix;      // (lanes = pixels of ONE channel group: with the four groups of a pixel in
                                                        // neighbouring lanes the atomics scatter over four planes: 1.36 -> 1.53 ms)
       const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_input(const _Float16* __rest
   }
   __syncthreads();
   // ---- offset gradient of the tile: [S, 18, H, W], channel 2 t = dy, 2 t + 1 = dx
-  for (int i = tid; i < 18 * kBPos; i += 512) {
+  for (int i = tid; i < 18 * kBPos; i += kBThreads) {
     const int ch = i / kBPos, pos = i % kBPos;
     const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
     if (y < H && xq < W)
@@ -1763,7 +1768,7 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
       const int64_t tiles = B * ((H + kBTH - 1) / kBTH) * ((W + kBTW - 1) / kBTW);
       S2A_CHECK_ARG(tiles < (1ll << 31), "%s: too many tiles", who);
       S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
-      k_dcn_bwd_input<<<(unsigned)tiles, 512, kBwdLds, st>>>(xn, gn, (const _Float16*)a.offset, wp, a.grad_input, (_Float16*)a.grad_offset,
+      k_dcn_bwd_input<<<(unsigned)tiles, kBThreads, kBwdLds, st>>>(xn, gn, (const _Float16*)a.offset, wp, a.grad_input, (_Float16*)a.grad_offset,
                                                             (int)B, (int)C, (int)H, (int)W, (int)O);
     } else {
       k_pack_weight_bwd_f32<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>((const float*)a.weight, (int)O, (int)C, wp);
