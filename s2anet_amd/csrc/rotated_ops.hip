@@ -3255,6 +3255,9 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     if (ss) S2A_HIP(hipStreamWaitEvent(q, ss->fork, 0));
     int rc = sort_c(q);
     if (rc != S2A_OK) return rc;
+    // ONE join for the main stream: the output-order queue also waits for the score-order queue, so its event covers both
+    // (every cross-stream wait is a ~6 us bubble in the waiting queue; the two side queues finish long before they are needed)
+    if (ss && spatial) S2A_HIP(hipStreamWaitEvent(q, ss->join[0], 0));
     if (ss) S2A_HIP(hipEventRecord(ss->join[1], q));
   } else {
     B.perm_glob = B.perm_seg;
@@ -3271,12 +3274,12 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   k_nms_finish_segments<<<512, kFinThreads, 0, st>>>(B.C, B.seg_start, B.num_seg, B.gq, pl.queue_cap, B.edges, pl.edge_cap,
                                                      B.state, B.blocked, n, spatial ? B.keyB_s : B.keyA_s, spatial ? 20 : 32,
                                                      ignore_key, use_ignore, force_global);
-  if (ss && spatial) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
+  if (ss && need_c) S2A_HIP(hipStreamWaitEvent(st, ss->join[1], 0));
+  else if (ss && spatial) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
   k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, spatial ? B.seg_start_a : B.seg_start, spatial ? B.num_seg_a : B.num_seg,
                                                 B.keyA_s, ignore_key, use_ignore, B.C,
                                                 pair_cap, pl.edge_cap, pl.tile_cap, B.state_fb, thr);
   k_nms_finish<<<g, 256, 0, st>>>(B.state, B.blocked, B.C, perm, B.state_fb, B.perm_seg, n, B.keep_orig);
-  if (ss && need_c) S2A_HIP(hipStreamWaitEvent(st, ss->join[1], 0));
   S2A_LAUNCH_CHECK();
   return S2A_OK;
 }
