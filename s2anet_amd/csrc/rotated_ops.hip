@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256) void k_spb_hist(const unsigned long long* __re
   }
 }
 // pass 3: exclusive scan of the histogram in two levels -- a wave per group of 64 buckets (in place, group total aside),
-// then one workgroup over the <= 1 024 group totals.  (One workgroup over 61 k buckets took 75 us, uncoalesced; the scan as
+// then the <= 1 024 group totals, by every workgroup of pass 4 for itself.  (One workgroup over 61 k buckets took 75 us, uncoalesced; the scan as
 // the last act of the LAST workgroup of pass 2 -- fence, ticket, scan -- 97 us: a device-scope release per workgroup writes
 // the XCD's dirty L2 lines back 782 times.)
 __global__ __launch_bounds__(256) void k_spb_scan1(uint32_t* __restrict__ hist, uint32_t* __restrict__ group_sum, int64_t n) {
@@ -774,32 +774,45 @@ __global__ __launch_bounds__(256) void k_spb_scan1(uint32_t* __restrict__ hist, 
   hist[g * 64 + lane] = incl - v;
   if (lane == 63) group_sum[g] = incl;
 }
-__global__ __launch_bounds__(1024) void k_spb_scan2(uint32_t* __restrict__ group_sum, int64_t n) {
-  __shared__ unsigned s_w[16];
-  const uint32_t groups = spb_buckets(n) / 64;                 // 16 .. 1024
-  const unsigned v = threadIdx.x < groups ? group_sum[threadIdx.x] : 0u;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) s_w[wave] = incl;
-  __syncthreads();
-  unsigned base = incl - v;
-  for (int w = 0; w < wave; w++) base += s_w[w];
-  if (threadIdx.x < groups) group_sum[threadIdx.x] = base;
-}
-// pass 4: rows into their places
+// pass 4: rows into their places.  The second level of the scan (<= 1 024 group totals) is done by every workgroup for itself
+// in LDS -- 4 KB of L2 reads and a block scan instead of a launch of its own (k_spb_scan2, 4.6 us of launch-paced time)
 __global__ __launch_bounds__(256) void k_spb_scatter(const unsigned long long* __restrict__ keyB, int64_t n,
-                                                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ group_base,
+                                                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ group_sum,
                                                      const uint32_t* __restrict__ bucket, const uint32_t* __restrict__ rank,
                                                      unsigned long long* __restrict__ keyB_s, int32_t* __restrict__ perm_sp) {
+  __shared__ unsigned s_base[1024];
+  __shared__ unsigned s_w[4];
+  {
+    const uint32_t groups = spb_buckets(n) / 64;               // 16 .. 1024
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned v[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t g = threadIdx.x * 4 + k;
+      v[k] = g < groups ? group_sum[g] : 0u;
+      tot += v[k];
+    }
+    unsigned incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned base = incl - tot;
+    for (int w = 0; w < wave; w++) base += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      s_base[threadIdx.x * 4 + k] = base;
+      base += v[k];
+    }
+    __syncthreads();
+  }
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   const uint32_t b = bucket[p];
-  const uint32_t pos = group_base[b >> 6] + hist[b] + rank[p];
+  const uint32_t pos = s_base[b >> 6] + hist[b] + rank[p];
   keyB_s[pos] = keyB[p];
   perm_sp[pos] = (int32_t)p;
 }
@@ -3201,7 +3214,6 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     if (own_sort) {
       k_spb_hist<<<g, 256, 0, st>>>(B.keyB, n, B.htab, B.spb_ctr, B.hist, B.bucket, B.rank, B.C, ignore_key, use_ignore);
       k_spb_scan1<<<kSpbGroups / 4, 256, 0, st>>>(B.hist, B.hist + kSpbHist + 64, n);
-      k_spb_scan2<<<1, 1024, 0, st>>>(B.hist + kSpbHist + 64, n);
       k_spb_scatter<<<g, 256, 0, st>>>(B.keyB, n, B.hist, B.hist + kSpbHist + 64, B.bucket, B.rank, B.keyB_s, B.perm_sp);
     } else {
       size_t rpb = pl.rocprim_bytes;
