@@ -957,7 +957,8 @@ __global__ __launch_bounds__(512) void k_dcn_bwd_input_f32(const float* __restri
 // ever transposed in software.
 //   * a workgroup owns ONE 64-channel chunk and ONE row of three taps and a slice of the position tiles (split-K: 21 slices
 //     x 12 owners = 252 workgroups on 256 CUs); its 3 x [O x 64] f32 results stay in registers over all its tiles
-//     (8 waves x 6 accumulator tiles) and go out once, as global f32 atomics;
+//     (8 waves x 6 accumulator tiles) and go out once, as a coalesced [O][3][64] block per workgroup that
+//     k_dcn_bwd_weight_reduce sums over the slices (no atomics);
 //   * per 4 x 16 position tile: gradOutput tile and the input patch of the chunk arrive in LDS (the NEXT tile's are already
 //     in flight in registers), the eight waves blend the three taps' column tiles into LDS (bilinear corners from the patch,
 //     as the forward does), then read both operands with transposing reads: 24 MFMAs per wave and tile.
@@ -1207,11 +1208,12 @@ __global__ __launch_bounds__(256) void k_dcn_bwd_weight_reduce(const float* __re
 // is one value per lane -- lane (l & 31, l >> 5) reads element l & 31 of row 2 ks + (l >> 5): 32 consecutive floats per half
 // wave, the two rows a pitch apart that is 32 (mod 64) floats, so the 64 lanes cover the 64 banks.
 // A workgroup owns ONE 64-channel chunk and ONE row of three taps and a slice of the 4 x 8 position tiles (12 owners x 21
-// slices = 252 workgroups); its 3 x [O x 64] f32 results stay in registers over all its tiles and go out once, as scaled
-// f32 atomics (gradWeight += scale * ..., deform_conv_cuda.cpp:455-459).  Twelve waves in two roles:
-//   * waves 0-7 (two per SIMD) own out channels 32 w .. 32 w + 31 and only run MFMAs: 16 k-steps x 6 MFMAs per tile, the
-//     column operand from LDS (requested one k-step ahead), the gradOutput operand straight from memory -- in NHWC a half
-//     wave's 32 out channels of one position are 128 contiguous bytes, and a wave needs just 16 values per lane and tile,
+// slices = 252 workgroups); its 3 x [O x 64] f32 results stay in registers over all its tiles and go out once, as a block
+// that k_dcn_bwd_weight_reduce sums over the slices and adds, scaled, to gradWeight (deform_conv_cuda.cpp:455-459).
+// Twelve waves in two roles:
+//   * waves 0-7 (two per SIMD) own out channels 32 w .. 32 w + 31 and only run MFMAs: 8 k-steps x 24 MFMAs (16x16x4) per
+//     tile, the column operand from LDS (requested one k-step ahead), the gradOutput operand straight from memory -- in NHWC
+//     the 32 out channels of one position are 128 contiguous bytes, and a wave needs just 16 values per lane and tile,
 //     so the whole next tile's operand is requested between this tile's MFMAs and waits in registers (no LDS copy of
 //     gradOutput at all; every element is loaded once per workgroup);
 //   * waves 8-11 (one per SIMD) prepare the NEXT tile under them: input patch -> LDS (requested a tile ahead into registers),
