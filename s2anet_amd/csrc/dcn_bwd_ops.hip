@@ -1202,11 +1202,11 @@ __global__ __launch_bounds__(256) void k_dcn_bwd_weight_reduce(const float* __re
 }
 
 // ================================================================= fused weight gradient (f32, AlignConv geometry)
-// k_dcn_bwd_weight's dataflow for float32 tensors on v_mfma_f32_32x32x2_f32 (64 FLOP / clk / SIMD; the 155 GFLOP of a P3 x 8
-// call are 0.99 ms at the 2.4 GHz peak, 1.2 ms at the ~1.95 GHz the chip holds under this kernel).  With f32 operands nothing
+// k_dcn_bwd_weight's dataflow for float32 tensors on v_mfma_f32_16x16x4_f32 (64 FLOP / clk / SIMD; the 155 GFLOP of a P3 x 8
+// call are 0.99 ms at the 2.4 GHz peak, 1.2 ms at the ~2.0 GHz the chip holds under this kernel).  With f32 operands nothing
 // has to be transposed: the contraction index (the position) is the ROW of the column tiles in LDS, and an f32 MFMA operand
-// is one value per lane -- lane (l & 31, l >> 5) reads element l & 31 of row 2 ks + (l >> 5): 32 consecutive floats per half
-// wave, the two rows a pitch apart that is 32 (mod 64) floats, so the 64 lanes cover the 64 banks.
+// is one value per lane -- lane (l & 15, l >> 4) reads element l & 15 of row 4 ks + (l >> 4): 16 consecutive floats per
+// quarter wave, the four rows a pitch apart that is 16 (mod 64) floats, so the 64 lanes cover the 64 banks.
 // A workgroup owns ONE 64-channel chunk and ONE row of three taps and a slice of the 4 x 8 position tiles (12 owners x 21
 // slices = 252 workgroups); its 3 x [O x 64] f32 results stay in registers over all its tiles and go out once, as a block
 // that k_dcn_bwd_weight_reduce sums over the slices and adds, scaled, to gradWeight (deform_conv_cuda.cpp:455-459).
