@@ -248,12 +248,30 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
 // S2A_BWD_ABL: timing-only ablations of k_dcn_bwd_input (never set in a shipped build): 1 = no global atomics of the gathered
 // input gradient, 2 = no gather pass at all, 4 = no offset-gradient pass, 8 = no MFMA jobs, 16 = no list building
 // (bits 1 / 2 / 4 / 8 act on k_dcn_bwd_input_f32 too; k_dcn_bwd_weight_f32: 32 = no MFMAs, 64 = no blend, 128 = no tile loads)
+#ifdef S2A_MEASURE
+// measurement builds: phase cycles of the weight-gradient kernels, summed over workgroups (s2a_debug_bwd_stamps reads and clears).
+// k_dcn_bwd_weight_f32: [0] MFMA halves, [1] B1 wait, [2] B2 wait (wave 0); [11..13] the same of wave 4; [3] land + table, [8] wait
+// for the loads, [9] land, [7] blend + requests, [10] requests (wave 8); [4] tiles, [5] workgroups, [6] kernel.
+// k_dcn_bwd_weight (f16, S2A_MEASURE_F16W): [0] loop-top barrier, [1] land + table, [2] requests, [3] blend, [7] MFMA; [4] [5] [6] as above
+__device__ unsigned long long g_bwd_dbg[16];
+#define BWD_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define BWD_T(v)
+#endif
 #ifndef S2A_BWD_ABL
 #define S2A_BWD_ABL 0
 #endif
 constexpr int kBTH = 4, kBTW = 16, kBPos = kBTH * kBTW, kBHalo = 4;
 constexpr int kBPH = kBTH + 2 * kBHalo, kBPW = kBTW + 2 * kBHalo, kBPix = kBPH * kBPW;   // 12 x 24 = 288
 constexpr int kBCh = 32;                       // input channels per chunk
+// the next tile's ten requests per thread are spread over the tile: REQ_A before each of the three blend trips (the third
+// takes what is left up to REQ_B), the rest before the MFMAs
+#ifndef S2A_BWD_REQ_A
+#define S2A_BWD_REQ_A 3
+#endif
+#ifndef S2A_BWD_REQ_B
+#define S2A_BWD_REQ_B 8
+#endif
 #ifndef S2A_BWD_THREADS
 #define S2A_BWD_THREADS 1024
 #endif
@@ -1036,30 +1054,36 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
     const int v = tid + 512 * i, pp = v >> 3;
     p_yx[i] = v < kWPatchPix * 8 ? ((pp / kBPW) << 8 | (pp % kBPW)) : -1;
   }
-  float off_yx[2] = {0.f, 0.f};                  // the table threads' two offsets, requested a tile ahead
-  auto issue = [&](const TilePos& tp_) {
+  // the table threads' two offsets, requested a tile ahead -- kept as loaded, each in a register of its own: a conversion (or
+  // hipcc packing the two halves into one register) right behind the loads waits for EVERY request made before them
+  // (vmcnt counts in order): that wait was the 2.9 k cycles per tile the stamps showed as "requests"
+  unsigned off_y_raw = 0u, off_x_raw = 0u;
+  // pieces [p0, p1) of the next tile's requests: 0 .. 4 = gradOutput vectors, 5 .. 9 = patch vectors (+ the table offsets with piece 9)
+  auto issue = [&](const TilePos& tp_, int p0, int p1) {
     const int b = tp_.b, ty0 = tp_.ty * kBTH, tx0 = tp_.tx * kBTW;
     const int oy = ty0 - 3, ox = tx0 - 3;
     const _Float16* gb = go + (int64_t)b * HW * O;
     const _Float16* xb = x + (int64_t)b * HW * C + cc * 64 + (tid & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < kGoVec; i++) {
-      gv[i] = f16x8b{};
-      const int y = ty0 + (g_yx[i] >> 8), xq = tx0 + (g_yx[i] & 255);
-      if (g_yx[i] >= 0 && y < H && xq < W) gv[i] = *reinterpret_cast<const f16x8b*>(gb + ((int64_t)y * W + xq) * O + g_ch[i]);
-    }
+    for (int i = 0; i < kGoVec; i++)
+      if (i >= p0 && i < p1) {
+        gv[i] = f16x8b{};
+        const int y = ty0 + (g_yx[i] >> 8), xq = tx0 + (g_yx[i] & 255);
+        if (g_yx[i] >= 0 && y < H && xq < W) gv[i] = *reinterpret_cast<const f16x8b*>(gb + ((int64_t)y * W + xq) * O + g_ch[i]);
+      }
 #pragma unroll
-    for (int i = 0; i < kPaVec; i++) {
-      pvv[i] = f16x8b{};
-      const int yy = oy + (p_yx[i] >> 8), xx = ox + (p_yx[i] & 255);
-      if (p_yx[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) pvv[i] = *reinterpret_cast<const f16x8b*>(xb + ((int64_t)yy * W + xx) * C);
-    }
-    if (tid < 3 * kWPos) {
+    for (int i = 0; i < kPaVec; i++)
+      if (kGoVec + i >= p0 && kGoVec + i < p1) {
+        pvv[i] = f16x8b{};
+        const int yy = oy + (p_yx[i] >> 8), xx = ox + (p_yx[i] & 255);
+        if (p_yx[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) pvv[i] = *reinterpret_cast<const f16x8b*>(xb + ((int64_t)yy * W + xx) * C);
+      }
+    if (p1 == kGoVec + kPaVec && tid < 3 * kWPos) {
       const int tl = tid / kWPos, pos = tid % kWPos, t = ky * 3 + tl;
       const int y = min(ty0 + (pos >> 4), H - 1), xq = min(tx0 + (pos & 15), W - 1);
       const _Float16* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
-      off_yx[0] = (float)ob[(int64_t)(2 * t) * HW];
-      off_yx[1] = (float)ob[(int64_t)(2 * t + 1) * HW];
+      off_y_raw = *reinterpret_cast<const unsigned short*>(ob + (int64_t)(2 * t) * HW);
+      off_x_raw = *reinterpret_cast<const unsigned short*>(ob + (int64_t)(2 * t + 1) * HW);
     }
   };
   auto land = [&]() {
@@ -1071,12 +1095,22 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
       if (p_yx[i] >= 0) *reinterpret_cast<f16x8b*>(s_patch + (tid + 512 * i) * 16) = pvv[i];
   };
 
+#ifdef S2A_MEASURE_F16W
+  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c7 = 0, c4 = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
   int tile = slice;
-  if (tile < ntiles) issue(cur);
+  if (tile < ntiles) issue(cur, 0, kGoVec + kPaVec);
   for (; tile < ntiles; tile += ksplit) {
     const int b = cur.b, ty0 = cur.ty * kBTH, tx0 = cur.tx * kBTW;
     const int oy = ty0 - 3, ox = tx0 - 3;
+#ifdef S2A_MEASURE_F16W
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();                             // the previous tile's operands have been read
+#ifdef S2A_MEASURE_F16W
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
     land();
     if (tid < 3 * kWPos) {                       // sampling table of this tile's three taps
       const int tl = tid / kWPos, pos = tid % kWPos, t = ky * 3 + tl;
@@ -1085,7 +1119,8 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
       tp.y = 0; tp.x = 0; tp.flags = 0u;
       for (int k = 0; k < 4; k++) tp.w[k] = (_Float16)0.f;
       if (y < H && xq < W) {
-        const float off_y = off_yx[0], off_x = off_yx[1];
+        const float off_y = (float)__builtin_bit_cast(_Float16, (unsigned short)off_y_raw);
+        const float off_x = (float)__builtin_bit_cast(_Float16, (unsigned short)off_x_raw);
         const float h_im = (float)(y - 1 + ky) + off_y, w_im = (float)(xq - 1 + tl) + off_x;
         if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
           const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
@@ -1105,38 +1140,70 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
       s_tab[tid] = tp;
     }
     __syncthreads();
-    if (tile + ksplit < ntiles) {                // next tile's loads: in flight under the blend and the MFMAs
-      advance(cur);
-      issue(cur);
-    }
-    // ---- column tiles of the three taps: item = (tap, position, 8-channel group)
-    for (int it = tid; it < 3 * kWPos * 8; it += 512) {
+#ifdef S2A_MEASURE_F16W
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef S2A_MEASURE_F16W
+    const unsigned long long t2b = t2;
+#endif
+    // ---- column tiles of the three taps: item = (tap, position, 8-channel group), one tap per trip; the next tile's ten
+    // requests per thread ride in pieces in front of the trips and of the MFMAs.  (Stamps, `scripts/bwd32_stamps.sh f16`: a tile
+    // is ~8.8 k cycles -- barrier 0.8, land + table 1.3, blend 2.8, MFMA 1.2 and ~2.5 k for the 69 KB of requests WHEREVER they are
+    // placed, whether they hit cache or not, with 25 instructions around each or one: the kernel moves ~330 KB through LDS and
+    // 69 KB into registers per tile and 0.26 k cycles of MFMA -- it is bound by that movement, not by the matrix pipe.)
+    const bool more = tile + ksplit < ntiles;
+    if (more) advance(cur);
+#pragma unroll
+    for (int trip = 0; trip < 3; trip++) {
+      const int it = tid + 512 * trip;
+      if (more) issue(cur, S2A_BWD_REQ_A * trip, trip == 2 ? S2A_BWD_REQ_B : S2A_BWD_REQ_A * (trip + 1));
       const int tl = it >> 9, r = it & 511, pos = r >> 3, q = r & 7;
       const BTap tp = s_tab[tl * kWPos + pos];
-      f16x8b outv = {};
-      if (tp.flags & 1u) {
-        f16x8b c4[4];
-        if (tp.flags & 2u) {
-          const char* p0 = s_patch + ((int)(tp.flags >> 2) * 8 + q) * 16;
-          c4[0] = *reinterpret_cast<const f16x8b*>(p0);
-          c4[1] = *reinterpret_cast<const f16x8b*>(p0 + 128);
-          c4[2] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 128);
-          c4[3] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 128 + 128);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const int yy = min(max((int)tp.y + (k >> 1), 0), H - 1), xx = min(max((int)tp.x + (k & 1), 0), W - 1);
-            c4[k] = *reinterpret_cast<const f16x8b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8);
-          }
-        }
+      char* dst = s_col + (tl * kWPos + pos) * kWColRow + q * 16;
+      // A sample whose corners left the window (wild offsets) reads the input from memory.  That path must not share a basic
+      // block join with the usual one: behind a join hipcc waits for ALL outstanding vector-memory operations -- the next
+      // tile's requests included (their whole latency, 2.9 k cycles per tile, sat in front of the first blend item).
+      if (!__any((tp.flags & 3u) == 1u)) {
+        // usual case, LDS only (an invalid sample: all-zero weights, window pixel 0)
+        const char* p0 = s_patch + ((int)(tp.flags >> 2) * 8 + q) * 16;
+        const f16x8b c0 = *reinterpret_cast<const f16x8b*>(p0), c1 = *reinterpret_cast<const f16x8b*>(p0 + 128);
+        const f16x8b c2 = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 128), c3 = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 128 + 128);
         const float w0 = (float)tp.w[0], w1 = (float)tp.w[1], w2 = (float)tp.w[2], w3 = (float)tp.w[3];
+        f16x8b outv;
 #pragma unroll
         for (int j = 0; j < 8; j++)
-          outv[j] = (_Float16)(w0 * (float)c4[0][j] + w1 * (float)c4[1][j] + w2 * (float)c4[2][j] + w3 * (float)c4[3][j]);
+          outv[j] = (_Float16)(w0 * (float)c0[j] + w1 * (float)c1[j] + w2 * (float)c2[j] + w3 * (float)c3[j]);
+        *reinterpret_cast<f16x8b*>(dst) = outv;
+      } else {
+        f16x8b outv = {};
+        if (tp.flags & 1u) {
+          f16x8b c4[4];
+          if (tp.flags & 2u) {
+            const char* p0 = s_patch + ((int)(tp.flags >> 2) * 8 + q) * 16;
+            c4[0] = *reinterpret_cast<const f16x8b*>(p0);
+            c4[1] = *reinterpret_cast<const f16x8b*>(p0 + 128);
+            c4[2] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 128);
+            c4[3] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 128 + 128);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const int yy = min(max((int)tp.y + (k >> 1), 0), H - 1), xx = min(max((int)tp.x + (k & 1), 0), W - 1);
+              c4[k] = *reinterpret_cast<const f16x8b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8);
+            }
+          }
+          const float w0 = (float)tp.w[0], w1 = (float)tp.w[1], w2 = (float)tp.w[2], w3 = (float)tp.w[3];
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            outv[j] = (_Float16)(w0 * (float)c4[0][j] + w1 * (float)c4[1][j] + w2 * (float)c4[2][j] + w3 * (float)c4[3][j]);
+        }
+        *reinterpret_cast<f16x8b*>(dst) = outv;
       }
-      *reinterpret_cast<f16x8b*>(s_col + (tl * kWPos + pos) * kWColRow + q * 16) = outv;
     }
     __syncthreads();
+#ifdef S2A_MEASURE_F16W
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+    if (more) issue(cur, S2A_BWD_REQ_B, kGoVec + kPaVec);
     // ---- gradW tiles += gradOutput^T . columns over the 64 positions: both operands by transposing reads
     // (lane 16 g + 4 q + p supplies row q, elements 4 p .. 4 p + 3 of its group's 4 x 16 block and receives column
     // (lane & 15) of the four rows; group g covers rows 8 (g >> 1) + 4 r .. + 3 of the k-step and columns 16 (g & 1) .. + 15)
@@ -1164,7 +1231,18 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
           }
       }
     }
+#ifdef S2A_MEASURE_F16W
+    const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+    c0 += t1 - t0; c1 += t2 - t1; c2 += t2b - t2; c3 += t3 - t2b; c7 += t4 - t3; c4++;
+#endif
   }
+#ifdef S2A_MEASURE_F16W
+  if (tid == 0) {
+    atomicAdd(&g_bwd_dbg[0], c0); atomicAdd(&g_bwd_dbg[1], c1); atomicAdd(&g_bwd_dbg[2], c2); atomicAdd(&g_bwd_dbg[3], c3);
+    atomicAdd(&g_bwd_dbg[7], c7); atomicAdd(&g_bwd_dbg[4], c4); atomicAdd(&g_bwd_dbg[5], 1ull);
+    atomicAdd(&g_bwd_dbg[6], __builtin_amdgcn_s_memtime() - t_begin);
+  }
+#endif
   // ---- results: rows = out channels (4 consecutive per register quad), columns = channels of the chunk; one block per workgroup
   if (mwave) {
     float* part = partial + (int64_t)blockIdx.x * O * 192;      // (blockIdx = slice * owners + owner)
@@ -1231,13 +1309,6 @@ constexpr int kFWColBuf = 3 * kFPos * kFWColRow;              // floats per colu
 __host__ __device__ constexpr int wgrad_f32_lds_bytes() {
   return kFPix * kFWPatRow * 4 + 2 * kFWColBuf * 4 + 3 * kFPos * 16 + 3 * kFPos * 8 + 64;
 }
-#ifdef S2A_MEASURE
-__device__ unsigned long long g_bwd_dbg[16];    // cycles: [0] MFMA halves, [1] B1 wait, [2] B2 wait (wave 0); [3] land + table, [7] blend + requests (wave 8); [4] tiles, [5] workgroups, [6] kernel
-#define BWD_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#else
-#define BWD_T(v)
-#endif
-
 __global__ __launch_bounds__(kFWThreads) void k_dcn_bwd_weight_f32(const float* __restrict__ x,        // NHWC [S,H,W,C]
                                                                   const float* __restrict__ go,       // NHWC [S,H,W,O]
                                                                   const float* __restrict__ offset,   // NCHW [S,18,H,W]
