@@ -264,14 +264,6 @@ __device__ unsigned long long g_bwd_dbg[16];
 constexpr int kBTH = 4, kBTW = 16, kBPos = kBTH * kBTW, kBHalo = 4;
 constexpr int kBPH = kBTH + 2 * kBHalo, kBPW = kBTW + 2 * kBHalo, kBPix = kBPH * kBPW;   // 12 x 24 = 288
 constexpr int kBCh = 32;                       // input channels per chunk
-// the next tile's ten requests per thread are spread over the tile: REQ_A before each of the three blend trips (the third
-// takes what is left up to REQ_B), the rest before the MFMAs
-#ifndef S2A_BWD_REQ_A
-#define S2A_BWD_REQ_A 3
-#endif
-#ifndef S2A_BWD_REQ_B
-#define S2A_BWD_REQ_B 8
-#endif
 #ifndef S2A_BWD_THREADS
 #define S2A_BWD_THREADS 1024
 #endif
@@ -1058,27 +1050,24 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
   // hipcc packing the two halves into one register) right behind the loads waits for EVERY request made before them
   // (vmcnt counts in order): that wait was the 2.9 k cycles per tile the stamps showed as "requests"
   unsigned off_y_raw = 0u, off_x_raw = 0u;
-  // pieces [p0, p1) of the next tile's requests: 0 .. 4 = gradOutput vectors, 5 .. 9 = patch vectors (+ the table offsets with piece 9)
-  auto issue = [&](const TilePos& tp_, int p0, int p1) {
+  auto issue = [&](const TilePos& tp_) {
     const int b = tp_.b, ty0 = tp_.ty * kBTH, tx0 = tp_.tx * kBTW;
     const int oy = ty0 - 3, ox = tx0 - 3;
     const _Float16* gb = go + (int64_t)b * HW * O;
     const _Float16* xb = x + (int64_t)b * HW * C + cc * 64 + (tid & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < kGoVec; i++)
-      if (i >= p0 && i < p1) {
-        gv[i] = f16x8b{};
-        const int y = ty0 + (g_yx[i] >> 8), xq = tx0 + (g_yx[i] & 255);
-        if (g_yx[i] >= 0 && y < H && xq < W) gv[i] = *reinterpret_cast<const f16x8b*>(gb + ((int64_t)y * W + xq) * O + g_ch[i]);
-      }
+    for (int i = 0; i < kGoVec; i++) {
+      gv[i] = f16x8b{};
+      const int y = ty0 + (g_yx[i] >> 8), xq = tx0 + (g_yx[i] & 255);
+      if (g_yx[i] >= 0 && y < H && xq < W) gv[i] = *reinterpret_cast<const f16x8b*>(gb + ((int64_t)y * W + xq) * O + g_ch[i]);
+    }
 #pragma unroll
-    for (int i = 0; i < kPaVec; i++)
-      if (kGoVec + i >= p0 && kGoVec + i < p1) {
-        pvv[i] = f16x8b{};
-        const int yy = oy + (p_yx[i] >> 8), xx = ox + (p_yx[i] & 255);
-        if (p_yx[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) pvv[i] = *reinterpret_cast<const f16x8b*>(xb + ((int64_t)yy * W + xx) * C);
-      }
-    if (p1 == kGoVec + kPaVec && tid < 3 * kWPos) {
+    for (int i = 0; i < kPaVec; i++) {
+      pvv[i] = f16x8b{};
+      const int yy = oy + (p_yx[i] >> 8), xx = ox + (p_yx[i] & 255);
+      if (p_yx[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) pvv[i] = *reinterpret_cast<const f16x8b*>(xb + ((int64_t)yy * W + xx) * C);
+    }
+    if (tid < 3 * kWPos) {
       const int tl = tid / kWPos, pos = tid % kWPos, t = ky * 3 + tl;
       const int y = min(ty0 + (pos >> 4), H - 1), xq = min(tx0 + (pos & 15), W - 1);
       const _Float16* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
@@ -1100,7 +1089,7 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
   int tile = slice;
-  if (tile < ntiles) issue(cur, 0, kGoVec + kPaVec);
+  if (tile < ntiles) issue(cur);
   for (; tile < ntiles; tile += ksplit) {
     const int b = cur.b, ty0 = cur.ty * kBTH, tx0 = cur.tx * kBTW;
     const int oy = ty0 - 3, ox = tx0 - 3;
@@ -1147,16 +1136,17 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
     const unsigned long long t2b = t2;
 #endif
     // ---- column tiles of the three taps: item = (tap, position, 8-channel group), one tap per trip; the next tile's ten
-    // requests per thread ride in pieces in front of the trips and of the MFMAs.  (Stamps, `scripts/bwd32_stamps.sh f16`: a tile
+    // requests per thread go out first.  (Stamps, `scripts/bwd32_stamps.sh f16`: a tile
     // is ~8.8 k cycles -- barrier 0.8, land + table 1.3, blend 2.8, MFMA 1.2 and ~2.5 k for the 69 KB of requests WHEREVER they are
     // placed, whether they hit cache or not, with 25 instructions around each or one: the kernel moves ~330 KB through LDS and
     // 69 KB into registers per tile and 0.26 k cycles of MFMA -- it is bound by that movement, not by the matrix pipe.)
-    const bool more = tile + ksplit < ntiles;
-    if (more) advance(cur);
+    if (tile + ksplit < ntiles) {                // next tile's loads: in flight under the blend and the MFMAs
+      advance(cur);
+      issue(cur);
+    }
 #pragma unroll
     for (int trip = 0; trip < 3; trip++) {
       const int it = tid + 512 * trip;
-      if (more) issue(cur, S2A_BWD_REQ_A * trip, trip == 2 ? S2A_BWD_REQ_B : S2A_BWD_REQ_A * (trip + 1));
       const int tl = it >> 9, r = it & 511, pos = r >> 3, q = r & 7;
       const BTap tp = s_tab[tl * kWPos + pos];
       char* dst = s_col + (tl * kWPos + pos) * kWColRow + q * 16;
@@ -1203,7 +1193,6 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
 #ifdef S2A_MEASURE_F16W
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
 #endif
-    if (more) issue(cur, S2A_BWD_REQ_B, kGoVec + kPaVec);
     // ---- gradW tiles += gradOutput^T . columns over the 64 positions: both operands by transposing reads
     // (lane 16 g + 4 q + p supplies row q, elements 4 p .. 4 p + 3 of its group's 4 x 16 block and receives column
     // (lane & 15) of the four rows; group g covers rows 8 (g >> 1) + 4 r .. + 3 of the k-step and columns 16 (g & 1) .. + 15)
