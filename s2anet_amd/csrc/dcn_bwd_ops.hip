@@ -264,10 +264,8 @@ __device__ unsigned long long g_bwd_dbg[16];
 constexpr int kBTH = 4, kBTW = 16, kBPos = kBTH * kBTW, kBHalo = 4;
 constexpr int kBPH = kBTH + 2 * kBHalo, kBPW = kBTW + 2 * kBHalo, kBPix = kBPH * kBPW;   // 12 x 24 = 288
 constexpr int kBCh = 32;                       // input channels per chunk
-#ifndef S2A_BWD_THREADS
-#define S2A_BWD_THREADS 1024
-#endif
-constexpr int kBThreads = S2A_BWD_THREADS;     // k_dcn_bwd_input: 512 or 1024 (the passes between the MFMA jobs are latency-bound loops)
+constexpr int kBThreads = 1024;                // k_dcn_bwd_input: the passes between the MFMA jobs are latency-bound loops -- sixteen waves
+                                               // instead of eight: 1.36 -> 1.34 ms (the f32 kernel: 2.56 -> 2.60, stays at 512)
 constexpr int kBGRow = kBCh + 4;               // floats per (tap, position) row of the column-gradient tiles: 144 B -- with 128-B rows every
                                                // lane of the gather pass read the SAME 8 banks (its channel group of a different row):
                                                // the pass took 19 k cycles per chunk for ~2 k cycles of instructions
