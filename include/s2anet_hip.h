@@ -483,6 +483,19 @@ int s2a_conv3x3_head_pyramid_f16(const void* x, const void* weight_frag, const v
 int s2a_orconv_pool_pyramid_f16(const void* x, const void* weight_frag, const void* bias, void* out, void* pooled,
                                 int64_t batch, int64_t channels, int64_t out_channels, const s2a_pyramid* pyr,
                                 s2a_stream_t stream);
+/* The same 3x3 / stride 1 / pad 1 convolution (bias, optional ReLU, optional orientation max-pool as
+ * s2a_orconv_pool_pyramid_f16) in the Winograd F(2,3) minimal-filtering form along x: 6 C O multiply-adds per output
+ * instead of 9 C O, f16 operands / f32 accumulation as the direct kernel (the reference leaves the algorithm to cuDNN,
+ * models/head.py:163-222).  Results differ from s2a_conv3x3_pyramid_f16 by the rounding of the transformed operands
+ * (one f16 rounding of d_i +- d_j and of the transformed filter): same tolerance against an f32 convolution.
+ *   weight_wino = s2a_conv_wino_pack_weight_f16 of the [O,C,3,3] f16 filter (s2a_conv_wino_packed_elems halfs; O a
+ *   multiple of 64, C a multiple of 32); pooled [P,O/8] or NULL; a one-level table serves a plain [B,H,W,C] tensor. */
+int64_t s2a_conv_wino_packed_elems(int64_t out_channels, int64_t channels);
+int s2a_conv_wino_pack_weight_f16(const void* weight, int64_t out_channels, int64_t channels, void* packed,
+                                  s2a_stream_t stream);
+int s2a_conv3x3_wino_pyramid_f16(const void* x, const void* weight_wino, const void* bias, void* out, void* pooled,
+                                 int64_t batch, int64_t channels, int64_t out_channels, int relu,
+                                 const s2a_pyramid* pyr, s2a_stream_t stream);
 int s2a_align_conv_pyramid_f16(const void* x, const float* anchors, const void* weight_packed, void* out,
                                int64_t batch, int64_t channels, int64_t out_channels, int relu,
                                const s2a_pyramid* pyr, s2a_stream_t stream);

@@ -119,6 +119,10 @@ SYMBOLS = {
     "s2a_conv3x3_head_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
                                              ctypes.POINTER(Pyramid), c_vp]),
     "s2a_orconv_pool_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, ctypes.POINTER(Pyramid), c_vp]),
+    "s2a_conv_wino_packed_elems": (c_i64, [c_i64, c_i64]),
+    "s2a_conv_wino_pack_weight_f16": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "s2a_conv3x3_wino_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
+                                             ctypes.POINTER(Pyramid), c_vp]),
     "s2a_align_conv_pyramid_f16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
                                            ctypes.POINTER(Pyramid), c_vp]),
     "s2a_fam_refine_anchors_pyramid": (c_int, [c_vp, c_i64, c_i64, ctypes.POINTER(Pyramid), c_f32, c_vp, c_vp]),

@@ -79,6 +79,32 @@ def conv_pack_weight(weight):
     return out
 
 
+def conv_wino_pack_weight(weight):
+    """[O,C,3,3] -> the transformed filter of the Winograd F(2,3) kernel in fragment order (s2a_conv_wino_pack_weight_f16);
+    O a multiple of 64, C a multiple of 32"""
+    w = weight.detach().to(torch.float16).contiguous()
+    O, C = w.shape[:2]
+    assert tuple(w.shape[2:]) == (3, 3) and O % 64 == 0 and C % 32 == 0
+    L = _lib.lib()
+    out = torch.empty((L.s2a_conv_wino_packed_elems(O, C),), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(L.s2a_conv_wino_pack_weight_f16(_lib.ptr(w), O, C, _lib.ptr(out), _lib.stream_ptr(w.device)))
+    return out
+
+
+def conv_wino_f16(x, packed_wino, bias, out_channels, relu=False, pool=False):
+    """relu?(conv3x3(x) + bias) on a plain channels-last tensor through the Winograd kernel (one-level pyramid)"""
+    from .pyramid import PyramidLayout, conv3x3_wino
+    B, C, H, W = x.shape
+    assert x.dtype == torch.float16 and x.is_contiguous(memory_format=torch.channels_last)
+    lay = PyramidLayout(B, [(H, W)], [1.0])
+    b = None if bias is None else bias.to(torch.float16).contiguous()
+    r = conv3x3_wino(lay, x.permute(0, 2, 3, 1).reshape(-1, C), packed_wino, b, out_channels, relu, pool)
+    if pool:
+        return (r[0].view(B, H, W, out_channels).permute(0, 3, 1, 2), r[1].view(B, H, W, out_channels // 8).permute(0, 3, 1, 2))
+    return r.view(B, H, W, out_channels).permute(0, 3, 1, 2)
+
+
 def conv_f16(x, packed_weight, bias, out_channels, ksize, stride=1, relu=False, residual=None, out=None):
     """relu?(conv(x) + bias (+ residual)) in ONE kernel; x f16 channels-last, packed_weight from
     conv_pack_weight; ksize 3 (pad 1, stride 1|2) or 1 (pad 0, stride 1|2)"""
@@ -173,6 +199,14 @@ class PackedWeightCache:
     def __init__(self):
         self.key, self.val = None, None
         self.bkey, self.bval = None, None
+        self.wkey, self.wval = None, None
+
+    def get_wino(self, w):
+        """the Winograd-transformed filter (conv_wino_pack_weight) of a [O,C,3,3] weight"""
+        key = (w._version, w.data_ptr(), w.device)
+        if self.wkey != key:
+            self.wkey, self.wval = key, conv_wino_pack_weight(w)
+        return self.wval
 
     def get(self, w):
         key = (w._version, w.data_ptr(), w.device)
@@ -215,6 +249,18 @@ class FusedConv2d(nn.Conv2d):
             self._packed = PackedWeightCache()
         width = max(64, self.out_channels)
         return self._packed.get(self.weight), self._packed.get_bias(self.bias, width), width
+
+    def wino_ok(self):
+        """a layer the Winograd kernel serves: 3x3 / stride 1 / pad 1, O a multiple of 64, C a multiple of 32"""
+        return (tuple(self.kernel_size) == (3, 3) and tuple(self.stride) == (1, 1) and tuple(self.padding) == (1, 1) and
+                tuple(self.dilation) == (1, 1) and self.groups == 1 and self.out_channels % 64 == 0 and
+                self.in_channels % 32 == 0)
+
+    def packed_args_wino(self):
+        """(transformed filter, f16 bias, out channels) for s2a_conv3x3_wino_pyramid_f16"""
+        if not hasattr(self, "_packed"):
+            self._packed = PackedWeightCache()
+        return self._packed.get_wino(self.weight), self._packed.get_bias(self.bias, self.out_channels), self.out_channels
 
     def forward(self, x, residual=None, out=None):
         """out: dense NHWC buffer for the result (library path only; the own kernel is called with out= directly)"""

@@ -148,8 +148,14 @@ class S2ANetHead(nn.Module):
         the packed intermediate buffers by name (tests / scripts/f16_fixture_diag.py)"""
         from . import pyramid as P
 
+        wino = P.wino_enabled()
+
         def tower(seq, t):
             for blk in seq:
+                if wino and blk[0].wino_ok() and blk[0].in_channels >= 128:     # Winograd F(2,3) along x (wino_ops.hip)
+                    w, b, o = blk[0].packed_args_wino()
+                    t = P.conv3x3_wino(layout, t, w, b, o, relu=True)
+                    continue
                 w, b, o = blk[0].packed_args()
                 t = P.conv3x3(layout, t, w, b, o, relu=True)
             return t
@@ -182,7 +188,11 @@ class S2ANetHead(nn.Module):
         if not hasattr(self.or_conv, "_packed"):
             from .fused import PackedWeightCache
             self.or_conv._packed = PackedWeightCache()
-        if self.or_pool.nOrientation == 8 and wa.shape[0] % 64 == 0:                        # conv + orientation max, one launch
+        if self.or_pool.nOrientation == 8 and wa.shape[0] % 64 == 0 and wino and wa.shape[1] % 32 == 0:
+            or_feat, pooled = P.conv3x3_wino(layout, al, self.or_conv._packed.get_wino(wa),
+                                             self.or_conv._packed.get_bias(self.or_conv.bias, wa.shape[0]), wa.shape[0],
+                                             relu=False, pool=True)
+        elif self.or_pool.nOrientation == 8 and wa.shape[0] % 64 == 0:                      # conv + orientation max, one launch
             or_feat, pooled = P.orconv_pool(layout, al, self.or_conv._packed.get(wa),
                                             self.or_conv._packed.get_bias(self.or_conv.bias, wa.shape[0]), wa.shape[0])
         else:

@@ -87,6 +87,28 @@ def orconv_pool(layout, x, packed_w, bias, out_channels, n_orientation=8):
     return out, pooled
 
 
+def conv3x3_wino(layout, x, packed_wino, bias, out_channels, relu, pool=False, out=None):
+    """3x3 / stride 1 / pad 1 on every level in the Winograd F(2,3)-along-x form (s2a_conv3x3_wino_pyramid_f16):
+    x[P,C] -> out[P,O]; pool: also the orientation max-pool [P,O/8] of the result (ORConv2d + RotationInvariantPooling)"""
+    L = _lib.lib()
+    if out is None:
+        out = layout.new(out_channels, x.device)
+    pooled = layout.new(out_channels // 8, x.device) if pool else None
+    with torch.cuda.device(x.device):
+        _lib.check(L.s2a_conv3x3_wino_pyramid_f16(_lib.ptr(x), _lib.ptr(packed_wino), _lib.ptr(bias), _lib.ptr(out),
+                                                  _lib.ptr(pooled), layout.batch, x.shape[1], out_channels, int(bool(relu)),
+                                                  ctypes.byref(layout.c), _lib.stream_ptr(x.device)))
+    return (out, pooled) if pool else out
+
+
+def wino_enabled():
+    """S2A_CONV_WINO=1: the regular 256 -> 256 layers of the head on the Winograd F(2,3) kernel instead of the direct one.
+    Off by default: measured level with the direct kernel on the same box (profiles/r06_wino_ab.txt), and the direct
+    kernel's outputs are the ones the stage hashes of tests/test_net_forward.py pin."""
+    import os
+    return os.environ.get("S2A_CONV_WINO", "0") == "1"
+
+
 def conv1x1(x, packed_w, bias, out_channels, relu, residual=None):
     """1x1 on packed rows (no geometry): x[P,C] -> out[P,O]"""
     L = _lib.lib()

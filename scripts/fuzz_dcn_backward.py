@@ -1,25 +1,24 @@
 """randomised deform_conv backward calls at the AlignConv geometry (ragged images, batches, 1-4 channel chunks, out channels
 16 ... 256, tame to wild offsets, f32 and f16, a non-zero gradInput / gradWeight, a scale) against the oracle
 (oracle.deform_conv_backward = deform_conv_cuda.cpp:262-489 restated): the fused entry points one by one, the one-call
-form, and the weight gradient twice (it has to be bit-identical).  Spare-GPU-minute fuzzing, not part of the test suite:
-python scripts/fuzz_dcn_backward.py [cases] [seed]"""
+form, and the weight gradient twice (it has to be bit-identical).  A bounded, seeded slice runs in the test suite
+(tests/test_gpu_fuzz.py); more cases by hand: python scripts/fuzz_dcn_backward.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-import oracle
-from s2anet_amd.dcn import deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda, _fused_backward
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-dev = torch.device("cuda:0")
-cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-bad = 0
-for c in range(cases):
+
+def bwd_case(rng, max_h=30, max_w=40):
+    """one random backward call -> (ok, description)"""
+    import oracle
+    from s2anet_amd.dcn import deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda, _fused_backward
+    dev = torch.device("cuda:0")
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     f16 = bool(rng.integers(0, 2))
     B = int(rng.choice([1, 2, 3]))
     C = 64 * int(rng.integers(1, 4))
     O = int(rng.choice([32, 64, 96, 256]))
-    H, W = int(rng.integers(3, 30)), int(rng.integers(3, 40))
+    H, W = int(rng.integers(3, max_h)), int(rng.integers(3, max_w))
     amp = float(rng.choice([0.3, 1.0, 2.5, 6.0]))
     scale = float(rng.choice([1.0, 0.5]))
     mk = lambda *s: rng.standard_normal(s).astype(np.float32)
@@ -47,9 +46,17 @@ for c in range(cases):
     tol_gin = tol_i * (3 if f16 else 1)        # f16: the entry point rounds gradInput + base once more
     ok = (errs["gin"] < tol_gin and errs["goff"] < tol_i and errs["gw"] < tol_w and errs["one_gin"] < tol_i
           and errs["one_goff"] < tol_i and errs["one_gw"] < tol_w and np.array_equal(gws[0], gws[1]))
-    bad += not ok
-    print("case %2d %s B %d C %3d O %3d %2dx%2d amp %.1f scale %.1f: %s  %s" % (
-        c, "f16" if f16 else "f32", B, C, O, H, W, amp, scale, "ok" if ok else "MISMATCH",
-        " ".join("%s %.1e" % kv for kv in errs.items())), flush=True)
-print("mismatches:", bad)
-sys.exit(1 if bad else 0)
+    return bool(ok), "%s B %d C %3d O %3d %2dx%2d amp %.1f scale %.1f: %s" % (
+        "f16" if f16 else "f32", B, C, O, H, W, amp, scale, " ".join("%s %.1e" % kv for kv in errs.items()))
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    bad = 0
+    for c in range(cases):
+        ok, msg = bwd_case(rng)
+        bad += not ok
+        print("case %2d %s  %s" % (c, "ok" if ok else "MISMATCH", msg), flush=True)
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)

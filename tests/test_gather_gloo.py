@@ -37,6 +37,64 @@ def worker(rank, world, port, B, K, q):
     dist.destroy_process_group()
 
 
+def uneven_worker(rank, world, port, G, K, q):
+    """a global batch the world does not divide: ranks hold different numbers of images"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = shard_range(G, world, rank)
+    gather = DetectionGather.for_global_batch(G, world, K, torch.device("cpu"))
+    d0, l0, c0 = make_rank_output(rank, b - a, K)
+    for _ in range(2):                                         # the staging rows are reused: second turn == first
+        wire = gather(pack_detections(d0, l0, c0))
+        assert tuple(wire.shape) == (world * gather.B, K * 7 + 1)
+        d, l, c = gather.unpack_global(wire)
+    raw_counts = gather.unpack(wire)[2].clone()
+    q.put((rank, d.clone(), l.clone(), c.clone(), raw_counts))
+    # too many rows for the slot size: refused with a message, not sent
+    try:
+        gather(torch.zeros((gather.B + 1, K * 7 + 1)))
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(target, world, *args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    return procs, q
+
+
+def test_uneven_shards_are_padded_and_stripped():
+    """global batch 5 over 2 ranks (3 + 2 images): every rank sends 3 rows, the short one a "no image" row with count -1;
+    unpack_global returns the 5 images in order, == the concatenation of the per-rank outputs"""
+    world, G, K = 2, 5, 20
+    procs, q = _spawn(uneven_worker, world, G, K)
+    got = [q.get(timeout=120) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = [make_rank_output(r, shard_range(G, world, r)[1] - shard_range(G, world, r)[0], K) for r in range(world)]
+    ed, el, ec = (torch.cat([e[i] for e in exp]) for i in range(3))
+    assert ed.shape[0] == G
+    for item in got:
+        if len(item) == 2:
+            assert "sized for 3 per rank" in item[1], item
+            continue
+        _, d, l, c, raw = item
+        assert torch.equal(d, ed) and torch.equal(l, el) and torch.equal(c, ec)
+        assert raw.tolist()[:3] == ec[:3].tolist() and raw.tolist()[3:5] == ec[3:].tolist() and raw.tolist()[5] == -1
+
+
 def test_shard_range_covers_batch():
     for gb, w in ((64, 8), (10, 4), (3, 8)):
         spans = [shard_range(gb, w, r) for r in range(w)]

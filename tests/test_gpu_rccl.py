@@ -84,6 +84,45 @@ def test_rccl_all_gather_world_of_one_equals_input(rccl_world_of_one, side):
 
 
 @pytest.mark.gpu
+def test_rccl_slot_reuse_waits_for_the_reader(rccl_world_of_one):
+    """reader -> next writer: a slow reader on a THIRD stream still holds views of slot k when the gather two turns later
+    is issued; the side stream must wait for everything that reader had queued before it overwrites the slot"""
+    dev = rccl_world_of_one
+    B, K = 8, 2000
+    gather = DetectionGather(1, B, K, dev, side_stream=True, force_collective=True)
+    host = [_wire(300 + i, B, K, dev) for i in range(3)]
+    wires = [h[0].to(dev) for h in host]
+    reader = torch.cuda.Stream(device=dev)
+    big = torch.empty((96 << 20,), dtype=torch.float32, device=dev).normal_()
+    torch.cuda.synchronize()
+    g0 = gather(wires[0])                                         # slot 0
+    with torch.cuda.stream(reader):
+        d, l, c = gather.unpack(g0)                               # the reader stream now owns views of slot 0
+        for _ in range(12):
+            big.mul_(1.0000001)                                   # ~ milliseconds of work in front of the read
+        kept = g0.clone()                                         # the read the next writer must not overtake
+    gather(wires[1])                                              # slot 1
+    gather(wires[2])                                              # slot 0 again: ordered behind the reader's queue
+    assert gather.reader_waits == 1
+    torch.cuda.synchronize()
+    assert torch.equal(kept.cpu(), host[0][0])                    # the clone saw turn 0's data, not turn 2's
+    assert torch.equal(gather.out.view(B, -1).cpu(), host[2][0])
+
+
+@pytest.mark.gpu
+def test_uneven_shard_pads_to_the_slot_size(rccl_world_of_one):
+    """a rank holding fewer images than the largest shard pads with count -1 rows (world of one: 3 images in a 4-row slot)"""
+    dev = rccl_world_of_one
+    K = 50
+    gather = DetectionGather(1, 4, K, dev, force_collective=True)
+    w, (d0, l0, c0) = _wire(9, 3, K, dev)
+    d, l, c = gather.unpack(gather(w.to(dev)))
+    assert torch.equal(d[:3].cpu(), d0) and torch.equal(c.cpu()[:3], c0) and int(c[3]) == -1
+    with pytest.raises(ValueError):
+        gather(torch.zeros((5, K * 7 + 1), device=dev))
+
+
+@pytest.mark.gpu
 def test_rccl_all_reduce_max_and_barrier(rccl_world_of_one):
     """the two other collectives bench.py issues around the timed region"""
     dev = rccl_world_of_one

@@ -55,3 +55,32 @@ def test_a_and_b_take_the_same_channel_group_and_cover_the_chunk():
                 assert cgroup_a == cgroup_b
                 seen.add((32 * a + row, cgroup_a))
     assert len(seen) == 64 * 8          # every (out channel, channel group) of the chunk exactly once per tap
+
+
+# ---- Winograd kernel (csrc/wino_ops.hip): raw patch with 80-byte pixels, lane (t = lane & 15, kg = lane >> 4) reads pixel
+# 2 t + j (j = 0..3) of a patch row, 16 B at kg * 16; staged output rows of 144 B with the even / odd column split
+W_PITCH, W_PC = 80, 34
+
+
+def test_wino_raw_patch_reads_are_conflict_free():
+    for j in range(4):
+        for row in range(6):
+            for g in GROUPS:
+                slots = {(((row * W_PC + 2 * (l & 15) + j) * W_PITCH + (l >> 4) * 16) // 16) % 16 for l in g}
+                assert len(slots) == 16
+
+
+def test_wino_dma_slots_cover_the_patch():
+    """slot v = pixel * 5 + q: q < 4 are the four 16-byte channel groups of the 32-channel chunk, q = 4 the pad"""
+    seen = set()
+    for v in range(48 * 64):
+        p, q = divmod(v, 5)
+        if q < 4 and p < 18 * W_PC:
+            assert v * 16 == p * W_PITCH + q * 16
+            seen.add((p, q))
+    assert len(seen) == 18 * W_PC * 4
+
+
+def test_wino_output_slots_are_a_permutation():
+    cols = sorted(2 * (s & 15) + ((s >> 4) & 1) for s in range(32))
+    assert cols == list(range(32))
