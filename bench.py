@@ -113,6 +113,8 @@ def parse():
     ap.add_argument("--no-fam-cls", action="store_true",
                     help="skip the FAM classification branch (unused at inference; the reference evaluates it)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="never replay from a graph (with N > 1 ranks the default is decided by the measured host issue time)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) also for ONE rank and send the detections through "
                          "all_gather_into_tensor instead of the world-of-one copy: executes the real collective path "
@@ -536,6 +538,24 @@ def cpu_baseline(seed, candidates, chips=3):
 
 
 # ------------------------------------------------------------------------------------------------ launcher
+def pin_rank_cpus(local_rank, local_world):
+    """give this rank a disjoint share of the CPUs the process may run on (N > 1: eight ranks each issue ~100 launches per
+    4-5 ms step from Python; without this they migrate over each other's cores).  Called BEFORE anything touches the GPU.
+    Returns the number of CPUs of the share, or None when the share would be empty / the call is not available."""
+    if os.environ.get("S2A_BENCH_NO_AFFINITY") or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        share = len(cpus) // local_world
+        if share < 1:
+            return None
+        mine = cpus[local_rank * share:(local_rank + 1) * share]
+        os.sched_setaffinity(0, mine)
+        return len(mine)
+    except OSError:
+        return None
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment, exactly what torch.distributed.run would set) and relay rank 0's stdout.  Nothing
@@ -631,6 +651,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert args.gpus == world, "--gpus must equal the number of launched ranks (WORLD_SIZE=%d)" % world
+    cpus_per_rank = pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # before any GPU call
     stub = bool(os.environ.get("S2A_BENCH_STUB"))
     if stub:
         if os.environ.get("S2A_BENCH_STUB_FAIL_RANK") == str(rank):     # launcher test: a rank that dies at start-up
@@ -695,27 +716,34 @@ def main():
     # (RCCL only: ProcessGroupNCCL orders its collective behind the current stream with events and never blocks the host;
     # gloo's CUDA path blocks the host in wait() -- the rehearsal backend measured 72 vs 14 ms per step with the side
     # stream -- so the rehearsal keeps the gather on the compute stream)
-    side = (dist_on and not stub and backend == "nccl" and args.streams <= 1 and not args.graph
+    side = (dist_on and not stub and backend == "nccl" and args.streams <= 1
             and not os.environ.get("S2A_BENCH_NO_SIDE_GATHER"))
     gathers = [DetectionGather(world, B, model.head.max_per_img, dev, side_stream=side, force_collective=force_dist)
                for _ in range(nslots)] if dist_on else None
     dropped = [torch.zeros((1,), dtype=torch.int64, device=dev) for _ in range(nslots)]
     slot, do_gather, last_wire = [0], [True], [None]
 
-    def step():
+    def detect_only():
         x = imgs if stub else batches[slot[0] % len(batches)]
         k = slot[0] % nslots
-        dets, labels, counts, wire = model.detect(x, max_candidates=max_cand, dropped_total=dropped[k], return_wire=True)
-        last_wire[0] = wire
+        out4 = model.detect(x, max_candidates=max_cand, dropped_total=dropped[k], return_wire=True)
+        last_wire[0] = out4[3]
+        return out4
+
+    def finish(out4):
+        """the exchange step behind a detect (eager even when detect is replayed from a graph: no collective is ever captured)"""
         if gathers is not None and do_gather[0]:
-            return gathers[k](wire)
-        return dets, labels, counts
+            return gathers[slot[0] % nslots](out4[3])
+        return out4[:3]
+
+    def step():
+        return finish(detect_only())
 
     for _ in range(max(args.warmup, 1)):
         out = step()
     sync()
-    runner = step
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    turn = [0]
     if streams:
         for k, st in enumerate(streams):                     # per-stream workspaces and allocator pools warm
             slot[0] = k
@@ -723,41 +751,80 @@ def main():
                 for _ in range(2):
                     out = step()
         sync()
-        turn = [0]
 
-        def runner():
-            slot[0] = turn[0] % len(streams)
-            with torch.cuda.stream(streams[slot[0]]):
-                step()
-            turn[0] += 1
-    if args.graph and not streams:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = step()
-        runner = graph.replay
-        runner()
-        sync()
-    elif args.graph:
-        # one captured graph per stream (own workspaces / gather slot), replayed round-robin: the host issues one
-        # launch per batch instead of ~140
-        graphs = []
-        for k, st in enumerate(streams):
-            slot[0] = k
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_, stream=st):
-                out = step()
-            graphs.append(g_)
-        sync()
-        gturn = [0]
+    def eager_runner():
+        if not streams:
+            return step()
+        slot[0] = turn[0] % len(streams)
+        with torch.cuda.stream(streams[slot[0]]):
+            step()
+        turn[0] += 1
 
-        def runner():
-            k = gturn[0] % len(streams)
-            with torch.cuda.stream(streams[k]):
-                graphs[k].replay()
-            gturn[0] += 1
-        for _ in range(len(streams)):
-            runner()
+    def issue_and_step_ms(fn, n):
+        """(host time for n calls of fn to RETURN, no synchronisation) and (time until the GPU has finished them), per call"""
         sync()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        t2 = time.perf_counter()
+        sync()
+        return (t2 - t1) / n * 1e3, (time.perf_counter() - t1) / n * 1e3
+
+    # N > 1: every rank issues its ~100 launches per step from its own Python thread.  If issuing alone takes more than half
+    # a step, the step is replayed from a captured graph (one host call per batch); the all-gather stays eager behind it.
+    graph_reason = None
+    use_graph = bool(args.graph) and not stub
+    if not stub and not args.graph and not args.no_graph and world > 1:
+        iss, stp = issue_and_step_ms(eager_runner, 6)
+        flag = torch.tensor([1.0 if iss > 0.5 * stp else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)           # one decision for the whole job
+        use_graph = bool(flag.item() > 0)
+        graph_reason = "eager host issue %.2f ms of a %.2f ms step on rank %d: %s" % (
+            iss, stp, rank, "graph replay" if use_graph else "eager launches kept")
+    runner = eager_runner
+    if use_graph:
+        try:
+            nk = len(streams) if streams else 1
+            graphs, statics = [], []
+            for k in range(nk):
+                slot[0] = k
+                g_ = torch.cuda.CUDAGraph()
+                if streams:
+                    with torch.cuda.graph(g_, stream=streams[k]):
+                        o4 = detect_only()
+                else:
+                    with torch.cuda.graph(g_):
+                        o4 = detect_only()
+                graphs.append(g_)
+                statics.append(o4)
+            sync()
+
+            def runner():
+                k = turn[0] % nk
+                slot[0] = k
+                # the replay rewrites the STATIC wire buffer: a side-stream gather of this slot's previous turn must have read it
+                if streams:
+                    with torch.cuda.stream(streams[k]):
+                        if gathers is not None:
+                            gathers[k].wait()
+                        graphs[k].replay()
+                        r = finish(statics[k])
+                else:
+                    if gathers is not None:
+                        gathers[k].wait()
+                    graphs[k].replay()
+                    r = finish(statics[k])
+                last_wire[0] = statics[k][3]
+                turn[0] += 1
+                return r
+            for _ in range(nk):
+                out = runner()
+            sync()
+        except Exception as e:      # a capture that fails must not cost the measurement: eager launches, reason on the line
+            use_graph, runner = False, eager_runner
+            graph_reason = "graph capture failed (%r): eager launches" % (e,)
+            sync()
+    args.graph = use_graph
 
     if dist_on:
         dist.barrier()
@@ -765,11 +832,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner()
+    t_issued = time.perf_counter()
     sync()
     if dist_on:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    host_issue_ms = (t_issued - t0) / args.steps * 1e3          # the host's share: all runner() calls returned, nothing waited for
     per_rank = None
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -781,46 +850,54 @@ def main():
             sync()
             # clones: the attribution loop below gathers into its own object, but the timed slots stay untouched anyway
             out = tuple(t_.clone() for t_ in gathers[(slot[0]) % nslots].unpack())
-        if not args.graph:
-            def loop_ms(fn, n):
-                sync()
-                t1 = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                sync()
-                return (time.perf_counter() - t1) / n * 1e3
-            do_gather[0] = False
-            compute_ms = loop_ms(runner, args.steps)
-            do_gather[0] = True
-            dist.barrier()
-            w_ = last_wire[0]
-            g_alone = DetectionGather(world, B, model.head.max_per_img, dev, side_stream=side, force_collective=force_dist)
+        def loop_ms(fn, n):
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            sync()
+            return (time.perf_counter() - t1) / n * 1e3
+        do_gather[0] = False
+        compute_ms = loop_ms(runner, args.steps)
+        do_gather[0] = True
+        dist.barrier()
+        w_ = last_wire[0]
+        g_alone = DetectionGather(world, B, model.head.max_per_img, dev, side_stream=side, force_collective=force_dist)
 
-            def gather_once():
-                g_alone(w_)
-                g_alone.wait()
-            gather_once()
-            gather_ms = loop_ms(gather_once, 20)
-            mine = {"rank": rank, "step_ms": round(elapsed / args.steps * 1e3, 3), "compute_ms": round(compute_ms, 3),
-                    "gather_ms": round(gather_ms, 3)}
-            allr = [None] * world
-            dist.all_gather_object(allr, mine)
-            per_rank = allr
+        def gather_once():
+            g_alone(w_)
+            g_alone.wait()
+        gather_once()
+        gather_ms = loop_ms(gather_once, 20)
+        mine = {"rank": rank, "step_ms": round(elapsed / args.steps * 1e3, 3), "compute_ms": round(compute_ms, 3),
+                "gather_ms": round(gather_ms, 3)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        per_rank = allr
     # the latency-optimal setting beside the throughput one, measured after the timed region: one batch at a time on the
     # default stream (what a scaling run with the side-stream gather uses); eager launches, same step
     single_stream = None
-    if streams and not stub and world == 1:
+    if streams and not stub and world == 1 and not use_graph:
         slot[0] = 0
         for _ in range(3):
             step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        ms1 = (time.perf_counter() - t1) / args.steps * 1e3
+        iss1, ms1 = issue_and_step_ms(step, args.steps)
         single_stream = {"ms_per_step": round(ms1, 3), "chips_s": round(B / ms1 * 1e3, 1), "steps": args.steps,
+                         "host_issue_ms_per_step": round(iss1, 3),
                          "note": "one batch at a time on one HIP stream (--streams 1), measured after the timed region"}
+        # the same step replayed from a captured HIP graph: one host call per batch (what N > 1 ranks switch to when their
+        # eager issue time exceeds half a step)
+        try:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                detect_only()
+            g1.replay()
+            issg, msg = issue_and_step_ms(g1.replay, args.steps)
+            single_stream["graph_replay"] = {"ms_per_step": round(msg, 3), "chips_s": round(B / msg * 1e3, 1),
+                                             "host_issue_ms_per_step": round(issg, 3)}
+        except Exception as e:
+            sync()
+            single_stream["graph_replay"] = {"failed": repr(e)}
     # outside the timed region: the static candidate cap must not have cut a single row in any step (the reference
     # never drops a candidate, utils/bbox_nms_rotated.py:29-40) -- one host read
     n_dropped = int(sum(int(d.item()) for d in dropped))
@@ -836,6 +913,7 @@ def main():
         "unit": "chips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "host_issue_ms_per_step": round(host_issue_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {
@@ -851,8 +929,11 @@ def main():
             "distinct_input_batches": 1 if stub else len(batches),
             "fam_cls_branch": not args.no_fam_cls, "hip_graph": bool(args.graph), "batches_in_flight": args.streams,
             "parallelism": "dp%d (one process per GPU)" % world, "collective_backend": collective,
+            "cpus_per_rank": cpus_per_rank,
         },
     }
+    if graph_reason is not None:
+        result["config"]["graph_decision"] = graph_reason
     if single_stream is not None:
         result["single_stream"] = single_stream
     if per_rank is not None:
