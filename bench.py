@@ -225,6 +225,14 @@ def measure_alignconv(model, batch, dtype, cap, iters=100):
     ach = flops / sec / 1e12
     # HBM traffic per launch: a recorded measurement (PMC passes cannot run inside this process), see recorded_traffic
     traffic, stale = recorded_traffic("align_conv_pyramid", batch, npos) if (cap is not None and es == 2) else (None, True)
+    probe = None
+    if cap is not None:
+        from s2anet_amd.alignconv import pack_weight
+        g = torch.Generator(device="cpu").manual_seed(7)
+        xd = torch.randn(x.shape, generator=g).to(x.device, x.dtype)
+        wdn = pack_weight((torch.randn(O, C, 3, 3, generator=g) * 0.02).to(x.device).to(dtype), dtype)
+        xz, wzn = torch.zeros_like(x), pack_weight(torch.zeros(O, C, 3, 3, device=x.device, dtype=dtype), dtype)
+        probe = _clock_probe(lambda: P.align_conv(layout, xz, anc, wzn, O), lambda: P.align_conv(layout, xd, anc, wdn, O))
     return {
         "kernel": "%s (fused AlignConv: anchors -> sampling -> 3x3 contraction -> ReLU; %s, batch %d, %s)"
                   % (kname, shape, batch, "f16" if es == 2 else "f32"),
@@ -233,11 +241,20 @@ def measure_alignconv(model, batch, dtype, cap, iters=100):
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_stale": stale,
         "avg_launch_us": round(sec * 1e6, 1),
+        "clock_probe": probe,
         "flops_per_launch": flops,
         "hbm_algorithmic_bytes_per_launch": alg_bytes,
         "hbm_achieved_GBs": round(alg_bytes / sec / 1e9, 1),
         "hbm_frac_of_8TBs": round(alg_bytes / sec / 1e9 / PEAK_HBM_GBS, 4),
     }
+
+
+def _clock_probe(launch_zero, launch_dense, iters=60):
+    """the same launch on all-zero and on dense random operands (scripts/pyr_power_probe.py): equal instruction streams, so
+    the two times differ only by the clock the chip holds -- a reader can split `frac` into kernel and DVFS"""
+    return {"zeros_us": round(_time_launches(launch_zero, iters) * 1e6, 1),
+            "dense_us": round(_time_launches(launch_dense, iters) * 1e6, 1),
+            "note": "same launch, all-zero vs dense N(0,1) operands; the step's own (ReLU-sparse) data is avg_launch_us"}
 
 
 def measure_conv_tower(model, cap, iters=100):
@@ -250,6 +267,12 @@ def measure_conv_tower(model, cap, iters=100):
     flops = 2.0 * 256 * 2304 * layout.pixels
     ach = flops / sec / 1e12
     traffic, stale = recorded_traffic("conv_tower_pyramid", layout.batch, layout.pixels)
+    from s2anet_amd.fused import conv_pack_weight
+    g = torch.Generator(device="cpu").manual_seed(7)
+    xd = torch.randn(x.shape, generator=g).to(x.device, x.dtype)
+    wd = conv_pack_weight((torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(x.device).half())
+    xz, wz = torch.zeros_like(x), torch.zeros_like(w)
+    probe = _clock_probe(lambda: P.conv3x3(layout, xz, wz, b, o, relu=True), lambda: P.conv3x3(layout, xd, wd, b, o, relu=True))
     return {"kernel": "k_conv_f16<9,4,2> (head conv tower 3x3 256->256 + bias + ReLU; five FPN levels pyramid-packed, "
                       "%d positions, f16)" % layout.pixels,
             "timing": "%d back-to-back launches of the step's own launch, alone on the GPU" % iters,
@@ -257,6 +280,7 @@ def measure_conv_tower(model, cap, iters=100):
             "frac": round(ach / PEAK_F16_TFLOPS, 4),
             "traffic": traffic, "traffic_stale": stale,
             "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops,
+            "clock_probe": probe,
             "hbm_algorithmic_bytes_per_launch": int(layout.pixels * 512 * 2 + 256 * 2304 * 2)}
 
 

@@ -39,7 +39,8 @@ extern "C" {
 
 #define S2A_DTYPE_F32 0
 #define S2A_DTYPE_F16 1
-#define S2A_DTYPE_F64 2 /* ARF forward / backward only (AT_DISPATCH_FLOATING_TYPES, ActiveRotatingFilter_cuda.cu:104,149) */
+#define S2A_DTYPE_F64 2 /* ARF forward / backward (AT_DISPATCH_FLOATING_TYPES, ActiveRotatingFilter_cuda.cu:104,149) and the generic
+                           deformable convolution + its three backward kernels (deform_conv_cuda_kernel.cu:258,352,450) */
 
 #define S2A_LAYOUT_NCHW 0 /* reference layout (contiguous NCHW) */
 #define S2A_LAYOUT_NHWC 1 /* channels-last storage of the same logical tensor */
@@ -175,7 +176,9 @@ int s2a_nms_rotated_segmented(const float* dets, const float* scores, const int3
  *   labels_out int32 [num_groups][max_per_group] (-1 padded) and counts_out int32 [num_groups]: optional copies.
  * row_labels[n] int32 = class of every row (out_cls of s2a_multiclass_candidates).
  * cand_found (device int64, may be NULL) = the untruncated candidate count of s2a_multiclass_candidates whose first
- * n rows these are: overflow_out (device int64[2], may be NULL) receives [found, found - n clamped at 0] and
+ * n rows these are.  Rows at or behind min(*cand_found, n) are PADDING by contract: they are never kept and (on every
+ * internal path) never take part in a comparison, whatever their segment id -- a caller that passes a smaller count
+ * than it filled rows cuts its own input.  overflow_out (device int64[2], may be NULL) receives [found, found - n clamped at 0] and
  * *dropped_total (device int64, may be NULL) is incremented by the second number (the reference never drops a
  * candidate, so a caller with a static row cap must be able to prove that nothing was cut). */
 int s2a_nms_rotated_segmented_dets(const float* dets, const float* scores, const int32_t* segment_ids,
@@ -364,12 +367,15 @@ int s2a_conv_nhwc_f16(const void* x, const void* weight_frag, const void* bias, 
  * deformable_col2im (:332-370), deformable_col2im_coord (:431-464).  p->batch = the number of images of
  * the chunk (the reference's im2col_step / parallel_imgs); layouts as the reference: im [S,C,H,W],
  * offset [S, dg*2*kH*kW, Ho, Wo] (same dtype as im), columns [C*kH*kW, S*Ho*Wo]; NCHW only.
- * s2a_deformable_col2im ACCUMULATES into grad_im_f32 [S,C,H,W] (always f32; caller zeroes it, as
- * deform_conv.py:88-90 does); s2a_deformable_col2im_coord overwrites grad_offset.  The GEMMs around
- * them (deform_conv_cuda.cpp:323-324, :455-459 addmm_) are library GEMMs on the host side. */
+ * s2a_deformable_col2im ACCUMULATES into grad_im_acc [S,C,H,W] (float32 for float32 / float16 columns, float64 for
+ * float64 columns; caller zeroes it, as deform_conv.py:88-90 does); s2a_deformable_col2im_coord overwrites grad_offset.
+ * The GEMMs around them (deform_conv_cuda.cpp:323-324, :455-459 addmm_) are library GEMMs on the host side.
+ * dtype S2A_DTYPE_F64 (the reference dispatches these kernels on double too: AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * deform_conv_cuda_kernel.cu:258,352,450): evaluated in double throughout -- s2a_deform_conv_forward takes it on its
+ * generic NCHW kernel (offsets float64 as well), and torch.autograd.gradcheck ties backward to forward on it. */
 int s2a_deformable_im2col(const void* im, const void* offset, void* columns, const s2a_dcn_params* p,
                           s2a_stream_t stream);
-int s2a_deformable_col2im(const void* columns, const void* offset, float* grad_im_f32,
+int s2a_deformable_col2im(const void* columns, const void* offset, void* grad_im_acc,
                           const s2a_dcn_params* p, s2a_stream_t stream);
 int s2a_deformable_col2im_coord(const void* columns, const void* im, const void* offset, void* grad_offset,
                                 const s2a_dcn_params* p, s2a_stream_t stream);

@@ -388,6 +388,51 @@ def deform_conv_forward(x, offset, weight, stride=(1, 1), padding=(1, 1), dilati
     return out
 
 
+def deform_conv_forward_f64(x, offset, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1,
+                            deformable_groups=1):
+    """the reference's scalar_t = double instantiation (AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:258):
+    deformable_im2col (:189-242) + deformable_im2col_bilinear (:83-114) + the per-group GEMM (deform_conv_cuda.cpp:222-237),
+    every operation in float64 -- plain numpy, small shapes only (test infrastructure like the rest of this package)"""
+    x, offset, weight = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, offset, weight))
+    B, C, H, W = x.shape
+    O, Cg, kH, kW = weight.shape
+    Ho = (H + 2 * padding[0] - (dilation[0] * (kH - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (kW - 1) + 1)) // stride[1] + 1
+    assert offset.shape == (B, deformable_groups * 2 * kH * kW, Ho, Wo) and Cg * groups == C
+    cols = np.zeros((B, C, kH * kW, Ho, Wo), np.float64)
+    ho, wo = np.meshgrid(np.arange(Ho), np.arange(Wo), indexing="ij")
+    cpdg = C // deformable_groups
+    for b in range(B):
+        for c in range(C):
+            dg = c // cpdg
+            im = x[b, c]
+            for i in range(kH):
+                for j in range(kW):
+                    t = i * kW + j
+                    h_im = (ho * stride[0] - padding[0] + i * dilation[0]) + offset[b, dg * 2 * kH * kW + 2 * t]
+                    w_im = (wo * stride[1] - padding[1] + j * dilation[1]) + offset[b, dg * 2 * kH * kW + 2 * t + 1]
+                    ok = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)            # :228
+                    hl, wl = np.floor(h_im).astype(np.int64), np.floor(w_im).astype(np.int64)
+                    hh_, wh_ = hl + 1, wl + 1
+                    lh, lw = h_im - hl, w_im - wl
+                    hh, hw = 1 - lh, 1 - lw
+
+                    def at(yy, xx, keep):
+                        keep = keep & ok
+                        return np.where(keep, im[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], 0.0)
+                    v1 = at(hl, wl, (hl >= 0) & (wl >= 0))                              # :97-108
+                    v2 = at(hl, wh_, (hl >= 0) & (wh_ <= W - 1))
+                    v3 = at(hh_, wl, (hh_ <= H - 1) & (wl >= 0))
+                    v4 = at(hh_, wh_, (hh_ <= H - 1) & (wh_ <= W - 1))
+                    cols[b, c, t] = np.where(ok, hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4, 0.0)   # :110-112
+    out = np.empty((B, O, Ho, Wo), np.float64)
+    Og = O // groups
+    for g in range(groups):
+        out[:, g * Og:(g + 1) * Og] = np.einsum("okt,bkthw->bohw", weight[g * Og:(g + 1) * Og].reshape(Og, Cg, kH * kW),
+                                                cols[:, g * Cg:(g + 1) * Cg])
+    return out
+
+
 def deform_conv_forward_half(x, offset, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), relu=False):
     """the reference's scalar_t = Half instantiation (models/dcn/deform_conv.py:45-46 casts the offsets to the input's
     dtype; deform_conv_cuda_kernel.cu:83-114,221-228 then compute h_im / w_im, the bilinear weights and the blend in

@@ -195,12 +195,15 @@ def require_cuda(*tensors):
             raise NotImplementedError("s2anet_amd ops run on the GPU only (got a CPU tensor)")
 
 
-def dtype_code(t):
+def dtype_code(t, f64=False):
+    """f64=True: entry points with a float64 instantiation (deformable convolution generic path, ARF)"""
     if t.dtype == torch.float32:
         return DTYPE_F32
     if t.dtype == torch.float16:
         return DTYPE_F16
-    raise TypeError(f"unsupported dtype {t.dtype} (float32 / float16 only)")
+    if f64 and t.dtype == torch.float64:
+        return DTYPE_F64
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 / float16{' / float64' if f64 else ''} only)")
 
 
 _ws_cache = {}

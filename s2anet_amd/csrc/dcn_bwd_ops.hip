@@ -26,16 +26,24 @@ struct BwdGeom {
   int C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg, S, Ho, Wo;
 };
 
+// arithmetic type of the three unfused kernels: the reference instantiates them per scalar type
+// (AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:258,352,450) -- double stays double (gradcheck runs on
+// it); float and half compute in float
 template <typename T>
-__device__ __forceinline__ float bilinear_at(const T* __restrict__ im, int W, int H, float h, float w) {
+struct BwdAcc { using type = float; };
+template <>
+struct BwdAcc<double> { using type = double; };
+
+template <typename T, typename A = float>
+__device__ __forceinline__ A bilinear_at(const T* __restrict__ im, int W, int H, A h, A w) {
   // deformable_im2col_bilinear (:83-114); caller has checked h > -1 && w > -1 && h < H && w < W
-  int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  int h_low = (int)floor(h), w_low = (int)floor(w);
   int h_high = h_low + 1, w_high = w_low + 1;
-  float lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
-  float v1 = (h_low >= 0 && w_low >= 0) ? (float)im[h_low * W + w_low] : 0.f;
-  float v2 = (h_low >= 0 && w_high <= W - 1) ? (float)im[h_low * W + w_high] : 0.f;
-  float v3 = (h_high <= H - 1 && w_low >= 0) ? (float)im[h_high * W + w_low] : 0.f;
-  float v4 = (h_high <= H - 1 && w_high <= W - 1) ? (float)im[h_high * W + w_high] : 0.f;
+  A lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
+  A v1 = (h_low >= 0 && w_low >= 0) ? (A)im[h_low * W + w_low] : (A)0;
+  A v2 = (h_low >= 0 && w_high <= W - 1) ? (A)im[h_low * W + w_high] : (A)0;
+  A v3 = (h_high <= H - 1 && w_low >= 0) ? (A)im[h_high * W + w_low] : (A)0;
+  A v4 = (h_high <= H - 1 && w_high <= W - 1) ? (A)im[h_high * W + w_high] : (A)0;
   return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
 }
 
@@ -43,6 +51,7 @@ __device__ __forceinline__ float bilinear_at(const T* __restrict__ im, int W, in
 template <typename T>
 __global__ void k_def_im2col(int64_t n, const T* __restrict__ im, const T* __restrict__ offset, BwdGeom g,
                              T* __restrict__ col) {
+  using A = typename BwdAcc<T>::type;
   for (int64_t index = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; index < n;
        index += (int64_t)gridDim.x * blockDim.x) {
     const int w_col = (int)(index % g.Wo);
@@ -58,19 +67,20 @@ __global__ void k_def_im2col(int64_t n, const T* __restrict__ im, const T* __res
     for (int i = 0; i < g.kh; i++)
       for (int j = 0; j < g.kw; j++) {
         const int t = i * g.kw + j;
-        const float oh = (float)offp[(int64_t)(2 * t) * HoWo], ow = (float)offp[(int64_t)(2 * t + 1) * HoWo];
-        const float h_im = h_in + i * g.dil_h + oh, w_im = w_in + j * g.dil_w + ow;
-        float val = 0.f;
-        if (h_im > -1 && w_im > -1 && h_im < g.H && w_im < g.W) val = bilinear_at(imp, g.W, g.H, h_im, w_im);
+        const A oh = (A)offp[(int64_t)(2 * t) * HoWo], ow = (A)offp[(int64_t)(2 * t + 1) * HoWo];
+        const A h_im = h_in + i * g.dil_h + oh, w_im = w_in + j * g.dil_w + ow;
+        A val = 0;
+        if (h_im > -1 && w_im > -1 && h_im < g.H && w_im < g.W) val = bilinear_at<T, A>(imp, g.W, g.H, h_im, w_im);
         colp[(int64_t)t * g.S * HoWo] = (T)val;
       }
   }
 }
 
-__device__ __forceinline__ float gradient_weight(float ah, float aw, int h, int w, int H, int W) {
-  if (ah <= -1 || ah >= H || aw <= -1 || aw >= W) return 0.f;
-  int hl = (int)floorf(ah), wl = (int)floorf(aw), hh = hl + 1, wh = wl + 1;
-  float weight = 0.f;
+template <typename A = float>
+__device__ __forceinline__ A gradient_weight(A ah, A aw, int h, int w, int H, int W) {
+  if (ah <= -1 || ah >= H || aw <= -1 || aw >= W) return (A)0;
+  int hl = (int)floor(ah), wl = (int)floor(aw), hh = hl + 1, wh = wl + 1;
+  A weight = 0;
   if (h == hl && w == wl) weight = (h + 1 - ah) * (w + 1 - aw);
   if (h == hl && w == wh) weight = (h + 1 - ah) * (aw + 1 - w);
   if (h == hh && w == wl) weight = (ah + 1 - h) * (w + 1 - aw);
@@ -81,7 +91,8 @@ __device__ __forceinline__ float gradient_weight(float ah, float aw, int h, int 
 // one thread per column entry (c, i, j, s, h_out, w_out): scatter into grad_im (f32, atomics)
 template <typename T>
 __global__ void k_def_col2im(int64_t n, const T* __restrict__ col, const T* __restrict__ offset, BwdGeom g,
-                             float* __restrict__ grad_im) {
+                             typename BwdAcc<T>::type* __restrict__ grad_im) {
+  using A = typename BwdAcc<T>::type;
   for (int64_t index = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; index < n;
        index += (int64_t)gridDim.x * blockDim.x) {
     const int w_out = (int)(index % g.Wo);
@@ -94,16 +105,16 @@ __global__ void k_def_col2im(int64_t n, const T* __restrict__ col, const T* __re
     const int64_t HoWo = (int64_t)g.Ho * g.Wo;
     const T* offp = offset + ((int64_t)s * g.dg + dgi) * 2 * g.kh * g.kw * HoWo + (int64_t)h_out * g.Wo + w_out;
     const int t = i * g.kw + j;
-    const float oh = (float)offp[(int64_t)(2 * t) * HoWo], ow = (float)offp[(int64_t)(2 * t + 1) * HoWo];
-    const float ch = h_out * g.stride_h - g.pad_h + i * g.dil_h + oh;
-    const float cw = w_out * g.stride_w - g.pad_w + j * g.dil_w + ow;
-    const float top = (float)col[index];
+    const A oh = (A)offp[(int64_t)(2 * t) * HoWo], ow = (A)offp[(int64_t)(2 * t + 1) * HoWo];
+    const A ch = h_out * g.stride_h - g.pad_h + i * g.dil_h + oh;
+    const A cw = w_out * g.stride_w - g.pad_w + j * g.dil_w + ow;
+    const A top = (A)col[index];
     const int cur_h = (int)ch, cur_w = (int)cw;      // truncation toward zero, as the reference (:318-319)
     for (int dy = -2; dy <= 2; dy++)
       for (int dx = -2; dx <= 2; dx++) {
         const int y = cur_h + dy, x = cur_w + dx;
-        if (y >= 0 && y < g.H && x >= 0 && x < g.W && fabsf(ch - y) < 1 && fabsf(cw - x) < 1) {
-          const float wgt = gradient_weight(ch, cw, y, x, g.H, g.W);
+        if (y >= 0 && y < g.H && x >= 0 && x < g.W && fabs(ch - y) < 1 && fabs(cw - x) < 1) {
+          const A wgt = gradient_weight<A>(ch, cw, y, x, g.H, g.W);
           atomicAdd(grad_im + (((int64_t)s * g.C + c) * g.H + y) * g.W + x, wgt * top);
         }
       }
@@ -173,22 +184,21 @@ __global__ __launch_bounds__(256) void k_def_col2im_tiled(const T* __restrict__ 
   }
 }
 
-template <typename T>
-__device__ __forceinline__ float coordinate_weight(float ah, float aw, int H, int W, const T* __restrict__ im,
-                                                   int dir) {
-  if (ah <= -1 || ah >= H || aw <= -1 || aw >= W) return 0.f;
-  int hl = (int)floorf(ah), wl = (int)floorf(aw), hh = hl + 1, wh = wl + 1;
-  float weight = 0.f;
+template <typename T, typename A = float>
+__device__ __forceinline__ A coordinate_weight(A ah, A aw, int H, int W, const T* __restrict__ im, int dir) {
+  if (ah <= -1 || ah >= H || aw <= -1 || aw >= W) return (A)0;
+  int hl = (int)floor(ah), wl = (int)floor(aw), hh = hl + 1, wh = wl + 1;
+  A weight = 0;
   if (dir == 0) {
-    if (hl >= 0 && wl >= 0) weight += -1 * (wl + 1 - aw) * (float)im[hl * W + wl];
-    if (hl >= 0 && wh <= W - 1) weight += -1 * (aw - wl) * (float)im[hl * W + wh];
-    if (hh <= H - 1 && wl >= 0) weight += (wl + 1 - aw) * (float)im[hh * W + wl];
-    if (hh <= H - 1 && wh <= W - 1) weight += (aw - wl) * (float)im[hh * W + wh];
+    if (hl >= 0 && wl >= 0) weight += -1 * (wl + 1 - aw) * (A)im[hl * W + wl];
+    if (hl >= 0 && wh <= W - 1) weight += -1 * (aw - wl) * (A)im[hl * W + wh];
+    if (hh <= H - 1 && wl >= 0) weight += (wl + 1 - aw) * (A)im[hh * W + wl];
+    if (hh <= H - 1 && wh <= W - 1) weight += (aw - wl) * (A)im[hh * W + wh];
   } else {
-    if (hl >= 0 && wl >= 0) weight += -1 * (hl + 1 - ah) * (float)im[hl * W + wl];
-    if (hl >= 0 && wh <= W - 1) weight += (hl + 1 - ah) * (float)im[hl * W + wh];
-    if (hh <= H - 1 && wl >= 0) weight += -1 * (ah - hl) * (float)im[hh * W + wl];
-    if (hh <= H - 1 && wh <= W - 1) weight += (ah - hl) * (float)im[hh * W + wh];
+    if (hl >= 0 && wl >= 0) weight += -1 * (hl + 1 - ah) * (A)im[hl * W + wl];
+    if (hl >= 0 && wh <= W - 1) weight += (hl + 1 - ah) * (A)im[hl * W + wh];
+    if (hh <= H - 1 && wl >= 0) weight += -1 * (ah - hl) * (A)im[hh * W + wl];
+    if (hh <= H - 1 && wh <= W - 1) weight += (ah - hl) * (A)im[hh * W + wh];
   }
   return weight;
 }
@@ -197,6 +207,7 @@ __device__ __forceinline__ float coordinate_weight(float ah, float aw, int H, in
 template <typename T>
 __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T* __restrict__ im,
                                    const T* __restrict__ offset, BwdGeom g, T* __restrict__ grad_offset) {
+  using A = typename BwdAcc<T>::type;
   const int offset_channels = 2 * g.kh * g.kw * g.dg;
   const int cpg = g.C / g.dg;                 // image channels per deformable group
   for (int64_t index = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; index < n;
@@ -211,17 +222,17 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
     const int i = t / g.kw, j = t % g.kw;
     const int64_t HoWo = (int64_t)g.Ho * g.Wo;
     const T* offp = offset + ((int64_t)s * g.dg + dgi) * 2 * g.kh * g.kw * HoWo + (int64_t)h * g.Wo + w;
-    const float oh = (float)offp[(int64_t)(2 * t) * HoWo], ow = (float)offp[(int64_t)(2 * t + 1) * HoWo];
-    float inv_h = h * g.stride_h - g.pad_h + i * g.dil_h + oh;
-    float inv_w = w * g.stride_w - g.pad_w + j * g.dil_w + ow;
+    const A oh = (A)offp[(int64_t)(2 * t) * HoWo], ow = (A)offp[(int64_t)(2 * t + 1) * HoWo];
+    A inv_h = h * g.stride_h - g.pad_h + i * g.dil_h + oh;
+    A inv_w = w * g.stride_w - g.pad_w + j * g.dil_w + ow;
     if (inv_h <= -1 || inv_w <= -1 || inv_h >= g.H || inv_w >= g.W) inv_h = inv_w = -2;
-    float val = 0.f;
+    A val = 0;
     for (int cc = 0; cc < cpg; cc++) {
       const int ch = dgi * cpg + cc;
       const T* imp = im + ((int64_t)s * g.C + ch) * g.H * g.W;
-      const float cw = coordinate_weight(inv_h, inv_w, g.H, g.W, imp, dir);
+      const A cw = coordinate_weight<T, A>(inv_h, inv_w, g.H, g.W, imp, dir);
       const int64_t col_pos = (((int64_t)ch * g.kh * g.kw + t) * g.S + s) * HoWo + (int64_t)h * g.Wo + w;
-      val += cw * (float)col[col_pos];
+      val += cw * (A)col[col_pos];
     }
     grad_offset[index] = (T)val;
   }
@@ -1672,7 +1683,7 @@ int make_geom(const s2a_dcn_params* pp, BwdGeom* g, const char* who) {
                 p.deformable_group > 0, "%s: bad kernel geometry", who);
   S2A_CHECK_ARG(p.batch >= 0 && p.channels > 0 && p.height > 0 && p.width > 0, "%s: bad shape", who);
   S2A_CHECK_ARG(p.channels % p.deformable_group == 0, "input channels must divide deformable group size");
-  S2A_CHECK_ARG(p.dtype == S2A_DTYPE_F32 || p.dtype == S2A_DTYPE_F16, "%s: dtype", who);
+  S2A_CHECK_ARG(p.dtype == S2A_DTYPE_F32 || p.dtype == S2A_DTYPE_F16 || p.dtype == S2A_DTYPE_F64, "%s: dtype", who);
   S2A_CHECK_ARG(p.layout == S2A_LAYOUT_NCHW, "%s: NCHW only", who);
   const int64_t Ho = (p.height + 2 * p.padH - (p.dilationH * (p.kH - 1) + 1)) / p.dH + 1;
   const int64_t Wo = (p.width + 2 * p.padW - (p.dilationW * (p.kW - 1) + 1)) / p.dW + 1;
@@ -1719,7 +1730,9 @@ extern "C" int s2a_deformable_im2col(const void* im, const void* offset, void* c
   if (n == 0) return S2A_OK;
   S2A_CHECK_ARG(im && offset && columns, "deformable_im2col: NULL tensor");
   hipStream_t st = as_stream(stream);
-  if (p->dtype == S2A_DTYPE_F32)
+  if (p->dtype == S2A_DTYPE_F64)
+    k_def_im2col<double><<<grid_for(n), 256, 0, st>>>(n, (const double*)im, (const double*)offset, g, (double*)columns);
+  else if (p->dtype == S2A_DTYPE_F32)
     k_def_im2col<float><<<grid_for(n), 256, 0, st>>>(n, (const float*)im, (const float*)offset, g, (float*)columns);
   else
     k_def_im2col<_Float16><<<grid_for(n), 256, 0, st>>>(n, (const _Float16*)im, (const _Float16*)offset, g, (_Float16*)columns);
@@ -1727,8 +1740,9 @@ extern "C" int s2a_deformable_im2col(const void* im, const void* offset, void* c
   return S2A_OK;
 }
 
-extern "C" int s2a_deformable_col2im(const void* columns, const void* offset, float* grad_im_f32,
+extern "C" int s2a_deformable_col2im(const void* columns, const void* offset, void* grad_im_acc,
                                      const s2a_dcn_params* p, s2a_stream_t stream) {
+  float* grad_im_f32 = (float*)grad_im_acc;      // float32 accumulator (float32 / float16 columns); float64 for float64 columns
   BwdGeom g;
   int rc = make_geom(p, &g, "deformable_col2im");
   if (rc != S2A_OK) return rc;
@@ -1736,6 +1750,11 @@ extern "C" int s2a_deformable_col2im(const void* columns, const void* offset, fl
   if (n == 0) return S2A_OK;
   S2A_CHECK_ARG(columns && offset && grad_im_f32, "deformable_col2im: NULL tensor");
   hipStream_t st = as_stream(stream);
+  if (p->dtype == S2A_DTYPE_F64) {
+    k_def_col2im<double><<<grid_for(n), 256, 0, st>>>(n, (const double*)columns, (const double*)offset, g, (double*)grad_im_acc);
+    S2A_LAUNCH_CHECK();
+    return S2A_OK;
+  }
   const bool tiled = g.kh == 3 && g.kw == 3 && g.stride_h == 1 && g.stride_w == 1 && g.dil_h == 1 && g.dil_w == 1 &&
                      (g.C / g.dg) % kC2Ch == 0 && !getenv("S2A_COL2IM_SIMPLE");
   if (tiled) {
@@ -1762,7 +1781,10 @@ extern "C" int s2a_deformable_col2im_coord(const void* columns, const void* im, 
   if (n == 0) return S2A_OK;
   S2A_CHECK_ARG(columns && im && offset && grad_offset, "deformable_col2im_coord: NULL tensor");
   hipStream_t st = as_stream(stream);
-  if (p->dtype == S2A_DTYPE_F32)
+  if (p->dtype == S2A_DTYPE_F64)
+    k_def_col2im_coord<double><<<grid_for(n), 256, 0, st>>>(n, (const double*)columns, (const double*)im,
+                                                            (const double*)offset, g, (double*)grad_offset);
+  else if (p->dtype == S2A_DTYPE_F32)
     k_def_col2im_coord<float><<<grid_for(n), 256, 0, st>>>(n, (const float*)columns, (const float*)im,
                                                            (const float*)offset, g, (float*)grad_offset);
   else
@@ -1808,6 +1830,8 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
   S2A_CHECK_ARG(O <= 256, "%s: needs out_channels <= 256", who);
   if (want_input) S2A_CHECK_ARG(C % 32 == 0 && O % 16 == 0, "%s: the input gradient needs channels %% 32 == 0, out_channels %% 16 == 0", who);
   if (want_weight) S2A_CHECK_ARG(C % 64 == 0 && O % 32 == 0, "%s: the weight gradient needs channels %% 64 == 0, out_channels %% 32 == 0", who);
+  // (every argument check sits in front of the first launch: a refused call leaves the caller's gradients untouched)
+  if (want_weight) S2A_CHECK_ARG(3 * (C / 64) <= kWgradMaxBlocks, "%s: the fused weight gradient takes channels <= %d", who, kWgradMaxBlocks / 3 * 64);
   if (B == 0 || (!want_input && !want_weight)) return S2A_OK;
   S2A_CHECK_ARG(a.input && a.offset && a.grad_output, "%s: NULL tensor", who);
   S2A_CHECK_ARG(!want_input || (a.weight && a.grad_offset), "%s: NULL tensor", who);
@@ -1848,7 +1872,6 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
   }
   if (want_weight) {
     const int owners = 3 * (int)(C / 64);
-    S2A_CHECK_ARG(owners <= kWgradMaxBlocks, "%s: the fused weight gradient takes channels <= %d", who, kWgradMaxBlocks / 3 * 64);
     int n_cu = 256;
     {
       int dev = 0;

@@ -2051,12 +2051,21 @@ constexpr int mfma_lds_bytes() { return NPOS * 9 * 32 + 2 * (kMaxO + NPOS) * kRo
 // mask / bias: the modulated form (DCNv2: modulated_deformable_im2col_gpu_kernel, deform_conv_cuda_kernel.cu:570-632:
 // every sampled value is multiplied by mask[b, dg, tap, ho, wo]; bias added after the contraction,
 // deform_conv_cuda.cpp:566-568); both null = plain deformable convolution.
+// arithmetic type of the generic kernel: the reference instantiates its kernels per scalar type
+// (AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:258,352,450): double stays double; float and half compute in
+// float here (half columns rounded once, as the fused f16 path)
+template <typename T>
+struct GenAcc { using type = float; };
+template <>
+struct GenAcc<double> { using type = double; };
+
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void k_dcn_generic(const T* __restrict__ x, const TO* __restrict__ offset,
                                                      const T* __restrict__ w, T* __restrict__ out,
                                                      s2a_dcn_params p, int Ho, int Wo,
                                                      const T* __restrict__ mask = nullptr,
                                                      const T* __restrict__ bias = nullptr) {
+  using A = typename GenAcc<T>::type;
   const int64_t total = p.batch * p.out_channels * Ho * Wo;
   const int Cg = (int)(p.channels / p.group), Og = (int)(p.out_channels / p.group);
   const int cpdg = (int)(p.channels / p.deformable_group);
@@ -2070,7 +2079,7 @@ __global__ __launch_bounds__(256) void k_dcn_generic(const T* __restrict__ x, co
     int o = (int)(r % p.out_channels);
     int64_t b = r / p.out_channels;
     int g = o / Og;
-    float acc = 0.f;
+    A acc = 0;
     for (int cl = 0; cl < Cg; cl++) {
       int c = g * Cg + cl;
       int dg = c / cpdg;
@@ -2080,34 +2089,35 @@ __global__ __launch_bounds__(256) void k_dcn_generic(const T* __restrict__ x, co
       for (int i = 0; i < p.kH; i++)
         for (int j = 0; j < p.kW; j++) {
           int t = i * p.kW + j;
-          float oh = (float)offp[((int64_t)(2 * t) * Ho + ho) * Wo + wo];
-          float ow = (float)offp[((int64_t)(2 * t + 1) * Ho + ho) * Wo + wo];
-          float h_im = (float)(ho * p.dH - p.padH + i * p.dilationH) + oh;
-          float w_im = (float)(wo * p.dW - p.padW + j * p.dilationW) + ow;
-          float v = 0.f;
+          A oh = (A)offp[((int64_t)(2 * t) * Ho + ho) * Wo + wo];
+          A ow = (A)offp[((int64_t)(2 * t + 1) * Ho + ho) * Wo + wo];
+          A h_im = (A)(ho * p.dH - p.padH + i * p.dilationH) + oh;
+          A w_im = (A)(wo * p.dW - p.padW + j * p.dilationW) + ow;
+          A v = 0;
           if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
-            int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            int h_low = (int)floor(h_im), w_low = (int)floor(w_im);
             int h_high = h_low + 1, w_high = w_low + 1;
-            float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
-            float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-            if (h_low >= 0 && w_low >= 0) v1 = (float)plane[h_low * W + w_low];
-            if (h_low >= 0 && w_high <= W - 1) v2 = (float)plane[h_low * W + w_high];
-            if (h_high <= H - 1 && w_low >= 0) v3 = (float)plane[h_high * W + w_low];
-            if (h_high <= H - 1 && w_high <= W - 1) v4 = (float)plane[h_high * W + w_high];
+            A lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+            A v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+            if (h_low >= 0 && w_low >= 0) v1 = (A)plane[h_low * W + w_low];
+            if (h_low >= 0 && w_high <= W - 1) v2 = (A)plane[h_low * W + w_high];
+            if (h_high <= H - 1 && w_low >= 0) v3 = (A)plane[h_high * W + w_low];
+            if (h_high <= H - 1 && w_high <= W - 1) v4 = (A)plane[h_high * W + w_high];
             v = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
           }
-          if (maskp) v *= (float)maskp[((int64_t)t * Ho + ho) * Wo + wo];
-          if (sizeof(T) == 2) v = (float)(T)v;  // f16 columns, as the f16 fast path
-          acc += (float)w[(((int64_t)o * Cg + cl) * p.kH + i) * p.kW + j] * v;
+          if (maskp) v *= (A)maskp[((int64_t)t * Ho + ho) * Wo + wo];
+          if (sizeof(T) == 2) v = (A)(T)v;  // f16 columns, as the f16 fast path
+          acc += (A)w[(((int64_t)o * Cg + cl) * p.kH + i) * p.kW + j] * v;
         }
     }
-    if (bias) acc += (float)bias[o];
-    if (p.relu) acc = fmaxf(acc, 0.f);
+    if (bias) acc += (A)bias[o];
+    if (p.relu) acc = acc > 0 ? acc : (A)0;
     out[e] = (T)acc;
   }
 }
 
 inline bool fast_path_ok(const s2a_dcn_params& p) {
+  if (p.dtype == S2A_DTYPE_F64) return false;       // float64: the generic kernel (API completeness, not a hot path)
   int kc = p.dtype == S2A_DTYPE_F32 ? 32 : 64;
   return p.kW == 3 && p.kH == 3 && p.dW == 1 && p.dH == 1 && p.padW == 1 && p.padH == 1 &&
          p.dilationW == 1 && p.dilationH == 1 && p.group == 1 && p.deformable_group == 1 &&
@@ -2115,7 +2125,7 @@ inline bool fast_path_ok(const s2a_dcn_params& p) {
          p.batch * p.height * p.width < (1ll << 31);
 }
 
-inline size_t esize(int dtype) { return dtype == S2A_DTYPE_F32 ? 4 : 2; }
+inline size_t esize(int dtype) { return dtype == S2A_DTYPE_F64 ? 8 : (dtype == S2A_DTYPE_F32 ? 4 : 2); }
 
 inline bool half_coords_requested() {
   const char* f = getenv("S2A_DCN_HALF_COORDS");
@@ -2274,8 +2284,9 @@ extern "C" int s2a_deform_conv_forward(const void* input, const void* weight, co
   S2A_CHECK_ARG(p.group > 0 && p.deformable_group > 0, "deform_conv: group counts must be positive");
   S2A_CHECK_ARG(p.channels % p.group == 0 && p.out_channels % p.group == 0, "deform_conv: channels must divide groups");
   S2A_CHECK_ARG(p.channels % p.deformable_group == 0, "input channels must divide deformable group size");
-  S2A_CHECK_ARG(p.dtype == S2A_DTYPE_F32 || p.dtype == S2A_DTYPE_F16, "deform_conv: dtype");
-  S2A_CHECK_ARG(p.offset_dtype == S2A_DTYPE_F32 || p.offset_dtype == p.dtype, "deform_conv: offset dtype");
+  S2A_CHECK_ARG(p.dtype == S2A_DTYPE_F32 || p.dtype == S2A_DTYPE_F16 || p.dtype == S2A_DTYPE_F64, "deform_conv: dtype");
+  S2A_CHECK_ARG(p.dtype == S2A_DTYPE_F64 ? p.offset_dtype == S2A_DTYPE_F64 : (p.offset_dtype == S2A_DTYPE_F32 || p.offset_dtype == p.dtype),
+                "deform_conv: offset dtype (float64 input: float64 offsets; otherwise float32 or the input's)");
   const int64_t Ho = (p.height + 2 * p.padH - (p.dilationH * (p.kH - 1) + 1)) / p.dH + 1;
   const int64_t Wo = (p.width + 2 * p.padW - (p.dilationW * (p.kW - 1) + 1)) / p.dW + 1;
   S2A_CHECK_ARG(Ho >= 1 && Wo >= 1, "Given input size: (%lld x %lld x %lld). Calculated output size: (%lld x %lld x %lld). Output size is too small",
@@ -2296,7 +2307,9 @@ extern "C" int s2a_deform_conv_forward(const void* input, const void* weight, co
   S2A_CHECK_ARG(p.layout == S2A_LAYOUT_NCHW, "deform_conv: the generic path supports NCHW only");
   const int64_t total = p.batch * p.out_channels * Ho * Wo;
   unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 65535);
-  if (p.dtype == S2A_DTYPE_F32)
+  if (p.dtype == S2A_DTYPE_F64)
+    k_dcn_generic<double, double><<<g, 256, 0, st>>>((const double*)input, (const double*)offset, (const double*)weight, (double*)output, p, (int)Ho, (int)Wo);
+  else if (p.dtype == S2A_DTYPE_F32)
     k_dcn_generic<float, float><<<g, 256, 0, st>>>((const float*)input, (const float*)offset, (const float*)weight, (float*)output, p, (int)Ho, (int)Wo);
   else if (p.offset_dtype == S2A_DTYPE_F32)
     k_dcn_generic<_Float16, float><<<g, 256, 0, st>>>((const _Float16*)input, (const float*)offset, (const _Float16*)weight, (_Float16*)output, p, (int)Ho, (int)Wo);

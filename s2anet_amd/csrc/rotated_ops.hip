@@ -518,6 +518,13 @@ __device__ __forceinline__ uint32_t nms_segkey(const float* __restrict__ labels,
   return 0u;
 }
 
+// rows at or behind *row_limit (when given: the candidate count of the producer, s2a_multiclass_candidates) are padding by
+// contract and are never read: a detector batch fills a quarter of its static buffer
+__device__ __forceinline__ int64_t seg_row_limit(const long long* __restrict__ row_limit, int64_t n) {
+  if (!row_limit) return n;
+  const long long v = *row_limit;
+  return v < 0 ? 0 : (v < (long long)n ? (int64_t)v : n);
+}
 constexpr int kPrepBlocks = 1024;     // upper bound of k_nms_prep's grid = number of bounding-box partials
 constexpr int kSegCountBlocks = 4096; // upper bound of the block-count arrays (segment heads, kept rows)
 
@@ -626,8 +633,12 @@ __global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ dets
                                                   uint32_t* __restrict__ seg_cnt, size_t nseg_cnt,
                                                   uint2* __restrict__ lo, uint2* __restrict__ hi, size_t slots,
                                                   unsigned long long* __restrict__ htab, uint32_t* __restrict__ hist,
-                                                  uint32_t* __restrict__ spb_ctr, uint32_t hist_zero) {
+                                                  uint32_t* __restrict__ spb_ctr, uint32_t hist_zero,
+                                                  const long long* __restrict__ row_limit) {
   const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // rows at or behind *row_limit are padding on EVERY path (the own segment sort never reads them; here they get the
+  // ignore key, as rows with a negative segment id): the result does not depend on which sort a call takes
+  const size_t nl = seg_ids ? (size_t)seg_row_limit(row_limit, n) : (size_t)n;
   if (htab) {                                    // own order-B sort: table, histogram and counters (filled by k_spb_insert)
     for (size_t i = i0; i < kSpbSlots; i += stride) htab[i] = kSpbEmpty;
     for (size_t i = i0; i < kSpbHist + 64; i += stride) hist[i] = 0u;
@@ -642,9 +653,10 @@ __global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ dets
     for (size_t i = i0; i < slots; i += stride) { lo[i] = make_uint2(0xffffffffu, 0xffffffffu); hi[i] = make_uint2(0u, 0u); }
   uint32_t lx = 0xffffffffu, ly = 0xffffffffu, hx = 0u, hy = 0u;
   for (size_t i = i0; i < (size_t)n; i += stride) {
-    const uint32_t sk = nms_segkey(labels, seg_ids, ignore_key, (int64_t)i);
+    const bool pad = i >= nl;
+    const uint32_t sk = pad ? ignore_key : nms_segkey(labels, seg_ids, ignore_key, (int64_t)i);
     unsigned long long g = groups ? (unsigned long long)(uint32_t)groups[i] : 0ull;
-    if (seg_ids && seg_ids[i] < 0) g = num_groups;   // ignored row: sorts behind every real group
+    if (pad || (seg_ids && seg_ids[i] < 0)) g = num_groups;   // ignored row: sorts behind every real group
     const unsigned long long sc = (unsigned long long)(~float_sortable(scores[i]));
     keyA[i] = ((unsigned long long)sk << 32) | sc;
     if (keyC) keyC[i] = (g << 32) | sc;
@@ -1175,13 +1187,6 @@ __global__ __launch_bounds__(1024) void k_nms_group_emit(const unsigned long lon
   }
 }
 
-// rows at or behind *row_limit (when given: the candidate count of the producer, s2a_multiclass_candidates) are padding by
-// contract and are never read: a detector batch fills a quarter of its static buffer
-__device__ __forceinline__ int64_t seg_row_limit(const long long* __restrict__ row_limit, int64_t n) {
-  if (!row_limit) return n;
-  const long long v = *row_limit;
-  return v < 0 ? 0 : (v < (long long)n ? (int64_t)v : n);
-}
 // bitonic sort of P (power of two, >= 128) 64-bit keys in LDS, ascending; NT threads; ends with a barrier.  Compare-exchange
 // distances up to 64 stay inside an aligned block of 128 keys: those stages run per wave on its own blocks with the two keys
 // of a lane in REGISTERS (distance 64 = the lane's own pair, shorter distances by cross-lane exchange) -- no workgroup barrier
@@ -2972,10 +2977,15 @@ finish:
     __syncthreads();
     if (tid == 0) {                                  // the workgroup that finishes last reports and clears the slot
       if (atomicAdd(&ctl->done, 1u) == nd - 1u) {
-        *count_dev = (int64_t)total;
+        // the status is read AGAIN here: a workgroup that timed out in its poll raised bit 8 (and wrote none of its rows)
+        // possibly after this one took its copy above -- the reporter is the last to arrive, so every such atomicOr is
+        // ordered in front of this load; a non-zero value reports count 0 and the host takes the general path
+        const unsigned status_now = status | __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned total_now = status_now ? 0u : total;
+        *count_dev = (int64_t)total_now;
         // (the host reads these two words after it has synchronised the stream: no copy launch behind the kernel)
-        __hip_atomic_store(&host_result[0], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_result[1], status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_result[0], total_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_result[1], status_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();
         ctl->kept = 0; ctl->ticket = 0; ctl->status = 0; ctl->done = 0;     // ready for the next call on this slot
       }
@@ -3170,7 +3180,8 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   k_nms_prep<<<gp, 256, 0, st>>>(dets, scores, labels, seg_ids, group_ids, num_groups, ignore_key, n, B.keyA,
                                  need_c ? B.keyC : nullptr, B.idx, B.bbox_part, B.C,
                                  reinterpret_cast<uint32_t*>(B.blocked), (2 * sz + 3) / 4, B.seg_cnt, sz + 2, lo, B.hi, slots,
-                                 own_sort ? B.htab : nullptr, B.hist, B.spb_ctr, seg_sort ? (uint32_t)kSegSortMaxSeg + 8u : 0u);
+                                 own_sort ? B.htab : nullptr, B.hist, B.spb_ctr, seg_sort ? (uint32_t)kSegSortMaxSeg + 8u : 0u,
+                                 row_limit);
   // A call is as long as its chain of LAUNCHES while the kernels are short (the host needs ~5 us per launch, a rocPRIM
   // sort is nine of them).  For big segments only the spatial order B is enqueued in front of the cull, and everything
   // behind the cull works on SPATIAL positions (greedy direction from the rank keys): the score order A is needed by the
@@ -3384,7 +3395,11 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
   // the general path below.  S2A_NMS_SMALL=0: A/B, tests
   {
     const char* e = std::getenv("S2A_NMS_SMALL");
-    const bool small = host_count != nullptr && n <= kSmallN && !(e && e[0] == '0') && !stream_capturing(st) &&
+    // (single class, labels == NULL: the rows are ONE segment -- beyond kSmallSeg rows the kernel could only report
+    // "segment too long"; skipped on the host instead of paying its launch + synchronisation first.  A multi-label call
+    // whose largest label exceeds kSmallSeg is only known on the device: it still pays that detour.)
+    const bool small = host_count != nullptr && n <= kSmallN && !(labels == nullptr && n > kSmallSeg) &&
+                       !(e && e[0] == '0') && !stream_capturing(st) &&
                        ws != nullptr && ws_bytes >= (size_t)n * 8 + 1024;
     if (small) {
       int slot = -1, device = 0;

@@ -39,13 +39,15 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
     squeeze = input.dim() == 3
     if squeeze:
         input, offset, output = input.unsqueeze(0), offset.unsqueeze(0), output.unsqueeze(0)
-    nhwc = _is_nhwc(input) and _is_nhwc(output)
+    nhwc = _is_nhwc(input) and _is_nhwc(output) and input.dtype != torch.float64
     x = input if nhwc else input.contiguous()
     w = weight.contiguous()
     if w.dtype != x.dtype:
         w = w.to(x.dtype)
     off = offset.contiguous()
-    if off.dtype not in (torch.float32, x.dtype):
+    if x.dtype == torch.float64:
+        off = off.double()                      # the float64 instantiation takes float64 offsets (deform_conv.py:45 casts them)
+    elif off.dtype not in (torch.float32, x.dtype):
         off = off.float()
     B, C, H, W = x.shape
     O = w.shape[0]
@@ -64,7 +66,7 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
         raise RuntimeError("output has the wrong shape")
     out = output if (nhwc or output.is_contiguous()) else torch.empty_like(output, memory_format=torch.contiguous_format)
     p = _lib.DcnParams(B, C, H, W, O, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
-                       deformable_group, _lib.dtype_code(x), _lib.dtype_code(off),
+                       deformable_group, _lib.dtype_code(x, f64=True), _lib.dtype_code(off, f64=True),
                        _lib.LAYOUT_NHWC if nhwc else _lib.LAYOUT_NCHW, int(bool(relu)))
     L = _lib.lib()
     with torch.cuda.device(x.device):
@@ -106,7 +108,7 @@ def _bwd_common(input, offset, gradOutput, weight_like, kW, kH, dW, dH, padW, pa
 
     def params(step):
         return _lib.DcnParams(step, C, H, W, O, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
-                              deformable_group, _lib.dtype_code(x), _lib.dtype_code(x), _lib.LAYOUT_NCHW, 0)
+                              deformable_group, _lib.dtype_code(x, f64=True), _lib.dtype_code(x, f64=True), _lib.LAYOUT_NCHW, 0)
     return x, off, go, (B, C, H, W, O, Ho, Wo), params
 
 
@@ -214,7 +216,8 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
         if not direct_off:
             gradOffset.view_as(goff).copy_(goff)
         return 1
-    gin32 = torch.zeros((B, C, H, W), dtype=torch.float32, device=x.device)
+    # accumulator of the scatter: float32 (float32 / float16 columns), float64 for the float64 instantiation
+    gin32 = torch.zeros((B, C, H, W), dtype=torch.float64 if x.dtype == torch.float64 else torch.float32, device=x.device)
     # f16 + AlignConv geometry: ONE fused kernel for the whole batch -- column gradient on the matrix cores, consumed in
     # LDS, no `columns` tensor (s2a_deform_conv_backward_input_f16); the chunking by im2col_step has nothing to chunk then
     if align_geom and x.dtype == torch.float16:
@@ -257,7 +260,8 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
     L = _lib.lib()
     step = im2col_step
     # f16 + AlignConv geometry: ONE fused kernel for the whole batch (columns formed and contracted in LDS, positions as the
-    # MFMA's K through transposing LDS reads, split-K atomics): s2a_deform_conv_backward_weight_f16
+    # MFMA's K through transposing LDS reads; every workgroup writes its partial block, k_dcn_bwd_weight_reduce sums them in a
+    # fixed order -- no atomics, bit-reproducible): s2a_deform_conv_backward_weight_f16
     fused = (x.dtype == torch.float16 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)
              and group == 1 and deformable_group == 1 and C % 64 == 0 and C <= 4096 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3
              and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
@@ -269,8 +273,8 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
                                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
         gradWeight.add_((float(scale) * acc).view_as(gradWeight).to(gradWeight.dtype))
         return 1
-    # f32 + AlignConv geometry: the same dataflow on v_mfma_f32_32x32x2_f32 (s2a_deform_conv_backward_weight_f32), scaled and
-    # accumulated straight into the caller's gradWeight when it is an f32 contiguous tensor
+    # f32 + AlignConv geometry: the same dataflow on v_mfma_f32_16x16x4_f32 (s2a_deform_conv_backward_weight_f32; partial blocks +
+    # deterministic reduce as well), scaled and accumulated straight into the caller's gradWeight when it is an f32 contiguous tensor
     fused32 = (x.dtype == torch.float32 and (kW, kH, dW, dH, padW, padH, dilationW, dilationH) == (3, 3, 1, 1, 1, 1, 1, 1)
                and group == 1 and deformable_group == 1 and C % 64 == 0 and C <= 4096 and O % 32 == 0 and O <= 256 and H >= 3 and W >= 3
                and not os.environ.get("S2A_DCN_BWD_UNFUSED"))
@@ -288,14 +292,15 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
     step = _cache_step(step, C * kH * kW * Ho * Wo * x.element_size())
     npos, p = step * Ho * Wo, params(step)
     cols = torch.empty((C * kH * kW, npos), dtype=x.dtype, device=x.device)
-    acc = torch.zeros((group, O // group, (C // group) * kH * kW), dtype=torch.float32, device=x.device)
+    acc_dt = torch.float64 if x.dtype == torch.float64 else torch.float32
+    acc = torch.zeros((group, O // group, (C // group) * kH * kW), dtype=acc_dt, device=x.device)
     with torch.cuda.device(x.device):
         st = _lib.stream_ptr(x.device)
         for e in range(B // step):
             sl = slice(e * step, (e + 1) * step)
             _lib.check(L.s2a_deformable_im2col(_lib.ptr(x[sl]), _lib.ptr(off[sl]), _lib.ptr(cols), p, st))
             g_e = go[sl].transpose(0, 1).reshape(group, O // group, npos)
-            acc += torch.bmm(g_e, cols.view(group, -1, npos).transpose(1, 2)).float()
+            acc += torch.bmm(g_e, cols.view(group, -1, npos).transpose(1, 2)).to(acc_dt)
     gradWeight.add_((float(scale) * acc).view_as(gradWeight).to(gradWeight.dtype))
     return 1
 

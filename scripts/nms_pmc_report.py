@@ -28,7 +28,10 @@ for k in kernels:
     r0 = d[0]
     c = {n: sum(v) / len(v) for n, v in cnt[k].items()}
     cycles = c["GRBM_GUI_ACTIVE"] / 8
-    wg = int(r0["Workgroup_Size_X"]); grid = int(r0["Grid_Size_X"]) // wg
+    # threads per workgroup and workgroups of the WHOLE grid (round 5 counted the x dimension only: k_iou_cull_lanes' 2-D grid
+    # came out as 4 "theoretical" waves per CU beside 9.3 achieved)
+    wg = int(r0["Workgroup_Size_X"]) * int(r0.get("Workgroup_Size_Y", 1) or 1) * int(r0.get("Workgroup_Size_Z", 1) or 1)
+    grid = (int(r0["Grid_Size_X"]) * int(r0.get("Grid_Size_Y", 1) or 1) * int(r0.get("Grid_Size_Z", 1) or 1)) // wg
     lds = int(r0["LDS_Block_Size"]); vg = int(r0["VGPR_Count"]) + int(r0["Accum_VGPR_Count"])
     waves_in_flight = c["SQ_WAVE_CYCLES"] * 4 / cycles
     by_vgpr = min(8, 512 // max(vg, 1)) * 4

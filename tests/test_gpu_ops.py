@@ -1815,7 +1815,8 @@ def test_dcn_backward_input_fused_f32_vs_oracle(rng, monkeypatch):
 
 def test_dcn_backward_weight_fused_f16_vs_oracle(rng, monkeypatch):
     """the fused f16 weight gradient (s2a_deform_conv_backward_weight_f16: columns formed in LDS, contracted over the
-    positions on the matrix cores through transposing LDS reads, split-K atomics) against the oracle
+    positions on the matrix cores through transposing LDS reads, per-workgroup partial blocks summed by
+    k_dcn_bwd_weight_reduce in a fixed order -- no atomics) against the oracle
     (deform_conv_cuda.cpp:376-489 restated) on the f16-rounded operands and against the unfused path (im2col + library
     GEMM): tame and wild offsets, ragged images, one and two channel chunks, fewer out channels than waves, scale"""
     from s2anet_amd.dcn import deform_conv_backward_parameters_cuda
@@ -1842,7 +1843,7 @@ def test_dcn_backward_weight_fused_f16_vs_oracle(rng, monkeypatch):
 
 def test_dcn_backward_weight_fused_f32_vs_oracle(rng, monkeypatch):
     """the fused f32 weight gradient (s2a_deform_conv_backward_weight_f32: columns formed in LDS, contracted over the
-    positions on v_mfma_f32_32x32x2_f32, split-K atomics straight into the caller's gradWeight, scaled) against the oracle
+    positions on v_mfma_f32_16x16x4_f32, partial blocks + deterministic reduce into the caller's gradWeight, scaled) against the oracle
     (deform_conv_cuda.cpp:376-489 restated) within the north_star's 1e-4 and against the unfused path: tame and wild
     offsets, ragged images, one and two channel chunks, fewer out channels than waves, scale, a non-zero gradWeight"""
     from s2anet_amd.dcn import deform_conv_backward_parameters_cuda
@@ -2161,3 +2162,65 @@ def test_pyramid_candidates_vs_stock_path():
     # positions come in ascending order inside a level and stay inside the image's rows of that level
     s0 = sel[:, :min(64 * 80, k)]
     assert (s0[:, 1:] > s0[:, :-1]).all()
+
+
+def _offsets_away_from_integers(rng, shape, amp=1.6):
+    """integer part anything, fractional part in [0.2, 0.8]: no sampling point on a grid line (where the bilinear sampler's
+    derivative jumps) or within 0.2 of the image-border rule h_im > -1 / < H"""
+    return np.floor(rng.uniform(-amp, amp, shape)) + rng.uniform(0.2, 0.8, shape)
+
+
+def test_deform_conv_float64_forward_vs_oracle(rng):
+    """the float64 instantiation (AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:258): generic geometry,
+    groups and deformable groups, against the float64 restatement to 1e-12"""
+    from s2anet_amd.dcn import deform_conv
+    for (B, C, H, W, O, k, st, pd, dl, g, dg) in ((2, 4, 7, 9, 6, 3, 1, 1, 1, 1, 1), (1, 8, 9, 11, 6, 3, 2, 1, 2, 2, 2),
+                                                  (2, 64, 12, 16, 64, 3, 1, 1, 1, 1, 1), (1, 6, 5, 6, 4, 1, 1, 0, 1, 1, 3)):
+        Ho = (H + 2 * pd - (dl * (k - 1) + 1)) // st + 1
+        Wo = (W + 2 * pd - (dl * (k - 1) + 1)) // st + 1
+        x = rng.standard_normal((B, C, H, W))
+        off = rng.standard_normal((B, dg * 2 * k * k, Ho, Wo)) * 1.5
+        w = rng.standard_normal((O, C // g, k, k)) * 0.3
+        got = deform_conv(cu(x), cu(off), cu(w), st, pd, dl, g, dg)
+        assert got.dtype == torch.float64
+        ref = oracle.deform_conv_forward_f64(x, off, w, (st, st), (pd, pd), (dl, dl), g, dg)
+        assert np.abs(got.cpu().numpy() - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    # a float64 tensor on an entry point without a float64 instantiation is refused, not silently narrowed
+    from s2anet_amd.alignconv import align_conv_forward
+    with pytest.raises(TypeError):
+        align_conv_forward(cu(rng.standard_normal((1, 64, 8, 8))), cu(np.zeros((1, 8, 8, 5), np.float32)),
+                           cu(rng.standard_normal((64, 64, 3, 3))), 8.0)
+
+
+def test_deform_conv_float64_gradcheck(rng):
+    """torch.autograd.gradcheck on the float64 instantiation ties the backward (deformable_col2im / col2im_coord / im2col +
+    the library GEMMs, deform_conv_cuda.cpp:262-489) to the forward independently of the oracle -- as the reference's own
+    smoke block does for ARF (models/orn/functions/active_rotating_filter.py:99).  [2,4,7,9], offsets away from integer
+    coordinates; plus a strided / dilated / grouped geometry."""
+    from s2anet_amd.dcn import deform_conv
+    x = cu(rng.standard_normal((2, 4, 7, 9))).requires_grad_()
+    off = cu(_offsets_away_from_integers(rng, (2, 18, 7, 9))).requires_grad_()
+    w = cu(rng.standard_normal((3, 4, 3, 3)) * 0.5).requires_grad_()
+    assert torch.autograd.gradcheck(lambda a, b, c: deform_conv(a, b, c, 1, 1, 1, 1, 1), (x, off, w), eps=1e-6, atol=1e-6,
+                                    rtol=1e-5, nondet_tol=1e-9)
+    x = cu(rng.standard_normal((1, 4, 8, 9))).requires_grad_()
+    off = cu(_offsets_away_from_integers(rng, (1, 36, 3, 4), amp=1.2)).requires_grad_()
+    w = cu(rng.standard_normal((4, 2, 3, 3)) * 0.5).requires_grad_()
+    assert torch.autograd.gradcheck(lambda a, b, c: deform_conv(a, b, c, 2, 1, 2, 2, 2), (x, off, w), eps=1e-6, atol=1e-6,
+                                    rtol=1e-5, nondet_tol=1e-9)
+
+
+def test_deform_conv_float64_backward_vs_f32_oracle(rng):
+    """the same float64 backward against the oracle's float32 restatement of deform_conv_cuda.cpp:262-489 (AlignConv
+    geometry): float noise apart"""
+    from s2anet_amd.dcn import deform_conv
+    B, C, H, W, O = 2, 8, 9, 10, 6
+    xn, wn = rng.standard_normal((B, C, H, W)).astype(np.float32), (rng.standard_normal((O, C, 3, 3)) * 0.2).astype(np.float32)
+    on = _offsets_away_from_integers(rng, (B, 18, H, W)).astype(np.float32)
+    gn = rng.standard_normal((B, O, H, W)).astype(np.float32)
+    gx, goff, gw = oracle.deform_conv_backward(xn, on, wn, gn)
+    x, off, w = (cu(a.astype(np.float64)).requires_grad_() for a in (xn, on, wn))
+    deform_conv(x, off, w, 1, 1, 1, 1, 1).backward(cu(gn.astype(np.float64)))
+    for got, ref in ((x.grad, gx), (off.grad, goff), (w.grad, gw)):
+        assert got.dtype == torch.float64
+        assert np.abs(got.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())

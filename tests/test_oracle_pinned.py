@@ -286,3 +286,18 @@ def test_deform_conv_restatement_vs_torch_grid_sample(rng):
     want = torch.einsum("ock,bckhw->bohw", torch.from_numpy(w).double().view(O, C, 9), col).float().numpy()
     got = oracle.deform_conv_forward(x, off, w)
     assert np.abs(got - want).max() < 2e-5, float(np.abs(got - want).max())
+
+
+def test_f64_deform_conv_restatement_agrees_with_the_f32_oracle():
+    """oracle.deform_conv_forward_f64 (numpy, float64) is the checker of the library's float64 instantiation
+    (tests/test_gpu_ops.py); here it is tied to the C++ restatement (float32) on general geometry: same algorithm, float noise"""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 4, 7, 9)).astype(np.float32)
+    off = (rng.standard_normal((2, 18, 7, 9)) * 1.5).astype(np.float32)
+    w = rng.standard_normal((6, 4, 3, 3)).astype(np.float32)
+    assert np.abs(oracle.deform_conv_forward(x, off, w) - oracle.deform_conv_forward_f64(x, off, w)).max() < 2e-5
+    x = rng.standard_normal((1, 4, 9, 11)).astype(np.float32)
+    w = rng.standard_normal((6, 2, 3, 3)).astype(np.float32)
+    off = rng.standard_normal((1, 36, 4, 5)).astype(np.float32)
+    kw = dict(stride=(2, 2), padding=(1, 1), dilation=(2, 2), groups=2, deformable_groups=2)
+    assert np.abs(oracle.deform_conv_forward(x, off, w, **kw) - oracle.deform_conv_forward_f64(x, off, w, **kw)).max() < 2e-5
