@@ -1026,13 +1026,19 @@ __global__ __launch_bounds__(256) void k_nms_keep_write(const uint8_t* __restric
                                                         const int32_t* __restrict__ perm_glob, int64_t n, int rows,
                                                         const uint32_t* __restrict__ cnt, int nb,
                                                         int64_t* __restrict__ keep, int64_t* __restrict__ count_dev,
-                                                        uint32_t* __restrict__ host_count /* pinned, mapped; may be NULL */) {
+                                                        uint32_t* __restrict__ host_count /* pinned, mapped; may be NULL */,
+                                                        const NmsCounters* __restrict__ C = nullptr, unsigned long long cap = 0,
+                                                        unsigned long long ecap = 0, unsigned long long tile_cap = 0) {
   unsigned before, total;
   count_prefix(cnt, nb, blockIdx.x, before, total);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *count_dev = (int64_t)total;
     // (a synchronous caller reads the count from host-mapped memory after its stream synchronise: no copy launch)
     if (host_count) __hip_atomic_store(host_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // deferred score order: did a list overflow (k_nms_greedy_direct's own condition)?  The host then runs the fallback.
+    if (host_count && C)
+      __hip_atomic_store(host_count + 1, (C->pairs > cap || C->edges > ecap || C->tiles > tile_cap || (C->status & 2u)) ? 1u : 0u,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = min(n, r0 + rows);
   unsigned running = before;
@@ -3142,12 +3148,45 @@ inline unsigned grid_for(int64_t n, int threads = 256) { return (unsigned)((n + 
 // rows per block of the block-count kernels: 256 up to 1 Mi rows, then whatever keeps the block count <= kSegCountBlocks
 inline int count_rows(int64_t n) { return 256 * (int)((n + 256ll * kSegCountBlocks - 1) / (256ll * kSegCountBlocks)); }
 
+// score order A: rows by (segment key, descending score) -> sorted[], state_fb[], perm_seg (+ segment starts / state when it
+// is the MAIN order of the call)
+int nms_order_a(const float* dets, int64_t n, uint32_t ignore_key, int use_ignore, const NmsPlan& pl, NmsBuffers& B,
+                hipStream_t q, bool main_order) {
+  const int rows = count_rows(n);
+  const int nb = (int)((n + rows - 1) / rows);
+  size_t rpb = pl.rocprim_bytes;
+  S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[0], rpb, B.keyA, B.keyA_s, B.idx, B.perm_seg, (size_t)n, 0, 64, q));
+  k_nms_seg_count<<<nb, 256, 0, q>>>(B.keyA_s, 32, n, rows, B.cnt, nullptr);
+  k_nms_pos_meta<<<nb, 256, 0, q>>>(dets, B.keyA_s, B.perm_seg, B.cnt, nb, rows, n, ignore_key, use_ignore, B.segidx1,
+                                    main_order ? B.seg_start : nullptr, B.num_seg, B.sorted,
+                                    main_order ? B.state : nullptr, B.state_fb,
+                                    main_order ? nullptr : B.seg_start_a, B.num_seg_a);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
+// the overflow fallback of a call whose score order was deferred (nms_core, defer_a): order A now, then the plain
+// definition of greedy NMS per segment and the keep flags from ITS states.  Only ever reached on pathologically dense input.
+int nms_overflow_fallback(const float* dets, int64_t n, float thr, const NmsPlan& pl, NmsBuffers& B, hipStream_t st) {
+  int rc = nms_order_a(dets, n, 0u, 0, pl, B, st, false);
+  if (rc != S2A_OK) return rc;
+  k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, B.seg_start_a, B.num_seg_a, B.keyA_s, 0u, 0, B.C, pl.queue_cap, pl.edge_cap,
+                                                pl.tile_cap, B.state_fb, thr);
+  k_nms_finish<<<grid_for(n), 256, 0, st>>>(B.state, B.blocked, B.C, B.perm_sp, B.state_fb, B.perm_seg, n, B.keep_orig);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+
 // shared core: everything up to keep_orig[].  On return the caller's stream has the (group, score) order of the OUTPUT
 // in B.perm_glob / B.keyC_s (joined from its side stream).
+// defer_a (in / out, may be NULL): a SYNCHRONOUS caller (it reads the keep count anyway) asks for the score order A of the
+// spatial path -- needed by the overflow fallback alone -- not to be built; *defer_a comes back true when it was left out:
+// the caller checks the overflow word behind its synchronisation and runs nms_overflow_fallback if it is set.  (The two
+// library sorts of order A and order C ran beside the cull on side streams: 25 launches, cull 186 -> 224 us at 200 k rows.)
 int nms_core(const float* dets, const float* scores, const float* labels, const int32_t* seg_ids,
              const int32_t* group_ids, int64_t n, uint32_t num_segments_hint, uint32_t num_groups,
              float thr, const NmsPlan& pl, NmsBuffers& B, hipStream_t st, bool side_streams, bool want_order_c = true,
-             const long long* row_limit = nullptr) {
+             const long long* row_limit = nullptr, bool* defer_a = nullptr) {
   size_t sz = (size_t)n;
   const unsigned g = grid_for(n);
   const uint32_t ignore_key = num_segments_hint;           // one past the last real segment
@@ -3165,6 +3204,9 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
   // S2A_NMS_SORTB=0: A/B, tests
   bool own_sort = spatial;
   if (const char* e = std::getenv("S2A_NMS_SORTB")) own_sort = spatial && e[0] != '0';
+  // (only when the output order is an order of its own: a single-class call without groups emits in order A itself)
+  const bool deferred = defer_a && *defer_a && spatial && need_c;
+  if (defer_a) *defer_a = deferred;
   uint2* lo = spatial ? B.lo : nullptr;
   const size_t slots = block_slots_for(sz);
   const unsigned gp = (unsigned)std::min<size_t>(kPrepBlocks, std::max<size_t>(grid_for(n), 1));
@@ -3203,18 +3245,12 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     S2A_HIP(hipEventRecord(ss->fork, st));
   }
   auto chain_a = [&](hipStream_t q, bool main_order) -> int {   // score order: sorted[], state_fb[] (+ segments, state)
-    size_t rpb = pl.rocprim_bytes;
-    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[0], rpb, B.keyA, B.keyA_s, B.idx, B.perm_seg, sz, 0, 64, q));
-    k_nms_seg_count<<<nb, 256, 0, q>>>(B.keyA_s, 32, n, rows, B.cnt, nullptr);
-    k_nms_pos_meta<<<nb, 256, 0, q>>>(dets, B.keyA_s, B.perm_seg, B.cnt, nb, rows, n, ignore_key, use_ignore, B.segidx1,
-                                      main_order ? B.seg_start : nullptr, B.num_seg, B.sorted,
-                                      main_order ? B.state : nullptr, B.state_fb,
-                                      main_order ? nullptr : B.seg_start_a, B.num_seg_a);
-    return S2A_OK;
+    return nms_order_a(dets, n, ignore_key, use_ignore, pl, B, q, main_order);
   };
   auto sort_c = [&](hipStream_t q) -> int {
     size_t rpb = pl.rocprim_bytes;
-    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[2], rpb, B.keyC, B.keyC_s, B.idx, B.perm_glob, sz, 0, 64, q));
+    // no groups: the key is the 32-bit score word alone (the group word is 0 for every row) -- half the radix passes
+    S2A_HIP(rocprim::radix_sort_pairs(B.rp_temp[2], rpb, B.keyC, B.keyC_s, B.idx, B.perm_glob, sz, 0, group_ids ? 64 : 32, q));
     return S2A_OK;
   };
   const PreBox* boxes = B.sorted;                // blocks in score order: the cull walks sorted[] itself
@@ -3266,7 +3302,7 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
       k_nms_cull_lanes<<<8192, kThreads, 0, st>>>(boxes, B.tiles, B.C, pl.tile_cap, B.gq, pl.queue_cap, thr);
   }
   // behind the cull's launch: the score order (spatial path: fallback only) and the output order
-  if (spatial) {
+  if (spatial && !deferred) {
     hipStream_t q = ss ? ss->s[0] : st;
     if (ss) S2A_HIP(hipStreamWaitEvent(q, ss->fork, 0));
     int rc = chain_a(q, false);
@@ -3280,7 +3316,7 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
     if (rc != S2A_OK) return rc;
     // ONE join for the main stream: the output-order queue also waits for the score-order queue, so its event covers both
     // (every cross-stream wait is a ~6 us bubble in the waiting queue; the two side queues finish long before they are needed)
-    if (ss && spatial) S2A_HIP(hipStreamWaitEvent(q, ss->join[0], 0));
+    if (ss && spatial && !deferred) S2A_HIP(hipStreamWaitEvent(q, ss->join[0], 0));
     if (ss) S2A_HIP(hipEventRecord(ss->join[1], q));
   } else {
     B.perm_glob = B.perm_seg;
@@ -3298,10 +3334,11 @@ int nms_core(const float* dets, const float* scores, const float* labels, const 
                                                      B.state, B.blocked, n, spatial ? B.keyB_s : B.keyA_s, spatial ? 20 : 32,
                                                      ignore_key, use_ignore, force_global);
   if (ss && need_c) S2A_HIP(hipStreamWaitEvent(st, ss->join[1], 0));
-  else if (ss && spatial) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
-  k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, spatial ? B.seg_start_a : B.seg_start, spatial ? B.num_seg_a : B.num_seg,
-                                                B.keyA_s, ignore_key, use_ignore, B.C,
-                                                pair_cap, pl.edge_cap, pl.tile_cap, B.state_fb, thr);
+  else if (ss && spatial && !deferred) S2A_HIP(hipStreamWaitEvent(st, ss->join[0], 0));
+  if (!deferred)
+    k_nms_greedy_direct<<<512, kThreads, 0, st>>>(B.sorted, spatial ? B.seg_start_a : B.seg_start, spatial ? B.num_seg_a : B.num_seg,
+                                                  B.keyA_s, ignore_key, use_ignore, B.C,
+                                                  pair_cap, pl.edge_cap, pl.tile_cap, B.state_fb, thr);
   k_nms_finish<<<g, 256, 0, st>>>(B.state, B.blocked, B.C, perm, B.state_fb, B.perm_seg, n, B.keep_orig);
   S2A_LAUNCH_CHECK();
   return S2A_OK;
@@ -3450,25 +3487,44 @@ int nms_dropin(const float* dets, const float* scores, const float* labels, int6
     set_error("nms_rotated: workspace too small (%zu < %zu)", ws_bytes, cv.off);
     return S2A_EWORKSPACE;
   }
-  int rc = nms_core(dets, scores, labels, nullptr, nullptr, n, 0, 1, thr, pl, B, st, true);
-  if (rc != S2A_OK) return rc;
+  // the count for a synchronous caller through a host-mapped word (a control slot of the small path's pool) when one is
+  // free: the D2H copy behind the last kernel was one more launch (4 us) in the launch-paced tail.  With such a word the
+  // score order of the spatial path (overflow fallback only) is deferred too: S2A_NMS_DEFER_A=0 builds it up front (A/B, tests)
+  int slot = -1, device = 0;
+  SmallCtl* ctl = nullptr;
+  if (host_count && !stream_capturing(st)) {
+    int rc2 = small_slot_acquire(&slot, &device, &ctl);
+    if (rc2 != S2A_OK) return rc2;
+  }
+  bool defer_a = slot >= 0;
+  if (const char* e = std::getenv("S2A_NMS_DEFER_A")) defer_a = defer_a && e[0] != '0';
+  int rc = nms_core(dets, scores, labels, nullptr, nullptr, n, 0, 1, thr, pl, B, st, true, true, nullptr, &defer_a);
+  if (rc != S2A_OK) {
+    if (slot >= 0) small_slot_release(device, slot, false, false);
+    return rc;
+  }
   {
     const int rows = count_rows(n);
     const int nb = (int)((n + rows - 1) / rows);
     k_nms_keep_count<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3);
-    // the count for a synchronous caller through a host-mapped word (a control slot of the small path's pool) when one is
-    // free: the D2H copy behind the last kernel was one more launch (4 us) in the launch-paced tail
-    int slot = -1, device = 0;
-    SmallCtl* ctl = nullptr;
-    if (host_count && !stream_capturing(st)) {
-      int rc2 = small_slot_acquire(&slot, &device, &ctl);
-      if (rc2 != S2A_OK) return rc2;
-    }
     volatile uint32_t* hres = slot >= 0 ? g_small_host[device] + 4 * slot : nullptr;
-    if (hres) hres[0] = 0xffffffffu;
+    if (hres) { hres[0] = 0xffffffffu; hres[1] = 0u; }
     k_nms_keep_write<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3, nb, keep, count_dev,
-                                         slot >= 0 ? g_small_host_dev[device] + 4 * slot : nullptr);
+                                         slot >= 0 ? g_small_host_dev[device] + 4 * slot : nullptr,
+                                         defer_a ? B.C : nullptr, pl.queue_cap, pl.edge_cap, pl.tile_cap);
     hipError_t he = hipGetLastError();
+    if (he == hipSuccess && defer_a) {
+      he = hipStreamSynchronize(st);
+      if (he == hipSuccess && hres[1] != 0u) {      // a list overflowed: the direct form settles the call (score order now)
+        int rcf = nms_overflow_fallback(dets, n, thr, pl, B, st);
+        if (rcf != S2A_OK) { small_slot_release(device, slot, false, false); return rcf; }
+        k_nms_keep_count<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3);
+        hres[0] = 0xffffffffu;
+        k_nms_keep_write<<<nb, 256, 0, st>>>(B.keep_orig, B.perm_glob, n, rows, B.cnt3, nb, keep, count_dev,
+                                             g_small_host_dev[device] + 4 * slot);
+        he = hipGetLastError();
+      }
+    }
 #ifdef S2A_MEASURE
     if (he == hipSuccess) { int rc_ = nms_debug_dump(B, n, st); if (rc_ != S2A_OK) { if (slot >= 0) small_slot_release(device, slot, false, false); return rc_; } }
 #endif

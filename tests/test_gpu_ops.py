@@ -2224,3 +2224,31 @@ def test_deform_conv_float64_backward_vs_f32_oracle(rng):
     for got, ref in ((x.grad, gx), (off.grad, goff), (w.grad, gw)):
         assert got.dtype == torch.float64
         assert np.abs(got.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_nms_deferred_score_order_and_its_fallback(rng, monkeypatch):
+    """round 6: a synchronous ml_nms_rotated call on the spatial path no longer builds the score order A beside the cull (the
+    overflow fallback alone reads it): the host checks the overflow word behind its synchronisation and builds it then.
+    (a) ordinary input: same keep list with the order built up front (S2A_NMS_DEFER_A=0) and deferred; (b) more distinct labels
+    than the order-B table numbers (status bit 2): the deferred fallback runs and gives the oracle's list; (c) a pile in which
+    nearly every pair of a label overlaps (lists sized for it still overflow nothing -> exact path) -- all == oracle."""
+    import s2anet_amd as S
+    n = 20000
+    d, s = rand_rboxes(rng, n), distinct_scores(rng, n)
+    lab = rng.integers(0, 15, n).astype(np.float32)
+    want = oracle.ml_nms_rotated(d, s, lab, 0.5)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("S2A_NMS_DEFER_A", mode)
+        assert np.array_equal(S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.5).cpu().numpy(), want), mode
+    lab = np.arange(n, dtype=np.float32) * 0.25                           # 20 000 distinct labels: the table reports itself full
+    want = oracle.ml_nms_rotated(d, s, lab, 0.5)
+    assert len(want) == n
+    for mode in ("0", "1"):
+        monkeypatch.setenv("S2A_NMS_DEFER_A", mode)
+        assert np.array_equal(S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.5).cpu().numpy(), want), mode
+    monkeypatch.delenv("S2A_NMS_DEFER_A")
+    n = 6000
+    d = rand_rboxes(rng, n, span=80, lo=30, hi=90)
+    s = distinct_scores(rng, n)
+    lab = rng.integers(0, 2, n).astype(np.float32)
+    assert np.array_equal(S.ml_nms_rotated(cu(d), cu(s), cu(lab), 0.3).cpu().numpy(), oracle.ml_nms_rotated(d, s, lab, 0.3))
