@@ -40,6 +40,18 @@ int launch_nms_scan(const unsigned long long* mask, const uint32_t* seg_start, c
                     uint8_t* keep_orig, uint32_t max_blocks, const unsigned long long* words_total,
                     unsigned long long words_bound, uint32_t* status, hipStream_t st);
 
+// greedy NMS by rounds over a list of suppression edges (rotated_ops.hip), shared with the polygon NMS: edges[e] = (i, j),
+// positions in descending-score order (i < j), one segment; *edge_count_dev of them (<= edge_cap); alive_list: scratch of
+// alive_cap >= edge_cap entries; order[p] = original row of position p; keep_orig[row] = 1 kept / 0 removed
+size_t nms_edge_rounds_workspace(int64_t n);
+int launch_nms_edge_rounds(uint2* edges, unsigned long long edge_cap, const unsigned long long* edge_count_dev, uint2* alive_list,
+                           unsigned long long alive_cap, int64_t n, const int32_t* order, uint8_t* keep_orig, void* workspace,
+                           size_t workspace_bytes, hipStream_t st);
+// kept rows of `order` compacted into keep[] (descending score), *count_dev = how many; cnt_scratch: keep_compact_scratch_words()
+size_t keep_compact_scratch_words();
+int launch_keep_compact(const uint8_t* keep_orig, const int32_t* order, int64_t n, uint32_t* cnt_scratch, int64_t* keep,
+                        int64_t* count_dev, hipStream_t st);
+
 }  // namespace s2a
 
 #define S2A_CHECK_ARG(cond, ...)          \

@@ -205,39 +205,149 @@ __global__ void k_poly_prep(const double* __restrict__ dets9, const int32_t* __r
 // triangle with the HBB test alone (inter > 0  <=>  hbb_ovr > 0: the union term is >= 1) and compacts the hits
 // into a dense pair list (wave ballot + one atomic per hit group); k_poly_heavy then runs polyiou with every
 // lane busy and ORs the suppression bits into the (zeroed) mask.  A full pair list falls back to k_poly_mask.
-__global__ __launch_bounds__(64) void k_poly_cull(const PolyBox* __restrict__ sorted, int64_t n,
-                                                  uint2* __restrict__ pairs, unsigned long long* __restrict__ count,
-                                                  unsigned long long cap) {
-  const uint32_t rb = blockIdx.y, cb = blockIdx.x;
-  if (cb < rb) return;
-  __shared__ double s_hbb[64][4];
-  const int64_t j0 = (int64_t)cb * 64;
-  if (j0 + threadIdx.x < n) {
-    const PolyBox& b = sorted[j0 + threadIdx.x];
-    s_hbb[threadIdx.x][0] = b.x1; s_hbb[threadIdx.x][1] = b.y1; s_hbb[threadIdx.x][2] = b.x2; s_hbb[threadIdx.x][3] = b.y2;
+// a listed pair whose polygon IoU cannot exceed the threshold is not evaluated: for two strictly convex quadrilaterals the
+// intersection lies inside the intersection of their axis-aligned boxes and the union holds the larger polygon, so
+// iou <= hbb_inter / max(area); skipped only with a margin (1e-9 of the two areas, absolute and relative) far above the
+// rounding of the double evaluation.  Anything else (non-convex or degenerate input, NaN) is evaluated.
+__device__ __forceinline__ bool poly_pair_below(const PolyBox& A, const PolyBox& B, double thresh) {
+  auto convex_area = [](const double* c, double& area) -> bool {
+    double cr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double ax = c[2 * ((k + 1) & 3)] - c[2 * k], ay = c[2 * ((k + 1) & 3) + 1] - c[2 * k + 1];
+      const double bx = c[2 * ((k + 2) & 3)] - c[2 * ((k + 1) & 3)], by = c[2 * ((k + 2) & 3) + 1] - c[2 * ((k + 1) & 3) + 1];
+      cr[k] = ax * by - ay * bx;
+    }
+    area = 0.5 * fabs((c[0] * c[3] - c[2] * c[1]) + (c[2] * c[5] - c[4] * c[3]) + (c[4] * c[7] - c[6] * c[5]) + (c[6] * c[1] - c[0] * c[7]));
+    return (cr[0] > 0 && cr[1] > 0 && cr[2] > 0 && cr[3] > 0) || (cr[0] < 0 && cr[1] < 0 && cr[2] < 0 && cr[3] < 0);
+  };
+  double aa, ab;
+  if (!convex_area(A.c, aa) || !convex_area(B.c, ab)) return false;
+  const double w = fmax(0.0, fmin(A.x2, B.x2) - fmax(A.x1, B.x1)), h = fmax(0.0, fmin(A.y2, B.y2) - fmax(A.y1, B.y1));
+  const double eps = 1e-9 * (aa + ab), big = fmax(aa, ab);
+  return w * h + eps < thresh * (big - eps) * (1.0 - 1e-9);
+}
+
+constexpr int kCullCols = 1024;       // columns (boxes j) a workgroup of k_poly_cull walks
+__global__ __launch_bounds__(256) void k_poly_cull(const PolyBox* __restrict__ sorted, int64_t n,
+                                                   uint2* __restrict__ pairs, unsigned long long* __restrict__ count,
+                                                   unsigned long long cap, double thresh) {
+  // 256 rows (one per thread) x 1 024 columns per workgroup.  (Round 5: one 64-thread workgroup per 64 x 64 tile and one atomic
+  // per column with a hit -- half a million adds to ONE address at 20 000 boxes: 8.8 of the call's 12 ms -- and every test in
+  // double arithmetic.)  Now: the boxes' axis-aligned bounds as FLOAT intervals rounded outwards (a conservative test on
+  // one ds_read_b128 per column); a pair that passes it takes the exact double test (hbb_inter > 0, :87-93) and, in the list
+  // form (thresh >= 0), the IoU upper bound poly_pair_below -- the exact pass then only sees pairs that can suppress; ONE
+  // reservation in the pair list per workgroup.
+  const int64_t r0 = (int64_t)blockIdx.y * 256, c0 = (int64_t)blockIdx.x * kCullCols;
+  if (c0 + kCullCols - 1 <= r0) return;          // every column of the chunk is at or in front of every row: no j > i
+  __shared__ float4 s_hbb[kCullCols];            // x1 (down), y1 (down), x2 (up), y2 (up)
+  for (int k = threadIdx.x; k < kCullCols; k += 256) {
+    const float qn = __builtin_nanf("");
+    float4 v = make_float4(qn, qn, qn, qn);      // (beyond the last box: every comparison below is false)
+    if (c0 + k < n) {
+      const PolyBox& b = sorted[c0 + k];
+      v = make_float4(__double2float_rd(b.x1), __double2float_rd(b.y1), __double2float_ru(b.x2), __double2float_ru(b.y2));
+    }
+    s_hbb[k] = v;
   }
   __syncthreads();
-  const int64_t i = (int64_t)rb * 64 + threadIdx.x;
-  double ax1 = 0, ay1 = 0, ax2 = -1, ay2 = -1;
-  if (i < n) { const PolyBox& a = sorted[i]; ax1 = a.x1; ay1 = a.y1; ax2 = a.x2; ay2 = a.y2; }
-  const unsigned lane = threadIdx.x;
-  for (int c = 0; c < 64; c++) {
-    const int64_t j = j0 + c;
+  const int64_t i = r0 + threadIdx.x;
+  float fx1 = __builtin_nanf(""), fy1 = fx1, fx2 = fx1, fy2 = fx1;
+  if (i < n) {
+    const PolyBox& a = sorted[i];
+    fx1 = __double2float_rd(a.x1); fy1 = __double2float_rd(a.y1); fx2 = __double2float_ru(a.x2); fy2 = __double2float_ru(a.y2);
+  }
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wave_row0 = r0 + (threadIdx.x & ~63);
+  // pass 1: this row's surviving columns as bit masks (registers); pass 2 writes them behind ONE reservation per workgroup
+  // (a reservation per wave and column block was still ~49 k adds to one address at 20 000 boxes: 0.65 ms of queueing)
+  unsigned long long masks[kCullCols / 64];
+  unsigned cnt = 0;
+#pragma unroll
+  for (int cb = 0; cb < kCullCols / 64; cb++) {
+    const int64_t j0 = c0 + cb * 64;
+    unsigned long long mine = 0;
+    if (j0 < n && j0 + 63 > wave_row0) {         // (wave-uniform: inside the list, not wholly in front of this wave's rows)
+#pragma unroll 8
+      for (int c = 0; c < 64; c++) {
+        const float4 hb = s_hbb[cb * 64 + c];
+        // w * h > 0 in double needs min(x2) > max(x1) and min(y2) > max(y1): the outward-rounded floats keep every such pair
+        if (fx2 > hb.x && hb.z > fx1 && fy2 > hb.y && hb.w > fy1 && j0 + c > i) mine |= 1ull << c;
+      }
+      if (mine) {                                // the exact test of the few float survivors (and the IoU bound of the list form)
+        const PolyBox& A = sorted[i];
+        unsigned long long keep = 0;
+        for (unsigned long long m = mine; m; m &= m - 1) {
+          const int c = __ffsll((long long)m) - 1;
+          const PolyBox& B = sorted[j0 + c];
+          const double w = fmax(0.0, fmin(A.x2, B.x2) - fmax(A.x1, B.x1));
+          const double h = fmax(0.0, fmin(A.y2, B.y2) - fmax(A.y1, B.y1));
+          if (w * h > 0 && !(thresh >= 0 && poly_pair_below(A, B, thresh))) keep |= 1ull << c;
+        }
+        mine = keep;
+      }
+    }
+    masks[cb] = mine;
+    cnt += (unsigned)__popcll(mine);
+  }
+  unsigned incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = (unsigned)__shfl_up((int)incl, o);
+    if (lane >= (unsigned)o) incl += t;
+  }
+  __shared__ unsigned s_wtot[4];
+  __shared__ unsigned long long s_base;
+  if (lane == 63) s_wtot[wave] = incl;
+  __syncthreads();
+  const unsigned total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+  if (total == 0) return;                        // (uniform)
+  if (threadIdx.x == 0) s_base = atomicAdd(count, (unsigned long long)total);
+  __syncthreads();
+  unsigned before = incl - cnt;
+  for (unsigned w2 = 0; w2 < wave; w2++) before += s_wtot[w2];
+  unsigned long long slot = s_base + before;
+#pragma unroll
+  for (int cb = 0; cb < kCullCols / 64; cb++) {
+    unsigned long long mine = masks[cb];
+    const int64_t j0 = c0 + cb * 64;
+    while (mine) {
+      const int c = __ffsll((long long)mine) - 1;
+      mine &= mine - 1;
+      if (slot < cap) pairs[slot] = make_uint2((unsigned)i, (unsigned)(j0 + c));
+      slot++;
+    }
+  }
+}
+
+// exact pass of the list form: polyiou of every listed pair; a pair that suppresses (overlap not <= thresh, :115) becomes an
+// EDGE (i -> j, positions in descending-score order) for the greedy resolve by rounds (rotated_ops.hip) -- no N x N / 64
+// mask, no serial scan
+__global__ __launch_bounds__(kPolyThreads) void k_poly_edges(const PolyBox* __restrict__ sorted,
+                                                             const uint2* __restrict__ pairs,
+                                                             const unsigned long long* __restrict__ count,
+                                                             unsigned long long cap, double thresh,
+                                                             uint2* __restrict__ edges, unsigned long long* __restrict__ edge_count) {
+  __shared__ D2 s_p[kPMax * kPolyThreads];
+  __shared__ D2 s_t[kTmpMax * kPolyThreads];
+  const unsigned long long total = *count < cap ? *count : cap;
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned long long stride = (unsigned long long)gridDim.x * kPolyThreads;
+  for (unsigned long long e0 = (unsigned long long)blockIdx.x * kPolyThreads; e0 < total; e0 += stride) {
+    const unsigned long long e = e0 + threadIdx.x;
     bool hit = false;
-    if (i < n && j < n && j > i) {
-      const double w = fmax(0.0, fmin(ax2, s_hbb[c][2]) - fmax(ax1, s_hbb[c][0]));
-      const double h = fmax(0.0, fmin(ay2, s_hbb[c][3]) - fmax(ay1, s_hbb[c][1]));
-      hit = w * h > 0;
+    uint2 pr = make_uint2(0u, 0u);
+    if (e < total) {
+      pr = pairs[e];
+      const double ovr = poly_iou(sorted[pr.x].c, sorted[pr.y].c, s_p + threadIdx.x, s_t + threadIdx.x);
+      hit = !(ovr <= thresh);
     }
     const unsigned long long m = __ballot(hit);
     if (m == 0) continue;
     unsigned long long base = 0;
-    if (lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(count, (unsigned long long)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (hit) {
-      const unsigned long long slot = base + __popcll(m & ((1ull << lane) - 1));
-      if (slot < cap) pairs[slot] = make_uint2((unsigned)i, (unsigned)j);
-    }
+    if (lane == 0) base = atomicAdd(edge_count, (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 0);
+    if (hit) edges[base + __popcll(m & ((1ull << lane) - 1ull))] = pr;      // (edges <= listed pairs <= cap: never overflows)
   }
 }
 
@@ -609,7 +719,8 @@ extern "C" size_t s2a_nms_poly_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   size_t sz = (size_t)n, nb = (sz + 63) / 64;
   return align_up(sz * 8) * 2 + align_up(sz * 4) * 2 + align_up(sz * sizeof(PolyBox)) + align_up(sz * nb * 8) +
-         align_up(sz) * 2 + align_up(sz * 40 + (8u << 20)) + align_up(poly_pair_cap(n) * 8) + 8192;
+         align_up(sz) * 2 + align_up(sz * 40 + (8u << 20)) + align_up(poly_pair_cap(n) * 8) * 3 +
+         nms_edge_rounds_workspace(n) + align_up(keep_compact_scratch_words() * 4) + 8192;
 }
 
 extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64_t* keep, int64_t* count_dev,
@@ -640,7 +751,12 @@ extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64
   void* rp = cv.take<char>(rpb);
   const size_t cap = poly_pair_cap(n);
   auto* pairs = cv.take<uint2>(cap);
-  if (!rp || !small || !pairs || cv.off > workspace_bytes) {
+  auto* edges = cv.take<uint2>(cap);
+  auto* alive = cv.take<uint2>(cap);
+  const size_t rounds_bytes = nms_edge_rounds_workspace(n);
+  void* rounds_ws = cv.take<char>(rounds_bytes);
+  auto* cnt_scratch = cv.take<uint32_t>(keep_compact_scratch_words());
+  if (!rp || !small || !pairs || !edges || !alive || !rounds_ws || !cnt_scratch || cv.off > workspace_bytes) {
     set_error("nms_poly: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
     return S2A_EWORKSPACE;
   }
@@ -659,10 +775,36 @@ extern "C" int s2a_nms_poly(const double* dets9, int64_t n, double thresh, int64
   S2A_HIP(rocprim::radix_sort_pairs(rp, need, key_a, key_b, idx_a, order, sz, 0, 64, st));
   k_poly_prep<<<g, 256, 0, st>>>(dets9, order, n, sorted, seg_start, num_seg, mask_off, nblk);
   dim3 grid((unsigned)nb, (unsigned)nb);
+  // LIST form (round 6; a synchronous caller, thresh >= 0): HBB pair list -> polyiou on the listed pairs -> suppression EDGES
+  // -> the greedy resolve by rounds the rotated NMS uses -> compaction.  No N x N / 64 mask, no serial scan (2.1 ms at
+  // 20 000 boxes), no library select.  The host reads the pair count with the keep count: a pair list that overflowed (dense
+  // scenes) sends the call through the mask form below.  S2A_POLY_NMS_LIST=0: the mask form always (A/B, tests)
+  const char* e_list = getenv("S2A_POLY_NMS_LIST");
+  if (thresh >= 0 && host_count && !(e_list && e_list[0] == '0')) {
+    unsigned long long* pair_count = small + 16;
+    unsigned long long* edge_count = small + 17;
+    k_poly_cull<<<dim3((unsigned)((n + kCullCols - 1) / kCullCols), (unsigned)((n + 255) / 256)), 256, 0, st>>>(sorted, n, pairs, pair_count, (unsigned long long)cap, thresh);
+    const unsigned hb = (unsigned)std::min<size_t>((cap + kPolyThreads - 1) / kPolyThreads, 256 * 16);
+    k_poly_edges<<<hb, kPolyThreads, 0, st>>>(sorted, pairs, pair_count, (unsigned long long)cap, thresh, edges, edge_count);
+    S2A_LAUNCH_CHECK();
+    int rcl = launch_nms_edge_rounds(edges, (unsigned long long)cap, edge_count, alive, (unsigned long long)cap, n, order, keep_orig,
+                                     rounds_ws, rounds_bytes, st);
+    if (rcl != S2A_OK) return rcl;
+    rcl = launch_keep_compact(keep_orig, order, n, cnt_scratch, keep, count_dev, st);
+    if (rcl != S2A_OK) return rcl;
+    unsigned long long host_pairs = 0;
+    S2A_HIP(hipMemcpyAsync(&host_pairs, pair_count, sizeof(host_pairs), hipMemcpyDeviceToHost, st));
+    S2A_HIP(hipMemcpyAsync(host_count, count_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    S2A_HIP(hipStreamSynchronize(st));
+    if (host_pairs <= (unsigned long long)cap) return S2A_OK;
+    // the pair list overflowed: the mask form settles the call (its own zero-fills first)
+    S2A_HIP(hipMemsetAsync(small + 16, 0, 16, st));
+    S2A_HIP(hipMemsetAsync(keep_orig, 0, sz, st));
+  }
   if (thresh >= 0) {
     unsigned long long* pair_count = small + 16;
     S2A_HIP(hipMemsetAsync(mask, 0, sz * nb * 8, st));
-    k_poly_cull<<<grid, 64, 0, st>>>(sorted, n, pairs, pair_count, (unsigned long long)cap);
+    k_poly_cull<<<dim3((unsigned)((n + kCullCols - 1) / kCullCols), (unsigned)((n + 255) / 256)), 256, 0, st>>>(sorted, n, pairs, pair_count, (unsigned long long)cap, -1.0);
     const unsigned hb = (unsigned)std::min<size_t>((cap + kPolyThreads - 1) / kPolyThreads, 256 * 16);
     k_poly_heavy<<<hb, kPolyThreads, 0, st>>>(sorted, pairs, pair_count, (unsigned long long)cap, thresh, (uint32_t)nb, mask);
     k_poly_mask<<<grid, 64, 0, st>>>(sorted, n, thresh, mask, pair_count, (unsigned long long)cap);   // overflow only

@@ -3556,6 +3556,63 @@ int build_flags_rotated() {
 #endif
   return f;
 }
+// ---- the greedy resolve by rounds over an EDGE list is metric-agnostic too: poly_ops.hip hands over the suppression edges
+// of its polygon IoU (i = the higher-scored row, j = the row it suppresses; positions in descending-score order, ONE segment)
+// and gets the keep flags of the original rows back -- four launched rounds, the per-segment clean-up, the view (the same
+// kernels as the rotated NMS behind its exact pass).
+namespace {
+struct EdgeRoundsWs {
+  NmsCounters C;
+  uint32_t seg_start[4];
+  uint32_t num_seg;
+  uint32_t cnt[kSegCountBlocks];
+};
+__global__ void k_edge_rounds_init(EdgeRoundsWs* __restrict__ W, uint8_t* __restrict__ state, uint8_t* __restrict__ blocked,
+                                   int64_t n, const unsigned long long* __restrict__ edge_count) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = i0; i < (size_t)n; i += stride) { state[i] = (uint8_t)kOpen; blocked[i] = 0; blocked[n + i] = 0; }
+  if (i0 == 0) {
+    W->C = NmsCounters{};
+    W->C.edges = *edge_count;
+    W->seg_start[0] = 0u;
+    W->seg_start[1] = (uint32_t)n;
+    W->num_seg = 1u;
+  }
+}
+}  // namespace
+size_t nms_edge_rounds_workspace(int64_t n) {
+  return align_up(sizeof(EdgeRoundsWs)) + align_up((size_t)n) + align_up(2 * (size_t)n) + 256;
+}
+int launch_nms_edge_rounds(uint2* edges, unsigned long long edge_cap, const unsigned long long* edge_count_dev, uint2* alive_list,
+                           unsigned long long alive_cap, int64_t n, const int32_t* order, uint8_t* keep_orig, void* workspace,
+                           size_t workspace_bytes, hipStream_t st) {
+  S2A_CHECK_ARG(n > 0 && n < (1ll << 31), "nms edge rounds: n out of range");
+  Carver cv(workspace, workspace_bytes);
+  auto* W = cv.take<EdgeRoundsWs>(1);
+  auto* state = cv.take<uint8_t>((size_t)n);
+  auto* blocked = cv.take<uint8_t>(2 * (size_t)n);
+  S2A_CHECK_ARG(W && state && blocked, "nms edge rounds: workspace too small");
+  k_edge_rounds_init<<<grid_for(n), 256, 0, st>>>(W, state, blocked, n, edge_count_dev);
+  for (int r = 1; r <= kNmsRounds; r++)
+    k_nms_round<<<256, kThreads, 0, st>>>(edges, &W->C, edge_cap, state, blocked, n, r, r == kNmsRounds ? alive_list : nullptr, alive_cap);
+  k_nms_finish_segments<<<1, kFinThreads, 0, st>>>(&W->C, W->seg_start, &W->num_seg, alive_list, alive_cap, edges, edge_cap, state,
+                                                   blocked, n, nullptr, 0, 0u, 0, 0);
+  k_nms_finish<<<grid_for(n), 256, 0, st>>>(state, blocked, &W->C, order, nullptr, nullptr, n, keep_orig);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+// kept rows of `order` (rows by descending score) -> keep[], count (device + optional host-mapped word): two launches
+int launch_keep_compact(const uint8_t* keep_orig, const int32_t* order, int64_t n, uint32_t* cnt_scratch /* kSegCountBlocks words */,
+                        int64_t* keep, int64_t* count_dev, hipStream_t st) {
+  const int rows = count_rows(n);
+  const int nb = (int)((n + rows - 1) / rows);
+  k_nms_keep_count<<<nb, 256, 0, st>>>(keep_orig, order, n, rows, cnt_scratch);
+  k_nms_keep_write<<<nb, 256, 0, st>>>(keep_orig, order, n, rows, cnt_scratch, nb, keep, count_dev, nullptr);
+  S2A_LAUNCH_CHECK();
+  return S2A_OK;
+}
+size_t keep_compact_scratch_words() { return (size_t)kSegCountBlocks; }
+
 // the greedy scan is metric-agnostic: poly_ops.hip (chip-merge NMS on polygon IoU) reuses it
 int launch_nms_scan(const unsigned long long* mask, const uint32_t* seg_start, const uint32_t* num_seg,
                     const unsigned long long* mask_off, const uint32_t* nblk, const int32_t* perm_seg,
@@ -3765,6 +3822,162 @@ __global__ __launch_bounds__(256) void k_assign_cols(const float* __restrict__ i
   if (lane == 0 && best >= 0) assign[m] = best;
 }
 
+// ---- LIST form (round 6): no [M,N] matrix.  The matrix form above is eleven launches (the IoU pipeline alone five) and a
+// strided column-maximum pass: 146 us at 32 gts, 211 us at 300 -- slower than the unfused pair at the sizes models/utils.py:33
+// sees.  Here, for N <= kAtMaxN gts and M x N pairs that fit the list:
+//   k_assign_cull   a workgroup owns 16 anchor rows with ALL gts in LDS: circle + separating-axis test of its 16 x N pairs,
+//                   the survivors into an LDS list, ONE global reservation per workgroup, (row, gt) pairs out;
+//   k_assign_exact  exact IoU of the listed pairs, every lane busy and the whole chip balanced (the 64 P7 anchors of a chip
+//                   overlap most gts: owned by one workgroup they took 0.5 ms): value kept in the list; row maximum / first
+//                   arg-max, the count of filtered entries and the column maxima by atomics;
+//   k_assign_rule3  with the final column maxima: the pairs that attain one -> rule 3 (all anchors), or the first such row;
+//   k_assign_rows   rules 1, 2 (and 3) per anchor; k_assign_last when one anchor per gt is taken.
+// Exact zeros never enter the list (a disjoint pair is 0.0 by the reference's own num == 0 return), so the row rules start
+// from "all zero" and only count filtered (negative) entries.  Needs min_pos_iou_thr >= 0 and pos_iou_thr > 0.
+constexpr int kAtRows = 16, kAtMaxN = 1024;
+constexpr unsigned long long kAtMaxPairs = 8ull << 20;       // list capacity = M x N (never overflows), at most this
+struct AtWs {                                                // carved from the workspace, in this order
+  PreBox* gt_pre; int* gt_key; int* gt_arg; unsigned long long* rowbest; int* nbad; int* r3; unsigned long long* count;
+  uint2* pair; float* val;
+};
+__global__ void k_assign_list_init(const float* __restrict__ gt, int N, int64_t M, AtWs w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    const float* g = gt + 5 * i;
+    w.gt_pre[i] = make_prebox(g[0], g[1], g[2], g[3], g[4], 0.f);
+    w.gt_key[i] = 0;
+    w.gt_arg[i] = 0x7fffffff;
+  }
+  if (i < M) { w.rowbest[i] = 0ull; w.nbad[i] = 0; w.r3[i] = -1; }
+  if (i == 0) *w.count = 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_assign_cull(const float* __restrict__ anchors, int64_t M, int N, float img_h, float img_w,
+                                                     int filt_anchor, AtWs w) {
+  extern __shared__ __attribute__((aligned(16))) char smem_at[];
+  PreBox* s_gt = reinterpret_cast<PreBox*>(smem_at);                                       // [N]
+  uint32_t* s_list = reinterpret_cast<uint32_t*>(smem_at + (size_t)N * sizeof(PreBox));    // [kAtRows * N]
+  __shared__ PreBox s_anc[kAtRows];
+  __shared__ uint8_t s_valid[kAtRows];
+  __shared__ unsigned s_cnt;
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t m0 = (int64_t)blockIdx.x * kAtRows;
+  for (int j = tid; j < N; j += 256) s_gt[j] = w.gt_pre[j];
+  if (tid < kAtRows) {
+    const int64_t m = m0 + tid;
+    bool valid = false;
+    PreBox A = {};
+    if (m < M) {
+      const float* a = anchors + 5 * m;
+      valid = !filt_anchor || anchor_valid(a, img_h, img_w);     // invalid anchors: every overlap is -0.5 (:97-98), nothing to list
+      A = make_prebox(a[0], a[1], a[2], a[3], a[4], 0.f);
+    }
+    s_anc[tid] = A;
+    s_valid[tid] = valid ? 1 : 0;
+  }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  const int total = kAtRows * N;
+  for (int i0 = 0; i0 < total; i0 += 256) {
+    const int idx = i0 + tid;
+    bool hit = false;
+    int r = 0, j = 0;
+    if (idx < total) {
+      r = idx / N; j = idx - r * N;
+      if (s_valid[r]) {
+        const PreBox& A = s_anc[r];
+        const PreBox& B = s_gt[j];
+        hit = !surely_disjoint(A.x, A.y, A.r, B.x, B.y, B.r) && !sat_disjoint(A, B);
+      }
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (bal) {
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+      base = (unsigned)__shfl((int)base, 0);
+      if (hit) s_list[base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)r << 16) | (uint32_t)j;
+    }
+  }
+  __syncthreads();
+  const unsigned cnt = s_cnt;
+  if (cnt == 0) return;                                          // (uniform)
+  if (tid == 0) s_base = atomicAdd(w.count, (unsigned long long)cnt);
+  __syncthreads();
+  const unsigned long long base = s_base;
+  for (unsigned e = tid; e < cnt; e += 256) {
+    const uint32_t rj = s_list[e];
+    w.pair[base + e] = make_uint2((unsigned)(m0 + (rj >> 16)), rj & 0xffffu);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_assign_exact(const float* __restrict__ anchors, int filt_iou, AtWs w) {
+  __shared__ float2 s_pts[24 * 256];
+  const unsigned long long total = *w.count;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (unsigned long long)gridDim.x * 256) {
+    const uint2 mj = w.pair[e];
+    const float* a = anchors + 5 * (int64_t)mj.x;
+    const PreBox A = make_prebox(a[0], a[1], a[2], a[3], a[4], 0.f);
+    float v = rbox_iou<256>(A, w.gt_pre[mj.y], s_pts + threadIdx.x);
+    if (filt_iou && !(v >= 0.f && v <= 1.f)) v = -0.5f;          // :86-93
+    v += 0.f;                                                    // -0.0 -> +0.0
+    w.val[e] = v;
+    if (v < 0.f) atomicAdd(w.nbad + mj.x, 1);
+    else if (v > 0.f) {
+      const int k = iou_key(v);
+      atomicMax(w.rowbest + mj.x, ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)(0xffffffffu - mj.y));
+      atomicMax(w.gt_key + mj.y, k);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_assign_rule3(float min_pos_thr, int assign_all, AtWs w) {
+  const unsigned long long total = *w.count;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (unsigned long long)gridDim.x * 256) {
+    const float v = w.val[e];
+    if (!(v > 0.f)) continue;
+    const uint2 mj = w.pair[e];
+    const int kc = w.gt_key[mj.y];
+    if (key_iou(kc) > min_pos_thr && iou_key(v) == kc) {         // :126: this anchor attains the gt's maximum
+      if (assign_all) atomicMax(w.r3 + mj.x, (int)mj.y);
+      else atomicMin(w.gt_arg + mj.y, (int)mj.x);
+    }
+  }
+}
+
+__global__ void k_assign_rows_list(const float* __restrict__ anchors, int64_t M, int N, float img_h, float img_w, float pos_thr,
+                                   float neg_thr, int filt_anchor, int assign_all, AtWs w, int64_t* __restrict__ assign) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const bool valid = !filt_anchor || anchor_valid(anchors + 5 * m, img_h, img_w);
+  const unsigned long long b = w.rowbest[m];
+  float best = 0.f;                                              // every entry that was not listed is an exact zero
+  int64_t arg = 0;
+  if (!valid || w.nbad[m] == N) best = -0.5f;                    // :97-98 / every overlap filtered
+  else if (b != 0ull) { best = key_iou((int)(b >> 32)); arg = (int64_t)(0xffffffffu - (uint32_t)(b & 0xffffffffull)); }
+  int64_t a = -2;
+  if (best >= 0.f && best < neg_thr) a = -1;                     // :108
+  if (best >= pos_thr) a = arg;                                  // :114-115
+  if (assign_all && w.r3[m] >= 0) a = w.r3[m];                   // :131-145: the last gt whose maximum the anchor attains
+  assign[m] = a;
+}
+
+// one anchor per gt (gt_max_assign_all = False): gt j's anchor is the first row attaining its maximum (gt_arg); the
+// reference's ascending loop lets a later gt overwrite an earlier one on the same anchor
+__global__ __launch_bounds__(1024) void k_assign_last(const int* __restrict__ gt_key, const int* __restrict__ gt_arg, int N,
+                                                      float min_pos_thr, int64_t* __restrict__ assign) {
+  __shared__ int s_m[kAtMaxN];
+  const int j = threadIdx.x;
+  int mine = -1;
+  if (j < N && key_iou(gt_key[j]) > min_pos_thr && gt_arg[j] != 0x7fffffff) mine = gt_arg[j];
+  if (j < kAtMaxN) s_m[j] = mine;
+  __syncthreads();
+  if (mine < 0) return;
+  for (int k = j + 1; k < N; k++)
+    if (s_m[k] == mine) return;
+  assign[mine] = j;
+}
+
 // no gt boxes (:72-80): valid anchors are negatives, the others stay ignored
 __global__ void k_assign_empty(const float* __restrict__ anchors, int64_t M, float img_h, float img_w, int filt_anchor,
                                int64_t* __restrict__ assign) {
@@ -3777,7 +3990,10 @@ __global__ void k_assign_empty(const float* __restrict__ anchors, int64_t M, flo
 
 extern "C" size_t s2a_assign_labels_workspace_bytes(int64_t num_anchors, int64_t num_gts) {
   const int64_t M = std::max<int64_t>(num_anchors, 1), N = std::max<int64_t>(num_gts, 1);
-  return align_up((size_t)M * N * 4) + 2 * align_up((size_t)N * 4) + s2a_box_iou_rotated_workspace_bytes(M, N) + 1024;
+  const size_t matrix_form = align_up((size_t)M * N * 4) + 2 * align_up((size_t)N * 4) + s2a_box_iou_rotated_workspace_bytes(M, N) + 1024;
+  const size_t list_form = align_up((size_t)N * 32) + 2 * align_up((size_t)N * 4) + align_up((size_t)M * 8) + 2 * align_up((size_t)M * 4) +
+                           256 + align_up((size_t)M * N * 8) + align_up((size_t)M * N * 4) + 1024;
+  return std::max(matrix_form, (unsigned long long)M * (unsigned long long)N <= (8ull << 20) ? list_form : (size_t)0);
 }
 
 extern "C" int s2a_assign_labels(const float* anchors, int64_t num_anchors, const float* gt_boxes, int64_t num_gts,
@@ -3794,6 +4010,46 @@ extern "C" int s2a_assign_labels(const float* anchors, int64_t num_anchors, cons
     k_assign_empty<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(anchors, M, img_h, img_w, filter_invalid_anchors, assign_gt_ids);
     S2A_LAUNCH_CHECK();
     return S2A_OK;
+  }
+  // list form: no IoU matrix, five short launches (see k_assign_cull).  S2A_ASSIGN_LIST=0: the matrix form (A/B, tests)
+  {
+    const char* e = std::getenv("S2A_ASSIGN_LIST");
+    const unsigned long long mn = (unsigned long long)M * (unsigned long long)N;
+    if (N <= kAtMaxN && mn <= kAtMaxPairs && min_pos_iou_thr >= 0.f && pos_iou_thr > 0.f && !(e && e[0] == '0')) {
+      Carver cvt(workspace, workspace_bytes);
+      AtWs w;
+      w.gt_pre = cvt.take<PreBox>((size_t)N);
+      w.gt_key = cvt.take<int>((size_t)N);
+      w.gt_arg = cvt.take<int>((size_t)N);
+      w.rowbest = cvt.take<unsigned long long>((size_t)M);
+      w.nbad = cvt.take<int>((size_t)M);
+      w.r3 = cvt.take<int>((size_t)M);
+      w.count = cvt.take<unsigned long long>(1);
+      w.pair = cvt.take<uint2>((size_t)mn);
+      w.val = cvt.take<float>((size_t)mn);
+      if (!w.val || !w.pair || !w.count || !w.r3 || !w.nbad || !w.rowbest || !w.gt_arg || !w.gt_key || !w.gt_pre) {
+        set_error("assign_labels: workspace too small (%zu < %zu)", workspace_bytes, cvt.off);
+        return S2A_EWORKSPACE;
+      }
+      const size_t lds = (size_t)N * sizeof(PreBox) + (size_t)kAtRows * N * 4;
+      static bool attr_set = false;
+      if (!attr_set) {
+        S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_cull), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kAtMaxN * sizeof(PreBox) + (size_t)kAtRows * kAtMaxN * 4)));
+        attr_set = true;
+      }
+      const int64_t mx = std::max<int64_t>(M, N);
+      k_assign_list_init<<<(unsigned)((mx + 255) / 256), 256, 0, st>>>(gt_boxes, (int)N, M, w);
+      k_assign_cull<<<(unsigned)((M + kAtRows - 1) / kAtRows), 256, lds, st>>>(anchors, M, (int)N, img_h, img_w, filter_invalid_anchors, w);
+      k_assign_exact<<<1024, 256, 0, st>>>(anchors, filter_invalid_ious, w);
+      k_assign_rule3<<<1024, 256, 0, st>>>(min_pos_iou_thr, gt_max_assign_all, w);
+      k_assign_rows_list<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(anchors, M, (int)N, img_h, img_w, pos_iou_thr, neg_iou_thr,
+                                                                      filter_invalid_anchors, gt_max_assign_all, w, assign_gt_ids);
+      if (!gt_max_assign_all)
+        k_assign_last<<<1, 1024, 0, st>>>(w.gt_key, w.gt_arg, (int)N, min_pos_iou_thr, assign_gt_ids);
+      S2A_LAUNCH_CHECK();
+      return S2A_OK;
+    }
   }
   Carver cv(workspace, workspace_bytes);
   float* ious = cv.take<float>((size_t)M * N);

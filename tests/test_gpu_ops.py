@@ -1441,8 +1441,12 @@ def test_polyiou_pairs_bitexact(rng):
     assert abs(polyiou_pairs(cu(np.array([[0, 0, 1, 0, 1, 1, 0, 1.0]])), cu(np.array([[.5, .5, 1.5, .5, 1.5, 1.5, .5, 1.5]]))).item() - 1 / 7) < 1e-12
 
 
-def test_merge_nms_poly(rng):
+@pytest.mark.parametrize("form", ["list", "mask"])
+def test_merge_nms_poly(rng, monkeypatch, form):
+    """both forms of s2a_nms_poly: the list form (HBB pair list -> polyiou -> suppression edges -> rounds; round 6, the default
+    of a synchronous call) and the N x N / 64 mask + scan form (S2A_POLY_NMS_LIST=0; also the overflow fallback of the list)"""
     from s2anet_amd.rotated import nms_poly
+    monkeypatch.setenv("S2A_POLY_NMS_LIST", "1" if form == "list" else "0")
     g = golden("merge_nms_poly.npz")
     for thr in (0.1, 0.5):
         k = nms_poly(cu(g["dets"]), thr).cpu().numpy()
@@ -1900,11 +1904,14 @@ def test_dcn_backward_autograd_one_call(rng, monkeypatch, dtype):
     assert np.array_equal(res["one-call"][1], res["separate"][1])
 
 
-def test_assign_labels_fused(rng):
+@pytest.mark.parametrize("form", ["list", "matrix"])
+def test_assign_labels_fused(rng, monkeypatch, form):
     """fused label assignment == the reference's assign_labels (golden from its own Python on its CPU IoU op;
-    the two sort branches of the IoU agree on these inputs) and == the oracle on fresh inputs"""
+    the two sort branches of the IoU agree on these inputs) and == the oracle on fresh inputs.  Both forms: the list form
+    (round 6: no IoU matrix, the default up to 1 024 gts / 8 Mi pairs) and the matrix form (S2A_ASSIGN_LIST=0, also taken beyond)"""
     from s2anet_amd.rotated import assign_labels
     from test_oracle_pinned import ASSIGN_CASES
+    monkeypatch.setenv("S2A_ASSIGN_LIST", "1" if form == "list" else "0")
     g = golden("assign_labels.npz")
     for tag, kw in ASSIGN_CASES:
         got = assign_labels(cu(g["anchors"]), cu(g["gts"]), **kw).cpu().numpy()
@@ -1919,6 +1926,25 @@ def test_assign_labels_fused(rng):
     got = assign_labels(cu(a), cu(gt)).cpu().numpy()
     assert np.array_equal(got, oracle.assign_labels(a, gt))
     assert (got >= 0).sum() >= 50
+    # one anchor per gt, anchors outside the image, 32 gts, exact ties (two gts on the same anchor, a gt copied twice)
+    gt32 = gt[:32].copy()
+    gt32[5] = gt32[4]
+    a2 = a.copy()
+    a2[::97, 0] = -5.0                                              # invalid anchors (:63-69)
+    for kw in (dict(gt_max_assign_all=False), dict(gt_max_assign_all=True, pos_iou_thr=0.3, neg_iou_thr=0.1, min_pos_iou_thr=0.2),
+               dict(filter_invalid_anchors=False), dict(imgs_size=(800, 900))):
+        got = assign_labels(cu(a2), cu(gt32), **kw).cpu().numpy()
+        assert np.array_equal(got, oracle.assign_labels(a2, gt32, **kw)), kw
+    # a dense pile: every anchor of a small patch overlaps every gt (the list holds all M x N pairs)
+    ad = rand_rboxes(rng, 700, span=60, lo=40, hi=90)
+    gd = rand_rboxes(rng, 200, span=60, lo=40, hi=90)
+    for kw in (dict(), dict(gt_max_assign_all=False)):
+        got = assign_labels(cu(ad), cu(gd), imgs_size=(2000, 2000), **kw).cpu().numpy()
+        assert np.array_equal(got, oracle.assign_labels(ad, gd, imgs_size=(2000, 2000), **kw)), kw
+    # more gts than the tile form holds: the matrix form answers whatever the switch says
+    gbig = rand_rboxes(rng, 1100, span=1024)
+    got = assign_labels(cu(a), cu(gbig)).cpu().numpy()
+    assert np.array_equal(got, oracle.assign_labels(a, gbig))
 
 
 def test_voc_eval_on_gpu(rng):
