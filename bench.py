@@ -376,7 +376,39 @@ def measure_ops(dev, with_cpu=True):
     sec5 = _time_launches(lambda: S.ml_nms_rotated(d5, s5, l5, 0.5), iters=20)
     ops["ml_nms_rotated_5k_x_15"] = {"us": round(sec5 * 1e6, 1), "keep": int(keep5.numel()),
                                      "note": "synchronous drop-in call incl. the host's wait for the count; one kernel launch"}
-    del d, sc, lab, d5, s5, l5
+    # sizes BETWEEN the one-launch path and the big path: single class at 2 000 rows (one segment beyond
+    # k_nms_small's 640 rows: skipped on the host now) and 12 000 rows x 15 labels (800 rows per label: known on the device only,
+    # so the call pays the small kernel's launch + wait before the general path)
+    d2, s2 = d[:2000].contiguous(), sc[:2000].contiguous()
+    from s2anet_amd.rotated import nms_rotated_raw
+    t2 = _time_launches(lambda: nms_rotated_raw(d2, s2, 0.5), iters=20)
+    d12, s12, l12 = d[:12000].contiguous(), sc[:12000].contiguous(), lab[:12000].contiguous()
+    t12 = _time_launches(lambda: S.ml_nms_rotated(d12, s12, l12, 0.5), iters=20)
+    ops["nms_fallback_zone"] = {"nms_rotated_2k_us": round(t2 * 1e6, 1), "ml_nms_rotated_12k_x_15_us": round(t12 * 1e6, 1)}
+    del d, sc, lab, d5, s5, l5, d2, s2, d12, s12, l12
+    # SURVEY 8(f) rows 1 / 2 that got a speed pass in round 6: chip-merge polygon NMS at 20 000 polygons and assign_labels on
+    # the 21 824 anchors of a chip
+    try:
+        import oracle as _o
+        from s2anet_amd.rotated import nms_poly, assign_labels
+        rp = np.random.default_rng(77)
+        polys = _o.rboxes_to_polys(_ops_inputs_rboxes(rp, 20000, span=2048.0))
+        dp = torch.from_numpy(np.concatenate([polys, ((rp.permutation(20000) + 1.0) / 20001.0)[:, None]], 1)).to(dev)
+        kp = nms_poly(dp, 0.3)
+        tp = _time_launches(lambda: nms_poly(dp, 0.3), iters=10)
+        ops["nms_poly_20k"] = {"ms": round(tp * 1e3, 3), "keep": int(kp.numel()), "dtype": "f64"}
+        ra = np.random.default_rng(5)
+        a = np.concatenate([_o.grid_anchors(1024 // st_, 1024 // st_, st_).reshape(-1, 5) for st_ in (8, 16, 32, 64, 128)]).astype(np.float32)
+        a[:, 4] = ra.uniform(-0.7, 2.3, a.shape[0])
+        A = torch.from_numpy(a).to(dev)
+        res = {}
+        for ng in (32, 300):
+            G = torch.from_numpy(_ops_inputs_rboxes(ra, ng)).to(dev)
+            res["gts_%d_us" % ng] = round(_time_launches(lambda: assign_labels(A, G), iters=20) * 1e6, 1)
+        ops["assign_labels_21824_anchors"] = res
+        del dp, A
+    except Exception as e:
+        ops["nms_poly_20k"] = {"failed": repr(e)}
     # SURVEY 8(f) row 1 at the AlignConv shape: deform_conv backward, P3 x batch 8, f16 and f32, AlignConv-like offsets
     for dt, tag in ((torch.float16, "f16"), (torch.float32, "f32")):
         key = "deform_conv_backward_8x256x128x128_" + tag
