@@ -23,7 +23,8 @@ namespace s2a {
 int build_flags_dcn();
 int build_flags_rotated();
 int build_flags_dcn_bwd();
+int build_flags_wino();
 }  // namespace s2a
 extern "C" int s2a_build_flags(void) {
-  return s2a::build_flags_dcn() | (s2a::build_flags_rotated() << 16) | (s2a::build_flags_dcn_bwd() << 24);
+  return s2a::build_flags_dcn() | (s2a::build_flags_rotated() << 16) | (s2a::build_flags_dcn_bwd() << 24) | (s2a::build_flags_wino() << 30);
 }

@@ -370,6 +370,10 @@ int64_t wino_levels(const s2a_pyramid* pyr, int64_t batch, WLevels* lt, int64_t*
 }  // namespace
 }  // namespace s2a
 
+namespace s2a {
+int build_flags_wino() { return S2A_WABL ? 1 : 0; }      // a timing-ablation object: reported by s2a_build_flags, refused by the loader
+}  // namespace s2a
+
 extern "C" int64_t s2a_conv_wino_packed_elems(int64_t out_channels, int64_t channels) {
   if (out_channels <= 0 || channels <= 0 || out_channels % 64 != 0 || channels % 32 != 0) return -1;
   return out_channels * channels * 12;

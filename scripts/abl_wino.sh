@@ -3,6 +3,7 @@
 #   bash scripts/abl_wino.sh 0 1 2 3 4 8
 # bits: 1 = no patch DMA in the loop, 2 = no filter DMA in the loop, 4 = no MFMAs, 8 = no barriers in the loop
 cd $GRAFT_REPO_ROOT
+export S2A_ALLOW_MEASURE_BUILD=1   # the objects built below carry a measurement switch (s2anet_amd/_lib.py refuses them otherwise)
 restore() { rm -f s2anet_amd/csrc/wino_ops.o; make -C s2anet_amd/csrc -s 2>&1 | grep -E "error" | head -3; }
 trap restore EXIT
 for a in "$@"; do
