@@ -81,7 +81,7 @@ def recorded_traffic(key, batch, pixels):
 
 def recorded_occupancy(group):
     """occupancy / VALU-utilisation record of the rotated-NMS and rotated-IoU kernels from the rocprofv3 PMC passes of the
-    round's evidence run (scripts/gpu_round5_final.sh -> scripts/nms_pmc_report.py --json -> profiles/rNN_ops_occupancy.json;
+    round's evidence run (scripts/gpu_round6_final.sh -> scripts/nms_pmc_report.py --json -> profiles/rNN_ops_occupancy.json;
     `group` = "ml_nms_200k" | "box_iou_10k").  Valid only for the kernel sources it was taken on: otherwise
     {"stale": True} -- never a number measured on other code."""
     import glob
@@ -156,7 +156,7 @@ def _time_launches(fn, iters=100):
     """HIP events on the launching stream (torch's current stream) around `iters` launches, after WARM_SECONDS of the same
     launches back to back: the operands of these measurements are built on the host, the GPU idles meanwhile and comes back
     at a low clock -- three warm-up launches measured the ramp (P3 x 8 AlignConv: 200-217 us cold, 167-177 us after 0.3 s;
-    in-kernel stamps 1.69 GHz against 2.1-2.3 GHz, scripts/p3_probe.py)"""
+    in-kernel stamps 1.69 GHz against 2.1-2.3 GHz, docs/HISTORY.md, round 4)"""
     t_w = time.perf_counter()
     n_w = 0
     while n_w < 3 or time.perf_counter() - t_w < WARM_SECONDS:

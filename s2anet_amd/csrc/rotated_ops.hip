@@ -3687,7 +3687,7 @@ extern "C" int s2a_box_iou_rotated(const float* boxes1, int64_t n, const float* 
     S2A_HIP(hipStreamWaitEvent(side, ss->fork, 0));
     // The fill is PACED (s_sleep between the stores of a wave): flat out it finishes 400 MB in 50-100 us but saturates the
     // memory system, and every dependent read of the kernels beside it then takes ~10 us -- the pair finder stretched
-    // from 59 to 105-125 us whatever its design and whatever the fill's workgroup count (scripts/iou_fill_scan.sh).  At 512
+    // from 59 to 105-125 us whatever its design and whatever the fill's workgroup count (docs/HISTORY.md, round 3).  At 512
     // workgroups and s_sleep 12 it moves ~3.5 TB/s (113 us at 10 k x 10 k), ends before the chain beside it does (pair
     // finding 62 + exact pass 60-65 us, both at their stand-alone speed) and the call takes ~157 us instead of ~195.
     int fill_wgs = 512, pace = 12;

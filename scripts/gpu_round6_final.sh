@@ -1,8 +1,8 @@
 #!/bin/bash
-# end-of-round evidence (round 5): full GPU suite, smoke, NMS / IoU counters (occupancy record for the driver line) and timelines,
+# end-of-round evidence (round 6): full GPU suite, smoke, NMS / IoU counters (occupancy record for the driver line) and timelines,
 # bench counters -> traffic record, steady-state tables (3 streams and 1), ops report, the bench line, the RCCL world-of-one
 # line, the half decode / NMS effect, the f16 fixture hashes, kernel list of a captured detect() replay.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5final; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r6final; mkdir -p $O; cd $R
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; rc=$?; echo "gpu tests rc=$rc"; tail -3 $O/gpu_tests.log | cut -c1-200
 if [ $rc -ne 0 ]; then exit 1; fi
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log | cut -c1-200
@@ -25,12 +25,12 @@ for p in srcs: h.update(open(p, "rb").read())
 rec = {"sources": srcs, "source_sha16": h.hexdigest()[:16],
        "ml_nms_200k": json.load(open("$O/nms_occupancy.json")), "box_iou_10k": json.load(open("$O/iou_occupancy.json"))}
 json.dump(rec, open("$O/ops_occupancy.json", "w"), indent=1)
-json.dump(rec, open("profiles/r05_ops_occupancy.json", "w"), indent=1)     # the bench below reads this copy
+json.dump(rec, open("profiles/r06_ops_occupancy.json", "w"), indent=1)     # the bench below reads this copy
 PY
 echo "== bench pmc"; bash scripts/pmc_bench.sh > $O/pmc_bench.log 2>&1; echo "pmc bench rc=$?"; cat gpurun_out/pmc_bench/traffic.json | head -c 900; echo
-python -c "import json; json.dump(json.load(open('gpurun_out/pmc_bench/traffic.json')), open('profiles/r05_traffic.json', 'w'), indent=1)"
-echo "== steady state"; bash scripts/prof_bench.sh r5final --no-ops > $O/prof_bench3.log 2>&1; head -3 $O/prof_bench3.log | cut -c1-160
-bash scripts/prof_bench.sh r5final_s1 --streams 1 --no-ops > $O/prof_bench1.log 2>&1; head -3 $O/prof_bench1.log | cut -c1-160
+python -c "import json; json.dump(json.load(open('gpurun_out/pmc_bench/traffic.json')), open('profiles/r06_traffic.json', 'w'), indent=1)"
+echo "== steady state"; bash scripts/prof_bench.sh r6final --no-ops > $O/prof_bench3.log 2>&1; head -3 $O/prof_bench3.log | cut -c1-160
+bash scripts/prof_bench.sh r6final_s1 --streams 1 --no-ops > $O/prof_bench1.log 2>&1; head -3 $O/prof_bench1.log | cut -c1-160
 echo "== graph replay kernels"; bash scripts/graph_trace.sh > $O/graph_replay_kernels.txt 2>&1; echo "graph trace rc=$?"; tail -1 $O/graph_replay_kernels.txt
 echo "== ops report"; timeout -k 10 600 python scripts/bench_ops.py --which all > $O/ops_report.jsonl 2> $O/ops_report.err; echo "ops rc=$?"; wc -l $O/ops_report.jsonl
 echo "== bench"; timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; head -c 400 $O/bench.json; echo
@@ -38,6 +38,10 @@ echo "== bench, RCCL world of one (side-stream gather)"; timeout -k 10 300 pytho
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-ops --streams 1 --graph 2>/dev/null | grep '^{' > $O/bench_s1_graph.json; python -c "
 import json
 d=json.load(open('$O/bench_s1_graph.json')); print('graph replay, 1 stream', d['value'], d['ms_per_step'])"
+echo "== bench, 2 ranks sharing the card under gloo (rehearsal of the N > 1 code path: graph decision, per-rank CPU sets)"
+S2A_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --streams 1 --steps 10 --no-cpu-baseline --no-ops 2>/dev/null | grep '^{' > $O/bench_2rank_gloo.json; head -c 300 $O/bench_2rank_gloo.json; echo
+echo "== Winograd F(2,3) tower kernel against the direct one, same box (+ timing ablations)"
+timeout -k 10 300 python scripts/bench_wino.py 3 2>/dev/null | grep kernel > $O/wino_ab.jsonl; cat $O/wino_ab.jsonl | cut -c1-160
 echo "== half decode / NMS effect"; timeout -k 10 300 python scripts/half_nms_effect.py > $O/half_nms_effect.log 2>&1; tail -1 $O/half_nms_effect.log | cut -c1-400
 echo "== clock probe"; timeout -k 10 300 python scripts/pyr_power_probe.py > $O/pyr_power_probe.jsonl 2>/dev/null; cat $O/pyr_power_probe.jsonl
 echo "== deform-conv backward: kernel trace + stamps of the f32 weight kernel"

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""assemble the committed profiles/r05_* files from what scripts/gpu_round5_final.sh left under gpurun_out/ (run in the
+"""assemble the committed profiles/r06_* files from what scripts/gpu_round6_final.sh left under gpurun_out/ (run in the
 build container, after the GPU call): python scripts/publish_profiles.py      (round 4's version of this script is in
 the history at a1629f9)"""
 import json, os, shutil, subprocess
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-RN = "r05"
-F = os.path.join(G, "r5final")
+RN = "r06"
+F = os.path.join(G, "r6final")
 head = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 
 
@@ -34,14 +34,13 @@ with open(os.path.join(P, RN + "_alignconv_pyramid_pmc.txt"), "w") as f:
 # rocprofv3 PMC passes over `python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ops` (scripts/pmc_bench.sh, tree %s).
 # FETCH_SIZE / WRITE_SIZE in KiB; gfx950: FETCH_SIZE reads half of a wide coalesced read -> read bytes = 2 x %.0f KiB = %.1f MB,
 # WRITE_SIZE exact -> %.1f MB; traffic per launch = %.1f MB vs %.1f MB algorithmic (in + out + filter + anchors) = %.2fx
-# (rounds 1-4: 256.2 / 256.4 / 256.5 / 247.7 MB; round 5 removed the dominated compile-time arms of this kernel, the instruction
-# stream of the shipped form is unchanged)
+# (rounds 1-5: 256.2 / 256.4 / 256.5 / 247.7 / 247.9 MB; round 6 did not touch this kernel)
 """ % (head, a["fetch_kib"], 2 * a["fetch_kib"] * 1024 / 1e6, a["write_kib"] * 1024 / 1e6, a["bytes"] / 1e6, alg / 1e6, a["bytes"] / alg))
 copy(os.path.join(G, "pmc_bench", "summary_k_conv_f16_9_4.txt"), "_conv_tower_pmc.txt")
 
 # 2. NMS / IoU counters (occupancy) and timelines
 with open(os.path.join(P, RN + "_nms_200k_pmc.txt"), "w") as f:
-    f.write("# ml_nms_rotated, 200 000 rows x 15 labels, round-5 pipeline (tree %s): rocprofv3 PMC passes over\n"
+    f.write("# ml_nms_rotated, 200 000 rows x 15 labels, round-6 pipeline (tree %s): rocprofv3 PMC passes over\n"
             "# `python scripts/bench_ops.py --which nms200k` (scripts/pmc_cmd.sh), report by scripts/nms_pmc_report.py\n" % head)
     f.write(cat(os.path.join(F, "nms_pmc_report.txt")))
     f.write("\n# kernel timeline of ONE call (scripts/nms_timeline.sh):\n")
@@ -58,10 +57,10 @@ json.dump(occ, open(os.path.join(P, RN + "_ops_occupancy.json"), "w"), indent=1)
 
 # 3. bench: line, steady-state tables, kernel stats, the captured-graph kernel list, the RCCL world-of-one line
 copy(os.path.join(F, "bench.json"), "_bench_line.json")
-for tag, out in (("r5final", "_bench_steady_state.txt"), ("r5final_s1", "_bench_steady_state_streams1.txt")):
+for tag, out in (("r6final", "_bench_steady_state.txt"), ("r6final_s1", "_bench_steady_state_streams1.txt")):
     copy(os.path.join(G, "prof_" + tag, "steady.txt"), out)
-copy(os.path.join(G, "prof_r5final", "kernel_stats.csv"), "_bench_kernel_stats.csv")
-copy(os.path.join(G, "prof_r5final", "line.json"), "_bench_line_under_rocprof.json")
+copy(os.path.join(G, "prof_r6final", "kernel_stats.csv"), "_bench_kernel_stats.csv")
+copy(os.path.join(G, "prof_r6final", "line.json"), "_bench_line_under_rocprof.json")
 copy(os.path.join(F, "graph_replay_kernels.txt"), "_graph_replay_kernels.txt")
 copy(os.path.join(F, "bench_rccl_world1.json"), "_bench_rccl_world1.json")
 
@@ -80,4 +79,7 @@ with open(os.path.join(P, RN + "_dcn_backward_kernel_stats.txt"), "w") as f:
     f.write(cat(os.path.join(F, "dcn_backward_kernel_stats.txt")))
     f.write("\n# k_dcn_bwd_weight_f32, cycles per 32-position tile (12.3 k of them MFMA):\n")
     f.write(cat(os.path.join(F, "dcn_backward_f32_weight_stamps.txt")))
+copy(os.path.join(F, "bench_2rank_gloo.json"), "_bench_2rank_gloo_rehearsal.json")
+copy(os.path.join(F, "bench_s1_graph.json"), "_bench_streams1_graph.json")
+copy(os.path.join(F, "wino_ab.jsonl"), "_wino_ab_evidence_box.jsonl")
 print("published for", head)
