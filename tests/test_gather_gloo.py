@@ -61,28 +61,42 @@ def uneven_worker(rank, world, port, G, K, q):
     dist.destroy_process_group()
 
 
-def _spawn(target, world, *args):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
-    for p in procs:
-        p.start()
-    return procs, q
+def _run_world(target, world, n_items, *args):
+    """start `world` gloo ranks of `target` on a fresh port and collect n_items queue entries; a rendezvous that fails because
+    the probed port was taken in between (rare, seen once on a busy box) is retried on another port"""
+    import queue
+    last = None
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = []
+        try:
+            for _ in range(n_items):
+                got.append(q.get(timeout=120))
+        except queue.Empty:
+            last = "timeout waiting for the ranks"
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+        if len(got) == n_items and all(p.exitcode == 0 for p in procs):
+            return got
+        last = last or "exit codes %s" % [p.exitcode for p in procs]
+    raise AssertionError("gloo world failed three times: %s" % last)
 
 
 def test_uneven_shards_are_padded_and_stripped():
     """global batch 5 over 2 ranks (3 + 2 images): every rank sends 3 rows, the short one a "no image" row with count -1;
     unpack_global returns the 5 images in order, == the concatenation of the per-rank outputs"""
     world, G, K = 2, 5, 20
-    procs, q = _spawn(uneven_worker, world, G, K)
-    got = [q.get(timeout=120) for _ in range(2 * world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got = _run_world(uneven_worker, world, 2 * world, G, K)
     exp = [make_rank_output(r, shard_range(G, world, r)[1] - shard_range(G, world, r)[0], K) for r in range(world)]
     ed, el, ec = (torch.cat([e[i] for e in exp]) for i in range(3))
     assert ed.shape[0] == G
@@ -110,19 +124,7 @@ def test_pack_roundtrip():
 
 def test_all_gather_equals_concatenation():
     world, B, K = 2, 3, 50
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, port, B, K, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got = _run_world(worker, world, world, B, K)
     exp = [make_rank_output(r, B, K) for r in range(world)]
     ed = torch.cat([e[0] for e in exp])
     el = torch.cat([e[1] for e in exp])
