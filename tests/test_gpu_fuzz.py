@@ -1,4 +1,4 @@
-"""Bounded, seeded slices of the randomised oracle checkers (scripts/fuzz_nms.py, fuzz_alignconv.py, fuzz_dcn_backward.py) so
+"""Bounded, seeded slices of the randomised oracle checkers (scripts/fuzz_nms.py, fuzz_alignconv.py, fuzz_dcn_backward.py, fuzz_f_ops.py) so
 that they are on the driver's record, and the one-launch small-input NMS under load: synchronous 5 000-row ml_nms_rotated
 calls while two other streams run the head (the occupancy k_nms_small's cross-workgroup ticket meets in bench.py).
 Reference: utils/ml_nms_rotated/src/nms_rotated_cuda.cu:74-137, models/dcn/src/deform_conv_cuda.cpp:262-489,
@@ -52,6 +52,15 @@ def test_fuzz_dcn_backward_slice():
     against the oracle; the weight gradient twice, bit-identical"""
     from scripts import fuzz_dcn_backward
     _run(fuzz_dcn_backward.bwd_case, 7, 8, max_h=20, max_w=28)
+
+
+def test_fuzz_assign_labels_and_nms_poly_slice():
+    """the two section-8(f) ops rewritten in round 6 (list forms): 10 random assign_labels calls (1 ... 9 000 anchors, 1 ... 1 025
+    gts -- both sides of the list form's limit --, exact ties, invalid anchors, both gt_max_assign_all settings, other thresholds)
+    and 10 random nms_poly calls (piles of identical polygons, reversed winding, score ties, thresholds 0 ... 0.95) == oracle"""
+    from scripts import fuzz_f_ops
+    _run(fuzz_f_ops.assign_case, 11, 10)
+    _run(fuzz_f_ops.poly_case, 12, 10)
 
 
 def _small_stats():
