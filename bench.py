@@ -389,16 +389,22 @@ def measure_ops(dev, with_cpu=True):
     # SURVEY 8(f) rows 1 / 2 that got a speed pass in round 6: chip-merge polygon NMS at 20 000 polygons and assign_labels on
     # the 21 824 anchors of a chip
     try:
-        import oracle as _o
         from s2anet_amd.rotated import nms_poly, assign_labels
         rp = np.random.default_rng(77)
-        polys = _o.rboxes_to_polys(_ops_inputs_rboxes(rp, 20000, span=2048.0))
-        dp = torch.from_numpy(np.concatenate([polys, ((rp.permutation(20000) + 1.0) / 20001.0)[:, None]], 1)).to(dev)
+        polys = rbox_to_poly(torch.from_numpy(_ops_inputs_rboxes(rp, 20000, span=2048.0)).to(dev)).double()
+        sc_p = torch.from_numpy((rp.permutation(20000) + 1.0) / 20001.0).to(dev)
+        dp = torch.cat([polys, sc_p[:, None]], 1).contiguous()
         kp = nms_poly(dp, 0.3)
         tp = _time_launches(lambda: nms_poly(dp, 0.3), iters=10)
         ops["nms_poly_20k"] = {"ms": round(tp * 1e3, 3), "keep": int(kp.numel()), "dtype": "f64"}
         ra = np.random.default_rng(5)
-        a = np.concatenate([_o.grid_anchors(1024 // st_, 1024 // st_, st_).reshape(-1, 5) for st_ in (8, 16, 32, 64, 128)]).astype(np.float32)
+        lev = []
+        for st_ in (8, 16, 32, 64, 128):      # the grid anchors of a 1024^2 chip (models/anchors.py:75-126): centres x * s + 0.5 (s - 1), side 4 s
+            n_ = CHIP // st_
+            ys_, xs_ = np.meshgrid(np.arange(n_, dtype=np.float32), np.arange(n_, dtype=np.float32), indexing="ij")
+            lev.append(np.stack([xs_ * st_ + 0.5 * (st_ - 1), ys_ * st_ + 0.5 * (st_ - 1), np.full_like(xs_, 4.0 * st_),
+                                 np.full_like(xs_, 4.0 * st_), np.zeros_like(xs_)], -1).reshape(-1, 5))
+        a = np.concatenate(lev).astype(np.float32)
         a[:, 4] = ra.uniform(-0.7, 2.3, a.shape[0])
         A = torch.from_numpy(a).to(dev)
         res = {}
