@@ -439,6 +439,15 @@ int s2a_deform_conv_backward(int dtype, const void* input, const void* offset, c
                              float* grad_input_f32, void* grad_offset, float* grad_weight_f32, float scale, int64_t batch,
                              int64_t channels, int64_t height, int64_t width, int64_t out_channels, void* workspace,
                              size_t workspace_bytes, s2a_stream_t stream);
+/* The same call with gradInput as DeformConvFunction.backward owns it (deform_conv.py:88: zeros_like(input)): grad_input
+ * [S,C,H,W] is a tensor of `dtype` and is OVERWRITTEN with the gradient (== the reference's accumulation into a zeroed
+ * tensor) -- no f32 copy on the caller's side and no conversion pass behind the call.  The tiles' sums are accumulated in f32
+ * (workspace, [S,H,W,C]: one pixel's 32 channels are one 128-byte atomic row) and rounded once.  Workspace:
+ * s2a_deform_conv_backward_workspace_bytes. */
+int s2a_deform_conv_backward_typed(int dtype, const void* input, const void* offset, const void* grad_output,
+                                   const void* weight, void* grad_input, void* grad_offset, float* grad_weight_f32,
+                                   float scale, int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                   int64_t out_channels, void* workspace, size_t workspace_bytes, s2a_stream_t stream);
 
 /* A bottleneck's conv2 + conv3 in one launch (models/backbone.py:56-83 with the BatchNorms folded):
  *   out = relu(W3 . relu(conv3x3(x; W2) + b2) + b3 + residual)        x [B,H,W,64] -> out [B,H,W,256], f16 NHWC

@@ -99,6 +99,8 @@ SYMBOLS = {
     "s2a_deform_conv_backward_workspace_bytes": (c_sz, [c_int, c_i64, c_i64, c_i64, c_i64, c_i64]),
     "s2a_deform_conv_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_i64,
                                          c_i64, c_vp, c_sz, c_vp]),
+    "s2a_deform_conv_backward_typed": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_i64,
+                                               c_i64, c_vp, c_sz, c_vp]),
     "s2a_deform_conv_backward_input_f32_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64, c_i64]),
     "s2a_deform_conv_backward_weight_f32_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64, c_i64]),
     "s2a_deform_conv_backward_weight_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_i64, c_i64,

@@ -238,6 +238,31 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
   }
 }
 
+// the fused input-gradient kernels sum into an [S, HW, C] f32 accumulator (128-byte atomic rows); this hands the result to
+// the caller's [S, C, HW] tensor: added to it (ACCUM: the f32 gradInput the reference's atomics accumulate into,
+// deform_conv_cuda_kernel.cu:339) or written in the tensor's own type (the zeroed gradInput of deform_conv.py:88)
+template <typename OutT, bool ACCUM>
+__global__ __launch_bounds__(256) void k_bwd_acc_to_nchw(const float* __restrict__ acc, int C, int64_t HW, OutT* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int64_t b = blockIdx.z, p0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t p = p0 + r;
+    const int c = c0 + tx;
+    if (c < C && p < HW) tile[r][tx] = acc[(b * HW + p) * C + c];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const int64_t p = p0 + tx;
+    if (c < C && p < HW) {
+      OutT* d = dst + (b * C + c) * HW + p;
+      if constexpr (ACCUM) *d = (OutT)((float)*d + tile[tx][r]);
+      else *d = (OutT)tile[tx][r];
+    }
+  }
+}
+
 // ================================================================= fused input + offset gradient (f16, AlignConv geometry)
 // deform_conv_backward_input_cuda (models/dcn/src/deform_conv_cuda.cpp:262-374) WITHOUT `columns` in HBM.  The reference
 // (and the first version here) materialises columns = W^T x gradOutput [C*9, N] per chunk (604 MB at P3, batch 8), then
@@ -252,8 +277,9 @@ __global__ void k_def_col2im_coord(int64_t n, const T* __restrict__ col, const T
 //     over channels, reduced over the four lanes of a position and added to an LDS array);
 //   * the INPUT gradient (deformable_col2im's scatter) is a GATHER: the list of (position, tap, corner, weight)
 //     contributions of every pixel of a 12 x 24 window is built once per tile, and per chunk a thread sums its pixel's list
-//     from the column-gradient tiles -- nine taps and all positions of the tile summed first -- and issues one global f32
-//     atomic per touched cell.
+//     from the column-gradient tiles -- nine taps and all positions of the tile summed first; the sums of a chunk are parked
+//     in LDS and leave as ONE global f32 atomic per touched cell and channel, 128-byte rows of an [S,H,W,C] accumulator
+//     (k_bwd_acc_to_nchw hands it to the caller's [S,C,H,W] tensor).
 // Samples whose corners leave the window / patch (offsets beyond its 2-3 pixel slack) take global loads and atomics.
 // HBM traffic per tile: gradOutput once, the input patch once per chunk, the gradient window once per chunk.
 // S2A_BWD_ABL: timing-only ablations of k_dcn_bwd_input (never set in a shipped build): 1 = no global atomics of the gathered
@@ -274,7 +300,11 @@ __device__ unsigned long long g_bwd_dbg[16];
 #endif
 constexpr int kBTH = 4, kBTW = 16, kBPos = kBTH * kBTW, kBHalo = 4;
 constexpr int kBPH = kBTH + 2 * kBHalo, kBPW = kBTW + 2 * kBHalo, kBPix = kBPH * kBPW;   // 12 x 24 = 288
-constexpr int kBCh = 32;                       // input channels per chunk
+// k_dcn_bwd_input's window.  (One row and one column less -- 11 x 23 = 253 pixels, so that the 1 012 (8-channel group, pixel)
+// items of the gather pass fit ONE trip of the 1 024 threads -- measured 816 -> 884 us at P3 x 8: with 2 instead of 3 pixels of
+// slack below / right more AlignConv samples leave the window and take the global path.)
+constexpr int kIPH = kBPH, kIPW = kBPW, kIPix = kIPH * kIPW;                             // 12 x 24 = 288
+constexpr int kBCh = 32;                       // input channels per chunk (the flush of the window sums takes 32: one 128-byte row per pixel)
 constexpr int kBThreads = 1024;                // k_dcn_bwd_input: the passes between the MFMA jobs are latency-bound loops -- sixteen waves
                                                // instead of eight: 1.36 -> 1.34 ms (the f32 kernel: 2.56 -> 2.60, stays at 512)
 constexpr int kBGRow = kBCh + 4;               // floats per (tap, position) row of the column-gradient tiles: 144 B -- with 128-B rows every
@@ -332,19 +362,19 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
                                                          const _Float16* __restrict__ go,       // NHWC [S,H,W,O]
                                                          const _Float16* __restrict__ offset,   // NCHW [S,18,H,W]
                                                          const _Float16* __restrict__ wpk,
-                                                         float* __restrict__ grad_in,           // NCHW [S,C,H,W] f32, accumulated
+                                                         float* __restrict__ grad_in,           // NHWC [S,H,W,C] f32, accumulated
                                                          _Float16* __restrict__ grad_off,       // NCHW [S,18,H,W]
                                                          int S, int C, int H, int W, int O) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_go = smem;                                                       // [64][kBGoRow]
   float* s_G = reinterpret_cast<float*>(s_go + kBPos * kBGoRow);            // [9][64][kBGRow] f32: column gradient of a chunk
   char* s_patch = reinterpret_cast<char*>(s_G + 9 * kBPos * kBGRow);        // [288][32 halfs]
-  BTap* s_tab = reinterpret_cast<BTap*>(s_patch + kBPix * kBCh * 2);        // [64 * 9]
+  BTap* s_tab = reinterpret_cast<BTap*>(s_patch + kIPix * kBCh * 2);        // [64 * 9]
   _Float16* s_frac = reinterpret_cast<_Float16*>(s_tab + kBPos * 9);        // [64 * 9][2]: lh, lw
   float* s_goff = reinterpret_cast<float*>(s_frac + kBPos * 9 * 2);         // [64 * 9][2]
   unsigned* s_list = reinterpret_cast<unsigned*>(s_goff + kBPos * 9 * 2);   // [64 * 9 * 4]: (tap * 64 + pos) << 16 | weight (f16 bits)
   unsigned* s_start = s_list + kBPos * 9 * 4;                               // [288 + 1] first list entry of a window pixel
-  unsigned* s_cur = s_start + kBPix + 1;                                    // [288] fill cursors
+  unsigned* s_cur = s_start + kIPix + 1;                                    // [288] fill cursors
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int txn = (W + kBTW - 1) / kBTW, tyn = (H + kBTH - 1) / kBTH;
   int t_ = blockIdx.x;
@@ -366,7 +396,7 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
     *reinterpret_cast<f16x8b*>(s_go + pos * kBGoRow + ch * 16) = d;
   }
   for (int e = tid; e < kBPos * 9 * 2; e += kBThreads) s_goff[e] = 0.f;
-  for (int e = tid; e <= kBPix; e += kBThreads) s_start[e] = 0u;
+  for (int e = tid; e <= kIPix; e += kBThreads) s_start[e] = 0u;
   for (int e = tid; e < kBPos * 9; e += kBThreads) {
     const int pos = e / 9, t = e % 9;
     const int y = ty0 + (pos >> 4), xq = tx0 + (pos & 15);
@@ -389,9 +419,9 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
         tp.w[3] = (_Float16)((b_ok && r_ok) ? lh * lw : 0.f);
         tp.y = (short)h_low;
         tp.x = (short)w_low;
-        const bool in = h_low >= oy && h_low + 1 <= oy + kBPH - 1 && w_low >= ox && w_low + 1 <= ox + kBPW - 1;
-        const int py = min(max(h_low - oy, 0), kBPH - 2), px = min(max(w_low - ox, 0), kBPW - 2);
-        tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kBPW + px) << 2);
+        const bool in = h_low >= oy && h_low + 1 <= oy + kIPH - 1 && w_low >= ox && w_low + 1 <= ox + kIPW - 1;
+        const int py = min(max(h_low - oy, 0), kIPH - 2), px = min(max(w_low - ox, 0), kIPW - 2);
+        tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kIPW + px) << 2);
       }
     }
     s_tab[e] = tp;
@@ -411,25 +441,25 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
     const int pix = (int)(tp.flags >> 2);
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      if ((float)tp.w[k] != 0.f) atomicAdd(&s_start[pix + (k >> 1) * kBPW + (k & 1) + 1], 1u);
+      if ((float)tp.w[k] != 0.f) atomicAdd(&s_start[pix + (k >> 1) * kIPW + (k & 1) + 1], 1u);
   }
   __syncthreads();
   if (wave == 0) {                               // inclusive scan of the 288 counts (shifted by one: s_start[p + 1])
     unsigned carry = 0;
-    for (int base = 0; base < kBPix; base += 64) {
+    for (int base = 0; base < kIPix; base += 64) {
       const int p = base + lane;
-      unsigned v = p < kBPix ? s_start[p + 1] : 0u;
+      unsigned v = p < kIPix ? s_start[p + 1] : 0u;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const unsigned u = (unsigned)__shfl_up((int)v, o);
         if (lane >= o) v += u;
       }
-      if (p < kBPix) s_start[p + 1] = carry + v;
+      if (p < kIPix) s_start[p + 1] = carry + v;
       carry += (unsigned)__shfl((int)v, 63);
     }
   }
   __syncthreads();
-  for (int e = tid; e < kBPix; e += kBThreads) s_cur[e] = s_start[e];
+  for (int e = tid; e < kIPix; e += kBThreads) s_cur[e] = s_start[e];
   __syncthreads();
   for (int e = tid; e < kBPos * 9; e += kBThreads) {
     const BTap tp = s_tab[e];
@@ -438,20 +468,21 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
 #pragma unroll
     for (int k = 0; k < 4; k++)
       if ((float)tp.w[k] != 0.f) {
-        const unsigned slot = atomicAdd(&s_cur[pix + (k >> 1) * kBPW + (k & 1)], 1u);
+        const unsigned slot = atomicAdd(&s_cur[pix + (k >> 1) * kIPW + (k & 1)], 1u);
         s_list[slot] = ((unsigned)(t * kBPos + pos) << 16) | (unsigned)__builtin_bit_cast(unsigned short, tp.w[k]);
       }
   }
 
   // patch of chunk cc: 288 pixels x 4 vectors of 8 channels; vector v -> pixel v >> 2, group v & 3
-  f16x8b pv[3];
+  constexpr int kPV = (kIPix * 4 + kBThreads - 1) / kBThreads;
+  f16x8b pv[kPV];
   auto patch_issue = [&](int cc) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < kPV; i++) {
       const int v = tid + kBThreads * i, p = v >> 2, q = v & 3;
       pv[i] = f16x8b{};
-      if (v < kBPix * 4) {
-        const int yy = oy + p / kBPW, xx = ox + p % kBPW;
+      if (v < kIPix * 4) {
+        const int yy = oy + p / kIPW, xx = ox + p % kIPW;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W)
           pv[i] = *reinterpret_cast<const f16x8b*>(x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * kBCh + q * 8);
       }
@@ -459,9 +490,9 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
   };
   auto patch_write = [&]() {
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < kPV; i++) {
       const int v = tid + kBThreads * i;
-      if (v < kBPix * 4) *reinterpret_cast<f16x8b*>(s_patch + v * 16) = pv[i];
+      if (v < kIPix * 4) *reinterpret_cast<f16x8b*>(s_patch + v * 16) = pv[i];
     }
   };
   patch_issue(0);
@@ -529,8 +560,8 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
         const char* p0 = s_patch + (pix * 4 + q) * 16;
         c4[0] = *reinterpret_cast<const f16x8b*>(p0);
         c4[1] = *reinterpret_cast<const f16x8b*>(p0 + 64);
-        c4[2] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 64);
-        c4[3] = *reinterpret_cast<const f16x8b*>(p0 + kBPW * 64 + 64);
+        c4[2] = *reinterpret_cast<const f16x8b*>(p0 + kIPW * 64);
+        c4[3] = *reinterpret_cast<const f16x8b*>(p0 + kIPW * 64 + 64);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -564,21 +595,28 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
           const float wk = (float)tp.w[k];
           if (wk == 0.f) continue;
           const int yy = (int)tp.y + (k >> 1), xx = (int)tp.x + (k & 1);
-          float* gp2 = grad_in + (((int64_t)b * C + cc * kBCh + q * 8) * H + yy) * W + xx;
+          float* gp2 = grad_in + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * kBCh + q * 8;
 #pragma unroll
-          for (int j = 0; j < 8; j++) atomicAdd(gp2 + (int64_t)j * HW, wk * G[j]);
+          for (int j = 0; j < 8; j++) atomicAdd(gp2 + j, wk * G[j]);
         }
       }
     }
-    // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels
-    for (int wi = tid; wi < ((S2A_BWD_ABL & 2) ? 0 : 4 * kBPix); wi += kBThreads) {
-      const int q = wi / kBPix, pix = wi % kBPix;      // (lanes = pixels of ONE channel group: with the four groups of a pixel in
-                                                       // neighbouring lanes the atomics scatter over four planes: 1.36 -> 1.53 ms)
-      const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
-      if (l0 == l1) continue;
-      float a8[8];
+    // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels of ONE
+    // channel group (conflict-free row reads).  The sums do not go to memory from here: a wave's 64 pixels of one channel
+    // are 64 different 1 KB rows of the [S,H,W,C] accumulator (and were 2-3 runs of <= 96 B in an [S,C,H,W] one: 452 us of
+    // atomics per P3 x 8 call, against 201 us for the same adds at lane-contiguous addresses, S2A_BWD_ABL 256 of round 6).
+    // They are parked in LDS -- in the room of the column-gradient tiles, which nobody reads any more -- and leave as
+    // 128-byte rows, one pixel's 32 channels per half wave: two full lines per atomic instruction.
+    constexpr int kNI = (4 * kIPix + kBThreads - 1) / kBThreads;
+    float a8[kNI][8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) a8[j] = 0.f;
+    for (int it = 0; it < kNI; it++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) a8[it][j] = 0.f;
+      const int wi = tid + it * kBThreads;
+      if (wi >= ((S2A_BWD_ABL & 2) ? 0 : 4 * kIPix)) continue;
+      const int q = wi / kIPix, pix = wi % kIPix;
+      const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
       // four list entries per trip: the entry -> row address -> two row reads chain is three dependent LDS round trips, and a
       // pixel in the middle of the tile has 20-40 entries (one entry per trip: 19 k cycles per chunk, all of it latency).
       // Entries past the end repeat the last one with weight 0; the sums run in list order as before.
@@ -597,14 +635,26 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
         for (int k = 0; k < 4; k++) {
           const float wk = l + k < l1 ? (float)__builtin_bit_cast(_Float16, (unsigned short)(ent[k] & 0xffffu)) : 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; j++) { a8[j] = __builtin_fmaf(wk, g0[k][j], a8[j]); a8[4 + j] = __builtin_fmaf(wk, g1[k][j], a8[4 + j]); }
+          for (int j = 0; j < 4; j++) { a8[it][j] = __builtin_fmaf(wk, g0[k][j], a8[it][j]); a8[it][4 + j] = __builtin_fmaf(wk, g1[k][j], a8[it][4 + j]); }
         }
       }
-      const int yy = oy + pix / kBPW, xx = ox + pix % kBPW;      // (pixels outside the image have no list: w = 0 there)
-      float* gp2 = grad_in + (((int64_t)b * C + cc * kBCh + q * 8) * H + yy) * W + xx;
-      if (S2A_BWD_ABL & 1) { if (a8[0] == 12345.f) gp2[0] = a8[1] + a8[2] + a8[3] + a8[4] + a8[5] + a8[6] + a8[7]; continue; }
+    }
+    __syncthreads();                             // every list has been summed: the column-gradient tiles are free
+    float* s_sum = s_G;                          // [288 window pixels][kBGRow]: 32 channel sums of the chunk
 #pragma unroll
-      for (int j = 0; j < 8; j++) atomicAdd(gp2 + (int64_t)j * HW, a8[j]);
+    for (int it = 0; it < kNI; it++) {
+      const int wi = tid + it * kBThreads;
+      if (wi >= 4 * kIPix) continue;
+      float* sp = s_sum + (wi % kIPix) * kBGRow + (wi / kIPix) * 8;
+      *reinterpret_cast<f32x4b*>(sp) = f32x4b{a8[it][0], a8[it][1], a8[it][2], a8[it][3]};
+      *reinterpret_cast<f32x4b*>(sp + 4) = f32x4b{a8[it][4], a8[it][5], a8[it][6], a8[it][7]};
+    }
+    __syncthreads();
+    for (int i = tid; i < ((S2A_BWD_ABL & 3) ? 0 : kIPix * kBCh); i += kBThreads) {
+      const int pix = i >> 5, c = i & 31;
+      if (s_start[pix] == s_start[pix + 1]) continue;            // (pixels outside the image have no list: w = 0 there)
+      const int yy = oy + pix / kIPW, xx = ox + pix % kIPW;
+      atomicAdd(grad_in + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * kBCh + c, s_sum[pix * kBGRow + c]);
     }
   }
   __syncthreads();
@@ -617,8 +667,8 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
   }
 }
 
-constexpr int kBwdLds = kBPos * kBGoRow + 9 * kBPos * kBGRow * 4 + kBPix * kBCh * 2 + kBPos * 9 * 16 + kBPos * 9 * 4 +
-                        kBPos * 9 * 8 + kBPos * 9 * 4 * 4 + (kBPix + 1) * 4 + kBPix * 4 + 64;   // ~152 KB
+constexpr int kBwdLds = kBPos * kBGoRow + 9 * kBPos * kBGRow * 4 + kIPix * kBCh * 2 + kBPos * 9 * 16 + kBPos * 9 * 4 +
+                        kBPos * 9 * 8 + kBPos * 9 * 4 * 4 + (kIPix + 1) * 4 + kIPix * 4 + 64;   // ~152 KB
 
 // ================================================================= fused input + offset gradient (f32, AlignConv geometry)
 // The same dataflow as k_dcn_bwd_input for float32 tensors (the reference trains in f32 unless amp is on: train.py), on the
@@ -919,7 +969,10 @@ __global__ __launch_bounds__(512) void k_dcn_bwd_input_f32(const float* __restri
         }
       }
     }
-    // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels
+    // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels.  (The
+    // f16 kernel's form -- sums parked in LDS, 128-byte rows of an [S,H,W,C] accumulator -- measured SLOWER here: 2416 -> 2516 us
+    // of kernel plus a 0.2 ms pass that adds the accumulator to gradInput.  This kernel waits for its f32 MFMA jobs, not for
+    // its atomics, and two more barriers per chunk cost more than the better-shaped adds return.)
     for (int wi = tid; wi < ((S2A_BWD_ABL & 2) ? 0 : 4 * kFPix); wi += 512) {
       const int q = wi / kFPix, pix = wi % kFPix;
       const unsigned l0 = s_start[pix], l1 = s_start[pix + 1];
@@ -1805,7 +1858,8 @@ namespace {
 struct FusedBwdArgs {
   int dtype;                                     // S2A_DTYPE_F16 / S2A_DTYPE_F32
   const void *input, *offset, *grad_output, *weight;
-  float* grad_input;                             // f32 [S,C,H,W], accumulated; NULL: no input / offset gradient
+  void* grad_input;                              // [S,C,H,W]; NULL: no input / offset gradient
+  int grad_input_typed;                          // 0: f32, ACCUMULATED (+=); 1: of `dtype`, OVERWRITTEN
   void* grad_offset;                             // dtype [S,18,H,W], overwritten
   float* grad_weight;                            // f32 [O,C,3,3], += scale * ...; NULL: no weight gradient
   float scale;
@@ -1815,7 +1869,7 @@ struct FusedBwdArgs {
 size_t fused_bwd_workspace(int dtype, bool want_input, bool want_weight, int64_t B, int64_t C, int64_t H, int64_t W, int64_t O) {
   const size_t el = dtype == S2A_DTYPE_F16 ? 2 : 4;
   size_t n = align_up((size_t)(B * H * W * C) * el) + align_up((size_t)(B * H * W * O) * el) + 1024;
-  if (want_input) n += align_up((size_t)(O * C * 9) * el);
+  if (want_input) n += align_up((size_t)(O * C * 9) * el) + (dtype == S2A_DTYPE_F16 ? align_up((size_t)(B * H * W * C) * 4) : 0);
   if (want_weight) n += align_up((size_t)kWgradMaxBlocks * O * 192 * 4);
   return n;
 }
@@ -1841,8 +1895,12 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
   T* xn = cv.take<T>((size_t)(B * HW * C));
   T* gn = cv.take<T>((size_t)(B * HW * O));
   T* wp = want_input ? cv.take<T>((size_t)(O * C * 9)) : nullptr;
+  // f16: [S,H,W,C] f32 accumulator the tiles' atomics add into (128-byte rows); f32: the caller's gradInput itself
+  float* gacc = (want_input && kHalf) ? cv.take<float>((size_t)(B * HW * C)) : nullptr;
   float* partial = want_weight ? cv.take<float>((size_t)kWgradMaxBlocks * O * 192) : nullptr;
-  S2A_CHECK_ARG(xn && gn && (!want_input || wp) && (!want_weight || partial), "%s: workspace too small", who);
+  S2A_CHECK_ARG(xn && gn && (!want_input || (wp && (gacc || !kHalf))) && (!want_weight || partial), "%s: workspace too small", who);
+  if (want_input && kHalf) S2A_HIP(hipMemsetAsync(gacc, 0, (size_t)(B * HW * C) * 4, st));
+  if (want_input && !kHalf && a.grad_input_typed) S2A_HIP(hipMemsetAsync(a.grad_input, 0, (size_t)(B * HW * C) * 4, st));
   k_bwd_nchw_to_nhwc<T><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B), 256, 0, st>>>((const T*)a.input, (int)C, HW, xn);
   k_bwd_nchw_to_nhwc<T><<<dim3((unsigned)((HW + 31) / 32), (unsigned)((O + 31) / 32), (unsigned)B), 256, 0, st>>>((const T*)a.grad_output, (int)O, HW, gn);
   if (want_input) {
@@ -1852,7 +1910,7 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
       const int64_t tiles = B * ((H + kBTH - 1) / kBTH) * ((W + kBTW - 1) / kBTW);
       S2A_CHECK_ARG(tiles < (1ll << 31), "%s: too many tiles", who);
       S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
-      k_dcn_bwd_input<<<(unsigned)tiles, kBThreads, kBwdLds, st>>>(xn, gn, (const _Float16*)a.offset, wp, a.grad_input, (_Float16*)a.grad_offset,
+      k_dcn_bwd_input<<<(unsigned)tiles, kBThreads, kBwdLds, st>>>(xn, gn, (const _Float16*)a.offset, wp, gacc, (_Float16*)a.grad_offset,
                                                             (int)B, (int)C, (int)H, (int)W, (int)O);
     } else {
       k_pack_weight_bwd_f32<<<(unsigned)((wtotal + 255) / 256), 256, 0, st>>>((const float*)a.weight, (int)O, (int)C, wp);
@@ -1862,11 +1920,16 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
       S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_input_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       if (O % 128 == 0)
-        k_dcn_bwd_input_f32<true><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, (const float*)a.offset, wp, a.grad_input, (float*)a.grad_offset,
+        k_dcn_bwd_input_f32<true><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, (const float*)a.offset, wp, (float*)a.grad_input, (float*)a.grad_offset,
                                                                     (int)B, (int)C, (int)H, (int)W, (int)O);
       else
-        k_dcn_bwd_input_f32<false><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, (const float*)a.offset, wp, a.grad_input, (float*)a.grad_offset,
+        k_dcn_bwd_input_f32<false><<<(unsigned)tiles, 512, lds, st>>>(xn, gn, (const float*)a.offset, wp, (float*)a.grad_input, (float*)a.grad_offset,
                                                                      (int)B, (int)C, (int)H, (int)W, (int)O);
+    }
+    if constexpr (kHalf) {
+      const dim3 fg((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+      if (a.grad_input_typed) k_bwd_acc_to_nchw<T, false><<<fg, 256, 0, st>>>(gacc, (int)C, HW, (T*)a.grad_input);
+      else k_bwd_acc_to_nchw<float, true><<<fg, 256, 0, st>>>(gacc, (int)C, HW, (float*)a.grad_input);
     }
     S2A_LAUNCH_CHECK();
   }
@@ -1926,7 +1989,7 @@ extern "C" int s2a_deform_conv_backward_input_f16(const void* input, const void*
                                                   int64_t out_channels, void* workspace, size_t workspace_bytes,
                                                   s2a_stream_t stream) {
   S2A_CHECK_ARG(batch == 0 || grad_input_f32, "deform_conv_backward_input_f16: NULL tensor");
-  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F16, input, offset, grad_output, weight, grad_input_f32, grad_offset, nullptr, 1.f, batch,
+  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F16, input, offset, grad_output, weight, grad_input_f32, 0, grad_offset, nullptr, 1.f, batch,
                                 channels, height, width, out_channels},
                    workspace, workspace_bytes, stream, "deform_conv_backward_input_f16");
 }
@@ -1942,7 +2005,7 @@ extern "C" int s2a_deform_conv_backward_input_f32(const float* input, const floa
                                                   int64_t out_channels, void* workspace, size_t workspace_bytes,
                                                   s2a_stream_t stream) {
   S2A_CHECK_ARG(batch == 0 || grad_input, "deform_conv_backward_input_f32: NULL tensor");
-  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F32, input, offset, grad_output, weight, grad_input, grad_offset, nullptr, 1.f, batch, channels,
+  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F32, input, offset, grad_output, weight, grad_input, 0, grad_offset, nullptr, 1.f, batch, channels,
                                 height, width, out_channels},
                    workspace, workspace_bytes, stream, "deform_conv_backward_input_f32");
 }
@@ -1957,7 +2020,7 @@ extern "C" int s2a_deform_conv_backward_weight_f16(const void* input, const void
                                                    int64_t width, int64_t out_channels, void* workspace,
                                                    size_t workspace_bytes, s2a_stream_t stream) {
   S2A_CHECK_ARG(batch == 0 || grad_weight_f32, "deform_conv_backward_weight_f16: NULL tensor");
-  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F16, input, offset, grad_output, nullptr, nullptr, nullptr, grad_weight_f32, 1.f, batch,
+  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F16, input, offset, grad_output, nullptr, nullptr, 0, nullptr, grad_weight_f32, 1.f, batch,
                                 channels, height, width, out_channels},
                    workspace, workspace_bytes, stream, "deform_conv_backward_weight_f16");
 }
@@ -1972,7 +2035,7 @@ extern "C" int s2a_deform_conv_backward_weight_f32(const float* input, const flo
                                                    int64_t height, int64_t width, int64_t out_channels, void* workspace,
                                                    size_t workspace_bytes, s2a_stream_t stream) {
   S2A_CHECK_ARG(batch == 0 || grad_weight, "deform_conv_backward_weight_f32: NULL tensor");
-  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F32, input, offset, grad_output, nullptr, nullptr, nullptr, grad_weight, scale, batch, channels,
+  return fused_bwd(FusedBwdArgs{S2A_DTYPE_F32, input, offset, grad_output, nullptr, nullptr, 0, nullptr, grad_weight, scale, batch, channels,
                                 height, width, out_channels},
                    workspace, workspace_bytes, stream, "deform_conv_backward_weight_f32");
 }
@@ -1989,7 +2052,18 @@ extern "C" int s2a_deform_conv_backward(int dtype, const void* input, const void
                                         const void* weight, float* grad_input_f32, void* grad_offset, float* grad_weight_f32,
                                         float scale, int64_t batch, int64_t channels, int64_t height, int64_t width,
                                         int64_t out_channels, void* workspace, size_t workspace_bytes, s2a_stream_t stream) {
-  return fused_bwd(FusedBwdArgs{dtype, input, offset, grad_output, weight, grad_input_f32, grad_offset, grad_weight_f32, scale, batch,
+  return fused_bwd(FusedBwdArgs{dtype, input, offset, grad_output, weight, grad_input_f32, 0, grad_offset, grad_weight_f32, scale, batch,
                                 channels, height, width, out_channels},
                    workspace, workspace_bytes, stream, "deform_conv_backward");
+}
+// The same call with gradInput as DeformConvFunction.backward hands it over (deform_conv.py:88: zeros_like(input)): a tensor of
+// `dtype`, [S,C,H,W], OVERWRITTEN with the gradient (no f32 copy on the caller's side, no conversion pass behind the call).
+// Workspace: s2a_deform_conv_backward_workspace_bytes.
+extern "C" int s2a_deform_conv_backward_typed(int dtype, const void* input, const void* offset, const void* grad_output,
+                                              const void* weight, void* grad_input, void* grad_offset, float* grad_weight_f32,
+                                              float scale, int64_t batch, int64_t channels, int64_t height, int64_t width,
+                                              int64_t out_channels, void* workspace, size_t workspace_bytes, s2a_stream_t stream) {
+  return fused_bwd(FusedBwdArgs{dtype, input, offset, grad_output, weight, grad_input, 1, grad_offset, grad_weight_f32, scale, batch,
+                                channels, height, width, out_channels},
+                   workspace, workspace_bytes, stream, "deform_conv_backward_typed");
 }

@@ -325,16 +325,17 @@ def _fused_backward(input, offset, weight, grad_output):
     x = input.contiguous()
     dt = x.dtype
     off, go, w = offset.to(dt).contiguous(), grad_output.to(dt).contiguous(), weight.to(dt).contiguous()
-    gin = torch.zeros((B, C, H, W), dtype=torch.float32, device=x.device)
+    gin = torch.empty((B, C, H, W), dtype=dt, device=x.device)           # overwritten, in the input's own type
     goff = torch.empty((B, 18, H, W), dtype=dt, device=x.device)
     gw = torch.zeros((O, C, 3, 3), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     code = _lib.dtype_code(x)
     ws = _lib.workspace(L.s2a_deform_conv_backward_workspace_bytes(code, B, C, H, W, O), x.device, "dcn_bwd")
     with torch.cuda.device(x.device):
-        _lib.check(L.s2a_deform_conv_backward(code, _lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(w), _lib.ptr(gin), _lib.ptr(goff),
-                                              _lib.ptr(gw), 1.0, B, C, H, W, O, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
-    return gin.to(input.dtype), goff.to(offset.dtype), gw.to(weight.dtype)
+        _lib.check(L.s2a_deform_conv_backward_typed(code, _lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(w), _lib.ptr(gin),
+                                                    _lib.ptr(goff), _lib.ptr(gw), 1.0, B, C, H, W, O, _lib.ptr(ws), ws.numel(),
+                                                    _lib.stream_ptr(x.device)))
+    return gin, goff.to(offset.dtype), gw.to(weight.dtype)
 
 
 class DeformConvFunction(torch.autograd.Function):
