@@ -500,17 +500,21 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
     __syncthreads();                             // everybody is done with the previous chunk's patch and column gradient
     patch_write();
     if (cc + 1 < CC) patch_issue(cc + 1);        // (in flight under this chunk's work)
-    // ---- column-gradient tiles of the nine taps on the matrix cores: job = (tap, 32-position half), 18 jobs over 8 waves
-    for (int job = wave; job < ((S2A_BWD_ABL & 8) ? 0 : 18); job += kBThreads / 64) {
-      const int t = job >> 1, ph = job & 1;
+    // ---- column-gradient tiles of the nine taps on the matrix cores: job = tap, both 32-position halves -- nine waves, one trip.
+    // (Jobs of one half, 18 over the sixteen waves, read every filter fragment twice: 288 KB per chunk through a CU's
+    // 64 B/clk vector-memory path, 7.2 k cycles for 2.5 k of MFMA; one wave with two accumulators reads it once.)
+    for (int job = wave; job < ((S2A_BWD_ABL & 8) ? 0 : 9); job += kBThreads / 64) {
+      const int t = job;
       const f16x8b* ap = reinterpret_cast<const f16x8b*>(wpk) + ((int64_t)(t * CC + cc) * KS) * 64 + lane;
-      const char* bp = s_go + (ph * 32 + (lane & 31)) * kBGoRow + (lane >> 5) * 16;
-      f32x16b acc;
+      const char* bp = s_go + (lane & 31) * kBGoRow + (lane >> 5) * 16;
+      f32x16b acc[2];
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[h][r] = 0.f;
       // the filter fragments come from L2: requested in batches of four right in front of their MFMAs they exposed that
-      // latency four times per job (11.5 k cycles per chunk for 2.3 k of MFMA) -- a batch of eight is in flight one batch ahead
-      constexpr int kAB = kBThreads >= 1024 ? 4 : 8;       // (a 1024-thread workgroup has 128 registers per lane)
+      // latency four times per job (11.5 k cycles per chunk for 2.3 k of MFMA) -- a batch is in flight one batch ahead
+      constexpr int kAB = 4;                               // (a 1024-thread workgroup has 128 registers per lane)
       f16x8b a0[kAB], a1[kAB];
       auto load_a = [&](int k0, f16x8b (&a)[kAB]) {
 #pragma unroll
@@ -518,13 +522,16 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
           if (k0 + k < KS) a[k] = ap[(int64_t)(k0 + k) * 64];
       };
       auto run = [&](int k0, const f16x8b (&a)[kAB]) {
-        f16x8b bb[kAB];
 #pragma unroll
-        for (int k = 0; k < kAB; k++)
-          if (k0 + k < KS) bb[k] = *reinterpret_cast<const f16x8b*>(bp + (k0 + k) * 32);
+        for (int h = 0; h < 2; h++) {
+          f16x8b bb[kAB];
 #pragma unroll
-        for (int k = 0; k < kAB; k++)
-          if (k0 + k < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k], bb[k], acc, 0, 0, 0);
+          for (int k = 0; k < kAB; k++)
+            if (k0 + k < KS) bb[k] = *reinterpret_cast<const f16x8b*>(bp + h * 32 * kBGoRow + (k0 + k) * 32);
+#pragma unroll
+          for (int k = 0; k < kAB; k++)
+            if (k0 + k < KS) acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k], bb[k], acc[h], 0, 0, 0);
+        }
       };
       load_a(0, a0);
       for (int k0 = 0; k0 < KS; k0 += 2 * kAB) {
@@ -534,11 +541,14 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
         if (k0 + kAB < KS) run(k0 + kAB, a1);
       }
       // D rows = channels (4 consecutive per register quad), columns = positions
-      float* gp = s_G + (t * kBPos + ph * 32 + (lane & 31)) * kBGRow + 4 * (lane >> 5);
 #pragma unroll
-      for (int rq = 0; rq < 4; rq++) {
-        const f32x4b v4 = {acc[rq * 4], acc[rq * 4 + 1], acc[rq * 4 + 2], acc[rq * 4 + 3]};
-        *reinterpret_cast<f32x4b*>(gp + 8 * rq) = v4;
+      for (int h = 0; h < 2; h++) {
+        float* gp = s_G + (t * kBPos + h * 32 + (lane & 31)) * kBGRow + 4 * (lane >> 5);
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+          const f32x4b v4 = {acc[h][rq * 4], acc[h][rq * 4 + 1], acc[h][rq * 4 + 2], acc[h][rq * 4 + 3]};
+          *reinterpret_cast<f32x4b*>(gp + 8 * rq) = v4;
+        }
       }
     }
     __syncthreads();
