@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kBThreads) void k_dcn_bwd_input(const _Float16* __r
     // ---- input gradient: every (8-channel group, window pixel) sums its list; consecutive lanes = consecutive pixels of ONE
     // channel group (conflict-free row reads).  The sums do not go to memory from here: a wave's 64 pixels of one channel
     // are 64 different 1 KB rows of the [S,H,W,C] accumulator (and were 2-3 runs of <= 96 B in an [S,C,H,W] one: 452 us of
-    // atomics per P3 x 8 call, against 201 us for the same adds at lane-contiguous addresses, S2A_BWD_ABL 256 of round 6).
+    // atomics per P3 x 8 call, against 201 us for the same adds at lane-contiguous addresses, a timing-only build of round 6, docs/HISTORY.md).
     // They are parked in LDS -- in the room of the column-gradient tiles, which nobody reads any more -- and leave as
     // 128-byte rows, one pixel's 32 channels per half wave: two full lines per atomic instruction.
     constexpr int kNI = (4 * kIPix + kBThreads - 1) / kBThreads;
