@@ -1757,7 +1757,8 @@ def test_dcn_backward_input_fused_f16_vs_oracle(rng, monkeypatch):
     operands, and against the unfused path (library GEMM + col2im kernels) on the same call: tame offsets (everything
     inside the LDS window), wild ones (global-atomic path), a ragged image (partly filled tiles), two channel chunks"""
     from s2anet_amd.dcn import deform_conv_backward_input_cuda
-    for (B, C, H, W, O, amp) in ((2, 64, 19, 45, 32, 0.7), (1, 32, 9, 20, 16, 5.0), (2, 64, 8, 16, 48, 2.0)):
+    # (the last two: H W % 8 == 0 -- the 16-bytes-per-lane staging copy, with a part-filled channel tile and a part-filled position tile)
+    for (B, C, H, W, O, amp) in ((2, 64, 19, 45, 32, 0.7), (1, 32, 9, 20, 16, 5.0), (2, 64, 8, 16, 48, 2.0), (1, 96, 5, 8, 16, 1.0)):
         xn = rng.standard_normal((B, C, H, W)).astype(np.float16)
         wn = (rng.standard_normal((O, C, 3, 3)) * 0.1).astype(np.float16)
         on = (rng.standard_normal((B, 18, H, W)) * amp).astype(np.float16)
