@@ -1350,6 +1350,294 @@ __global__ __launch_bounds__(512, 2) void k_dcn_bwd_weight(const _Float16* __res
   }
 }
 
+// ================================================================= fused weight gradient (f32 tensors as three bf16 planes)
+// The f32 matrix instruction runs at 1/16 of the 16-bit rate: k_dcn_bwd_weight_f32 below is its MFMA stream (1.1 of 1.58 ms at
+// P3 x 8).  An f32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 significand bits; hi = rne(x), mid = rne(x - hi),
+// lo = rne(x - hi - mid)), and a product of two such sums, without the three terms below 2^-24 of it, is six bf16 products:
+//     a b ~ a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2        (f32 accumulation on the matrix cores, |error| <~ 3 * 2^-24 |a b|:
+//                                                                  the size of ONE f32 rounding of the product)
+// -- six 16-bit MFMAs for eight f32 ones of half their length: 2.7 x fewer matrix cycles at the accuracy of f32 arithmetic
+// (the tests hold it to the same 1e-4 bound as the f32 instruction; measured difference to it ~1e-6 relative).
+// Dataflow = k_dcn_bwd_weight's (f16) on 4 x 8 position tiles (window 12 x 16, as the f32 kernels): the gradOutput tile is
+// split into its three planes when it lands in LDS, the input patch stays f32 (the bilinear blend runs in f32, as the
+// reference's), every blended column value is split as it is written, and the MFMA waves read all planes with the
+// transposing 16-bit LDS read.  One workgroup = one 64-channel chunk x one row of three taps x a slice of the tiles; partial
+// blocks and the fixed-order reduce as before (bit-identical from run to run).  S2A_BWD_F32_WEIGHT=mfma32 selects the f32
+// instruction's kernel (A/B and the tests' cross-check).
+constexpr int kXPos = kFPos;                    // 32 positions per tile
+constexpr int kXPatRow = 272;                   // bytes per window pixel of the f32 patch (64 floats + 16: conflict-light corner reads)
+constexpr int kXTabRow = 32;                    // bytes per sampling-table entry
+constexpr int kXColRow = 160;                   // bytes per position of a column plane: 64 bf16 + pad (pitch = 40 dwords: the four rows of a
+                                                // transposing read start in banks 0, 40, 16, 56 -- four different 16-bank groups, as with the
+                                                // f16 kernel's 48; 192 B would put the three planes of O = 256 past the LDS)
+struct alignas(16) XTap {
+  short y, x;        // top-left bilinear corner, image coordinates
+  unsigned flags;    // bit 0: sample valid; bit 1: all four corners inside the LDS window; bits 31..2: window pixel index
+  float w[4];        // hh*hw, hh*lw, lh*hw, lh*lw; 0 where the corner is outside the image
+  unsigned pad[2];
+};
+static_assert(sizeof(XTap) == kXTabRow, "table entry");
+__host__ __device__ inline int wgrad_x3_lds_bytes(int O) {
+  const int dw = O / 2, gop = (dw + ((16 - (dw & 63)) & 63)) * 4;
+  return 3 * kXPos * gop + kFPix * kXPatRow + 9 * kXPos * kXColRow + 3 * kXPos * kXTabRow;
+}
+using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4b = __attribute__((ext_vector_type(4))) __bf16;
+// x = hi + mid + lo exactly (finite x, no underflow of the low parts); each part round-to-nearest-even
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  mid = (__bf16)r1;
+  lo = (__bf16)(r1 - (float)mid);
+}
+
+__global__ __launch_bounds__(512) void k_dcn_bwd_weight_x3(const float* __restrict__ x,        // NHWC [S,H,W,C]
+                                                          const float* __restrict__ go,       // NHWC [S,H,W,O]
+                                                          const float* __restrict__ offset,   // NCHW [S,18,H,W]
+                                                          float* __restrict__ partial,        // [slice][owner][O][3 taps][64] f32
+                                                          int S, int C, int H, int W, int O, int ksplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int gop = wgrad_go_pitch(O);
+  char* s_go = smem;                                          // [3 planes][32][gop] bf16
+  char* s_patch = s_go + 3 * kXPos * gop;                     // [192][kXPatRow] f32
+  char* s_col = s_patch + kFPix * kXPatRow;                   // [3 planes][3 taps][32][kXColRow] bf16
+  XTap* s_tab = reinterpret_cast<XTap*>(s_col + 9 * kXPos * kXColRow);   // [3 * 32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CC = C / 64;
+  const int owner = blockIdx.x % (3 * CC), slice = blockIdx.x / (3 * CC);
+  const int cc = owner / 3, ky = owner % 3;
+  const int txn = (W + kFTW - 1) / kFTW, tyn = (H + kFTH - 1) / kFTH;
+  const int ntiles = S * tyn * txn;
+  const int64_t HW = (int64_t)H * W;
+  const int OT = O / 32;                                      // out-channel tiles; wave w owns tile w (O <= 256)
+  const bool mwave = wave < OT;
+  f32x16b acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
+
+  // registers that carry the NEXT tile's gradOutput tile and patch (issued a tile ahead): 32 x O / 4 and 192 x 16 vectors of 4 floats
+  constexpr int kGoVec = 4, kPaVec = 6;
+  f32x4b gv[kGoVec], pvv[kPaVec];
+  struct TilePos { int b, ty, tx; };
+  TilePos cur;
+  {
+    const int tile = min(slice, ntiles - 1), r = tile / txn;
+    cur.tx = tile % txn; cur.ty = r % tyn; cur.b = r / tyn;
+  }
+  auto advance = [&](TilePos& p) {
+    p.tx += ksplit;
+    while (p.tx >= txn) {
+      p.tx -= txn;
+      if (++p.ty == tyn) { p.ty = 0; ++p.b; }
+    }
+  };
+  const int ovec = O / 4;
+  int g_yx[kGoVec], g_ch[kGoVec], g_lds[kGoVec], p_yx[kPaVec], p_lds[kPaVec];     // y << 8 | x inside the tile / the window; -1: no such vector
+#pragma unroll
+  for (int i = 0; i < kGoVec; i++) {
+    const int v = tid + 512 * i;
+    const int pos = v / ovec, ch = v % ovec;
+    g_yx[i] = v < kXPos * ovec ? ((pos >> 3) << 8 | (pos & 7)) : -1;
+    g_ch[i] = ch * 4;
+    g_lds[i] = pos * gop + ch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < kPaVec; i++) {
+    const int v = tid + 512 * i, pp = v >> 4;                  // 16 vectors of 4 channels per pixel
+    p_yx[i] = v < kFPix * 16 ? ((pp / kFPW) << 8 | (pp % kFPW)) : -1;
+    p_lds[i] = pp * kXPatRow + (v & 15) * 16;
+  }
+  float off_y_raw = 0.f, off_x_raw = 0.f;        // the table threads' two offsets, requested a tile ahead
+  auto issue = [&](const TilePos& tp_) {
+    const int b = tp_.b, ty0 = tp_.ty * kFTH, tx0 = tp_.tx * kFTW;
+    const int oy = ty0 - 3, ox = tx0 - 3;
+    const float* gb = go + (int64_t)b * HW * O;
+    const float* xb = x + (int64_t)b * HW * C + cc * 64 + (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < kGoVec; i++) {
+      gv[i] = f32x4b{0.f, 0.f, 0.f, 0.f};
+      const int y = ty0 + (g_yx[i] >> 8), xq = tx0 + (g_yx[i] & 255);
+      if (g_yx[i] >= 0 && y < H && xq < W) gv[i] = *reinterpret_cast<const f32x4b*>(gb + ((int64_t)y * W + xq) * O + g_ch[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kPaVec; i++) {
+      pvv[i] = f32x4b{0.f, 0.f, 0.f, 0.f};
+      const int yy = oy + (p_yx[i] >> 8), xx = ox + (p_yx[i] & 255);
+      if (p_yx[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) pvv[i] = *reinterpret_cast<const f32x4b*>(xb + ((int64_t)yy * W + xx) * C);
+    }
+    if (tid < 3 * kXPos) {
+      const int tl = tid / kXPos, pos = tid % kXPos, t = ky * 3 + tl;
+      const int y = min(ty0 + (pos >> 3), H - 1), xq = min(tx0 + (pos & 7), W - 1);
+      const float* ob = offset + ((int64_t)b * 18) * HW + (int64_t)y * W + xq;
+      off_y_raw = ob[(int64_t)(2 * t) * HW];
+      off_x_raw = ob[(int64_t)(2 * t + 1) * HW];
+    }
+  };
+  auto land = [&]() {
+#pragma unroll
+    for (int i = 0; i < kGoVec; i++)
+      if (g_yx[i] >= 0) {
+        bf16x4b h, m, l;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { __bf16 a, b2, c; split3(gv[i][j], a, b2, c); h[j] = a; m[j] = b2; l[j] = c; }
+        *reinterpret_cast<bf16x4b*>(s_go + g_lds[i]) = h;
+        *reinterpret_cast<bf16x4b*>(s_go + kXPos * gop + g_lds[i]) = m;
+        *reinterpret_cast<bf16x4b*>(s_go + 2 * kXPos * gop + g_lds[i]) = l;
+      }
+#pragma unroll
+    for (int i = 0; i < kPaVec; i++)
+      if (p_yx[i] >= 0) *reinterpret_cast<f32x4b*>(s_patch + p_lds[i]) = pvv[i];
+  };
+
+  int tile = slice;
+  if (tile < ntiles) issue(cur);
+  for (; tile < ntiles; tile += ksplit) {
+    const int b = cur.b, ty0 = cur.ty * kFTH, tx0 = cur.tx * kFTW;
+    const int oy = ty0 - 3, ox = tx0 - 3;
+    __syncthreads();                             // the previous tile's operands have been read
+    land();
+    if (tid < 3 * kXPos) {                       // sampling table of this tile's three taps
+      const int tl = tid / kXPos, pos = tid % kXPos;
+      const int y = ty0 + (pos >> 3), xq = tx0 + (pos & 7);
+      XTap tp;
+      tp.y = 0; tp.x = 0; tp.flags = 0u; tp.pad[0] = 0u; tp.pad[1] = 0u;
+      for (int k = 0; k < 4; k++) tp.w[k] = 0.f;
+      if (y < H && xq < W) {
+        const float h_im = (float)(y - 1 + ky) + off_y_raw, w_im = (float)(xq - 1 + tl) + off_x_raw;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+          const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+          tp.w[0] = (t_ok && l_ok) ? hh * hw : 0.f;
+          tp.w[1] = (t_ok && r_ok) ? hh * lw : 0.f;
+          tp.w[2] = (b_ok && l_ok) ? lh * hw : 0.f;
+          tp.w[3] = (b_ok && r_ok) ? lh * lw : 0.f;
+          tp.y = (short)h_low;
+          tp.x = (short)w_low;
+          const bool in = h_low >= oy && h_low + 1 <= oy + kFPH - 1 && w_low >= ox && w_low + 1 <= ox + kFPW - 1;
+          const int py = min(max(h_low - oy, 0), kFPH - 2), px = min(max(w_low - ox, 0), kFPW - 2);
+          tp.flags = 1u | (in ? 2u : 0u) | ((unsigned)(py * kFPW + px) << 2);
+        }
+      }
+      s_tab[tid] = tp;
+    }
+    __syncthreads();
+    if (tile + ksplit < ntiles) {                // next tile's loads: in flight under the blend and the MFMAs
+      advance(cur);
+      issue(cur);
+    }
+    // ---- column tiles of the three taps, blended in f32 (im2col_bilinear, kernel.cu:83-114: v1..v4 weighted in this order)
+    // and split into the three planes: item = (tap, position, 8-channel group), 768 items.  (1 536 items of four channels, three
+    // per thread, balance the trips but measured 1 023 -> 1 062 us: twice the table reads and address arithmetic.)
+#pragma unroll
+    for (int trip = 0; trip < 2; trip++) {
+      const int it = tid + 512 * trip;
+      if (it >= 3 * kXPos * 8) continue;
+      const int tl = it >> 8, r = it & 255, pos = r >> 3, q = r & 7;
+      const XTap tp = s_tab[tl * kXPos + pos];
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v8[j] = 0.f;
+      // (as in the f16 kernel: the memory path of a sample that left the window must not share a join with the LDS path)
+      if (!__any((tp.flags & 3u) == 1u)) {
+        const char* p0 = s_patch + (int)(tp.flags >> 2) * kXPatRow + q * 32;
+#pragma unroll
+        for (int hv = 0; hv < 2; hv++) {
+          const f32x4b c0 = *reinterpret_cast<const f32x4b*>(p0 + hv * 16), c1 = *reinterpret_cast<const f32x4b*>(p0 + kXPatRow + hv * 16);
+          const f32x4b c2 = *reinterpret_cast<const f32x4b*>(p0 + kFPW * kXPatRow + hv * 16);
+          const f32x4b c3 = *reinterpret_cast<const f32x4b*>(p0 + kFPW * kXPatRow + kXPatRow + hv * 16);
+#pragma unroll
+          for (int j = 0; j < 4; j++) v8[hv * 4 + j] = tp.w[0] * c0[j] + tp.w[1] * c1[j] + tp.w[2] * c2[j] + tp.w[3] * c3[j];
+        }
+      } else if (tp.flags & 1u) {
+        f32x4b c4[4][2];
+        if (tp.flags & 2u) {
+          const char* p0 = s_patch + (int)(tp.flags >> 2) * kXPatRow + q * 32;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int hv = 0; hv < 2; hv++)
+              c4[k][hv] = *reinterpret_cast<const f32x4b*>(p0 + (k >> 1) * kFPW * kXPatRow + (k & 1) * kXPatRow + hv * 16);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int yy = min(max((int)tp.y + (k >> 1), 0), H - 1), xx = min(max((int)tp.x + (k & 1), 0), W - 1);
+            const float* gp = x + ((int64_t)b * HW + (int64_t)yy * W + xx) * C + cc * 64 + q * 8;
+            c4[k][0] = *reinterpret_cast<const f32x4b*>(gp);
+            c4[k][1] = *reinterpret_cast<const f32x4b*>(gp + 4);
+          }
+        }
+#pragma unroll
+        for (int hv = 0; hv < 2; hv++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            v8[hv * 4 + j] = tp.w[0] * c4[0][hv][j] + tp.w[1] * c4[1][hv][j] + tp.w[2] * c4[2][hv][j] + tp.w[3] * c4[3][hv][j];
+      }
+      bf16x8b h, m, l;
+#pragma unroll
+      for (int j = 0; j < 8; j++) { __bf16 a, b2, c; split3(v8[j], a, b2, c); h[j] = a; m[j] = b2; l[j] = c; }
+      char* dst = s_col + (tl * kXPos + pos) * kXColRow + q * 16;
+      *reinterpret_cast<bf16x8b*>(dst) = h;
+      *reinterpret_cast<bf16x8b*>(dst + 3 * kXPos * kXColRow) = m;
+      *reinterpret_cast<bf16x8b*>(dst + 6 * kXPos * kXColRow) = l;
+    }
+    __syncthreads();
+    // ---- gradW tiles += gradOutput^T . columns over the 32 positions, six plane products per tile; both operands by
+    // transposing reads (lane maps: k_dcn_bwd_weight)
+    if (mwave) {
+      const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+      const char* a_base = s_go + (8 * (g >> 1) + qq) * gop + (wave * 32 + 16 * (g & 1) + 4 * pp) * 2;
+      const char* b_base = s_col + (8 * (g >> 1) + qq) * kXColRow + (16 * (g & 1) + 4 * pp) * 2;
+#pragma unroll
+      for (int ks = 0; ks < kXPos / 16; ks++) {
+        auto tr = [&](const char* p) {
+          return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4b*)p);
+        };
+        auto frag = [&](const char* p, int pitch) {
+          const s16x4b lo = tr(p + (ks * 16) * pitch), hi = tr(p + (ks * 16 + 4) * pitch);
+          const __attribute__((ext_vector_type(8))) short v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          return __builtin_bit_cast(bf16x8b, v);
+        };
+        bf16x8b A[3];
+#pragma unroll
+        for (int pa = 0; pa < 3; pa++) A[pa] = frag(a_base + pa * kXPos * gop, gop);
+#pragma unroll
+        for (int tl = 0; tl < 3; tl++)
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++) {
+            bf16x8b Bf[3];
+#pragma unroll
+            for (int pb = 0; pb < 3; pb++) Bf[pb] = frag(b_base + (pb * 3 + tl) * kXPos * kXColRow + ct * 64, kXColRow);
+            // small terms first
+            acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bf[0], acc[tl][ct], 0, 0, 0);
+            acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bf[2], acc[tl][ct], 0, 0, 0);
+            acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bf[1], acc[tl][ct], 0, 0, 0);
+            acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bf[0], acc[tl][ct], 0, 0, 0);
+            acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bf[1], acc[tl][ct], 0, 0, 0);
+            acc[tl][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bf[0], acc[tl][ct], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // ---- results: rows = out channels (4 consecutive per register quad), columns = channels of the chunk; one block per workgroup
+  if (mwave) {
+    float* part = partial + (int64_t)blockIdx.x * O * 192;      // (blockIdx = slice * owners + owner)
+#pragma unroll
+    for (int tl = 0; tl < 3; tl++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int o = wave * 32 + 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5);
+          part[(o * 3 + tl) * 64 + ct * 32 + (lane & 31)] = acc[tl][ct][r];
+        }
+  }
+}
+
 // gradWeight += scale * (sum over the position slices of the workgroups' partial results).  The fused weight-gradient kernels
 // used to add their 3 x [O x 64] register tiles into gradWeight with f32 atomics: 12.4 M lane atomics per call, 36 bytes apart
 // (nine taps between two channels), 21 slices contending for every address -- 2.3 k cycles per tile of the f32 kernel, ~0.2 ms
@@ -2009,10 +2297,20 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
       const int64_t tiles = B * ((H + kFTH - 1) / kFTH) * ((W + kFTW - 1) / kFTW);
       S2A_CHECK_ARG(tiles < (1ll << 31), "%s: too many tiles", who);
       ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::min(n_cu, kWgradMaxBlocks) / owners));
-      const int lds = wgrad_f32_lds_bytes();
-      S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      k_dcn_bwd_weight_f32<<<(unsigned)((owners * ksplit + 7) / 8 * 8), kFWThreads, lds, st>>>(xn, gn, (const float*)a.offset, partial, (int)B,
-                                                                                             (int)C, (int)H, (int)W, (int)O, ksplit);
+      // default: the f32 tensors as three bf16 planes on the 16-bit matrix instruction (k_dcn_bwd_weight_x3); S2A_BWD_F32_WEIGHT=mfma32:
+      // the f32 instruction's kernel
+      const char* wsel = std::getenv("S2A_BWD_F32_WEIGHT");
+      if (wsel && wsel[0] == 'm') {
+        const int lds = wgrad_f32_lds_bytes();
+        S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        k_dcn_bwd_weight_f32<<<(unsigned)((owners * ksplit + 7) / 8 * 8), kFWThreads, lds, st>>>(xn, gn, (const float*)a.offset, partial, (int)B,
+                                                                                               (int)C, (int)H, (int)W, (int)O, ksplit);
+      } else {
+        const int lds = wgrad_x3_lds_bytes((int)O);
+        S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcn_bwd_weight_x3), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        k_dcn_bwd_weight_x3<<<(unsigned)(owners * ksplit), 512, lds, st>>>(xn, gn, (const float*)a.offset, partial, (int)B, (int)C, (int)H,
+                                                                         (int)W, (int)O, ksplit);
+      }
     }
     const int64_t nout = O * C * 9;
     k_dcn_bwd_weight_reduce<<<(unsigned)((nout + 255) / 256), 256, 0, st>>>(partial, a.grad_weight, a.scale, (int)O, (int)C, ksplit);

@@ -1848,27 +1848,40 @@ def test_dcn_backward_weight_fused_f16_vs_oracle(rng, monkeypatch):
 
 def test_dcn_backward_weight_fused_f32_vs_oracle(rng, monkeypatch):
     """the fused f32 weight gradient (s2a_deform_conv_backward_weight_f32: columns formed in LDS, contracted over the
-    positions on v_mfma_f32_16x16x4_f32, partial blocks + deterministic reduce into the caller's gradWeight, scaled) against the oracle
+    positions on the matrix cores, partial blocks + deterministic reduce into the caller's gradWeight, scaled) against the oracle
     (deform_conv_cuda.cpp:376-489 restated) within the north_star's 1e-4 and against the unfused path: tame and wild
-    offsets, ragged images, one and two channel chunks, fewer out channels than waves, scale, a non-zero gradWeight"""
+    offsets, ragged images, one and two channel chunks, fewer out channels than waves, scale, a non-zero gradWeight.
+    Both fused kernels: the default (round 6: the f32 tensors as three bf16 planes, six 16-bit products per f32 product --
+    k_dcn_bwd_weight_x3) and the f32 matrix instruction's (S2A_BWD_F32_WEIGHT=mfma32); the two agree to ~1e-6 of the largest
+    entry, two orders inside the bound, and each is bit-identical from call to call"""
     from s2anet_amd.dcn import deform_conv_backward_parameters_cuda
     for (B, C, H, W, O, amp, scale) in ((2, 64, 19, 45, 32, 0.7, 1.0), (1, 128, 9, 20, 64, 5.0, 0.5), (3, 64, 8, 16, 256, 2.0, 1.0)):
         xn = rng.standard_normal((B, C, H, W)).astype(np.float32)
         on = (rng.standard_normal((B, 18, H, W)) * amp).astype(np.float32)
         gn = (rng.standard_normal((B, O, H, W)) * 0.5).astype(np.float32)
+        if O == 256:
+            gn[0, :, 2, 3] *= 1e-3          # magnitudes spread over many binades: the split must carry small and large values alike
+            xn[0, ::7] *= 300.0
         base = rng.standard_normal((O, C, 3, 3)).astype(np.float32)
         _, _, gw = oracle.deform_conv_backward(xn, on, np.zeros((O, C, 3, 3), np.float32), gn)
         gw = gw * scale
-        for mode in ("fused", "unfused"):
+        got = {}
+        for mode in ("fused", "fused-again", "fused-mfma32", "unfused"):
+            monkeypatch.delenv("S2A_DCN_BWD_UNFUSED", raising=False)
+            monkeypatch.delenv("S2A_BWD_F32_WEIGHT", raising=False)
             if mode == "unfused":
                 monkeypatch.setenv("S2A_DCN_BWD_UNFUSED", "1")
-            else:
-                monkeypatch.delenv("S2A_DCN_BWD_UNFUSED", raising=False)
+            if mode == "fused-mfma32":
+                monkeypatch.setenv("S2A_BWD_F32_WEIGHT", "mfma32")
             gwt = cu(base).clone()
             assert deform_conv_backward_parameters_cuda(cu(xn), cu(on), cu(gn), gwt, None, None, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1,
                                                         scale, B) == 1
-            err = np.abs(gwt.cpu().numpy() - base - gw).max()
+            got[mode] = gwt.cpu().numpy() - base
+            err = np.abs(got[mode] - gw).max()
             assert err < 1e-4 * max(1.0, np.abs(gw).max()), (mode, (B, C, H, W, O), err, np.abs(gw).max())
+        assert np.array_equal(got["fused"], got["fused-again"])
+        d = np.abs(got["fused"] - got["fused-mfma32"]).max()
+        assert d < 1e-5 * max(1.0, np.abs(gw).max()), (d, np.abs(gw).max())
         assert np.abs(gw).max() > 1.0
 
 
