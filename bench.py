@@ -438,7 +438,9 @@ def measure_ops(dev, with_cpu=True):
                 "GFLOP_each": round(flop / 1e9, 1),
                 "mfma_frac_one_call": round(2 * flop / t_both / 1e12 / (PEAK_F16_TFLOPS if dt == torch.float16 else PEAK_F32_TFLOPS), 4),
                 "note": "fused kernels, no columns tensor, weight gradient without atomics (host-side tensor conversions included); "
-                        "one call = what DeformConvFunction.backward runs"}
+                        "one call = what DeformConvFunction.backward runs"
+                        + ("" if dt == torch.float16 else "; mfma_frac is of the f32 matrix instruction's peak: the column gradient runs on it, "
+                           "the weight gradient on six bf16 products per f32 product (k_dcn_bwd_weight_x3)")}
             del xb, offb, gob, gi, goff, gw
         except Exception as e:          # a report, never a reason to lose the line
             ops[key] = {"failed": repr(e)}

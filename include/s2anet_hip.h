@@ -417,9 +417,12 @@ int s2a_deform_conv_backward_weight_f16(const void* input, const void* offset, c
                                         int64_t width, int64_t out_channels, void* workspace, size_t workspace_bytes,
                                         s2a_stream_t stream);
 
-/* The same entry for f32 tensors (same geometry limits; v_mfma_f32_16x16x4_f32, 4 x 8 position tiles, loader waves beside the
- * MFMA waves): grad_weight [O,C,3,3] f32 is the caller's gradWeight, += scale * gradOutput x columns^T in place
- * (deform_conv_cuda.cpp:455-459); deterministic as above. */
+/* The same entry for f32 tensors (same geometry limits, 4 x 8 position tiles): grad_weight [O,C,3,3] f32 is the caller's
+ * gradWeight, += scale * gradOutput x columns^T in place (deform_conv_cuda.cpp:455-459); deterministic as above.
+ * Arithmetic: every f32 operand is split EXACTLY into three bf16 values (8 + 8 + 8 significand bits) and a product is the six
+ * largest of the nine plane products, accumulated in f32 on the 16-bit matrix instruction -- the accuracy of f32 arithmetic
+ * (|error| of a product <~ 3 * 2^-24 of it; the bilinear blend itself runs in f32), 2.7 x fewer matrix cycles than
+ * v_mfma_f32_16x16x4_f32.  The environment switch S2A_BWD_F32_WEIGHT=mfma32 selects the kernel on the f32 instruction. */
 size_t s2a_deform_conv_backward_weight_f32_workspace_bytes(int64_t batch, int64_t channels, int64_t height, int64_t width,
                                                            int64_t out_channels);
 int s2a_deform_conv_backward_weight_f32(const float* input, const float* offset, const float* grad_output,
