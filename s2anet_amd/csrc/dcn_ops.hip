@@ -2042,6 +2042,234 @@ inline int device_cu_count(int* out) {
   return S2A_OK;
 }
 
+// ------------------------------------------------------------------ f32 AlignConv / deformable conv on the 16-bit matrix instruction
+// The f32 matrix instruction runs at 1/16 of the 16-bit rate (k_dcn_mfma<float>: 0.55 of ITS peak = 225 us for one
+// [1,256,128,128] level).  An f32 value is EXACTLY the sum of three bf16 values (hi = rne(x), mid = rne(x - hi), lo = rne(x - hi -
+// mid): 8 + 8 + 8 significand bits), and a product without its three smallest cross terms is six bf16 products accumulated
+// in f32 (|error| <~ 3 * 2^-24 of the product: one f32 rounding) -- six v_mfma_f32_32x32x16_bf16 for eight 32x32x2 f32 ones of
+// a quarter their length.  k_dcn_x3 is k_dcn_mfma's dataflow with that arithmetic: per stage (tap, 16 input channels) the
+// four bilinear corners of every position are gathered from the NHWC input, blended in f32 (im2col_bilinear's order) and
+// written to LDS as three bf16 planes; the filter was split into its planes when it was packed (k_pack_weight_x3); the waves
+// read both operands with ds_read_b128 (48-byte rows: conflict-free) and run 6 MFMAs per output tile and stage.
+// S2A_DCN_F32=mfma32 selects the f32 instruction's kernel (A/B, and the tests' cross-check).
+constexpr int kX3KC = 16;                       // input channels per stage = one k-step of 32x32x16
+constexpr int kX3Row = 48;                      // bytes per LDS row: 16 bf16 + 16 B pad (12 dwords: sixteen rows start in sixteen 4-bank groups)
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+template <int NPOS>
+constexpr int x3_lds_bytes() { return NPOS * 9 * 32 + 2 * 3 * (kMaxO + NPOS) * kX3Row; }      // 110 592 / 147 456
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  mid = (__bf16)r1;
+  lo = (__bf16)(r1 - (float)mid);
+}
+// weight [O][C][9] f32 -> [stage s = (c / 16) * 9 + tap][plane][O][16] bf16
+__global__ void k_pack_weight_x3(const float* __restrict__ w, int O, int C, __bf16* __restrict__ wp) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)O * C * 9) return;
+  const int t = (int)(e % 9);
+  const int64_t oc = e / 9;
+  const int c = (int)(oc % C), o = (int)(oc / C);
+  const int64_t st = (int64_t)(c / kX3KC) * 9 + t;
+  __bf16 h, m, l;
+  split3(w[e], h, m, l);
+  const int64_t base = (st * 3 * O + o) * kX3KC + (c % kX3KC), plane = (int64_t)O * kX3KC;
+  wp[base] = h;
+  wp[base + plane] = m;
+  wp[base + 2 * plane] = l;
+}
+
+template <bool OUT_NHWC, int SRC, int NPOS>
+__global__ __launch_bounds__(512, 1) void k_dcn_x3(const float* __restrict__ x,       // NHWC
+                                                   const float* __restrict__ src,     // offsets | anchors
+                                                   const __bf16* __restrict__ wp,     // k_pack_weight_x3
+                                                   float* __restrict__ out, int64_t Ntot, int C, int H,
+                                                   int W, int O, float stride, int relu) {
+  // eight waves, two per SIMD (one wave's blend / split / requests run under the other's MFMAs): wave = (64-out-channel group
+  // wave & 3, position half wave >> 2)
+  constexpr int NT = NPOS / 64;        // 32-wide position tiles per wave
+  constexpr int kItems = NPOS * 4;     // (position, 4-channel group) items per stage: one per thread (NPOS 64: threads 0-255)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [ taps NPOS*9*32 B | A0 (3 planes) | B0 (3 planes) | A1 | B1 ]
+  Tap* s_tab = reinterpret_cast<Tap*>(smem);
+  constexpr int kTabBytes = NPOS * 9 * 32;
+  constexpr int kAPlane = kMaxO * kX3Row, kBPlane = NPOS * kX3Row;
+  constexpr int kBufBytes = 3 * (kAPlane + kBPlane);
+  char* s_buf = smem + kTabBytes;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, phalf = tid >> 8;
+  const int64_t HW = (int64_t)H * W;
+  const int64_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int o0 = blockIdx.y * kMaxO;
+  const int Oloc = min(kMaxO, O - o0);
+  const int CC = C / kX3KC;
+  const int nstage = 9 * CC;
+
+  // ---- sampling table for this tile (as k_dcn_mfma)
+  for (int e = tid; e < NPOS * 9; e += 512) {
+    int pl = e / 9, t = e % 9;
+    int64_t g = tile_pos(tile, pl, NPOS / 16, H, W, HW, Ntot);
+    Tap tp;
+    if (g >= 0) {
+      int64_t b = g / HW, p = g % HW;
+      int y = (int)(p / W), xq = (int)(p % W);
+      int ky = t / 3, kx = t % 3;
+      float off_y, off_x;
+      if (SRC == 0) {
+        const float* ob = src + (b * 18) * HW + p;
+        off_y = ob[(int64_t)(2 * t) * HW];
+        off_x = ob[(int64_t)(2 * t + 1) * HW];
+      } else {
+        AnchorCtx c = anchor_ctx(src + g * 5, stride);
+        anchor_offset(c, ky, kx, (float)y, (float)xq, off_y, off_x);
+      }
+      float h_im = (float)(y - 1 + ky) + off_y;  // kernel.cu:226-227
+      float w_im = (float)(xq - 1 + kx) + off_x;
+      tp = make_tap(h_im, w_im, H, W, b * HW);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        tp.idx[k] = 0;
+        tp.w[k] = 0.f;
+      }
+    }
+    s_tab[e] = tp;
+  }
+  __syncthreads();
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  // per-thread staging registers, TWO sets: one wave per SIMD runs a stage's 24-48 MFMAs in 0.8-1.5 k cycles, less than an L2
+  // round trip under load, so a stage's requests go out TWO stages ahead (one stage ahead: 202 us for one [1,256,128,128]
+  // level against 227 on the f32 instruction; the matrix work is 46 us)
+  struct Stage {
+    f32x4 cv[4];
+    float cw[4];
+    bf16x8 av[3];                      // 3 planes x 256 rows x two 16-byte halves = 1 536 vectors
+  };
+  Stage ra, rb;
+
+  auto issue = [&](int s, Stage& r_) {
+    const int t = s % 9, cc = s / 9;
+    if (tid < kItems) {
+      const int pl = tid >> 2, q = tid & 3;
+      const Tap tp = s_tab[pl * 9 + t];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        r_.cw[k] = tp.w[k];
+        r_.cv[k] = *reinterpret_cast<const f32x4*>(x + (int64_t)tp.idx[k] * C + cc * kX3KC + q * 4);
+      }
+    }
+    const __bf16* wsrc = wp + (int64_t)s * 3 * O * kX3KC;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      int idx = tid + 512 * r;
+      int plane = idx >> 9, row = (idx & 511) >> 1, q = idx & 1;
+      if (row < Oloc) r_.av[r] = *reinterpret_cast<const bf16x8*>(wsrc + ((int64_t)plane * O + o0 + row) * kX3KC + q * 8);
+    }
+  };
+  auto commit = [&](int buf, const Stage& r_) {
+    char* A = s_buf + buf * kBufBytes;
+    char* Bm = A + 3 * kAPlane;
+    if (tid < kItems) {
+      const int pl = tid >> 2, q = tid & 3;
+      const f32x4 v = blend<float>(r_.cv, r_.cw);
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { __bf16 a, b2, c; split3(v[j], a, b2, c); h[j] = a; m[j] = b2; l[j] = c; }
+      char* d = Bm + pl * kX3Row + q * 8;
+      *reinterpret_cast<bf16x4*>(d) = h;
+      *reinterpret_cast<bf16x4*>(d + kBPlane) = m;
+      *reinterpret_cast<bf16x4*>(d + 2 * kBPlane) = l;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      int idx = tid + 512 * r;
+      int plane = idx >> 9, row = (idx & 511) >> 1, q = idx & 1;
+      if (row < Oloc) *reinterpret_cast<bf16x8*>(A + plane * kAPlane + row * kX3Row + q * 16) = r_.av[r];
+    }
+  };
+
+  const bool wave_active = wave * 64 < Oloc;
+  auto mfma_stage = [&](int buf) {
+    if (!wave_active) return;
+    const char* A = s_buf + buf * kBufBytes;
+    const char* Bm = A + 3 * kAPlane;
+    const char* wrow = A + (wave * 64 + (lane & 31)) * kX3Row + (lane >> 5) * 16;
+    const char* prow = Bm + (phalf * NT * 32 + (lane & 31)) * kX3Row + (lane >> 5) * 16;
+    bf16x8 wf[3][2], pf[3][NT];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) wf[p][h] = *reinterpret_cast<const bf16x8*>(wrow + p * kAPlane + h * 32 * kX3Row);
+#pragma unroll
+      for (int h = 0; h < NT; h++) pf[p][h] = *reinterpret_cast<const bf16x8*>(prow + p * kBPlane + h * 32 * kX3Row);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++) {
+        // (filter plane, column plane): the three small terms first
+        constexpr int kPw[6] = {2, 0, 1, 1, 0, 0}, kPp[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          if constexpr (OUT_NHWC)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[kPp[k]][b], wf[kPw[k]][a], acc[a][b], 0, 0, 0);
+          else
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kPw[k]][a], pf[kPp[k]][b], acc[a][b], 0, 0, 0);
+        }
+      }
+  };
+  // stage s: requests of stage s + 2 (into the set stage s used), MFMAs of stage s, operands of stage s + 1 into the other buffer
+  auto step = [&](int s, Stage& r_issue, const Stage& r_commit) {
+    if (s + 2 < nstage) issue(s + 2, r_issue);
+    mfma_stage(s & 1);
+    if (s + 1 < nstage) commit((s + 1) & 1, r_commit);
+    __syncthreads();
+  };
+  issue(0, ra);
+  if (nstage > 1) issue(1, rb);
+  commit(0, ra);
+  __syncthreads();
+  for (int s = 0; s < nstage; s += 2) {
+    step(s, ra, rb);
+    if (s + 1 < nstage) step(s + 1, rb, ra);
+  }
+
+  if (!wave_active) return;
+  // ---- epilogue: ReLU + store.  acc[a][b] = (out-channel tile a, position tile b);
+  // MFMA D layout: column = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float v = acc[a][b][r];
+        if (relu) v = fmaxf(v, 0.f);
+        int rowi = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if constexpr (OUT_NHWC) {
+          int64_t g = tile_pos(tile, 32 * (phalf * NT + b) + rowi, NPOS / 16, H, W, HW, Ntot);
+          int och = o0 + wave * 64 + 32 * a + (lane & 31);
+          if (g >= 0) out[g * O + och] = v;
+        } else {
+          int och = o0 + wave * 64 + 32 * a + rowi;
+          int64_t g = tile_pos(tile, 32 * (phalf * NT + b) + (lane & 31), NPOS / 16, H, W, HW, Ntot);
+          if (g >= 0) {
+            int64_t bi = g / HW, p = g % HW;
+            out[(bi * O + och) * HW + p] = v;
+          }
+        }
+      }
+}
+
 template <int NPOS>
 constexpr int mfma_lds_bytes() { return NPOS * 9 * 32 + 2 * (kMaxO + NPOS) * kRowBytes; }  // 110592 / 147456
 
@@ -2140,6 +2368,33 @@ int launch_fast(const T* x_nhwc, const float* src, bool from_anchors, const T* w
   // 128-position tiles once they still give every CU >= 2 workgroups; else 64
   auto ntiles = [&](int npos) { return B * (int64_t)((W + 15) / 16) * ((H + npos / 16 - 1) / (npos / 16)); };
   const bool big = ntiles(128) >= 512;
+  if constexpr (sizeof(T) == 4) {
+    // f32: the three-bf16-plane kernel (its filter planes sit behind the f32 stage layout in the packed buffer) unless
+    // S2A_DCN_F32=mfma32 asks for the f32 matrix instruction
+    const char* sel = getenv("S2A_DCN_F32");
+    if (!(sel && sel[0] == 'm')) {
+      const __bf16* wx3 = reinterpret_cast<const __bf16*>(wp + (size_t)O * C * 9);
+#define S2A_DCN_LAUNCH_X3(NHWC, SRC, NPOS)                                                        \
+      do {                                                                                        \
+        auto kern = k_dcn_x3<NHWC, SRC, NPOS>;                                                    \
+        constexpr int lds = x3_lds_bytes<NPOS>();                                                 \
+        dim3 grid((unsigned)ntiles(NPOS), (unsigned)((O + kMaxO - 1) / kMaxO));                   \
+        S2A_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));            \
+        kern<<<grid, 512, lds, st>>>(x_nhwc, src, wx3, out, Ntot, C, H, W, O, stride, relu);      \
+      } while (0)
+#define S2A_DCN_PICK_X3(NHWC, SRC) do { if (big) S2A_DCN_LAUNCH_X3(NHWC, SRC, 128); else S2A_DCN_LAUNCH_X3(NHWC, SRC, 64); } while (0)
+      if (out_nhwc) {
+        if (from_anchors) S2A_DCN_PICK_X3(true, 1); else S2A_DCN_PICK_X3(true, 0);
+      } else {
+        if (from_anchors) S2A_DCN_PICK_X3(false, 1); else S2A_DCN_PICK_X3(false, 0);
+      }
+#undef S2A_DCN_PICK_X3
+#undef S2A_DCN_LAUNCH_X3
+      S2A_LAUNCH_CHECK();
+      return S2A_OK;
+    }
+  }
 #define S2A_DCN_LAUNCH(NHWC, SRC, NPOS)                                                           \
   do {                                                                                            \
     auto kern = k_dcn_mfma<T, NHWC, SRC, NPOS>;                                                   \
@@ -2232,8 +2487,8 @@ int run_fast(const void* input, const float* src, bool from_anchors, const void*
                 ((uintptr_t)ws % 16) == 0, "deform_conv: tensors must be 16-byte aligned");
   Carver cv(ws, ws_bytes);
   const size_t wel = (size_t)O * C * 9;
-  const bool has_frag = sizeof(T) == 2;             // f16 packs both layouts back to back
-  T* wp = weight_packed ? const_cast<T*>((const T*)weight) : cv.take<T>(wel * (has_frag ? 2 : 1));
+  const bool has_frag = sizeof(T) == 2;             // f16 packs both layouts back to back; f32: the stage layout, then the three bf16 planes
+  T* wp = weight_packed ? const_cast<T*>((const T*)weight) : cv.take<T>(has_frag ? wel * 2 : wel * 5 / 2);
   T* xn = nullptr;
   if (layout == S2A_LAYOUT_NCHW) xn = cv.take<T>((size_t)B * C * H * W);
   if (!wp || (layout == S2A_LAYOUT_NCHW && !xn)) {
@@ -2245,6 +2500,8 @@ int run_fast(const void* input, const float* src, bool from_anchors, const void*
     k_pack_weight<T><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const T*)weight, O, C, KC, wp);
     if constexpr (sizeof(T) == 2) {
       k_pack_weight_frag16<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, O, C, wp + wel);
+    } else {
+      k_pack_weight_x3<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const float*)weight, O, C, reinterpret_cast<__bf16*>(wp + wel));
     }
   }
   const T* wfrag = has_frag ? wp + wel : nullptr;
@@ -2267,7 +2524,7 @@ using namespace s2a;
 extern "C" size_t s2a_deform_conv_workspace_bytes(const s2a_dcn_params* p) {
   if (!p) return 0;
   size_t es = esize(p->dtype);
-  size_t b = align_up((size_t)p->out_channels * p->channels * p->kH * p->kW * es * 2) + 256;
+  size_t b = align_up((size_t)p->out_channels * p->channels * p->kH * p->kW * es * 3) + 256;      // packed filter: f16 two layouts, f32 2.5 x
   if (p->layout == S2A_LAYOUT_NCHW) b += align_up((size_t)p->batch * p->channels * p->height * p->width * es);
   return b;
 }
@@ -2353,7 +2610,7 @@ extern "C" int s2a_modulated_deform_conv_forward(const void* input, const void* 
 extern "C" size_t s2a_align_conv_workspace_bytes(const s2a_align_params* p) {
   if (!p) return 0;
   size_t es = esize(p->dtype);
-  size_t b = align_up((size_t)p->out_channels * p->channels * 9 * es * 2) + 256;
+  size_t b = align_up((size_t)p->out_channels * p->channels * 9 * es * 3) + 256;      // packed filter: f16 two layouts, f32 2.5 x
   if (p->layout == S2A_LAYOUT_NCHW) b += align_up((size_t)p->batch * p->channels * p->height * p->width * es);
   return b;
 }
@@ -2393,6 +2650,8 @@ extern "C" int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int
   hipStream_t st = as_stream(stream);
   if (dtype == S2A_DTYPE_F32) {
     k_pack_weight<float><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const float*)weight, (int)out_channels, (int)channels, kc, (float*)packed);
+    k_pack_weight_x3<<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const float*)weight, (int)out_channels, (int)channels,
+                                                                    reinterpret_cast<__bf16*>((float*)packed + wtot));
   } else {
     S2A_CHECK_ARG(out_channels % 64 == 0, "dcn_pack_weight: out_channels must be a multiple of 64");
     k_pack_weight<_Float16><<<(unsigned)((wtot + 255) / 256), 256, 0, st>>>((const _Float16*)weight, (int)out_channels, (int)channels, kc, (_Float16*)packed);
@@ -2403,8 +2662,10 @@ extern "C" int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int
 }
 
 extern "C" int64_t s2a_dcn_packed_elems(int64_t out_channels, int64_t channels, int dtype) {
-  // f16 holds two layouts back to back (stage-major for the LDS-staged kernels, MFMA-fragment order for the patch-staged kernel)
-  return out_channels * channels * 9 * (dtype == S2A_DTYPE_F16 ? 2 : 1);
+  // f16 holds two layouts back to back (stage-major for the LDS-staged kernels, MFMA-fragment order for the patch-staged kernel);
+  // f32: the stage-major f32 layout, then the filter's three bf16 planes (k_dcn_x3): 1 + 1.5 elements per weight
+  const int64_t wel = out_channels * channels * 9;
+  return dtype == S2A_DTYPE_F16 ? wel * 2 : wel * 5 / 2;
 }
 
 namespace s2a {
