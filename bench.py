@@ -353,9 +353,16 @@ def measure_ops(dev, with_cpu=True):
         x = x32.to(dev, dt).contiguous(memory_format=torch.channels_last)
         wp = pack_weight(w32.to(dev, dt), dt)
         sec = _time_launches(lambda: align_conv_forward(x, anc, wp, 8, relu=True, packed=True, out_channels=O), iters=50)
-        ops["alignconv_1x256x128x128_" + name] = {
-            "us": round(sec * 1e6, 1), "TFLOPs": round(flops / sec / 1e12, 1), "bound": "mfma",
-            "mfma_frac": round(flops / sec / 1e12 / peak, 4), "peak_TFLOPs": peak}
+        row = {"us": round(sec * 1e6, 1), "TFLOPs": round(flops / sec / 1e12, 1), "bound": "mfma",
+               "mfma_frac": round(flops / sec / 1e12 / peak, 4), "peak_TFLOPs": peak}
+        if name == "f32" and not os.environ.get("S2A_DCN_F32", "").startswith("m"):
+            # the f32 forward runs on the 16-bit matrix instruction: every f32 product = six bf16 products (k_dcn_x3)
+            row["peak_TFLOPs"] = round(PEAK_F16_TFLOPS / 6, 1)
+            row["mfma_frac"] = round(flops / sec / 1e12 / (PEAK_F16_TFLOPS / 6), 4)
+            row["note"] = ("f32 tensors as three bf16 planes: six 16-bit matrix products per f32 product, so the peak is a sixth of the "
+                           "16-bit peak; against the f32 matrix instruction's own peak (%.1f TFLOP/s) the rate is %.2f"
+                           % (PEAK_F32_TFLOPS, flops / sec / 1e12 / PEAK_F32_TFLOPS))
+        ops["alignconv_1x256x128x128_" + name] = row
     # configs[4]
     n, nl = 200000, 15
     d = torch.from_numpy(_ops_inputs_rboxes(rng, n)).to(dev)

@@ -870,15 +870,32 @@ def test_dcn_generic_path_golden():
     assert np.allclose(out, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("kernel", ["x3", "mfma32"])
 @pytest.mark.parametrize("shape", [(1, 64, 13, 17, 64), (2, 256, 16, 16, 256), (1, 32, 8, 8, 128), (3, 64, 5, 7, 320)])
-def test_dcn_mfma_f32_vs_oracle(rng, shape):
+def test_dcn_mfma_f32_vs_oracle(rng, shape, kernel, monkeypatch):
+    """the fused f32 forward against the oracle, both kernels: the default since round 6 (k_dcn_x3: every f32 operand as
+    three bf16 planes, six 16-bit products per f32 product) and the f32 matrix instruction's (S2A_DCN_F32=mfma32); the
+    second parameter value also holds the two against each other an order of magnitude inside the bound, on operands
+    whose magnitudes span many binades"""
     import s2anet_amd as S
+    if kernel == "mfma32":
+        monkeypatch.setenv("S2A_DCN_F32", "mfma32")
+    else:
+        monkeypatch.delenv("S2A_DCN_F32", raising=False)
     B, C, H, W, O = shape
     x, w, off = _dcn_inputs(rng, B, C, H, W, O)
     ref = oracle.deform_conv_forward(x, off, w)
     out = S.deform_conv(cu(x), cu(off), cu(w), 1, 1, 1, 1, 1).cpu().numpy()
     err = np.abs(out - ref).max()
     assert err < 1e-4, err                              # north-star tolerance, f32 path
+    if kernel == "mfma32":
+        xs = x * np.exp2(rng.integers(-12, 12, (1, C, 1, 1))).astype(np.float32)       # channel scales over 24 binades
+        ws = w * np.exp2(-rng.integers(-12, 12, (1, C, 1, 1))).astype(np.float32)      # ... undone by the filter
+        a = S.deform_conv(cu(xs), cu(off), cu(ws), 1, 1, 1, 1, 1).cpu().numpy()
+        monkeypatch.delenv("S2A_DCN_F32", raising=False)
+        b = S.deform_conv(cu(xs), cu(off), cu(ws), 1, 1, 1, 1, 1).cpu().numpy()
+        assert np.abs(a - b).max() < 1e-5 * max(1.0, np.abs(a).max()), (np.abs(a - b).max(), np.abs(a).max())
+        monkeypatch.setenv("S2A_DCN_F32", "mfma32")
     # channels-last storage in and out: same numbers
     xc = cu(x).contiguous(memory_format=torch.channels_last)
     outc = S.deform_conv(xc, cu(off), cu(w), 1, 1, 1, 1, 1)
