@@ -292,7 +292,8 @@ size_t s2a_align_conv_workspace_bytes(const s2a_align_params* p);
 /* weight[O,C,3,3] -> the layouts the fused kernels stream: stage-major [C/KC][9][O][KC]
  * (KC = 32 for f32, 64 for f16) and right behind it, for f16, a second copy in MFMA-fragment order; for f32, the filter split
  * into three bf16 planes, [C/16][9][plane][O][16] (hi + mid + lo = the f32 value exactly: the f32 forward runs on the 16-bit
- * matrix instruction, six plane products per f32 product, S2A_DCN_F32=mfma32 selects the f32 instruction).
+ * matrix instruction, six plane products per f32 product -- the accuracy of f32 arithmetic for finite operands; an infinite
+ * operand gives NaN where f32 arithmetic gives +-inf; S2A_DCN_F32=mfma32 selects the f32 instruction).
  * `packed` must hold s2a_dcn_packed_elems(O, C, dtype) elements (f16: 2 per weight, f32: 2.5 per weight). */
 int64_t s2a_dcn_packed_elems(int64_t out_channels, int64_t channels, int dtype);
 int s2a_dcn_pack_weight(const void* weight, int64_t out_channels, int64_t channels, int dtype,
