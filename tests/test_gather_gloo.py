@@ -65,8 +65,11 @@ def _run_world(target, world, n_items, *args):
     """start `world` gloo ranks of `target` on a fresh port and collect n_items queue entries; a rendezvous that fails because
     the probed port was taken in between (rare, seen once on a busy box) is retried on another port"""
     import queue
+    import time
     last = None
-    for attempt in range(3):
+    for attempt in range(5):
+        if attempt:
+            time.sleep(1.0 + attempt)      # (a busy box: give the previous world's sockets time to close)
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -88,8 +91,8 @@ def _run_world(target, world, n_items, *args):
                 p.terminate()
         if len(got) == n_items and all(p.exitcode == 0 for p in procs):
             return got
-        last = last or "exit codes %s" % [p.exitcode for p in procs]
-    raise AssertionError("gloo world failed three times: %s" % last)
+        last = (last or "") + " attempt %d: %d of %d items, exit codes %s;" % (attempt, len(got), n_items, [p.exitcode for p in procs])
+    raise AssertionError("gloo world failed five times: %s" % last)
 
 
 def test_uneven_shards_are_padded_and_stripped():
