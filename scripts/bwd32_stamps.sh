@@ -10,4 +10,5 @@ if [ "$1" = "f16" ]; then
   exit
 fi
 rm -f s2anet_amd/csrc/dcn_bwd_ops.o; make -C s2anet_amd/csrc -s EXTRA="-DS2A_MEASURE $1" 2>&1 | grep error
-timeout -k 10 200 python scripts/bwd32_stamps.py
+# (the stamps sit in the f32-instruction kernel; since round 6 the default f32 weight gradient is the three-plane kernel)
+S2A_BWD_F32_WEIGHT=mfma32 timeout -k 10 200 python scripts/bwd32_stamps.py
