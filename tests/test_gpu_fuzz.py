@@ -54,6 +54,14 @@ def test_fuzz_dcn_backward_slice():
     _run(fuzz_dcn_backward.bwd_case, 7, 8, max_h=20, max_w=28)
 
 
+def test_fuzz_dcn_f32_forward_slice():
+    """6 random float32 forward calls: the three-bf16-plane kernel (default since round 6) against the oracle (1e-4) and against
+    the f32 matrix instruction's kernel (1e-5 of the largest output); ragged images, 1 ... 10 channel chunks, 64 ... 320 out
+    channels, tame to wild offsets, both storage orders, operands scaled over 20 binades"""
+    from scripts import fuzz_dcn_f32
+    _run(fuzz_dcn_f32.fwd_case, 31, 6, max_h=24, max_w=30)
+
+
 def test_fuzz_assign_labels_and_nms_poly_slice():
     """the two section-8(f) ops rewritten in round 6 (list forms): 10 random assign_labels calls (1 ... 9 000 anchors, 1 ... 1 025
     gts -- both sides of the list form's limit --, exact ties, invalid anchors, both gt_max_assign_all settings, other thresholds)
