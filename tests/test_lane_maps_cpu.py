@@ -84,3 +84,38 @@ def test_wino_dma_slots_cover_the_patch():
 def test_wino_output_slots_are_a_permutation():
     cols = sorted(2 * (s & 15) + ((s >> 4) & 1) for s in range(32))
     assert cols == list(range(32))
+
+
+# ---------------------------------------------------------------- the three-bf16-plane arithmetic of the f32 kernels (round 6)
+def _bf16_rne(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 -- what v_cvt_pk_bf16_f32 does for finite values"""
+    import numpy as np
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def test_three_bf16_planes_are_exact_and_six_products_are_an_f32_product():
+    """k_dcn_x3 / k_dcn_bwd_weight_x3 (csrc/dcn_ops.hip, dcn_bwd_ops.hip: split3): x == hi + mid + lo EXACTLY for finite f32 values
+    away from the underflow range, and the six plane products kept (a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2) differ from the
+    exact product by less than 3 * 2^-24 of it -- the three dropped terms (a2 b3, a3 b2, a3 b3) are below 2^-24 each"""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(200000) * np.exp2(rng.integers(-40, 40, 200000))).astype(np.float32)
+    y = (rng.standard_normal(200000) * np.exp2(rng.integers(-40, 40, 200000))).astype(np.float32)
+
+    def split(v):
+        hi = _bf16_rne(v)
+        r1 = (v - hi).astype(np.float32)              # exact: both are multiples of the same ulp and the difference fits
+        mid = _bf16_rne(r1)
+        lo = _bf16_rne((r1 - mid).astype(np.float32))
+        return hi, mid, lo
+    xh, xm, xl = split(x)
+    yh, ym, yl = split(y)
+    assert np.array_equal((xh.astype(np.float64) + xm.astype(np.float64) + xl.astype(np.float64)), x.astype(np.float64))
+    assert np.array_equal((yh.astype(np.float64) + ym.astype(np.float64) + yl.astype(np.float64)), y.astype(np.float64))
+    f = np.float64
+    six = xh.astype(f) * yh + xh.astype(f) * ym + xm.astype(f) * yh + xh.astype(f) * yl + xl.astype(f) * yh + xm.astype(f) * ym
+    exact = x.astype(f) * y.astype(f)
+    rel = np.abs(six - exact) / np.abs(exact)
+    assert rel.max() < 3 * 2.0 ** -24, rel.max()
