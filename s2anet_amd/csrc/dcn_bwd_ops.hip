@@ -7,9 +7,19 @@
 // (s2anet_amd/dcn.py, mirroring deform_conv_cuda.cpp:262-489) chunks the batch by im2col_step and runs
 // the two plain GEMMs around them on the library, exactly as the reference does with addmm_.
 // Layouts are the reference's: im [S,C,H,W], offset [S, dg*2*kh*kw, Ho, Wo], columns
-// [C*kh*kw, S*Ho*Wo] (row = (c*kh + i)*kw + j, column = (s*Ho + h)*Wo + w).  First version: one thread
-// per element, HBM-bound like the reference's dataflow; the input gradient always accumulates in f32
-// (the reference adds in the storage type, half atomics included).
+// [C*kh*kw, S*Ho*Wo] (row = (c*kh + i)*kw + j, column = (s*Ho + h)*Wo + w).  The input gradient always
+// accumulates in f32 (the reference adds in the storage type, half atomics included).
+// What is in this file:
+//   k_def_im2col / k_def_col2im(_tiled) / k_def_col2im_coord   the three device functions, element per thread, any geometry,
+//                                                               f16 / f32 / f64 (the path beside the library GEMMs)
+//   AlignConv geometry (3x3, stride 1, pad 1, one group), fused, no `columns` tensor:
+//   k_dcn_bwd_input (f16)        column gradient on the matrix cores, consumed in LDS; offset gradient; input gradient as a
+//                                gather, summed into an [S,H,W,C] f32 accumulator in 128-byte atomic rows
+//   k_dcn_bwd_input_f32          the same on the f32 matrix instruction
+//   k_dcn_bwd_weight (f16)       columns formed in LDS, contracted over the positions (transposing LDS reads), split-K + reduce
+//   k_dcn_bwd_weight_x3          f32 tensors as three bf16 planes per operand on the 16-bit matrix instruction (the default)
+//   k_dcn_bwd_weight_f32         the same on the f32 matrix instruction (S2A_BWD_F32_WEIGHT=mfma32)
+//   fused_bwd_run + the extern "C" entry points at the end of the file
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
