@@ -216,20 +216,23 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
         if not direct_off:
             gradOffset.view_as(goff).copy_(goff)
         return 1
-    # accumulator of the scatter: float32 (float32 / float16 columns), float64 for the float64 instantiation
-    gin32 = torch.zeros((B, C, H, W), dtype=torch.float64 if x.dtype == torch.float64 else torch.float32, device=x.device)
     # f16 + AlignConv geometry: ONE fused kernel for the whole batch -- column gradient on the matrix cores, consumed in
     # LDS, no `columns` tensor (s2a_deform_conv_backward_input_f16); the chunking by im2col_step has nothing to chunk then
     if align_geom and x.dtype == torch.float16:
         nbytes = L.s2a_deform_conv_backward_input_workspace_bytes(B, C, H, W, O)
         ws = _lib.workspace(nbytes, x.device, "dcn_bwd")
+        # the library sums in f32 and hands the gradient over rounded to f16 once (s2a_deform_conv_backward_typed without the weight
+        # gradient): the same values as an f32 tensor converted here, without the zero-filled f32 copy and its two passes
+        gin16 = torch.empty((B, C, H, W), dtype=torch.float16, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.s2a_deform_conv_backward_input_f16(_lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(w), _lib.ptr(gin32),
-                                                            _lib.ptr(goff), B, C, H, W, O, _lib.ptr(ws), ws.numel(),
-                                                            _lib.stream_ptr(x.device)))
-        gradInput.view(B, C, H, W).add_(gin32.to(gradInput.dtype))
+            _lib.check(L.s2a_deform_conv_backward_typed(_lib.dtype_code(x), _lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(w),
+                                                        _lib.ptr(gin16), _lib.ptr(goff), None, 1.0, B, C, H, W, O, _lib.ptr(ws),
+                                                        ws.numel(), _lib.stream_ptr(x.device)))
+        gradInput.view(B, C, H, W).add_(gin16.to(gradInput.dtype))
         gradOffset.view_as(goff).copy_(goff)
         return 1
+    # accumulator of the scatter: float32 (float32 / float16 columns), float64 for the float64 instantiation
+    gin32 = torch.zeros((B, C, H, W), dtype=torch.float64 if x.dtype == torch.float64 else torch.float32, device=x.device)
     wg = w.view(group, O // group, -1)                                  # [g, O/g, C/g*kh*kw]
     # (cache-sized chunks as in deform_conv_backward_parameters_cuda measured 5 % SLOWER here, 10.1 -> 10.6 ms at P3 x 8 f32:
     # this path is bound by the scatter's atomics and the coordinate pass, not by where `columns` lives)

@@ -1798,6 +1798,18 @@ def test_dcn_backward_input_fused_f16_vs_oracle(rng, monkeypatch):
             tol_o = (4e-3 if mode == "fused" else 3e-2) * max(1.0, np.abs(goff).max())
             assert np.abs(gi - gx).max() < tol_i, (mode, (B, C, H, W, O), np.abs(gi - gx).max(), np.abs(gx).max())
             assert np.abs(go_ - goff).max() < tol_o, (mode, (B, C, H, W, O), np.abs(go_ - goff).max(), np.abs(goff).max())
+        # the C entry that ACCUMULATES into the caller's f32 tensor (the Python side goes through the typed entry since round 6):
+        # += on a non-zero tensor, same tolerance
+        from s2anet_amd import _lib
+        L = _lib.lib()
+        base = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        acc, goff16 = cu(base).clone(), torch.empty(B, 18, H, W, device=dev(), dtype=torch.float16)
+        ws = _lib.workspace(L.s2a_deform_conv_backward_input_workspace_bytes(B, C, H, W, O), dev(), "dcn_bwd")
+        xt, ot, gt, wt = cu(xn), cu(on), cu(gn), cu(wn)
+        _lib.check(L.s2a_deform_conv_backward_input_f16(_lib.ptr(xt), _lib.ptr(ot), _lib.ptr(gt), _lib.ptr(wt), _lib.ptr(acc),
+                                                        _lib.ptr(goff16), B, C, H, W, O, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev())))
+        assert np.abs(acc.cpu().numpy() - base - gx).max() < 4e-3 * max(1.0, np.abs(gx).max())
+        assert np.abs(goff16.float().cpu().numpy() - goff).max() < 4e-3 * max(1.0, np.abs(goff).max())
         assert np.abs(gx).max() > 0.5 and np.abs(goff).max() > 0.5
 
 
