@@ -74,6 +74,20 @@ int launch_keep_compact(const uint8_t* keep_orig, const int32_t* order, int64_t 
 
 #define S2A_LAUNCH_CHECK() S2A_HIP(hipGetLastError())
 
+#ifdef __HIPCC__
+// f32 tensors on the 16-bit matrix instruction (k_dcn_x3, k_dcn_bwd_weight_x3): x == hi + mid + lo EXACTLY for finite x away
+// from the underflow range -- three round-to-nearest-even bf16 values, 8 + 8 + 8 significand bits (tests/test_lane_maps_cpu.py
+// restates this on the CPU); a product of two such sums without its three smallest cross terms is six bf16 products
+namespace s2a {
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  mid = (__bf16)r1;
+  lo = (__bf16)(r1 - (float)mid);
+}
+}  // namespace s2a
+#endif
+
 // Entry points that still issue hipMemsetAsync / rocprim::select (the drop-in nms_rotated / ml_nms_rotated / nms_poly
 // forms: they return a device count the host usually reads anyway) are NOT graph-safe on ROCm 7.2: they
 // refuse a capturing stream instead of producing a graph that misbehaves on its second replay.  The capturable

@@ -1393,13 +1393,6 @@ __host__ __device__ inline int wgrad_x3_lds_bytes(int O) {
 }
 using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4b = __attribute__((ext_vector_type(4))) __bf16;
-// x = hi + mid + lo exactly (finite x, no underflow of the low parts); each part round-to-nearest-even
-__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
-  hi = (__bf16)x;
-  const float r1 = x - (float)hi;
-  mid = (__bf16)r1;
-  lo = (__bf16)(r1 - (float)mid);
-}
 
 __global__ __launch_bounds__(512) void k_dcn_bwd_weight_x3(const float* __restrict__ x,        // NHWC [S,H,W,C]
                                                           const float* __restrict__ go,       // NHWC [S,H,W,O]

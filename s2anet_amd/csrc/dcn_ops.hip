@@ -2058,12 +2058,6 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 template <int NPOS>
 constexpr int x3_lds_bytes() { return NPOS * 9 * 32 + 2 * 3 * (kMaxO + NPOS) * kX3Row; }      // 110 592 / 147 456
-__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
-  hi = (__bf16)x;
-  const float r1 = x - (float)hi;
-  mid = (__bf16)r1;
-  lo = (__bf16)(r1 - (float)mid);
-}
 // weight [O][C][9] f32 -> [stage s = (c / 16) * 9 + tap][plane][O][16] bf16
 __global__ void k_pack_weight_x3(const float* __restrict__ w, int O, int C, __bf16* __restrict__ wp) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
