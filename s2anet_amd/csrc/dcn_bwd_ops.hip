@@ -279,6 +279,11 @@ __global__ __launch_bounds__(256) void k_bwd_nchw_to_nhwc_h8(const _Float16* __r
   }
 }
 
+__global__ __launch_bounds__(256) void k_bwd_zero4(__attribute__((ext_vector_type(4))) float* __restrict__ p, int64_t n4) {
+  const __attribute__((ext_vector_type(4))) float z = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) p[i] = z;
+}
+
 // the fused input-gradient kernels sum into an [S, HW, C] f32 accumulator (128-byte atomic rows); this hands the result to
 // the caller's [S, C, HW] tensor: added to it (ACCUM: the f32 gradInput the reference's atomics accumulate into,
 // deform_conv_cuda_kernel.cu:339) or written in the tensor's own type (the zeroed gradInput of deform_conv.py:88)
@@ -2231,8 +2236,13 @@ int fused_bwd_run(const FusedBwdArgs& a, void* workspace, size_t workspace_bytes
   float* gacc = (want_input && kHalf) ? cv.take<float>((size_t)(B * HW * C)) : nullptr;
   float* partial = want_weight ? cv.take<float>((size_t)kWgradMaxBlocks * O * 192) : nullptr;
   S2A_CHECK_ARG(xn && gn && (!want_input || (wp && (gacc || !kHalf))) && (!want_weight || partial), "%s: workspace too small", who);
-  if (want_input && kHalf) S2A_HIP(hipMemsetAsync(gacc, 0, (size_t)(B * HW * C) * 4, st));
-  if (want_input && !kHalf && a.grad_input_typed) S2A_HIP(hipMemsetAsync(a.grad_input, 0, (size_t)(B * HW * C) * 4, st));
+  // (an own fill kernel, not hipMemsetAsync: memset nodes of a captured graph are not replayed correctly on ROCm 7.2, DESIGN 5 --
+  // a backward captured into a HIP graph would otherwise sum into a stale accumulator from its second replay on)
+  if (want_input && (kHalf || a.grad_input_typed)) {
+    float* z = kHalf ? gacc : (float*)a.grad_input;
+    const int64_t nz4 = B * HW * C / 4;          // (C % 32 == 0)
+    k_bwd_zero4<<<(unsigned)std::min<int64_t>((nz4 + 255) / 256, 65536), 256, 0, st>>>(reinterpret_cast<f32x4b*>(z), nz4);
+  }
   auto to_nhwc = [&](const void* src, int64_t ch, T* dst) {
     if constexpr (kHalf) {
       if (ch % 8 == 0 && HW % 8 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
